@@ -1,0 +1,548 @@
+"""CPU oracle for the pressure-surrogate hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a NumPy restatement (written from the behaviour of the reference,
+not copied from it) of the per-timestep surrogate pipeline
+
+    grid -> overlapping 128x128 blocks -> PCA encode -> dense MLP -> PCA decode
+         -> serial block-offset reassembly -> global reference shift
+
+as performed by the three reference variants.  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import it; the product path (the HIP library behind ``include/psm.h``) never
+does and fails loudly when the HIP extension is missing.
+
+Reference files followed (paths relative to /root/reference):
+
+  PM  = Thesis_Work/Chapter5/parallelized/test_case/python_module.py
+  SMD = Improved_SM/deltaU_to_deltaP/source/pressureSM_deltas/SM_call.py
+  UGP = Improved_SM/U_to_gradP/evaluation/Eval_dual_Dense_onlycil.py
+  UTL = Improved_SM/deltaU_to_deltaP/source/pressureSM_deltas/utils.py
+  NNS = Improved_SM/deltaU_to_deltaP/source/pressureSM_deltas/NNs.py
+
+Parity status: PINNED for the block layout, PCA encode/decode and the
+reassembly of all three variants by golden vectors produced by executing the
+reference's own (pure-NumPy) statements in this container
+(tests/golden/make_golden.py extracts them from the reference files at run
+time; nothing of the reference is stored in this repository).  The dense
+network itself is third-party arithmetic (Keras ``Dense`` == relu(x@W+b),
+TensorFlow is not installable here) and is pinned only through the real
+trained weights file and the published definition of the layer.
+
+Precision mirrors the reference: float64 for PCA and reassembly, float32 for
+the MLP (Keras floatx).
+
+Build-defined behaviour (the reference is undefined there):
+when the last block row coincides with the previous one (``p_i == 0``, e.g. a
+256-row grid with the gradP stride of 32) the reference evaluates an empty
+slice (NaN poisons the whole field, UGP:340/359) or raises a broadcast error
+(SMD:335).  With ``degenerate='skip'`` (default) that duplicate row is left out
+of the reassembly; ``degenerate='strict'`` reproduces the NumPy semantics.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+CHAPTER5 = "chapter5"
+DELTAS = "deltas"
+GRADP = "gradp"
+VARIANTS = (CHAPTER5, DELTAS, GRADP)
+
+
+# --------------------------------------------------------------------------
+# small helpers
+# --------------------------------------------------------------------------
+def mmean(values: np.ndarray, mask: np.ndarray) -> float:
+    """Mean of ``values`` where ``mask`` is set; NaN for an empty selection
+    (NumPy's behaviour for ``np.mean`` of an empty array, which every variant
+    relies on and then probes with ``np.isnan``: SMD:252, UGP:315, PM:417)."""
+    sel = values[mask]
+    if sel.size == 0:
+        return float("nan")
+    return float(np.mean(sel))
+
+
+def default_overlap(variant: str, S: int = 128) -> int:
+    """PM:304 ``int(0.1*shape)``; SMD:788 / entry_point default 0.25;
+    UGP:708 ``int(0.75*shape)`` (there called ``avance``)."""
+    return {CHAPTER5: int(0.1 * S), DELTAS: int(0.25 * S), GRADP: int(0.75 * S)}[variant]
+
+
+# --------------------------------------------------------------------------
+# a7  block layout
+# --------------------------------------------------------------------------
+@dataclass
+class Layout:
+    variant: str
+    Ny: int
+    Nx: int
+    S: int
+    ov: int                      # width of the overlap strip ("avance" in PM/UGP)
+    n_x: int
+    n_y: int
+    origins: List[Tuple[int, int]] = field(default_factory=list)   # (y0, x0)
+    tags: List[Tuple[int, int]] = field(default_factory=list)      # (idx_i, idx_j)
+
+    @property
+    def stride(self) -> int:
+        return self.S - self.ov
+
+    @property
+    def B(self) -> int:
+        return len(self.origins)
+
+
+def block_layout(variant: str, Ny: int, Nx: int, S: int = 128, ov: int | None = None) -> Layout:
+    """Sliding-window enumeration of the three variants.
+
+    chapter5: PM:306-329   (right->left, floor counts, extra ``-1`` column)
+    deltas  : SMD:461-479  (right->left, ceil in x, tag = (i, n_x-j))
+    gradp   : UGP:479-500  (left->right, ceil in x, tag = (i, j))
+    """
+    if ov is None:
+        ov = default_overlap(variant, S)
+    if Ny < S or Nx < S:
+        raise ValueError("grid smaller than one block")
+    st = S - ov
+    lay = Layout(variant, Ny, Nx, S, ov, 0, 0)
+    if variant == CHAPTER5:
+        lay.n_x = int((Nx - S) / st)
+        lay.n_y = int((Ny - S) / st)
+        for i in range(lay.n_y + 2):
+            y0 = Ny - S if i == lay.n_y + 1 else i * st
+            for j in range(lay.n_x + 1):
+                lay.origins.append((y0, Nx - S - j * st))
+                lay.tags.append((i, lay.n_x - j))
+                if j == lay.n_x:
+                    lay.origins.append((y0, 0))
+                    lay.tags.append((i, -1))
+    elif variant == DELTAS:
+        lay.n_x = int(math.ceil((Nx - S) / st))
+        lay.n_y = int((Ny - S) / st)
+        for i in range(lay.n_y + 2):
+            y0 = Ny - S if i == lay.n_y + 1 else i * st
+            for j in range(lay.n_x + 1):
+                x0 = 0 if j == lay.n_x else Nx - S - j * st
+                lay.origins.append((y0, x0))
+                lay.tags.append((i, lay.n_x - j))
+    elif variant == GRADP:
+        lay.n_x = int(math.ceil((Nx - S) / st))
+        lay.n_y = int((Ny - S) / st)
+        for i in range(lay.n_y + 2):
+            y0 = Ny - S if i == lay.n_y + 1 else i * st
+            for j in range(lay.n_x + 1):
+                x0 = Nx - S if j == lay.n_x else j * st
+                lay.origins.append((y0, x0))
+                lay.tags.append((i, j))
+    else:
+        raise ValueError(f"unknown variant {variant!r}")
+    return lay
+
+
+def extract_blocks(grid: np.ndarray, lay: Layout, c_in: int) -> np.ndarray:
+    """``x_array`` of PM:332 / SMD:481 / UGP:502: [B, S, S, c_in] copies of the
+    first ``c_in`` channels of ``grid[Ny, Nx, C]``."""
+    S = lay.S
+    out = np.empty((lay.B, S, S, c_in), dtype=grid.dtype)
+    for b, (y0, x0) in enumerate(lay.origins):
+        out[b] = grid[y0:y0 + S, x0:x0 + S, :c_in]
+    return out
+
+
+# --------------------------------------------------------------------------
+# a9 / a10 / a11   PCA encode, MLP, PCA decode
+# --------------------------------------------------------------------------
+@dataclass
+class Scaler:
+    """PCA-coefficient scaling, UTL:290-329 / SMD:505-539 / PM:351,365."""
+    kind: str = "max_abs"            # max_abs | std | min_max
+    in_a: np.ndarray | float = 1.0   # max_abs_in | mean_in | min_in
+    in_b: np.ndarray | float = 1.0   # (unused)   | std_in  | max_in
+    out_a: np.ndarray | float = 1.0  # max_abs_out| mean_out| min_out
+    out_b: np.ndarray | float = 1.0  # (unused)   | std_out | max_out
+
+    def fwd(self, t):
+        if self.kind == "max_abs":
+            return t / self.in_a
+        if self.kind == "std":
+            return (t - self.in_a) / self.in_b
+        if self.kind == "min_max":
+            return (t - self.in_a) / (self.in_b - self.in_a)
+        raise ValueError("Standardization method not valid")
+
+    def inv(self, r):
+        if self.kind == "max_abs":
+            return r * self.out_a
+        if self.kind == "std":
+            return r * self.out_b + self.out_a
+        if self.kind == "min_max":
+            return r * (self.out_b - self.out_a) + self.out_a
+        raise ValueError("Standardization method not valid")
+
+
+@dataclass
+class Model:
+    """Everything the surrogate needs besides the grid."""
+    variant: str
+    c_in: int
+    c_out: int
+    comp_in: np.ndarray       # [P_i, S*S*c_in]   sklearn components_[:P_i]
+    mean_in: np.ndarray       # [S*S*c_in]        sklearn mean_
+    comp_out: np.ndarray      # [P_o, S*S*c_out]
+    mean_out: np.ndarray      # [S*S*c_out]
+    weights: Sequence[Tuple[np.ndarray, np.ndarray]]   # [(W[in,out] f32, b[out] f32)], last = linear head
+    scaler: Scaler = field(default_factory=Scaler)
+    out_scale: float = 1.0    # SMD:551 max_abs_p * U_max^2 (1 for gradp, UGP:537-538)
+    S: int = 128
+    ov: int | None = None
+    sdf_ch: int = 2
+
+    def overlap(self) -> int:
+        return default_overlap(self.variant, self.S) if self.ov is None else self.ov
+
+
+def pca_encode(x_blocks: np.ndarray, comp_in: np.ndarray, mean_in: np.ndarray) -> np.ndarray:
+    """PM:344-349 / sklearn ``transform`` (SMD:494, UGP:518):
+    ``(X - mean_) @ components_[:P].T`` in float64."""
+    flat = x_blocks.reshape(x_blocks.shape[0], -1).astype(np.float64)
+    return np.dot(flat - mean_in, comp_in.T)
+
+
+def mlp_forward(x: np.ndarray, weights) -> np.ndarray:
+    """Keras ``Dense`` stack (PM:121-134, NNS:8-38): relu(x@W+b) for every layer
+    but the last, which is linear.  float32 like Keras (floatx)."""
+    h = np.asarray(x, dtype=np.float32)
+    n = len(weights)
+    for li, (W, b) in enumerate(weights):
+        h = h @ np.asarray(W, np.float32) + np.asarray(b, np.float32)
+        if li != n - 1:
+            h = np.maximum(h, np.float32(0))
+    return h
+
+
+def pca_decode(res: np.ndarray, comp_out: np.ndarray, mean_out: np.ndarray, S: int, c_out: int) -> np.ndarray:
+    """PM:365-366 / SMD:541-542 / UGP:533-534: ``res @ components_[:P] + mean_``
+    reshaped to [B, S, S, c_out] (channel last, interleaved)."""
+    flat = np.dot(np.asarray(res, np.float64), comp_out) + mean_out
+    return flat.reshape(res.shape[0], S, S, c_out)
+
+
+# --------------------------------------------------------------------------
+# a12  reassembly -- one function per reference variant
+# --------------------------------------------------------------------------
+@dataclass
+class Assembly:
+    field: np.ndarray            # [Ny, Nx] float64
+    offsets: np.ndarray          # [B] correction subtracted from each block (NaN for skipped)
+    shift: float                 # final global reference shift
+    covered: np.ndarray          # [Ny, Nx] bool, cells written by a paste
+
+
+def assemble_deltas(pred, x_blocks, lay: Layout, ref_bc: float = 0.0, sdf_ch: int = 2,
+                    degenerate: str = "skip") -> Assembly:
+    """SMD:182-365 (``assemble_prediction`` with ``apply_filter=False`` and
+    ``apply_deltaU_change_wgt=False`` as called at SMD:573-575)."""
+    S, ov, n_x, n_y, Ny, Nx = lay.S, lay.ov, lay.n_x, lay.n_y, lay.Ny, lay.Nx
+    st = S - ov
+    if n_x < 1:
+        raise ValueError("deltas reassembly needs at least two block columns (SMD:237-240 reads the previous block)")
+    pred = np.array(pred, dtype=np.float64, copy=True)
+    p_i = Ny - (st * n_y + S)                      # SMD:213
+    p_j = Nx - (st * n_x + S)                      # SMD:216
+    lim = ov - p_j                                 # SMD:238
+    if p_i == 0 and degenerate != "skip":
+        raise ValueError("reference undefined: p_i == 0 raises a broadcast error at SMD:335")
+    out = np.zeros((Ny, Nx))
+    cov = np.zeros((Ny, Nx), bool)
+    offs = np.full(lay.B, np.nan)
+    up = np.zeros(n_x + 1)                          # SMD:210 BC_ups
+    prev = None
+    for b, (ti, tj) in enumerate(lay.tags):
+        if ti == n_y + 1 and p_i == 0:
+            continue
+        m = x_blocks[b, :, :, sdf_ch] != 0
+        cur = pred[b]
+
+        def side(w):        # right strip of this block against the left strip of the previous one
+            return mmean(cur[:, S - w:], m[:, S - w:]) - mmean(prev[:, :w], m[:, :w])
+
+        if ti == 0:                                              # SMD:228-246
+            if b == 0:
+                c = mmean(cur[:, S - 1], m[:, S - 1]) - ref_bc
+            else:
+                c = side(ov)
+            if tj == 0:
+                c = side(lim)
+            cur -= c
+            up[tj] = mmean(cur[S - ov:, :], m[S - ov:, :])
+        elif ti != n_y + 1:                                      # SMD:249-283
+            if math.isnan(up[tj]):
+                if tj == 0:
+                    c = side(lim)
+                elif tj == n_x:
+                    c = mmean(cur[:ov, :], m[:ov, :]) - up[tj]
+                else:
+                    c = side(ov)
+            else:
+                c = mmean(cur[:ov, :], m[:ov, :]) - up[tj]
+            cur -= c
+            up[tj] = mmean(cur[S - ov:, :], m[S - ov:, :])
+            if ti == n_y:
+                up[tj] = mmean(cur[p_i:, :], m[p_i:, :])         # rows -(S-p_i):
+        else:                                                    # SMD:286-328
+            a0, a1 = S - p_i - ov, S - p_i
+            if tj == n_x:
+                c = mmean(cur[a0:a1, :], m[a0:a1, :]) - up[tj]
+            else:
+                n_up = int(np.count_nonzero(m[a0:a1, :]))
+                if n_up / 128 ** 2 > 0.9:                        # SMD:307 (hard-wired 128)
+                    c = side(lim) if tj == 0 else side(ov)
+                else:
+                    c = mmean(cur[:S - p_i, :], m[:S - p_i, :]) - up[tj]
+            cur -= c
+        offs[b] = c
+        prev = cur
+        # ---- paste (SMD:334-348); later blocks overwrite earlier ones
+        jr = n_x - tj
+        xs = slice(0, S) if tj == 0 else slice(Nx - S - jr * st, Nx - jr * st)
+        if ti == n_y + 1:
+            out[Ny - p_i:, xs] = cur[S - p_i:, :]
+            cov[Ny - p_i:, xs] = True
+        else:
+            out[st * ti: st * ti + S, xs] = cur
+            cov[st * ti: st * ti + S, xs] = True
+    shift = float(np.mean(3.0 * out[:, -1] - out[:, -2]) / 3.0)   # SMD:350
+    out -= shift
+    return Assembly(out, offs, shift, cov)
+
+
+def assemble_gradp(which: str, pred, x_blocks, lay: Layout, ref_bc: float = 0.0, sdf_ch: int = 2,
+                   degenerate: str = "skip") -> Assembly:
+    """UGP:255-369 for one output channel; ``which`` is 'dp_dx' or 'dp_dy'."""
+    if which not in ("dp_dx", "dp_dy"):
+        raise ValueError(which)
+    S, ov, n_x, n_y, Ny, Nx = lay.S, lay.ov, lay.n_x, lay.n_y, lay.Ny, lay.Nx
+    st = S - ov
+    if n_x < 1:
+        raise ValueError("gradp reassembly needs at least two block columns (UGP:307-310)")
+    pred = np.array(pred, dtype=np.float64, copy=True)
+    p_i = Ny - (S * (n_y + 1) - n_y * ov)          # UGP:277
+    p_j = (Nx - S) - n_x * st                      # UGP:278
+    lim = ov - p_j                                 # UGP:308
+    out = np.zeros((Ny, Nx))
+    cov = np.zeros((Ny, Nx), bool)
+    offs = np.full(lay.B, np.nan)
+    up = np.zeros(n_x + 1)
+    prev = None
+    skip_last = (p_i == 0 and degenerate == "skip")
+    for b, (ti, tj) in enumerate(lay.tags):
+        if ti == n_y + 1 and skip_last:
+            continue
+        m = x_blocks[b, :, :, sdf_ch] != 0
+        cur = pred[b]
+
+        def side(w):        # left strip of this block against the right strip of the previous one
+            return mmean(cur[:, :w], m[:, :w]) - mmean(prev[:, S - w:], m[:, S - w:])
+
+        if ti == 0:                                              # UGP:288-312
+            if b == 0:
+                if which == "dp_dx":
+                    col = 0
+                    while not m[:, col].any():
+                        col += 1
+                        if col >= S:
+                            raise ValueError("first block has no flow cell")
+                    c = mmean(cur[:, col], m[:, col]) - ref_bc
+                else:
+                    c = mmean(cur[1, :], m[1, :]) - ref_bc
+            else:
+                c = side(ov)
+            if tj == n_x:
+                c = side(lim)
+            cur -= c
+            up[tj] = mmean(cur[S - ov:, :], m[S - ov:, :])
+        elif ti != n_y + 1:                                      # UGP:314-328
+            if math.isnan(up[tj]):
+                c = side(lim) if tj == n_x else side(ov)
+            else:
+                c = mmean(cur[:ov, :], m[:ov, :]) - up[tj]
+            cur -= c
+            up[tj] = mmean(cur[S - ov:, :], m[S - ov:, :])
+            if ti == n_y:
+                up[tj] = mmean(cur[p_i:, :], m[p_i:, :])
+        else:                                                    # UGP:330-341
+            if math.isnan(up[tj]):
+                c = side(lim) if tj == n_x else side(ov)
+            else:
+                # python slice [-p_i-ov:-p_i]; empty when p_i == 0 (strict mode)
+                a0, a1 = (S - p_i - ov, S - p_i) if p_i != 0 else (S - ov, 0)
+                c = mmean(cur[a0:a1, :], m[a0:a1, :]) - up[tj]
+            cur -= c
+        offs[b] = c
+        prev = cur
+        # ---- paste (UGP:345-356)
+        ys = slice(Ny - st, Ny) if ti == n_y + 1 else slice(ti * st, ti * st + S)
+        src_rows = slice(ov, S) if ti == n_y + 1 else slice(0, S)
+        if tj == n_x:
+            out[ys, Nx - lim:] = cur[src_rows, S - lim:]
+            cov[ys, Nx - lim:] = True
+        else:
+            out[ys, tj * st: tj * st + S] = cur[src_rows, :]
+            cov[ys, tj * st: tj * st + S] = True
+    if which == "dp_dx":
+        shift = float(np.mean(3.0 * out[:, 0] - out[:, 1]) / 3.0)    # UGP:359
+    else:
+        shift = float(np.mean(3.0 * out[1, :] - out[2, :]) / 3.0)    # UGP:361
+    out -= shift
+    return Assembly(out, offs, shift, cov)
+
+
+def assemble_chapter5(pred, x_blocks, lay: Layout, sdf_ch: int = 2) -> Assembly:
+    """PM:373-472 (inline correction loop of ``py_func``)."""
+    S, av, n_x, n_y, Ny, Nx = lay.S, lay.ov, lay.n_x, lay.n_y, lay.Ny, lay.Nx
+    st = S - av
+    pred = np.array(pred, dtype=np.float64, copy=True)
+    p = Ny - (S * (n_y + 1) - n_y * av)            # PM:410
+    p_j = (Nx - S) - n_x * S + n_x * av            # PM:397
+    out = np.zeros((Ny, Nx))
+    cov = np.zeros((Ny, Nx), bool)
+    offs = np.full(lay.B, np.nan)
+    up = np.zeros(n_x + 1)                          # BC_ups
+    up_m1 = float("nan")                            # BC_up_  (column tagged -1)
+    ant0 = float("nan")                             # BC_ant_0
+    alter = 0.0                                     # BC_alter
+    R = slice(S - av, S)                            # last `avance` rows / columns
+    for b, (ti, tj) in enumerate(lay.tags):
+        m = x_blocks[b, :, :, sdf_ch] != 0
+        cur = pred[b]
+        C = slice(p_j, p_j + av)
+        if ti == 0:                                              # PM:388-405
+            if tj == n_x:
+                c = mmean(cur[:, R], m[:, R]) - 0.0
+                cur -= c
+                up[tj] = mmean(cur[R, R], m[R, R])
+            elif tj == -1:
+                c = mmean(cur[:, C], m[:, C]) - ant0
+                cur -= c
+                up_m1 = mmean(cur[R, C], m[R, C])
+            else:
+                c = mmean(cur[:, R], m[:, R]) - ant0
+                cur -= c
+                up[tj] = mmean(cur[R, :], m[R, :])
+            ant0 = mmean(cur[:, :av], m[:, :av])
+        elif ti == n_y + 1:                                      # PM:407-423
+            T = slice(S - p - av, S - p)
+            if tj == -1:
+                c = mmean(cur[T, C], m[T, C]) - up_m1
+            elif math.isnan(up[tj]):
+                c = mmean(cur[:, R], m[:, R]) - alter
+            else:
+                c = mmean(cur[T, :], m[T, :]) - up[tj]
+            cur -= c
+        else:                                                    # PM:425-441
+            if tj == -1:
+                c = mmean(cur[:av, C], m[:av, C]) - up_m1
+                cur -= c
+                up_m1 = float(np.mean(cur[R, C]))                # PM:432, unmasked
+            else:
+                if math.isnan(up[tj]):
+                    c = mmean(cur[:, R], m[:, R]) - alter
+                else:
+                    c = mmean(cur[:av, :], m[:av, :]) - up[tj]
+                cur -= c
+                up[tj] = mmean(cur[R, :], m[R, :])
+        alter = mmean(cur[:, :av], m[:, :av])                    # PM:445
+        offs[b] = c
+        # ---- paste (PM:449-467)
+        if ti == n_y + 1 and tj == -1:
+            w = Nx - (n_x + 1) * st - av
+            out[Ny - st:, :w] = cur[av:, :w]
+            cov[Ny - st:, :w] = True
+        elif tj == -1:
+            out[ti * st: ti * st + S, :S] = cur
+            cov[ti * st: ti * st + S, :S] = True
+        else:
+            j = n_x - tj
+            xs = slice(Nx - S - j * st, Nx - j * st)
+            if ti == n_y + 1:
+                out[Ny - st:, xs] = cur[av:, :]
+                cov[Ny - st:, xs] = True
+            else:
+                out[ti * st: ti * st + S, xs] = cur
+                cov[ti * st: ti * st + S, xs] = True
+    shift = float(np.mean(3.0 * out[:, -1] - out[:, -2]) / 3.0)   # PM:472
+    out -= shift
+    return Assembly(out, offs, shift, cov)
+
+
+# --------------------------------------------------------------------------
+# whole grid-native solve  (PM:299-473, SMD:452-575, UGP:470-547)
+# --------------------------------------------------------------------------
+@dataclass
+class Solve:
+    x_blocks: np.ndarray      # [B,S,S,c_in]
+    coeff_in: np.ndarray      # [B,P_i]  PCA coefficients before scaling (f64)
+    x_input: np.ndarray       # [B,P_i]  scaled network input (f64)
+    res: np.ndarray           # [B,P_o]  raw network output (f32)
+    block_pred: np.ndarray    # [B,S,S,c_out] decoded (and out_scale'd) blocks (f64)
+    fields: np.ndarray        # [Ny,Nx,c_out] assembled (f64)
+    assemblies: list
+
+
+def solve_grid(grid: np.ndarray, model: Model, degenerate: str = "skip") -> Solve:
+    """One grid-native solve.  ``grid`` is the already normalised
+    [Ny, Nx, >=c_in] image of PM:288-297 / SMD:430-444 / UGP:453-468."""
+    Ny, Nx = grid.shape[:2]
+    lay = block_layout(model.variant, Ny, Nx, model.S, model.overlap())
+    xb = extract_blocks(np.asarray(grid, np.float64), lay, model.c_in)
+    coeff = pca_encode(xb, model.comp_in, model.mean_in)
+    x_in = model.scaler.fwd(coeff)
+    res = mlp_forward(x_in, model.weights)
+    dec_in = model.scaler.inv(res.astype(np.float64))
+    bp = pca_decode(dec_in, model.comp_out, model.mean_out, model.S, model.c_out) * model.out_scale
+    fields = np.zeros((Ny, Nx, model.c_out))
+    asm = []
+    if model.variant == CHAPTER5:
+        a = assemble_chapter5(bp[..., 0], xb, lay, model.sdf_ch)
+        fields[..., 0] = a.field
+        asm.append(a)
+    elif model.variant == DELTAS:
+        a = assemble_deltas(bp[..., 0], xb, lay, 0.0, model.sdf_ch, degenerate)
+        fields[..., 0] = a.field
+        asm.append(a)
+    else:
+        for ch, which in enumerate(("dp_dx", "dp_dy")):
+            a = assemble_gradp(which, bp[..., ch], xb, lay, 0.0, model.sdf_ch, degenerate)
+            fields[..., ch] = a.field
+            asm.append(a)
+    return Solve(xb, coeff, x_in, res, bp, fields, asm)
+
+
+# --------------------------------------------------------------------------
+# a1 / a5  grid + barycentric interpolation (mesh <-> grid, "next" rows)
+# --------------------------------------------------------------------------
+def create_uniform_grid(x_min, x_max, y_min, y_max, delta):
+    """PM:42-48 / UTL:111-125: cell-centred uniform grid, flattened row-major
+    with y as the outer index."""
+    nx = int(round((x_max - x_min) / delta))
+    ny = int(round((y_max - y_min) / delta))
+    X0 = np.linspace(x_min + delta / 2, x_max - delta / 2, num=nx)
+    Y0 = np.linspace(y_min + delta / 2, y_max - delta / 2, num=ny)
+    XX, YY = np.meshgrid(X0, Y0)
+    return XX.flatten(), YY.flatten()
+
+
+def interpolate(values, vtx, wts):
+    """PM:64-65: ``sum_j values[vtx[n,j]] * wts[n,j]``."""
+    return np.einsum("nj,nj->n", np.take(values, vtx), wts)
+
+
+def interpolate_fill(values, vtx, wts, fill_value=np.nan):
+    """PM:67-70 / UTL:75-90: as ``interpolate`` with ``fill_value`` wherever a
+    barycentric weight is negative (target outside the triangulation)."""
+    ret = interpolate(values, vtx, wts)
+    ret[np.any(wts < 0, axis=1)] = fill_value
+    return ret

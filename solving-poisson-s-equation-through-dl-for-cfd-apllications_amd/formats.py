@@ -1,0 +1,249 @@
+"""On-disk artefact readers for the surrogate path.
+
+* Keras ``.h5`` weight files (``weights.h5``, ``model_*.h5``): HDF5 superblock
+  v0, old-style groups (B-tree + local heap + symbol nodes), v1 object
+  headers, contiguous little-endian datasets.  Written by the reference with
+  ``model.save_weights`` (Thesis_Work/Chapter5/parallelized/test_case/
+  save_weights.py:1-4) and read with ``model.load_weights`` (python_module.py:170).
+  h5py is not available on the target image, so this is a small dependency-free
+  reader for exactly that subset; anything else raises ``H5FormatError``.
+* ``maxs`` / ``maxs_PCA`` text files (python_module.py:106-110, SM_call.py:70-72).
+* ``mean_std.npz`` / ``min_max_values.npz`` scalers (utils.py:299,313).
+"""
+from __future__ import annotations
+
+import re
+import struct
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+
+class H5FormatError(ValueError):
+    pass
+
+
+_SIG = b"\x89HDF\r\n\x1a\n"
+_UNDEF = 0xFFFFFFFFFFFFFFFF
+
+
+class _H5:
+    def __init__(self, buf: bytes):
+        self.b = buf
+        if buf[:8] != _SIG:
+            raise H5FormatError("not an HDF5 file")
+        ver = buf[8]
+        if ver != 0:
+            raise H5FormatError(f"superblock version {ver} not supported (only v0)")
+        self.so, self.sl = buf[13], buf[14]
+        if (self.so, self.sl) != (8, 8):
+            raise H5FormatError("only 8-byte offsets/lengths supported")
+        # 8 sig + 8 version bytes + 2+2 (group K) + 4 flags = 24 ; then 4 addresses
+        self.base = self.u64(24)
+        root_entry = 24 + 4 * 8
+        self.root = self._sym_entry(root_entry)
+
+    # -- primitives
+    def u8(self, o): return self.b[o]
+    def u16(self, o): return struct.unpack_from("<H", self.b, o)[0]
+    def u32(self, o): return struct.unpack_from("<I", self.b, o)[0]
+    def u64(self, o): return struct.unpack_from("<Q", self.b, o)[0]
+
+    def _sym_entry(self, o):
+        name_off = self.u64(o)
+        hdr = self.u64(o + 8)
+        cache = self.u32(o + 16)
+        btree = heap = None
+        if cache == 1:
+            btree = self.u64(o + 24)
+            heap = self.u64(o + 32)
+        return dict(name_off=name_off, hdr=hdr, cache=cache, btree=btree, heap=heap)
+
+    # -- object header v1: list of (type, body_offset, size)
+    def messages(self, addr) -> List[Tuple[int, int, int]]:
+        if self.u8(addr) != 1:
+            raise H5FormatError("only version-1 object headers supported")
+        nmsg = self.u16(addr + 2)
+        hsize = self.u32(addr + 8)
+        blocks = [(addr + 16, hsize)]
+        out = []
+        while blocks and len(out) < nmsg:
+            o, size = blocks.pop(0)
+            end = o + size
+            while o + 8 <= end and len(out) < nmsg:
+                mtype = self.u16(o)
+                msize = self.u16(o + 2)
+                body = o + 8
+                if mtype == 0x10:                      # continuation
+                    blocks.append((self.u64(body), self.u64(body + 8)))
+                out.append((mtype, body, msize))
+                o = body + msize
+        return out
+
+    def _heap_data(self, heap_addr) -> int:
+        if self.b[heap_addr:heap_addr + 4] != b"HEAP":
+            raise H5FormatError("bad local heap")
+        return self.u64(heap_addr + 8 + 8 + 8)
+
+    def _cstr(self, o) -> str:
+        e = self.b.index(b"\0", o)
+        return self.b[o:e].decode("ascii")
+
+    def _group_tables(self, hdr_addr):
+        """B-tree / heap addresses of an old-style group from its symbol-table message."""
+        for mtype, body, _ in self.messages(hdr_addr):
+            if mtype == 0x11:
+                return self.u64(body), self.u64(body + 8)
+        return None
+
+    def children(self, btree, heap) -> Dict[str, dict]:
+        names: Dict[str, dict] = {}
+        hdata = self._heap_data(heap)
+
+        def walk(node):
+            if self.b[node:node + 4] == b"TREE":
+                ntype, level, used = self.u8(node + 4), self.u8(node + 5), self.u16(node + 6)
+                if ntype != 0:
+                    raise H5FormatError("unexpected B-tree node type")
+                o = node + 8 + 16          # skip siblings
+                for k in range(used):
+                    child = self.u64(o + 8 + k * 16)   # key(8) child(8) pairs
+                    walk(child)
+            elif self.b[node:node + 4] == b"SNOD":
+                n = self.u16(node + 6)
+                for k in range(n):
+                    e = self._sym_entry(node + 8 + k * 40)
+                    names[self._cstr(hdata + e["name_off"])] = e
+            else:
+                raise H5FormatError("bad group node")
+        walk(btree)
+        return names
+
+    def dataset(self, hdr_addr) -> np.ndarray:
+        shape = dtype = None
+        data_addr = data_size = None
+        for mtype, body, _ in self.messages(hdr_addr):
+            if mtype == 0x01:                          # dataspace
+                ver, rank = self.u8(body), self.u8(body + 1)
+                o = body + (8 if ver == 1 else 4)
+                shape = tuple(self.u64(o + 8 * i) for i in range(rank))
+            elif mtype == 0x03:                        # datatype
+                cls = self.u8(body) & 0x0F
+                bits0 = self.u8(body + 1)
+                size = self.u32(body + 4)
+                if bits0 & 1:
+                    raise H5FormatError("big-endian data not supported")
+                if cls == 1 and size in (4, 8):
+                    dtype = np.dtype("<f4" if size == 4 else "<f8")
+                elif cls == 0 and size in (4, 8):
+                    dtype = np.dtype("<i4" if size == 4 else "<i8")
+                else:
+                    dtype = None
+            elif mtype == 0x08:                        # layout
+                ver = self.u8(body)
+                if ver == 3:
+                    if self.u8(body + 1) != 1:
+                        raise H5FormatError("only contiguous layout supported")
+                    data_addr, data_size = self.u64(body + 2), self.u64(body + 10)
+                elif ver in (1, 2):
+                    rank, lclass = self.u8(body + 1), self.u8(body + 2)
+                    if lclass != 1:
+                        raise H5FormatError("only contiguous layout supported")
+                    data_addr = self.u64(body + 8)
+                    data_size = None
+                else:
+                    raise H5FormatError("layout version not supported")
+        if shape is None or dtype is None or data_addr is None or data_addr == _UNDEF:
+            raise H5FormatError("not a plain numeric contiguous dataset")
+        count = int(np.prod(shape)) if shape else 1
+        a = np.frombuffer(self.b, dtype=dtype, count=count, offset=self.base + data_addr)
+        return a.reshape(shape).copy()
+
+    def walk(self, entry=None, prefix=""):
+        """Yield (path, symbol entry) for every leaf that is not a group."""
+        entry = self.root if entry is None else entry
+        tabs = (entry["btree"], entry["heap"]) if entry["cache"] == 1 else self._group_tables(entry["hdr"])
+        if tabs is None:
+            yield prefix, entry
+            return
+        for name, e in self.children(*tabs).items():
+            yield from self.walk(e, f"{prefix}/{name}")
+
+
+def read_h5_datasets(path: str) -> Dict[str, np.ndarray]:
+    """All numeric contiguous datasets of a (v0, contiguous) HDF5 file by path."""
+    with open(path, "rb") as f:
+        h = _H5(f.read())
+    out = {}
+    for p, e in h.walk():
+        try:
+            out[p] = h.dataset(e["hdr"])
+        except H5FormatError:
+            continue
+    return out
+
+
+def _layer_key(name: str):
+    m = re.fullmatch(r"dense(?:_(\d+))?", name)
+    return (0, int(m.group(1) or 0)) if m else (1, name)
+
+
+def read_keras_dense_weights(path: str) -> List[Tuple[np.ndarray, np.ndarray]]:
+    """Ordered [(kernel[in,out] f32, bias[out] f32)] of a Keras Dense stack.
+
+    Layers are identified by their HDF5 group names (``dense``, ``dense_1`` ...)
+    and ordered by that index, then checked for chaining shapes -- the order in
+    the file is never assumed (SURVEY.md §7 "hard parts")."""
+    ds = read_h5_datasets(path)
+    layers: Dict[str, Dict[str, np.ndarray]] = {}
+    for p, a in ds.items():
+        parts = [q for q in p.split("/") if q]
+        leaf = parts[-1]
+        if leaf not in ("kernel:0", "bias:0"):
+            continue
+        lname = next((q for q in parts if re.fullmatch(r"dense(?:_\d+)?", q)), None)
+        if lname is None:
+            continue
+        layers.setdefault(lname, {})[leaf] = a
+    names = sorted(layers, key=_layer_key)
+    out = []
+    for n in names:
+        if "kernel:0" not in layers[n] or "bias:0" not in layers[n]:
+            raise H5FormatError(f"layer {n} lacks kernel or bias")
+        W = np.ascontiguousarray(layers[n]["kernel:0"], np.float32)
+        b = np.ascontiguousarray(layers[n]["bias:0"], np.float32)
+        if W.ndim != 2 or b.shape != (W.shape[1],):
+            raise H5FormatError(f"layer {n}: unexpected shapes {W.shape} {b.shape}")
+        out.append((W, b))
+    for (W0, _), (W1, _) in zip(out, out[1:]):
+        if W0.shape[1] != W1.shape[0]:
+            raise H5FormatError("dense layers do not chain")
+    if not out:
+        raise H5FormatError("no dense layers found")
+    return out
+
+
+def read_maxs(path: str) -> np.ndarray:
+    """``np.loadtxt`` of the one-value-per-line ``maxs`` / ``maxs_PCA`` files."""
+    return np.atleast_1d(np.loadtxt(path))
+
+
+def read_scaler_npz(path: str, kind: str):
+    """``mean_std.npz`` (kind 'std') or ``min_max_values.npz`` (kind 'min_max')
+    -> (in_a, in_b, out_a, out_b) as written by utils.py:299,313."""
+    d = np.load(path)
+    if kind == "std":
+        return d["mean_in"], d["std_in"], d["mean_out"], d["std_out"]
+    if kind == "min_max":
+        return d["min_in"], d["max_in"], d["min_out"], d["max_out"]
+    raise ValueError("Standardization method not valid")
+
+
+def select_num_pc(explained_variance_ratio: np.ndarray, var: float, max_num_pc: int | None) -> int:
+    """PC-count rule.  With ``max_num_pc`` (SM_call.py:86-87): first index whose
+    cumulative ratio exceeds ``var`` if that index is in (1, max_num_pc], else
+    ``max_num_pc``; without (python_module.py:112-113): the bare argmax."""
+    k = int(np.argmax(np.cumsum(explained_variance_ratio) > var))
+    if max_num_pc is None:
+        return k
+    return k if (k > 1 and k <= max_num_pc) else int(max_num_pc)

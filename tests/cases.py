@@ -1,0 +1,63 @@
+"""Seeded test cases shared by tests/golden/make_golden.py (which runs the
+reference's statements on them) and the parity tests (which rebuild the same
+inputs and compare the oracle / the HIP path with the stored outputs)."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from psm_amd import synthetic
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# name -> spec.  'band' = (y0, y1, x0, x1) rectangle zeroed in every channel (a
+# large solid body) placed so that one block's bottom overlap strip holds no
+# flow cell: drives the np.isnan(BC_ups[..]) branches without poisoning the field.
+GOLDEN_CASES = {
+    "gradp_272x288":      dict(variant="gradp", Ny=272, Nx=288, seed=11, p=32),
+    "gradp_300x300":      dict(variant="gradp", Ny=300, Nx=300, seed=12, p=32),
+    "gradp_nan_280x320":  dict(variant="gradp", Ny=280, Nx=320, seed=13, p=24, band=(64, 160, 64, 192), obstacle="none"),
+    "deltas_256x256":     dict(variant="deltas", Ny=256, Nx=256, seed=21, p=32, scaler="std", U_max_norm=1.3, max_abs_p=0.51),
+    "deltas_300x420":     dict(variant="deltas", Ny=300, Nx=420, seed=22, p=32, scaler="min_max", U_max_norm=0.8, max_abs_p=0.9),
+    "deltas_nan_256x256": dict(variant="deltas", Ny=256, Nx=256, seed=23, p=24, scaler="max_abs", band=(96, 128, 32, 160), obstacle="none"),
+    "chapter5_128x128_real": dict(variant="chapter5", Ny=128, Nx=128, real_weights=True),
+    "chapter5_300x400":   dict(variant="chapter5", Ny=300, Nx=400, seed=31, p=32),
+    "chapter5_nan_300x400": dict(variant="chapter5", Ny=300, Nx=400, seed=32, p=24, band=(116, 128, 156, 284), obstacle="none"),
+}
+
+
+def real_chapter5_weights():
+    d = np.load(os.path.join(GOLDEN_DIR, "chapter5_weights.npz"))
+    n = len([k for k in d.files if k.startswith("W")])
+    return [(d[f"W{i}"], d[f"b{i}"]) for i in range(n)], d["maxs"], d["maxs_PCA"]
+
+
+def build(name: str):
+    """-> (grid[Ny,Nx,C] float64, SurrogateModel) for a GOLDEN_CASES entry."""
+    sp = GOLDEN_CASES[name]
+    v, Ny, Nx = sp["variant"], sp["Ny"], sp["Nx"]
+    if sp.get("real_weights"):
+        # BASELINE config 0: real trained MLP (45->512x3->48) of the reference's
+        # Chapter-5 test case, its maxs_PCA scalers, synthetic PCA seed 1234.
+        W, maxs, maxs_pca = real_chapter5_weights()
+        model = synthetic.make_model("chapter5", p_in=W[0][0].shape[0], p_out=W[-1][0].shape[1], weights=W)
+        model.in_a, model.out_a = float(maxs_pca[0]), float(maxs_pca[1])
+        grid = synthetic.cavity_grid(Ny)
+        grid[..., 2] *= 0.5           # PM:292 keeps the SDF un-normalised: any non-unit scale
+        return grid, model
+    extra = {"gradp": 3, "deltas": 2, "chapter5": 0}[v]
+    grid = synthetic.channel_grid(Ny, Nx, seed=sp["seed"], extra_channels=extra,
+                                  obstacle=sp.get("obstacle", "circle"))
+    if "band" in sp:
+        y0, y1, x0, x1 = sp["band"]
+        grid[y0:y1, x0:x1, :] = 0.0
+    model = synthetic.make_model(v, p_in=sp["p"], p_out=sp["p"], scaler_kind=sp.get("scaler"),
+                                 seed_pca=1000 + sp["seed"], seed_w=sp["seed"])
+    if v == "deltas":
+        model.out_scale = sp.get("max_abs_p", 1.0) * sp.get("U_max_norm", 1.0) ** 2
+    return grid, model
+
+
+def load_golden(name: str):
+    return np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"))

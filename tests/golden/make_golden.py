@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE'S OWN
+STATEMENTS on seeded synthetic inputs.  Runs only in the build container (it
+needs /root/reference); the GPU box and the test-suite only read the ``.npz``
+files it writes.
+
+How the reference is executed although its modules cannot be imported here
+(every one imports TensorFlow / h5py / mpi4py / shapely at module level and
+those are not installed): the reference ``.py`` files are parsed
+with ``ast`` *at run time*, the statements of the hot path (block extraction,
+PCA encode, scaling, PCA decode, ``assemble_prediction`` / the inline
+correction loop, global shift) are compiled unmodified and executed with
+
+  * ``np``            -> the real NumPy,
+  * ``self.pcainput`` -> a real scikit-learn ``PCA`` object carrying the seeded
+                         synthetic ``components_`` / ``mean_`` (the reference's
+                         pickles are missing from the snapshot),
+  * ``self.model`` / ``model`` -> a NumPy callable ``relu(x@W+b)`` stack with
+                         Keras ``Dense`` semantics (TensorFlow is third-party,
+                         un-vendored and not installable here).
+
+Statements that only print, plot or compute error metrics are dropped.  No
+reference source text is stored in this repository: only inputs' seeds and the
+numeric outputs.
+
+Usage:  python tests/golden/make_golden.py
+"""
+from __future__ import annotations
+
+import ast
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import psm_amd  # noqa: E402
+from psm_amd import formats, synthetic  # noqa: E402
+
+REF = "/root/reference"
+PM = f"{REF}/Thesis_Work/Chapter5/parallelized/test_case/python_module.py"
+SMD = f"{REF}/Improved_SM/deltaU_to_deltaP/source/pressureSM_deltas/SM_call.py"
+UGP = f"{REF}/Improved_SM/U_to_gradP/evaluation/Eval_dual_Dense_onlycil.py"
+WEIGHTS = f"{REF}/Thesis_Work/Chapter5/parallelized/test_case/weights.h5"
+MAXS = f"{REF}/Thesis_Work/Chapter5/parallelized/test_case/maxs"
+MAXS_PCA = f"{REF}/Thesis_Work/Chapter5/parallelized/test_case/maxs_PCA"
+
+DROP = ("print(", "utils.", "plt.", "pred_minus_true", "fig.", "axs[")
+
+
+# --------------------------------------------------------------------------
+# ast helpers
+# --------------------------------------------------------------------------
+def _tree(path):
+    with open(path) as f:
+        return ast.parse(f.read(), filename=path)
+
+
+def _find_fn(tree, name, cls=None):
+    body = tree.body
+    if cls is not None:
+        body = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls).body
+    return next(n for n in body if isinstance(n, ast.FunctionDef) and n.name == name)
+
+
+def _src(node):
+    return ast.unparse(node)
+
+
+def _slice(stmts, first_pred, last_pred):
+    i0 = next(i for i, s in enumerate(stmts) if first_pred(_src(s)))
+    i1 = next(i for i, s in enumerate(stmts) if i >= i0 and last_pred(_src(s)))
+    keep = [s for s in stmts[i0:i1 + 1] if not any(d in _src(s) for d in DROP)]
+    return keep
+
+
+def _run(stmts, glb, loc, filename):
+    mod = ast.Module(body=stmts, type_ignores=[])
+    ast.fix_missing_locations(mod)
+    exec(compile(mod, filename, "exec"), glb, loc)
+
+
+def _method(tree, cls, name, glb, filename):
+    fn = _find_fn(tree, name, cls)
+    mod = ast.Module(body=[fn], type_ignores=[])
+    ast.fix_missing_locations(mod)
+    ns = dict(glb)
+    exec(compile(mod, filename, "exec"), ns)
+    return ns[name]
+
+
+# --------------------------------------------------------------------------
+# stand-ins for the missing artefacts (NOT for arithmetic of the reference)
+# --------------------------------------------------------------------------
+def sk_pca(comp, mean):
+    from sklearn.decomposition import PCA
+    p = PCA(n_components=comp.shape[0])
+    p.components_ = np.asarray(comp, np.float64)
+    p.mean_ = np.asarray(mean, np.float64)
+    p.n_features_in_ = comp.shape[1]
+    p.n_components_ = comp.shape[0]
+    p.whiten = False
+    ev = np.linspace(2.0, 1.0, comp.shape[0])
+    p.explained_variance_ = ev
+    p.explained_variance_ratio_ = ev / ev.sum()
+    return p
+
+
+def dense_callable(weights):
+    def model(x):
+        h = np.asarray(x, np.float32)
+        for li, (W, b) in enumerate(weights):
+            h = h @ W + b
+            if li != len(weights) - 1:
+                h = np.maximum(h, np.float32(0))
+        return h
+    return model
+
+
+def solid_band(grid, y0, y1, x0, x1):
+    """Zero a rectangle of every channel (a big solid body): forces the
+    'no flow cell in the strip' NaN branches of the reassembly."""
+    g = grid.copy()
+    g[y0:y1, x0:x1, :] = 0.0
+    return g
+
+
+# --------------------------------------------------------------------------
+# the three reference executions
+# --------------------------------------------------------------------------
+def run_gradp(grid6, model, keep_labels=False):
+    """UGP.timeStep, from the block extraction to the four assemblies."""
+    tree = _tree(UGP)
+    glb = {"np": np, "ndimage": None}
+    asm = _method(tree, "Evaluation", "assemble_prediction", glb, UGP)
+    Ev = type("Ev", (), {"assemble_prediction": asm})
+    self = Ev()
+    self.avance, self.shape = model.ov if model.ov is not None else int(0.75 * model.S), model.S
+    self.pcainput, self.pcap = sk_pca(model.comp_in, model.mean_in), sk_pca(model.comp_out, model.mean_out)
+    self.pc_in, self.pc_p = model.p_in, model.p_out
+    self.max_abs_input_PCA, self.max_abs_output_PCA = model.in_a, model.out_a
+    self.model = dense_callable(model.weights)
+    body = _find_fn(tree, "timeStep", "Evaluation").body
+    stmts = _slice(body, lambda s: s.startswith("x_list = []"), lambda s: s.startswith("test_dPdy ="))
+    loc = {"self": self, "grid": grid6[None].astype(np.float64).copy(), "apply_filter": False}
+    with np.errstate(all="ignore"):
+        _run(stmts, glb, loc, UGP)
+    out = dict(x_input=np.asarray(loc["x_input"], np.float64),
+               fields=np.stack([loc["res_dPdx"][0, :, :, 0], loc["res_dPdy"][0, :, :, 0]], -1),
+               n_blocks=np.int64(loc["N"]))
+    if keep_labels:   # labels pushed through the same reassembly (UGP:546-547 self-check)
+        out["label_fields"] = np.stack([loc["test_dPdx"][0, :, :, 0], loc["test_dPdy"][0, :, :, 0]], -1)
+    return out
+
+
+def run_deltas(grid5, model, U_max_norm=1.0, max_abs_p=1.0):
+    """SMD.timeStep, from the block extraction to ``assemble_prediction``."""
+    tree = _tree(SMD)
+    glb = {"np": np, "ndimage": None}
+    asm = _method(tree, "Evaluation", "assemble_prediction", glb, SMD)
+    Ev = type("Ev", (), {"assemble_prediction": asm})
+    self = Ev()
+    self.overlap, self.shape = model.ov if model.ov is not None else int(0.25 * model.S), model.S
+    self.pcainput, self.pcap = sk_pca(model.comp_in, model.mean_in), sk_pca(model.comp_out, model.mean_out)
+    self.pc_in, self.pc_p = model.p_in, model.p_out
+    self.standardization_method = model.scaler_kind
+    self.max_abs_input_PCA, self.max_abs_output_PCA = model.in_a, model.out_a
+    self.max_abs_p = max_abs_p
+    self.model = dense_callable(model.weights)
+    body = _find_fn(tree, "timeStep", "Evaluation").body
+    stmts = _slice(body, lambda s: s.startswith("x_list = []"),
+                   lambda s: s.startswith("(deltap_res, change_in_deltap) =") or s.startswith("deltap_res, change_in_deltap ="))
+    Ny, Nx = grid5.shape[:2]
+    loc = {"self": self, "grid": grid5[None].astype(np.float64).copy(), "apply_filter": False,
+           "U_max_norm": U_max_norm, "deltaU_change_grid": np.zeros((Ny, Nx)),
+           "deltaP_prev_grid": np.zeros((Ny, Nx))}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as td:
+        os.chdir(td)
+        try:
+            if model.scaler_kind == "std":
+                np.savez("mean_std.npz", mean_in=model.in_a, std_in=model.in_b, mean_out=model.out_a, std_out=model.out_b)
+            elif model.scaler_kind == "min_max":
+                np.savez("min_max_values.npz", min_in=model.in_a, max_in=model.in_b, min_out=model.out_a, max_out=model.out_b)
+            with np.errstate(all="ignore"):
+                _run(stmts, glb, loc, SMD)
+        finally:
+            os.chdir(cwd)
+    return dict(x_input=np.asarray(loc["x_input"], np.float64), fields=np.asarray(loc["deltap_res"])[..., None],
+                n_blocks=np.int64(loc["N"]))
+
+
+def run_chapter5(grid3, model):
+    """PM.py_func (rank-0 branch), from the block extraction to the final shift."""
+    tree = _tree(PM)
+    fn = _find_fn(tree, "py_func")
+    rank0 = [n for n in fn.body if isinstance(n, ast.If) and "rank == 0" in _src(n.test)]
+    body = max(rank0, key=lambda n: len(n.body)).body
+    stmts = _slice(body, lambda s: s.startswith("x_list = []"), lambda s: s.startswith("result_array = result_array[0, :, :, 0]"))
+    import time as _time
+    glb = {"np": np, "time": _time, "model": dense_callable(model.weights),
+           "pca_mean_input": model.mean_in, "comp_input": model.comp_in, "max_abs_input_PCA": model.in_a,
+           "max_abs_p_PCA": model.out_a, "comp_p": model.comp_out, "pca_mean_p": model.mean_out}
+    loc = {"grid": grid3[None].astype(np.float64).copy()}
+    with np.errstate(all="ignore"):
+        _run(stmts, glb, loc, PM)
+    return dict(x_input=np.asarray(loc["x_input"], np.float64), fields=np.asarray(loc["result_array"])[..., None],
+                n_blocks=np.int64(loc["N"]))
+
+
+# --------------------------------------------------------------------------
+# cases (inputs are regenerated from these specs by tests/cases.py)
+# --------------------------------------------------------------------------
+def main():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cases
+    os.makedirs(HERE, exist_ok=True)
+
+    # real trained artefacts of the reference test case -> data fixture
+    W = formats.read_keras_dense_weights(WEIGHTS)
+    maxs, maxs_pca = formats.read_maxs(MAXS), formats.read_maxs(MAXS_PCA)
+    flat = {}
+    for i, (w, b) in enumerate(W):
+        flat[f"W{i}"], flat[f"b{i}"] = w, b
+    np.savez_compressed(os.path.join(HERE, "chapter5_weights.npz"), maxs=maxs, maxs_PCA=maxs_pca, **flat)
+    print("chapter5_weights.npz", [w.shape for w, _ in W])
+
+    for name in cases.GOLDEN_CASES:
+        grid, model = cases.build(name)
+        if model.variant == "gradp":
+            out = run_gradp(grid, model, keep_labels=(name == "gradp_272x288"))
+        elif model.variant == "deltas":
+            out = run_deltas(grid, model, U_max_norm=cases.GOLDEN_CASES[name].get("U_max_norm", 1.0),
+                             max_abs_p=cases.GOLDEN_CASES[name].get("max_abs_p", 1.0))
+        else:
+            out = run_chapter5(grid, model)
+        np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+        f = out["fields"]
+        print(f"{name}: B={int(out['n_blocks'])} fields{f.shape} nan={int(np.isnan(f).sum())} "
+              f"|x_input|max={np.abs(out['x_input']).max():.3f} |f|max={np.nanmax(np.abs(f)):.4f}")
+
+
+if __name__ == "__main__":
+    main()
