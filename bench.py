@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- pressure-solves/sec of the surrogate hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload at every N (weak scaling: the per-GPU work is fixed): BASELINE.json
+configs[1] -- 256x256 channel-with-obstacle U_to_gradP inference, batch 1, fp32,
+P_i = P_o = 128, MLP 3x512 (SURVEY.md §8 d config 1; synthetic seeded input,
+seeded random-init weights of that architecture).  One step = one solve
+(grid[256,256,3] -> fields[256,256,2]) through the C-ABI with the input already
+resident in HBM; steps are issued back to back on one stream (hipGraph replay),
+K steps are timed between barrier + synchronize on both sides, MAX over ranks.
+For N > 1 each rank drives its own GPU with its own independent cases (the case
+batch is sharded, no data-path collective); RCCL is used only for the barrier
+and the max-reduction of the time.
+
+Extra objects on the JSON line:
+  roofline     dominant kernel (encode) : algorithmic bytes per launch / average
+               launch duration measured with HIP events on the launch stream in an
+               instrumented pass over the same K steps right after the timed region.
+  cpu_baseline the NumPy oracle ("port" of the reference's algorithm, float64 PCA +
+               float32 MLP like the reference) timed on the host cores, rank 0, N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NY = NX = 256
+P = 128
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def algorithmic_bytes(model, ny, nx):
+    """SURVEY.md §8(d) BYTES formula, split per kernel group (float32 = 4 B)."""
+    S2 = model.S ** 2
+    enc = 4 * (ny * nx * model.c_in + S2 * model.c_in * model.p_in + S2 * model.c_in)
+    dec = 4 * (S2 * model.c_out * model.p_out + S2 * model.c_out + ny * nx * model.c_out)
+    mlp = 4 * sum(W.size + b.size for W, b in model.weights)
+    return {"encode": enc, "decode": dec, "mlp": mlp, "total": enc + dec + mlp}
+
+
+def cpu_baseline(model, grid, budget_s=12.0, max_solves=40):
+    """Time the oracle on the host cores (bounded sample of the same workload)."""
+    from oracle import psm_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    sc = orc.Scaler(model.scaler_kind, model.in_a, model.in_b, model.out_a, model.out_b)
+    om = orc.Model(model.variant, model.c_in, model.c_out, model.comp_in, model.mean_in, model.comp_out,
+                   model.mean_out, model.weights, sc, model.out_scale, model.S, model.ov, model.sdf_ch)
+    g = grid.astype(np.float64)
+    orc.solve_grid(g, om)                       # warm-up (BLAS threads, page faults)
+    n, t0 = 0, time.perf_counter()
+    while n < max_solves and (time.perf_counter() - t0) < budget_s:
+        sol = orc.solve_grid(g, om)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "solves/s", "cores": int(cores), "kind": "port",
+            "sample": f"{n} sequential 256x256 gradP solves of the NumPy oracle (float64 PCA/reassembly, float32 MLP) in {dt:.1f} s"}, sol
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inputs", type=int, default=4, help="distinct input grids rotated through (all resident in HBM)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import psm_amd
+    from psm_amd import synthetic
+    model = synthetic.make_model("gradp", p_in=P, p_out=P)
+    sur = psm_amd.GridSurrogate(model, NY, NX, max_cases=1, device=local_rank)
+    # independent cases per rank (different seeds), all resident in HBM before timing
+    grids = [synthetic.channel_grid(NY, NX, seed=1 + 1000 * rank + i).astype(np.float32) for i in range(args.inputs)]
+    d_in = [torch.from_numpy(g).cuda() for g in grids]
+    d_out = [torch.empty((NY, NX, model.c_out), dtype=torch.float32, device="cuda") for _ in grids]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(i):
+        k = i % len(d_in)
+        sur.solve_device(d_in[k].data_ptr(), 1, d_out[k].data_ptr(), stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    barrier()
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+
+    # ---- roofline of the dominant kernel: instrumented pass over the same K steps
+    ab = algorithmic_bytes(model, NY, NX)
+    prof = sur.profile(d_in[0].data_ptr(), 1, d_out[0].data_ptr())
+    dom = "encode"
+    sur.enable_kernel_timing(dom)
+    for i in range(args.steps):
+        step(i)
+    tot_ms, launches = sur.kernel_timing(dom)
+    sur.enable_kernel_timing(dom, False)
+    avg_s = tot_ms / max(launches, 1) * 1e-3
+    achieved = ab[dom] / avg_s / 1e9
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_encode.json")
+    if os.path.exists(pmc_file):
+        try:
+            traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"kernel": "psm_encode_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes": ab[dom], "avg_launch_us": avg_s * 1e6, "launches": launches,
+                "per_kernel_ms_one_solve": prof}
+
+    out = {
+        "metric": "pressure-solves/sec (256x256 U->p inference)", "value": world * args.steps / dt_max,
+        "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: 256x256 channel+obstacle U_to_gradP, batch 1, fp32, "
+                               "B=30 blocks of 128x128x3, P_i=P_o=128, MLP 3x512, one independent case stream per GPU",
+                   "grid": [NY, NX], "blocks": sur.B, "p_in": P, "p_out": P, "cases_per_step_per_gpu": 1,
+                   "parallelism": f"case-sharded x{world} (no data-path collective)"},
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cb, sol = cpu_baseline(model, grids[0])
+        out["cpu_baseline"] = cb
+        got = d_out[0].cpu().numpy()
+        ref = sol.fields
+        out["l2_vs_oracle"] = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+        out["gpu_over_cpu"] = out["value"] / cb["value"]
+    if rank == 0:
+        print(json.dumps(out))
+    sur.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,176 @@
+/* psm.h -- C-ABI of the MI355X-native pressure-surrogate path ("libpsm_hip.so").
+ *
+ * Drop-in boundary for the surrogate call of the DLPoissonFoam solvers and the
+ * Improved_SM evaluators of pauloacs/Solving-Poisson-s-Equation-through-DL-for-
+ * CFD-apllications.  Paths below are relative to that repository.
+ *
+ *   PM  = Thesis_Work/Chapter5/parallelized/test_case/python_module.py
+ *   PCI = Thesis_Work/Chapter5/parallelized/DLPoissonSolver/PythonComm_init.H
+ *   PC  = Thesis_Work/Chapter5/parallelized/DLPoissonSolver/PythonComm.H
+ *   SMD = Improved_SM/deltaU_to_deltaP/source/pressureSM_deltas/SM_call.py
+ *   UGP = Improved_SM/U_to_gradP/evaluation/Eval_dual_Dense_onlycil.py
+ *
+ * Plain C types only: pointers, sizes, int status.  Every function returns
+ * PSM_OK (0) or a negative error; the message is available from
+ * psm_last_error().  Nothing here aborts the host solver (the reference
+ * dereferences NULL on failure: PCI:11-18, log.DL:34-42).
+ *
+ * Ownership: the caller owns every buffer it passes; the library copies what
+ * it needs before returning and never keeps a caller pointer (the reference
+ * borrows the solver's buffer through PyArray_SimpleNewFromData, PC:17).
+ * Threading: one in-flight call per handle; handles are independent.
+ */
+#ifndef PSM_H_
+#define PSM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSM_ABI_VERSION 1
+
+/* block layout + reassembly variant */
+#define PSM_VARIANT_CHAPTER5 0 /* PM:303-332, 373-472 */
+#define PSM_VARIANT_DELTAS   1 /* SMD:452-482, 182-365 */
+#define PSM_VARIANT_GRADP    2 /* UGP:476-500, 255-369 */
+
+/* scaling of the PCA coefficients around the network */
+#define PSM_SCALER_MAX_ABS 0 /* PM:351,365; UGP:525,531; SMD:521-523,536-537 */
+#define PSM_SCALER_STD     1 /* SMD:505-512,532-533 */
+#define PSM_SCALER_MIN_MAX 2 /* SMD:513-520,534-535 */
+
+#define PSM_OK               0
+#define PSM_ERR_ARG         -1 /* invalid argument / shape */
+#define PSM_ERR_STATE       -2 /* call order (model incomplete, no plan, ...) */
+#define PSM_ERR_HIP         -3 /* a HIP runtime call failed */
+#define PSM_ERR_NO_DEVICE   -4 /* no usable gfx950 device */
+#define PSM_ERR_UNSUPPORTED -5 /* shape the reference itself cannot process */
+#define PSM_ERR_NOMEM       -6
+
+/* intermediate results readable with psm_read_stage (parity tests) */
+#define PSM_STAGE_X_INPUT    0 /* [rows, p_in]   scaled network input (PM:351)      */
+#define PSM_STAGE_RES        1 /* [rows, p_out]  network output, inverse-scaled      */
+#define PSM_STAGE_BLOCK_PRED 2 /* [rows, S*S*c_out] decoded blocks (PM:365-366)      */
+#define PSM_STAGE_OFFSETS    3 /* [cases, c_out, B] per-block corrections (BC_coor)  */
+#define PSM_STAGE_SHIFT      4 /* [cases, c_out] global shift (PM:472)               */
+
+/* kernels of one solve, in launch order (psm_profile_solve) */
+#define PSM_K_ENCODE   0
+#define PSM_K_REDUCE   1
+#define PSM_K_MLP      2 /* all dense layers together */
+#define PSM_K_DECODE   3
+#define PSM_K_STRIPS   4
+#define PSM_K_CHAIN    5
+#define PSM_K_PASTE    6
+#define PSM_K_COUNT    7
+
+typedef struct psm_handle psm_handle;
+
+/* Replaces the module-level constants of PM:103-134,195,303-304 and the
+ * Evaluation(...) constructor arguments of SMD:27 / UGP:31. */
+typedef struct psm_config {
+  int32_t abi_version;   /* PSM_ABI_VERSION */
+  int32_t variant;       /* PSM_VARIANT_* */
+  int32_t block;         /* S, block edge (128: PM:303, SMD "shape") */
+  int32_t overlap;       /* overlap-strip width; 0 = variant default (12 / 32 / 96) */
+  int32_t c_in;          /* input channels (3; 4 for pressureSM_Poisson) */
+  int32_t c_out;         /* output channels (1; 2 for U_to_gradP) */
+  int32_t p_in;          /* retained input PCs  (PM:113, SMD:87) */
+  int32_t p_out;         /* retained output PCs (PM:112, SMD:86) */
+  int32_t n_dense;       /* Dense layers including the linear head (PM:125-129) */
+  int32_t scaler;        /* PSM_SCALER_* */
+  int32_t sdf_channel;   /* channel whose non-zero cells are flow cells (2) */
+  int32_t device;        /* HIP device ordinal */
+  int32_t max_cases;     /* capacity of the case batch (>=1) */
+  int32_t strict_degenerate; /* 1: keep NumPy semantics when the last block row
+                                duplicates the previous one (NaN field, UGP:340);
+                                0: leave that row out */
+} psm_config;
+
+/* ---- lifetime ------------------------------------------------------------ */
+/* Replaces Py_Initialize + import python_module (PCI:3-18). */
+int psm_create(const psm_config* cfg, psm_handle** out);
+void psm_destroy(psm_handle* h);
+/* Message of the last failure on `h` (or of the last failed psm_create when h is NULL). */
+const char* psm_last_error(const psm_handle* h);
+
+/* ---- model artefacts (PM:103-118,168-170; SMD:70-87,507-519) -------------- */
+/* sklearn components_[:p] ([p, S*S*c] row-major) and mean_ ([S*S*c]). */
+int psm_set_pca(psm_handle* h, const double* comp_in, const double* mean_in,
+                const double* comp_out, const double* mean_out);
+/* Keras Dense kernel [n_in, n_out] row-major and bias [n_out]; layer in [0, n_dense). */
+int psm_set_dense(psm_handle* h, int32_t layer, int32_t n_in, int32_t n_out,
+                  const float* kernel, const float* bias);
+/* max_abs: in_a[0] = max_abs_input_PCA, out_a[0] = max_abs_output_PCA (others ignored);
+ * std: in_a = mean_in, in_b = std_in, out_a = mean_out, out_b = std_out  ([p_in]/[p_out]);
+ * min_max: in_a = min_in, in_b = max_in, out_a = min_out, out_b = max_out. */
+int psm_set_scaler(psm_handle* h, const double* in_a, const double* in_b,
+                   const double* out_a, const double* out_b);
+
+/* ---- geometry ------------------------------------------------------------ */
+/* Fix the uniform grid shape (grid_shape_y/x of PM:216-217) and build the block
+ * tables; the grid-native counterpart of init_func (PM:172-247). */
+int psm_plan_grid(psm_handle* h, int32_t ny, int32_t nx);
+/* Number of blocks per case of the current plan (len(x_list), PM:332). */
+int psm_num_blocks(const psm_handle* h);
+
+/* ---- per-step solve: grid-native counterpart of py_func (PM:249-517) and of
+ *      Evaluation.timeStep from block extraction to assemble_prediction
+ *      (SMD:452-575, UGP:470-547) ------------------------------------------- */
+/* Host buffers.  grid: [n_cases, ny, nx, c_in] float32 NHWC, already normalised
+ * as at PM:288-297; fields: [n_cases, ny, nx, c_out].  out_scale: per-case factor
+ * applied to the decoded blocks (max_abs_p*U_max^2, SMD:551) or NULL for 1.
+ * Synchronous, like py_func. */
+int psm_solve_grid(psm_handle* h, const float* grid, int32_t n_cases,
+                   const float* out_scale, float* fields);
+/* Device buffers (HIP pointers on cfg.device), asynchronous on `stream`
+ * (hipStream_t; NULL = the handle's own stream).  out_scale is a HOST pointer
+ * (or NULL) read before return. */
+int psm_solve_grid_device(psm_handle* h, const float* d_grid, int32_t n_cases,
+                          const float* out_scale, float* d_fields, void* stream);
+/* Reassembly alone (assemble_prediction, SMD:182 / UGP:255; correction loop PM:373-472)
+ * of caller-supplied decoded blocks block_pred[B, S*S*c_out] for ONE case, host
+ * buffers, synchronous.  grid supplies the flow mask (its sdf channel). */
+int psm_reassemble(psm_handle* h, const float* grid, const float* block_pred, float* fields);
+/* Wait for everything submitted through this handle. */
+int psm_synchronize(psm_handle* h);
+
+/* ---- introspection ------------------------------------------------------- */
+/* Copy an intermediate of the LAST solve to host memory (float32). */
+int psm_read_stage(psm_handle* h, int32_t stage, float* dst, size_t dst_floats);
+/* Run one solve with a HIP event pair around every kernel group on the
+ * launch stream; ms[PSM_K_COUNT] receives the durations in milliseconds. */
+int psm_profile_solve(psm_handle* h, const float* d_grid, int32_t n_cases,
+                      float* d_fields, float* ms);
+/* Accumulated device time (ms) and launch count of kernel group `k`, measured
+ * with HIP events on the launch stream while event timing is enabled. */
+int psm_enable_kernel_timing(psm_handle* h, int32_t kernel, int32_t on);
+int psm_get_kernel_timing(psm_handle* h, int32_t kernel, double* total_ms, int64_t* launches);
+
+/* ---- host-only helpers (no GPU needed) ----------------------------------- */
+/* Block layout of a variant: writes up to `cap` rows of (y0, x0, idx_i, idx_j)
+ * into blocks[4*cap]; returns the number of blocks (or <0).  n_x / n_y as at
+ * PM:306-307, SMD:461-462, UGP:479-480. */
+int psm_layout(int32_t variant, int32_t ny, int32_t nx, int32_t block, int32_t overlap,
+               int32_t* blocks, int32_t cap, int32_t* n_x, int32_t* n_y);
+/* Which block (index into the layout) supplies each output cell after all
+ * pastes, and from which local cell: owner[ny*nx] = b*S*S + r*S + c (or -1). */
+int psm_owner_map(int32_t variant, int32_t ny, int32_t nx, int32_t block, int32_t overlap,
+                  int32_t strict_degenerate, int32_t* owner);
+/* Host replay of the device reassembly (strip table -> offset chain -> owner-map
+ * paste) on caller-supplied decoded blocks pred[B, S*S*c_out] and one grid
+ * [ny, nx, c_in].  Verification helper for the plan tables; never called by
+ * psm_solve_*.  offsets [c_out, B] and shifts [c_out] may be NULL. */
+int psm_debug_reassemble_host(int32_t variant, int32_t ny, int32_t nx, int32_t block, int32_t overlap,
+                              int32_t strict_degenerate, int32_t c_in, int32_t c_out, int32_t sdf_channel,
+                              const float* grid, const float* pred, float* fields, float* offsets,
+                              float* shifts);
+int psm_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSM_H_ */

@@ -1,0 +1,744 @@
+// psm_api.cpp -- C-ABI of libpsm_hip.so (include/psm.h): handle, weight packing,
+// HBM layout, hipGraph-captured launch sequence, pinned host staging.
+// Compiled with hipcc for gfx950 only.  There is no CPU fallback: without a
+// usable device psm_create fails with PSM_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/psm.h"
+#include "psm_kernels.h"
+#include "psm_plan.h"
+
+namespace {
+thread_local std::string g_create_error;
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct DenseLayer {
+  int n_in = 0, n_out = 0, Kpad = 0, ldw = 0;
+  float* W = nullptr;
+  float* b = nullptr;
+  bool set = false;
+};
+
+struct GraphKey {
+  int n; const void* g; void* f;
+  bool operator<(const GraphKey& o) const { return std::tie(n, g, f) < std::tie(o.n, o.g, o.f); }
+};
+}  // namespace
+
+struct psm_handle {
+  psm_config cfg{};
+  std::string err;
+  int S = 0, ov = 0, K_in = 0, K_out = 0, ld_in = 0, ld_out = 0, NT = 0, n_slices = 0, Gd = 0, n_coltiles = 0;
+  bool have_pca = false, have_scaler = false;
+  std::vector<DenseLayer> dense;
+  float *d_mean_in = nullptr, *d_mean_out = nullptr;
+  float4 *d_bpack_in = nullptr, *d_bpack_out = nullptr;
+  float *d_ia = nullptr, *d_ib = nullptr, *d_sa = nullptr, *d_sb = nullptr;
+  // plan
+  bool planned = false;
+  PsmPlan plan;
+  int Ny = 0, Nx = 0, B = 0, Mcap = 0, Mpad_cap = 0, n_strips = 0, Lmax = 0, max_width = 0;
+  float *d_part = nullptr, *d_xin = nullptr, *d_act[2] = {nullptr, nullptr}, *d_res = nullptr, *d_pred = nullptr;
+  int64_t* d_row_base = nullptr;
+  float *d_row_scale = nullptr, *d_ones = nullptr;
+  int32_t *d_strips = nullptr, *d_blk = nullptr, *d_owner = nullptr, *d_shiftA = nullptr, *d_shiftB = nullptr;
+  PsmBlock* d_blocks = nullptr;
+  float2* d_sres = nullptr;
+  float *d_offs = nullptr, *d_shift = nullptr;
+  float *d_grid_stage = nullptr, *d_fields_stage = nullptr;
+  float *h_grid = nullptr, *h_fields = nullptr;
+  // row-scale upload ring (pinned)
+  static constexpr int RING = 8;
+  float* h_scale[RING] = {};
+  hipEvent_t scale_ev[RING] = {};
+  int scale_pos = 0;
+  hipStream_t stream = nullptr;
+  std::map<GraphKey, hipGraphExec_t> graphs;
+  bool use_graph = true;
+  int last_cases = 0;
+  // event timing of one kernel group
+  int timed_kernel = -1;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> timed_events;
+  double timed_total_ms = 0.0;
+  int64_t timed_launches = 0;
+};
+
+namespace {
+
+int fail(psm_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg; else g_create_error = msg;
+  return code;
+}
+
+#define HIPCHK(h, expr)                                                                      \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail((h), PSM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+  } while (0)
+
+template <typename T>
+int dev_alloc(psm_handle* h, T** p, size_t n) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (n == 0) n = 1;
+  hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+  if (e != hipSuccess) return fail(h, PSM_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+  return PSM_OK;
+}
+
+template <typename T>
+int dev_upload(psm_handle* h, T** p, const std::vector<T>& v) {
+  int rc = dev_alloc(h, p, v.size());
+  if (rc) return rc;
+  if (!v.empty()) HIPCHK(h, hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return PSM_OK;
+}
+
+template <typename T>
+void dev_free(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+void destroy_graphs(psm_handle* h) {
+  for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+  h->graphs.clear();
+}
+
+void free_plan(psm_handle* h) {
+  destroy_graphs(h);
+  dev_free(h->d_part); dev_free(h->d_xin); dev_free(h->d_act[0]); dev_free(h->d_act[1]); dev_free(h->d_res);
+  dev_free(h->d_pred); dev_free(h->d_row_base); dev_free(h->d_row_scale); dev_free(h->d_ones); dev_free(h->d_strips);
+  dev_free(h->d_blk); dev_free(h->d_owner); dev_free(h->d_shiftA); dev_free(h->d_shiftB); dev_free(h->d_blocks);
+  dev_free(h->d_sres); dev_free(h->d_offs); dev_free(h->d_shift); dev_free(h->d_grid_stage); dev_free(h->d_fields_stage);
+  if (h->h_grid) { (void)hipHostFree(h->h_grid); h->h_grid = nullptr; }
+  if (h->h_fields) { (void)hipHostFree(h->h_fields); h->h_fields = nullptr; }
+  h->planned = false;
+}
+
+// ---- weight packing ----------------------------------------------------------
+// comp_in [P][K] (sklearn components_) -> [slice][ntile][G][64 lanes] float4 so that one wave
+// instruction of the encode kernel reads 1 KiB contiguous; element j of lane l in group g is
+// comp[32*t + (l&31)][slice*KS + 8*g + 4*(l>>5) + j]  (zero for padded components).
+std::vector<float4> pack_comp_in(const double* comp, int P, int K, int c_in, int S, int NT) {
+  const int KS = PSM_PIX_PER_SLICE * c_in, G = KS / 8, n_slices = S * S / PSM_PIX_PER_SLICE;
+  std::vector<float4> out((size_t)n_slices * NT * G * 64);
+  for (int s = 0; s < n_slices; ++s)
+    for (int t = 0; t < NT; ++t)
+      for (int g = 0; g < G; ++g)
+        for (int l = 0; l < 64; ++l) {
+          const int p = 32 * t + (l & 31);
+          const int64_t k = (int64_t)s * KS + 8 * g + 4 * (l >> 5);
+          float v[4] = {0, 0, 0, 0};
+          if (p < P) for (int j = 0; j < 4; ++j) v[j] = (float)comp[(int64_t)p * K + k + j];
+          out[(((size_t)s * NT + t) * G + g) * 64 + l] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+  return out;
+}
+
+// comp_out [P][K_out] -> [coltile][Gd][64] float4: element j of lane l in group g is
+// comp[8*g + 4*(l>>5) + j][32*ct + (l&31)]  (zero for padded components).
+std::vector<float4> pack_comp_out(const double* comp, int P, int K_out, int Gd) {
+  const int nct = K_out / 32;
+  std::vector<float4> out((size_t)nct * Gd * 64);
+  for (int ct = 0; ct < nct; ++ct)
+    for (int g = 0; g < Gd; ++g)
+      for (int l = 0; l < 64; ++l) {
+        const int col = 32 * ct + (l & 31);
+        float v[4];
+        for (int j = 0; j < 4; ++j) {
+          const int p = 8 * g + 4 * (l >> 5) + j;
+          v[j] = p < P ? (float)comp[(int64_t)p * K_out + col] : 0.f;
+        }
+        out[((size_t)ct * Gd + g) * 64 + l] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+  return out;
+}
+
+bool model_complete(const psm_handle* h) {
+  if (!h->have_pca || !h->have_scaler) return false;
+  for (auto& d : h->dense) if (!d.set) return false;
+  return true;
+}
+
+// ---- the launch sequence -------------------------------------------------------
+struct Timer {                      // optional event pair around one kernel group
+  psm_handle* h; hipStream_t st; int k; hipEvent_t* ev;   // ev: [PSM_K_COUNT+1] profile events or null
+  void before(int kernel) {
+    if (ev && kernel == 0) (void)hipEventRecord(ev[0], st);
+    if (h->timed_kernel == kernel) {
+      hipEvent_t a, b;
+      (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+      (void)hipEventRecord(a, st);
+      h->timed_events.push_back({a, b});
+    }
+  }
+  void after(int kernel) {
+    if (ev) (void)hipEventRecord(ev[kernel + 1], st);
+    if (h->timed_kernel == kernel) (void)hipEventRecord(h->timed_events.back().second, st);
+  }
+};
+
+int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields, const float* d_row_scale,
+               hipStream_t st, hipEvent_t* prof) {
+  const int M = n_cases * h->B, Mpad = round_up(M, 32);
+  Timer tm{h, st, 0, prof};
+  PsmEncodeArgs ea{};
+  ea.grid = d_grid; ea.mean = h->d_mean_in; ea.bpack = h->d_bpack_in; ea.part = h->d_part;
+  ea.row_base = h->d_row_base; ea.row_stride = (int64_t)h->Nx * h->cfg.c_in;
+  ea.M = M; ea.Mpad = Mpad; ea.NT = h->NT; ea.ldp = h->ld_in; ea.S = h->S; ea.c_in = h->cfg.c_in;
+  bool aligned = ((h->Nx * h->cfg.c_in) % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_grid) & 15) == 0) &&
+                 ((h->Ny * (int64_t)h->Nx * h->cfg.c_in) % 4 == 0);
+  for (auto& b : h->plan.blocks) if ((b.x0 * h->cfg.c_in) % 4 != 0) aligned = false;
+  ea.aligned = aligned ? 1 : 0;
+  tm.before(PSM_K_ENCODE);
+  HIPCHK(h, psm_launch_encode(ea, st));
+  tm.after(PSM_K_ENCODE);
+
+  PsmReduceArgs ra{h->d_part, h->d_xin, h->d_ia, h->d_ib, h->n_slices, Mpad, h->ld_in};
+  tm.before(PSM_K_REDUCE);
+  HIPCHK(h, psm_launch_reduce(ra, st));
+  tm.after(PSM_K_REDUCE);
+
+  tm.before(PSM_K_MLP);
+  const float* cur = h->d_xin; int ld_cur = h->ld_in;
+  const int nl = (int)h->dense.size();
+  for (int l = 0; l < nl; ++l) {
+    const DenseLayer& d = h->dense[l];
+    const bool head = (l == nl - 1);
+    PsmDenseArgs da{};
+    da.in = cur; da.ld_in = ld_cur; da.W = d.W; da.ld_w = d.ldw; da.bias = d.b;
+    da.sa = h->d_sa; da.sb = h->d_sb;
+    da.out = head ? h->d_res : h->d_act[l & 1]; da.ld_out = d.ldw;
+    da.Kpad = d.Kpad; da.Mpad = Mpad; da.relu = head ? 0 : 1; da.head = head ? 1 : 0;
+    HIPCHK(h, psm_launch_dense(da, st));
+    cur = da.out; ld_cur = d.ldw;
+  }
+  tm.after(PSM_K_MLP);
+
+  PsmDecodeArgs de{};
+  de.res = h->d_res; de.ld_res = h->ld_out; de.bpack = h->d_bpack_out; de.mean = h->d_mean_out;
+  de.row_scale = d_row_scale; de.pred = h->d_pred; de.M = M; de.Mpad = Mpad; de.Gd = h->Gd;
+  de.n_coltiles = h->n_coltiles; de.K_out = h->K_out;
+  tm.before(PSM_K_DECODE);
+  HIPCHK(h, psm_launch_decode(de, st));
+  tm.after(PSM_K_DECODE);
+
+  PsmStripArgs sa{};
+  sa.pred = h->d_pred; sa.grid = d_grid; sa.strips = h->d_strips; sa.blk_y0x0 = h->d_blk; sa.sres = h->d_sres;
+  sa.n_strips = h->n_strips; sa.B = h->B; sa.S = h->S; sa.c_in = h->cfg.c_in; sa.c_out = h->cfg.c_out;
+  sa.sdf_ch = h->cfg.sdf_channel; sa.Ny = h->Ny; sa.Nx = h->Nx;
+  tm.before(PSM_K_STRIPS);
+  HIPCHK(h, psm_launch_strips(sa, n_cases, st));
+  tm.after(PSM_K_STRIPS);
+
+  PsmChainArgs ca{};
+  ca.cp = h->plan.cp; ca.blocks = h->d_blocks; ca.sres = h->d_sres; ca.pred = h->d_pred; ca.owner = h->d_owner;
+  ca.shiftA = h->d_shiftA; ca.shiftB = h->d_shiftB;
+  for (int f = 0; f < 2; ++f) ca.shiftL[f] = (int)h->plan.shiftA[f].size();
+  ca.Lmax = h->Lmax; ca.offs = h->d_offs; ca.shift = h->d_shift; ca.n_strips = h->n_strips; ca.c_out = h->cfg.c_out;
+  tm.before(PSM_K_CHAIN);
+  HIPCHK(h, psm_launch_chain(ca, n_cases, st));
+  tm.after(PSM_K_CHAIN);
+
+  PsmPasteArgs pa{h->d_pred, h->d_owner, h->d_offs, h->d_shift, d_fields, h->B, h->S, h->cfg.c_out, h->Ny * h->Nx};
+  tm.before(PSM_K_PASTE);
+  HIPCHK(h, psm_launch_paste(pa, n_cases, st));
+  tm.after(PSM_K_PASTE);
+  return PSM_OK;
+}
+
+int prepare_scale(psm_handle* h, const float* out_scale, int n_cases, hipStream_t st, const float** d_scale) {
+  if (!out_scale) { *d_scale = h->d_ones; return PSM_OK; }
+  const int M = n_cases * h->B;
+  const int slot = h->scale_pos;
+  h->scale_pos = (h->scale_pos + 1) % psm_handle::RING;
+  HIPCHK(h, hipEventSynchronize(h->scale_ev[slot]));
+  for (int c = 0; c < n_cases; ++c)
+    for (int b = 0; b < h->B; ++b) h->h_scale[slot][c * h->B + b] = out_scale[c];
+  HIPCHK(h, hipMemcpyAsync(h->d_row_scale, h->h_scale[slot], (size_t)M * sizeof(float), hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipEventRecord(h->scale_ev[slot], st));
+  *d_scale = h->d_row_scale;
+  return PSM_OK;
+}
+
+int solve_device(psm_handle* h, const float* d_grid, int n_cases, const float* out_scale, float* d_fields,
+                 hipStream_t st, hipEvent_t* prof) {
+  if (!h) return PSM_ERR_ARG;
+  if (!h->planned) return fail(h, PSM_ERR_STATE, "psm_plan_grid has not been called");
+  if (!d_grid || !d_fields) return fail(h, PSM_ERR_ARG, "null buffer");
+  if (n_cases < 1 || n_cases > h->cfg.max_cases) return fail(h, PSM_ERR_ARG, "n_cases outside [1, max_cases]");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  if (!st) st = h->stream;
+  const float* d_scale = nullptr;
+  int rc = prepare_scale(h, out_scale, n_cases, st, &d_scale);
+  if (rc) return rc;
+  h->last_cases = n_cases;
+  const bool eager = prof || h->timed_kernel >= 0 || !h->use_graph;
+  if (eager) return launch_all(h, d_grid, n_cases, d_fields, d_scale, st, prof);
+  GraphKey key{n_cases * 2 + (out_scale ? 1 : 0), d_grid, d_fields};
+  auto it = h->graphs.find(key);
+  if (it == h->graphs.end()) {
+    if (h->graphs.size() > 64) destroy_graphs(h);
+    hipGraph_t graph = nullptr;
+    HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
+    rc = launch_all(h, d_grid, n_cases, d_fields, d_scale, h->stream, nullptr);
+    hipError_t e = hipStreamEndCapture(h->stream, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) return fail(h, PSM_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return fail(h, PSM_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    it = h->graphs.emplace(key, exec).first;
+  }
+  HIPCHK(h, hipGraphLaunch(it->second, st));
+  return PSM_OK;
+}
+
+}  // namespace
+
+// ============================================================================
+extern "C" {
+
+int psm_abi_version(void) { return PSM_ABI_VERSION; }
+
+const char* psm_last_error(const psm_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int psm_create(const psm_config* cfg, psm_handle** out) {
+  if (!cfg || !out) return fail(nullptr, PSM_ERR_ARG, "null argument");
+  *out = nullptr;
+  if (cfg->abi_version != PSM_ABI_VERSION) return fail(nullptr, PSM_ERR_ARG, "psm_config.abi_version mismatch");
+  if (cfg->variant < 0 || cfg->variant > 2) return fail(nullptr, PSM_ERR_ARG, "unknown variant");
+  if (cfg->block <= 0 || cfg->block % 64) return fail(nullptr, PSM_ERR_ARG, "block must be a positive multiple of 64");
+  if (cfg->c_in < 1 || cfg->c_in > 4) return fail(nullptr, PSM_ERR_ARG, "c_in must be 1..4");
+  if (cfg->c_out < 1 || cfg->c_out > 2) return fail(nullptr, PSM_ERR_ARG, "c_out must be 1 or 2");
+  if (cfg->variant == PSM_VARIANT_GRADP && cfg->c_out != 2) return fail(nullptr, PSM_ERR_ARG, "gradp needs c_out == 2");
+  if (cfg->variant != PSM_VARIANT_GRADP && cfg->c_out != 1) return fail(nullptr, PSM_ERR_ARG, "this variant needs c_out == 1");
+  if (cfg->p_in < 1 || cfg->p_in > 1024 || cfg->p_out < 1 || cfg->p_out > 1024) return fail(nullptr, PSM_ERR_ARG, "p_in/p_out must be 1..1024");
+  if (cfg->n_dense < 1 || cfg->n_dense > 64) return fail(nullptr, PSM_ERR_ARG, "n_dense must be 1..64");
+  if (cfg->scaler < 0 || cfg->scaler > 2) return fail(nullptr, PSM_ERR_ARG, "Standardization method not valid");
+  if (cfg->sdf_channel < 0 || cfg->sdf_channel >= cfg->c_in) return fail(nullptr, PSM_ERR_ARG, "sdf_channel outside the input channels");
+  if (cfg->max_cases < 1) return fail(nullptr, PSM_ERR_ARG, "max_cases must be >= 1");
+  if (cfg->overlap < 0 || cfg->overlap >= cfg->block) return fail(nullptr, PSM_ERR_ARG, "overlap must lie in [0, block)");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(nullptr, PSM_ERR_NO_DEVICE, "no HIP device: the surrogate path has no CPU fallback");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, PSM_ERR_ARG, "device ordinal out of range");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return fail(nullptr, PSM_ERR_HIP, "hipGetDeviceProperties failed");
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    return fail(nullptr, PSM_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+  psm_handle* h = new psm_handle();
+  h->cfg = *cfg;
+  h->S = cfg->block;
+  h->ov = cfg->overlap > 0 ? cfg->overlap : psm_default_overlap(cfg->variant, cfg->block);
+  h->K_in = h->S * h->S * cfg->c_in;
+  h->K_out = h->S * h->S * cfg->c_out;
+  h->ld_in = round_up(cfg->p_in, 32);
+  h->ld_out = round_up(cfg->p_out, 32);
+  h->NT = h->ld_in / 32;
+  h->n_slices = h->S * h->S / PSM_PIX_PER_SLICE;
+  h->Gd = h->ld_out / 8;
+  h->n_coltiles = h->K_out / 32;
+  h->dense.resize(cfg->n_dense);
+  const char* ng = getenv("PSM_NO_GRAPH");
+  h->use_graph = !(ng && ng[0] == '1');
+  if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    return fail(nullptr, PSM_ERR_HIP, "cannot create a stream on the device");
+  }
+  for (int i = 0; i < psm_handle::RING; ++i) (void)hipEventCreateWithFlags(&h->scale_ev[i], hipEventDisableTiming);
+  *out = h;
+  return PSM_OK;
+}
+
+void psm_destroy(psm_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->cfg.device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  (void)hipDeviceSynchronize();
+  free_plan(h);
+  for (auto& d : h->dense) { dev_free(d.W); dev_free(d.b); }
+  dev_free(h->d_mean_in); dev_free(h->d_mean_out); dev_free(h->d_bpack_in); dev_free(h->d_bpack_out);
+  dev_free(h->d_ia); dev_free(h->d_ib); dev_free(h->d_sa); dev_free(h->d_sb);
+  for (int i = 0; i < psm_handle::RING; ++i) {
+    if (h->h_scale[i]) (void)hipHostFree(h->h_scale[i]);
+    if (h->scale_ev[i]) (void)hipEventDestroy(h->scale_ev[i]);
+  }
+  for (auto& p : h->timed_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int psm_set_pca(psm_handle* h, const double* comp_in, const double* mean_in, const double* comp_out, const double* mean_out) {
+  if (!h) return PSM_ERR_ARG;
+  if (!comp_in || !mean_in || !comp_out || !mean_out) return fail(h, PSM_ERR_ARG, "null PCA array");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  destroy_graphs(h);
+  std::vector<float> mi(h->K_in), mo(h->K_out);
+  for (int k = 0; k < h->K_in; ++k) mi[k] = (float)mean_in[k];
+  for (int k = 0; k < h->K_out; ++k) mo[k] = (float)mean_out[k];
+  int rc;
+  if ((rc = dev_upload(h, &h->d_mean_in, mi))) return rc;
+  if ((rc = dev_upload(h, &h->d_mean_out, mo))) return rc;
+  if ((rc = dev_upload(h, &h->d_bpack_in, pack_comp_in(comp_in, h->cfg.p_in, h->K_in, h->cfg.c_in, h->S, h->NT)))) return rc;
+  if ((rc = dev_upload(h, &h->d_bpack_out, pack_comp_out(comp_out, h->cfg.p_out, h->K_out, h->Gd)))) return rc;
+  h->have_pca = true;
+  return PSM_OK;
+}
+
+int psm_set_dense(psm_handle* h, int32_t layer, int32_t n_in, int32_t n_out, const float* kernel, const float* bias) {
+  if (!h) return PSM_ERR_ARG;
+  if (layer < 0 || layer >= (int)h->dense.size()) return fail(h, PSM_ERR_ARG, "layer index out of range");
+  if (!kernel || !bias || n_in < 1 || n_out < 1 || n_in > 4096 || n_out > 4096) return fail(h, PSM_ERR_ARG, "bad dense layer");
+  if (layer == 0 && n_in != h->cfg.p_in) return fail(h, PSM_ERR_ARG, "first layer input width must equal p_in");
+  if (layer == (int)h->dense.size() - 1 && n_out != h->cfg.p_out) return fail(h, PSM_ERR_ARG, "head width must equal p_out");
+  if (layer > 0 && h->dense[layer - 1].set && h->dense[layer - 1].n_out != n_in) return fail(h, PSM_ERR_ARG, "dense layers do not chain");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  destroy_graphs(h);
+  DenseLayer& d = h->dense[layer];
+  d.n_in = n_in; d.n_out = n_out; d.Kpad = round_up(n_in, 32); d.ldw = round_up(n_out, 32);
+  std::vector<float> W((size_t)d.Kpad * d.ldw, 0.f), b(d.ldw, 0.f);
+  for (int k = 0; k < n_in; ++k) memcpy(&W[(size_t)k * d.ldw], kernel + (size_t)k * n_out, n_out * sizeof(float));
+  memcpy(b.data(), bias, n_out * sizeof(float));
+  int rc;
+  if ((rc = dev_upload(h, &d.W, W))) return rc;
+  if ((rc = dev_upload(h, &d.b, b))) return rc;
+  d.set = true;
+  return PSM_OK;
+}
+
+int psm_set_scaler(psm_handle* h, const double* in_a, const double* in_b, const double* out_a, const double* out_b) {
+  if (!h) return PSM_ERR_ARG;
+  if (!in_a || !out_a) return fail(h, PSM_ERR_ARG, "null scaler array");
+  if (h->cfg.scaler != PSM_SCALER_MAX_ABS && (!in_b || !out_b)) return fail(h, PSM_ERR_ARG, "null scaler array");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  std::vector<float> ia(h->ld_in, 0.f), ib(h->ld_in, 0.f), sa(h->ld_out, 0.f), sb(h->ld_out, 0.f);
+  // x_in = coeff*ia + ib ; res' = res*sa + sb  (affine forms of SMD:505-539, evaluated in f64 here)
+  for (int p = 0; p < h->cfg.p_in; ++p) {
+    double a, b;
+    if (h->cfg.scaler == PSM_SCALER_MAX_ABS) { a = 1.0 / in_a[0]; b = 0.0; }
+    else if (h->cfg.scaler == PSM_SCALER_STD) { a = 1.0 / in_b[p]; b = -in_a[p] / in_b[p]; }
+    else { a = 1.0 / (in_b[p] - in_a[p]); b = -in_a[p] / (in_b[p] - in_a[p]); }
+    ia[p] = (float)a; ib[p] = (float)b;
+  }
+  for (int p = 0; p < h->cfg.p_out; ++p) {
+    double a, b;
+    if (h->cfg.scaler == PSM_SCALER_MAX_ABS) { a = out_a[0]; b = 0.0; }
+    else if (h->cfg.scaler == PSM_SCALER_STD) { a = out_b[p]; b = out_a[p]; }
+    else { a = out_b[p] - out_a[p]; b = out_a[p]; }
+    sa[p] = (float)a; sb[p] = (float)b;
+  }
+  int rc;
+  if ((rc = dev_upload(h, &h->d_ia, ia))) return rc;
+  if ((rc = dev_upload(h, &h->d_ib, ib))) return rc;
+  if ((rc = dev_upload(h, &h->d_sa, sa))) return rc;
+  if ((rc = dev_upload(h, &h->d_sb, sb))) return rc;
+  h->have_scaler = true;
+  return PSM_OK;
+}
+
+int psm_plan_grid(psm_handle* h, int32_t ny, int32_t nx) {
+  if (!h) return PSM_ERR_ARG;
+  if (!model_complete(h)) return fail(h, PSM_ERR_STATE, "model incomplete: call psm_set_pca, psm_set_scaler and psm_set_dense for every layer first");
+  for (size_t l = 1; l < h->dense.size(); ++l)
+    if (h->dense[l - 1].n_out != h->dense[l].n_in) return fail(h, PSM_ERR_ARG, "dense layers do not chain");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  free_plan(h);
+  std::string err;
+  int rc = psm_build_plan(h->cfg.variant, ny, nx, h->S, h->ov, h->cfg.strict_degenerate != 0, h->plan, err);
+  if (rc) return fail(h, rc, err);
+  h->Ny = ny; h->Nx = nx; h->B = (int)h->plan.blocks.size();
+  h->Mcap = h->cfg.max_cases * h->B;
+  h->Mpad_cap = round_up(h->Mcap, 32);
+  h->n_strips = (int)h->plan.strips.size();
+  h->max_width = h->ld_in;
+  for (auto& d : h->dense) h->max_width = std::max(h->max_width, d.ldw);
+  const size_t npix = (size_t)ny * nx;
+  if ((rc = dev_alloc(h, &h->d_part, (size_t)h->n_slices * h->Mpad_cap * h->ld_in))) return rc;
+  if ((rc = dev_alloc(h, &h->d_xin, (size_t)h->Mpad_cap * h->ld_in))) return rc;
+  if ((rc = dev_alloc(h, &h->d_act[0], (size_t)h->Mpad_cap * h->max_width))) return rc;
+  if ((rc = dev_alloc(h, &h->d_act[1], (size_t)h->Mpad_cap * h->max_width))) return rc;
+  if ((rc = dev_alloc(h, &h->d_res, (size_t)h->Mpad_cap * h->ld_out))) return rc;
+  if ((rc = dev_alloc(h, &h->d_pred, (size_t)h->Mcap * h->K_out))) return rc;
+  if ((rc = dev_alloc(h, &h->d_row_scale, (size_t)h->Mpad_cap))) return rc;
+  if ((rc = dev_alloc(h, &h->d_sres, (size_t)h->cfg.max_cases * h->cfg.c_out * h->n_strips))) return rc;
+  if ((rc = dev_alloc(h, &h->d_offs, (size_t)h->cfg.max_cases * h->cfg.c_out * h->B))) return rc;
+  if ((rc = dev_alloc(h, &h->d_shift, (size_t)h->cfg.max_cases * h->cfg.c_out))) return rc;
+  if ((rc = dev_alloc(h, &h->d_grid_stage, (size_t)h->cfg.max_cases * npix * h->cfg.c_in))) return rc;
+  if ((rc = dev_alloc(h, &h->d_fields_stage, (size_t)h->cfg.max_cases * npix * h->cfg.c_out))) return rc;
+  HIPCHK(h, hipHostMalloc((void**)&h->h_grid, (size_t)h->cfg.max_cases * npix * h->cfg.c_in * sizeof(float), hipHostMallocDefault));
+  HIPCHK(h, hipHostMalloc((void**)&h->h_fields, (size_t)h->cfg.max_cases * npix * h->cfg.c_out * sizeof(float), hipHostMallocDefault));
+  for (int i = 0; i < psm_handle::RING; ++i) {
+    if (h->h_scale[i]) { (void)hipHostFree(h->h_scale[i]); h->h_scale[i] = nullptr; }
+    HIPCHK(h, hipHostMalloc((void**)&h->h_scale[i], (size_t)h->Mpad_cap * sizeof(float), hipHostMallocDefault));
+  }
+  std::vector<float> ones(h->Mpad_cap, 1.f);
+  if ((rc = dev_upload(h, &h->d_ones, ones))) return rc;
+  std::vector<int64_t> rb(h->Mpad_cap, -1);
+  for (int c = 0; c < h->cfg.max_cases; ++c)
+    for (int b = 0; b < h->B; ++b)
+      rb[(size_t)c * h->B + b] = (((int64_t)c * ny + h->plan.blocks[b].y0) * nx + h->plan.blocks[b].x0) * h->cfg.c_in;
+  if ((rc = dev_upload(h, &h->d_row_base, rb))) return rc;
+  std::vector<int32_t> st6((size_t)h->n_strips * 6), yx((size_t)h->B * 2);
+  for (int e = 0; e < h->n_strips; ++e) {
+    const PsmStrip& s = h->plan.strips[e];
+    int32_t* o = &st6[(size_t)e * 6];
+    o[0] = s.data; o[1] = s.mask; o[2] = s.r0; o[3] = s.r1; o[4] = s.c0; o[5] = s.c1;
+  }
+  for (int b = 0; b < h->B; ++b) { yx[2 * b] = h->plan.blocks[b].y0; yx[2 * b + 1] = h->plan.blocks[b].x0; }
+  if ((rc = dev_upload(h, &h->d_strips, st6))) return rc;
+  if ((rc = dev_upload(h, &h->d_blk, yx))) return rc;
+  if ((rc = dev_upload(h, &h->d_blocks, h->plan.blocks))) return rc;
+  if ((rc = dev_upload(h, &h->d_owner, h->plan.owner))) return rc;
+  h->Lmax = (int)std::max(h->plan.shiftA[0].size(), h->plan.shiftA[1].size());
+  std::vector<int32_t> sA((size_t)2 * h->Lmax, 0), sB((size_t)2 * h->Lmax, 0);
+  for (int f = 0; f < 2; ++f) {
+    std::copy(h->plan.shiftA[f].begin(), h->plan.shiftA[f].end(), sA.begin() + (size_t)f * h->Lmax);
+    std::copy(h->plan.shiftB[f].begin(), h->plan.shiftB[f].end(), sB.begin() + (size_t)f * h->Lmax);
+  }
+  if ((rc = dev_upload(h, &h->d_shiftA, sA))) return rc;
+  if ((rc = dev_upload(h, &h->d_shiftB, sB))) return rc;
+  HIPCHK(h, hipMemset(h->d_part, 0, (size_t)h->n_slices * h->Mpad_cap * h->ld_in * sizeof(float)));
+  HIPCHK(h, hipMemset(h->d_act[0], 0, (size_t)h->Mpad_cap * h->max_width * sizeof(float)));
+  HIPCHK(h, hipMemset(h->d_act[1], 0, (size_t)h->Mpad_cap * h->max_width * sizeof(float)));
+  HIPCHK(h, hipDeviceSynchronize());
+  h->planned = true;
+  return PSM_OK;
+}
+
+int psm_num_blocks(const psm_handle* h) { return (h && h->planned) ? h->B : PSM_ERR_STATE; }
+
+int psm_solve_grid_device(psm_handle* h, const float* d_grid, int32_t n_cases, const float* out_scale,
+                          float* d_fields, void* stream) {
+  return solve_device(h, d_grid, n_cases, out_scale, d_fields, (hipStream_t)stream, nullptr);
+}
+
+int psm_solve_grid(psm_handle* h, const float* grid, int32_t n_cases, const float* out_scale, float* fields) {
+  if (!h) return PSM_ERR_ARG;
+  if (!h->planned) return fail(h, PSM_ERR_STATE, "psm_plan_grid has not been called");
+  if (!grid || !fields) return fail(h, PSM_ERR_ARG, "null buffer");
+  if (n_cases < 1 || n_cases > h->cfg.max_cases) return fail(h, PSM_ERR_ARG, "n_cases outside [1, max_cases]");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  const size_t npix = (size_t)h->Ny * h->Nx;
+  const size_t gin = (size_t)n_cases * npix * h->cfg.c_in * sizeof(float);
+  const size_t gout = (size_t)n_cases * npix * h->cfg.c_out * sizeof(float);
+  memcpy(h->h_grid, grid, gin);
+  HIPCHK(h, hipMemcpyAsync(h->d_grid_stage, h->h_grid, gin, hipMemcpyHostToDevice, h->stream));
+  int rc = solve_device(h, h->d_grid_stage, n_cases, out_scale, h->d_fields_stage, h->stream, nullptr);
+  if (rc) return rc;
+  HIPCHK(h, hipMemcpyAsync(h->h_fields, h->d_fields_stage, gout, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  memcpy(fields, h->h_fields, gout);
+  return PSM_OK;
+}
+
+int psm_reassemble(psm_handle* h, const float* grid, const float* block_pred, float* fields) {
+  if (!h) return PSM_ERR_ARG;
+  if (!h->planned) return fail(h, PSM_ERR_STATE, "psm_plan_grid has not been called");
+  if (!grid || !block_pred || !fields) return fail(h, PSM_ERR_ARG, "null buffer");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  hipStream_t st = h->stream;
+  const size_t npix = (size_t)h->Ny * h->Nx;
+  HIPCHK(h, hipMemcpyAsync(h->d_grid_stage, grid, npix * h->cfg.c_in * sizeof(float), hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpyAsync(h->d_pred, block_pred, (size_t)h->B * h->K_out * sizeof(float), hipMemcpyHostToDevice, st));
+  PsmStripArgs sa{};
+  sa.pred = h->d_pred; sa.grid = h->d_grid_stage; sa.strips = h->d_strips; sa.blk_y0x0 = h->d_blk; sa.sres = h->d_sres;
+  sa.n_strips = h->n_strips; sa.B = h->B; sa.S = h->S; sa.c_in = h->cfg.c_in; sa.c_out = h->cfg.c_out;
+  sa.sdf_ch = h->cfg.sdf_channel; sa.Ny = h->Ny; sa.Nx = h->Nx;
+  HIPCHK(h, psm_launch_strips(sa, 1, st));
+  PsmChainArgs ca{};
+  ca.cp = h->plan.cp; ca.blocks = h->d_blocks; ca.sres = h->d_sres; ca.pred = h->d_pred; ca.owner = h->d_owner;
+  ca.shiftA = h->d_shiftA; ca.shiftB = h->d_shiftB;
+  for (int f = 0; f < 2; ++f) ca.shiftL[f] = (int)h->plan.shiftA[f].size();
+  ca.Lmax = h->Lmax; ca.offs = h->d_offs; ca.shift = h->d_shift; ca.n_strips = h->n_strips; ca.c_out = h->cfg.c_out;
+  HIPCHK(h, psm_launch_chain(ca, 1, st));
+  PsmPasteArgs pa{h->d_pred, h->d_owner, h->d_offs, h->d_shift, h->d_fields_stage, h->B, h->S, h->cfg.c_out, h->Ny * h->Nx};
+  HIPCHK(h, psm_launch_paste(pa, 1, st));
+  HIPCHK(h, hipMemcpyAsync(fields, h->d_fields_stage, npix * h->cfg.c_out * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  h->last_cases = 1;
+  return PSM_OK;
+}
+
+int psm_synchronize(psm_handle* h) {
+  if (!h) return PSM_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipDeviceSynchronize());
+  return PSM_OK;
+}
+
+int psm_read_stage(psm_handle* h, int32_t stage, float* dst, size_t dst_floats) {
+  if (!h || !dst) return PSM_ERR_ARG;
+  if (!h->planned || h->last_cases < 1) return fail(h, PSM_ERR_STATE, "no solve has run yet");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipDeviceSynchronize());
+  const int M = h->last_cases * h->B;
+  auto rows = [&](const float* src, int ld, int width) -> int {
+    if (dst_floats < (size_t)M * width) return fail(h, PSM_ERR_ARG, "destination too small");
+    HIPCHK(h, hipMemcpy2D(dst, (size_t)width * sizeof(float), src, (size_t)ld * sizeof(float), (size_t)width * sizeof(float), M, hipMemcpyDeviceToHost));
+    return PSM_OK;
+  };
+  switch (stage) {
+    case PSM_STAGE_X_INPUT: return rows(h->d_xin, h->ld_in, h->cfg.p_in);
+    case PSM_STAGE_RES: return rows(h->d_res, h->ld_out, h->cfg.p_out);
+    case PSM_STAGE_BLOCK_PRED: return rows(h->d_pred, h->K_out, h->K_out);
+    case PSM_STAGE_OFFSETS: {
+      const size_t n = (size_t)h->last_cases * h->cfg.c_out * h->B;
+      if (dst_floats < n) return fail(h, PSM_ERR_ARG, "destination too small");
+      HIPCHK(h, hipMemcpy(dst, h->d_offs, n * sizeof(float), hipMemcpyDeviceToHost));
+      return PSM_OK;
+    }
+    case PSM_STAGE_SHIFT: {
+      const size_t n = (size_t)h->last_cases * h->cfg.c_out;
+      if (dst_floats < n) return fail(h, PSM_ERR_ARG, "destination too small");
+      HIPCHK(h, hipMemcpy(dst, h->d_shift, n * sizeof(float), hipMemcpyDeviceToHost));
+      return PSM_OK;
+    }
+  }
+  return fail(h, PSM_ERR_ARG, "unknown stage");
+}
+
+int psm_profile_solve(psm_handle* h, const float* d_grid, int32_t n_cases, float* d_fields, float* ms) {
+  if (!h || !ms) return PSM_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  hipEvent_t ev[PSM_K_COUNT + 1];
+  for (auto& e : ev) HIPCHK(h, hipEventCreate(&e));
+  int rc = solve_device(h, d_grid, n_cases, nullptr, d_fields, h->stream, ev);
+  if (rc == PSM_OK) {
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) rc = fail(h, PSM_ERR_HIP, hipGetErrorString(e));
+  }
+  if (rc == PSM_OK)
+    for (int k = 0; k < PSM_K_COUNT; ++k) {
+      float t = 0.f;
+      (void)hipEventElapsedTime(&t, ev[k], ev[k + 1]);
+      ms[k] = t;
+    }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return rc;
+}
+
+int psm_enable_kernel_timing(psm_handle* h, int32_t kernel, int32_t on) {
+  if (!h) return PSM_ERR_ARG;
+  if (kernel < 0 || kernel >= PSM_K_COUNT) return fail(h, PSM_ERR_ARG, "unknown kernel group");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipDeviceSynchronize());
+  for (auto& p : h->timed_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+  h->timed_events.clear();
+  h->timed_total_ms = 0.0; h->timed_launches = 0;
+  h->timed_kernel = on ? kernel : -1;
+  return PSM_OK;
+}
+
+int psm_get_kernel_timing(psm_handle* h, int32_t kernel, double* total_ms, int64_t* launches) {
+  if (!h || !total_ms || !launches) return PSM_ERR_ARG;
+  if (kernel != h->timed_kernel) return fail(h, PSM_ERR_STATE, "timing is not enabled for this kernel group");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipDeviceSynchronize());
+  for (auto& p : h->timed_events) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, p.first, p.second) == hipSuccess) { h->timed_total_ms += t; h->timed_launches += 1; }
+    (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second);
+  }
+  h->timed_events.clear();
+  *total_ms = h->timed_total_ms; *launches = h->timed_launches;
+  return PSM_OK;
+}
+
+// ---- host-only helpers -------------------------------------------------------
+int psm_layout(int32_t variant, int32_t ny, int32_t nx, int32_t block, int32_t overlap, int32_t* blocks, int32_t cap,
+               int32_t* n_x, int32_t* n_y) {
+  std::vector<PsmBlock> b;
+  std::string err;
+  int nx_ = 0, ny_ = 0;
+  int rc = psm_build_layout(variant, ny, nx, block, overlap, b, nx_, ny_, err);
+  if (rc) return fail(nullptr, rc, err);
+  if (n_x) *n_x = nx_;
+  if (n_y) *n_y = ny_;
+  if (blocks)
+    for (int i = 0; i < (int)b.size() && i < cap; ++i) {
+      blocks[4 * i] = b[i].y0; blocks[4 * i + 1] = b[i].x0; blocks[4 * i + 2] = b[i].ti; blocks[4 * i + 3] = b[i].tj;
+    }
+  return (int)b.size();
+}
+
+int psm_owner_map(int32_t variant, int32_t ny, int32_t nx, int32_t block, int32_t overlap, int32_t strict, int32_t* owner) {
+  if (!owner) return fail(nullptr, PSM_ERR_ARG, "null owner buffer");
+  PsmPlan plan;
+  std::string err;
+  int rc = psm_build_plan(variant, ny, nx, block, overlap, strict != 0, plan, err);
+  if (rc) return fail(nullptr, rc, err);
+  memcpy(owner, plan.owner.data(), plan.owner.size() * sizeof(int32_t));
+  return PSM_OK;
+}
+
+
+// Host replay of the device reassembly (strip table -> chain -> owner-map paste) on
+// caller-supplied decoded blocks.  Verification helper for the plan tables and the
+// chain logic only: nothing in psm_solve_* calls it.
+namespace {
+struct HostStripView {
+  const float* sum; const float* cnt;
+  float mean(int s) const { return sum[s] / cnt[s]; }
+  float count(int s) const { return cnt[s]; }
+};
+}  // namespace
+
+int psm_debug_reassemble_host(int32_t variant, int32_t ny, int32_t nx, int32_t block, int32_t overlap, int32_t strict,
+                              int32_t c_in, int32_t c_out, int32_t sdf_ch, const float* grid, const float* pred,
+                              float* fields, float* offsets, float* shifts) {
+  if (!grid || !pred || !fields) return fail(nullptr, PSM_ERR_ARG, "null buffer");
+  PsmPlan plan;
+  std::string err;
+  int rc = psm_build_plan(variant, ny, nx, block, overlap, strict != 0, plan, err);
+  if (rc) return fail(nullptr, rc, err);
+  const int S = block, SS = S * S, B = plan.cp.B, NSTR = (int)plan.strips.size();
+  std::vector<float> sum(NSTR), cnt(NSTR), offs(B), up(PSM_MAX_COLS);
+  for (int f = 0; f < c_out; ++f) {
+    for (int e = 0; e < NSTR; ++e) {
+      const PsmStrip& st = plan.strips[e];
+      float s = 0.f, c = 0.f;
+      for (int r = st.r0; r < st.r1; ++r)
+        for (int cc = st.c0; cc < st.c1; ++cc) {
+          bool on = true;
+          if (st.mask >= 0) {
+            const PsmBlock& mb = plan.blocks[st.mask];
+            on = grid[((size_t)(mb.y0 + r) * nx + mb.x0 + cc) * c_in + sdf_ch] != 0.f;
+          }
+          if (on) { s += pred[((size_t)st.data * SS + r * S + cc) * c_out + f]; c += 1.f; }
+        }
+      sum[e] = s; cnt[e] = c;
+    }
+    HostStripView sv{sum.data(), cnt.data()};
+    psm_chain<float>(plan.cp, plan.blocks.data(), sv, f, up.data(), offs.data());
+    double acc = 0.0;
+    const size_t L = plan.shiftA[f].size();
+    for (size_t k = 0; k < L; ++k) {
+      const int oa = plan.owner[plan.shiftA[f][k]], ob = plan.owner[plan.shiftB[f][k]];
+      const float va = oa >= 0 ? pred[(size_t)oa * c_out + f] - offs[oa / SS] : 0.f;
+      const float vb = ob >= 0 ? pred[(size_t)ob * c_out + f] - offs[ob / SS] : 0.f;
+      acc += 3.0 * va - vb;
+    }
+    const float shift = (float)(acc / (double)L / 3.0);
+    for (size_t pix = 0; pix < (size_t)ny * nx; ++pix) {
+      const int o = plan.owner[pix];
+      fields[pix * c_out + f] = o >= 0 ? pred[(size_t)o * c_out + f] - offs[o / SS] - shift : 0.f;
+    }
+    if (offsets) memcpy(offsets + (size_t)f * B, offs.data(), B * sizeof(float));
+    if (shifts) shifts[f] = shift;
+  }
+  return PSM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,81 @@
+// psm_kernels.h -- launchers of the HIP kernels of one surrogate solve (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "psm_plan.h"
+
+// Tiling constants shared by the host packers and the kernels -----------------
+constexpr int PSM_PIX_PER_SLICE = 64;  // pixels of one block row handled by an encode workgroup
+constexpr int PSM_MT_CHUNK = 4;        // 32-row M tiles staged in LDS at once
+
+struct PsmEncodeArgs {
+  const float* grid;       // [cases, Ny, Nx, C_in]
+  const float* mean;       // [K_in]
+  const float4* bpack;     // [slices][NT][G][64] float4 (see pack_comp_in)
+  float* part;             // [slices][Mpad][ldp]
+  const int64_t* row_base; // [Mpad] float offset of each block's origin in grid, -1 = padding row
+  int64_t row_stride;      // Nx*C_in floats
+  int M, Mpad, NT, ldp, S, c_in, aligned;
+};
+
+struct PsmReduceArgs {
+  const float* part; float* xin;       // xin [Mpad][ldp]
+  const float* ia; const float* ib;    // affine input scaler per column (0 on padding)
+  int n_slices, Mpad, ldp;
+};
+
+struct PsmDenseArgs {
+  const float* in; int ld_in;          // [Mpad][ld_in]
+  const float* W; int ld_w;            // [Kpad][ld_w] zero padded
+  const float* bias;                   // [ld_w]
+  const float* sa; const float* sb;    // head only: out = (acc+bias)*sa + sb
+  float* out; int ld_out;              // [Mpad][ld_out]
+  int Kpad, Mpad, relu, head;
+};
+
+struct PsmDecodeArgs {
+  const float* res; int ld_res;        // [Mpad][ld_res] inverse-scaled network output
+  const float4* bpack;                 // [ncoltiles][Gd][64] float4
+  const float* mean;                   // [K_out]
+  const float* row_scale;              // [Mpad] out_scale per block row
+  float* pred;                         // [M][K_out]
+  int M, Mpad, Gd, n_coltiles, K_out;
+};
+
+struct PsmStripArgs {
+  const float* pred;                   // [cases*B][S*S*c_out]
+  const float* grid;                   // [cases][Ny][Nx][c_in]
+  const int32_t* strips;               // [n_strips][6]
+  const int32_t* blk_y0x0;             // [B][2]
+  float2* sres;                        // [cases][c_out][n_strips] (sum, count)
+  int n_strips, B, S, c_in, c_out, sdf_ch, Ny, Nx;
+};
+
+struct PsmChainArgs {
+  PsmChainParams cp;
+  const PsmBlock* blocks;              // [B]
+  const float2* sres;
+  const float* pred;
+  const int32_t* owner;                // [Ny*Nx]
+  const int32_t* shiftA; const int32_t* shiftB;   // [c_out][Lmax]
+  int shiftL[2]; int Lmax;
+  float* offs;                         // [cases][c_out][B]
+  float* shift;                        // [cases][c_out]
+  int n_strips, c_out;
+};
+
+struct PsmPasteArgs {
+  const float* pred; const int32_t* owner; const float* offs; const float* shift;
+  float* fields;                       // [cases][Ny][Nx][c_out]
+  int B, S, c_out, npix;
+};
+
+hipError_t psm_launch_encode(const PsmEncodeArgs& a, hipStream_t s);
+hipError_t psm_launch_reduce(const PsmReduceArgs& a, hipStream_t s);
+hipError_t psm_launch_dense(const PsmDenseArgs& a, hipStream_t s);
+hipError_t psm_launch_decode(const PsmDecodeArgs& a, hipStream_t s);
+hipError_t psm_launch_strips(const PsmStripArgs& a, int n_cases, hipStream_t s);
+hipError_t psm_launch_chain(const PsmChainArgs& a, int n_cases, hipStream_t s);
+hipError_t psm_launch_paste(const PsmPasteArgs& a, int n_cases, hipStream_t s);

@@ -1,0 +1,311 @@
+"""Host-side mirror of the reference's surrogate interface on top of the C-ABI.
+
+``GridSurrogate`` owns one ``psm_handle`` (include/psm.h).  The two
+``Evaluation*`` classes keep the names, argument order and meaning of the
+reference operators for the part of the path that is built so far
+(SURVEY.md §8 a7-a12):
+
+* ``pressureSM_deltas.SM_call.Evaluation`` -- ``assemble_prediction`` (SM_call.py:182)
+  and the grid-native body of ``timeStep`` (SM_call.py:452-575),
+* ``U_to_gradP`` ``Evaluation`` -- ``assemble_prediction`` (Eval_dual_Dense_onlycil.py:255)
+  and the grid-native body of ``timeStep`` (:470-547),
+* the Chapter-5 solver module -- the grid-native body of ``py_func``
+  (python_module.py:299-473) as ``SolverModule.py_func_grid``.
+
+Everything numeric runs in the HIP library; NumPy is only used to hand buffers
+over.  Error behaviour follows the reference where it has one (``ValueError(
+"Standardization method not valid")``, SM_call.py:525), otherwise ``PsmError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .synthetic import SurrogateModel
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class GridSurrogate:
+    """One surrogate model bound to one uniform grid shape on one GPU."""
+
+    def __init__(self, model: SurrogateModel, ny: int, nx: int, max_cases: int = 1, device: int = 0,
+                 strict_degenerate: bool = False):
+        if model.scaler_kind not in _lib.SCALERS:
+            raise ValueError("Standardization method not valid")
+        self.lib = _lib.load()
+        self.model, self.ny, self.nx, self.max_cases = model, int(ny), int(nx), int(max_cases)
+        cfg = _lib.psm_config(
+            abi_version=_lib.PSM_ABI_VERSION, variant=_lib.VARIANTS[model.variant], block=model.S,
+            overlap=0 if model.ov is None else int(model.ov), c_in=model.c_in, c_out=model.c_out,
+            p_in=model.p_in, p_out=model.p_out, n_dense=len(model.weights), scaler=_lib.SCALERS[model.scaler_kind],
+            sdf_channel=model.sdf_ch, device=device, max_cases=max_cases, strict_degenerate=int(strict_degenerate))
+        h = C.c_void_p()
+        _lib.check(self.lib.psm_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        try:
+            ci, mi, co, mo = _f64(model.comp_in), _f64(model.mean_in), _f64(model.comp_out), _f64(model.mean_out)
+            if ci.shape != (model.p_in, model.S ** 2 * model.c_in) or co.shape != (model.p_out, model.S ** 2 * model.c_out):
+                raise ValueError("PCA component matrices have the wrong shape")
+            self._chk(self.lib.psm_set_pca(h, _p(ci, C.c_double), _p(mi, C.c_double), _p(co, C.c_double), _p(mo, C.c_double)))
+            for l, (W, b) in enumerate(model.weights):
+                W, b = _f32(W), _f32(b)
+                self._chk(self.lib.psm_set_dense(h, l, W.shape[0], W.shape[1], _p(W, C.c_float), _p(b, C.c_float)))
+            ia = _f64(np.broadcast_to(model.in_a, (model.p_in,)))
+            ib = _f64(np.broadcast_to(model.in_b, (model.p_in,)))
+            oa = _f64(np.broadcast_to(model.out_a, (model.p_out,)))
+            ob = _f64(np.broadcast_to(model.out_b, (model.p_out,)))
+            self._chk(self.lib.psm_set_scaler(h, _p(ia, C.c_double), _p(ib, C.c_double), _p(oa, C.c_double), _p(ob, C.c_double)))
+            self._chk(self.lib.psm_plan_grid(h, self.ny, self.nx))
+            self.B = self.lib.psm_num_blocks(h)
+        except Exception:
+            self.close()
+            raise
+
+    # -- plumbing
+    def _chk(self, rc):
+        return _lib.check(rc, self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.psm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- solves
+    def solve(self, grid: np.ndarray, out_scale: Optional[Sequence[float]] = None) -> np.ndarray:
+        """grid [Ny,Nx,>=c_in] or [n,Ny,Nx,>=c_in] (normalised, PM:288-297) -> fields [n,Ny,Nx,c_out] f32."""
+        g = np.asarray(grid)
+        if g.ndim == 3:
+            g = g[None]
+        if g.ndim != 4 or g.shape[1:3] != (self.ny, self.nx) or g.shape[3] < self.model.c_in:
+            raise ValueError(f"grid must be [n,{self.ny},{self.nx},>={self.model.c_in}]")
+        g = _f32(g[..., :self.model.c_in])
+        n = g.shape[0]
+        out = np.empty((n, self.ny, self.nx, self.model.c_out), np.float32)
+        sc = None
+        if out_scale is not None:
+            sc = _f32(np.broadcast_to(out_scale, (n,)))
+        self._chk(self.lib.psm_solve_grid(self.h, _p(g, C.c_float), n, _p(sc, C.c_float) if sc is not None else None,
+                                          _p(out, C.c_float)))
+        return out
+
+    def solve_device(self, d_grid: int, n_cases: int, d_fields: int, stream: int = 0,
+                     out_scale: Optional[Sequence[float]] = None):
+        """Asynchronous solve on raw device pointers (e.g. ``torch.Tensor.data_ptr()``)."""
+        sc = None
+        if out_scale is not None:
+            sc = _f32(np.broadcast_to(out_scale, (n_cases,)))
+        self._chk(self.lib.psm_solve_grid_device(self.h, C.c_void_p(d_grid), n_cases,
+                                                 _p(sc, C.c_float) if sc is not None else None,
+                                                 C.c_void_p(d_fields), C.c_void_p(stream)))
+
+    def synchronize(self):
+        self._chk(self.lib.psm_synchronize(self.h))
+
+    def reassemble(self, grid: np.ndarray, block_pred: np.ndarray) -> np.ndarray:
+        """Reassembly alone: block_pred [B,S,S,c_out] (or [B,S,S] when c_out==1) -> [Ny,Nx,c_out]."""
+        g = _f32(np.asarray(grid)[..., :self.model.c_in])
+        bp = _f32(np.asarray(block_pred).reshape(self.B, -1))
+        if bp.shape[1] != self.model.S ** 2 * self.model.c_out:
+            raise ValueError("block_pred has the wrong shape")
+        out = np.empty((self.ny, self.nx, self.model.c_out), np.float32)
+        self._chk(self.lib.psm_reassemble(self.h, _p(g, C.c_float), _p(bp, C.c_float), _p(out, C.c_float)))
+        return out
+
+    # -- introspection
+    def stage(self, name: str, n_cases: int = 1) -> np.ndarray:
+        m = self.model
+        rows = n_cases * self.B
+        shape = {"x_input": (rows, m.p_in), "res": (rows, m.p_out), "block_pred": (rows, m.S, m.S, m.c_out),
+                 "offsets": (n_cases, m.c_out, self.B), "shift": (n_cases, m.c_out)}[name]
+        out = np.empty(shape, np.float32)
+        self._chk(self.lib.psm_read_stage(self.h, _lib.STAGES[name], _p(out, C.c_float), out.size))
+        return out
+
+    def profile(self, d_grid: int, n_cases: int, d_fields: int) -> dict:
+        ms = (C.c_float * len(_lib.KERNELS))()
+        self._chk(self.lib.psm_profile_solve(self.h, C.c_void_p(d_grid), n_cases, C.c_void_p(d_fields), ms))
+        return dict(zip(_lib.KERNELS, [float(v) for v in ms]))
+
+    def enable_kernel_timing(self, kernel: str, on: bool = True):
+        self._chk(self.lib.psm_enable_kernel_timing(self.h, _lib.KERNELS.index(kernel), int(on)))
+
+    def kernel_timing(self, kernel: str):
+        t, n = C.c_double(), C.c_int64()
+        self._chk(self.lib.psm_get_kernel_timing(self.h, _lib.KERNELS.index(kernel), C.byref(t), C.byref(n)))
+        return t.value, n.value
+
+
+# ---------------------------------------------------------------------------
+# host-only helpers (no GPU): layout / owner map / host replay of the reassembly
+# ---------------------------------------------------------------------------
+def layout(variant: str, ny: int, nx: int, S: int = 128, ov: int = 0):
+    """-> (blocks[B,4] = (y0, x0, idx_i, idx_j), n_x, n_y) as enumerated at
+    PM:306-329 / SMD:461-479 / UGP:479-500."""
+    lib = _lib.load()
+    nxv, nyv = C.c_int32(), C.c_int32()
+    n = lib.psm_layout(_lib.VARIANTS[variant], ny, nx, S, ov, None, 0, C.byref(nxv), C.byref(nyv))
+    if n < 0:
+        raise _lib.PsmError(n, _lib.last_error())
+    blocks = np.zeros((n, 4), np.int32)
+    lib.psm_layout(_lib.VARIANTS[variant], ny, nx, S, ov, _p(blocks, C.c_int32), n, None, None)
+    return blocks, nxv.value, nyv.value
+
+
+def owner_map(variant: str, ny: int, nx: int, S: int = 128, ov: int = 0, strict: bool = False) -> np.ndarray:
+    out = np.empty((ny, nx), np.int32)
+    _lib.check(_lib.load().psm_owner_map(_lib.VARIANTS[variant], ny, nx, S, ov, int(strict), _p(out, C.c_int32)))
+    return out
+
+
+def debug_reassemble_host(variant: str, grid: np.ndarray, block_pred: np.ndarray, c_out: int, S: int = 128,
+                          ov: int = 0, strict: bool = False, sdf_ch: int = 2):
+    """Host replay of the device reassembly tables (verification helper)."""
+    g = _f32(grid)
+    ny, nx, c_in = g.shape
+    B = block_pred.shape[0]
+    bp = _f32(np.asarray(block_pred).reshape(B, -1))
+    fields = np.empty((ny, nx, c_out), np.float32)
+    offs = np.empty((c_out, B), np.float32)
+    sh = np.empty((c_out,), np.float32)
+    _lib.check(_lib.load().psm_debug_reassemble_host(
+        _lib.VARIANTS[variant], ny, nx, S, ov, int(strict), c_in, c_out, sdf_ch, _p(g, C.c_float), _p(bp, C.c_float),
+        _p(fields, C.c_float), _p(offs, C.c_float), _p(sh, C.c_float)))
+    return fields, offs, sh
+
+
+# ---------------------------------------------------------------------------
+# reference-shaped operators
+# ---------------------------------------------------------------------------
+def _grid_from_blocks(x_array: np.ndarray, blocks: np.ndarray, ny: int, nx: int) -> np.ndarray:
+    """Rebuild the grid image from the overlapping input blocks (the reference keeps
+    only ``self.x_array`` around when it calls ``assemble_prediction``)."""
+    S = x_array.shape[1]
+    g = np.zeros((ny, nx, x_array.shape[3]), np.float32)
+    for b, (y0, x0, _, _) in enumerate(blocks):
+        g[y0:y0 + S, x0:x0 + S] = x_array[b]
+    return g
+
+
+class Evaluation:
+    """``pressureSM_deltas.SM_call.Evaluation`` (SM_call.py:26-87) on the GPU path.
+
+    ``model`` carries the artefacts the reference loads from the working
+    directory (``maxs``, the Keras model, ``ipca_*.pkl``, ``mean_std.npz``)."""
+    variant = "deltas"
+
+    def __init__(self, delta, shape, overlap, var_p, var_in, dataset_path, model_path, max_num_PC,
+                 standardization_method, model: SurrogateModel = None, device: int = 0):
+        if standardization_method not in ("std", "min_max", "max_abs"):
+            raise ValueError("Standardization method not valid")
+        if model is None:
+            raise NotImplementedError("loading artefacts from dataset_path/model_path is not built yet: pass model=")
+        self.delta, self.shape, self.overlap = delta, shape, overlap
+        self.var_p, self.var_in, self.dataset_path, self.max_num_PC = var_p, var_in, dataset_path, max_num_PC
+        self.standardization_method = standardization_method
+        self.artifacts = model
+        self.pc_in, self.pc_p = model.p_in, model.p_out
+        self.device = device
+        self.Ref_BC = 0
+        self._sur = None
+        self.x_array = None
+
+    def _surrogate(self, ny, nx):
+        if self._sur is None or (self._sur.ny, self._sur.nx) != (ny, nx):
+            if self._sur is not None:
+                self._sur.close()
+            self._sur = GridSurrogate(self.artifacts, ny, nx, 1, self.device)
+        return self._sur
+
+    def timeStep_grid(self, grid: np.ndarray, U_max_norm: float = 1.0, max_abs_p: float = 1.0) -> np.ndarray:
+        """Grid-native body of ``timeStep`` (SM_call.py:452-575): -> deltap_res [Ny,Nx]."""
+        sur = self._surrogate(grid.shape[0], grid.shape[1])
+        return sur.solve(grid, out_scale=[max_abs_p * U_max_norm ** 2])[0, :, :, 0]
+
+    def assemble_prediction(self, array, indices_list, n_x, n_y, apply_filter, shape_x, shape_y,
+                            deltaU_change_grid=None, deltaP_prev_grid=None, apply_deltaU_change_wgt=False):
+        """SM_call.py:182: ``array`` [B,S,S] corrected and pasted into [shape_y, shape_x].
+        The flow mask comes from ``self.x_array`` like in the reference."""
+        if apply_filter or apply_deltaU_change_wgt:
+            raise NotImplementedError("Gaussian filter / deltaU-change weighting are not built yet (SURVEY §8 a13)")
+        if self.x_array is None:
+            raise ValueError("self.x_array must hold the input blocks")
+        blocks, nx_, ny_ = layout(self.variant, shape_y, shape_x, self.shape, self.overlap)
+        if (nx_, ny_) != (n_x, n_y) or len(indices_list) != len(blocks):
+            raise ValueError("n_x / n_y / indices_list do not match this grid")
+        sur = self._surrogate(shape_y, shape_x)
+        grid = _grid_from_blocks(np.asarray(self.x_array, np.float32), blocks, shape_y, shape_x)
+        return sur.reassemble(grid, np.asarray(array))[..., 0], None
+
+
+class EvaluationGradP(Evaluation):
+    """``U_to_gradP`` ``Evaluation`` (Eval_dual_Dense_onlycil.py:30-66)."""
+    variant = "gradp"
+
+    def __init__(self, delta, shape, avance, var_p, var_in, hdf5_path, model_path, max_number_PC,
+                 model: SurrogateModel = None, device: int = 0):
+        super().__init__(delta, shape, avance, var_p, var_in, hdf5_path, model_path, max_number_PC,
+                         model.scaler_kind if model is not None else "max_abs", model, device)
+        self.avance = avance
+
+    def timeStep_grid(self, grid: np.ndarray) -> np.ndarray:
+        """Eval_dual_Dense_onlycil.py:470-547: -> [Ny,Nx,2] = (res_dPdx, res_dPdy)."""
+        return self._surrogate(grid.shape[0], grid.shape[1]).solve(grid)[0]
+
+    def assemble_prediction(self, field, array, indices_list, n_x, n_y, apply_filter, shape_x, shape_y):
+        """Eval_dual_Dense_onlycil.py:255: one channel ('dp_dx' | 'dp_dy') of decoded blocks."""
+        if field not in ("dp_dx", "dp_dy"):
+            raise ValueError(field)
+        if apply_filter:
+            raise NotImplementedError("Gaussian filter is not built yet (SURVEY §8 a13)")
+        blocks, nx_, ny_ = layout(self.variant, shape_y, shape_x, self.shape, self.avance)
+        if (nx_, ny_) != (n_x, n_y) or len(indices_list) != len(blocks):
+            raise ValueError("n_x / n_y / indices_list do not match this grid")
+        sur = self._surrogate(shape_y, shape_x)
+        grid = _grid_from_blocks(np.asarray(self.x_array, np.float32), blocks, shape_y, shape_x)
+        a = np.asarray(array, np.float32)
+        both = np.zeros(a.shape + (2,), np.float32)
+        ch = 0 if field == "dp_dx" else 1
+        both[..., ch] = a
+        return sur.reassemble(grid, both)[None, :, :, ch:ch + 1]
+
+
+class SolverModule:
+    """Chapter-5 ``python_module`` (python_module.py) -- grid-native body of
+    ``py_func`` (:299-473).  The mesh<->grid ends (init_func, interpolation,
+    near-wall fallback) are SURVEY §8 f.1 and not built yet."""
+
+    def __init__(self, model: SurrogateModel, device: int = 0):
+        self.model, self.device, self._sur = model, device, None
+
+    def py_func_grid(self, grid: np.ndarray) -> np.ndarray:
+        if self._sur is None or (self._sur.ny, self._sur.nx) != grid.shape[:2]:
+            if self._sur is not None:
+                self._sur.close()
+            self._sur = GridSurrogate(self.model, grid.shape[0], grid.shape[1], 1, self.device)
+        return self._sur.solve(grid)[0, :, :, 0]
