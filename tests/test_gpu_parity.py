@@ -176,10 +176,13 @@ def test_device_pointer_api_graph_and_eager_agree():
 
 
 def test_reassembly_properties_full_size():
-    """Size-independent properties of a12 at the BASELINE grid sizes:
-    (i) per-block constants are absorbed by the offsets (field unchanged),
-    (ii) a global field cut into blocks comes back up to one constant (the
-         reference's own self-check, UGP:546-547 / SMD:577-580)."""
+    """a12 at the BASELINE grid sizes (incl. the shipped 400x3000 case, 104 blocks):
+    (i)   per-block constants are absorbed by the offsets (field unchanged),
+    (ii)  the device result equals the oracle's reassembly of the same blocks,
+    (iii) a global field cut into blocks comes back up to one constant (the reference's
+          own self-check, UGP:546-547 / SMD:577-580) -- exact for gradp without an
+          obstacle; elsewhere the reference compares strips of different cells
+          (SMD:292 vs SMD:283, masks of SMD:235) and is only "almost perfect"."""
     rng = np.random.default_rng(0)
     for variant, ny, nx in (("gradp", 256, 256), ("deltas", 256, 256), ("deltas", 512, 512), ("chapter5", 400, 3000)):
         model = synthetic.make_model(variant, p_in=8, p_out=8)
@@ -188,15 +191,24 @@ def test_reassembly_properties_full_size():
         yy, xx = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
         truth = np.stack([np.sin(xx / 50.0 + c) + np.cos(yy / 31.0) for c in range(c_out)], -1)
         lay = orc.block_layout(variant, ny, nx)
-        bp = orc.extract_blocks(truth, lay, c_out)
+        bp = orc.extract_blocks(truth, lay, c_out).astype(np.float32)
+        open_grid = synthetic.channel_grid(ny, nx, seed=8, obstacle="none").astype(np.float32)
         with GridSurrogate(model, ny, nx) as sur:
             f0 = sur.reassemble(grid, bp)
-            f1 = sur.reassemble(grid, bp + rng.standard_normal((lay.B, 1, 1, c_out)))
+            f1 = sur.reassemble(grid, bp + rng.standard_normal((lay.B, 1, 1, c_out)).astype(np.float32))
+            f2 = sur.reassemble(open_grid, bp)
         assert np.abs(f0 - f1).max() <= 2e-4
-        flow = grid[..., 2] != 0
+        xb = orc.extract_blocks(grid.astype(np.float64), lay, 3)
         for c in range(c_out):
-            d = (f0[..., c] - truth[..., c])[flow]
-            assert d.max() - d.min() <= 2e-4
+            if variant == "gradp":
+                ref = orc.assemble_gradp(("dp_dx", "dp_dy")[c], bp[..., c], xb, lay).field
+                d = f2[..., c] - truth[..., c]
+                assert d.max() - d.min() <= 2e-4
+            elif variant == "deltas":
+                ref = orc.assemble_deltas(bp[..., c], xb, lay).field
+            else:
+                ref = orc.assemble_chapter5(bp[..., c], xb, lay).field
+            assert np.abs(f0[..., c] - ref).max() <= 2e-4
 
 
 def test_reference_shaped_assemble_prediction():
