@@ -1,0 +1,18 @@
+import numpy as np, sys, ctypes as C
+sys.path.insert(0,'.')
+import psm_amd
+from psm_amd import synthetic, _lib
+import torch
+model = synthetic.make_model("gradp")
+grid = synthetic.channel_grid(256,256,seed=1).astype(np.float32)
+with psm_amd.GridSurrogate(model,256,256) as sur:
+    d_in = torch.from_numpy(grid).cuda(); d_out = torch.empty((256,256,2),dtype=torch.float32,device="cuda")
+    acc=[]
+    for it in range(50):
+        sur.solve_device(d_in.data_ptr(),1,d_out.data_ptr(),0)
+        sur.synchronize()
+        out=np.zeros(15,np.float32)
+        sur._chk(sur.lib.psm_read_stage(sur.h,5,out.ctypes.data_as(C.POINTER(C.c_float)),15))
+        acc.append(out.copy())
+    a=np.median(np.array(acc[10:]),axis=0)
+    print("assemble stamps (us): phase1=%.2f  reload=%.2f  chain=%.2f  post=%.2f  paste=%.2f"%tuple(a[:5]))

@@ -11,7 +11,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpsm_hip.so")
+LIB_PATH = os.environ.get("PSM_LIB") or os.path.join(HERE, "libpsm_hip.so")   # PSM_LIB: diagnostic builds only
 HEADER = os.path.join(os.path.dirname(HERE), "include", "psm.h")
 
 PSM_ABI_VERSION = 1

@@ -50,10 +50,14 @@ struct psm_handle {
   float *d_part = nullptr, *d_xin = nullptr, *d_act[2] = {nullptr, nullptr}, *d_res = nullptr, *d_pred = nullptr;
   int64_t* d_row_base = nullptr;
   float *d_row_scale = nullptr, *d_ones = nullptr;
-  int32_t *d_strips = nullptr, *d_blk = nullptr, *d_owner = nullptr, *d_shiftA = nullptr, *d_shiftB = nullptr;
+  int32_t *d_strips = nullptr, *d_blk = nullptr, *d_owner = nullptr, *d_shiftA = nullptr, *d_shiftB = nullptr, *d_shiftOwnA = nullptr, *d_shiftOwnB = nullptr;
+  float* d_shiftW = nullptr;
   PsmBlock* d_blocks = nullptr;
-  float2* d_sres = nullptr;
+  float4* d_spart = nullptr;
+  float2* d_colpart = nullptr;
+  int n_bands = 0;
   float *d_offs = nullptr, *d_shift = nullptr;
+  unsigned long long* d_stamps = nullptr;
   float *d_grid_stage = nullptr, *d_fields_stage = nullptr;
   float *h_grid = nullptr, *h_fields = nullptr;
   // row-scale upload ring (pinned)
@@ -64,6 +68,7 @@ struct psm_handle {
   hipStream_t stream = nullptr;
   std::map<GraphKey, hipGraphExec_t> graphs;
   bool use_graph = true;
+  bool fused_assemble = false;
   int last_cases = 0;
   // event timing of one kernel group
   int timed_kernel = -1;
@@ -115,8 +120,8 @@ void free_plan(psm_handle* h) {
   destroy_graphs(h);
   dev_free(h->d_part); dev_free(h->d_xin); dev_free(h->d_act[0]); dev_free(h->d_act[1]); dev_free(h->d_res);
   dev_free(h->d_pred); dev_free(h->d_row_base); dev_free(h->d_row_scale); dev_free(h->d_ones); dev_free(h->d_strips);
-  dev_free(h->d_blk); dev_free(h->d_owner); dev_free(h->d_shiftA); dev_free(h->d_shiftB); dev_free(h->d_blocks);
-  dev_free(h->d_sres); dev_free(h->d_offs); dev_free(h->d_shift); dev_free(h->d_grid_stage); dev_free(h->d_fields_stage);
+  dev_free(h->d_blk); dev_free(h->d_owner); dev_free(h->d_shiftA); dev_free(h->d_shiftB); dev_free(h->d_shiftOwnA); dev_free(h->d_shiftOwnB); dev_free(h->d_shiftW); dev_free(h->d_blocks);
+  dev_free(h->d_spart); dev_free(h->d_colpart); dev_free(h->d_offs); dev_free(h->d_shift); dev_free(h->d_stamps); dev_free(h->d_grid_stage); dev_free(h->d_fields_stage);
   if (h->h_grid) { (void)hipHostFree(h->h_grid); h->h_grid = nullptr; }
   if (h->h_fields) { (void)hipHostFree(h->h_fields); h->h_fields = nullptr; }
   h->planned = false;
@@ -231,23 +236,30 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
   tm.after(PSM_K_DECODE);
 
   PsmStripArgs sa{};
-  sa.pred = h->d_pred; sa.grid = d_grid; sa.strips = h->d_strips; sa.blk_y0x0 = h->d_blk; sa.sres = h->d_sres;
-  sa.n_strips = h->n_strips; sa.B = h->B; sa.S = h->S; sa.c_in = h->cfg.c_in; sa.c_out = h->cfg.c_out;
+  sa.pred = h->d_pred; sa.grid = d_grid; sa.strips = h->d_strips; sa.blk_y0x0 = h->d_blk; sa.spart = h->d_spart; sa.colpart = h->d_colpart; sa.NS = h->plan.cp.NS; sa.n_bands = h->n_bands;
+  sa.B = h->B; sa.S = h->S; sa.c_in = h->cfg.c_in; sa.c_out = h->cfg.c_out;
   sa.sdf_ch = h->cfg.sdf_channel; sa.Ny = h->Ny; sa.Nx = h->Nx;
   tm.before(PSM_K_STRIPS);
   HIPCHK(h, psm_launch_strips(sa, n_cases, st));
   tm.after(PSM_K_STRIPS);
 
   PsmChainArgs ca{};
-  ca.cp = h->plan.cp; ca.blocks = h->d_blocks; ca.sres = h->d_sres; ca.pred = h->d_pred; ca.owner = h->d_owner;
-  ca.shiftA = h->d_shiftA; ca.shiftB = h->d_shiftB;
+  ca.cp = h->plan.cp; ca.blocks = h->d_blocks; ca.spart = h->d_spart; ca.colpart = h->d_colpart; ca.n_bands = h->n_bands; ca.pred = h->d_pred; ca.owner = h->d_owner;
+  ca.shiftA = h->d_shiftA; ca.shiftB = h->d_shiftB; ca.shiftOwnA = h->d_shiftOwnA; ca.shiftOwnB = h->d_shiftOwnB; ca.shiftW = h->d_shiftW;
   for (int f = 0; f < 2; ++f) ca.shiftL[f] = (int)h->plan.shiftA[f].size();
-  ca.Lmax = h->Lmax; ca.offs = h->d_offs; ca.shift = h->d_shift; ca.n_strips = h->n_strips; ca.c_out = h->cfg.c_out;
+  ca.Lmax = h->Lmax; ca.offs = h->d_offs; ca.shift = h->d_shift; ca.n_strips = h->n_strips; ca.c_out = h->cfg.c_out; ca.stamps = h->d_stamps;
+  PsmPasteArgs pa{h->d_pred, h->d_owner, h->d_offs, h->d_shift, d_fields, h->B, h->S, h->cfg.c_out, h->Ny * h->Nx};
+  if (h->fused_assemble) {       // few blocks: every paste workgroup re-runs the chain (one launch less)
+    tm.before(PSM_K_CHAIN);
+    tm.after(PSM_K_CHAIN);
+    tm.before(PSM_K_PASTE);
+    HIPCHK(h, psm_launch_assemble(ca, pa, n_cases, st));
+    tm.after(PSM_K_PASTE);
+    return PSM_OK;
+  }
   tm.before(PSM_K_CHAIN);
   HIPCHK(h, psm_launch_chain(ca, n_cases, st));
   tm.after(PSM_K_CHAIN);
-
-  PsmPasteArgs pa{h->d_pred, h->d_owner, h->d_offs, h->d_shift, d_fields, h->B, h->S, h->cfg.c_out, h->Ny * h->Nx};
   tm.before(PSM_K_PASTE);
   HIPCHK(h, psm_launch_paste(pa, n_cases, st));
   tm.after(PSM_K_PASTE);
@@ -316,7 +328,7 @@ int psm_create(const psm_config* cfg, psm_handle** out) {
   *out = nullptr;
   if (cfg->abi_version != PSM_ABI_VERSION) return fail(nullptr, PSM_ERR_ARG, "psm_config.abi_version mismatch");
   if (cfg->variant < 0 || cfg->variant > 2) return fail(nullptr, PSM_ERR_ARG, "unknown variant");
-  if (cfg->block <= 0 || cfg->block % 64) return fail(nullptr, PSM_ERR_ARG, "block must be a positive multiple of 64");
+  if (cfg->block != 128) return fail(nullptr, PSM_ERR_UNSUPPORTED, "block must be 128 (the only block edge the reference uses: python_module.py:303, entry_point.py --shape 128)");
   if (cfg->c_in < 1 || cfg->c_in > 4) return fail(nullptr, PSM_ERR_ARG, "c_in must be 1..4");
   if (cfg->c_out < 1 || cfg->c_out > 2) return fail(nullptr, PSM_ERR_ARG, "c_out must be 1 or 2");
   if (cfg->variant == PSM_VARIANT_GRADP && cfg->c_out != 2) return fail(nullptr, PSM_ERR_ARG, "gradp needs c_out == 2");
@@ -349,8 +361,12 @@ int psm_create(const psm_config* cfg, psm_handle** out) {
   h->Gd = h->ld_out / 8;
   h->n_coltiles = h->K_out / 32;
   h->dense.resize(cfg->n_dense);
-  const char* ng = getenv("PSM_NO_GRAPH");
-  h->use_graph = !(ng && ng[0] == '1');
+  // Launch mode: plain stream launches by default.  Measured on MI355X (ROCm 7.2) one hipGraph
+  // replay per solve costs ~5 us more per solve than the same kernels launched eagerly (a gap
+  // of ~8 us between consecutive replays against back-to-back kernels), and the host enqueues
+  // the ~9 launches faster than the GPU retires them.  PSM_GRAPH=1 selects graph replay.
+  const char* ug = getenv("PSM_GRAPH");
+  h->use_graph = (ug && ug[0] == '1');
   if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     delete h;
     return fail(nullptr, PSM_ERR_HIP, "cannot create a stream on the device");
@@ -471,9 +487,14 @@ int psm_plan_grid(psm_handle* h, int32_t ny, int32_t nx) {
   if ((rc = dev_alloc(h, &h->d_res, (size_t)h->Mpad_cap * h->ld_out))) return rc;
   if ((rc = dev_alloc(h, &h->d_pred, (size_t)h->Mcap * h->K_out))) return rc;
   if ((rc = dev_alloc(h, &h->d_row_scale, (size_t)h->Mpad_cap))) return rc;
-  if ((rc = dev_alloc(h, &h->d_sres, (size_t)h->cfg.max_cases * h->cfg.c_out * h->n_strips))) return rc;
+  h->n_bands = h->S / PSM_STRIP_BAND;
+  if ((rc = dev_alloc(h, &h->d_spart, (size_t)h->cfg.max_cases * h->B * h->n_bands * h->plan.cp.NS))) return rc;
+  if (h->cfg.variant == PSM_VARIANT_GRADP)
+    if ((rc = dev_alloc(h, &h->d_colpart, (size_t)h->cfg.max_cases * h->n_bands * 128))) return rc;
   if ((rc = dev_alloc(h, &h->d_offs, (size_t)h->cfg.max_cases * h->cfg.c_out * h->B))) return rc;
   if ((rc = dev_alloc(h, &h->d_shift, (size_t)h->cfg.max_cases * h->cfg.c_out))) return rc;
+  if ((rc = dev_alloc(h, &h->d_stamps, (size_t)16))) return rc;
+  HIPCHK(h, hipMemset(h->d_stamps, 0, 16 * sizeof(unsigned long long)));
   if ((rc = dev_alloc(h, &h->d_grid_stage, (size_t)h->cfg.max_cases * npix * h->cfg.c_in))) return rc;
   if ((rc = dev_alloc(h, &h->d_fields_stage, (size_t)h->cfg.max_cases * npix * h->cfg.c_out))) return rc;
   HIPCHK(h, hipHostMalloc((void**)&h->h_grid, (size_t)h->cfg.max_cases * npix * h->cfg.c_in * sizeof(float), hipHostMallocDefault));
@@ -508,10 +529,33 @@ int psm_plan_grid(psm_handle* h, int32_t ny, int32_t nx) {
   }
   if ((rc = dev_upload(h, &h->d_shiftA, sA))) return rc;
   if ((rc = dev_upload(h, &h->d_shiftB, sB))) return rc;
+  {
+    std::vector<int32_t> oA(sA.size(), -1), oB(sB.size(), -1);
+    std::vector<float> w((size_t)2 * h->B, 0.f);
+    const int SS = h->S * h->S;
+    for (int f = 0; f < 2; ++f) {
+      const size_t L = h->plan.shiftA[f].size();
+      std::vector<double> acc(h->B, 0.0);
+      for (size_t k = 0; k < L; ++k) {
+        const int a_ = h->plan.owner[h->plan.shiftA[f][k]], b_ = h->plan.owner[h->plan.shiftB[f][k]];
+        oA[(size_t)f * h->Lmax + k] = a_; oB[(size_t)f * h->Lmax + k] = b_;
+        if (a_ >= 0) acc[a_ / SS] += 3.0;
+        if (b_ >= 0) acc[b_ / SS] -= 1.0;
+      }
+      for (int b = 0; b < h->B; ++b) w[(size_t)f * h->B + b] = L ? (float)(acc[b] / (3.0 * (double)L)) : 0.f;
+    }
+    if ((rc = dev_upload(h, &h->d_shiftOwnA, oA))) return rc;
+    if ((rc = dev_upload(h, &h->d_shiftOwnB, oB))) return rc;
+    if ((rc = dev_upload(h, &h->d_shiftW, w))) return rc;
+  }
   HIPCHK(h, hipMemset(h->d_part, 0, (size_t)h->n_slices * h->Mpad_cap * h->ld_in * sizeof(float)));
   HIPCHK(h, hipMemset(h->d_act[0], 0, (size_t)h->Mpad_cap * h->max_width * sizeof(float)));
   HIPCHK(h, hipMemset(h->d_act[1], 0, (size_t)h->Mpad_cap * h->max_width * sizeof(float)));
   HIPCHK(h, hipDeviceSynchronize());
+  {
+    const char* nf = getenv("PSM_NO_FUSED_ASSEMBLE");
+    h->fused_assemble = (h->B <= 64 && h->plan.cp.n_x < 64) && !(nf && nf[0] == '1');
+  }
   h->planned = true;
   return PSM_OK;
 }
@@ -552,15 +596,15 @@ int psm_reassemble(psm_handle* h, const float* grid, const float* block_pred, fl
   HIPCHK(h, hipMemcpyAsync(h->d_grid_stage, grid, npix * h->cfg.c_in * sizeof(float), hipMemcpyHostToDevice, st));
   HIPCHK(h, hipMemcpyAsync(h->d_pred, block_pred, (size_t)h->B * h->K_out * sizeof(float), hipMemcpyHostToDevice, st));
   PsmStripArgs sa{};
-  sa.pred = h->d_pred; sa.grid = h->d_grid_stage; sa.strips = h->d_strips; sa.blk_y0x0 = h->d_blk; sa.sres = h->d_sres;
-  sa.n_strips = h->n_strips; sa.B = h->B; sa.S = h->S; sa.c_in = h->cfg.c_in; sa.c_out = h->cfg.c_out;
+  sa.pred = h->d_pred; sa.grid = h->d_grid_stage; sa.strips = h->d_strips; sa.blk_y0x0 = h->d_blk; sa.spart = h->d_spart; sa.colpart = h->d_colpart; sa.NS = h->plan.cp.NS; sa.n_bands = h->n_bands;
+  sa.B = h->B; sa.S = h->S; sa.c_in = h->cfg.c_in; sa.c_out = h->cfg.c_out;
   sa.sdf_ch = h->cfg.sdf_channel; sa.Ny = h->Ny; sa.Nx = h->Nx;
   HIPCHK(h, psm_launch_strips(sa, 1, st));
   PsmChainArgs ca{};
-  ca.cp = h->plan.cp; ca.blocks = h->d_blocks; ca.sres = h->d_sres; ca.pred = h->d_pred; ca.owner = h->d_owner;
-  ca.shiftA = h->d_shiftA; ca.shiftB = h->d_shiftB;
+  ca.cp = h->plan.cp; ca.blocks = h->d_blocks; ca.spart = h->d_spart; ca.colpart = h->d_colpart; ca.n_bands = h->n_bands; ca.pred = h->d_pred; ca.owner = h->d_owner;
+  ca.shiftA = h->d_shiftA; ca.shiftB = h->d_shiftB; ca.shiftOwnA = h->d_shiftOwnA; ca.shiftOwnB = h->d_shiftOwnB; ca.shiftW = h->d_shiftW;
   for (int f = 0; f < 2; ++f) ca.shiftL[f] = (int)h->plan.shiftA[f].size();
-  ca.Lmax = h->Lmax; ca.offs = h->d_offs; ca.shift = h->d_shift; ca.n_strips = h->n_strips; ca.c_out = h->cfg.c_out;
+  ca.Lmax = h->Lmax; ca.offs = h->d_offs; ca.shift = h->d_shift; ca.n_strips = h->n_strips; ca.c_out = h->cfg.c_out; ca.stamps = h->d_stamps;
   HIPCHK(h, psm_launch_chain(ca, 1, st));
   PsmPasteArgs pa{h->d_pred, h->d_owner, h->d_offs, h->d_shift, h->d_fields_stage, h->B, h->S, h->cfg.c_out, h->Ny * h->Nx};
   HIPCHK(h, psm_launch_paste(pa, 1, st));
@@ -603,6 +647,13 @@ int psm_read_stage(psm_handle* h, int32_t stage, float* dst, size_t dst_floats) 
       const size_t n = (size_t)h->last_cases * h->cfg.c_out;
       if (dst_floats < n) return fail(h, PSM_ERR_ARG, "destination too small");
       HIPCHK(h, hipMemcpy(dst, h->d_shift, n * sizeof(float), hipMemcpyDeviceToHost));
+      return PSM_OK;
+    }
+    case 5: {   // diagnostic builds only: stamp deltas of workgroup 0 in microseconds
+      unsigned long long t[16];
+      if (dst_floats < 15) return fail(h, PSM_ERR_ARG, "destination too small");
+      HIPCHK(h, hipMemcpy(t, h->d_stamps, sizeof(t), hipMemcpyDeviceToHost));
+      for (int k = 0; k < 15; ++k) dst[k] = (t[k + 1] && t[k]) ? (float)((double)(t[k + 1] - t[k]) * 0.01) : 0.f;
       return PSM_OK;
     }
   }
@@ -687,14 +738,6 @@ int psm_owner_map(int32_t variant, int32_t ny, int32_t nx, int32_t block, int32_
 // Host replay of the device reassembly (strip table -> chain -> owner-map paste) on
 // caller-supplied decoded blocks.  Verification helper for the plan tables and the
 // chain logic only: nothing in psm_solve_* calls it.
-namespace {
-struct HostStripView {
-  const float* sum; const float* cnt;
-  float mean(int s) const { return sum[s] / cnt[s]; }
-  float count(int s) const { return cnt[s]; }
-};
-}  // namespace
-
 int psm_debug_reassemble_host(int32_t variant, int32_t ny, int32_t nx, int32_t block, int32_t overlap, int32_t strict,
                               int32_t c_in, int32_t c_out, int32_t sdf_ch, const float* grid, const float* pred,
                               float* fields, float* offsets, float* shifts) {
@@ -718,10 +761,11 @@ int psm_debug_reassemble_host(int32_t variant, int32_t ny, int32_t nx, int32_t b
           }
           if (on) { s += pred[((size_t)st.data * SS + r * S + cc) * c_out + f]; c += 1.f; }
         }
-      sum[e] = s; cnt[e] = c;
+      sum[e] = s / c; cnt[e] = c;     // mean; 0/0 -> NaN like np.mean([])
     }
-    HostStripView sv{sum.data(), cnt.data()};
-    psm_chain<float>(plan.cp, plan.blocks.data(), sv, f, up.data(), offs.data());
+    for (auto& u : up) u = 0.f;
+    PsmArrayChainCtx<float> cx{plan.blocks.data(), sum.data(), cnt.data(), plan.cp.NS, plan.cp.col_base, S, up.data(), offs.data()};
+    psm_chain<float>(plan.cp, cx, f);
     double acc = 0.0;
     const size_t L = plan.shiftA[f].size();
     for (size_t k = 0; k < L; ++k) {

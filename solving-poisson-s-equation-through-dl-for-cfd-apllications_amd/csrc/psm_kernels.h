@@ -9,6 +9,7 @@
 // Tiling constants shared by the host packers and the kernels -----------------
 constexpr int PSM_PIX_PER_SLICE = 64;  // pixels of one block row handled by an encode workgroup
 constexpr int PSM_MT_CHUNK = 4;        // 32-row M tiles staged in LDS at once
+constexpr int PSM_STRIP_BAND = 16;     // block rows handled by one strips workgroup
 
 struct PsmEncodeArgs {
   const float* grid;       // [cases, Ny, Nx, C_in]
@@ -47,23 +48,27 @@ struct PsmDecodeArgs {
 struct PsmStripArgs {
   const float* pred;                   // [cases*B][S*S*c_out]
   const float* grid;                   // [cases][Ny][Nx][c_in]
-  const int32_t* strips;               // [n_strips][6]
+  const int32_t* strips;               // [B*NS (+S)][6]
   const int32_t* blk_y0x0;             // [B][2]
-  float2* sres;                        // [cases][c_out][n_strips] (sum, count)
-  int n_strips, B, S, c_in, c_out, sdf_ch, Ny, Nx;
+  float4* spart;                       // [cases][B][n_bands][NS] (sum f0, sum f1, count, -)
+  float2* colpart;                     // gradp: [cases][n_bands][128] column sums of block 0 (else null)
+  int NS, n_bands, B, S, c_in, c_out, sdf_ch, Ny, Nx;
 };
 
 struct PsmChainArgs {
   PsmChainParams cp;
   const PsmBlock* blocks;              // [B]
-  const float2* sres;
+  const float4* spart; const float2* colpart; int n_bands;
   const float* pred;
   const int32_t* owner;                // [Ny*Nx]
-  const int32_t* shiftA; const int32_t* shiftB;   // [c_out][Lmax]
+  const int32_t* shiftA; const int32_t* shiftB;   // [c_out][Lmax] cell indices
+  const int32_t* shiftOwnA; const int32_t* shiftOwnB;   // [c_out][Lmax] owner[cell]
+  const float* shiftW;                 // [c_out][B] weight of each block's offset in the shift
   int shiftL[2]; int Lmax;
   float* offs;                         // [cases][c_out][B]
   float* shift;                        // [cases][c_out]
   int n_strips, c_out;
+  unsigned long long* stamps;          // diagnostic build (-DPSM_STAMPS) only: s_memrealtime stamps of workgroup 0
 };
 
 struct PsmPasteArgs {
@@ -79,3 +84,5 @@ hipError_t psm_launch_decode(const PsmDecodeArgs& a, hipStream_t s);
 hipError_t psm_launch_strips(const PsmStripArgs& a, int n_cases, hipStream_t s);
 hipError_t psm_launch_chain(const PsmChainArgs& a, int n_cases, hipStream_t s);
 hipError_t psm_launch_paste(const PsmPasteArgs& a, int n_cases, hipStream_t s);
+// chain + shift + paste in one launch; valid when B <= 64 and n_x < 64
+hipError_t psm_launch_assemble(const PsmChainArgs& a, const PsmPasteArgs& p, int n_cases, hipStream_t s);

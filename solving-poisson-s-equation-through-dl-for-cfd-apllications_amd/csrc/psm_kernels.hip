@@ -21,6 +21,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// Diagnostic stamps (100 MHz wall clock) -- compiled only with -DPSM_STAMPS, never in the shipped library.
+#ifdef PSM_STAMPS
+#define PSM_STAMP(buf, k) do { if ((buf) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) (buf)[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PSM_STAMP(buf, k) do { } while (0)
+#endif
+
 __device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
 // ---------------------------------------------------------------------------
@@ -31,65 +38,105 @@ __global__ __launch_bounds__(256) void psm_encode_kernel(PsmEncodeArgs a) {
   constexpr int KS = PSM_PIX_PER_SLICE * C_IN;  // K elements per workgroup
   constexpr int G = KS / 8;                     // groups of 8 k
   constexpr int LDA = KS + 4;                   // LDS row stride (floats): 16-B slots rotate by one per row
-  constexpr int Q = KS / 4;
+  constexpr int Q = KS / 4;                     // 16-byte pieces per activation row (<= 64)
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int s = blockIdx.x;
   const int runs = a.S / PSM_PIX_PER_SLICE;
   const int r = s / runs, c0 = (s - r * runs) * PSM_PIX_PER_SLICE;
   const int64_t src_off = (int64_t)r * a.row_stride + (int64_t)c0 * C_IN;
-  const float* __restrict__ mean = a.mean + (int64_t)s * KS;
   const int NT = a.NT;
   const int i = lane & 31, h = lane >> 5;
+  const int ql = lane < Q ? lane : Q - 1;       // lanes >= Q idle in the staging (C_IN < 4)
+  const float4 mu = *reinterpret_cast<const float4*>(a.mean + (int64_t)s * KS + 4 * ql);
 
+  // One activation row per wave and step: the row's origin is wave-uniform (scalar load),
+  // the lanes read 16 contiguous bytes each.  All loads of a batch are issued before any use.
+  auto load_rows = [&](float4 (&x)[8], int m0, int row0) {    // rows row0 + wave + 4u (u < 8) of chunk m0
+    int64_t rb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) rb[u] = a.row_base[min(m0 + row0 + wave + 4 * u, a.M - 1)];   // scalar loads
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float* src = a.grid + rb[u] + src_off + 4 * ql;
+      if (ALIGNED) x[u] = *reinterpret_cast<const float4*>(src);
+      else x[u] = make_float4(src[0], src[1], src[2], src[3]);
+    }
+  };
+  auto write_rows = [&](const float4 (&x)[8], int m0, int row0) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int row = row0 + wave + 4 * u;
+      const float keep = (m0 + row) < a.M ? 1.f : 0.f;          // padding rows -> 0 (no branch)
+      const float4 v = make_float4((x[u].x - mu.x) * keep, (x[u].y - mu.y) * keep, (x[u].z - mu.z) * keep, (x[u].w - mu.w) * keep);
+      if (lane < Q) *reinterpret_cast<float4*>(&lds[row * LDA + 4 * lane]) = v;
+    }
+  };
+  auto stage_rows = [&](int m0, int row0) {
+    float4 x[8];
+    load_rows(x, m0, row0);
+    write_rows(x, m0, row0);
+  };
+  auto gemm_tile = [&](const float4 (&b)[G], int mt, int t, int m0, bool store) {
+    f32x16 acc = {0};
+    const float* arow = &lds[(mt * 32 + i) * LDA + 4 * h];
+    float4 av = *reinterpret_cast<const float4*>(arow);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float4 an = *reinterpret_cast<const float4*>(arow + 8 * (g + 1 < G ? g + 1 : g));   // next group in flight
+      acc = MFMA32(av.x, b[g].x, acc);
+      acc = MFMA32(av.y, b[g].y, acc);
+      acc = MFMA32(av.z, b[g].z, acc);
+      acc = MFMA32(av.w, b[g].w, acc);
+      av = an;
+    }
+    if (store) {
+      float* out = a.part + ((int64_t)s * a.Mpad + m0 + mt * 32) * a.ldp + t * 32 + i;
+#pragma unroll
+      for (int rg = 0; rg < 16; ++rg) out[(int64_t)acc_row(rg, h) * a.ldp] = acc[rg];
+    }
+  };
+
+  if (NT <= 4 && a.Mpad <= 32 * PSM_MT_CHUNK) {
+    // common case (<= 128 components, <= 128 block rows): straight-line so that the weight
+    // stream stays in flight behind the first MFMAs (counted vmcnt).  Every wave computes (a
+    // wave without a tile of its own recomputes the last one and stores nothing): keeps the
+    // weight loads unconditional, ahead of the barrier.
+    const int t = min(wave, NT - 1);
+    float4 x0[8];
+    load_rows(x0, 0, 0);                        // first 32 rows: loads issued BEFORE the weights
+    __builtin_amdgcn_sched_barrier(0);
+    float4 b[G];
+    {
+      const float4* p = a.bpack + (((int64_t)s * NT + t) * G) * 64 + lane;
+#pragma unroll
+      for (int g = 0; g < G; ++g) b[g] = p[g * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    write_rows(x0, 0, 0);                       // waits for the activation rows only (counted vmcnt)
+    for (int row0 = 32; row0 < a.Mpad; row0 += 32) stage_rows(0, row0);
+    __syncthreads();
+    gemm_tile(b, 0, t, 0, wave < NT);           // peeled: counted waits on the weight stream
+    for (int mt = 1; mt < a.Mpad / 32; ++mt) gemm_tile(b, mt, t, 0, wave < NT);
+    return;
+  }
+
+  // general case: any number of component tiles / row chunks
   float4 b[G];
   int cur_t = -1;
-  auto load_b = [&](int t) {
-    const float4* p = a.bpack + (((int64_t)s * NT + t) * G) * 64 + lane;
-#pragma unroll
-    for (int g = 0; g < G; ++g) b[g] = p[g * 64];
-    cur_t = t;
-  };
-  if (wave < NT) load_b(wave);  // weights stream: issued before the activation tile is staged
-
   for (int m0 = 0; m0 < a.Mpad; m0 += 32 * PSM_MT_CHUNK) {
     const int rows = min(32 * PSM_MT_CHUNK, a.Mpad - m0);
-    for (int idx = tid; idx < rows * Q; idx += 256) {
-      const int row = idx / Q, q = idx - row * Q;
-      const int m = m0 + row;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < a.M) {
-        const int64_t base = a.row_base[m];
-        const float* src = a.grid + base + src_off + 4 * q;
-        float4 x;
-        if (ALIGNED) {
-          x = *reinterpret_cast<const float4*>(src);
-        } else {
-          x = make_float4(src[0], src[1], src[2], src[3]);
-        }
-        const float4 mu = *reinterpret_cast<const float4*>(mean + 4 * q);
-        v = make_float4(x.x - mu.x, x.y - mu.y, x.z - mu.z, x.w - mu.w);
-      }
-      *reinterpret_cast<float4*>(&lds[row * LDA + 4 * q]) = v;
-    }
+    for (int row0 = 0; row0 < rows; row0 += 32) stage_rows(m0, row0);
     __syncthreads();
     for (int t = wave; t < NT; t += 4) {
-      if (t != cur_t) load_b(t);
-      for (int mt = 0; mt < rows / 32; ++mt) {
-        f32x16 acc = {0};
-        const float* arow = &lds[(mt * 32 + i) * LDA + 4 * h];
+      if (t != cur_t) {
+        const float4* p = a.bpack + (((int64_t)s * NT + t) * G) * 64 + lane;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const float4 av = *reinterpret_cast<const float4*>(arow + 8 * g);
-          acc = MFMA32(av.x, b[g].x, acc);
-          acc = MFMA32(av.y, b[g].y, acc);
-          acc = MFMA32(av.z, b[g].z, acc);
-          acc = MFMA32(av.w, b[g].w, acc);
-        }
-        float* out = a.part + ((int64_t)s * a.Mpad + m0 + mt * 32) * a.ldp + t * 32 + i;
-#pragma unroll
-        for (int rg = 0; rg < 16; ++rg) out[(int64_t)acc_row(rg, h) * a.ldp] = acc[rg];
+        for (int g = 0; g < G; ++g) b[g] = p[g * 64];
+        cur_t = t;
       }
+      for (int mt = 0; mt < rows / 32; ++mt) gemm_tile(b, mt, t, m0, true);
     }
     __syncthreads();
   }
@@ -113,29 +160,32 @@ hipError_t psm_launch_encode(const PsmEncodeArgs& a, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------
-// reduce (+ input scaler)
+// reduce (+ input scaler): 16 waves x 16 slabs in flight per lane, one round trip
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void psm_reduce_kernel(PsmReduceArgs a) {
-  __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void psm_reduce_kernel(PsmReduceArgs a) {
+  __shared__ float red[16][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t total = (int64_t)a.Mpad * a.ldp;
   const int64_t o = (int64_t)blockIdx.x * 64 + lane;
-  const int per = (a.n_slices + 3) / 4;
+  const int per = (a.n_slices + 15) / 16;
   const int s0 = wave * per, s1 = min(a.n_slices, s0 + per);
-  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
   const float* p = a.part + o;
+  float acc = 0.f;
   int s = s0;
-  for (; s + 4 <= s1; s += 4) {
-    acc0 += p[(int64_t)(s + 0) * total];
-    acc1 += p[(int64_t)(s + 1) * total];
-    acc2 += p[(int64_t)(s + 2) * total];
-    acc3 += p[(int64_t)(s + 3) * total];
+  for (; s + 16 <= s1; s += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = p[(int64_t)(s + u) * total];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += v[u];       // fixed order: deterministic
   }
-  for (; s < s1; ++s) acc0 += p[(int64_t)s * total];
-  red[wave][lane] = (acc0 + acc1) + (acc2 + acc3);
+  for (; s < s1; ++s) acc += p[(int64_t)s * total];
+  red[wave][lane] = acc;
   __syncthreads();
   if (wave == 0) {
-    const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) v += red[w][lane];
     const int col = (int)(o % a.ldp);
     a.xin[o] = v * a.ia[col] + a.ib[col];
   }
@@ -143,39 +193,78 @@ __global__ __launch_bounds__(256) void psm_reduce_kernel(PsmReduceArgs a) {
 
 hipError_t psm_launch_reduce(const PsmReduceArgs& a, hipStream_t st) {
   const int64_t total = (int64_t)a.Mpad * a.ldp;
-  hipLaunchKernelGGL(psm_reduce_kernel, dim3((unsigned)(total / 64)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(psm_reduce_kernel, dim3((unsigned)(total / 64)), dim3(1024), 0, st, a);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
-// dense layer
+// dense layer: v_mfma_f32_16x16x4_f32, one 16-column tile x 32 rows per workgroup,
+// K split over 8 waves, operands prefetched to registers in one round trip.
+//   A: lane l holds A[i = l&15][k = l>>4];  B: lane l holds B[k = l>>4][j = l&15]
+//   D: lane l, reg r holds D[4*(l>>4) + r][l&15]
+// k order inside a group of 16: step j uses k = 16g + 4*(l>>4) + j (one float4 of A per lane).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void psm_dense_kernel(PsmDenseArgs a) {
-  __shared__ float red[4][32 * 33];
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+template <int KG>   // groups of 16 k per wave held in registers per pass
+__global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a) {
+  __shared__ float red[8][2][16 * 17];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nt = blockIdx.x, mt = blockIdx.y;
-  const int i = lane & 31, h = lane >> 5;
-  const int klen = a.Kpad / 4, kq = wave * klen;  // Kpad is a multiple of 32
-  const float* arow = a.in + (int64_t)(mt * 32 + i) * a.ld_in + kq + 4 * h;
-  const float* wcol = a.W + (int64_t)(kq + 4 * h) * a.ld_w + nt * 32 + i;
-  f32x16 acc = {0};
-  for (int g = 0; g < klen / 8; ++g) {
-    const float4 av = *reinterpret_cast<const float4*>(arow + 8 * g);
-    const float* w = wcol + (int64_t)(8 * g) * a.ld_w;
-    const float b0 = w[0], b1 = w[a.ld_w], b2 = w[2 * (int64_t)a.ld_w], b3 = w[3 * (int64_t)a.ld_w];
-    acc = MFMA32(av.x, b0, acc);
-    acc = MFMA32(av.y, b1, acc);
-    acc = MFMA32(av.z, b2, acc);
-    acc = MFMA32(av.w, b3, acc);
+  const int i = lane & 15, kq = lane >> 4;
+  const int klen = a.Kpad / 8;                       // per wave; Kpad multiple of 32 -> klen multiple of 4
+  const int k0 = wave * klen;
+  f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+  const float* arow0 = a.in + (int64_t)(mt * 32 + i) * a.ld_in + k0 + 4 * kq;
+  const float* arow1 = arow0 + (int64_t)16 * a.ld_in;
+  const float* wcol = a.W + (int64_t)(k0 + 4 * kq) * a.ld_w + nt * 16 + i;
+  const int ngroups = klen / 16, rem = klen - ngroups * 16;   // rem in {0,4,8,12}: handled 4 k at a time
+  for (int g0 = 0; g0 < ngroups; g0 += KG) {
+    float4 a0[KG], a1[KG];
+    float w[KG][4];
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+      if (g0 + g < ngroups) {
+        a0[g] = *reinterpret_cast<const float4*>(arow0 + 16 * (g0 + g));
+        a1[g] = *reinterpret_cast<const float4*>(arow1 + 16 * (g0 + g));
+        const float* wp = wcol + (int64_t)(16 * (g0 + g)) * a.ld_w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[g][j] = wp[(int64_t)j * a.ld_w];
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+      if (g0 + g < ngroups) {
+        acc0 = MFMA16(a0[g].x, w[g][0], acc0); acc1 = MFMA16(a1[g].x, w[g][0], acc1);
+        acc0 = MFMA16(a0[g].y, w[g][1], acc0); acc1 = MFMA16(a1[g].y, w[g][1], acc1);
+        acc0 = MFMA16(a0[g].z, w[g][2], acc0); acc1 = MFMA16(a1[g].z, w[g][2], acc1);
+        acc0 = MFMA16(a0[g].w, w[g][3], acc0); acc1 = MFMA16(a1[g].w, w[g][3], acc1);
+      }
+    }
   }
+  // tail: remaining multiples of 4 k (natural order: step uses k = base + kq)
+  for (int kk = ngroups * 16; kk < klen; kk += 4) {
+    const float av0 = a.in[(int64_t)(mt * 32 + i) * a.ld_in + k0 + kk + kq];
+    const float av1 = a.in[(int64_t)(mt * 32 + 16 + i) * a.ld_in + k0 + kk + kq];
+    const float wv = a.W[(int64_t)(k0 + kk + kq) * a.ld_w + nt * 16 + i];
+    acc0 = MFMA16(av0, wv, acc0);
+    acc1 = MFMA16(av1, wv, acc1);
+  }
+  (void)rem;
 #pragma unroll
-  for (int rg = 0; rg < 16; ++rg) red[wave][acc_row(rg, h) * 33 + i] = acc[rg];
+  for (int r = 0; r < 4; ++r) {
+    red[wave][0][(4 * kq + r) * 17 + i] = acc0[r];
+    red[wave][1][(4 * kq + r) * 17 + i] = acc1[r];
+  }
   __syncthreads();
+  {
+    const int row = tid >> 4, col = tid & 15;          // 512 threads = 32 rows x 16 cols
+    const int half = row >> 4, r16 = row & 15;
+    float v = 0.f;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int idx = tid + 256 * q, row = idx >> 5, col = idx & 31;
-    const int n = nt * 32 + col;
-    float v = (red[0][row * 33 + col] + red[1][row * 33 + col]) + (red[2][row * 33 + col] + red[3][row * 33 + col]);
+    for (int w8 = 0; w8 < 8; ++w8) v += red[w8][half][r16 * 17 + col];
+    const int n = nt * 16 + col;
     v += a.bias[n];
     if (a.relu) v = fmaxf(v, 0.f);
     if (a.head) v = v * a.sa[n] + a.sb[n];
@@ -184,20 +273,89 @@ __global__ __launch_bounds__(256) void psm_dense_kernel(PsmDenseArgs a) {
 }
 
 hipError_t psm_launch_dense(const PsmDenseArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(psm_dense_kernel, dim3(a.ld_w / 32, a.Mpad / 32), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((psm_dense_kernel<4>), dim3(a.ld_w / 16, a.Mpad / 32), dim3(512), 0, st, a);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
 // decode
 // ---------------------------------------------------------------------------
+// Fast path: <= 128 output components (ld_res == 128, 16 groups of 8 k): the whole weight
+// slice of a wave (16 x 16 B per lane) is issued behind the activation-tile loads and stays in
+// flight under the first MFMAs (counted vmcnt).
+typedef float v4f __attribute__((ext_vector_type(4)));
 template <int MTC>
+__global__ __launch_bounds__(256) void psm_decode128_kernel(PsmDecodeArgs a, int m_base) {
+  constexpr int LDR = 128, LDA = LDR + 4, Q = LDR / 4, GD = LDR / 8, NA = MTC * 32 * Q / 256;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int ct = min(blockIdx.x * 4 + wave, a.n_coltiles - 1);
+  const bool live = (blockIdx.x * 4 + wave) < a.n_coltiles;
+  auto load_tile = [&](v4f (&x)[NA]) {
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      const int idx = tid + 256 * u, row = idx / Q, q = idx - row * Q;
+      const int m = min(m_base + row, a.Mpad - 1);
+      x[u] = *reinterpret_cast<const v4f*>(a.res + (int64_t)m * LDR + 4 * q);
+    }
+  };
+  auto write_tile = [&](const v4f (&x)[NA]) {
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      const int idx = tid + 256 * u, row = idx / Q, q = idx - row * Q;
+      *reinterpret_cast<v4f*>(&lds[row * LDA + 4 * q]) = x[u];
+    }
+  };
+  v4f x[NA];
+  load_tile(x);
+  __builtin_amdgcn_sched_barrier(0);
+  float4 b[GD];
+  const float4* bp = a.bpack + ((int64_t)ct * GD) * 64 + lane;
+#pragma unroll
+  for (int g = 0; g < GD; ++g) b[g] = bp[g * 64];
+  const int col = ct * 32 + i;
+  const float mu = a.mean[col];
+  __builtin_amdgcn_sched_barrier(0);
+  write_tile(x);
+  __syncthreads();
+  f32x16 acc[MTC];
+#pragma unroll
+  for (int mt = 0; mt < MTC; ++mt) {
+    acc[mt] = (f32x16){0};
+    const float* arow = &lds[(mt * 32 + i) * LDA + 4 * h];
+    float4 av = *reinterpret_cast<const float4*>(arow);
+#pragma unroll
+    for (int g = 0; g < GD; ++g) {
+      const float4 an = *reinterpret_cast<const float4*>(arow + 8 * (g + 1 < GD ? g + 1 : g));
+      acc[mt] = MFMA32(av.x, b[g].x, acc[mt]);
+      acc[mt] = MFMA32(av.y, b[g].y, acc[mt]);
+      acc[mt] = MFMA32(av.z, b[g].z, acc[mt]);
+      acc[mt] = MFMA32(av.w, b[g].w, acc[mt]);
+      av = an;
+    }
+  }
+  if (!live) return;
+#pragma unroll
+  for (int mt = 0; mt < MTC; ++mt) {
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) {
+      const int m = m_base + mt * 32 + acc_row(rg, h);
+      if (m < a.M) a.pred[(int64_t)m * a.K_out + col] = (acc[mt][rg] + mu) * a.row_scale[m];
+    }
+  }
+}
+
+template <int MTC, int GCH>   // GCH: groups of 8 k whose weights are prefetched together
 __global__ __launch_bounds__(256) void psm_decode_kernel(PsmDecodeArgs a, int m_base) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int LDA = a.ld_res + 4, Q = a.ld_res / 4;
-  const int ct = blockIdx.x * 4 + wave;
+  const int ct = min(blockIdx.x * 4 + wave, a.n_coltiles - 1);
+  const bool live = (blockIdx.x * 4 + wave) < a.n_coltiles;
+  const float4* bp = a.bpack + ((int64_t)ct * a.Gd) * 64 + lane;
+  // activation tile first (needed first), then the weight stream
   for (int idx = tid; idx < MTC * 32 * Q; idx += 256) {
     const int row = idx / Q, q = idx - row * Q;
     const int m = m_base + row;
@@ -205,31 +363,36 @@ __global__ __launch_bounds__(256) void psm_decode_kernel(PsmDecodeArgs a, int m_
     if (m < a.Mpad) v = *reinterpret_cast<const float4*>(a.res + (int64_t)m * a.ld_res + 4 * q);
     *reinterpret_cast<float4*>(&lds[row * LDA + 4 * q]) = v;
   }
+  float4 b[GCH];
+#pragma unroll
+  for (int g = 0; g < GCH; ++g) b[g] = bp[(int64_t)min(g, a.Gd - 1) * 64];
+  const int col = ct * 32 + i;
+  const float mu = a.mean[col];
   __syncthreads();
-  if (ct >= a.n_coltiles) return;
   f32x16 acc[MTC];
 #pragma unroll
   for (int mt = 0; mt < MTC; ++mt) acc[mt] = (f32x16){0};
-  const float4* bp = a.bpack + ((int64_t)ct * a.Gd) * 64 + lane;
-  for (int g0 = 0; g0 < a.Gd; g0 += 4) {   // Gd is a multiple of 4
-    float4 b[4];
+  for (int g0 = 0; g0 < a.Gd; g0 += GCH) {   // Gd is a multiple of 4; GCH in {4, 16}
+    if (g0 > 0) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) b[g] = bp[(int64_t)(g0 + g) * 64];
+      for (int g = 0; g < GCH; ++g) b[g] = bp[(int64_t)min(g0 + g, a.Gd - 1) * 64];
+    }
 #pragma unroll
     for (int mt = 0; mt < MTC; ++mt) {
       const float* arow = &lds[(mt * 32 + i) * LDA + 4 * h + 8 * g0];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 av = *reinterpret_cast<const float4*>(arow + 8 * g);
-        acc[mt] = MFMA32(av.x, b[g].x, acc[mt]);
-        acc[mt] = MFMA32(av.y, b[g].y, acc[mt]);
-        acc[mt] = MFMA32(av.z, b[g].z, acc[mt]);
-        acc[mt] = MFMA32(av.w, b[g].w, acc[mt]);
+      for (int g = 0; g < GCH; ++g) {
+        if (g0 + g < a.Gd) {
+          const float4 av = *reinterpret_cast<const float4*>(arow + 8 * g);
+          acc[mt] = MFMA32(av.x, b[g].x, acc[mt]);
+          acc[mt] = MFMA32(av.y, b[g].y, acc[mt]);
+          acc[mt] = MFMA32(av.z, b[g].z, acc[mt]);
+          acc[mt] = MFMA32(av.w, b[g].w, acc[mt]);
+        }
       }
     }
   }
-  const int col = ct * 32 + i;
-  const float mu = a.mean[col];
+  if (!live) return;
 #pragma unroll
   for (int mt = 0; mt < MTC; ++mt) {
 #pragma unroll
@@ -247,9 +410,15 @@ hipError_t psm_launch_decode(const PsmDecodeArgs& a, hipStream_t st) {
     const int tiles = (a.Mpad - m_base) / 32;
     const int mtc = tiles >= 4 ? 4 : (tiles >= 2 ? 2 : 1);
     const size_t lds = (size_t)mtc * 32 * (a.ld_res + 4) * sizeof(float);
-    if (mtc == 4) hipLaunchKernelGGL((psm_decode_kernel<4>), dim3(nwg), dim3(256), lds, st, a, m_base);
-    else if (mtc == 2) hipLaunchKernelGGL((psm_decode_kernel<2>), dim3(nwg), dim3(256), lds, st, a, m_base);
-    else hipLaunchKernelGGL((psm_decode_kernel<1>), dim3(nwg), dim3(256), lds, st, a, m_base);
+    const bool g16 = (a.Gd % 16 == 0);
+#define DEC(M_, G_) hipLaunchKernelGGL((psm_decode_kernel<M_, G_>), dim3(nwg), dim3(256), lds, st, a, m_base)
+#define DEC128(M_) hipLaunchKernelGGL((psm_decode128_kernel<M_>), dim3(nwg), dim3(256), lds, st, a, m_base)
+    if (a.ld_res == 128) { if (mtc == 4) DEC128(4); else if (mtc == 2) DEC128(2); else DEC128(1); }
+    else if (mtc == 4) { if (g16) DEC(4, 16); else DEC(4, 4); }
+    else if (mtc == 2) { if (g16) DEC(2, 16); else DEC(2, 4); }
+    else { if (g16) DEC(1, 16); else DEC(1, 4); }
+#undef DEC
+#undef DEC128
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     m_base += mtc * 32;
@@ -258,7 +427,10 @@ hipError_t psm_launch_decode(const PsmDecodeArgs& a, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------
-// strips
+// strips: one workgroup per (block, band of 16 rows).  Every decoded value of the band
+// (the block's own and the previous block's, the latter under THIS block's mask) is read
+// once into registers; the band's contribution to each of the block's strip rectangles is
+// reduced over the workgroup and stored as a partial (sum per field, count).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -266,84 +438,381 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+template <int C_OUT>
 __global__ __launch_bounds__(256) void psm_strips_kernel(PsmStripArgs a) {
-  __shared__ float red[2][4];
+  constexpr int RB = PSM_STRIP_BAND;                 // rows per band
+  constexpr int RPT = RB / 2;                        // rows per thread (two half-bands of 128 columns)
+  __shared__ float2 colred[2][128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int e = blockIdx.x, f = blockIdx.y, cs = blockIdx.z;
-  const int32_t* st = a.strips + (int64_t)e * 6;
-  const int data = st[0], mask = st[1], r0 = st[2], r1 = st[3], c0 = st[4], c1 = st[5];
-  const int w = c1 - c0, n = w * (r1 - r0);
-  const int SS = a.S * a.S;
-  const float* pred = a.pred + ((int64_t)(cs * a.B + data) * SS) * a.c_out + f;
-  const float* gm = nullptr;
-  if (mask >= 0)
-    gm = a.grid + (((int64_t)cs * a.Ny + a.blk_y0x0[2 * mask]) * a.Nx + a.blk_y0x0[2 * mask + 1]) * a.c_in + a.sdf_ch;
-  float sum = 0.f, cnt = 0.f;
-  for (int idx = tid; idx < n; idx += 256) {
-    const int rr = idx / w, cc = idx - rr * w;
-    const int r = r0 + rr, c = c0 + cc;
-    bool on = true;
-    if (gm) on = gm[((int64_t)r * a.Nx + c) * a.c_in] != 0.f;
-    if (on) {
-      sum += pred[(int64_t)(r * a.S + c) * a.c_out];
-      cnt += 1.f;
+  const int b = blockIdx.x, band = blockIdx.y, cs = blockIdx.z;
+  const int S = a.S, SS = S * S;
+  const int c = tid & 127, half = tid >> 7;
+  const int rbase = band * RB + half * RPT;
+  const float* self = a.pred + ((int64_t)(cs * a.B + b) * SS + (int64_t)rbase * S + c) * C_OUT;
+  const float* prev = b > 0 ? self - (int64_t)SS * C_OUT : self;
+  const float* gm = a.grid + (((int64_t)cs * a.Ny + a.blk_y0x0[2 * b] + rbase) * a.Nx + a.blk_y0x0[2 * b + 1] + c) * a.c_in + a.sdf_ch;
+  float vs[RPT][C_OUT], vp[RPT][C_OUT];
+  bool on[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+#pragma unroll
+    for (int f = 0; f < C_OUT; ++f) {
+      vs[k][f] = self[(int64_t)k * S * C_OUT + f];
+      vp[k][f] = prev[(int64_t)k * S * C_OUT + f];
+    }
+    on[k] = gm[(int64_t)k * a.Nx * a.c_in] != 0.f;
+  }
+  const int NS = a.NS;
+  const int32_t* st = a.strips + (int64_t)b * NS * 6;
+  float4* outp = a.spart + (((int64_t)cs * a.B + b) * a.n_bands + band) * NS;
+  __shared__ float wsum[4][C_NS][3];
+#pragma unroll
+  for (int s = 0; s < C_NS; ++s) {
+    if (s < NS) {      // uniform
+      const int data = st[6 * s], mask = st[6 * s + 1], r0 = st[6 * s + 2], r1 = st[6 * s + 3], c0 = st[6 * s + 4], c1 = st[6 * s + 5];
+      float s0 = 0.f, s1 = 0.f, cnt = 0.f;
+      // rows of this band inside the rectangle? (uniform over the workgroup)
+      const bool live = !(r1 <= band * RB || r0 >= (band + 1) * RB || c1 <= c0);
+      if (live) {
+        if (c >= c0 && c < c1) {
+          const bool use_prev = (data != b);
+#pragma unroll
+          for (int k = 0; k < RPT; ++k) {
+            const int r = rbase + k;
+            if (r >= r0 && r < r1 && (mask < 0 || on[k])) {
+              s0 += use_prev ? vp[k][0] : vs[k][0];
+              if (C_OUT > 1) s1 += use_prev ? vp[k][C_OUT - 1] : vs[k][C_OUT - 1];
+              cnt += 1.f;
+            }
+          }
+        }
+        s0 = wave_sum(s0); s1 = wave_sum(s1); cnt = wave_sum(cnt);
+      }
+      if (lane == 0) { wsum[wave][s][0] = s0; wsum[wave][s][1] = s1; wsum[wave][s][2] = cnt; }
     }
   }
-  sum = wave_sum(sum);
-  cnt = wave_sum(cnt);
-  if (lane == 0) { red[0][wave] = sum; red[1][wave] = cnt; }
   __syncthreads();
-  if (tid == 0) {
-    const float S_ = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-    const float C_ = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-    a.sres[((int64_t)cs * a.c_out + f) * a.n_strips + e] = make_float2(S_, C_);
+  if (tid < NS) {
+    const int s = tid;
+    outp[s] = make_float4((wsum[0][s][0] + wsum[1][s][0]) + (wsum[2][s][0] + wsum[3][s][0]),
+                          (wsum[0][s][1] + wsum[1][s][1]) + (wsum[2][s][1] + wsum[3][s][1]),
+                          (wsum[0][s][2] + wsum[1][s][2]) + (wsum[2][s][2] + wsum[3][s][2]), 0.f);
+  }
+  // gradp: per-column sums of block 0, field 0 (first column holding a flow cell, UGP:294-300)
+  if (a.colpart && b == 0) {
+    float s0 = 0.f, cnt = 0.f;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k)
+      if (on[k]) { s0 += vs[k][0]; cnt += 1.f; }
+    colred[half][c] = make_float2(s0, cnt);
+    __syncthreads();
+    if (half == 0) {
+      const float2 u = colred[0][c], v = colred[1][c];
+      a.colpart[((int64_t)cs * a.n_bands + band) * 128 + c] = make_float2(u.x + v.x, u.y + v.y);
+    }
   }
 }
 
 hipError_t psm_launch_strips(const PsmStripArgs& a, int n_cases, hipStream_t st) {
-  hipLaunchKernelGGL(psm_strips_kernel, dim3(a.n_strips, a.c_out, n_cases), dim3(256), 0, st, a);
+  if (a.S != 128) return hipErrorInvalidValue;
+  if (a.c_out == 1) hipLaunchKernelGGL((psm_strips_kernel<1>), dim3(a.B, a.n_bands, n_cases), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((psm_strips_kernel<2>), dim3(a.B, a.n_bands, n_cases), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
-// chain (+ global shift)
+// chain (+ global shift): one workgroup per case.  All strip partials are combined into
+// LDS by the whole workgroup, lane 0 of wave f runs the serial recurrence of field f.
 // ---------------------------------------------------------------------------
-struct PsmStripView {
-  const float2* p;
-  __device__ float mean(int s) const { const float2 v = p[s]; return v.x / v.y; }   // 0/0 -> NaN like np.mean([])
-  __device__ float count(int s) const { return p[s].y; }
-};
-
-__global__ __launch_bounds__(64) void psm_chain_kernel(PsmChainArgs a) {
-  extern __shared__ float sm[];   // [PSM_MAX_COLS] up + [B] offs
-  float* up = sm;
-  float* offs = sm + PSM_MAX_COLS;
-  const int lane = threadIdx.x;
-  const int f = blockIdx.x, cs = blockIdx.y;
-  const int B = a.cp.B, SS = a.cp.S * a.cp.S;
-  PsmStripView sv{a.sres + ((int64_t)cs * a.c_out + f) * a.n_strips};
-  if (lane == 0) psm_chain<float>(a.cp, a.blocks, sv, f, up, offs);
-  __syncthreads();
-  float* go = a.offs + ((int64_t)cs * a.c_out + f) * B;
-  for (int b = lane; b < B; b += 64) go[b] = offs[b];
-  const int L = a.shiftL[f];
-  const int32_t* la = a.shiftA + (int64_t)f * a.Lmax;
-  const int32_t* lb = a.shiftB + (int64_t)f * a.Lmax;
-  const float* pred = a.pred + ((int64_t)cs * B * SS) * a.c_out + f;
-  float acc = 0.f;
-  for (int k = lane; k < L; k += 64) {
-    const int oa = a.owner[la[k]], ob = a.owner[lb[k]];
-    const float va = oa >= 0 ? pred[(int64_t)oa * a.c_out] - offs[oa / SS] : 0.f;
-    const float vb = ob >= 0 ? pred[(int64_t)ob * a.c_out] - offs[ob / SS] : 0.f;
-    acc += 3.f * va - vb;
+// Row-parallel form of the offset chain (one wave per field, lane = position of the block
+// in its row).  Blocks of one row only depend on each other through the value handed from the
+// previously enumerated block (c_prev in SMD/UGP, BC_ant_0 / BC_alter in PM); inside a row
+// that hand-over is needed by the whole first row and, elsewhere, only by blocks whose
+// BC_ups entry is NaN.  So every row is evaluated lane-parallel from the block above
+// (BC_ups is lane-local), followed by an in-order fix-up loop over just the lanes that need
+// the hand-over -- the same arithmetic, in the same order, as the serial recurrence
+// (psm_chain_v in psm_plan.h, which stays the host replay and the fallback for > 64 columns).
+template <int VARIANT>
+__device__ __forceinline__ void psm_chain_rows(const PsmChainParams& P, const float* smean, const float* scnt,
+                                               const PsmBlock* blk, int field, int lane, float* offs_out) {
+  const int n_x = P.n_x, n_y = P.n_y, NS = P.NS;
+  const int ncol = (VARIANT == PSMV_CHAPTER5) ? n_x + 2 : n_x + 1;
+  const int nrow = n_y + 2;
+  const bool act = lane < ncol;
+  const int l = act ? lane : 0;
+  int tj;
+  if (VARIANT == PSMV_GRADP) tj = l;
+  else if (VARIANT == PSMV_DELTAS) tj = n_x - l;
+  else tj = (l <= n_x) ? n_x - l : -1;
+  const float ref = P.ref_bc;
+  float first_col = NAN;                                      // UGP:294-300
+  if (VARIANT == PSMV_GRADP && field == 0)
+    for (int c = 0; c < 128; ++c)
+      if (scnt[P.col_base + c] > 0.f) { first_col = smean[P.col_base + c]; break; }
+  float up = (VARIANT == PSMV_CHAPTER5 && tj == -1) ? NAN : 0.f;   // BC_ups[tj] / BC_up_
+  float carry = (VARIANT == PSMV_CHAPTER5) ? NAN : 0.f;             // c_prev | BC_ant_0 / BC_alter
+  auto rl = [](float v, int q) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), q)); };
+  for (int r = 0; r < nrow; ++r) {
+    const int b = r * ncol + l;
+    const bool first = (r == 0), last = (r == n_y + 1);
+    if (last && P.skip_last) {                                // duplicate last row left out (uniform)
+      if (act) offs_out[b] = NAN;
+      continue;
+    }
+    const float* mp = smean + b * NS;
+    const bool unan = (up != up);
+    float A, Bm = 0.f, L = 0.f, c;
+    bool need;
+    if (VARIANT == PSMV_DELTAS) {
+      const bool lim = (tj == 0);
+      A = lim ? mp[D_CUR_R_LIM] : mp[D_CUR_R_OV];
+      Bm = lim ? mp[D_PREV_L_LIM] : mp[D_PREV_L_OV];
+      if (first) { c = mp[D_COL_LAST] - ref; need = (lane != 0); }
+      else if (!last) { c = mp[D_TOP] - up; need = unan && !(tj != 0 && tj == n_x); }
+      else {
+        const bool use_side = scnt[b * NS + D_ROWS_UP] / 16384.f > 0.9f;   // SMD:307
+        c = (tj == n_x) ? mp[D_ROWS_UP] - up : mp[D_ROWS_HEAD] - up;
+        need = (tj != n_x) && use_side;
+      }
+    } else if (VARIANT == PSMV_GRADP) {
+      const bool lim = (tj == n_x);
+      A = lim ? mp[G_CUR_L_LIM] : mp[G_CUR_L_OV];
+      Bm = lim ? mp[G_PREV_R_LIM] : mp[G_PREV_R_OV];
+      if (first) { c = (field == 0 ? first_col : mp[G_ROW1]) - ref; need = (lane != 0); }
+      else { c = (last ? mp[G_ROWS_UP] : mp[G_TOP]) - up; need = unan; }
+    } else {
+      const bool m1 = (tj == -1), nx = (tj == n_x);
+      A = (first && m1) ? mp[C_COLS_C] : mp[C_COLS_R];
+      L = mp[C_COLS_0];
+      if (first) { c = mp[C_COLS_R] - 0.f; need = !nx; }
+      else if (!last) { c = (m1 ? mp[C_TOPC] : mp[C_TOP]) - up; need = !m1 && unan; }
+      else { c = (m1 ? mp[C_TC] : mp[C_ROWS_T]) - up; need = !m1 && unan; }
+    }
+    unsigned long long todo = __ballot(need && act);
+    while (todo) {                                            // in enumeration order
+      const int q = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const float out_prev = (VARIANT == PSMV_CHAPTER5) ? L - c : c;
+      const float cin = (q == 0) ? carry : rl(out_prev, q > 0 ? q - 1 : 0);
+      const float cnew = (VARIANT == PSMV_CHAPTER5) ? A - cin : A - (Bm - cin);
+      c = (lane == q) ? cnew : c;
+    }
+    carry = rl((VARIANT == PSMV_CHAPTER5) ? L - c : c, ncol - 1);
+    if (VARIANT == PSMV_DELTAS) {
+      if (!last) up = ((!first && r == n_y) ? mp[D_ROWS_PI] : mp[D_BOTTOM]) - c;
+    } else if (VARIANT == PSMV_GRADP) {
+      if (!last) up = ((!first && r == n_y) ? mp[G_ROWS_PI] : mp[G_BOTTOM]) - c;
+    } else {
+      const bool m1 = (tj == -1), nx = (tj == n_x);
+      if (first) up = (nx ? mp[C_RR] : (m1 ? mp[C_RC] : mp[C_ROWS_R])) - c;
+      else if (!last) up = (m1 ? mp[C_RC_UNMASKED] : mp[C_ROWS_R]) - c;
+    }
+    if (act) offs_out[b] = c;
   }
-  acc = wave_sum(acc);
-  if (lane == 0) a.shift[cs * a.c_out + f] = acc / (float)L / 3.f;
+}
+
+__device__ __forceinline__ void psm_chain_wave(const PsmChainParams& P, const float* smean, const float* scnt,
+                                               const PsmBlock* blk, int field, int lane, float* offs_out) {
+  if (P.variant == PSMV_DELTAS) psm_chain_rows<PSMV_DELTAS>(P, smean, scnt, blk, field, lane, offs_out);
+  else if (P.variant == PSMV_GRADP) psm_chain_rows<PSMV_GRADP>(P, smean, scnt, blk, field, lane, offs_out);
+  else psm_chain_rows<PSMV_CHAPTER5>(P, smean, scnt, blk, field, lane, offs_out);
+}
+
+__global__ __launch_bounds__(512) void psm_chain_kernel(PsmChainArgs a) {
+  constexpr int NB = 128 / PSM_STRIP_BAND;            // bands per block
+  extern __shared__ float sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cs = blockIdx.x;
+  const int B = a.cp.B, SS = a.cp.S * a.cp.S, NS = a.cp.NS, C = a.c_out;
+  const int nst = a.n_strips;                         // B*NS (+128 column strips for gradp)
+  float* smean = sm;                                  // [C][nst]  sum/count (0/0 -> NaN like np.mean([]))
+  float* scnt = smean + C * nst;                      // [nst]
+  float* offs = scnt + nst;                           // [C][B]
+  float* up = offs + C * B;                           // [C][PSM_MAX_COLS] (fallback path only)
+  float* wred = up + C * PSM_MAX_COLS;                // [8]
+  const float4* sp = a.spart + (int64_t)cs * B * NB * NS;
+  for (int idx = tid; idx < B * NS; idx += 512) {
+    const int b = idx / NS, s = idx - b * NS;
+    float4 v[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) v[q] = sp[((int64_t)b * NB + q) * NS + s];   // all bands in flight
+    float s0 = 0.f, s1 = 0.f, cn = 0.f;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) { s0 += v[q].x; s1 += v[q].y; cn += v[q].z; }
+    smean[idx] = s0 / cn;
+    if (C > 1) smean[nst + idx] = s1 / cn;
+    scnt[idx] = cn;
+  }
+  if (a.colpart) {
+    for (int c = tid; c < 128; c += 512) {
+      float2 v[NB];
+#pragma unroll
+      for (int q = 0; q < NB; ++q) v[q] = a.colpart[((int64_t)cs * NB + q) * 128 + c];
+      float s0 = 0.f, cn = 0.f;
+#pragma unroll
+      for (int q = 0; q < NB; ++q) { s0 += v[q].x; cn += v[q].y; }
+      smean[B * NS + c] = s0 / cn;
+      if (C > 1) smean[nst + B * NS + c] = 0.f;
+      scnt[B * NS + c] = cn;
+    }
+  }
+  for (int idx = tid; idx < C * PSM_MAX_COLS; idx += 512) up[idx] = 0.f;
+  __syncthreads();
+  if (wave < C) {
+    if (a.cp.n_x + 2 <= 64) {
+      psm_chain_wave(a.cp, smean + wave * nst, scnt, a.blocks, wave, lane, offs + wave * B);
+    } else if (lane == 0) {
+      PsmArrayChainCtx<float> cx{a.blocks, smean + wave * nst, scnt, NS, a.cp.col_base, a.cp.S, up + wave * PSM_MAX_COLS, offs + wave * B};
+      psm_chain<float>(a.cp, cx, wave);
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < C * B; idx += 512) a.offs[(int64_t)cs * C * B + idx] = offs[idx];
+  for (int f = 0; f < C; ++f) {
+    const int L = a.shiftL[f];
+    const int32_t* la = a.shiftA + (int64_t)f * a.Lmax;
+    const int32_t* lb = a.shiftB + (int64_t)f * a.Lmax;
+    const float* pred = a.pred + ((int64_t)cs * B * SS) * C + f;
+    float acc = 0.f;
+    for (int k = tid; k < L; k += 512) {
+      const int oa = a.owner[la[k]], ob = a.owner[lb[k]];
+      const float va = oa >= 0 ? pred[(int64_t)oa * C] - offs[f * B + oa / SS] : 0.f;
+      const float vb = ob >= 0 ? pred[(int64_t)ob * C] - offs[f * B + ob / SS] : 0.f;
+      acc += 3.f * va - vb;
+    }
+    acc = wave_sum(acc);
+    __syncthreads();
+    if (lane == 0) wred[wave] = acc;
+    __syncthreads();
+    if (tid == 0) {
+      float t = 0.f;
+      for (int w = 0; w < 8; ++w) t += wred[w];
+      a.shift[cs * C + f] = t / (float)L / 3.f;
+    }
+  }
 }
 
 hipError_t psm_launch_chain(const PsmChainArgs& a, int n_cases, hipStream_t st) {
-  const size_t lds = (size_t)(PSM_MAX_COLS + a.cp.B) * sizeof(float);
-  hipLaunchKernelGGL(psm_chain_kernel, dim3(a.c_out, n_cases), dim3(64), lds, st, a);
+  const size_t lds = ((size_t)a.c_out * a.n_strips + a.n_strips + (size_t)a.c_out * a.cp.B + (size_t)a.c_out * PSM_MAX_COLS + 8) * sizeof(float);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(psm_chain_kernel, dim3(n_cases), dim3(512), lds, st, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// assemble = chain + shift + paste in one launch (small block counts): every paste
+// workgroup re-runs the (cheap, register-resident) offset chain instead of waiting for a
+// separate one-workgroup launch.  The global shift is split into a part that does not
+// depend on the offsets (gathered while the strip partials are in flight) and a weighted
+// sum of the offsets:  shift = sum_k(3 pred[A_k] - pred[B_k])/(3L) - sum_b w_b offs_b.
+// ---------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void psm_assemble_kernel(PsmChainArgs a, PsmPasteArgs p) {
+  constexpr int NB = 128 / PSM_STRIP_BAND;
+  extern __shared__ float sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cs = blockIdx.y;
+  const int B = a.cp.B, SS = a.cp.S * a.cp.S, NS = a.cp.NS;
+  const int nst = a.n_strips;
+  float* smean = sm;                                  // [C][nst]
+  float* scnt = smean + C * nst;                      // [nst]
+  float* offs = scnt + nst;                           // [C][B]
+  float* wred = offs + C * B;                         // [C][4] + [C] shift
+  PSM_STAMP(a.stamps, 0);
+  // this thread's cell: issue its gather early
+  const int pix = blockIdx.x * 256 + tid;
+  const int o = pix < p.npix ? a.owner[pix] : -1;
+  const float* predc = a.pred + ((int64_t)cs * B * SS) * C;
+  float src[C];
+#pragma unroll
+  for (int f = 0; f < C; ++f) src[f] = o >= 0 ? predc[(int64_t)o * C + f] : 0.f;
+  // strip partials -> means
+  const float4* sp = a.spart + (int64_t)cs * B * NB * NS;
+  for (int idx = tid; idx < B * NS; idx += 256) {
+    const int b = idx / NS, s = idx - b * NS;
+    float4 v[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) v[q] = sp[((int64_t)b * NB + q) * NS + s];
+    float s0 = 0.f, s1 = 0.f, cn = 0.f;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) { s0 += v[q].x; s1 += v[q].y; cn += v[q].z; }
+    smean[idx] = s0 / cn;
+    if (C > 1) smean[nst + idx] = s1 / cn;
+    scnt[idx] = cn;
+  }
+  if (a.colpart) {
+    for (int c = tid; c < 128; c += 256) {
+      float2 v[NB];
+#pragma unroll
+      for (int q = 0; q < NB; ++q) v[q] = a.colpart[((int64_t)cs * NB + q) * 128 + c];
+      float s0 = 0.f, cn = 0.f;
+#pragma unroll
+      for (int q = 0; q < NB; ++q) { s0 += v[q].x; cn += v[q].y; }
+      smean[B * NS + c] = s0 / cn;
+      if (C > 1) smean[nst + B * NS + c] = 0.f;
+      scnt[B * NS + c] = cn;
+    }
+  }
+  // offset-independent part of the shift
+  float pp[C];
+#pragma unroll
+  for (int f = 0; f < C; ++f) {
+    const int L = a.shiftL[f];
+    const int32_t* oa = a.shiftOwnA + (int64_t)f * a.Lmax;
+    const int32_t* ob = a.shiftOwnB + (int64_t)f * a.Lmax;
+    float acc = 0.f;
+    for (int k = tid; k < L; k += 256) {
+      const int ia = oa[k], ib = ob[k];
+      const float va = ia >= 0 ? predc[(int64_t)ia * C + f] : 0.f;
+      const float vb = ib >= 0 ? predc[(int64_t)ib * C + f] : 0.f;
+      acc += 3.f * va - vb;
+    }
+    pp[f] = wave_sum(acc);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int f = 0; f < C; ++f) wred[f * 4 + wave] = pp[f];
+  }
+  __syncthreads();
+  PSM_STAMP(a.stamps, 1);
+  if (wave < C) {
+    PSM_STAMP(a.stamps, 2);
+    psm_chain_wave(a.cp, smean + wave * nst, scnt, a.blocks, wave, lane, offs + wave * B);
+    PSM_STAMP(a.stamps, 3);
+    // shift of this field: weighted sum of the offsets (B <= 64 on this path); same-wave LDS
+    // writes above are visible to the wave's own later reads
+    const float w = lane < B ? a.shiftW[wave * B + lane] : 0.f;
+    float t = (w != 0.f) ? w * offs[wave * B + lane] : 0.f;
+    t = wave_sum(t);
+    if (lane == 0) {
+      const float part = (wred[wave * 4 + 0] + wred[wave * 4 + 1]) + (wred[wave * 4 + 2] + wred[wave * 4 + 3]);
+      wred[4 * C + wave] = part / (float)a.shiftL[wave] / 3.f - t;
+    }
+  }
+  __syncthreads();
+  PSM_STAMP(a.stamps, 4);
+  if (blockIdx.x == 0) {       // introspection copies (psm_read_stage)
+    for (int idx = tid; idx < C * B; idx += 256) a.offs[(int64_t)cs * C * B + idx] = offs[idx];
+    if (tid < C) a.shift[cs * C + tid] = wred[4 * C + tid];
+  }
+  if (pix >= p.npix) return;
+  float* out = p.fields + ((int64_t)cs * p.npix + pix) * C;
+  if (o < 0) {
+#pragma unroll
+    for (int f = 0; f < C; ++f) out[f] = 0.f;
+    return;
+  }
+  const int b = o / SS;
+#pragma unroll
+  for (int f = 0; f < C; ++f) out[f] = src[f] - offs[f * B + b] - wred[4 * C + f];
+  PSM_STAMP(a.stamps, 5);
+}
+
+hipError_t psm_launch_assemble(const PsmChainArgs& a, const PsmPasteArgs& p, int n_cases, hipStream_t st) {
+  const size_t lds = ((size_t)a.c_out * a.n_strips + a.n_strips + (size_t)a.c_out * a.cp.B + 6 * a.c_out + 8) * sizeof(float);
+  const dim3 grid((p.npix + 255) / 256, n_cases);
+  if (a.c_out == 1) hipLaunchKernelGGL((psm_assemble_kernel<1>), grid, dim3(256), lds, st, a, p);
+  else hipLaunchKernelGGL((psm_assemble_kernel<2>), grid, dim3(256), lds, st, a, p);
   return hipGetLastError();
 }
 

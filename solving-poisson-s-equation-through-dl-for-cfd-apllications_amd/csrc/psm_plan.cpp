@@ -103,6 +103,7 @@ int psm_build_plan(int variant, int Ny, int Nx, int S, int ov, bool strict, PsmP
   }
   const bool skip_last = (variant != PSMV_CHAPTER5) && P.p_i == 0 && !strict;
   for (auto& b : plan.blocks) b.skip = (skip_last && b.ti == n_y + 1) ? 1 : 0;
+  P.skip_last = skip_last ? 1 : 0;
 
   // ---- strips ---------------------------------------------------------------
   const int NS = P.NS;

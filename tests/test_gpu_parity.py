@@ -152,8 +152,9 @@ def test_big_architecture_and_many_components():
     assert np.abs(f - sol.fields).max() <= 1e-4 * np.abs(sol.fields).max()
 
 
-def test_device_pointer_api_graph_and_eager_agree():
+def test_device_pointer_api_graph_and_eager_agree(monkeypatch):
     import torch
+    monkeypatch.setenv("PSM_GRAPH", "1")          # this handle replays a captured hipGraph
     model = synthetic.make_model("gradp", p_in=64, p_out=64)
     grid = synthetic.channel_grid(256, 256, seed=1).astype(np.float32)
     with GridSurrogate(model, 256, 256) as sur:
