@@ -8,7 +8,7 @@ configs[1] -- 256x256 channel-with-obstacle U_to_gradP inference, batch 1, fp32,
 P_i = P_o = 128, MLP 3x512 (SURVEY.md §8 d config 1; synthetic seeded input,
 seeded random-init weights of that architecture).  One step = one solve
 (grid[256,256,3] -> fields[256,256,2]) through the C-ABI with the input already
-resident in HBM; steps are issued back to back on one stream (hipGraph replay),
+resident in HBM; steps are issued back to back on one stream (plain launches),
 K steps are timed between barrier + synchronize on both sides, MAX over ranks.
 For N > 1 each rank drives its own GPU with its own independent cases (the case
 batch is sharded, no data-path collective); RCCL is used only for the barrier
@@ -16,8 +16,11 @@ and the max-reduction of the time.
 
 Extra objects on the JSON line:
   roofline     dominant kernel (encode) : algorithmic bytes per launch / average
-               launch duration measured with HIP events on the launch stream in an
-               instrumented pass over the same K steps right after the timed region.
+               launch duration measured with HIP events on the launch stream
+               (hipExtLaunchKernel start/stop events = the dispatch's own begin/end) in
+               an instrumented pass over the same K steps right after the timed region;
+               "traffic" = HBM-side bytes per launch from the committed PMC run
+               (profiles/pmc_encode.json: 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction).
   cpu_baseline the NumPy oracle ("port" of the reference's algorithm, float64 PCA +
                float32 MLP like the reference) timed on the host cores, rank 0, N=1.
 """
@@ -46,7 +49,7 @@ def algorithmic_bytes(model, ny, nx):
     return {"encode": enc, "decode": dec, "mlp": mlp, "total": enc + dec + mlp}
 
 
-def cpu_baseline(model, grid, budget_s=12.0, max_solves=40):
+def cpu_baseline(model, grid, budget_s=12.0, max_solves=2000):
     """Time the oracle on the host cores (bounded sample of the same workload)."""
     from oracle import psm_oracle as orc
     try:
@@ -126,7 +129,8 @@ def main():
     ab = algorithmic_bytes(model, NY, NX)
     prof = sur.profile(d_in[0].data_ptr(), 1, d_out[0].data_ptr())
     dom = "encode"
-    sur.enable_kernel_timing(dom)
+    REPEAT = 1            # every launch of the timed region's pipeline, one event pair each (hipExtLaunchKernel)
+    sur.enable_kernel_timing(dom, True, REPEAT)
     for i in range(args.steps):
         step(i)
     tot_ms, launches = sur.kernel_timing(dom)
@@ -143,6 +147,7 @@ def main():
     roofline = {"kernel": "psm_encode_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes": ab[dom], "avg_launch_us": avg_s * 1e6, "launches": launches,
+                "launches_per_event_pair": REPEAT,
                 "per_kernel_ms_one_solve": prof}
 
     out = {

@@ -146,9 +146,16 @@ int psm_read_stage(psm_handle* h, int32_t stage, float* dst, size_t dst_floats);
 int psm_profile_solve(psm_handle* h, const float* d_grid, int32_t n_cases,
                       float* d_fields, float* ms);
 /* Accumulated device time (ms) and launch count of kernel group `k`, measured
- * with HIP events on the launch stream while event timing is enabled. */
+ * with HIP events on the launch stream while event timing is enabled.
+ * on = 0 disables; on = R >= 1 launches the (idempotent) group R times back to
+ * back between the two events of every solve, which amortises the ~2.7 us an
+ * event pair adds to a single launch. */
 int psm_enable_kernel_timing(psm_handle* h, int32_t kernel, int32_t on);
 int psm_get_kernel_timing(psm_handle* h, int32_t kernel, double* total_ms, int64_t* launches);
+
+/* Median elapsed time (ms) of `n` EMPTY HIP event pairs recorded back to back on the launch
+ * stream: the cost of the event timing itself, to be subtracted from per-launch event times. */
+int psm_event_pair_overhead(psm_handle* h, int32_t n, double* median_ms);
 
 /* ---- host-only helpers (no GPU needed) ----------------------------------- */
 /* Block layout of a variant: writes up to `cap` rows of (y0, x0, idx_i, idx_j)

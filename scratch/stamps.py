@@ -8,11 +8,16 @@ grid = synthetic.channel_grid(256,256,seed=1).astype(np.float32)
 with psm_amd.GridSurrogate(model,256,256) as sur:
     d_in = torch.from_numpy(grid).cuda(); d_out = torch.empty((256,256,2),dtype=torch.float32,device="cuda")
     acc=[]
-    for it in range(50):
-        sur.solve_device(d_in.data_ptr(),1,d_out.data_ptr(),0)
+    for it in range(60):
+        for k in range(3): sur.solve_device(d_in.data_ptr(),1,d_out.data_ptr(),0)
         sur.synchronize()
-        out=np.zeros(15,np.float32)
-        sur._chk(sur.lib.psm_read_stage(sur.h,5,out.ctypes.data_as(C.POINTER(C.c_float)),15))
+        out=np.zeros(64,np.float32)
+        sur._chk(sur.lib.psm_read_stage(sur.h,5,out.ctypes.data_as(C.POINTER(C.c_float)),64))
         acc.append(out.copy())
     a=np.median(np.array(acc[10:]),axis=0)
-    print("assemble stamps (us): phase1=%.2f  reload=%.2f  chain=%.2f  post=%.2f  paste=%.2f"%tuple(a[:5]))
+    print("encode  : stage(A loads,B issue,LDS,barrier)=%.2f  mfma+store=%.2f"%(a[0],a[1]))
+    print("reduce  : loads+sum=%.2f"%a[8])
+    print("dense   : loads+mfma=%.2f  reduce+store=%.2f"%(a[12],a[13]))
+    print("decode  : stage=%.2f  mfma=%.2f  store=%.2f"%(a[20],a[21],a[22]))
+    print("strips  : loads=%.2f  slots=%.2f"%(a[28],a[29]))
+    print("assemble: phase1=%.2f  pre=%.2f  chain=%.2f  post=%.2f  paste=%.2f"%tuple(a[36:41]))

@@ -60,6 +60,7 @@ SIGNATURES = {
     "psm_profile_solve": (C.c_int, [_hp, C.c_void_p, C.c_int32, C.c_void_p, _f32p]),
     "psm_enable_kernel_timing": (C.c_int, [_hp, C.c_int32, C.c_int32]),
     "psm_get_kernel_timing": (C.c_int, [_hp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "psm_event_pair_overhead": (C.c_int, [_hp, C.c_int32, C.POINTER(C.c_double)]),
     "psm_layout": (C.c_int, [C.c_int32] * 5 + [_i32p, C.c_int32, _i32p, _i32p]),
     "psm_owner_map": (C.c_int, [C.c_int32] * 6 + [_i32p]),
     "psm_debug_reassemble_host": (C.c_int, [C.c_int32] * 9 + [_f32p, _f32p, _f32p, _f32p, _f32p]),

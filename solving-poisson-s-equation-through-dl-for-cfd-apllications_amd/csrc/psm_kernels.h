@@ -77,7 +77,9 @@ struct PsmPasteArgs {
   int B, S, c_out, npix;
 };
 
-hipError_t psm_launch_encode(const PsmEncodeArgs& a, hipStream_t s);
+hipError_t psm_read_stamps(unsigned long long* out);   // [64]; zeros unless built with -DPSM_STAMPS
+// ev_start / ev_stop (optional): stamped with the dispatch's own begin / end (hipExtLaunchKernel)
+hipError_t psm_launch_encode(const PsmEncodeArgs& a, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t psm_launch_reduce(const PsmReduceArgs& a, hipStream_t s);
 hipError_t psm_launch_dense(const PsmDenseArgs& a, hipStream_t s);
 hipError_t psm_launch_decode(const PsmDecodeArgs& a, hipStream_t s);

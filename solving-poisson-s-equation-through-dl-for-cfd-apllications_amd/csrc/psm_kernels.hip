@@ -17,15 +17,20 @@
 // lane half h) so that one 16-byte read per lane feeds four MFMAs; both operands use it.
 #include "psm_kernels.h"
 
+#include <hip/hip_ext.h>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 // Diagnostic stamps (100 MHz wall clock) -- compiled only with -DPSM_STAMPS, never in the shipped library.
 #ifdef PSM_STAMPS
-#define PSM_STAMP(buf, k) do { if ((buf) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) (buf)[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ unsigned long long g_psm_stamps[64];
+#define PSM_STAMP(buf, k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_psm_stamps[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+hipError_t psm_read_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_psm_stamps), sizeof(g_psm_stamps)); }
 #else
 #define PSM_STAMP(buf, k) do { } while (0)
+hipError_t psm_read_stamps(unsigned long long* out) { for (int i = 0; i < 64; ++i) out[i] = 0; return hipSuccess; }
 #endif
 
 __device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
@@ -56,7 +61,7 @@ __global__ __launch_bounds__(256) void psm_encode_kernel(PsmEncodeArgs a) {
   auto load_rows = [&](float4 (&x)[8], int m0, int row0) {    // rows row0 + wave + 4u (u < 8) of chunk m0
     int64_t rb[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) rb[u] = a.row_base[min(m0 + row0 + wave + 4 * u, a.M - 1)];   // scalar loads
+    for (int u = 0; u < 8; ++u) rb[u] = a.row_base[min(m0 + row0 + wave + 4 * u, a.M - 1)];   // wave-uniform: scalar loads
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const float* src = a.grid + rb[u] + src_off + 4 * ql;
@@ -104,6 +109,7 @@ __global__ __launch_bounds__(256) void psm_encode_kernel(PsmEncodeArgs a) {
     // wave without a tile of its own recomputes the last one and stores nothing): keeps the
     // weight loads unconditional, ahead of the barrier.
     const int t = min(wave, NT - 1);
+    PSM_STAMP(0, 0);
     float4 x0[8];
     load_rows(x0, 0, 0);                        // first 32 rows: loads issued BEFORE the weights
     __builtin_amdgcn_sched_barrier(0);
@@ -117,8 +123,10 @@ __global__ __launch_bounds__(256) void psm_encode_kernel(PsmEncodeArgs a) {
     write_rows(x0, 0, 0);                       // waits for the activation rows only (counted vmcnt)
     for (int row0 = 32; row0 < a.Mpad; row0 += 32) stage_rows(0, row0);
     __syncthreads();
+    PSM_STAMP(0, 1);
     gemm_tile(b, 0, t, 0, wave < NT);           // peeled: counted waits on the weight stream
     for (int mt = 1; mt < a.Mpad / 32; ++mt) gemm_tile(b, mt, t, 0, wave < NT);
+    PSM_STAMP(0, 2);
     return;
   }
 
@@ -142,20 +150,22 @@ __global__ __launch_bounds__(256) void psm_encode_kernel(PsmEncodeArgs a) {
   }
 }
 
-hipError_t psm_launch_encode(const PsmEncodeArgs& a, hipStream_t st) {
+hipError_t psm_launch_encode(const PsmEncodeArgs& a, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
   const int n_slices = a.S * a.S / PSM_PIX_PER_SLICE;
   const int rows = a.Mpad < 32 * PSM_MT_CHUNK ? a.Mpad : 32 * PSM_MT_CHUNK;
   const size_t lds = (size_t)rows * (PSM_PIX_PER_SLICE * a.c_in + 4) * sizeof(float);
-#define ENC(C)                                                                                   \
-  case C:                                                                                        \
-    if (a.aligned) hipLaunchKernelGGL((psm_encode_kernel<C, true>), dim3(n_slices), dim3(256), lds, st, a); \
-    else hipLaunchKernelGGL((psm_encode_kernel<C, false>), dim3(n_slices), dim3(256), lds, st, a); \
-    break;
+  // With events: hipExtLaunchKernelGGL stamps them with the dispatch's own begin / end times
+  // (the source rocprofv3 reads), not with separate marker packets around the launch.
+#define ENC2(C, AL)                                                                                          \
+  if (ev_start) hipExtLaunchKernelGGL((psm_encode_kernel<C, AL>), dim3(n_slices), dim3(256), (std::uint32_t)lds, st, ev_start, ev_stop, 0, a); \
+  else hipLaunchKernelGGL((psm_encode_kernel<C, AL>), dim3(n_slices), dim3(256), lds, st, a)
+#define ENC(C) case C: if (a.aligned) { ENC2(C, true); } else { ENC2(C, false); } break;
   switch (a.c_in) {
     ENC(1) ENC(2) ENC(3) ENC(4)
     default: return hipErrorInvalidValue;
   }
 #undef ENC
+#undef ENC2
   return hipGetLastError();
 }
 
@@ -170,6 +180,7 @@ __global__ __launch_bounds__(1024) void psm_reduce_kernel(PsmReduceArgs a) {
   const int per = (a.n_slices + 15) / 16;
   const int s0 = wave * per, s1 = min(a.n_slices, s0 + per);
   const float* p = a.part + o;
+  PSM_STAMP(0, 8);
   float acc = 0.f;
   int s = s0;
   for (; s + 16 <= s1; s += 16) {
@@ -182,6 +193,7 @@ __global__ __launch_bounds__(1024) void psm_reduce_kernel(PsmReduceArgs a) {
   for (; s < s1; ++s) acc += p[(int64_t)s * total];
   red[wave][lane] = acc;
   __syncthreads();
+  PSM_STAMP(0, 9);
   if (wave == 0) {
     float v = 0.f;
 #pragma unroll
@@ -215,6 +227,11 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a) {
   const int i = lane & 15, kq = lane >> 4;
   const int klen = a.Kpad / 8;                       // per wave; Kpad multiple of 32 -> klen multiple of 4
   const int k0 = wave * klen;
+  PSM_STAMP(0, 12);
+  // epilogue operands of this thread's output column: in flight from the start
+  const int n_out = nt * 16 + (tid & 15);
+  const float bias_v = a.bias[n_out];
+  const float sa_v = a.head ? a.sa[n_out] : 1.f, sb_v = a.head ? a.sb[n_out] : 0.f;
   f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
   const float* arow0 = a.in + (int64_t)(mt * 32 + i) * a.ld_in + k0 + 4 * kq;
   const float* arow1 = arow0 + (int64_t)16 * a.ld_in;
@@ -252,6 +269,7 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a) {
     acc1 = MFMA16(av1, wv, acc1);
   }
   (void)rem;
+  PSM_STAMP(0, 13);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     red[wave][0][(4 * kq + r) * 17 + i] = acc0[r];
@@ -264,12 +282,12 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a) {
     float v = 0.f;
 #pragma unroll
     for (int w8 = 0; w8 < 8; ++w8) v += red[w8][half][r16 * 17 + col];
-    const int n = nt * 16 + col;
-    v += a.bias[n];
+    v += bias_v;
     if (a.relu) v = fmaxf(v, 0.f);
-    if (a.head) v = v * a.sa[n] + a.sb[n];
-    a.out[(int64_t)(mt * 32 + row) * a.ld_out + n] = v;
+    if (a.head) v = v * sa_v + sb_v;
+    a.out[(int64_t)(mt * 32 + row) * a.ld_out + n_out] = v;
   }
+  PSM_STAMP(0, 14);
 }
 
 hipError_t psm_launch_dense(const PsmDenseArgs& a, hipStream_t st) {
@@ -307,8 +325,10 @@ __global__ __launch_bounds__(256) void psm_decode128_kernel(PsmDecodeArgs a, int
       *reinterpret_cast<v4f*>(&lds[row * LDA + 4 * q]) = x[u];
     }
   };
+  PSM_STAMP(0, 20);
   v4f x[NA];
   load_tile(x);
+  const float rs = a.row_scale[min(m_base + (tid & (MTC * 32 - 1)), a.Mpad - 1)];
   __builtin_amdgcn_sched_barrier(0);
   float4 b[GD];
   const float4* bp = a.bpack + ((int64_t)ct * GD) * 64 + lane;
@@ -318,7 +338,10 @@ __global__ __launch_bounds__(256) void psm_decode128_kernel(PsmDecodeArgs a, int
   const float mu = a.mean[col];
   __builtin_amdgcn_sched_barrier(0);
   write_tile(x);
+  float* lrs = lds + MTC * 32 * LDA;           // [MTC*32] out_scale per block row
+  if (tid < MTC * 32) lrs[tid] = rs;
   __syncthreads();
+  PSM_STAMP(0, 21);
   f32x16 acc[MTC];
 #pragma unroll
   for (int mt = 0; mt < MTC; ++mt) {
@@ -335,15 +358,18 @@ __global__ __launch_bounds__(256) void psm_decode128_kernel(PsmDecodeArgs a, int
       av = an;
     }
   }
+  PSM_STAMP(0, 22);
   if (!live) return;
 #pragma unroll
   for (int mt = 0; mt < MTC; ++mt) {
 #pragma unroll
     for (int rg = 0; rg < 16; ++rg) {
-      const int m = m_base + mt * 32 + acc_row(rg, h);
-      if (m < a.M) a.pred[(int64_t)m * a.K_out + col] = (acc[mt][rg] + mu) * a.row_scale[m];
+      const int rr = mt * 32 + acc_row(rg, h);
+      const int m = m_base + rr;
+      if (m < a.M) a.pred[(int64_t)m * a.K_out + col] = (acc[mt][rg] + mu) * lrs[rr];
     }
   }
+  PSM_STAMP(0, 23);
 }
 
 template <int MTC, int GCH>   // GCH: groups of 8 k whose weights are prefetched together
@@ -412,13 +438,16 @@ hipError_t psm_launch_decode(const PsmDecodeArgs& a, hipStream_t st) {
     const size_t lds = (size_t)mtc * 32 * (a.ld_res + 4) * sizeof(float);
     const bool g16 = (a.Gd % 16 == 0);
 #define DEC(M_, G_) hipLaunchKernelGGL((psm_decode_kernel<M_, G_>), dim3(nwg), dim3(256), lds, st, a, m_base)
-#define DEC128(M_) hipLaunchKernelGGL((psm_decode128_kernel<M_>), dim3(nwg), dim3(256), lds, st, a, m_base)
-    if (a.ld_res == 128) { if (mtc == 4) DEC128(4); else if (mtc == 2) DEC128(2); else DEC128(1); }
+    if (a.ld_res == 128) {
+      const size_t lds128 = lds + (size_t)mtc * 32 * sizeof(float);
+      if (mtc == 4) hipLaunchKernelGGL((psm_decode128_kernel<4>), dim3(nwg), dim3(256), lds128, st, a, m_base);
+      else if (mtc == 2) hipLaunchKernelGGL((psm_decode128_kernel<2>), dim3(nwg), dim3(256), lds128, st, a, m_base);
+      else hipLaunchKernelGGL((psm_decode128_kernel<1>), dim3(nwg), dim3(256), lds128, st, a, m_base);
+    }
     else if (mtc == 4) { if (g16) DEC(4, 16); else DEC(4, 4); }
     else if (mtc == 2) { if (g16) DEC(2, 16); else DEC(2, 4); }
     else { if (g16) DEC(1, 16); else DEC(1, 4); }
 #undef DEC
-#undef DEC128
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     m_base += mtc * 32;
@@ -432,10 +461,20 @@ hipError_t psm_launch_decode(const PsmDecodeArgs& a, hipStream_t st) {
 // once into registers; the band's contribution to each of the block's strip rectangles is
 // reduced over the workgroup and stored as a partial (sum per field, count).
 // ---------------------------------------------------------------------------
+// 64-lane sum on the VALU (DPP row shifts + row broadcasts, ~6 instructions) instead of
+// __shfl_down, which lowers to ds_bpermute (an LDS round trip per step).  Every lane must be
+// active; the total is returned in all lanes (readlane 63).
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;
+#define PSM_DPP_ADD(ctrl, rmask)                                                                             \
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xf, true))
+  PSM_DPP_ADD(0x111, 0xf);   // row_shr:1
+  PSM_DPP_ADD(0x112, 0xf);   // row_shr:2
+  PSM_DPP_ADD(0x114, 0xf);   // row_shr:4
+  PSM_DPP_ADD(0x118, 0xf);   // row_shr:8  -> lane 15 of each row of 16 holds the row total
+  PSM_DPP_ADD(0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+  PSM_DPP_ADD(0x143, 0xc);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave total
+#undef PSM_DPP_ADD
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 template <int C_OUT>
@@ -451,6 +490,9 @@ __global__ __launch_bounds__(256) void psm_strips_kernel(PsmStripArgs a) {
   const float* self = a.pred + ((int64_t)(cs * a.B + b) * SS + (int64_t)rbase * S + c) * C_OUT;
   const float* prev = b > 0 ? self - (int64_t)SS * C_OUT : self;
   const float* gm = a.grid + (((int64_t)cs * a.Ny + a.blk_y0x0[2 * b] + rbase) * a.Nx + a.blk_y0x0[2 * b + 1] + c) * a.c_in + a.sdf_ch;
+  PSM_STAMP(0, 28);
+  __shared__ int32_t tab[C_NS * 6];                 // this block's strip rectangles
+  if (tid < a.NS * 6) tab[tid] = a.strips[(int64_t)b * a.NS * 6 + tid];
   float vs[RPT][C_OUT], vp[RPT][C_OUT];
   bool on[RPT];
 #pragma unroll
@@ -463,9 +505,26 @@ __global__ __launch_bounds__(256) void psm_strips_kernel(PsmStripArgs a) {
     on[k] = gm[(int64_t)k * a.Nx * a.c_in] != 0.f;
   }
   const int NS = a.NS;
-  const int32_t* st = a.strips + (int64_t)b * NS * 6;
+  __syncthreads();
+  if (on[0]) PSM_STAMP(0, 29); else PSM_STAMP(0, 29);      // after the loads have landed
+  const int32_t* st = tab;
   float4* outp = a.spart + (((int64_t)cs * a.B + b) * a.n_bands + band) * NS;
   __shared__ float wsum[4][C_NS][3];
+  // per-thread totals over its RPT rows (flow cells only / all cells): most rectangles cover the
+  // band's rows completely, then only the column test is left per slot
+  float tot_s[C_OUT], tot_p[C_OUT], tot_cnt = 0.f, all_s[C_OUT];
+#pragma unroll
+  for (int f = 0; f < C_OUT; ++f) { tot_s[f] = 0.f; tot_p[f] = 0.f; all_s[f] = 0.f; }
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+#pragma unroll
+    for (int f = 0; f < C_OUT; ++f) {
+      tot_s[f] += on[k] ? vs[k][f] : 0.f;
+      tot_p[f] += on[k] ? vp[k][f] : 0.f;
+      all_s[f] += vs[k][f];
+    }
+    tot_cnt += on[k] ? 1.f : 0.f;
+  }
 #pragma unroll
   for (int s = 0; s < C_NS; ++s) {
     if (s < NS) {      // uniform
@@ -474,8 +533,13 @@ __global__ __launch_bounds__(256) void psm_strips_kernel(PsmStripArgs a) {
       // rows of this band inside the rectangle? (uniform over the workgroup)
       const bool live = !(r1 <= band * RB || r0 >= (band + 1) * RB || c1 <= c0);
       if (live) {
-        if (c >= c0 && c < c1) {
-          const bool use_prev = (data != b);
+        const bool incol = (c >= c0 && c < c1);
+        const bool use_prev = (data != b);
+        if (r0 <= band * RB && r1 >= (band + 1) * RB) {      // whole band (uniform)
+          if (mask < 0) { s0 = all_s[0]; s1 = all_s[C_OUT - 1]; cnt = (float)RPT; }
+          else { s0 = use_prev ? tot_p[0] : tot_s[0]; s1 = use_prev ? tot_p[C_OUT - 1] : tot_s[C_OUT - 1]; cnt = tot_cnt; }
+          s0 = incol ? s0 : 0.f; s1 = incol ? s1 : 0.f; cnt = incol ? cnt : 0.f;
+        } else if (incol) {
 #pragma unroll
           for (int k = 0; k < RPT; ++k) {
             const int r = rbase + k;
@@ -486,12 +550,13 @@ __global__ __launch_bounds__(256) void psm_strips_kernel(PsmStripArgs a) {
             }
           }
         }
-        s0 = wave_sum(s0); s1 = wave_sum(s1); cnt = wave_sum(cnt);
+        s0 = wave_sum(s0); if (C_OUT > 1) s1 = wave_sum(s1); cnt = wave_sum(cnt);
       }
       if (lane == 0) { wsum[wave][s][0] = s0; wsum[wave][s][1] = s1; wsum[wave][s][2] = cnt; }
     }
   }
   __syncthreads();
+  PSM_STAMP(0, 30);
   if (tid < NS) {
     const int s = tid;
     outp[s] = make_float4((wsum[0][s][0] + wsum[1][s][0]) + (wsum[2][s][0] + wsum[3][s][0]),
@@ -718,54 +783,79 @@ __global__ __launch_bounds__(256) void psm_assemble_kernel(PsmChainArgs a, PsmPa
   float* scnt = smean + C * nst;                      // [nst]
   float* offs = scnt + nst;                           // [C][B]
   float* wred = offs + C * B;                         // [C][4] + [C] shift
-  PSM_STAMP(a.stamps, 0);
-  // this thread's cell: issue its gather early
+  PSM_STAMP(0, 36);
+  // ---- phase 1a: every independent load (cell owner, shift-list owners, strip partials)
   const int pix = blockIdx.x * 256 + tid;
   const int o = pix < p.npix ? a.owner[pix] : -1;
-  const float* predc = a.pred + ((int64_t)cs * B * SS) * C;
-  float src[C];
+  int la[C], lb[C];                                  // one shift-list entry per thread and field (L <= 256 on this path)
 #pragma unroll
-  for (int f = 0; f < C; ++f) src[f] = o >= 0 ? predc[(int64_t)o * C + f] : 0.f;
-  // strip partials -> means
-  const float4* sp = a.spart + (int64_t)cs * B * NB * NS;
-  for (int idx = tid; idx < B * NS; idx += 256) {
-    const int b = idx / NS, s = idx - b * NS;
-    float4 v[NB];
-#pragma unroll
-    for (int q = 0; q < NB; ++q) v[q] = sp[((int64_t)b * NB + q) * NS + s];
-    float s0 = 0.f, s1 = 0.f, cn = 0.f;
-#pragma unroll
-    for (int q = 0; q < NB; ++q) { s0 += v[q].x; s1 += v[q].y; cn += v[q].z; }
-    smean[idx] = s0 / cn;
-    if (C > 1) smean[nst + idx] = s1 / cn;
-    scnt[idx] = cn;
+  for (int f = 0; f < C; ++f) {
+    const bool in = tid < a.shiftL[f];
+    la[f] = in ? a.shiftOwnA[(int64_t)f * a.Lmax + tid] : -1;
+    lb[f] = in ? a.shiftOwnB[(int64_t)f * a.Lmax + tid] : -1;
   }
-  if (a.colpart) {
-    for (int c = tid; c < 128; c += 256) {
-      float2 v[NB];
+  const float4* sp = a.spart + (int64_t)cs * B * NB * NS;
+  const int idx0 = tid, idx1 = tid + 256;             // B*NS <= 64*11 = 704 -> at most 3 per thread
+  v4f pv0[NB], pv1[NB];
+  {
+    const int b0 = min(idx0, B * NS - 1) / NS, s0 = min(idx0, B * NS - 1) - b0 * NS;
+    const int b1 = min(idx1, B * NS - 1) / NS, s1 = min(idx1, B * NS - 1) - b1 * NS;
 #pragma unroll
-      for (int q = 0; q < NB; ++q) v[q] = a.colpart[((int64_t)cs * NB + q) * 128 + c];
-      float s0 = 0.f, cn = 0.f;
-#pragma unroll
-      for (int q = 0; q < NB; ++q) { s0 += v[q].x; cn += v[q].y; }
-      smean[B * NS + c] = s0 / cn;
-      if (C > 1) smean[nst + B * NS + c] = 0.f;
-      scnt[B * NS + c] = cn;
+    for (int q = 0; q < NB; ++q) {
+      pv0[q] = *reinterpret_cast<const v4f*>(sp + ((int64_t)b0 * NB + q) * NS + s0);
+      pv1[q] = *reinterpret_cast<const v4f*>(sp + ((int64_t)b1 * NB + q) * NS + s1);
     }
+  }
+  float2 cp[NB];
+#pragma unroll
+  for (int q = 0; q < NB; ++q) cp[q] = (a.colpart && tid < 128) ? a.colpart[((int64_t)cs * NB + q) * 128 + tid] : make_float2(0.f, 0.f);
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- phase 1b: dependent gathers from the decoded blocks
+  const float* predc = a.pred + ((int64_t)cs * B * SS) * C;
+  float src[C], ga[C], gb[C];
+#pragma unroll
+  for (int f = 0; f < C; ++f) {
+    src[f] = o >= 0 ? predc[(int64_t)o * C + f] : 0.f;
+    ga[f] = la[f] >= 0 ? predc[(int64_t)la[f] * C + f] : 0.f;
+    gb[f] = lb[f] >= 0 ? predc[(int64_t)lb[f] * C + f] : 0.f;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- strip partials -> means
+  auto fold = [&](const v4f (&v)[NB], int idx) {
+    if (idx < B * NS) {
+      float s0 = 0.f, s1 = 0.f, cn = 0.f;
+#pragma unroll
+      for (int q = 0; q < NB; ++q) { s0 += v[q].x; s1 += v[q].y; cn += v[q].z; }
+      smean[idx] = s0 / cn;
+      if (C > 1) smean[nst + idx] = s1 / cn;
+      scnt[idx] = cn;
+    }
+  };
+  fold(pv0, idx0);
+  fold(pv1, idx1);
+  for (int idx = tid + 512; idx < B * NS; idx += 256) {   // only for > 46 blocks
+    const int b = idx / NS, s = idx - b * NS;
+    v4f v[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) v[q] = *reinterpret_cast<const v4f*>(sp + ((int64_t)b * NB + q) * NS + s);
+    fold(v, idx);
+  }
+  if (a.colpart && tid < 128) {
+    float s0 = 0.f, cn = 0.f;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) { s0 += cp[q].x; cn += cp[q].y; }
+    smean[B * NS + tid] = s0 / cn;
+    if (C > 1) smean[nst + B * NS + tid] = 0.f;
+    scnt[B * NS + tid] = cn;
   }
   // offset-independent part of the shift
   float pp[C];
 #pragma unroll
   for (int f = 0; f < C; ++f) {
-    const int L = a.shiftL[f];
-    const int32_t* oa = a.shiftOwnA + (int64_t)f * a.Lmax;
-    const int32_t* ob = a.shiftOwnB + (int64_t)f * a.Lmax;
-    float acc = 0.f;
-    for (int k = tid; k < L; k += 256) {
-      const int ia = oa[k], ib = ob[k];
-      const float va = ia >= 0 ? predc[(int64_t)ia * C + f] : 0.f;
-      const float vb = ib >= 0 ? predc[(int64_t)ib * C + f] : 0.f;
-      acc += 3.f * va - vb;
+    float acc = 3.f * ga[f] - gb[f];
+    for (int k = tid + 256; k < a.shiftL[f]; k += 256) {   // lists longer than 256 (not on the small-grid path)
+      const int ia = a.shiftOwnA[(int64_t)f * a.Lmax + k], ib = a.shiftOwnB[(int64_t)f * a.Lmax + k];
+      acc += 3.f * (ia >= 0 ? predc[(int64_t)ia * C + f] : 0.f) - (ib >= 0 ? predc[(int64_t)ib * C + f] : 0.f);
     }
     pp[f] = wave_sum(acc);
   }
@@ -774,11 +864,11 @@ __global__ __launch_bounds__(256) void psm_assemble_kernel(PsmChainArgs a, PsmPa
     for (int f = 0; f < C; ++f) wred[f * 4 + wave] = pp[f];
   }
   __syncthreads();
-  PSM_STAMP(a.stamps, 1);
+  PSM_STAMP(0, 37);
   if (wave < C) {
-    PSM_STAMP(a.stamps, 2);
+    PSM_STAMP(0, 38);
     psm_chain_wave(a.cp, smean + wave * nst, scnt, a.blocks, wave, lane, offs + wave * B);
-    PSM_STAMP(a.stamps, 3);
+    PSM_STAMP(0, 39);
     // shift of this field: weighted sum of the offsets (B <= 64 on this path); same-wave LDS
     // writes above are visible to the wave's own later reads
     const float w = lane < B ? a.shiftW[wave * B + lane] : 0.f;
@@ -790,7 +880,7 @@ __global__ __launch_bounds__(256) void psm_assemble_kernel(PsmChainArgs a, PsmPa
     }
   }
   __syncthreads();
-  PSM_STAMP(a.stamps, 4);
+  PSM_STAMP(0, 40);
   if (blockIdx.x == 0) {       // introspection copies (psm_read_stage)
     for (int idx = tid; idx < C * B; idx += 256) a.offs[(int64_t)cs * C * B + idx] = offs[idx];
     if (tid < C) a.shift[cs * C + tid] = wred[4 * C + tid];
@@ -805,7 +895,7 @@ __global__ __launch_bounds__(256) void psm_assemble_kernel(PsmChainArgs a, PsmPa
   const int b = o / SS;
 #pragma unroll
   for (int f = 0; f < C; ++f) out[f] = src[f] - offs[f * B + b] - wred[4 * C + f];
-  PSM_STAMP(a.stamps, 5);
+  PSM_STAMP(0, 41);
 }
 
 hipError_t psm_launch_assemble(const PsmChainArgs& a, const PsmPasteArgs& p, int n_cases, hipStream_t st) {

@@ -152,8 +152,14 @@ class GridSurrogate:
         self._chk(self.lib.psm_profile_solve(self.h, C.c_void_p(d_grid), n_cases, C.c_void_p(d_fields), ms))
         return dict(zip(_lib.KERNELS, [float(v) for v in ms]))
 
-    def enable_kernel_timing(self, kernel: str, on: bool = True):
-        self._chk(self.lib.psm_enable_kernel_timing(self.h, _lib.KERNELS.index(kernel), int(on)))
+    def enable_kernel_timing(self, kernel: str, on=True, repeat: int = 1):
+        """Event-time one kernel group; ``repeat`` launches per event pair (see psm.h)."""
+        self._chk(self.lib.psm_enable_kernel_timing(self.h, _lib.KERNELS.index(kernel), int(repeat) if on else 0))
+
+    def event_pair_overhead_ms(self, n: int = 200) -> float:
+        t = C.c_double()
+        self._chk(self.lib.psm_event_pair_overhead(self.h, n, C.byref(t)))
+        return t.value
 
     def kernel_timing(self, kernel: str):
         t, n = C.c_double(), C.c_int64()
