@@ -81,16 +81,11 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import psm_amd
+    from psm_amd import dist as pdist
+    rank, world, local_rank = pdist.env_world()
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    pdist.init("nccl", torch.device("cuda", local_rank))
 
     import psm_amd
     from psm_amd import synthetic
@@ -106,24 +101,7 @@ def main():
         k = i % len(d_in)
         sur.solve_device(d_in[k].data_ptr(), 1, d_out[k].data_ptr(), stream)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    barrier()
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt_max = float(t.item())
+    dt_max = pdist.timed_region(step, args.steps, args.warmup, torch.cuda.synchronize, "cuda")
 
     # ---- roofline of the dominant kernel: instrumented pass over the same K steps
     ab = algorithmic_bytes(model, NY, NX)
@@ -151,7 +129,8 @@ def main():
                 "per_kernel_ms_one_solve": prof}
 
     out = {
-        "metric": "pressure-solves/sec (256x256 U->p inference)", "value": world * args.steps / dt_max,
+        "metric": "pressure-solves/sec (256x256 U->p inference)",
+        "value": pdist.aggregate_throughput(1, args.steps, world, dt_max),
         "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -173,6 +152,7 @@ def main():
         print(json.dumps(out))
     sur.close()
     if world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 
