@@ -52,11 +52,9 @@ def algorithmic_bytes(model, ny, nx):
 def cpu_baseline(model, grid, budget_s=12.0, max_solves=2000):
     """Time the oracle on the host cores (bounded sample of the same workload)."""
     from oracle import psm_oracle as orc
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count() or 1
+    from psm_amd import hostinfo
+    cores = hostinfo.available_cpus()            # CPU share of this process (affinity / cgroup quota)
+    _limit = hostinfo.limit_blas_threads(cores)  # BLAS pool = the threads actually used
     sc = orc.Scaler(model.scaler_kind, model.in_a, model.in_b, model.out_a, model.out_b)
     om = orc.Model(model.variant, model.c_in, model.c_out, model.comp_in, model.mean_in, model.comp_out,
                    model.mean_out, model.weights, sc, model.out_scale, model.S, model.ov, model.sdf_ch)

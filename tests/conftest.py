@@ -11,3 +11,8 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+# BLAS pools sized to the CPU share of this process (a GPU box may expose 128 cores but grant 16)
+import psm_amd  # noqa: E402
+_blas_limit = psm_amd.hostinfo.limit_blas_threads()
