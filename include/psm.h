@@ -135,6 +135,31 @@ int psm_solve_grid_device(psm_handle* h, const float* d_grid, int32_t n_cases,
  * of caller-supplied decoded blocks block_pred[B, S*S*c_out] for ONE case, host
  * buffers, synchronous.  grid supplies the flow mask (its sdf channel). */
 int psm_reassemble(psm_handle* h, const float* grid, const float* block_pred, float* fields);
+/* ---- mesh-side entry: the contract of PythonComm_init.H / PythonComm.H ------------
+ * psm_set_geometry installs the one-time tables that init_func builds (PM:195-243):
+ *   vtx_m2g/wts_m2g [ny*nx,3]  simplices + barycentric weights, mesh -> grid (interp_weights, PM:210)
+ *   indices         [ny*nx,2]  (ii, jj) image cell of every grid point (PM:233-241); points that
+ *                              are outside the domain carry whatever the caller put there (the
+ *                              reference: np.zeros in SMD:161, np.empty in PM:225) and are
+ *                              scattered in order like the NumPy fancy assignment (last wins)
+ *   sdfunct         [ny*nx]    signed-distance image (PM:227,240)
+ *   vtx_g2m/wts_g2m [n_cells,3] grid -> mesh (PM:211)
+ *   maxs            [4]        max_abs_Ux, max_abs_Uy, max_abs_dist, max_abs_p (PM:109)
+ *   normalise_sdf   0: SDF channel as is (PM:292), 1: divided by max_abs_dist (SMD:443)
+ *   fill_input      0: interpolate (PM:280), 1: interpolate_fill (SMD:421-423)
+ *   wall_threshold  cells whose interpolated SDF is below it keep the previous p (0.05, PM:494)
+ * It also fixes the grid shape (psm_plan_grid).  Requires c_in == 3, c_out == 1. */
+int psm_set_geometry(psm_handle* h, int64_t n_cells, int32_t ny, int32_t nx,
+                     const int32_t* vtx_m2g, const double* wts_m2g, const int32_t* indices,
+                     const double* sdfunct, const int32_t* vtx_g2m, const double* wts_g2m,
+                     const double* maxs, int32_t normalise_sdf, int32_t fill_input,
+                     double wall_threshold);
+/* py_func (PM:249-517, serial form PM1:199-444): cells [n,5] float64 = (Ux, Uy, Cx, Cy, p) as
+ * packed at PythonComm.H:2-9 -> p_out [n] float64 as read at PythonComm.H:31-36.  `rank` is
+ * accepted for signature compatibility (the MPI funnel, PM:258/511, stays with the caller).
+ * Synchronous. */
+int psm_solve(psm_handle* h, const double* cells, int64_t n, int32_t rank, double* p_out);
+
 /* Wait for everything submitted through this handle. */
 int psm_synchronize(psm_handle* h);
 

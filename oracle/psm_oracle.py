@@ -546,3 +546,113 @@ def interpolate_fill(values, vtx, wts, fill_value=np.nan):
     ret = interpolate(values, vtx, wts)
     ret[np.any(wts < 0, axis=1)] = fill_value
     return ret
+
+
+# --------------------------------------------------------------------------
+# mesh-side ends of the solver call (a1-a6, a14): init_func / py_func on one rank
+# --------------------------------------------------------------------------
+@dataclass
+class Geometry:
+    ny: int
+    nx: int
+    vert_m2g: np.ndarray     # vert_OFtoNP   (PM:210)
+    wts_m2g: np.ndarray      # weights_OFtoNP
+    vert_g2m: np.ndarray     # vert_NPtoOF   (PM:211)
+    wts_g2m: np.ndarray
+    indices: np.ndarray      # [ny*nx, 2] (ii, jj)  (PM:225-243)
+    sdfunct: np.ndarray      # [ny, nx]
+
+
+def interp_weights(xyz, uvw):
+    """PM:52-62 (qhull Delaunay of the source points, barycentric coordinates of the targets)."""
+    from scipy.spatial import Delaunay
+    tri = Delaunay(xyz)
+    simplex = tri.find_simplex(uvw)
+    vertices = np.take(tri.simplices, simplex, axis=0)
+    T = np.take(tri.transform, simplex, axis=0)
+    bary = np.einsum("njk,nk->nj", T[:, :2, :], uvw - T[:, 2])
+    return vertices, np.hstack((bary, 1 - bary.sum(axis=1, keepdims=True)))
+
+
+def _inside_convex_hull(pts, cloud):
+    """Strictly inside the convex hull of ``cloud`` (the reference: shapely convex_hull +
+    matplotlib Path.contains_points, PM:83-90)."""
+    from scipy.spatial import ConvexHull
+    hv = cloud[ConvexHull(cloud).vertices]            # counter-clockwise
+    inside = np.ones(len(pts), bool)
+    for a, b in zip(hv, np.roll(hv, -1, axis=0)):
+        cross = (b[0] - a[0]) * (pts[:, 1] - a[1]) - (b[1] - a[1]) * (pts[:, 0] - a[0])
+        inside &= cross > 0
+    return inside
+
+
+def domain_dist(top, obst, xy0, every=10):
+    """PM:72-99."""
+    from scipy.spatial.distance import cdist
+    box = ((xy0[:, 0] <= top[:, 0].max()) & (xy0[:, 0] >= top[:, 0].min())
+           & (xy0[:, 1] <= top[:, 1].max()) & (xy0[:, 1] >= top[:, 1].min()))
+    dom = box & ~_inside_convex_hull(xy0, obst)
+    d = np.minimum(cdist(xy0, obst[::every]).min(axis=1), cdist(xy0, top[::every]).min(axis=1))
+    return dom, d * dom
+
+
+def init_geometry(array, top, obst, delta=5e-3, every=10) -> Geometry:
+    """``init_func`` on one rank, PM:195-243, with ``indices`` zero-initialised (SMD:161; PM:225
+    leaves it uninitialised)."""
+    x_min, x_max = round(np.min(array[:, 2]), 2), round(np.max(array[:, 2]), 2)
+    y_min, y_max = round(np.min(array[:, 3]), 2), round(np.max(array[:, 3]), 2)
+    X0, Y0 = create_uniform_grid(x_min, x_max, y_min, y_max, delta)
+    xy0 = np.c_[X0, Y0]
+    pts = array[:, 2:4]
+    v1, w1 = interp_weights(pts, xy0)
+    v2, w2 = interp_weights(xy0, pts)
+    dom, sdf = domain_dist(top, obst, xy0, every)
+    ny, nx = int(round((y_max - y_min) / delta)), int(round((x_max - x_min) / delta))
+    x0, y0 = X0.min(), Y0.min()
+    ux = interpolate_fill(array[:, 0], v1, w1)
+    indices = np.zeros((len(X0), 2), int)
+    sdfunct = np.zeros((ny, nx))
+    for step in range(len(X0)):
+        if dom[step] and not np.isnan(ux[step]):
+            jj = int(round((X0[step] - x0) / delta))
+            ii = int(round((Y0[step] - y0) / delta))
+            indices[step] = (ii, jj)
+            sdfunct[ii, jj] = sdf[step]
+    return Geometry(ny, nx, v1, w1, v2, w2, indices, sdfunct)
+
+
+def mesh_to_grid(array, geo: Geometry, max_abs_Ux, max_abs_Uy, sdf_div=1.0, fill=False):
+    """PM:267-297 (``fill=False``) / SMD:404-444 (``fill=True``, ``sdf_div=max_abs_dist``)."""
+    U_max = np.max(np.sqrt(np.square(array[:, 0]) + np.square(array[:, 1])))
+    f = interpolate_fill if fill else interpolate
+    ux = f(array[:, 0] / U_max, geo.vert_m2g, geo.wts_m2g)
+    uy = f(array[:, 1] / U_max, geo.vert_m2g, geo.wts_m2g)
+    grid = np.zeros((geo.ny, geo.nx, 3))
+    idx = tuple(geo.indices.T)
+    grid[:, :, 0][idx] = ux / max_abs_Ux
+    grid[:, :, 1][idx] = uy / max_abs_Uy
+    grid[:, :, 2] = geo.sdfunct / sdf_div
+    grid[np.isnan(grid)] = 0
+    return grid, U_max
+
+
+def grid_to_mesh(result, array, geo: Geometry, max_abs_p, U_max, wall=0.05):
+    """PM:481-496."""
+    p_unif = result[tuple(geo.indices.T)]
+    p_interp = interpolate_fill(p_unif, geo.vert_g2m, geo.wts_g2m)
+    p = p_interp * max_abs_p * U_max ** 2
+    sdf_mesh = interpolate_fill(geo.sdfunct, geo.vert_g2m, geo.wts_g2m)
+    prev = array[:, 4]
+    with np.errstate(invalid="ignore"):
+        near = sdf_mesh < wall
+    p[near] = prev[near]
+    nanm = np.isnan(p_interp)
+    p[nanm] = prev[nanm]
+    return p
+
+
+def py_func_mesh(array, geo: Geometry, model: Model, maxs):
+    """One serial ``py_func`` call (PM1:199-444 / PM:249-517 on one rank): cells[N,5] -> p[N]."""
+    grid, U_max = mesh_to_grid(array, geo, maxs[0], maxs[1])
+    sol = solve_grid(grid, model)
+    return grid_to_mesh(sol.fields[..., 0], array, geo, maxs[3], U_max), grid, sol

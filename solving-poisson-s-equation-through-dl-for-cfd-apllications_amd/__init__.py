@@ -3,7 +3,7 @@
 The directory name carries hyphens (it is fixed by the project layout), so the
 package is imported through the root-level alias module ``psm_amd``.
 """
-from . import _lib, dist, formats, hostinfo, surrogate, synthetic  # noqa: F401
+from . import _lib, dist, formats, geometry, hostinfo, surrogate, synthetic  # noqa: F401
 from .surrogate import Evaluation, EvaluationGradP, GridSurrogate, SolverModule  # noqa: F401
 from .synthetic import SurrogateModel  # noqa: F401
 

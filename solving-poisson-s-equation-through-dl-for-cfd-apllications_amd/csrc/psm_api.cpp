@@ -14,6 +14,7 @@
 
 #include "../../include/psm.h"
 #include "psm_kernels.h"
+#include "psm_mesh.h"
 #include "psm_plan.h"
 
 namespace {
@@ -58,6 +59,15 @@ struct psm_handle {
   int n_bands = 0;
   float *d_offs = nullptr, *d_shift = nullptr;
   unsigned long long* d_stamps = nullptr;
+  // mesh-side tables (psm_set_geometry)
+  bool have_geometry = false;
+  int64_t n_cells = 0;
+  int32_t *d_vtx_m2g = nullptr, *d_src_of_cell = nullptr, *d_vtx_g2m = nullptr, *d_cell_of_point = nullptr;
+  double *d_wts_m2g = nullptr, *d_sdf = nullptr, *d_wts_g2m = nullptr, *d_cells = nullptr, *d_p = nullptr, *d_umax = nullptr;
+  uint8_t* d_near_wall = nullptr;
+  double *h_cells = nullptr, *h_p = nullptr;
+  double maxs[4] = {1, 1, 1, 1};
+  int normalise_sdf = 0, fill_input = 0;
   float *d_grid_stage = nullptr, *d_fields_stage = nullptr;
   float *h_grid = nullptr, *h_fields = nullptr;
   // row-scale upload ring (pinned)
@@ -165,6 +175,15 @@ std::vector<float4> pack_comp_out(const double* comp, int P, int K_out, int Gd) 
         out[((size_t)ct * Gd + g) * 64 + l] = make_float4(v[0], v[1], v[2], v[3]);
       }
   return out;
+}
+
+void free_geometry(psm_handle* h) {
+  dev_free(h->d_vtx_m2g); dev_free(h->d_src_of_cell); dev_free(h->d_vtx_g2m); dev_free(h->d_cell_of_point);
+  dev_free(h->d_wts_m2g); dev_free(h->d_sdf); dev_free(h->d_wts_g2m); dev_free(h->d_cells); dev_free(h->d_p);
+  dev_free(h->d_umax); dev_free(h->d_near_wall);
+  if (h->h_cells) { (void)hipHostFree(h->h_cells); h->h_cells = nullptr; }
+  if (h->h_p) { (void)hipHostFree(h->h_p); h->h_p = nullptr; }
+  h->have_geometry = false;
 }
 
 bool model_complete(const psm_handle* h) {
@@ -399,6 +418,7 @@ void psm_destroy(psm_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   (void)hipDeviceSynchronize();
   free_plan(h);
+  free_geometry(h);
   for (auto& d : h->dense) { dev_free(d.W); dev_free(d.b); }
   dev_free(h->d_mean_in); dev_free(h->d_mean_out); dev_free(h->d_bpack_in); dev_free(h->d_bpack_out);
   dev_free(h->d_ia); dev_free(h->d_ib); dev_free(h->d_sa); dev_free(h->d_sb);
@@ -628,6 +648,93 @@ int psm_reassemble(psm_handle* h, const float* grid, const float* block_pred, fl
   HIPCHK(h, hipMemcpyAsync(fields, h->d_fields_stage, npix * h->cfg.c_out * sizeof(float), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
   h->last_cases = 1;
+  return PSM_OK;
+}
+
+int psm_set_geometry(psm_handle* h, int64_t n_cells, int32_t ny, int32_t nx, const int32_t* vtx_m2g, const double* wts_m2g,
+                     const int32_t* indices, const double* sdfunct, const int32_t* vtx_g2m, const double* wts_g2m,
+                     const double* maxs, int32_t normalise_sdf, int32_t fill_input, double wall_threshold) {
+  if (!h) return PSM_ERR_ARG;
+  if (!vtx_m2g || !wts_m2g || !indices || !sdfunct || !vtx_g2m || !wts_g2m || !maxs) return fail(h, PSM_ERR_ARG, "null geometry table");
+  if (n_cells < 1 || n_cells > (int64_t)1 << 30) return fail(h, PSM_ERR_ARG, "bad cell count");
+  if (h->cfg.c_in != 3 || h->cfg.c_out != 1) return fail(h, PSM_ERR_UNSUPPORTED, "the mesh entry needs c_in == 3 and c_out == 1 (python_module.py:288-292)");
+  const int64_t ng = (int64_t)ny * nx;
+  for (int64_t t = 0; t < ng; ++t) {
+    for (int j = 0; j < 3; ++j)
+      if (vtx_m2g[t * 3 + j] < 0 || vtx_m2g[t * 3 + j] >= n_cells) return fail(h, PSM_ERR_ARG, "mesh->grid vertex index out of range");
+    if (indices[t * 2] < 0 || indices[t * 2] >= ny || indices[t * 2 + 1] < 0 || indices[t * 2 + 1] >= nx)
+      return fail(h, PSM_ERR_ARG, "indices outside the grid");
+  }
+  for (int64_t n = 0; n < n_cells; ++n)
+    for (int j = 0; j < 3; ++j)
+      if (vtx_g2m[n * 3 + j] < 0 || vtx_g2m[n * 3 + j] >= ng) return fail(h, PSM_ERR_ARG, "grid->mesh vertex index out of range");
+  int rc = psm_plan_grid(h, ny, nx);
+  if (rc) return rc;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  free_geometry(h);
+  h->n_cells = n_cells;
+  for (int k = 0; k < 4; ++k) h->maxs[k] = maxs[k];
+  h->normalise_sdf = normalise_sdf; h->fill_input = fill_input;
+  // NumPy fancy assignment grid[...][tuple(indices.T)] = values writes in point order: last wins
+  std::vector<int32_t> src(ng, -1), cop(ng);
+  for (int64_t t = 0; t < ng; ++t) {
+    const int64_t cell = (int64_t)indices[t * 2] * nx + indices[t * 2 + 1];
+    src[cell] = (int32_t)t;
+    cop[t] = (int32_t)cell;
+  }
+  // sdf_mesh = interpolate_fill(sdfunct.flatten(), vert_NPtoOF, weights_NPtoOF) < threshold  (PM:492-494)
+  std::vector<uint8_t> nw(n_cells, 0);
+  for (int64_t n = 0; n < n_cells; ++n) {
+    double acc = 0.0; bool neg = false;
+    for (int j = 0; j < 3; ++j) { acc += sdfunct[vtx_g2m[n * 3 + j]] * wts_g2m[n * 3 + j]; neg = neg || wts_g2m[n * 3 + j] < 0.0; }
+    nw[n] = (!neg && acc < wall_threshold) ? 1 : 0;     // NaN (fill) compares false
+  }
+  std::vector<int32_t> v1(vtx_m2g, vtx_m2g + ng * 3), v2(vtx_g2m, vtx_g2m + n_cells * 3);
+  std::vector<double> w1(wts_m2g, wts_m2g + ng * 3), w2(wts_g2m, wts_g2m + n_cells * 3), sd(sdfunct, sdfunct + ng);
+  if ((rc = dev_upload(h, &h->d_vtx_m2g, v1))) return rc;
+  if ((rc = dev_upload(h, &h->d_wts_m2g, w1))) return rc;
+  if ((rc = dev_upload(h, &h->d_src_of_cell, src))) return rc;
+  if ((rc = dev_upload(h, &h->d_cell_of_point, cop))) return rc;
+  if ((rc = dev_upload(h, &h->d_sdf, sd))) return rc;
+  if ((rc = dev_upload(h, &h->d_vtx_g2m, v2))) return rc;
+  if ((rc = dev_upload(h, &h->d_wts_g2m, w2))) return rc;
+  if ((rc = dev_upload(h, &h->d_near_wall, nw))) return rc;
+  if ((rc = dev_alloc(h, &h->d_cells, (size_t)n_cells * 5))) return rc;
+  if ((rc = dev_alloc(h, &h->d_p, (size_t)n_cells))) return rc;
+  if ((rc = dev_alloc(h, &h->d_umax, (size_t)1))) return rc;
+  HIPCHK(h, hipHostMalloc((void**)&h->h_cells, (size_t)n_cells * 5 * sizeof(double), hipHostMallocDefault));
+  HIPCHK(h, hipHostMalloc((void**)&h->h_p, (size_t)n_cells * sizeof(double), hipHostMallocDefault));
+  h->have_geometry = true;
+  return PSM_OK;
+}
+
+int psm_solve(psm_handle* h, const double* cells, int64_t n, int32_t rank, double* p_out) {
+  (void)rank;
+  if (!h) return PSM_ERR_ARG;
+  if (!h->have_geometry) return fail(h, PSM_ERR_STATE, "psm_set_geometry has not been called");
+  if (!cells || !p_out) return fail(h, PSM_ERR_ARG, "null buffer");
+  if (n != h->n_cells) return fail(h, PSM_ERR_ARG, "cell count differs from the geometry");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  hipStream_t st = h->stream;
+  memcpy(h->h_cells, cells, (size_t)n * 5 * sizeof(double));
+  HIPCHK(h, hipMemcpyAsync(h->d_cells, h->h_cells, (size_t)n * 5 * sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(h, psm_launch_umax(h->d_cells, n, h->d_umax, st));
+  PsmToGridArgs ga{};
+  ga.cells = h->d_cells; ga.umax = h->d_umax; ga.vtx = h->d_vtx_m2g; ga.wts = h->d_wts_m2g; ga.src_of_cell = h->d_src_of_cell;
+  ga.sdf = h->d_sdf; ga.grid = h->d_grid_stage; ga.n_grid = (int64_t)h->Ny * h->Nx;
+  ga.max_abs_ux = h->maxs[0]; ga.max_abs_uy = h->maxs[1]; ga.sdf_scale = h->normalise_sdf ? 1.0 / h->maxs[2] : 1.0;
+  ga.c_in = h->cfg.c_in; ga.fill = h->fill_input;
+  HIPCHK(h, psm_launch_to_grid(ga, st));
+  int rc = solve_device(h, h->d_grid_stage, 1, nullptr, h->d_fields_stage, st, nullptr);
+  if (rc) return rc;
+  PsmToMeshArgs ma{};
+  ma.cells = h->d_cells; ma.umax = h->d_umax; ma.vtx = h->d_vtx_g2m; ma.wts = h->d_wts_g2m; ma.cell_of_point = h->d_cell_of_point;
+  ma.field = h->d_fields_stage; ma.near_wall = h->d_near_wall; ma.p_out = h->d_p; ma.n_cells = n; ma.max_abs_p = h->maxs[3];
+  ma.c_out = h->cfg.c_out;
+  HIPCHK(h, psm_launch_to_mesh(ma, st));
+  HIPCHK(h, hipMemcpyAsync(h->h_p, h->d_p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  memcpy(p_out, h->h_p, (size_t)n * sizeof(double));
   return PSM_OK;
 }
 

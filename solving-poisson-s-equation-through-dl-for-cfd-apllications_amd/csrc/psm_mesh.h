@@ -1,0 +1,36 @@
+// psm_mesh.h -- launchers of the mesh <-> grid kernels (see psm_mesh.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+struct PsmToGridArgs {
+  const double* cells;          // [N,5] Ux,Uy,Cx,Cy,p
+  const double* umax;           // device scalar
+  const int32_t* vtx;           // [n_grid,3] mesh->grid simplices (interp_weights, PM:52-62)
+  const double* wts;            // [n_grid,3]
+  const int32_t* src_of_cell;   // [n_grid] last grid point scattered into each cell (NumPy fancy assignment order), -1 none
+  const double* sdf;            // [n_grid] sdfunct
+  float* grid;                  // [n_grid][c_in]
+  int64_t n_grid;
+  double max_abs_ux, max_abs_uy, sdf_scale;
+  int c_in, fill;               // fill: 1 = interpolate_fill (NaN where a weight is negative), 0 = interpolate
+};
+
+struct PsmToMeshArgs {
+  const double* cells;          // [N,5]
+  const double* umax;
+  const int32_t* vtx;           // [N,3] grid->mesh simplices
+  const double* wts;            // [N,3]
+  const int32_t* cell_of_point; // [n_grid] flat cell index of indices[point]
+  const float* field;           // [n_grid][c_out]
+  const uint8_t* near_wall;     // [N] interpolated SDF < threshold (PM:492-494), constant per geometry
+  double* p_out;                // [N]
+  int64_t n_cells;
+  double max_abs_p;
+  int c_out;
+};
+
+hipError_t psm_launch_umax(const double* cells, int64_t n, double* umax, hipStream_t st);
+hipError_t psm_launch_to_grid(const PsmToGridArgs& a, hipStream_t st);
+hipError_t psm_launch_to_mesh(const PsmToMeshArgs& a, hipStream_t st);

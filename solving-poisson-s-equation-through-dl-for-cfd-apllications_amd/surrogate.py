@@ -302,16 +302,52 @@ class EvaluationGradP(Evaluation):
 
 
 class SolverModule:
-    """Chapter-5 ``python_module`` (python_module.py) -- grid-native body of
-    ``py_func`` (:299-473).  The mesh<->grid ends (init_func, interpolation,
-    near-wall fallback) are SURVEY §8 f.1 and not built yet."""
+    """Chapter-5 ``python_module`` (python_module.py): ``init_func`` / ``py_func`` with the
+    reference's signatures on one rank (the serial solver, singleCore/test_Case/python_module.py:
+    139,199; in the parallel solver the mpi4py gather/scatter of python_module.py:179-185,258,511
+    stays around these calls).  ``maxs`` = (max_abs_Ux, max_abs_Uy, max_abs_dist, max_abs_p) of
+    the ``maxs`` file (python_module.py:106-109)."""
 
-    def __init__(self, model: SurrogateModel, device: int = 0):
-        self.model, self.device, self._sur = model, device, None
+    def __init__(self, model: SurrogateModel, maxs=(1.0, 1.0, 1.0, 1.0), device: int = 0, delta: float = 5e-3):
+        self.model, self.maxs, self.device, self.delta = model, tuple(float(v) for v in maxs), device, delta
+        self._sur = None
+        self.tables = None
 
+    # -- grid-native body (python_module.py:299-473)
     def py_func_grid(self, grid: np.ndarray) -> np.ndarray:
         if self._sur is None or (self._sur.ny, self._sur.nx) != grid.shape[:2]:
             if self._sur is not None:
                 self._sur.close()
             self._sur = GridSurrogate(self.model, grid.shape[0], grid.shape[1], 1, self.device)
         return self._sur.solve(grid)[0, :, :, 0]
+
+    # -- the solver boundary
+    def init_func(self, array, top_boundary, obst_boundary, placeholder=0):
+        """python_module.py:172: one-time tables (host, SciPy qhull like the reference), handed
+        to the GPU library with psm_set_geometry.  Returns 0."""
+        from .geometry import build_geometry
+        t = build_geometry(np.asarray(array, np.float64), top_boundary, obst_boundary, self.delta)
+        if self._sur is not None:
+            self._sur.close()
+        self._sur = GridSurrogate(self.model, t.ny, t.nx, 1, self.device)
+        v1, w1 = np.ascontiguousarray(t.vtx_m2g, np.int32), _f64(t.wts_m2g)
+        v2, w2 = np.ascontiguousarray(t.vtx_g2m, np.int32), _f64(t.wts_g2m)
+        idx, sdf, mx = np.ascontiguousarray(t.indices, np.int32), _f64(t.sdfunct), _f64(self.maxs)
+        self._sur._chk(self._sur.lib.psm_set_geometry(
+            self._sur.h, int(np.asarray(array).shape[0]), t.ny, t.nx, _p(v1, C.c_int32), _p(w1, C.c_double),
+            _p(idx, C.c_int32), _p(sdf, C.c_double), _p(v2, C.c_int32), _p(w2, C.c_double), _p(mx, C.c_double),
+            0, 0, 0.05))
+        self.tables = t
+        return 0
+
+    def py_func(self, array_in, placeholder=0) -> np.ndarray:
+        """python_module.py:249: cells [N,5] float64 -> p [N] float64."""
+        if self.tables is None:
+            raise RuntimeError("init_func has not been called")
+        a = _f64(array_in)
+        if a.ndim != 2 or a.shape[1] != 5:
+            raise ValueError("array must be [N,5] = (Ux, Uy, Cx, Cy, p)")
+        out = np.empty(a.shape[0], np.float64)
+        self._sur._chk(self._sur.lib.psm_solve(self._sur.h, _p(a, C.c_double), a.shape[0], int(placeholder),
+                                                _p(out, C.c_double)))
+        return out

@@ -215,3 +215,34 @@ def random_obstacle_cases(n: int, Ny: int = 256, Nx: int = 256, seed: int = 3) -
                               cx=float(rng.uniform(0.2, 0.6)), cy=float(rng.uniform(0.35, 0.65)),
                               r=float(rng.uniform(0.06, 0.14)))
     return out
+
+
+# --------------------------------------------------------------------------
+# solver-side input: unstructured cell centres + boundary patches (PythonComm_init.H:58-77)
+# --------------------------------------------------------------------------
+def channel_mesh(Lx: float = 1.5, Ly: float = 0.7, h: float = 0.008, seed: int = 5, cx: float = 0.4, cy: float = 0.0,
+                 R: float = 0.08, step: int = 0):
+    """Jittered cell-centre cloud of a channel with a circular obstacle.
+    Returns (array[N,5] = Ux, Uy, Cx, Cy, p; top[Nt,2] (both walls); obst[No,2])."""
+    rng = np.random.default_rng(seed)
+    nx, ny = int(round(Lx / h)), int(round(Ly / h))
+    X, Y = np.meshgrid((np.arange(nx) + 0.5) * h, (np.arange(ny) + 0.5) * h - Ly / 2)
+    X = X + rng.uniform(-0.25, 0.25, X.shape) * h
+    Y = Y + rng.uniform(-0.25, 0.25, Y.shape) * h
+    X, Y = X.ravel(), Y.ravel()
+    keep = (X - cx) ** 2 + (Y - cy) ** 2 > (R + 0.3 * h) ** 2
+    X, Y = X[keep], Y[keep]
+    yn = 2 * Y / Ly
+    rr2 = np.maximum((X - cx) ** 2 + (Y - cy) ** 2, 1e-12)
+    k = R * R / rr2
+    dx, dy = X - cx, Y - cy
+    ph = 0.15 * step
+    Ux = 1.2 * (1 - yn * yn) * (1 - k * (dx * dx - dy * dy) / rr2) + 0.03 * np.sin(9 * X + ph) * np.cos(7 * Y)
+    Uy = 1.2 * (1 - yn * yn) * (-k * 2 * dx * dy / rr2) + 0.03 * np.cos(8 * X - ph) * np.sin(6 * Y)
+    p = 0.4 * (Lx - X) / Lx + 0.1 * np.cos(5 * X + ph) * yn
+    array = np.stack([Ux, Uy, X, Y, p], axis=1)
+    xs = np.arange(0.0, Lx + 1e-9, h / 2)
+    top = np.concatenate([np.stack([xs, np.full_like(xs, Ly / 2)], 1), np.stack([xs, np.full_like(xs, -Ly / 2)], 1)])
+    th = np.linspace(0, 2 * np.pi, 240, endpoint=False)
+    obst = np.stack([cx + R * np.cos(th), cy + R * np.sin(th)], 1)
+    return array, top, obst

@@ -61,3 +61,13 @@ def build(name: str):
 
 def load_golden(name: str):
     return np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"))
+
+
+MESH_MAXS = (1.0, 0.536133, 0.999023, 0.510742)      # the reference test case's `maxs` file
+
+
+def build_mesh_case(step: int = 0):
+    """Solver-side case: (array[N,5], top, obst, model, maxs) -- 140x300 grid, 8 chapter5 blocks."""
+    array, top, obst = synthetic.channel_mesh(step=step)
+    model = synthetic.make_model("chapter5", p_in=32, p_out=32, seed_pca=4321, seed_w=11)
+    return array, top, obst, model, MESH_MAXS

@@ -213,6 +213,60 @@ def run_chapter5(grid3, model):
                 n_blocks=np.int64(loc["N"]))
 
 
+def run_py_func_mesh(array, geo, model, maxs):
+    """PM.py_func, the whole rank-0 body from the gathered cell array to the final p
+    (python_module.py:264-496), with the one-time tables of init_func supplied (their
+    construction needs shapely, which is not installed)."""
+    tree = _tree(PM)
+    import time as _time
+    glb = {"np": np, "time": _time}
+    for fname in ("interpolate", "interpolate_fill"):            # the reference's own helpers
+        fn = _find_fn(tree, fname)
+        mod = ast.Module(body=[fn], type_ignores=[]); ast.fix_missing_locations(mod)
+        exec(compile(mod, PM, "exec"), glb)
+    glb.update(model=dense_callable(model.weights), pca_mean_input=model.mean_in, comp_input=model.comp_in,
+               max_abs_input_PCA=model.in_a, max_abs_p_PCA=model.out_a, comp_p=model.comp_out, pca_mean_p=model.mean_out,
+               max_abs_Ux=maxs[0], max_abs_Uy=maxs[1], max_abs_dist=maxs[2], max_abs_p=maxs[3],
+               vert_OFtoNP=geo.vert_m2g, weights_OFtoNP=geo.wts_m2g, vert_NPtoOF=geo.vert_g2m, weights_NPtoOF=geo.wts_g2m,
+               indices=geo.indices, sdfunct=geo.sdfunct[:, :, None], grid_shape_y=geo.ny, grid_shape_x=geo.nx)
+    fn = _find_fn(tree, "py_func")
+    rank0 = [n for n in fn.body if isinstance(n, ast.If) and "rank == 0" in _src(n.test)]
+    body = max(rank0, key=lambda n: len(n.body)).body
+    stmts = _slice(body, lambda s: s.startswith("array = np.concatenate(array_global)"),
+                   lambda s: s.startswith("p[np.isnan(p_interp)] ="))
+    loc = {"array_global": [np.asarray(array, np.float64)]}
+    with np.errstate(all="ignore"):
+        _run(stmts, glb, loc, PM)
+    return dict(p=np.asarray(loc["p"], np.float64), grid=np.asarray(loc["grid"][0], np.float64),
+                U_max_norm=np.float64(loc["U_max_norm"]), n_blocks=np.int64(loc["N"]))
+
+
+def run_init_helpers(array, delta):
+    """The pure NumPy/SciPy helpers of init_func executed from the reference file:
+    create_uniform_grid (PM:42-48) and interp_weights (PM:154-161) in both directions."""
+    tree = _tree(PM)
+    import scipy.spatial as _sp
+    try:
+        import scipy.spatial.qhull as qhull          # the reference's import (older SciPy)
+    except Exception:
+        qhull = types.SimpleNamespace(Delaunay=_sp.Delaunay)
+    glb = {"np": np, "qhull": qhull, "d": 2}
+    for fname in ("create_uniform_grid",):
+        fn = _find_fn(tree, fname)
+        mod = ast.Module(body=[fn], type_ignores=[]); ast.fix_missing_locations(mod)
+        exec(compile(mod, PM, "exec"), glb)
+    fns = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "interp_weights"]
+    mod = ast.Module(body=[fns[-1]], type_ignores=[]); ast.fix_missing_locations(mod)   # the later definition wins at import
+    exec(compile(mod, PM, "exec"), glb)
+    x_min, x_max = round(np.min(array[:, 2]), 2), round(np.max(array[:, 2]), 2)
+    y_min, y_max = round(np.min(array[:, 3]), 2), round(np.max(array[:, 3]), 2)
+    X0, Y0 = glb["create_uniform_grid"](x_min, x_max, y_min, y_max, delta)
+    xy0 = np.concatenate((np.expand_dims(X0, axis=1), np.expand_dims(Y0, axis=1)), axis=-1)
+    v1, w1 = glb["interp_weights"](array[:, 2:4], xy0)
+    v2, w2 = glb["interp_weights"](xy0, array[:, 2:4])
+    return X0, Y0, v1, w1, v2, w2
+
+
 # --------------------------------------------------------------------------
 # cases (inputs are regenerated from these specs by tests/cases.py)
 # --------------------------------------------------------------------------
@@ -229,6 +283,21 @@ def main():
         flat[f"W{i}"], flat[f"b{i}"] = w, b
     np.savez_compressed(os.path.join(HERE, "chapter5_weights.npz"), maxs=maxs, maxs_PCA=maxs_pca, **flat)
     print("chapter5_weights.npz", [w.shape for w, _ in W])
+
+    # ---- mesh-side boundary (py_func on one rank) --------------------------------
+    from oracle import psm_oracle as orc
+    array, top, obst, model, maxs = cases.build_mesh_case()
+    geo = orc.init_geometry(array, top, obst)
+    X0, Y0, v1, w1, v2, w2 = run_init_helpers(array, 5e-3)
+    out = run_py_func_mesh(array, geo, model, maxs)
+    # table checks kept small: checksums of the reference helpers' outputs
+    out.update(ref_grid_n=np.int64(len(X0)), ref_X0_sum=np.float64(X0.sum()), ref_Y0_sum=np.float64(Y0.sum()),
+               ref_v1_sum=np.int64(v1.astype(np.int64).sum()), ref_v2_sum=np.int64(v2.astype(np.int64).sum()),
+               ref_w1_abs_sum=np.float64(np.abs(w1).sum()), ref_w2_abs_sum=np.float64(np.abs(w2).sum()))
+    out["grid"] = out["grid"].astype(np.float32)          # keep the fixture small; p stays float64
+    np.savez_compressed(os.path.join(HERE, "mesh_chapter5.npz"), **out)
+    print(f"mesh_chapter5: N={len(array)} grid={geo.ny}x{geo.nx} B={int(out['n_blocks'])} |p|max={np.abs(out['p']).max():.4f} "
+          f"fallback cells={(out['p'] == array[:, 4]).sum()}")
 
     for name in cases.GOLDEN_CASES:
         grid, model = cases.build(name)

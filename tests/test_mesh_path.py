@@ -1,0 +1,74 @@
+"""Solver boundary (cells[N,5] float64 -> p[N] float64; PythonComm.H:2-9,31-36):
+oracle vs the outputs of the reference's whole rank-0 ``py_func`` body, host tables of the
+product vs the oracle, and (GPU) the C-ABI ``psm_set_geometry`` / ``psm_solve`` path."""
+import numpy as np
+import pytest
+
+import cases
+from oracle import psm_oracle as orc
+from psm_amd import SolverModule, geometry
+from test_oracle_golden import oracle_model
+
+
+@pytest.fixture(scope="module")
+def mesh_case():
+    array, top, obst, model, maxs = cases.build_mesh_case()
+    geo = orc.init_geometry(array, top, obst)
+    return array, top, obst, model, maxs, geo, cases.load_golden("mesh_chapter5")
+
+
+def test_init_tables_match_the_reference_helpers(mesh_case):
+    array, top, obst, model, maxs, geo, gold = mesh_case
+    # create_uniform_grid / interp_weights of the reference file, executed by make_golden.py
+    assert geo.ny * geo.nx == int(gold["ref_grid_n"])
+    X0, Y0 = orc.create_uniform_grid(round(array[:, 2].min(), 2), round(array[:, 2].max(), 2),
+                                     round(array[:, 3].min(), 2), round(array[:, 3].max(), 2), 5e-3)
+    assert np.isclose(X0.sum(), float(gold["ref_X0_sum"]), rtol=1e-13)
+    assert np.isclose(Y0.sum(), float(gold["ref_Y0_sum"]), rtol=1e-13, atol=1e-9)
+    assert int(geo.vert_m2g.astype(np.int64).sum()) == int(gold["ref_v1_sum"])
+    assert int(geo.vert_g2m.astype(np.int64).sum()) == int(gold["ref_v2_sum"])
+    assert np.isclose(np.abs(geo.wts_m2g).sum(), float(gold["ref_w1_abs_sum"]), rtol=1e-12)
+    assert np.isclose(np.abs(geo.wts_g2m).sum(), float(gold["ref_w2_abs_sum"]), rtol=1e-12)
+
+
+def test_oracle_py_func_matches_reference_run(mesh_case):
+    array, top, obst, model, maxs, geo, gold = mesh_case
+    p, grid, sol = orc.py_func_mesh(array, geo, oracle_model(model), maxs)
+    assert sol.x_blocks.shape[0] == int(gold["n_blocks"])
+    np.testing.assert_allclose(grid, gold["grid"], rtol=0, atol=2e-7)          # fixture stored as float32
+    np.testing.assert_allclose(p, gold["p"], rtol=1e-6, atol=1e-6 * np.abs(gold["p"]).max())
+    fb = p == array[:, 4]
+    assert 0 < fb.sum() < len(p)                                               # near-wall / NaN fallback exercised
+
+
+def test_product_host_tables_equal_oracle(mesh_case):
+    array, top, obst, model, maxs, geo, gold = mesh_case
+    t = geometry.build_geometry(array, top, obst)
+    assert (t.ny, t.nx) == (geo.ny, geo.nx)
+    np.testing.assert_array_equal(t.vtx_m2g, geo.vert_m2g)
+    np.testing.assert_array_equal(t.vtx_g2m, geo.vert_g2m)
+    np.testing.assert_allclose(t.wts_m2g, geo.wts_m2g, rtol=0, atol=1e-14)
+    np.testing.assert_allclose(t.wts_g2m, geo.wts_g2m, rtol=0, atol=1e-14)
+    np.testing.assert_array_equal(t.indices, geo.indices)
+    np.testing.assert_allclose(t.sdfunct, geo.sdfunct, rtol=0, atol=1e-14)
+
+
+@pytest.mark.gpu
+def test_solver_module_init_func_py_func(mesh_case):
+    array, top, obst, model, maxs, geo, gold = mesh_case
+    sm = SolverModule(model, maxs)
+    assert sm.init_func(array, top, obst, 0) == 0
+    p = sm.py_func(array, 0)
+    assert p.dtype == np.float64 and p.shape == (len(array),)
+    ref = gold["p"]
+    # cells that keep the previous pressure are bit-identical; the others within the f32 tolerance
+    fb = ref == array[:, 4]
+    np.testing.assert_array_equal(p[fb], array[fb, 4])
+    assert np.abs(p - ref).max() <= 2e-4 * np.abs(ref).max()
+    # a second time step through the same handle (different fields, same geometry)
+    array2, _, _ = cases.synthetic.channel_mesh(step=3)
+    p2 = sm.py_func(array2, 0)
+    ref2, _, _ = orc.py_func_mesh(array2, geo, oracle_model(model), maxs)
+    assert np.abs(p2 - ref2).max() <= 2e-4 * np.abs(ref2).max()
+    with pytest.raises(Exception):
+        sm.py_func(array2[:-5], 0)              # wrong cell count: reported, not fatal
