@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scratch/prof.sh TAG  -- GPU tests, rocprof kernel stats, bench line
+# usage: tools/prof.sh TAG  -- GPU tests, rocprof kernel stats, bench line
 TAG=$1
 export TMPDIR=/tmp; R=$PWD; mkdir -p gpurun_out/prof_$TAG
 timeout -k 10 600 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.log 2>&1; echo "pytest rc=$?"; tail -2 gpurun_out/gpu_tests.log
