@@ -35,21 +35,32 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-NY = NX = 256
 P = 128
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
+# BASELINE.json configs as (variant, Ny, Nx, cases per step per GPU, precision, description)
+WORKLOADS = {
+    "config1": ("gradp", 256, 256, 1, "f32", "BASELINE configs[1]: 256x256 channel+obstacle U_to_gradP, batch 1, fp32, "
+                "B=30 blocks of 128x128x3, P_i=P_o=128, MLP 3x512, one independent case stream per GPU"),
+    "config2": ("deltas", 256, 256, 1, "f32", "BASELINE configs[2]: 256x256 deltaU_to_deltaP, sequential solves (PISO correctors), "
+                "B=9 blocks, P=128, MLP 3x512"),
+    "config3": ("deltas", 256, 256, 8, "f32", "BASELINE configs[3]: random-obstacle 256x256 cases, 8 per GPU per step, "
+                "B=9 blocks per case, P=128, MLP 3x512"),
+    "config4": ("deltas", 512, 512, 1, "bf16", "BASELINE configs[4]: 512x512 high-Re cylinder, bf16 operands / f32 accumulate, "
+                "B=30 blocks, P=128, MLP 3x512"),
+}
 
-def algorithmic_bytes(model, ny, nx):
+
+def algorithmic_bytes(model, ny, nx, wbytes=4):
     """SURVEY.md §8(d) BYTES formula, split per kernel group (float32 = 4 B)."""
     S2 = model.S ** 2
-    enc = 4 * (ny * nx * model.c_in + S2 * model.c_in * model.p_in + S2 * model.c_in)
-    dec = 4 * (S2 * model.c_out * model.p_out + S2 * model.c_out + ny * nx * model.c_out)
-    mlp = 4 * sum(W.size + b.size for W, b in model.weights)
+    enc = 4 * (ny * nx * model.c_in + S2 * model.c_in) + wbytes * S2 * model.c_in * model.p_in
+    dec = 4 * (S2 * model.c_out + ny * nx * model.c_out) + wbytes * S2 * model.c_out * model.p_out
+    mlp = wbytes * sum(W.size for W, b in model.weights) + 4 * sum(b.size for W, b in model.weights)
     return {"encode": enc, "decode": dec, "mlp": mlp, "total": enc + dec + mlp}
 
 
-def cpu_baseline(model, grid, budget_s=12.0, max_solves=2000):
+def cpu_baseline(model, grid, precision="f32", budget_s=12.0, max_solves=2000):
     """Time the oracle on the host cores (bounded sample of the same workload)."""
     from oracle import psm_oracle as orc
     from psm_amd import hostinfo
@@ -59,14 +70,15 @@ def cpu_baseline(model, grid, budget_s=12.0, max_solves=2000):
     om = orc.Model(model.variant, model.c_in, model.c_out, model.comp_in, model.mean_in, model.comp_out,
                    model.mean_out, model.weights, sc, model.out_scale, model.S, model.ov, model.sdf_ch)
     g = grid.astype(np.float64)
-    orc.solve_grid(g, om)                       # warm-up (BLAS threads, page faults)
+    orc.solve_grid(g, om, precision=precision)  # warm-up (BLAS threads, page faults)
     n, t0 = 0, time.perf_counter()
     while n < max_solves and (time.perf_counter() - t0) < budget_s:
-        sol = orc.solve_grid(g, om)
+        sol = orc.solve_grid(g, om, precision=precision)
         n += 1
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "solves/s", "cores": int(cores), "kind": "port",
-            "sample": f"{n} sequential 256x256 gradP solves of the NumPy oracle (float64 PCA/reassembly, float32 MLP) in {dt:.1f} s"}, sol
+            "sample": f"{n} sequential {grid.shape[0]}x{grid.shape[1]} {model.variant} solves of the NumPy oracle "
+                      f"(float64 PCA/reassembly, float32 MLP) in {dt:.1f} s"}, sol
 
 
 def main():
@@ -76,6 +88,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inputs", type=int, default=4, help="distinct input grids rotated through (all resident in HBM)")
+    ap.add_argument("--workload", default="config1", choices=sorted(WORKLOADS),
+                    help="BASELINE.json config to run (default: configs[1], the one the metric is quoted on)")
     args = ap.parse_args()
 
     import torch
@@ -87,23 +101,28 @@ def main():
 
     import psm_amd
     from psm_amd import synthetic
-    model = synthetic.make_model("gradp", p_in=P, p_out=P)
-    sur = psm_amd.GridSurrogate(model, NY, NX, max_cases=1, device=local_rank)
+    variant, NY, NX, NC, precision, wl_desc = WORKLOADS[args.workload]
+    model = synthetic.make_model(variant, p_in=P, p_out=P)
+    sur = psm_amd.GridSurrogate(model, NY, NX, max_cases=NC, device=local_rank, precision=precision)
     # independent cases per rank (different seeds), all resident in HBM before timing
-    grids = [synthetic.channel_grid(NY, NX, seed=1 + 1000 * rank + i).astype(np.float32) for i in range(args.inputs)]
+    if NC == 1:
+        grids = [synthetic.channel_grid(NY, NX, seed=1 + 1000 * rank + i, noise=0.05 if NY > 256 else 0.02).astype(np.float32)[None]
+                 for i in range(args.inputs)]
+    else:
+        grids = [synthetic.random_obstacle_cases(NC, NY, NX, seed=3 + 1000 * rank + i).astype(np.float32) for i in range(args.inputs)]
     d_in = [torch.from_numpy(g).cuda() for g in grids]
-    d_out = [torch.empty((NY, NX, model.c_out), dtype=torch.float32, device="cuda") for _ in grids]
+    d_out = [torch.empty((NC, NY, NX, model.c_out), dtype=torch.float32, device="cuda") for _ in grids]
     stream = torch.cuda.current_stream().cuda_stream
 
     def step(i):
         k = i % len(d_in)
-        sur.solve_device(d_in[k].data_ptr(), 1, d_out[k].data_ptr(), stream)
+        sur.solve_device(d_in[k].data_ptr(), NC, d_out[k].data_ptr(), stream)
 
     dt_max = pdist.timed_region(step, args.steps, args.warmup, torch.cuda.synchronize, "cuda")
 
     # ---- roofline of the dominant kernel: instrumented pass over the same K steps
-    ab = algorithmic_bytes(model, NY, NX)
-    prof = sur.profile(d_in[0].data_ptr(), 1, d_out[0].data_ptr())
+    ab = algorithmic_bytes(model, NY, NX, 2 if precision == "bf16" else 4)
+    prof = sur.profile(d_in[0].data_ptr(), NC, d_out[0].data_ptr())
     dom = "encode"
     REPEAT = 1            # every launch of the timed region's pipeline, one event pair each (hipExtLaunchKernel)
     sur.enable_kernel_timing(dom, True, REPEAT)
@@ -115,7 +134,7 @@ def main():
     achieved = ab[dom] / avg_s / 1e9
     traffic = None
     pmc_file = os.path.join(ROOT, "profiles", "pmc_encode.json")
-    if os.path.exists(pmc_file):
+    if os.path.exists(pmc_file) and args.workload == "config1":
         try:
             traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
         except Exception:
@@ -128,21 +147,20 @@ def main():
 
     out = {
         "metric": "pressure-solves/sec (256x256 U->p inference)",
-        "value": pdist.aggregate_throughput(1, args.steps, world, dt_max),
+        "value": pdist.aggregate_throughput(NC, args.steps, world, dt_max),
         "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: 256x256 channel+obstacle U_to_gradP, batch 1, fp32, "
-                               "B=30 blocks of 128x128x3, P_i=P_o=128, MLP 3x512, one independent case stream per GPU",
-                   "grid": [NY, NX], "blocks": sur.B, "p_in": P, "p_out": P, "cases_per_step_per_gpu": 1,
+        "vs_baseline": None, "dtype": precision, "data": "synthetic",
+        "config": {"workload": wl_desc,
+                   "grid": [NY, NX], "blocks": sur.B, "p_in": P, "p_out": P, "cases_per_step_per_gpu": NC,
                    "parallelism": f"case-sharded x{world} (no data-path collective)"},
         "roofline": roofline,
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cb, sol = cpu_baseline(model, grids[0])
+        cb, sol = cpu_baseline(model, grids[0][0], precision)
         out["cpu_baseline"] = cb
-        got = d_out[0].cpu().numpy()
+        got = d_out[0][0].cpu().numpy()
         ref = sol.fields
         out["l2_vs_oracle"] = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
         out["gpu_over_cpu"] = out["value"] / cb["value"]

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PSM_ABI_VERSION 1
+#define PSM_ABI_VERSION 2
 
 /* block layout + reassembly variant */
 #define PSM_VARIANT_CHAPTER5 0 /* PM:303-332, 373-472 */
@@ -41,6 +41,10 @@ extern "C" {
 #define PSM_SCALER_MAX_ABS 0 /* PM:351,365; UGP:525,531; SMD:521-523,536-537 */
 #define PSM_SCALER_STD     1 /* SMD:505-512,532-533 */
 #define PSM_SCALER_MIN_MAX 2 /* SMD:513-520,534-535 */
+
+/* arithmetic of the PCA contractions and the dense layers */
+#define PSM_PRECISION_F32  0 /* exact-f32 MFMA (v_mfma_f32_32x32x2_f32) */
+#define PSM_PRECISION_BF16 1 /* bf16 operands (bases, weights, activations), f32 accumulation (v_mfma_f32_32x32x16_bf16) */
 
 #define PSM_OK               0
 #define PSM_ERR_ARG         -1 /* invalid argument / shape */
@@ -88,6 +92,7 @@ typedef struct psm_config {
   int32_t strict_degenerate; /* 1: keep NumPy semantics when the last block row
                                 duplicates the previous one (NaN field, UGP:340);
                                 0: leave that row out */
+  int32_t precision;     /* PSM_PRECISION_* */
 } psm_config;
 
 /* ---- lifetime ------------------------------------------------------------ */

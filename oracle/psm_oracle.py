@@ -492,17 +492,47 @@ class Solve:
     assemblies: list
 
 
-def solve_grid(grid: np.ndarray, model: Model, degenerate: str = "skip") -> Solve:
+def bf16_round(x) -> np.ndarray:
+    """Round-to-nearest-even to bfloat16, returned as float32 (what v_cvt_pk_bf16_f32 does)."""
+    f = np.ascontiguousarray(x, dtype=np.float32)
+    u = f.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    out = r.view(np.float32).copy()
+    out[np.isnan(f)] = np.nan
+    return out
+
+
+def solve_grid(grid: np.ndarray, model: Model, degenerate: str = "skip", precision: str = "f32") -> Solve:
     """One grid-native solve.  ``grid`` is the already normalised
-    [Ny, Nx, >=c_in] image of PM:288-297 / SMD:430-444 / UGP:453-468."""
+    [Ny, Nx, >=c_in] image of PM:288-297 / SMD:430-444 / UGP:453-468.
+
+    ``precision='bf16'`` emulates the bf16 operand path of the HIP library (BASELINE config 4;
+    no reference counterpart): bases, weights and the activations entering each contraction are
+    rounded to bfloat16, products and sums are exact/float64 here (float32 on the GPU)."""
     Ny, Nx = grid.shape[:2]
     lay = block_layout(model.variant, Ny, Nx, model.S, model.overlap())
     xb = extract_blocks(np.asarray(grid, np.float64), lay, model.c_in)
-    coeff = pca_encode(xb, model.comp_in, model.mean_in)
-    x_in = model.scaler.fwd(coeff)
-    res = mlp_forward(x_in, model.weights)
-    dec_in = model.scaler.inv(res.astype(np.float64))
-    bp = pca_decode(dec_in, model.comp_out, model.mean_out, model.S, model.c_out) * model.out_scale
+    if precision == "bf16":
+        flat = xb.reshape(lay.B, -1).astype(np.float32) - model.mean_in.astype(np.float32)
+        coeff = bf16_round(flat).astype(np.float64) @ bf16_round(model.comp_in).astype(np.float64).T
+        x_in = model.scaler.fwd(coeff)
+        h = np.asarray(x_in, np.float32)
+        for li, (W, b) in enumerate(model.weights):
+            h = (bf16_round(h).astype(np.float64) @ bf16_round(W).astype(np.float64)).astype(np.float32) + np.asarray(b, np.float32)
+            if li != len(model.weights) - 1:
+                h = np.maximum(h, np.float32(0))
+        res = h
+        dec_in = model.scaler.inv(res.astype(np.float64))
+        flat_out = bf16_round(dec_in).astype(np.float64) @ bf16_round(model.comp_out).astype(np.float64) + model.mean_out
+        bp = flat_out.reshape(lay.B, model.S, model.S, model.c_out) * model.out_scale
+    elif precision == "f32":
+        coeff = pca_encode(xb, model.comp_in, model.mean_in)
+        x_in = model.scaler.fwd(coeff)
+        res = mlp_forward(x_in, model.weights)
+        dec_in = model.scaler.inv(res.astype(np.float64))
+        bp = pca_decode(dec_in, model.comp_out, model.mean_out, model.S, model.c_out) * model.out_scale
+    else:
+        raise ValueError(precision)
     fields = np.zeros((Ny, Nx, model.c_out))
     asm = []
     if model.variant == CHAPTER5:

@@ -14,9 +14,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PSM_LIB") or os.path.join(HERE, "libpsm_hip.so")   # PSM_LIB: diagnostic builds only
 HEADER = os.path.join(os.path.dirname(HERE), "include", "psm.h")
 
-PSM_ABI_VERSION = 1
+PSM_ABI_VERSION = 2
 VARIANTS = {"chapter5": 0, "deltas": 1, "gradp": 2}
 SCALERS = {"max_abs": 0, "std": 1, "min_max": 2}
+PRECISIONS = {"f32": 0, "bf16": 1}
 STAGES = {"x_input": 0, "res": 1, "block_pred": 2, "offsets": 3, "shift": 4}
 KERNELS = ("encode", "reduce", "mlp", "decode", "strips", "chain", "paste")
 ERRORS = {0: "PSM_OK", -1: "PSM_ERR_ARG", -2: "PSM_ERR_STATE", -3: "PSM_ERR_HIP", -4: "PSM_ERR_NO_DEVICE",
@@ -36,7 +37,7 @@ class PsmError(RuntimeError):
 class psm_config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "abi_version", "variant", "block", "overlap", "c_in", "c_out", "p_in", "p_out", "n_dense", "scaler",
-        "sdf_channel", "device", "max_cases", "strict_degenerate")]
+        "sdf_channel", "device", "max_cases", "strict_degenerate", "precision")]
 
 
 _f32p, _f64p, _i32p = C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int32)

@@ -186,6 +186,49 @@ void free_geometry(psm_handle* h) {
   h->have_geometry = false;
 }
 
+inline uint16_t f2bf(double v) {             // round-to-nearest-even float -> bf16 (NaN stays NaN)
+  const float f = (float)v;
+  uint32_t u; memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+// bf16 tilings for v_mfma_f32_32x32x16_bf16: 16 bytes (8 bf16) per lane and MFMA step.
+//  comp_in : [slice][ntile][g = KS/16][64]; element j of lane l = comp[32t+(l&31)][slice*KS + 16g + 8(l>>5) + j]
+//  comp_out: [coltile][g = ld_out/16][64]; element j of lane l = comp[16g + 8(l>>5) + j][32ct + (l&31)]
+std::vector<uint16_t> pack_comp_in_bf16(const double* comp, int P, int K, int c_in, int S, int NT) {
+  const int KS = PSM_PIX_PER_SLICE * c_in, G = KS / 16, n_slices = S * S / PSM_PIX_PER_SLICE;
+  std::vector<uint16_t> out((size_t)n_slices * NT * G * 64 * 8, 0);
+  for (int s = 0; s < n_slices; ++s)
+    for (int t = 0; t < NT; ++t)
+      for (int g = 0; g < G; ++g)
+        for (int l = 0; l < 64; ++l) {
+          const int p = 32 * t + (l & 31);
+          if (p >= P) continue;
+          const int64_t k = (int64_t)s * KS + 16 * g + 8 * (l >> 5);
+          uint16_t* o = &out[((((size_t)s * NT + t) * G + g) * 64 + l) * 8];
+          for (int j = 0; j < 8; ++j) o[j] = f2bf(comp[(int64_t)p * K + k + j]);
+        }
+  return out;
+}
+
+std::vector<uint16_t> pack_comp_out_bf16(const double* comp, int P, int K_out, int G) {
+  const int nct = K_out / 32;
+  std::vector<uint16_t> out((size_t)nct * G * 64 * 8, 0);
+  for (int ct = 0; ct < nct; ++ct)
+    for (int g = 0; g < G; ++g)
+      for (int l = 0; l < 64; ++l) {
+        const int col = 32 * ct + (l & 31);
+        uint16_t* o = &out[(((size_t)ct * G + g) * 64 + l) * 8];
+        for (int j = 0; j < 8; ++j) {
+          const int p = 16 * g + 8 * (l >> 5) + j;
+          o[j] = p < P ? f2bf(comp[(int64_t)p * K_out + col]) : 0;
+        }
+      }
+  return out;
+}
+
 bool model_complete(const psm_handle* h) {
   if (!h->have_pca || !h->have_scaler) return false;
   for (auto& d : h->dense) if (!d.set) return false;
@@ -219,6 +262,7 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
                hipStream_t st, hipEvent_t* prof) {
   const int M = n_cases * h->B, Mpad = round_up(M, 32);
   Timer tm{h, st, 0, prof};
+  const bool bf16 = (h->cfg.precision == PSM_PRECISION_BF16);
   PsmEncodeArgs ea{};
   ea.grid = d_grid; ea.mean = h->d_mean_in; ea.bpack = h->d_bpack_in; ea.part = h->d_part;
   ea.row_base = h->d_row_base; ea.row_stride = (int64_t)h->Nx * h->cfg.c_in;
@@ -233,10 +277,10 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
     h->timed_events.push_back({e0, e1});
-    HIPCHK(h, psm_launch_encode(ea, st, e0, e1));
+    HIPCHK(h, bf16 ? psm_launch_encode_bf16(ea, st, e0, e1) : psm_launch_encode(ea, st, e0, e1));
   } else {
     tm.before(PSM_K_ENCODE);
-    HIPCHK(h, psm_launch_encode(ea, st));
+    HIPCHK(h, bf16 ? psm_launch_encode_bf16(ea, st) : psm_launch_encode(ea, st));
     tm.after(PSM_K_ENCODE);
   }
 
@@ -257,6 +301,7 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
     da.sa = h->d_sa; da.sb = h->d_sb;
     da.out = head ? h->d_res : h->d_act[l & 1]; da.ld_out = d.ldw;
     da.Kpad = d.Kpad; da.Mpad = Mpad; da.relu = head ? 0 : 1; da.head = head ? 1 : 0;
+    da.bf16 = (h->cfg.precision == PSM_PRECISION_BF16) ? 1 : 0;
     HIPCHK(h, psm_launch_dense(da, st));
     cur = da.out; ld_cur = d.ldw;
   }
@@ -268,7 +313,7 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
   de.row_scale = d_row_scale; de.pred = h->d_pred; de.M = M; de.Mpad = Mpad; de.Gd = h->Gd;
   de.n_coltiles = h->n_coltiles; de.K_out = h->K_out;
   tm.before(PSM_K_DECODE);
-  PSM_REPEAT(h, PSM_K_DECODE) HIPCHK(h, psm_launch_decode(de, st));
+  PSM_REPEAT(h, PSM_K_DECODE) HIPCHK(h, bf16 ? psm_launch_decode_bf16(de, st) : psm_launch_decode(de, st));
   tm.after(PSM_K_DECODE);
 
   PsmStripArgs sa{};
@@ -375,6 +420,7 @@ int psm_create(const psm_config* cfg, psm_handle** out) {
   if (cfg->sdf_channel < 0 || cfg->sdf_channel >= cfg->c_in) return fail(nullptr, PSM_ERR_ARG, "sdf_channel outside the input channels");
   if (cfg->max_cases < 1) return fail(nullptr, PSM_ERR_ARG, "max_cases must be >= 1");
   if (cfg->overlap < 0 || cfg->overlap >= cfg->block) return fail(nullptr, PSM_ERR_ARG, "overlap must lie in [0, block)");
+  if (cfg->precision != PSM_PRECISION_F32 && cfg->precision != PSM_PRECISION_BF16) return fail(nullptr, PSM_ERR_ARG, "unknown precision");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0)
@@ -442,8 +488,19 @@ int psm_set_pca(psm_handle* h, const double* comp_in, const double* mean_in, con
   int rc;
   if ((rc = dev_upload(h, &h->d_mean_in, mi))) return rc;
   if ((rc = dev_upload(h, &h->d_mean_out, mo))) return rc;
+  if (h->cfg.precision == PSM_PRECISION_BF16) {
+    std::vector<uint16_t> bi = pack_comp_in_bf16(comp_in, h->cfg.p_in, h->K_in, h->cfg.c_in, h->S, h->NT);
+    std::vector<uint16_t> bo = pack_comp_out_bf16(comp_out, h->cfg.p_out, h->K_out, h->ld_out / 16);
+    uint16_t *di = nullptr, *dox = nullptr;
+    if ((rc = dev_upload(h, &di, bi))) return rc;
+    if ((rc = dev_upload(h, &dox, bo))) { dev_free(di); return rc; }
+    dev_free(h->d_bpack_in); dev_free(h->d_bpack_out);
+    h->d_bpack_in = reinterpret_cast<float4*>(di);
+    h->d_bpack_out = reinterpret_cast<float4*>(dox);
+  } else {
   if ((rc = dev_upload(h, &h->d_bpack_in, pack_comp_in(comp_in, h->cfg.p_in, h->K_in, h->cfg.c_in, h->S, h->NT)))) return rc;
   if ((rc = dev_upload(h, &h->d_bpack_out, pack_comp_out(comp_out, h->cfg.p_out, h->K_out, h->Gd)))) return rc;
+  }
   h->have_pca = true;
   return PSM_OK;
 }
@@ -463,7 +520,14 @@ int psm_set_dense(psm_handle* h, int32_t layer, int32_t n_in, int32_t n_out, con
   for (int k = 0; k < n_in; ++k) memcpy(&W[(size_t)k * d.ldw], kernel + (size_t)k * n_out, n_out * sizeof(float));
   memcpy(b.data(), bias, n_out * sizeof(float));
   int rc;
-  if ((rc = dev_upload(h, &d.W, W))) return rc;
+  if (h->cfg.precision == PSM_PRECISION_BF16) {
+    std::vector<uint16_t> Wb(W.size());
+    for (size_t q = 0; q < W.size(); ++q) Wb[q] = f2bf(W[q]);
+    uint16_t* dw = nullptr;
+    if ((rc = dev_upload(h, &dw, Wb))) return rc;
+    dev_free(d.W);
+    d.W = reinterpret_cast<float*>(dw);
+  } else if ((rc = dev_upload(h, &d.W, W))) return rc;
   if ((rc = dev_upload(h, &d.b, b))) return rc;
   d.set = true;
   return PSM_OK;

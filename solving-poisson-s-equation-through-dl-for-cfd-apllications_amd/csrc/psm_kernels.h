@@ -34,6 +34,7 @@ struct PsmDenseArgs {
   const float* sa; const float* sb;    // head only: out = (acc+bias)*sa + sb
   float* out; int ld_out;              // [Mpad][ld_out]
   int Kpad, Mpad, relu, head;
+  int bf16;                            // W points to bf16 [Kpad][ld_w]; activations rounded to bf16 on load
 };
 
 struct PsmDecodeArgs {
@@ -80,6 +81,9 @@ struct PsmPasteArgs {
 hipError_t psm_read_stamps(unsigned long long* out);   // [64]; zeros unless built with -DPSM_STAMPS
 // ev_start / ev_stop (optional): stamped with the dispatch's own begin / end (hipExtLaunchKernel)
 hipError_t psm_launch_encode(const PsmEncodeArgs& a, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// bf16 operand path (psm_bf16.hip): bpack / weights point to bf16 data in the same tilings
+hipError_t psm_launch_encode_bf16(const PsmEncodeArgs& a, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+hipError_t psm_launch_decode_bf16(const PsmDecodeArgs& a, hipStream_t s);
 hipError_t psm_launch_reduce(const PsmReduceArgs& a, hipStream_t s);
 hipError_t psm_launch_dense(const PsmDenseArgs& a, hipStream_t s);
 hipError_t psm_launch_decode(const PsmDecodeArgs& a, hipStream_t s);

@@ -219,7 +219,10 @@ hipError_t psm_launch_reduce(const PsmReduceArgs& a, hipStream_t st) {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-template <int KG>   // groups of 16 k per wave held in registers per pass
+// BF16: weights stored as bf16, activations rounded to bf16 on load; products are then exact
+// and the f32 MFMA accumulates them exactly like v_mfma_*_bf16 would (this layer is latency
+// bound, the bf16 storage only halves its weight bytes).
+template <int KG, bool BF16>   // KG: groups of 16 k per wave held in registers per pass
 __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a) {
   __shared__ float red[8][2][16 * 17];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -236,6 +239,8 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a) {
   const float* arow0 = a.in + (int64_t)(mt * 32 + i) * a.ld_in + k0 + 4 * kq;
   const float* arow1 = arow0 + (int64_t)16 * a.ld_in;
   const float* wcol = a.W + (int64_t)(k0 + 4 * kq) * a.ld_w + nt * 16 + i;
+  const __bf16* wcolb = reinterpret_cast<const __bf16*>(a.W) + (int64_t)(k0 + 4 * kq) * a.ld_w + nt * 16 + i;
+  auto rnd = [](float v) { return BF16 ? (float)(__bf16)v : v; };
   const int ngroups = klen / 16, rem = klen - ngroups * 16;   // rem in {0,4,8,12}: handled 4 k at a time
   for (int g0 = 0; g0 < ngroups; g0 += KG) {
     float4 a0[KG], a1[KG];
@@ -245,18 +250,20 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a) {
       if (g0 + g < ngroups) {
         a0[g] = *reinterpret_cast<const float4*>(arow0 + 16 * (g0 + g));
         a1[g] = *reinterpret_cast<const float4*>(arow1 + 16 * (g0 + g));
-        const float* wp = wcol + (int64_t)(16 * (g0 + g)) * a.ld_w;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) w[g][j] = wp[(int64_t)j * a.ld_w];
+        for (int j = 0; j < 4; ++j) {
+          const int64_t off = (int64_t)(16 * (g0 + g) + j) * a.ld_w;
+          w[g][j] = BF16 ? (float)wcolb[off] : wcol[off];
+        }
       }
     }
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
       if (g0 + g < ngroups) {
-        acc0 = MFMA16(a0[g].x, w[g][0], acc0); acc1 = MFMA16(a1[g].x, w[g][0], acc1);
-        acc0 = MFMA16(a0[g].y, w[g][1], acc0); acc1 = MFMA16(a1[g].y, w[g][1], acc1);
-        acc0 = MFMA16(a0[g].z, w[g][2], acc0); acc1 = MFMA16(a1[g].z, w[g][2], acc1);
-        acc0 = MFMA16(a0[g].w, w[g][3], acc0); acc1 = MFMA16(a1[g].w, w[g][3], acc1);
+        acc0 = MFMA16(rnd(a0[g].x), w[g][0], acc0); acc1 = MFMA16(rnd(a1[g].x), w[g][0], acc1);
+        acc0 = MFMA16(rnd(a0[g].y), w[g][1], acc0); acc1 = MFMA16(rnd(a1[g].y), w[g][1], acc1);
+        acc0 = MFMA16(rnd(a0[g].z), w[g][2], acc0); acc1 = MFMA16(rnd(a1[g].z), w[g][2], acc1);
+        acc0 = MFMA16(rnd(a0[g].w), w[g][3], acc0); acc1 = MFMA16(rnd(a1[g].w), w[g][3], acc1);
       }
     }
   }
@@ -264,9 +271,10 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a) {
   for (int kk = ngroups * 16; kk < klen; kk += 4) {
     const float av0 = a.in[(int64_t)(mt * 32 + i) * a.ld_in + k0 + kk + kq];
     const float av1 = a.in[(int64_t)(mt * 32 + 16 + i) * a.ld_in + k0 + kk + kq];
-    const float wv = a.W[(int64_t)(k0 + kk + kq) * a.ld_w + nt * 16 + i];
-    acc0 = MFMA16(av0, wv, acc0);
-    acc1 = MFMA16(av1, wv, acc1);
+    const int64_t woff = (int64_t)(k0 + kk + kq) * a.ld_w + nt * 16 + i;
+    const float wv = BF16 ? (float)reinterpret_cast<const __bf16*>(a.W)[woff] : a.W[woff];
+    acc0 = MFMA16(rnd(av0), wv, acc0);
+    acc1 = MFMA16(rnd(av1), wv, acc1);
   }
   (void)rem;
   PSM_STAMP(0, 13);
@@ -291,7 +299,8 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a) {
 }
 
 hipError_t psm_launch_dense(const PsmDenseArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL((psm_dense_kernel<4>), dim3(a.ld_w / 16, a.Mpad / 32), dim3(512), 0, st, a);
+  if (a.bf16) hipLaunchKernelGGL((psm_dense_kernel<4, true>), dim3(a.ld_w / 16, a.Mpad / 32), dim3(512), 0, st, a);
+  else hipLaunchKernelGGL((psm_dense_kernel<4, false>), dim3(a.ld_w / 16, a.Mpad / 32), dim3(512), 0, st, a);
   return hipGetLastError();
 }
 

@@ -43,7 +43,9 @@ class GridSurrogate:
     """One surrogate model bound to one uniform grid shape on one GPU."""
 
     def __init__(self, model: SurrogateModel, ny: int, nx: int, max_cases: int = 1, device: int = 0,
-                 strict_degenerate: bool = False):
+                 strict_degenerate: bool = False, precision: str = "f32"):
+        if precision not in _lib.PRECISIONS:
+            raise ValueError("precision must be 'f32' or 'bf16'")
         if model.scaler_kind not in _lib.SCALERS:
             raise ValueError("Standardization method not valid")
         self.lib = _lib.load()
@@ -52,7 +54,8 @@ class GridSurrogate:
             abi_version=_lib.PSM_ABI_VERSION, variant=_lib.VARIANTS[model.variant], block=model.S,
             overlap=0 if model.ov is None else int(model.ov), c_in=model.c_in, c_out=model.c_out,
             p_in=model.p_in, p_out=model.p_out, n_dense=len(model.weights), scaler=_lib.SCALERS[model.scaler_kind],
-            sdf_channel=model.sdf_ch, device=device, max_cases=max_cases, strict_degenerate=int(strict_degenerate))
+            sdf_channel=model.sdf_ch, device=device, max_cases=max_cases, strict_degenerate=int(strict_degenerate),
+            precision=_lib.PRECISIONS[precision])
         h = C.c_void_p()
         _lib.check(self.lib.psm_create(C.byref(cfg), C.byref(h)))
         self.h = h

@@ -248,3 +248,37 @@ def test_errors_are_reported_not_fatal():
     bad.scaler_kind = "zscore"
     with pytest.raises(ValueError, match="Standardization method not valid"):
         GridSurrogate(bad, 256, 256)
+
+
+def test_config4_bf16_512():
+    """BASELINE config 4: 512x512, bf16 operands / f32 accumulation (v_mfma_f32_32x32x16_bf16).
+    No reference counterpart (the reference is float64/float32): compared with the oracle's bf16
+    emulation (same roundings, exact sums) and, loosely, with the full-precision oracle.
+    Tolerance: bf16 has 8 significant bits; an activation that sits on a rounding boundary may
+    round differently after float32 vs float64 accumulation."""
+    model = synthetic.make_model("deltas")
+    grid = synthetic.channel_grid(512, 512, seed=4, noise=0.05).astype(np.float32)
+    with GridSurrogate(model, 512, 512, precision="bf16") as sur:
+        assert sur.B == 30
+        f = sur.solve(grid)[0]
+        x = sur.stage("x_input")
+        bp = sur.stage("block_pred")
+    om = oracle_model(model)
+    emu = orc.solve_grid(grid.astype(np.float64), om, precision="bf16")
+    full = orc.solve_grid(grid.astype(np.float64), om)
+    assert np.isfinite(f).all()
+    e_x, e_bp, e_f = rel_l2(x, emu.x_input), rel_l2(bp, emu.block_pred), rel_l2(f, emu.fields)
+    print("bf16 vs emulation: x_in %.2e block_pred %.2e fields %.2e; vs f64 oracle fields %.2e" % (e_x, e_bp, e_f, rel_l2(f, full.fields)))
+    assert e_x <= 1e-4            # same roundings, f32 vs f64 accumulation only
+    assert e_bp <= 5e-3 and e_f <= 5e-3     # a coefficient on a bf16 rounding boundary may flip (f32 vs f64 sums)
+    assert rel_l2(x, full.x_input) <= 2e-2 and rel_l2(f, full.fields) <= 5e-2
+
+
+def test_bf16_all_variants_small():
+    for variant, ny, nx in (("gradp", 272, 288), ("chapter5", 300, 400)):
+        model = synthetic.make_model(variant, p_in=40, p_out=24)
+        grid = synthetic.channel_grid(ny, nx, seed=9).astype(np.float32)
+        with GridSurrogate(model, ny, nx, precision="bf16") as sur:
+            f = sur.solve(grid)[0]
+        emu = orc.solve_grid(grid.astype(np.float64), oracle_model(model), precision="bf16")
+        assert rel_l2(f, emu.fields) <= 5e-3
