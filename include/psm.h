@@ -165,6 +165,13 @@ int psm_set_geometry(psm_handle* h, int64_t n_cells, int32_t ny, int32_t nx,
  * Synchronous. */
 int psm_solve(psm_handle* h, const double* cells, int64_t n, int32_t rank, double* p_out);
 
+/* scipy.ndimage.gaussian_filter(field, sigma=(sigma_y, sigma_x), order=0) as used at
+ * SM_call.py:353-363 (sigma (10,10) on the assembled field, (50,50) on the deltaU-change
+ * weight) and Eval_dual_Dense_onlycil.py:366-367: mode 'reflect', truncate 4.  Host buffers
+ * [ny, nx] float32, synchronous; in and out may alias.  Independent of the plan. */
+int psm_gaussian_filter(psm_handle* h, const float* in, int32_t ny, int32_t nx, double sigma_y,
+                        double sigma_x, float* out);
+
 /* Wait for everything submitted through this handle. */
 int psm_synchronize(psm_handle* h);
 

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -799,6 +800,42 @@ int psm_solve(psm_handle* h, const double* cells, int64_t n, int32_t rank, doubl
   HIPCHK(h, hipMemcpyAsync(h->h_p, h->d_p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
   memcpy(p_out, h->h_p, (size_t)n * sizeof(double));
+  return PSM_OK;
+}
+
+int psm_gaussian_filter(psm_handle* h, const float* in, int32_t ny, int32_t nx, double sigma_y, double sigma_x, float* out) {
+  if (!h) return PSM_ERR_ARG;
+  if (!in || !out || ny < 1 || nx < 1 || (int64_t)ny * nx > ((int64_t)1 << 28)) return fail(h, PSM_ERR_ARG, "bad field");
+  if (!(sigma_y > 0.0) || !(sigma_x > 0.0) || sigma_y > 1e4 || sigma_x > 1e4) return fail(h, PSM_ERR_ARG, "sigma must be positive");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  hipStream_t st = h->stream;
+  const size_t n = (size_t)ny * nx;
+  float *d_a = nullptr, *d_b = nullptr, *d_w = nullptr;
+  int rc = PSM_OK;
+  auto weights = [](double sigma, std::vector<float>& w) {      // scipy.ndimage._gaussian_kernel1d, order 0
+    const int r = (int)(4.0 * sigma + 0.5);
+    std::vector<double> p(2 * r + 1);
+    double sum = 0.0;
+    for (int x = -r; x <= r; ++x) { p[x + r] = std::exp(-0.5 / (sigma * sigma) * (double)x * (double)x); sum += p[x + r]; }
+    w.resize(2 * r + 1);
+    for (int k = 0; k < 2 * r + 1; ++k) w[k] = (float)(p[k] / sum);
+    return r;
+  };
+  std::vector<float> wy, wx;
+  const int ry = weights(sigma_y, wy), rx = weights(sigma_x, wx);
+  std::vector<float> wall(wy);
+  wall.insert(wall.end(), wx.begin(), wx.end());
+  if ((rc = dev_alloc(h, &d_a, n)) || (rc = dev_alloc(h, &d_b, n)) || (rc = dev_upload(h, &d_w, wall))) {
+    dev_free(d_a); dev_free(d_b); dev_free(d_w);
+    return rc;
+  }
+  hipError_t e = hipMemcpyAsync(d_a, in, n * sizeof(float), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = psm_launch_gauss1d(d_a, d_b, ny, nx, 0, ry, d_w, st);
+  if (e == hipSuccess) e = psm_launch_gauss1d(d_b, d_a, ny, nx, 1, rx, d_w + wy.size(), st);
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d_a, n * sizeof(float), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  dev_free(d_a); dev_free(d_b); dev_free(d_w);
+  if (e != hipSuccess) return fail(h, PSM_ERR_HIP, std::string("gaussian filter: ") + hipGetErrorString(e));
   return PSM_OK;
 }
 

@@ -96,3 +96,31 @@ hipError_t psm_launch_to_mesh(const PsmToMeshArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(psm_to_mesh_kernel, dim3((unsigned)((a.n_cells + 255) / 256)), dim3(256), 0, st, a);
   return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------
+// separable Gaussian smoothing of an assembled field (SMD:353-363, UGP:366-367):
+// scipy.ndimage.gaussian_filter(order=0, mode='reflect', truncate=4.0) = correlate1d along
+// axis 0, then along axis 1, with weights exp(-x^2 / 2 sigma^2) / sum over |x| <= int(4 sigma + 0.5)
+// and half-sample-symmetric ("reflect": d c b a | a b c d | d c b a) boundaries.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void psm_gauss1d_kernel(const float* in, float* out, int ny, int nx, int axis,
+                                                          int radius, const float* wts) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= ny * nx) return;
+  const int y = idx / nx, x = idx - y * nx;
+  const int n = axis == 0 ? ny : nx, i = axis == 0 ? y : x, stride = axis == 0 ? nx : 1;
+  const float* line = in + (axis == 0 ? x : y * nx);
+  float acc = 0.f;
+  for (int t = -radius; t <= radius; ++t) {
+    int j = (i + t) % (2 * n);
+    if (j < 0) j += 2 * n;
+    if (j >= n) j = 2 * n - 1 - j;
+    acc += wts[t + radius] * line[(int64_t)j * stride];
+  }
+  out[idx] = acc;
+}
+
+hipError_t psm_launch_gauss1d(const float* in, float* out, int ny, int nx, int axis, int radius, const float* wts, hipStream_t st) {
+  hipLaunchKernelGGL(psm_gauss1d_kernel, dim3((ny * nx + 255) / 256), dim3(256), 0, st, in, out, ny, nx, axis, radius, wts);
+  return hipGetLastError();
+}

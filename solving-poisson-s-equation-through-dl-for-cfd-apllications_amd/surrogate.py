@@ -140,6 +140,16 @@ class GridSurrogate:
         self._chk(self.lib.psm_reassemble(self.h, _p(g, C.c_float), _p(bp, C.c_float), _p(out, C.c_float)))
         return out
 
+    def gaussian_filter(self, field: np.ndarray, sigma=(10.0, 10.0)) -> np.ndarray:
+        """scipy.ndimage.gaussian_filter(field, sigma, order=0) on the GPU (SM_call.py:353-363)."""
+        f = _f32(field)
+        if f.ndim != 2:
+            raise ValueError("field must be 2-D")
+        out = np.empty_like(f)
+        self._chk(self.lib.psm_gaussian_filter(self.h, _p(f, C.c_float), f.shape[0], f.shape[1], float(sigma[0]),
+                                                float(sigma[1]), _p(out, C.c_float)))
+        return out
+
     # -- introspection
     def stage(self, name: str, n_cases: int = 1) -> np.ndarray:
         m = self.model
@@ -260,8 +270,6 @@ class Evaluation:
                             deltaU_change_grid=None, deltaP_prev_grid=None, apply_deltaU_change_wgt=False):
         """SM_call.py:182: ``array`` [B,S,S] corrected and pasted into [shape_y, shape_x].
         The flow mask comes from ``self.x_array`` like in the reference."""
-        if apply_filter or apply_deltaU_change_wgt:
-            raise NotImplementedError("Gaussian filter / deltaU-change weighting are not built yet (SURVEY §8 a13)")
         if self.x_array is None:
             raise ValueError("self.x_array must hold the input blocks")
         blocks, nx_, ny_ = layout(self.variant, shape_y, shape_x, self.shape, self.overlap)
@@ -269,7 +277,16 @@ class Evaluation:
             raise ValueError("n_x / n_y / indices_list do not match this grid")
         sur = self._surrogate(shape_y, shape_x)
         grid = _grid_from_blocks(np.asarray(self.x_array, np.float32), blocks, shape_y, shape_x)
-        return sur.reassemble(grid, np.asarray(array))[..., 0], None
+        result = sur.reassemble(grid, np.asarray(array))[..., 0]
+        filter_tuple = (10, 10)                                   # SM_call.py:353
+        if apply_filter:
+            result = sur.gaussian_filter(result, filter_tuple)
+        change_in_deltap = None
+        if apply_deltaU_change_wgt:                               # SM_call.py:359-363
+            w = sur.gaussian_filter(np.asarray(deltaU_change_grid, np.float32), (50, 50))
+            change_in_deltap = (result - np.asarray(deltaP_prev_grid, np.float32)) * w
+            change_in_deltap = sur.gaussian_filter(change_in_deltap, filter_tuple)
+        return result, change_in_deltap
 
 
 class EvaluationGradP(Evaluation):
@@ -290,8 +307,6 @@ class EvaluationGradP(Evaluation):
         """Eval_dual_Dense_onlycil.py:255: one channel ('dp_dx' | 'dp_dy') of decoded blocks."""
         if field not in ("dp_dx", "dp_dy"):
             raise ValueError(field)
-        if apply_filter:
-            raise NotImplementedError("Gaussian filter is not built yet (SURVEY §8 a13)")
         blocks, nx_, ny_ = layout(self.variant, shape_y, shape_x, self.shape, self.avance)
         if (nx_, ny_) != (n_x, n_y) or len(indices_list) != len(blocks):
             raise ValueError("n_x / n_y / indices_list do not match this grid")
@@ -301,7 +316,10 @@ class EvaluationGradP(Evaluation):
         both = np.zeros(a.shape + (2,), np.float32)
         ch = 0 if field == "dp_dx" else 1
         both[..., ch] = a
-        return sur.reassemble(grid, both)[None, :, :, ch:ch + 1]
+        res = sur.reassemble(grid, both)[..., ch]
+        if apply_filter:                                          # Eval_dual_Dense_onlycil.py:366-367 (returns the 2-D array)
+            return sur.gaussian_filter(res, (10, 10))
+        return res[None, :, :, None]
 
 
 class SolverModule:

@@ -71,3 +71,21 @@ def build_mesh_case(step: int = 0):
     array, top, obst = synthetic.channel_mesh(step=step)
     model = synthetic.make_model("chapter5", p_in=32, p_out=32, seed_pca=4321, seed_w=11)
     return array, top, obst, model, MESH_MAXS
+
+
+def build_filter_case():
+    """Inputs of the optional post-steps of assemble_prediction (SM_call.py:352-363): decoded blocks of
+    the deltas_256x256 case (oracle), a deltaU-change image and a previous delta-p image."""
+    from oracle import psm_oracle as orc
+    grid, model = build("deltas_256x256")
+    sc = orc.Scaler(model.scaler_kind, model.in_a, model.in_b, model.out_a, model.out_b)
+    om = orc.Model(model.variant, model.c_in, model.c_out, model.comp_in, model.mean_in, model.comp_out, model.mean_out,
+                   model.weights, sc, model.out_scale, model.S, model.ov, model.sdf_ch)
+    sol = orc.solve_grid(grid, om)
+    rng = np.random.default_rng(77)
+    ny, nx = grid.shape[:2]
+    yy, xx = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
+    dU = np.abs(np.sin(xx / 40.0) * np.cos(yy / 25.0)) + 0.05 * rng.random((ny, nx))
+    dU /= dU.max()
+    dPprev = 0.3 * np.cos(xx / 33.0 + 1.0) * np.sin(yy / 47.0) + 0.02 * rng.standard_normal((ny, nx))
+    return grid, model, sol.block_pred[..., 0], dU, dPprev

@@ -299,6 +299,21 @@ def main():
     print(f"mesh_chapter5: N={len(array)} grid={geo.ny}x{geo.nx} B={int(out['n_blocks'])} |p|max={np.abs(out['p']).max():.4f} "
           f"fallback cells={(out['p'] == array[:, 4]).sum()}")
 
+    # ---- optional post-steps of assemble_prediction (pressureSM_Poisson/SM_call.py:334, 504-517):
+    #      Gaussian filter + deltaU-change weighting, run on the decoded blocks of one deltas case
+    grid, model, bp, dU, dPprev = cases.build_filter_case()
+    SMP = f"{REF}/Improved_SM/deltaU_to_deltaP/source/pressureSM_Poisson/SM_call.py"
+    import scipy.ndimage as _ndi
+    tree = _tree(SMP)
+    asm = _method(tree, "Evaluation", "assemble_prediction", {"np": np, "ndimage": _ndi}, SMP)
+    lay = orc.block_layout("deltas", grid.shape[0], grid.shape[1])
+    me = types.SimpleNamespace(overlap=lay.ov, shape=lay.S, Ref_BC=0, x_array=orc.extract_blocks(grid, lay, 3))
+    with np.errstate(all="ignore"):
+        res, chg = asm(me, bp.copy(), [list(t) for t in lay.tags], lay.n_x, lay.n_y, True, grid.shape[1], grid.shape[0],
+                       dU.copy(), dPprev.copy(), True)
+    np.savez_compressed(os.path.join(HERE, "deltas_filters_256x256.npz"), result=res.astype(np.float32), change=chg.astype(np.float32))
+    print("deltas_filters_256x256: |res|max=%.4f |change|max=%.5f" % (np.abs(res).max(), np.abs(chg).max()))
+
     for name in cases.GOLDEN_CASES:
         grid, model = cases.build(name)
         if model.variant == "gradp":

@@ -72,3 +72,40 @@ def test_solver_module_init_func_py_func(mesh_case):
     assert np.abs(p2 - ref2).max() <= 2e-4 * np.abs(ref2).max()
     with pytest.raises(Exception):
         sm.py_func(array2[:-5], 0)              # wrong cell count: reported, not fatal
+
+
+def test_oracle_filters_match_reference_run():
+    """assemble_prediction with apply_filter / apply_deltaU_change_wgt (SM_call.py:352-363): the oracle's
+    reassembly followed by SciPy's gaussian_filter (the routine the reference calls) against the run of
+    the reference's own method."""
+    import scipy.ndimage as ndi
+    grid, model, bp, dU, dPprev = cases.build_filter_case()
+    gold = cases.load_golden("deltas_filters_256x256")
+    lay = orc.block_layout("deltas", *grid.shape[:2])
+    a = orc.assemble_deltas(bp, orc.extract_blocks(grid, lay, 3), lay)
+    res = ndi.gaussian_filter(a.field, sigma=(10, 10), order=0)
+    w = ndi.gaussian_filter(dU, sigma=(50, 50), order=0)
+    chg = ndi.gaussian_filter((res - dPprev) * w, sigma=(10, 10), order=0)
+    np.testing.assert_allclose(res, gold["result"], rtol=0, atol=2e-7)
+    np.testing.assert_allclose(chg, gold["change"], rtol=0, atol=2e-7)
+
+
+@pytest.mark.gpu
+def test_gpu_filters_and_weighting():
+    from psm_amd import Evaluation
+    grid, model, bp, dU, dPprev = cases.build_filter_case()
+    gold = cases.load_golden("deltas_filters_256x256")
+    lay = orc.block_layout("deltas", *grid.shape[:2])
+    ev = Evaluation(5e-3, 128, 32, 0.95, 0.95, None, None, 128, "std", model=model)
+    ev.x_array = orc.extract_blocks(grid, lay, 3)
+    res, chg = ev.assemble_prediction(bp, [list(t) for t in lay.tags], lay.n_x, lay.n_y, True, 256, 256, dU, dPprev, True)
+    assert np.abs(res - gold["result"]).max() <= 1e-4 * np.abs(gold["result"]).max()
+    assert np.abs(chg - gold["change"]).max() <= 1e-4 * max(np.abs(gold["change"]).max(), 1e-3)
+    # the filter alone against SciPy, including a radius larger than the image (sigma 50 -> radius 200 on 131 rows)
+    import scipy.ndimage as ndi
+    rng = np.random.default_rng(3)
+    f = rng.standard_normal((131, 257)).astype(np.float32)
+    for sig in ((10, 10), (50, 50), (2.5, 7.0)):
+        got = ev._surrogate(256, 256).gaussian_filter(f, sig)
+        ref = ndi.gaussian_filter(f.astype(np.float64), sigma=sig, order=0)
+        assert np.abs(got - ref).max() <= 2e-6
