@@ -172,6 +172,17 @@ int psm_solve(psm_handle* h, const double* cells, int64_t n, int32_t rank, doubl
 int psm_gaussian_filter(psm_handle* h, const float* in, int32_t ny, int32_t nx, double sigma_y,
                         double sigma_x, float* out);
 
+/* U_to_gradP: integrate the assembled (dp/dx, dp/dy) into p (integrate_field,
+ * Eval_dual_Dense_onlycil.py:371-416, and the four-quadrant stitching :597-628).
+ * psm_set_integration fixes the geometry: sdfunct [ny*nx] (self.sdfunct[:,:,0], also used by the
+ * reference as the per-row "reset" index list), the cut (center_y = 200 and center_x of :599-600)
+ * and the grid spacings np.diff(xl)[0], np.diff(yl)[0].  psm_integrate_gradp: gradp [ny,nx,2]
+ * -> p [ny,nx], host float32 buffers, synchronous.  Returns PSM_ERR_UNSUPPORTED where the
+ * reference itself raises (unequal flow-cell counts at the cut, index list outside a block). */
+int psm_set_integration(psm_handle* h, int32_t ny, int32_t nx, const double* sdfunct, int32_t center_y,
+                        int32_t center_x, double dx, double dy);
+int psm_integrate_gradp(psm_handle* h, const float* gradp, float* p_out);
+
 /* Wait for everything submitted through this handle. */
 int psm_synchronize(psm_handle* h);
 

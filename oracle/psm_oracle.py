@@ -686,3 +686,54 @@ def py_func_mesh(array, geo: Geometry, model: Model, maxs):
     grid, U_max = mesh_to_grid(array, geo, maxs[0], maxs[1])
     sol = solve_grid(grid, model)
     return grid_to_mesh(sol.fields[..., 0], array, geo, maxs[3], U_max), grid, sol
+
+
+# --------------------------------------------------------------------------
+# U_to_gradP: integration of the assembled gradient into p (UGP:371-416, 592-628)
+# --------------------------------------------------------------------------
+def integrate_field(block, sdfunct, dx, dy, direction_x=1, direction_y=1):
+    """UGP:371-416.  ``block`` [h,w,2] = (dp/dx, dp/dy).  Quirks kept: row ``i`` of the GLOBAL
+    ``sdfunct`` (full width, cast to int) is used as an index list into the block row ("reset the
+    cumulative sum at the obstacle"), whatever the block's position."""
+    gx = np.array(block[..., 0], dtype=np.float64)
+    gy = np.array(block[..., 1], dtype=np.float64)
+    h, w = gx.shape
+    SdPx = np.empty((h, w))
+    for i in range(h):
+        aaa = gx[i].copy()
+        ccc = np.cumsum(aaa)
+        nn = sdfunct[i, :].astype(int)
+        dd = np.diff(np.concatenate(([0.0], ccc[nn])))
+        aaa[nn] = -dd
+        SdPx[i] = np.cumsum(aaa) * dx
+    SdPy = np.cumsum(gy, axis=0) * dy
+    ij = -1 if direction_x == -1 else 0
+    ii = -1 if direction_y == -1 else 0
+    return SdPy[:, ij][:, None] - SdPy[ii, ij] + SdPx - SdPx[:, ij][:, None]
+
+
+def integrate_gradp(gradP, sdfunct, dx, dy, center_y, center_x):
+    """UGP:597-628: the domain is cut into four quadrants at (center_y, center_x); each is integrated
+    from its outer corner and the left quadrants are shifted onto the right ones over the flow cells
+    of the two columns at the cut."""
+    Ny, Nx = gradP.shape[:2]
+    cy, cx = center_y, center_x
+    out = np.empty((Ny, Nx))
+    p1 = integrate_field(gradP[:cy, cx - 1:, :], sdfunct, dx, dy, direction_x=-1)
+    out[:cy, cx - 1:] = p1
+    p2 = integrate_field(gradP[:cy, :cx, :], sdfunct, dx, dy)
+    m1, m2 = sdfunct[:cy, cx - 1] != 0, sdfunct[:cy, cx] != 0
+    out[:cy, :cx] = p2 - (p2[:, -1][m2] - p1[:, 0][m1]).mean()
+    p3 = integrate_field(gradP[cy:, cx - 1:, :], sdfunct, dx, dy, direction_x=-1, direction_y=-1)
+    out[cy:, cx - 1:] = p3
+    p4 = integrate_field(gradP[cy:, :cx, :], sdfunct, dx, dy, direction_y=-1)
+    m3, m4 = sdfunct[cy:, cx - 1] != 0, sdfunct[cy:, cx] != 0
+    out[cy:, :cx] = p4 - (p4[:, -1][m4] - p3[:, 0][m3]).mean()
+    return out
+
+
+def integration_center(sdfunct, x_min, x_max, X0_min, delta, row=200):
+    """UGP:594-600: ``center_p_x`` from the obstacle's extent on grid row ``row`` (hard-wired 200)."""
+    xl = np.linspace(x_min, x_max, sdfunct.shape[1])
+    solid = sdfunct[row, :] == 0
+    return int(((xl[solid].max() + xl[solid].min()) / 2 - X0_min) / delta), int(row)

@@ -60,6 +60,8 @@ SIGNATURES = {
                                    C.c_int32, C.c_int32, C.c_double]),
     "psm_solve": (C.c_int, [_hp, _f64p, C.c_int64, C.c_int32, _f64p]),
     "psm_gaussian_filter": (C.c_int, [_hp, _f32p, C.c_int32, C.c_int32, C.c_double, C.c_double, _f32p]),
+    "psm_set_integration": (C.c_int, [_hp, C.c_int32, C.c_int32, _f64p, C.c_int32, C.c_int32, C.c_double, C.c_double]),
+    "psm_integrate_gradp": (C.c_int, [_hp, _f32p, _f32p]),
     "psm_synchronize": (C.c_int, [_hp]),
     "psm_read_stage": (C.c_int, [_hp, C.c_int32, _f32p, C.c_size_t]),
     "psm_profile_solve": (C.c_int, [_hp, C.c_void_p, C.c_int32, C.c_void_p, _f32p]),

@@ -66,6 +66,11 @@ struct psm_handle {
   int32_t *d_vtx_m2g = nullptr, *d_src_of_cell = nullptr, *d_vtx_g2m = nullptr, *d_cell_of_point = nullptr;
   double *d_wts_m2g = nullptr, *d_sdf = nullptr, *d_wts_g2m = nullptr, *d_cells = nullptr, *d_p = nullptr, *d_umax = nullptr;
   uint8_t* d_near_wall = nullptr;
+  // U_to_gradP integration (psm_set_integration)
+  bool have_integ = false;
+  PsmIntegArgs integ{};
+  int2 *d_fixups = nullptr, *d_pairs = nullptr;
+  float *d_integ_buf = nullptr, *d_gradp = nullptr;
   double *h_cells = nullptr, *h_p = nullptr;
   double maxs[4] = {1, 1, 1, 1};
   int normalise_sdf = 0, fill_input = 0;
@@ -182,6 +187,8 @@ void free_geometry(psm_handle* h) {
   dev_free(h->d_vtx_m2g); dev_free(h->d_src_of_cell); dev_free(h->d_vtx_g2m); dev_free(h->d_cell_of_point);
   dev_free(h->d_wts_m2g); dev_free(h->d_sdf); dev_free(h->d_wts_g2m); dev_free(h->d_cells); dev_free(h->d_p);
   dev_free(h->d_umax); dev_free(h->d_near_wall);
+  dev_free(h->d_fixups); dev_free(h->d_pairs); dev_free(h->d_integ_buf); dev_free(h->d_gradp);
+  h->have_integ = false;
   if (h->h_cells) { (void)hipHostFree(h->h_cells); h->h_cells = nullptr; }
   if (h->h_p) { (void)hipHostFree(h->h_p); h->h_p = nullptr; }
   h->have_geometry = false;
@@ -836,6 +843,72 @@ int psm_gaussian_filter(psm_handle* h, const float* in, int32_t ny, int32_t nx, 
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   dev_free(d_a); dev_free(d_b); dev_free(d_w);
   if (e != hipSuccess) return fail(h, PSM_ERR_HIP, std::string("gaussian filter: ") + hipGetErrorString(e));
+  return PSM_OK;
+}
+
+int psm_set_integration(psm_handle* h, int32_t ny, int32_t nx, const double* sdfunct, int32_t cy, int32_t cx, double dx, double dy) {
+  if (!h) return PSM_ERR_ARG;
+  if (!sdfunct || ny < 2 || nx < 3) return fail(h, PSM_ERR_ARG, "bad integration geometry");
+  if (cy < 1 || cy >= ny || cx < 1 || cx >= nx) return fail(h, PSM_ERR_ARG, "cut outside the grid");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  const int wl = cx, wr = nx - cx + 1, hmax = std::max(cy, ny - cy);
+  // "reset" quirk (Eval_dual_Dense_onlycil.py:394-396): nn = sdfunct[i,:].astype(int) indexes the block row
+  std::vector<int2> fix((size_t)hmax * PSM_INTEG_MAX_FIX, make_int2(-1, -1));
+  for (int a = 0; a < hmax; ++a) {
+    std::map<int, int> last;                       // index value -> last position
+    std::vector<int> nn(nx);
+    for (int k = 0; k < nx; ++k) {
+      nn[k] = (int)sdfunct[(int64_t)a * nx + k];   // C truncation == astype(int) for finite values
+      if (nn[k] < 0) nn[k] += std::min(wl, wr);    // negative indices wrap in NumPy; not expected for a distance
+      last[nn[k]] = k;
+    }
+    if ((int)last.size() > PSM_INTEG_MAX_FIX) return fail(h, PSM_ERR_UNSUPPORTED, "more distinct int(sdf) values on a row than supported");
+    int e = 0;
+    for (auto& kv : last) {
+      if (kv.first >= std::min(wl, wr)) return fail(h, PSM_ERR_UNSUPPORTED, "int(sdfunct) indexes outside a quadrant row (the reference raises IndexError)");
+      fix[(size_t)a * PSM_INTEG_MAX_FIX + e++] = make_int2(kv.first, kv.second > 0 ? nn[kv.second - 1] : -1);
+    }
+  }
+  std::vector<int2> pairs;
+  int npair[2];
+  for (int q = 0; q < 2; ++q) {
+    const int r0 = q ? cy : 0, r1 = q ? ny : cy;
+    std::vector<int> rl, rr;
+    for (int y = r0; y < r1; ++y) {
+      if (sdfunct[(int64_t)y * nx + cx] != 0.0) rl.push_back(y);        // mask2 / mask4 (column cx)
+      if (sdfunct[(int64_t)y * nx + cx - 1] != 0.0) rr.push_back(y);    // mask1 / mask3 (column cx-1)
+    }
+    if (rl.size() != rr.size()) return fail(h, PSM_ERR_UNSUPPORTED, "flow-cell counts of the two cut columns differ (the reference raises a broadcast error)");
+    npair[q] = (int)rl.size();
+    for (size_t k = 0; k < rl.size(); ++k) pairs.push_back(make_int2(rl[k], rr[k]));
+  }
+  int rc;
+  if ((rc = dev_upload(h, &h->d_fixups, fix))) return rc;
+  if (pairs.empty()) pairs.push_back(make_int2(0, 0));
+  if ((rc = dev_upload(h, &h->d_pairs, pairs))) return rc;
+  const size_t nbuf = (size_t)ny * wl + (size_t)ny * wr + 2 * (size_t)ny + 2 + (size_t)ny * nx;
+  if ((rc = dev_alloc(h, &h->d_integ_buf, nbuf))) return rc;
+  if ((rc = dev_alloc(h, &h->d_gradp, (size_t)ny * nx * 2))) return rc;
+  PsmIntegArgs& a = h->integ;
+  a.gradp = h->d_gradp; a.fixups = h->d_fixups; a.pairs = h->d_pairs; a.npair[0] = npair[0]; a.npair[1] = npair[1];
+  a.rxl = h->d_integ_buf; a.rxr = a.rxl + (size_t)ny * wl; a.yl = a.rxr + (size_t)ny * wr; a.yr = a.yl + ny;
+  a.corr = a.yr + ny; a.p_out = a.corr + 2;
+  a.ny = ny; a.nx = nx; a.cy = cy; a.cx = cx; a.dx = (float)dx; a.dy = (float)dy;
+  h->have_integ = true;
+  return PSM_OK;
+}
+
+int psm_integrate_gradp(psm_handle* h, const float* gradp, float* p_out) {
+  if (!h) return PSM_ERR_ARG;
+  if (!h->have_integ) return fail(h, PSM_ERR_STATE, "psm_set_integration has not been called");
+  if (!gradp || !p_out) return fail(h, PSM_ERR_ARG, "null buffer");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  hipStream_t st = h->stream;
+  const size_t n = (size_t)h->integ.ny * h->integ.nx;
+  HIPCHK(h, hipMemcpyAsync(h->d_gradp, gradp, n * 2 * sizeof(float), hipMemcpyHostToDevice, st));
+  HIPCHK(h, psm_launch_integrate(h->integ, st));
+  HIPCHK(h, hipMemcpyAsync(p_out, h->integ.p_out, n * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
   return PSM_OK;
 }
 

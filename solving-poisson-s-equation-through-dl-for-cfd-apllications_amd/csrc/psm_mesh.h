@@ -36,3 +36,19 @@ hipError_t psm_launch_to_grid(const PsmToGridArgs& a, hipStream_t st);
 hipError_t psm_launch_to_mesh(const PsmToMeshArgs& a, hipStream_t st);
 // one pass of the separable Gaussian filter (axis 0 = rows direction, 1 = columns)
 hipError_t psm_launch_gauss1d(const float* in, float* out, int ny, int nx, int axis, int radius, const float* wts, hipStream_t st);
+
+// ---- U_to_gradP integration (UGP:371-416, 592-628)
+constexpr int PSM_INTEG_MAX_FIX = 4;   // distinct indices the "reset" quirk may touch per row
+struct PsmIntegArgs {
+  const float* gradp;        // [ny][nx][2]
+  const int2* fixups;        // [max(cy, ny-cy)][PSM_INTEG_MAX_FIX] (v, u), v = -1: unused
+  const int2* pairs;         // [npair[0] + npair[1]] (row in left block, row in right block), global rows
+  int npair[2];
+  float* rxl; float* rxr;    // [ny][cx], [ny][nx-cx+1]
+  float* yl; float* yr;      // [ny]
+  float* corr;               // [2]
+  float* p_out;              // [ny][nx]
+  int ny, nx, cy, cx;
+  float dx, dy;
+};
+hipError_t psm_launch_integrate(const PsmIntegArgs& a, hipStream_t st);

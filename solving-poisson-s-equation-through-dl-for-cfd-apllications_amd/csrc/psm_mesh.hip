@@ -124,3 +124,121 @@ hipError_t psm_launch_gauss1d(const float* in, float* out, int ny, int nx, int a
   hipLaunchKernelGGL(psm_gauss1d_kernel, dim3((ny * nx + 255) / 256), dim3(256), 0, st, in, out, ny, nx, axis, radius, wts);
   return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------
+// U_to_gradP: integration of (dp/dx, dp/dy) into p over four quadrants
+// (integrate_field UGP:371-416, stitching UGP:597-628).  For a quadrant with reference corner
+// column `ij` and row `ii` the reference's double loop reduces to
+//     Phat[a,b] = (SdPy[a,ij] - SdPy[ii,ij]) + (SdPx[a,b] - SdPx[a,ij])
+// i.e. one row-wise cumulative sum per row (with the reference's "reset at the obstacle" index
+// quirk, precomputed per row on the host as (v, u) pairs: aaa[v] = -(ccc[v] - ccc[u])) and ONE
+// column-wise cumulative sum per side.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void psm_block_scan256(float* sh, float& v, int tid) {   // inclusive scan of 256 values
+  sh[tid] = v;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const float t = tid >= o ? sh[tid - o] : 0.f;
+    __syncthreads();
+    sh[tid] += t;
+    __syncthreads();
+  }
+  v = sh[tid];
+}
+
+__global__ __launch_bounds__(256) void psm_integ_rows_kernel(PsmIntegArgs a) {
+  __shared__ float sh[256];
+  __shared__ float fix[2 * PSM_INTEG_MAX_FIX + 2];
+  const int tid = threadIdx.x, y = blockIdx.x;
+  const int la = y < a.cy ? y : y - a.cy;                       // block-local row: indexes the fix-up table
+  const int2* fx = a.fixups + (int64_t)la * PSM_INTEG_MAX_FIX;
+  for (int side = 0; side < 2; ++side) {                        // 0: left block [0,cx), 1: right block [cx-1,nx)
+    const int x0 = side == 0 ? 0 : a.cx - 1, w = side == 0 ? a.cx : a.nx - a.cx + 1;
+    float* out = side == 0 ? a.rxl + (int64_t)y * a.cx : a.rxr + (int64_t)y * (a.nx - a.cx + 1);
+    const float* g = a.gradp + ((int64_t)y * a.nx + x0) * 2;    // channel 0
+    const int per = (w + 255) / 256, j0 = tid * per, j1 = min(w, j0 + per);
+    float s = 0.f;
+    for (int j = j0; j < j1; ++j) s += g[2 * j];
+    float incl = s;
+    psm_block_scan256(sh, incl, tid);
+    float run = incl - s;                                       // exclusive prefix of this thread's chunk
+    for (int j = j0; j < j1; ++j) { run += g[2 * j]; out[j] = run; }   // ccc
+    __syncthreads();
+    // "aaa[nn] = -dd": per distinct index v, delta_v = -(ccc[v] - ccc[u]) - aaa[v]
+    if (tid < PSM_INTEG_MAX_FIX) {
+      const int v = fx[tid].x, u = fx[tid].y;
+      float d = 0.f;
+      if (v >= 0 && v < w) d = -(out[v] - (u >= 0 ? out[u] : 0.f)) - g[2 * v];
+      fix[tid] = d;
+    }
+    __syncthreads();
+    for (int j = j0; j < j1; ++j) {
+      float add = 0.f;
+#pragma unroll
+      for (int e = 0; e < PSM_INTEG_MAX_FIX; ++e) add += (fx[e].x >= 0 && fx[e].x <= j) ? fix[e] : 0.f;
+      out[j] += add;
+    }
+    __syncthreads();
+    const float ref = out[side == 0 ? 0 : w - 1];               // SdPx[a, ij]
+    __syncthreads();
+    for (int j = j0; j < j1; ++j) out[j] = (out[j] - ref) * a.dx;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(1024) void psm_integ_cols_kernel(PsmIntegArgs a) {
+  // column cumulative sums of dp/dy at global columns 0 (left blocks) and nx-1 (right blocks),
+  // restarted at the cut row; then the shift of the left quadrants onto the right ones
+  extern __shared__ float sm[];                                  // [2][ny]
+  const int tid = threadIdx.x;
+  float* yl = sm; float* yr = sm + a.ny;
+  if (tid < 4) {                                                 // 4 short serial scans (ny <= a few thousand)
+    const int side = tid & 1, bottom = tid >> 1;
+    const int r0 = bottom ? a.cy : 0, r1 = bottom ? a.ny : a.cy;
+    const int col = side == 0 ? 0 : a.nx - 1;
+    float* dst = side == 0 ? yl : yr;
+    float run = 0.f;
+    for (int y = r0; y < r1; ++y) { run += a.gradp[((int64_t)y * a.nx + col) * 2 + 1]; dst[y] = run; }
+    const float ref = bottom ? dst[r1 - 1] : dst[r0];            // SdPy[ii, ij]
+    for (int y = r0; y < r1; ++y) dst[y] = (dst[y] - ref) * a.dy;
+  }
+  __syncthreads();
+  for (int y = tid; y < a.ny; y += 1024) { a.yl[y] = yl[y]; a.yr[y] = yr[y]; }
+  __shared__ float red[2][16];
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = a.nx - a.cx + 1;
+  for (int q = 0; q < 2; ++q) {                                  // top pair (blocks 2 vs 1), bottom pair (4 vs 3)
+    const int n = a.npair[q];
+    const int2* pr = a.pairs + (q == 0 ? 0 : a.npair[0]);
+    float acc = 0.f;
+    for (int k = tid; k < n; k += 1024) {
+      const int rl = pr[k].x, rr = pr[k].y;                      // global rows
+      acc += (yl[rl] + a.rxl[(int64_t)rl * a.cx + a.cx - 1]) - (yr[rr] + a.rxr[(int64_t)rr * wr]);
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (lane == 0) red[q][wave] = acc;
+  }
+  __syncthreads();
+  if (tid < 2) {
+    float t = 0.f;
+    for (int w8 = 0; w8 < 16; ++w8) t += red[tid][w8];
+    a.corr[tid] = t / (float)a.npair[tid];                       // mean of an empty selection -> NaN like NumPy
+  }
+}
+
+__global__ __launch_bounds__(256) void psm_integ_write_kernel(PsmIntegArgs a) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.ny * a.nx) return;
+  const int y = idx / a.nx, x = idx - y * a.nx;
+  float v;
+  if (x < a.cx) v = a.yl[y] + a.rxl[(int64_t)y * a.cx + x] - a.corr[y < a.cy ? 0 : 1];
+  else v = a.yr[y] + a.rxr[(int64_t)y * (a.nx - a.cx + 1) + (x - (a.cx - 1))];
+  a.p_out[idx] = v;
+}
+
+hipError_t psm_launch_integrate(const PsmIntegArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(psm_integ_rows_kernel, dim3(a.ny), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(psm_integ_cols_kernel, dim3(1), dim3(1024), (size_t)2 * a.ny * sizeof(float), st, a);
+  hipLaunchKernelGGL(psm_integ_write_kernel, dim3((a.ny * a.nx + 255) / 256), dim3(256), 0, st, a);
+  return hipGetLastError();
+}

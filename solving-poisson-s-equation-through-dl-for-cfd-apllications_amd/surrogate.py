@@ -150,6 +150,22 @@ class GridSurrogate:
                                                 float(sigma[1]), _p(out, C.c_float)))
         return out
 
+    def set_integration(self, sdfunct: np.ndarray, center_y: int, center_x: int, dx: float, dy: float):
+        """Geometry of the gradP -> p integration (Eval_dual_Dense_onlycil.py:592-628)."""
+        sd = _f64(sdfunct)
+        self._integ_shape = sd.shape
+        self._chk(self.lib.psm_set_integration(self.h, sd.shape[0], sd.shape[1], _p(sd, C.c_double), int(center_y),
+                                                int(center_x), float(dx), float(dy)))
+
+    def integrate_gradp(self, gradp: np.ndarray) -> np.ndarray:
+        """(dp/dx, dp/dy) [Ny,Nx,2] -> p [Ny,Nx] (integrate_field + four-quadrant stitching)."""
+        g = _f32(gradp)
+        if g.shape != tuple(self._integ_shape) + (2,):
+            raise ValueError("gradp must be [Ny,Nx,2] of the integration geometry")
+        out = np.empty(self._integ_shape, np.float32)
+        self._chk(self.lib.psm_integrate_gradp(self.h, _p(g, C.c_float), _p(out, C.c_float)))
+        return out
+
     # -- introspection
     def stage(self, name: str, n_cases: int = 1) -> np.ndarray:
         m = self.model

@@ -89,3 +89,21 @@ def build_filter_case():
     dU /= dU.max()
     dPprev = 0.3 * np.cos(xx / 33.0 + 1.0) * np.sin(yy / 47.0) + 0.02 * rng.standard_normal((ny, nx))
     return grid, model, sol.block_pred[..., 0], dU, dPprev
+
+
+def build_integration_case():
+    """U_to_gradP integration (Eval_dual_Dense_onlycil.py:592-628): 320x384 grid whose obstacle crosses
+    the hard-wired row 200; (dp/dx, dp/dy) = gradient of an analytic p + noise; sdfunct in metres (< 1)."""
+    Ny, Nx, delta = 320, 384, 5e-3
+    g = synthetic.channel_grid(Ny, Nx, seed=41, cx=0.35, cy=200.5 / Ny, r=0.1)
+    sdfunct = g[..., 2] * 0.3
+    x_min, y_min = -0.5, -0.8
+    x_max, y_max = x_min + Nx * delta, y_min + Ny * delta
+    X0 = np.linspace(x_min + delta / 2, x_max - delta / 2, Nx)
+    yy, xx = np.meshgrid(np.linspace(y_min, y_max, Ny), np.linspace(x_min, x_max, Nx), indexing="ij")
+    rng = np.random.default_rng(5)
+    gx = 3 * np.cos(3 * xx) * np.cos(2 * yy) + 0.05 * rng.standard_normal((Ny, Nx))
+    gy = -2 * np.sin(3 * xx) * np.sin(2 * yy) + 0.05 * rng.standard_normal((Ny, Nx))
+    gradP = np.stack([gx, gy], -1)
+    gradP[sdfunct == 0] = 0.0
+    return dict(gradP=gradP, sdfunct=sdfunct, X0=X0, delta=delta, min_x=x_min, max_x=x_max, min_y=y_min, max_y=y_max)

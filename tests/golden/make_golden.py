@@ -314,6 +314,24 @@ def main():
     np.savez_compressed(os.path.join(HERE, "deltas_filters_256x256.npz"), result=res.astype(np.float32), change=chg.astype(np.float32))
     print("deltas_filters_256x256: |res|max=%.4f |change|max=%.5f" % (np.abs(res).max(), np.abs(chg).max()))
 
+    # ---- U_to_gradP: integrate_field + four-quadrant stitching (UGP:371-416, 592-628)
+    ic = cases.build_integration_case()
+    tree = _tree(UGP)
+    integ = _method(tree, "Evaluation", "integrate_field", {"np": np}, UGP)
+    Ev = type("Ev", (), {"integrate_field": integ})
+    me = Ev()
+    me.sdfunct = ic["sdfunct"][:, :, None]; me.X0 = ic["X0"]; me.delta = ic["delta"]
+    me.min_x, me.max_x, me.min_y, me.max_y = ic["min_x"], ic["max_x"], ic["min_y"], ic["max_y"]
+    body = _find_fn(tree, "timeStep", "Evaluation").body
+    stmts = _slice(body, lambda s: s.startswith("gradP = np.concatenate"), lambda s: s.startswith("result[center_p_y:, :center_p_x] = pBlock4Corrected"))
+    g4 = ic["gradP"][None]
+    loc = {"self": me, "res_dPdx": g4[..., 0:1].copy(), "res_dPdy": g4[..., 1:2].copy(), "grid": np.zeros((1,) + ic["gradP"].shape[:2] + (6,))}
+    with np.errstate(all="ignore"):
+        _run(stmts, {"np": np}, loc, UGP)
+    np.savez_compressed(os.path.join(HERE, "gradp_integration_320x384.npz"), p=np.asarray(loc["result"], np.float32),
+                        center_p_x=np.int64(loc["center_p_x"]), center_p_y=np.int64(loc["center_p_y"]))
+    print("gradp_integration: center", int(loc["center_p_x"]), int(loc["center_p_y"]), "|p|max=%.4f" % np.abs(loc["result"]).max())
+
     for name in cases.GOLDEN_CASES:
         grid, model = cases.build(name)
         if model.variant == "gradp":

@@ -1,0 +1,49 @@
+"""Minimal HIP runtime access through ctypes for the GPU tests (device buffers without importing
+torch, whose first import on a fresh box can take minutes)."""
+import ctypes as C
+
+import numpy as np
+
+_hip = None
+
+
+def hip():
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        _hip.hipFree.argtypes = [C.c_void_p]
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _hip.hipDeviceSynchronize.argtypes = []
+    return _hip
+
+
+class DeviceArray:
+    def __init__(self, host: np.ndarray = None, shape=None, dtype=np.float32):
+        if host is not None:
+            host = np.ascontiguousarray(host)
+            shape, dtype = host.shape, host.dtype
+        self.shape, self.dtype = tuple(shape), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = C.c_void_p()
+        assert hip().hipMalloc(C.byref(p), self.nbytes) == 0
+        self.ptr = p.value
+        if host is not None:
+            assert hip().hipMemcpy(self.ptr, host.ctypes.data, self.nbytes, 1) == 0      # H2D
+
+    def numpy(self) -> np.ndarray:
+        assert hip().hipDeviceSynchronize() == 0
+        out = np.empty(self.shape, self.dtype)
+        assert hip().hipMemcpy(out.ctypes.data, self.ptr, self.nbytes, 2) == 0           # D2H
+        return out
+
+    def free(self):
+        if self.ptr:
+            hip().hipFree(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -153,27 +153,33 @@ def test_big_architecture_and_many_components():
 
 
 def test_device_pointer_api_graph_and_eager_agree(monkeypatch):
-    import torch
-    monkeypatch.setenv("PSM_GRAPH", "1")          # this handle replays a captured hipGraph
+    from hipmem import DeviceArray
     model = synthetic.make_model("gradp", p_in=64, p_out=64)
     grid = synthetic.channel_grid(256, 256, seed=1).astype(np.float32)
     with GridSurrogate(model, 256, 256) as sur:
         host = sur.solve(grid)[0]
-        d_in = torch.from_numpy(grid).cuda()
-        d_out = torch.empty((256, 256, 2), dtype=torch.float32, device="cuda")
-        st = torch.cuda.current_stream().cuda_stream
-        for _ in range(3):      # first call captures the graph, the others replay it
-            sur.solve_device(d_in.data_ptr(), 1, d_out.data_ptr(), st)
-        torch.cuda.synchronize()
-        np.testing.assert_array_equal(d_out.cpu().numpy(), host)
-        ms = sur.profile(d_in.data_ptr(), 1, d_out.data_ptr())       # eager launches with events
-        np.testing.assert_array_equal(d_out.cpu().numpy(), host)
-        assert all(v > 0 for v in ms.values())
+        d_in = DeviceArray(grid)
+        d_out = DeviceArray(shape=(256, 256, 2), dtype=np.float32)
+        for _ in range(3):      # plain stream launches on the handle's own stream
+            sur.solve_device(d_in.ptr, 1, d_out.ptr, 0)
+        sur.synchronize()
+        np.testing.assert_array_equal(d_out.numpy(), host)
+        ms = sur.profile(d_in.ptr, 1, d_out.ptr)       # launches with events around every kernel group
+        np.testing.assert_array_equal(d_out.numpy(), host)
+        assert ms["encode"] > 0 and ms["decode"] > 0 and ms["paste"] > 0
         sur.enable_kernel_timing("encode")
-        sur.solve_device(d_in.data_ptr(), 1, d_out.data_ptr(), st)
+        sur.solve_device(d_in.ptr, 1, d_out.ptr, 0)
         total, n = sur.kernel_timing("encode")
         sur.enable_kernel_timing("encode", False)
         assert n == 1 and total > 0
+        assert sur.event_pair_overhead_ms(50) >= 0
+    monkeypatch.setenv("PSM_GRAPH", "1")          # a second handle that replays a captured hipGraph
+    with GridSurrogate(model, 256, 256) as sur:
+        for _ in range(3):      # first call captures the graph, the others replay it
+            sur.solve_device(d_in.ptr, 1, d_out.ptr, 0)
+        sur.synchronize()
+        np.testing.assert_array_equal(d_out.numpy(), host)
+    d_in.free(); d_out.free()
 
 
 def test_reassembly_properties_full_size():

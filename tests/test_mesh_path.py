@@ -109,3 +109,39 @@ def test_gpu_filters_and_weighting():
         got = ev._surrogate(256, 256).gaussian_filter(f, sig)
         ref = ndi.gaussian_filter(f.astype(np.float64), sigma=sig, order=0)
         assert np.abs(got - ref).max() <= 2e-6
+
+
+def _integ_setup():
+    ic = cases.build_integration_case()
+    Ny, Nx = ic["sdfunct"].shape
+    cx, cy = orc.integration_center(ic["sdfunct"], ic["min_x"], ic["max_x"], ic["X0"].min(), ic["delta"])
+    dx = (ic["max_x"] - ic["min_x"]) / (Nx - 1)          # np.diff(xl)[0] of UGP:594
+    dy = (ic["max_y"] - ic["min_y"]) / (Ny - 1)
+    return ic, cx, cy, dx, dy
+
+
+def test_oracle_integration_matches_reference_run():
+    ic, cx, cy, dx, dy = _integ_setup()
+    gold = cases.load_golden("gradp_integration_320x384")
+    assert (cx, cy) == (int(gold["center_p_x"]), int(gold["center_p_y"]))
+    p = orc.integrate_gradp(ic["gradP"], ic["sdfunct"], dx, dy, cy, cx)
+    np.testing.assert_allclose(p, gold["p"], rtol=0, atol=5e-7 * np.abs(gold["p"]).max() + 1e-7)
+
+
+@pytest.mark.gpu
+def test_gpu_integration_of_gradp():
+    from psm_amd import GridSurrogate
+    ic, cx, cy, dx, dy = _integ_setup()
+    gold = cases.load_golden("gradp_integration_320x384")
+    model = cases.synthetic.make_model("gradp", p_in=8, p_out=8)
+    with GridSurrogate(model, 320, 384) as sur:
+        sur.set_integration(ic["sdfunct"], cy, cx, dx, dy)
+        p = sur.integrate_gradp(ic["gradP"])
+        assert np.abs(p - gold["p"]).max() <= 1e-4 * np.abs(gold["p"]).max()
+        # sdf values >= 1 exercise the reference's index quirk (int(sdf) = 1 -> a second fix-up index)
+        sd2 = ic["sdfunct"].copy()
+        sd2[10:40, 50:90] = 1.2
+        sur.set_integration(sd2, cy, cx, dx, dy)
+        p2 = sur.integrate_gradp(ic["gradP"])
+        ref2 = orc.integrate_gradp(ic["gradP"], sd2, dx, dy, cy, cx)
+        assert np.abs(p2 - ref2).max() <= 1e-4 * np.abs(ref2).max()
