@@ -85,6 +85,8 @@ struct psm_handle {
   std::map<GraphKey, hipGraphExec_t> graphs;
   bool use_graph = true;
   bool fused_assemble = false;
+  int debug_skip = 0;                   // PSM_DEBUG_SKIP bit mask of kernel groups NOT launched (timing experiments only)
+  bool fuse_reduce_dense1 = true;       // PSM_NO_FUSED_REDUCE=1 disables
   int last_cases = 0;
   // event timing of one kernel group
   int timed_kernel = -1;
@@ -247,7 +249,7 @@ bool model_complete(const psm_handle* h) {
 // launches of a kernel group: once, or `timed_repeat` times back to back between the two timing
 // events when that group is being timed (the group is idempotent; amortises the ~2.7 us an event
 // pair adds to a single launch)
-#define PSM_REPEAT(h, k) for (int rep_ = 0, nrep_ = ((h)->timed_kernel == (k) ? (h)->timed_repeat : 1); rep_ < nrep_; ++rep_)
+#define PSM_REPEAT(h, k) for (int rep_ = 0, nrep_ = (((h)->debug_skip >> (k)) & 1) ? 0 : ((h)->timed_kernel == (k) ? (h)->timed_repeat : 1); rep_ < nrep_; ++rep_)
 
 struct Timer {                      // optional event pair around one kernel group
   psm_handle* h; hipStream_t st; int k; hipEvent_t* ev;   // ev: [PSM_K_COUNT+1] profile events or null
@@ -288,20 +290,13 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
     HIPCHK(h, bf16 ? psm_launch_encode_bf16(ea, st, e0, e1) : psm_launch_encode(ea, st, e0, e1));
   } else {
     tm.before(PSM_K_ENCODE);
-    HIPCHK(h, bf16 ? psm_launch_encode_bf16(ea, st) : psm_launch_encode(ea, st));
+    PSM_REPEAT(h, PSM_K_ENCODE) HIPCHK(h, bf16 ? psm_launch_encode_bf16(ea, st) : psm_launch_encode(ea, st));
     tm.after(PSM_K_ENCODE);
   }
 
   PsmReduceArgs ra{h->d_part, h->d_xin, h->d_ia, h->d_ib, h->n_slices, Mpad, h->ld_in};
-  tm.before(PSM_K_REDUCE);
-  PSM_REPEAT(h, PSM_K_REDUCE) HIPCHK(h, psm_launch_reduce(ra, st));
-  tm.after(PSM_K_REDUCE);
-
-  tm.before(PSM_K_MLP);
   const int nl = (int)h->dense.size();
-  PSM_REPEAT(h, PSM_K_MLP) {
-  const float* cur = h->d_xin; int ld_cur = h->ld_in;
-  for (int l = 0; l < nl; ++l) {
+  auto dense_args = [&](int l, const float* cur, int ld_cur) {
     const DenseLayer& d = h->dense[l];
     const bool head = (l == nl - 1);
     PsmDenseArgs da{};
@@ -310,9 +305,36 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
     da.out = head ? h->d_res : h->d_act[l & 1]; da.ld_out = d.ldw;
     da.Kpad = d.Kpad; da.Mpad = Mpad; da.relu = head ? 0 : 1; da.head = head ? 1 : 0;
     da.bf16 = (h->cfg.precision == PSM_PRECISION_BF16) ? 1 : 0;
-    HIPCHK(h, psm_launch_dense(da, st));
-    cur = da.out; ld_cur = d.ldw;
+    return da;
+  };
+  // few block rows: slab reduce + first dense layer in one launch (one workgroup per row)
+  const bool fuse1 = h->fuse_reduce_dense1 && Mpad <= 128 && h->ld_in <= 512 && h->dense[0].ldw <= 1024 &&
+                     h->timed_kernel != PSM_K_REDUCE;
+  int l_first = 0;
+  if (fuse1) {
+    tm.before(PSM_K_REDUCE);
+    tm.after(PSM_K_REDUCE);
+    tm.before(PSM_K_MLP);
+  } else {
+    tm.before(PSM_K_REDUCE);
+    PSM_REPEAT(h, PSM_K_REDUCE) HIPCHK(h, psm_launch_reduce(ra, st));
+    tm.after(PSM_K_REDUCE);
+    tm.before(PSM_K_MLP);
   }
+  PSM_REPEAT(h, PSM_K_MLP) {
+    const float* cur = h->d_xin; int ld_cur = h->ld_in;
+    l_first = 0;
+    if (fuse1) {
+      PsmDenseArgs d0 = dense_args(0, cur, ld_cur);
+      HIPCHK(h, psm_launch_reduce_dense1(ra, d0, st));
+      cur = d0.out; ld_cur = h->dense[0].ldw;
+      l_first = 1;
+    }
+    for (int l = l_first; l < nl; ++l) {
+      PsmDenseArgs da = dense_args(l, cur, ld_cur);
+      HIPCHK(h, psm_launch_dense(da, st));
+      cur = da.out; ld_cur = h->dense[l].ldw;
+    }
   }
   tm.after(PSM_K_MLP);
 
@@ -661,6 +683,14 @@ int psm_plan_grid(psm_handle* h, int32_t ny, int32_t nx) {
   HIPCHK(h, hipMemset(h->d_act[0], 0, (size_t)h->Mpad_cap * h->max_width * sizeof(float)));
   HIPCHK(h, hipMemset(h->d_act[1], 0, (size_t)h->Mpad_cap * h->max_width * sizeof(float)));
   HIPCHK(h, hipDeviceSynchronize());
+  {
+    const char* ds = getenv("PSM_DEBUG_SKIP");
+    h->debug_skip = ds ? atoi(ds) : 0;
+  }
+  {
+    const char* nr = getenv("PSM_NO_FUSED_REDUCE");
+    h->fuse_reduce_dense1 = !(nr && nr[0] == '1');
+  }
   {
     const char* nf = getenv("PSM_NO_FUSED_ASSEMBLE");
     h->fused_assemble = (h->B <= 64 && h->plan.cp.n_x < 64) && !(nf && nf[0] == '1');

@@ -85,6 +85,8 @@ hipError_t psm_launch_encode(const PsmEncodeArgs& a, hipStream_t s, hipEvent_t e
 hipError_t psm_launch_encode_bf16(const PsmEncodeArgs& a, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t psm_launch_decode_bf16(const PsmDecodeArgs& a, hipStream_t s);
 hipError_t psm_launch_reduce(const PsmReduceArgs& a, hipStream_t s);
+// slab reduce + first dense layer in one launch (ldp <= 512, layer width <= 1024)
+hipError_t psm_launch_reduce_dense1(const PsmReduceArgs& r, const PsmDenseArgs& d, hipStream_t s);
 hipError_t psm_launch_dense(const PsmDenseArgs& a, hipStream_t s);
 hipError_t psm_launch_decode(const PsmDecodeArgs& a, hipStream_t s);
 hipError_t psm_launch_strips(const PsmStripArgs& a, int n_cases, hipStream_t s);

@@ -210,6 +210,89 @@ hipError_t psm_launch_reduce(const PsmReduceArgs& a, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------
+// reduce + first dense layer in one launch (small row counts): one workgroup per block row
+// (and column half of the layer) sums the row's split-K slabs, applies the input scaler and,
+// having the WHOLE coefficient row in LDS, finishes x@W1+b1, ReLU for its columns on the
+// VALU -- the contraction is only p_in (<= 512) long.  Saves a launch (~5 us) over
+// psm_reduce_kernel + psm_dense_kernel; slab summation order is that of psm_reduce_kernel.
+// ---------------------------------------------------------------------------
+template <bool BF16>
+__global__ __launch_bounds__(1024) void psm_reduce_dense1_kernel(PsmReduceArgs r, PsmDenseArgs d) {
+  __shared__ float red[16][512];
+  __shared__ float xrow[512];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = blockIdx.x;
+  const int64_t total = (int64_t)r.Mpad * r.ldp;
+  const int per = (r.n_slices + 15) / 16;
+  const int s0 = wave * per, s1 = min(r.n_slices, s0 + per);
+  for (int p0 = 0; p0 < r.ldp; p0 += 64) {
+    const int pcol = p0 + lane;
+    if (pcol < r.ldp) {
+      const float* p = r.part + (int64_t)m * r.ldp + pcol;
+      float acc = 0.f;
+      int s = s0;
+      for (; s + 16 <= s1; s += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = p[(int64_t)(s + u) * total];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += v[u];
+      }
+      for (; s < s1; ++s) acc += p[(int64_t)s * total];
+      red[wave][pcol] = acc;
+    }
+  }
+  __syncthreads();
+  for (int pcol = tid; pcol < r.ldp; pcol += 1024) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) v += red[w][pcol];
+    const float x = v * r.ia[pcol] + r.ib[pcol];
+    if (blockIdx.y == 0) r.xin[(int64_t)m * r.ldp + pcol] = x;       // kept for psm_read_stage
+    xrow[pcol] = BF16 ? (float)(__bf16)x : x;
+  }
+  __syncthreads();
+  // ---- x @ W1 + b1, ReLU: thread = (column, quarter of K); K = d.Kpad (multiple of 32)
+  float* part4 = &red[0][0];                                           // [4][ncols <= 512]
+  const int ncols = d.ld_w / gridDim.y, n0 = blockIdx.y * ncols;
+  const int kp = tid >> 8, kq = d.Kpad / 4;
+  for (int nl = tid & 255; nl < ncols; nl += 256) {
+    const int n = n0 + nl;
+    float acc = 0.f;
+    if (BF16) {
+      const __bf16* w = reinterpret_cast<const __bf16*>(d.W) + (int64_t)(kp * kq) * d.ld_w + n;
+      for (int k = 0; k < kq; ++k) acc = fmaf(xrow[kp * kq + k], (float)w[(int64_t)k * d.ld_w], acc);
+    } else {
+      const float* w = d.W + (int64_t)(kp * kq) * d.ld_w + n;
+      for (int k = 0; k < kq; k += 8) {
+        float wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = w[(int64_t)(k + u) * d.ld_w];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fmaf(xrow[kp * kq + k + u], wv[u], acc);
+      }
+    }
+    part4[kp * 512 + nl] = acc;
+  }
+  __syncthreads();
+  for (int nl = tid; nl < ncols; nl += 1024) {
+    const int n = n0 + nl;
+    float v = ((part4[nl] + part4[512 + nl]) + (part4[1024 + nl] + part4[1536 + nl])) + d.bias[n];
+    if (d.relu) v = fmaxf(v, 0.f);
+    if (d.head) v = v * d.sa[n] + d.sb[n];
+    d.out[(int64_t)m * d.ld_out + n] = v;
+  }
+}
+
+hipError_t psm_launch_reduce_dense1(const PsmReduceArgs& r, const PsmDenseArgs& d, hipStream_t st) {
+  if (r.ldp > 512 || d.ld_w > 1024 || (d.ld_w / 2) % 1 != 0) return hipErrorInvalidValue;
+  const dim3 grid(r.Mpad, 2);
+  if (d.bf16) hipLaunchKernelGGL((psm_reduce_dense1_kernel<true>), grid, dim3(1024), 0, st, r, d);
+  else hipLaunchKernelGGL((psm_reduce_dense1_kernel<false>), grid, dim3(1024), 0, st, r, d);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // dense layer: v_mfma_f32_16x16x4_f32, one 16-column tile x 32 rows per workgroup,
 // K split over 8 waves, operands prefetched to registers in one round trip.
 //   A: lane l holds A[i = l&15][k = l>>4];  B: lane l holds B[k = l>>4][j = l&15]

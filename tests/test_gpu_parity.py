@@ -111,7 +111,9 @@ def test_config3_case_batch_equals_single_cases():
             check_against_oracle(sur, grids[c], model, sol, n_cases=8, case=c)
             assert np.abs(batch[c] - sol.fields).max() <= 1e-4 * np.abs(sol.fields).max()
         singles = np.stack([sur.solve(grids[c], out_scale=[scales[c]])[0] for c in range(8)])
-    np.testing.assert_array_equal(batch, singles)     # same kernels, same reduction order: bit-identical
+    # 8 cases (96 block rows) and single cases (32 rows) may take different dense-layer paths: same
+    # arithmetic, different summation order
+    np.testing.assert_allclose(batch, singles, rtol=0, atol=2e-6 * np.abs(singles).max())
 
 
 def test_config0_chapter5_real_weights_via_solver_module():
