@@ -24,8 +24,9 @@ thread_local std::string g_create_error;
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 struct DenseLayer {
-  int n_in = 0, n_out = 0, Kpad = 0, ldw = 0;
-  float* W = nullptr;
+  int n_in = 0, n_out = 0, Kpad = 0, ldw = 0, Kp = 0;
+  float* W = nullptr;      // [Kpad][ldw] (bf16 precision: bf16 elements)
+  void* Wp = nullptr;      // MFMA-packed copy, see psm_dense_kernel
   float* b = nullptr;
   bool set = false;
 };
@@ -300,11 +301,12 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
     const DenseLayer& d = h->dense[l];
     const bool head = (l == nl - 1);
     PsmDenseArgs da{};
-    da.in = cur; da.ld_in = ld_cur; da.W = d.W; da.ld_w = d.ldw; da.bias = d.b;
+    da.in = cur; da.ld_in = ld_cur; da.W = d.W; da.ld_w = d.ldw; da.bias = d.b; da.Wp = d.Wp; da.Kp = d.Kp;
     da.sa = h->d_sa; da.sb = h->d_sb;
     da.out = head ? h->d_res : h->d_act[l & 1]; da.ld_out = d.ldw;
     da.Kpad = d.Kpad; da.Mpad = Mpad; da.relu = head ? 0 : 1; da.head = head ? 1 : 0;
     da.bf16 = (h->cfg.precision == PSM_PRECISION_BF16) ? 1 : 0;
+    da.layer = l;
     return da;
   };
   // few block rows: slab reduce + first dense layer in one launch (one workgroup per row)
@@ -495,7 +497,7 @@ void psm_destroy(psm_handle* h) {
   (void)hipDeviceSynchronize();
   free_plan(h);
   free_geometry(h);
-  for (auto& d : h->dense) { dev_free(d.W); dev_free(d.b); }
+  for (auto& d : h->dense) { dev_free(d.W); dev_free(d.b); if (d.Wp) { (void)hipFree(d.Wp); d.Wp = nullptr; } }
   dev_free(h->d_mean_in); dev_free(h->d_mean_out); dev_free(h->d_bpack_in); dev_free(h->d_bpack_out);
   dev_free(h->d_ia); dev_free(h->d_ib); dev_free(h->d_sa); dev_free(h->d_sb);
   for (int i = 0; i < psm_handle::RING; ++i) {
@@ -550,14 +552,35 @@ int psm_set_dense(psm_handle* h, int32_t layer, int32_t n_in, int32_t n_out, con
   for (int k = 0; k < n_in; ++k) memcpy(&W[(size_t)k * d.ldw], kernel + (size_t)k * n_out, n_out * sizeof(float));
   memcpy(b.data(), bias, n_out * sizeof(float));
   int rc;
+  // MFMA-packed copy: Wp[nt][kg][lane][j] = W[16*kg + 4*(lane>>4) + j][16*nt + (lane&15)], contraction
+  // padded with zero rows to Kp (128, 256 or a multiple of 512: whole passes of the dense kernel)
+  d.Kp = d.Kpad <= 128 ? 128 : (d.Kpad <= 256 ? 256 : round_up(d.Kpad, 512));
+  const int groups = d.Kp / 16, ntiles = d.ldw / 16;
+  std::vector<float> Wp((size_t)ntiles * groups * 64 * 4, 0.f);
+  for (int nt = 0; nt < ntiles; ++nt)
+    for (int kg = 0; kg < groups; ++kg)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 4; ++j) {
+          const int k = 16 * kg + 4 * (lane >> 4) + j, n = 16 * nt + (lane & 15);
+          if (k < n_in && n < n_out) Wp[(((size_t)nt * groups + kg) * 64 + lane) * 4 + j] = kernel[(size_t)k * n_out + n];
+        }
+  if (d.Wp) { (void)hipFree(d.Wp); d.Wp = nullptr; }
   if (h->cfg.precision == PSM_PRECISION_BF16) {
-    std::vector<uint16_t> Wb(W.size());
+    std::vector<uint16_t> Wb(W.size()), Wpb(Wp.size());
     for (size_t q = 0; q < W.size(); ++q) Wb[q] = f2bf(W[q]);
-    uint16_t* dw = nullptr;
+    for (size_t q = 0; q < Wp.size(); ++q) Wpb[q] = f2bf(Wp[q]);
+    uint16_t *dw = nullptr, *dwp = nullptr;
     if ((rc = dev_upload(h, &dw, Wb))) return rc;
+    if ((rc = dev_upload(h, &dwp, Wpb))) { dev_free(dw); return rc; }
     dev_free(d.W);
     d.W = reinterpret_cast<float*>(dw);
-  } else if ((rc = dev_upload(h, &d.W, W))) return rc;
+    d.Wp = dwp;
+  } else {
+    if ((rc = dev_upload(h, &d.W, W))) return rc;
+    float* dwp = nullptr;
+    if ((rc = dev_upload(h, &dwp, Wp))) return rc;
+    d.Wp = dwp;
+  }
   if ((rc = dev_upload(h, &d.b, b))) return rc;
   d.set = true;
   return PSM_OK;
@@ -975,6 +998,15 @@ int psm_read_stage(psm_handle* h, int32_t stage, float* dst, size_t dst_floats) 
       const size_t n = (size_t)h->last_cases * h->cfg.c_out;
       if (dst_floats < n) return fail(h, PSM_ERR_ARG, "destination too small");
       HIPCHK(h, hipMemcpy(dst, h->d_shift, n * sizeof(float), hipMemcpyDeviceToHost));
+      return PSM_OK;
+    }
+    case 6: {   // diagnostic builds only: raw stamps of workgroup 0, microseconds after the earliest one
+      unsigned long long t[64];
+      if (dst_floats < 64) return fail(h, PSM_ERR_ARG, "destination too small");
+      HIPCHK(h, psm_read_stamps(t));
+      unsigned long long t0 = ~0ull;
+      for (int k = 0; k < 64; ++k) if (t[k] && t[k] < t0) t0 = t[k];
+      for (int k = 0; k < 64; ++k) dst[k] = t[k] ? (float)((double)(t[k] - t0) * 0.01) : -1.f;
       return PSM_OK;
     }
     case 5: {   // diagnostic builds only: stamp deltas of workgroup 0 in microseconds

@@ -29,12 +29,15 @@ struct PsmReduceArgs {
 
 struct PsmDenseArgs {
   const float* in; int ld_in;          // [Mpad][ld_in]
-  const float* W; int ld_w;            // [Kpad][ld_w] zero padded
+  const float* W; int ld_w;            // [Kpad][ld_w] zero padded (natural layout: fused reduce + layer-1 kernel)
+  const void* Wp; int Kp;              // MFMA-packed copy [ld_w/16][Kp/16][64 lanes][4] (f32, or bf16 when bf16 != 0);
+                                       // Kp = contraction length padded to 128 / 256 / a multiple of 512, zero rows beyond Kpad
   const float* bias;                   // [ld_w]
   const float* sa; const float* sb;    // head only: out = (acc+bias)*sa + sb
   float* out; int ld_out;              // [Mpad][ld_out]
   int Kpad, Mpad, relu, head;
   int bf16;                            // W points to bf16 [Kpad][ld_w]; activations rounded to bf16 on load
+  int layer;                           // layer index (diagnostic stamps only)
 };
 
 struct PsmDecodeArgs {

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(1024) void psm_reduce_kernel(PsmReduceArgs a) {
   const int per = (a.n_slices + 15) / 16;
   const int s0 = wave * per, s1 = min(a.n_slices, s0 + per);
   const float* p = a.part + o;
-  PSM_STAMP(0, 8);
+  PSM_STAMP(0, 16);
   float acc = 0.f;
   int s = s0;
   for (; s + 16 <= s1; s += 16) {
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(1024) void psm_reduce_kernel(PsmReduceArgs a) {
   for (; s < s1; ++s) acc += p[(int64_t)s * total];
   red[wave][lane] = acc;
   __syncthreads();
-  PSM_STAMP(0, 9);
+  PSM_STAMP(0, 17);
   if (wave == 0) {
     float v = 0.f;
 #pragma unroll
@@ -216,72 +216,123 @@ hipError_t psm_launch_reduce(const PsmReduceArgs& a, hipStream_t st) {
 // VALU -- the contraction is only p_in (<= 512) long.  Saves a launch (~5 us) over
 // psm_reduce_kernel + psm_dense_kernel; slab summation order is that of psm_reduce_kernel.
 // ---------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <bool BF16>
 __global__ __launch_bounds__(1024) void psm_reduce_dense1_kernel(PsmReduceArgs r, PsmDenseArgs d) {
   __shared__ float red[16][512];
-  __shared__ float xrow[512];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ __attribute__((aligned(16))) float xrow[512];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = blockIdx.x;
   const int64_t total = (int64_t)r.Mpad * r.ldp;
   const int per = (r.n_slices + 15) / 16;
   const int s0 = wave * per, s1 = min(r.n_slices, s0 + per);
-  for (int p0 = 0; p0 < r.ldp; p0 += 64) {
-    const int pcol = p0 + lane;
-    if (pcol < r.ldp) {
-      const float* p = r.part + (int64_t)m * r.ldp + pcol;
-      float acc = 0.f;
-      int s = s0;
-      for (; s + 16 <= s1; s += 16) {
-        float v[16];
+  PSM_STAMP(0, 8);
+  // first-layer weights of this thread's first column / K quarter: independent of the slabs, so
+  // they are requested first and arrive under the slab reduction.  Addresses are a wave-uniform
+  // row base plus a 32-bit lane offset.
+  const int ncols = d.ld_w / gridDim.y, n0 = blockIdx.y * ncols;
+  const int kp = wave >> 2, kq = d.Kpad / 4;               // 4 waves (256 columns) per K quarter
+  const int nl0 = tid & 255;
+  const int ncol0 = n0 + min(nl0, ncols - 1);
+  float wv0[32];
+  if (!BF16) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = p[(int64_t)(s + u) * total];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) acc += v[u];
-      }
-      for (; s < s1; ++s) acc += p[(int64_t)s * total];
-      red[wave][pcol] = acc;
+    for (int u = 0; u < 32; ++u) {
+      const float* wrow = d.W + (int64_t)(kp * kq + min(u, kq - 1)) * d.ld_w;     // uniform
+      wv0[u] = wrow[ncol0];
     }
   }
+  // input-scaler operands of the coefficient this thread finishes below
+  const int pfin = min(tid, r.ldp - 1);
+  const float ia_v = r.ia[pfin], ib_v = r.ib[pfin];
+  const float bias0 = d.bias[n0 + min(tid, ncols - 1)];
+  __builtin_amdgcn_sched_barrier(0);
+  // slab sums: wave w adds slabs [16w, 16w+16) for two 64-column groups per pass, all 32 loads
+  // of a pass in flight together (n_slices == 256: per == 16)
+  for (int p0 = 0; p0 < r.ldp; p0 += 128) {
+    const int pc0 = p0 + lane, pc1 = p0 + 64 + lane;
+    const int o0 = m * r.ldp + min(pc0, r.ldp - 1), o1 = m * r.ldp + min(pc1, r.ldp - 1);
+    float acc0 = 0.f, acc1 = 0.f;
+    int s = s0;
+    for (; s + 16 <= s1; s += 16) {
+      float v0[16], v1[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const float* slab = r.part + (int64_t)(s + u) * total;                     // uniform
+        v0[u] = slab[o0];
+        v1[u] = slab[o1];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc0 += v0[u];     // fixed order: that of psm_reduce_kernel
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc1 += v1[u];
+    }
+    for (; s < s1; ++s) { const float* slab = r.part + (int64_t)s * total; acc0 += slab[o0]; acc1 += slab[o1]; }
+    if (pc0 < r.ldp) red[wave][pc0] = acc0;
+    if (pc1 < r.ldp) red[wave][pc1] = acc1;
+  }
   __syncthreads();
-  for (int pcol = tid; pcol < r.ldp; pcol += 1024) {
+  PSM_STAMP(0, 9);
+  float x_keep = 0.f;
+  if (tid < r.ldp) {
     float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) v += red[w][pcol];
-    const float x = v * r.ia[pcol] + r.ib[pcol];
-    if (blockIdx.y == 0) r.xin[(int64_t)m * r.ldp + pcol] = x;       // kept for psm_read_stage
-    xrow[pcol] = BF16 ? (float)(__bf16)x : x;
+    for (int w = 0; w < 16; ++w) v += red[w][tid];
+    x_keep = v * ia_v + ib_v;
+    xrow[tid] = BF16 ? (float)(__bf16)x_keep : x_keep;
   }
   __syncthreads();
   // ---- x @ W1 + b1, ReLU: thread = (column, quarter of K); K = d.Kpad (multiple of 32)
   float* part4 = &red[0][0];                                           // [4][ncols <= 512]
-  const int ncols = d.ld_w / gridDim.y, n0 = blockIdx.y * ncols;
-  const int kp = tid >> 8, kq = d.Kpad / 4;
-  for (int nl = tid & 255; nl < ncols; nl += 256) {
+  for (int nl = nl0; nl < ncols; nl += 256) {
     const int n = n0 + nl;
     float acc = 0.f;
     if (BF16) {
       const __bf16* w = reinterpret_cast<const __bf16*>(d.W) + (int64_t)(kp * kq) * d.ld_w + n;
       for (int k = 0; k < kq; ++k) acc = fmaf(xrow[kp * kq + k], (float)w[(int64_t)k * d.ld_w], acc);
     } else {
-      const float* w = d.W + (int64_t)(kp * kq) * d.ld_w + n;
-      for (int k = 0; k < kq; k += 8) {
-        float wv[8];
+      // kq is a multiple of 8; up to 32 weight rows in flight per thread (one round trip for
+      // p_in <= 128), k ascending.  Branch-free: rows beyond kq are clamped loads with a zero
+      // weight, so that the LDS reads and FMAs of a chunk are one straight line.
+      for (int k = 0; k < kq; k += 32) {
+        float wv[32];
+        if (k == 0 && nl == nl0) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) wv[u] = w[(int64_t)(k + u) * d.ld_w];
+          for (int u = 0; u < 32; ++u) wv[u] = wv0[u];
+        } else {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc = fmaf(xrow[kp * kq + k + u], wv[u], acc);
+          for (int u = 0; u < 32; ++u) {
+            const float* wrow = d.W + (int64_t)(kp * kq + min(k + u, kq - 1)) * d.ld_w;
+            wv[u] = wrow[n];
+          }
+        }
+        f32x4 xv[8];
+#pragma unroll
+        for (int u4 = 0; u4 < 8; ++u4)
+          xv[u4] = *reinterpret_cast<const f32x4*>(&xrow[kp * kq + min(k + 4 * u4, kq - 4)]);
+#pragma unroll
+        for (int u4 = 0; u4 < 8; ++u4) {
+          const bool in = (k + 4 * u4 < kq);                     // uniform; kq is a multiple of 4
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc = fmaf(xv[u4][j], in ? wv[4 * u4 + j] : 0.f, acc);
+        }
       }
     }
     part4[kp * 512 + nl] = acc;
   }
   __syncthreads();
+  PSM_STAMP(0, 10);
   for (int nl = tid; nl < ncols; nl += 1024) {
     const int n = n0 + nl;
-    float v = ((part4[nl] + part4[512 + nl]) + (part4[1024 + nl] + part4[1536 + nl])) + d.bias[n];
+    float v = ((part4[nl] + part4[512 + nl]) + (part4[1024 + nl] + part4[1536 + nl])) + (nl == tid ? bias0 : d.bias[n]);
     if (d.relu) v = fmaxf(v, 0.f);
     if (d.head) v = v * d.sa[n] + d.sb[n];
     d.out[(int64_t)m * d.ld_out + n] = v;
   }
+  // scaled coefficients, kept for psm_read_stage: stored last so that no barrier waits for them
+  if (blockIdx.y == 0 && tid < r.ldp) r.xin[(int64_t)m * r.ldp + tid] = x_keep;
+  PSM_STAMP(0, 11);
 }
 
 hipError_t psm_launch_reduce_dense1(const PsmReduceArgs& r, const PsmDenseArgs& d, hipStream_t st) {
@@ -299,76 +350,75 @@ hipError_t psm_launch_reduce_dense1(const PsmReduceArgs& r, const PsmDenseArgs& 
 //   D: lane l, reg r holds D[4*(l>>4) + r][l&15]
 // k order inside a group of 16: step j uses k = 16g + 4*(l>>4) + j (one float4 of A per lane).
 // ---------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // BF16: weights stored as bf16, activations rounded to bf16 on load; products are then exact
 // and the f32 MFMA accumulates them exactly like v_mfma_*_bf16 would (this layer is latency
 // bound, the bf16 storage only halves its weight bytes).
-template <int KG, bool BF16>   // KG: groups of 16 k per wave held in registers per pass
+//
+// Weights come MFMA-packed (psm_api.cpp pack_dense): the four k of a lane's group are one
+// 16-byte (bf16: 8-byte) piece and a wave's group is 1 KiB contiguous, so the whole operand set
+// of a wave (NGC groups: 2*NGC + NGC loads per lane) is requested up front, unconditionally, and
+// the MFMAs wait on it with counted vmcnt -- one memory round trip per pass.  Columns of the
+// activation row beyond ld_in are clamped (their weights are zero rows).
+// ROWS = 16 (few block rows: twice the workgroups, each pulling 2/3 of the bytes -- the layer
+// is bound by what ONE CU can pull per round trip) or 32 (weights read once per 32 rows).
+template <int NGC, bool BF16, int ROWS>   // NGC: groups of 16 k per wave per pass
 __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a) {
   __shared__ float red[8][2][16 * 17];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nt = blockIdx.x, mt = blockIdx.y;
   const int i = lane & 15, kq = lane >> 4;
-  const int klen = a.Kpad / 8;                       // per wave; Kpad multiple of 32 -> klen multiple of 4
-  const int k0 = wave * klen;
-  PSM_STAMP(0, 12);
+  const int groups = a.Kp / 16;                      // all waves
+  const int ng = groups / 8;                         // per wave: a multiple of NGC
+  PSM_STAMP(0, 44 + 4 * (a.layer & 3));
   // epilogue operands of this thread's output column: in flight from the start
   const int n_out = nt * 16 + (tid & 15);
   const float bias_v = a.bias[n_out];
   const float sa_v = a.head ? a.sa[n_out] : 1.f, sb_v = a.head ? a.sb[n_out] : 0.f;
   f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-  const float* arow0 = a.in + (int64_t)(mt * 32 + i) * a.ld_in + k0 + 4 * kq;
+  const float* arow0 = a.in + (int64_t)(mt * ROWS + i) * a.ld_in;
   const float* arow1 = arow0 + (int64_t)16 * a.ld_in;
-  const float* wcol = a.W + (int64_t)(k0 + 4 * kq) * a.ld_w + nt * 16 + i;
-  const __bf16* wcolb = reinterpret_cast<const __bf16*>(a.W) + (int64_t)(k0 + 4 * kq) * a.ld_w + nt * 16 + i;
+  const int g_first = wave * ng;
+  const int kmax = a.ld_in - 4;
   auto rnd = [](float v) { return BF16 ? (float)(__bf16)v : v; };
-  const int ngroups = klen / 16, rem = klen - ngroups * 16;   // rem in {0,4,8,12}: handled 4 k at a time
-  for (int g0 = 0; g0 < ngroups; g0 += KG) {
-    float4 a0[KG], a1[KG];
-    float w[KG][4];
+  for (int g0 = 0; g0 < ng; g0 += NGC) {
+    f32x4 a0[NGC], a1[NGC], w[NGC];
 #pragma unroll
-    for (int g = 0; g < KG; ++g) {
-      if (g0 + g < ngroups) {
-        a0[g] = *reinterpret_cast<const float4*>(arow0 + 16 * (g0 + g));
-        a1[g] = *reinterpret_cast<const float4*>(arow1 + 16 * (g0 + g));
+    for (int g = 0; g < NGC; ++g) {
+      const int kcol = min(16 * (g_first + g0 + g) + 4 * kq, kmax);
+      a0[g] = *reinterpret_cast<const f32x4*>(arow0 + kcol);
+      if (ROWS == 32) a1[g] = *reinterpret_cast<const f32x4*>(arow1 + kcol);
+    }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int64_t off = (int64_t)(16 * (g0 + g) + j) * a.ld_w;
-          w[g][j] = BF16 ? (float)wcolb[off] : wcol[off];
-        }
+    for (int g = 0; g < NGC; ++g) {
+      const int64_t widx = ((int64_t)nt * groups + g_first + g0 + g) * 64 + lane;
+      if (BF16) {
+        const uint2 u = reinterpret_cast<const uint2*>(a.Wp)[widx];
+        w[g] = (f32x4){__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                       __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+      } else {
+        w[g] = reinterpret_cast<const f32x4*>(a.Wp)[widx];
       }
     }
 #pragma unroll
-    for (int g = 0; g < KG; ++g) {
-      if (g0 + g < ngroups) {
-        acc0 = MFMA16(rnd(a0[g].x), w[g][0], acc0); acc1 = MFMA16(rnd(a1[g].x), w[g][0], acc1);
-        acc0 = MFMA16(rnd(a0[g].y), w[g][1], acc0); acc1 = MFMA16(rnd(a1[g].y), w[g][1], acc1);
-        acc0 = MFMA16(rnd(a0[g].z), w[g][2], acc0); acc1 = MFMA16(rnd(a1[g].z), w[g][2], acc1);
-        acc0 = MFMA16(rnd(a0[g].w), w[g][3], acc0); acc1 = MFMA16(rnd(a1[g].w), w[g][3], acc1);
-      }
+    for (int g = 0; g < NGC; ++g) {
+      acc0 = MFMA16(rnd(a0[g].x), w[g].x, acc0); if (ROWS == 32) acc1 = MFMA16(rnd(a1[g].x), w[g].x, acc1);
+      acc0 = MFMA16(rnd(a0[g].y), w[g].y, acc0); if (ROWS == 32) acc1 = MFMA16(rnd(a1[g].y), w[g].y, acc1);
+      acc0 = MFMA16(rnd(a0[g].z), w[g].z, acc0); if (ROWS == 32) acc1 = MFMA16(rnd(a1[g].z), w[g].z, acc1);
+      acc0 = MFMA16(rnd(a0[g].w), w[g].w, acc0); if (ROWS == 32) acc1 = MFMA16(rnd(a1[g].w), w[g].w, acc1);
     }
   }
-  // tail: remaining multiples of 4 k (natural order: step uses k = base + kq)
-  for (int kk = ngroups * 16; kk < klen; kk += 4) {
-    const float av0 = a.in[(int64_t)(mt * 32 + i) * a.ld_in + k0 + kk + kq];
-    const float av1 = a.in[(int64_t)(mt * 32 + 16 + i) * a.ld_in + k0 + kk + kq];
-    const int64_t woff = (int64_t)(k0 + kk + kq) * a.ld_w + nt * 16 + i;
-    const float wv = BF16 ? (float)reinterpret_cast<const __bf16*>(a.W)[woff] : a.W[woff];
-    acc0 = MFMA16(rnd(av0), wv, acc0);
-    acc1 = MFMA16(rnd(av1), wv, acc1);
-  }
-  (void)rem;
-  PSM_STAMP(0, 13);
+  PSM_STAMP(0, 45 + 4 * (a.layer & 3));
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     red[wave][0][(4 * kq + r) * 17 + i] = acc0[r];
-    red[wave][1][(4 * kq + r) * 17 + i] = acc1[r];
+    if (ROWS == 32) red[wave][1][(4 * kq + r) * 17 + i] = acc1[r];
   }
   __syncthreads();
-  {
-    const int row = tid >> 4, col = tid & 15;          // 512 threads = 32 rows x 16 cols
+  if (tid < ROWS * 16) {
+    const int row = tid >> 4, col = tid & 15;          // ROWS rows x 16 cols
     const int half = row >> 4, r16 = row & 15;
     float v = 0.f;
 #pragma unroll
@@ -376,14 +426,28 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a) {
     v += bias_v;
     if (a.relu) v = fmaxf(v, 0.f);
     if (a.head) v = v * sa_v + sb_v;
-    a.out[(int64_t)(mt * 32 + row) * a.ld_out + n_out] = v;
+    a.out[(int64_t)(mt * ROWS + row) * a.ld_out + n_out] = v;
   }
-  PSM_STAMP(0, 14);
+  PSM_STAMP(0, 46 + 4 * (a.layer & 3));
 }
 
 hipError_t psm_launch_dense(const PsmDenseArgs& a, hipStream_t st) {
-  if (a.bf16) hipLaunchKernelGGL((psm_dense_kernel<4, true>), dim3(a.ld_w / 16, a.Mpad / 32), dim3(512), 0, st, a);
-  else hipLaunchKernelGGL((psm_dense_kernel<4, false>), dim3(a.ld_w / 16, a.Mpad / 32), dim3(512), 0, st, a);
+  const int ng = a.Kp / 128;                       // groups of 16 k per wave
+  if (!a.Wp || a.Kp % 128 != 0 || (ng > 2 && ng % 4 != 0) || a.ld_in < 4) return hipErrorInvalidValue;
+  const bool r16 = a.Mpad <= 64;
+  const dim3 grid(a.ld_w / 16, a.Mpad / (r16 ? 16 : 32)), blk(512);
+#define DENSE(N)                                                                            \
+  do {                                                                                      \
+    if (r16) {                                                                              \
+      if (a.bf16) hipLaunchKernelGGL((psm_dense_kernel<N, true, 16>), grid, blk, 0, st, a); \
+      else hipLaunchKernelGGL((psm_dense_kernel<N, false, 16>), grid, blk, 0, st, a);       \
+    } else {                                                                                \
+      if (a.bf16) hipLaunchKernelGGL((psm_dense_kernel<N, true, 32>), grid, blk, 0, st, a); \
+      else hipLaunchKernelGGL((psm_dense_kernel<N, false, 32>), grid, blk, 0, st, a);       \
+    }                                                                                       \
+  } while (0)
+  if (ng == 1) DENSE(1); else if (ng == 2) DENSE(2); else DENSE(4);
+#undef DENSE
   return hipGetLastError();
 }
 
@@ -597,13 +661,13 @@ __global__ __launch_bounds__(256) void psm_strips_kernel(PsmStripArgs a) {
     on[k] = gm[(int64_t)k * a.Nx * a.c_in] != 0.f;
   }
   const int NS = a.NS;
-  __syncthreads();
-  if (on[0]) PSM_STAMP(0, 29); else PSM_STAMP(0, 29);      // after the loads have landed
-  const int32_t* st = tab;
-  float4* outp = a.spart + (((int64_t)cs * a.B + b) * a.n_bands + band) * NS;
+  // per-thread totals over its RPT rows (flow cells only / all cells), then per-COLUMN totals of
+  // the band in LDS: a rectangle covering the band's rows completely (the usual case) is then a
+  // sum of column totals over [c0, c1), done by ONE wave per slot
+  constexpr int NQ = 3 * C_OUT + 1;                  // masked self [C], masked prev [C], unmasked self [C], flow-cell count
+  __shared__ float colT[NQ][2][128];
+  __shared__ float fin[C_NS][3];
   __shared__ float wsum[4][C_NS][3];
-  // per-thread totals over its RPT rows (flow cells only / all cells): most rectangles cover the
-  // band's rows completely, then only the column test is left per slot
   float tot_s[C_OUT], tot_p[C_OUT], tot_cnt = 0.f, all_s[C_OUT];
 #pragma unroll
   for (int f = 0; f < C_OUT; ++f) { tot_s[f] = 0.f; tot_p[f] = 0.f; all_s[f] = 0.f; }
@@ -618,20 +682,27 @@ __global__ __launch_bounds__(256) void psm_strips_kernel(PsmStripArgs a) {
     tot_cnt += on[k] ? 1.f : 0.f;
   }
 #pragma unroll
+  for (int f = 0; f < C_OUT; ++f) {
+    colT[f][half][c] = tot_s[f];
+    colT[C_OUT + f][half][c] = tot_p[f];
+    colT[2 * C_OUT + f][half][c] = all_s[f];
+  }
+  colT[3 * C_OUT][half][c] = tot_cnt;
+  __syncthreads();
+  PSM_STAMP(0, 29);                                  // loads landed, column totals in LDS
+  const int32_t* st = tab;
+  float4* outp = a.spart + (((int64_t)cs * a.B + b) * a.n_bands + band) * NS;
+#pragma unroll
   for (int s = 0; s < C_NS; ++s) {
     if (s < NS) {      // uniform
       const int data = st[6 * s], mask = st[6 * s + 1], r0 = st[6 * s + 2], r1 = st[6 * s + 3], c0 = st[6 * s + 4], c1 = st[6 * s + 5];
-      float s0 = 0.f, s1 = 0.f, cnt = 0.f;
       // rows of this band inside the rectangle? (uniform over the workgroup)
       const bool live = !(r1 <= band * RB || r0 >= (band + 1) * RB || c1 <= c0);
-      if (live) {
-        const bool incol = (c >= c0 && c < c1);
-        const bool use_prev = (data != b);
-        if (r0 <= band * RB && r1 >= (band + 1) * RB) {      // whole band (uniform)
-          if (mask < 0) { s0 = all_s[0]; s1 = all_s[C_OUT - 1]; cnt = (float)RPT; }
-          else { s0 = use_prev ? tot_p[0] : tot_s[0]; s1 = use_prev ? tot_p[C_OUT - 1] : tot_s[C_OUT - 1]; cnt = tot_cnt; }
-          s0 = incol ? s0 : 0.f; s1 = incol ? s1 : 0.f; cnt = incol ? cnt : 0.f;
-        } else if (incol) {
+      const bool whole = (r0 <= band * RB && r1 >= (band + 1) * RB);
+      const bool use_prev = (data != b);
+      if (live && !whole) {                           // band cut by the rectangle: row tests, whole workgroup
+        float s0 = 0.f, s1 = 0.f, cnt = 0.f;
+        if (c >= c0 && c < c1) {
 #pragma unroll
           for (int k = 0; k < RPT; ++k) {
             const int r = rbase + k;
@@ -643,17 +714,38 @@ __global__ __launch_bounds__(256) void psm_strips_kernel(PsmStripArgs a) {
           }
         }
         s0 = wave_sum(s0); if (C_OUT > 1) s1 = wave_sum(s1); cnt = wave_sum(cnt);
+        if (lane == 0) { wsum[wave][s][0] = s0; wsum[wave][s][1] = s1; wsum[wave][s][2] = cnt; }
+      } else if ((s & 3) == wave) {                   // one wave per slot (wave-uniform)
+        float s0 = 0.f, s1 = 0.f, cnt = 0.f;
+        if (live) {
+          const int qb = mask < 0 ? 2 * C_OUT : (use_prev ? C_OUT : 0);
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const int cc = lane + 64 * h2;
+            const bool in = (cc >= c0 && cc < c1);
+            s0 += in ? colT[qb][0][cc] + colT[qb][1][cc] : 0.f;
+            if (C_OUT > 1) s1 += in ? colT[qb + C_OUT - 1][0][cc] + colT[qb + C_OUT - 1][1][cc] : 0.f;
+            cnt += in ? (mask < 0 ? (float)RB : colT[3 * C_OUT][0][cc] + colT[3 * C_OUT][1][cc]) : 0.f;
+          }
+          s0 = wave_sum(s0); if (C_OUT > 1) s1 = wave_sum(s1); cnt = wave_sum(cnt);
+        }
+        if (lane == 0) { fin[s][0] = s0; fin[s][1] = s1; fin[s][2] = cnt; }
       }
-      if (lane == 0) { wsum[wave][s][0] = s0; wsum[wave][s][1] = s1; wsum[wave][s][2] = cnt; }
     }
   }
   __syncthreads();
   PSM_STAMP(0, 30);
   if (tid < NS) {
     const int s = tid;
-    outp[s] = make_float4((wsum[0][s][0] + wsum[1][s][0]) + (wsum[2][s][0] + wsum[3][s][0]),
-                          (wsum[0][s][1] + wsum[1][s][1]) + (wsum[2][s][1] + wsum[3][s][1]),
-                          (wsum[0][s][2] + wsum[1][s][2]) + (wsum[2][s][2] + wsum[3][s][2]), 0.f);
+    const int r0 = st[6 * s + 2], r1 = st[6 * s + 3], c0 = st[6 * s + 4], c1 = st[6 * s + 5];
+    const bool live = !(r1 <= band * RB || r0 >= (band + 1) * RB || c1 <= c0);
+    const bool whole = (r0 <= band * RB && r1 >= (band + 1) * RB);
+    if (live && !whole)
+      outp[s] = make_float4((wsum[0][s][0] + wsum[1][s][0]) + (wsum[2][s][0] + wsum[3][s][0]),
+                            (wsum[0][s][1] + wsum[1][s][1]) + (wsum[2][s][1] + wsum[3][s][1]),
+                            (wsum[0][s][2] + wsum[1][s][2]) + (wsum[2][s][2] + wsum[3][s][2]), 0.f);
+    else
+      outp[s] = make_float4(fin[s][0], C_OUT > 1 ? fin[s][1] : fin[s][0], fin[s][2], 0.f);
   }
   // gradp: per-column sums of block 0, field 0 (first column holding a flow cell, UGP:294-300)
   if (a.colpart && b == 0) {
@@ -709,14 +801,27 @@ __device__ __forceinline__ void psm_chain_rows(const PsmChainParams& P, const fl
   float up = (VARIANT == PSMV_CHAPTER5 && tj == -1) ? NAN : 0.f;   // BC_ups[tj] / BC_up_
   float carry = (VARIANT == PSMV_CHAPTER5) ? NAN : 0.f;             // c_prev | BC_ant_0 / BC_alter
   auto rl = [](float v, int q) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), q)); };
+  // The strip means of a row's blocks do not depend on the chain: all C_NS of them (plus one
+  // count) are read a row ahead, unconditionally, so that the recurrence itself runs on registers.
+  const int bmax = nrow * ncol - 1;
+  auto fetch = [&](float (&M)[C_NS], float& cnt_up, int r) {
+    const int b = min(r * ncol + l, bmax);
+#pragma unroll
+    for (int s = 0; s < C_NS; ++s) M[s] = smean[b * NS + min(s, NS - 1)];
+    cnt_up = (VARIANT == PSMV_DELTAS) ? scnt[b * NS + D_ROWS_UP] : 0.f;
+  };
+  float M[C_NS], cnt_up;
+  fetch(M, cnt_up, 0);
   for (int r = 0; r < nrow; ++r) {
+    float Mn[C_NS], cnt_up_n;
+    fetch(Mn, cnt_up_n, r + 1);                               // clamped on the last row
     const int b = r * ncol + l;
     const bool first = (r == 0), last = (r == n_y + 1);
     if (last && P.skip_last) {                                // duplicate last row left out (uniform)
       if (act) offs_out[b] = NAN;
       continue;
     }
-    const float* mp = smean + b * NS;
+    const float* mp = M;
     const bool unan = (up != up);
     float A, Bm = 0.f, L = 0.f, c;
     bool need;
@@ -727,7 +832,7 @@ __device__ __forceinline__ void psm_chain_rows(const PsmChainParams& P, const fl
       if (first) { c = mp[D_COL_LAST] - ref; need = (lane != 0); }
       else if (!last) { c = mp[D_TOP] - up; need = unan && !(tj != 0 && tj == n_x); }
       else {
-        const bool use_side = scnt[b * NS + D_ROWS_UP] / 16384.f > 0.9f;   // SMD:307
+        const bool use_side = cnt_up / 16384.f > 0.9f;         // SMD:307
         c = (tj == n_x) ? mp[D_ROWS_UP] - up : mp[D_ROWS_HEAD] - up;
         need = (tj != n_x) && use_side;
       }
@@ -765,6 +870,9 @@ __device__ __forceinline__ void psm_chain_rows(const PsmChainParams& P, const fl
       else if (!last) up = (m1 ? mp[C_RC_UNMASKED] : mp[C_ROWS_R]) - c;
     }
     if (act) offs_out[b] = c;
+#pragma unroll
+    for (int s = 0; s < C_NS; ++s) M[s] = Mn[s];
+    cnt_up = cnt_up_n;
   }
 }
 
@@ -876,15 +984,17 @@ __global__ __launch_bounds__(256) void psm_assemble_kernel(PsmChainArgs a, PsmPa
   float* offs = scnt + nst;                           // [C][B]
   float* wred = offs + C * B;                         // [C][4] + [C] shift
   PSM_STAMP(0, 36);
-  // ---- phase 1a: every independent load (cell owner, shift-list owners, strip partials)
+  // ---- phase 1a: every independent load (cell owner, shift-list owners, strip partials).
+  // Straight-line: indices are clamped and results selected, so that all loads of a phase are
+  // in flight together (a conditional load costs a branch and, with it, a drained vmcnt).
   const int pix = blockIdx.x * 256 + tid;
-  const int o = pix < p.npix ? a.owner[pix] : -1;
+  const int o_raw = a.owner[min(pix, p.npix - 1)];
   int la[C], lb[C];                                  // one shift-list entry per thread and field (L <= 256 on this path)
 #pragma unroll
   for (int f = 0; f < C; ++f) {
-    const bool in = tid < a.shiftL[f];
-    la[f] = in ? a.shiftOwnA[(int64_t)f * a.Lmax + tid] : -1;
-    lb[f] = in ? a.shiftOwnB[(int64_t)f * a.Lmax + tid] : -1;
+    const int kk = (int)((int64_t)f * a.Lmax) + min(tid, max(a.shiftL[f], 1) - 1);
+    la[f] = a.shiftOwnA[kk];
+    lb[f] = a.shiftOwnB[kk];
   }
   const float4* sp = a.spart + (int64_t)cs * B * NB * NS;
   const int idx0 = tid, idx1 = tid + 256;             // B*NS <= 64*11 = 704 -> at most 3 per thread
@@ -899,27 +1009,34 @@ __global__ __launch_bounds__(256) void psm_assemble_kernel(PsmChainArgs a, PsmPa
     }
   }
   float2 cp[NB];
+  if (a.colpart) {                                    // uniform
 #pragma unroll
-  for (int q = 0; q < NB; ++q) cp[q] = (a.colpart && tid < 128) ? a.colpart[((int64_t)cs * NB + q) * 128 + tid] : make_float2(0.f, 0.f);
+    for (int q = 0; q < NB; ++q) cp[q] = a.colpart[((int64_t)cs * NB + q) * 128 + (tid & 127)];
+  }
   __builtin_amdgcn_sched_barrier(0);
   // ---- phase 1b: dependent gathers from the decoded blocks
+  const int o = pix < p.npix ? o_raw : -1;
   const float* predc = a.pred + ((int64_t)cs * B * SS) * C;
   float src[C], ga[C], gb[C];
 #pragma unroll
   for (int f = 0; f < C; ++f) {
-    src[f] = o >= 0 ? predc[(int64_t)o * C + f] : 0.f;
-    ga[f] = la[f] >= 0 ? predc[(int64_t)la[f] * C + f] : 0.f;
-    gb[f] = lb[f] >= 0 ? predc[(int64_t)lb[f] * C + f] : 0.f;
+    const bool in = tid < a.shiftL[f];
+    la[f] = in ? la[f] : -1;
+    lb[f] = in ? lb[f] : -1;
+    src[f] = predc[(int64_t)max(o, 0) * C + f];
+    ga[f] = predc[(int64_t)max(la[f], 0) * C + f];
+    gb[f] = predc[(int64_t)max(lb[f], 0) * C + f];
   }
   __builtin_amdgcn_sched_barrier(0);
   // ---- strip partials -> means
   auto fold = [&](const v4f (&v)[NB], int idx) {
-    if (idx < B * NS) {
-      float s0 = 0.f, s1 = 0.f, cn = 0.f;
+    float s0 = 0.f, s1 = 0.f, cn = 0.f;
 #pragma unroll
-      for (int q = 0; q < NB; ++q) { s0 += v[q].x; s1 += v[q].y; cn += v[q].z; }
-      smean[idx] = s0 / cn;
-      if (C > 1) smean[nst + idx] = s1 / cn;
+    for (int q = 0; q < NB; ++q) { s0 += v[q].x; s1 += v[q].y; cn += v[q].z; }
+    const float m0 = s0 / cn, m1 = s1 / cn;
+    if (idx < B * NS) {
+      smean[idx] = m0;
+      if (C > 1) smean[nst + idx] = m1;
       scnt[idx] = cn;
     }
   };
@@ -932,19 +1049,22 @@ __global__ __launch_bounds__(256) void psm_assemble_kernel(PsmChainArgs a, PsmPa
     for (int q = 0; q < NB; ++q) v[q] = *reinterpret_cast<const v4f*>(sp + ((int64_t)b * NB + q) * NS + s);
     fold(v, idx);
   }
-  if (a.colpart && tid < 128) {
+  if (a.colpart) {
     float s0 = 0.f, cn = 0.f;
 #pragma unroll
     for (int q = 0; q < NB; ++q) { s0 += cp[q].x; cn += cp[q].y; }
-    smean[B * NS + tid] = s0 / cn;
-    if (C > 1) smean[nst + B * NS + tid] = 0.f;
-    scnt[B * NS + tid] = cn;
+    const float m0 = s0 / cn;
+    if (tid < 128) {
+      smean[B * NS + tid] = m0;
+      if (C > 1) smean[nst + B * NS + tid] = 0.f;
+      scnt[B * NS + tid] = cn;
+    }
   }
   // offset-independent part of the shift
   float pp[C];
 #pragma unroll
   for (int f = 0; f < C; ++f) {
-    float acc = 3.f * ga[f] - gb[f];
+    float acc = 3.f * (la[f] >= 0 ? ga[f] : 0.f) - (lb[f] >= 0 ? gb[f] : 0.f);
     for (int k = tid + 256; k < a.shiftL[f]; k += 256) {   // lists longer than 256 (not on the small-grid path)
       const int ia = a.shiftOwnA[(int64_t)f * a.Lmax + k], ib = a.shiftOwnB[(int64_t)f * a.Lmax + k];
       acc += 3.f * (ia >= 0 ? predc[(int64_t)ia * C + f] : 0.f) - (ib >= 0 ? predc[(int64_t)ib * C + f] : 0.f);
