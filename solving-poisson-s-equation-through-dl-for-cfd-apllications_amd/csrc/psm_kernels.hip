@@ -648,9 +648,10 @@ __global__ __launch_bounds__(256) void psm_strips_kernel(PsmStripArgs a) {
   const float* gm = a.grid + (((int64_t)cs * a.Ny + a.blk_y0x0[2 * b] + rbase) * a.Nx + a.blk_y0x0[2 * b + 1] + c) * a.c_in + a.sdf_ch;
   PSM_STAMP(0, 28);
   __shared__ int32_t tab[C_NS * 6];                 // this block's strip rectangles
-  if (tid < a.NS * 6) tab[tid] = a.strips[(int64_t)b * a.NS * 6 + tid];
   float vs[RPT][C_OUT], vp[RPT][C_OUT];
   bool on[RPT];
+  // decoded values and the rectangle table first: their addresses need nothing but the launch
+  // arguments; the mask loads wait for the block's grid origin (a dependent scalar load)
 #pragma unroll
   for (int k = 0; k < RPT; ++k) {
 #pragma unroll
@@ -658,8 +659,16 @@ __global__ __launch_bounds__(256) void psm_strips_kernel(PsmStripArgs a) {
       vs[k][f] = self[(int64_t)k * S * C_OUT + f];
       vp[k][f] = prev[(int64_t)k * S * C_OUT + f];
     }
-    on[k] = gm[(int64_t)k * a.Nx * a.c_in] != 0.f;
   }
+  const int32_t tabv = a.strips[(int64_t)b * a.NS * 6 + min(tid, a.NS * 6 - 1)];
+  __builtin_amdgcn_sched_barrier(0);
+  float gv[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) gv[k] = gm[(int64_t)k * a.Nx * a.c_in];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) on[k] = gv[k] != 0.f;
+  if (tid < a.NS * 6) tab[tid] = tabv;
   const int NS = a.NS;
   // per-thread totals over its RPT rows (flow cells only / all cells), then per-COLUMN totals of
   // the band in LDS: a rectangle covering the band's rows completely (the usual case) is then a
@@ -692,60 +701,83 @@ __global__ __launch_bounds__(256) void psm_strips_kernel(PsmStripArgs a) {
   PSM_STAMP(0, 29);                                  // loads landed, column totals in LDS
   const int32_t* st = tab;
   float4* outp = a.spart + (((int64_t)cs * a.B + b) * a.n_bands + band) * NS;
+  static_assert(C_NS <= 12, "three slots per wave");
+  // slots whose rectangle cuts this band (row tests needed): found once, by every wave
+  unsigned long long pmask;
+  {
+    const int sl = min(lane, NS - 1);
+    const int r0 = st[6 * sl + 2], r1 = st[6 * sl + 3], c0 = st[6 * sl + 4], c1 = st[6 * sl + 5];
+    const bool live = !(r1 <= band * RB || r0 >= (band + 1) * RB || c1 <= c0);
+    const bool whole = (r0 <= band * RB && r1 >= (band + 1) * RB);
+    pmask = __ballot(lane < NS && live && !whole);
+  }
+  // every other slot is a sum of column totals over [c0, c1): wave w takes slots w, w+4, w+8 --
+  // straight-line (selects, no branches), nine wave sums interleaved
+  float rs[3][3];
 #pragma unroll
-  for (int s = 0; s < C_NS; ++s) {
-    if (s < NS) {      // uniform
-      const int data = st[6 * s], mask = st[6 * s + 1], r0 = st[6 * s + 2], r1 = st[6 * s + 3], c0 = st[6 * s + 4], c1 = st[6 * s + 5];
-      // rows of this band inside the rectangle? (uniform over the workgroup)
-      const bool live = !(r1 <= band * RB || r0 >= (band + 1) * RB || c1 <= c0);
-      const bool whole = (r0 <= band * RB && r1 >= (band + 1) * RB);
-      const bool use_prev = (data != b);
-      if (live && !whole) {                           // band cut by the rectangle: row tests, whole workgroup
-        float s0 = 0.f, s1 = 0.f, cnt = 0.f;
-        if (c >= c0 && c < c1) {
+  for (int j = 0; j < 3; ++j) {
+    const int s = wave + 4 * j, sv = min(s, NS - 1);
+    const int data = st[6 * sv], mask = st[6 * sv + 1], r0 = st[6 * sv + 2], r1 = st[6 * sv + 3], c0 = st[6 * sv + 4], c1 = st[6 * sv + 5];
+    const bool live = !(r1 <= band * RB || r0 >= (band + 1) * RB || c1 <= c0);
+    const bool whole = (r0 <= band * RB && r1 >= (band + 1) * RB);
+    const bool ok = (s < NS) && live && whole;
+    const int qb = mask < 0 ? 2 * C_OUT : (data != b ? C_OUT : 0);
+    float s0 = 0.f, s1 = 0.f, cnt = 0.f;
 #pragma unroll
-          for (int k = 0; k < RPT; ++k) {
-            const int r = rbase + k;
-            if (r >= r0 && r < r1 && (mask < 0 || on[k])) {
-              s0 += use_prev ? vp[k][0] : vs[k][0];
-              if (C_OUT > 1) s1 += use_prev ? vp[k][C_OUT - 1] : vs[k][C_OUT - 1];
-              cnt += 1.f;
-            }
-          }
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int cc = lane + 64 * h2;
+      const bool in = ok && (cc >= c0 && cc < c1);
+      const float t0 = colT[qb][0][cc] + colT[qb][1][cc];
+      const float t1 = colT[qb + C_OUT - 1][0][cc] + colT[qb + C_OUT - 1][1][cc];
+      const float tc = colT[3 * C_OUT][0][cc] + colT[3 * C_OUT][1][cc];
+      s0 += in ? t0 : 0.f;
+      s1 += in ? t1 : 0.f;
+      cnt += in ? (mask < 0 ? (float)RB : tc) : 0.f;
+    }
+    rs[j][0] = s0; rs[j][1] = s1; rs[j][2] = cnt;
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    rs[j][0] = wave_sum(rs[j][0]);
+    if (C_OUT > 1) rs[j][1] = wave_sum(rs[j][1]); else rs[j][1] = rs[j][0];
+    rs[j][2] = wave_sum(rs[j][2]);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int s = wave + 4 * j;
+      if (s < C_NS) { fin[s][0] = rs[j][0]; fin[s][1] = rs[j][1]; fin[s][2] = rs[j][2]; }
+    }
+  }
+  for (unsigned long long pm = pmask; pm; pm &= pm - 1) {     // band cut by the rectangle: row tests, whole workgroup
+    const int s = __ffsll((long long)pm) - 1;
+    const int data = st[6 * s], mask = st[6 * s + 1], r0 = st[6 * s + 2], r1 = st[6 * s + 3], c0 = st[6 * s + 4], c1 = st[6 * s + 5];
+    const bool use_prev = (data != b);
+    float s0 = 0.f, s1 = 0.f, cnt = 0.f;
+    if (c >= c0 && c < c1) {
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        const int r = rbase + k;
+        if (r >= r0 && r < r1 && (mask < 0 || on[k])) {
+          s0 += use_prev ? vp[k][0] : vs[k][0];
+          if (C_OUT > 1) s1 += use_prev ? vp[k][C_OUT - 1] : vs[k][C_OUT - 1];
+          cnt += 1.f;
         }
-        s0 = wave_sum(s0); if (C_OUT > 1) s1 = wave_sum(s1); cnt = wave_sum(cnt);
-        if (lane == 0) { wsum[wave][s][0] = s0; wsum[wave][s][1] = s1; wsum[wave][s][2] = cnt; }
-      } else if ((s & 3) == wave) {                   // one wave per slot (wave-uniform)
-        float s0 = 0.f, s1 = 0.f, cnt = 0.f;
-        if (live) {
-          const int qb = mask < 0 ? 2 * C_OUT : (use_prev ? C_OUT : 0);
-#pragma unroll
-          for (int h2 = 0; h2 < 2; ++h2) {
-            const int cc = lane + 64 * h2;
-            const bool in = (cc >= c0 && cc < c1);
-            s0 += in ? colT[qb][0][cc] + colT[qb][1][cc] : 0.f;
-            if (C_OUT > 1) s1 += in ? colT[qb + C_OUT - 1][0][cc] + colT[qb + C_OUT - 1][1][cc] : 0.f;
-            cnt += in ? (mask < 0 ? (float)RB : colT[3 * C_OUT][0][cc] + colT[3 * C_OUT][1][cc]) : 0.f;
-          }
-          s0 = wave_sum(s0); if (C_OUT > 1) s1 = wave_sum(s1); cnt = wave_sum(cnt);
-        }
-        if (lane == 0) { fin[s][0] = s0; fin[s][1] = s1; fin[s][2] = cnt; }
       }
     }
+    s0 = wave_sum(s0); if (C_OUT > 1) s1 = wave_sum(s1); cnt = wave_sum(cnt);
+    if (lane == 0) { wsum[wave][s][0] = s0; wsum[wave][s][1] = s1; wsum[wave][s][2] = cnt; }
   }
   __syncthreads();
   PSM_STAMP(0, 30);
   if (tid < NS) {
     const int s = tid;
-    const int r0 = st[6 * s + 2], r1 = st[6 * s + 3], c0 = st[6 * s + 4], c1 = st[6 * s + 5];
-    const bool live = !(r1 <= band * RB || r0 >= (band + 1) * RB || c1 <= c0);
-    const bool whole = (r0 <= band * RB && r1 >= (band + 1) * RB);
-    if (live && !whole)
+    if ((pmask >> s) & 1ull)
       outp[s] = make_float4((wsum[0][s][0] + wsum[1][s][0]) + (wsum[2][s][0] + wsum[3][s][0]),
                             (wsum[0][s][1] + wsum[1][s][1]) + (wsum[2][s][1] + wsum[3][s][1]),
                             (wsum[0][s][2] + wsum[1][s][2]) + (wsum[2][s][2] + wsum[3][s][2]), 0.f);
     else
-      outp[s] = make_float4(fin[s][0], C_OUT > 1 ? fin[s][1] : fin[s][0], fin[s][2], 0.f);
+      outp[s] = make_float4(fin[s][0], fin[s][1], fin[s][2], 0.f);
   }
   // gradp: per-column sums of block 0, field 0 (first column holding a flow cell, UGP:294-300)
   if (a.colpart && b == 0) {
@@ -784,7 +816,7 @@ hipError_t psm_launch_strips(const PsmStripArgs& a, int n_cases, hipStream_t st)
 template <int VARIANT>
 __device__ __forceinline__ void psm_chain_rows(const PsmChainParams& P, const float* smean, const float* scnt,
                                                const PsmBlock* blk, int field, int lane, float* offs_out) {
-  const int n_x = P.n_x, n_y = P.n_y, NS = P.NS;
+  const int n_x = P.n_x, n_y = P.n_y;
   const int ncol = (VARIANT == PSMV_CHAPTER5) ? n_x + 2 : n_x + 1;
   const int nrow = n_y + 2;
   const bool act = lane < ncol;
@@ -803,17 +835,18 @@ __device__ __forceinline__ void psm_chain_rows(const PsmChainParams& P, const fl
   auto rl = [](float v, int q) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), q)); };
   // The strip means of a row's blocks do not depend on the chain: all C_NS of them (plus one
   // count) are read a row ahead, unconditionally, so that the recurrence itself runs on registers.
+  constexpr int NSV = (VARIANT == PSMV_DELTAS) ? (int)D_NS : (VARIANT == PSMV_GRADP ? (int)G_NS : (int)C_NS);   // == P.NS
   const int bmax = nrow * ncol - 1;
-  auto fetch = [&](float (&M)[C_NS], float& cnt_up, int r) {
-    const int b = min(r * ncol + l, bmax);
+  auto fetch = [&](float (&M)[NSV], float& cnt_up, int r) {
+    const float* mp = smean + min(r * ncol + l, bmax) * NSV;
 #pragma unroll
-    for (int s = 0; s < C_NS; ++s) M[s] = smean[b * NS + min(s, NS - 1)];
-    cnt_up = (VARIANT == PSMV_DELTAS) ? scnt[b * NS + D_ROWS_UP] : 0.f;
+    for (int s = 0; s < NSV; ++s) M[s] = mp[s];
+    cnt_up = (VARIANT == PSMV_DELTAS) ? scnt[min(r * ncol + l, bmax) * NSV + D_ROWS_UP] : 0.f;
   };
-  float M[C_NS], cnt_up;
+  float M[NSV], cnt_up;
   fetch(M, cnt_up, 0);
   for (int r = 0; r < nrow; ++r) {
-    float Mn[C_NS], cnt_up_n;
+    float Mn[NSV], cnt_up_n;
     fetch(Mn, cnt_up_n, r + 1);                               // clamped on the last row
     const int b = r * ncol + l;
     const bool first = (r == 0), last = (r == n_y + 1);
@@ -871,7 +904,7 @@ __device__ __forceinline__ void psm_chain_rows(const PsmChainParams& P, const fl
     }
     if (act) offs_out[b] = c;
 #pragma unroll
-    for (int s = 0; s < C_NS; ++s) M[s] = Mn[s];
+    for (int s = 0; s < NSV; ++s) M[s] = Mn[s];
     cnt_up = cnt_up_n;
   }
 }

@@ -1,0 +1,38 @@
+"""Condense the rocprofv3 outputs of tools/prof_full.sh TAG into the files kept under profiles/:
+profiles/<TAG>_kernel_stats.csv, <TAG>_bench.json.log, <TAG>_pmc_summary.csv, pmc_encode.json.
+HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (KB counters; FETCH doubled per the gfx950 note in
+MI355X_MICROARCH.md's HBM section for 16-B/lane coalesced streams)."""
+import csv, glob, json, os, shutil, sys
+tag = sys.argv[1]
+O = f"gpurun_out/full_{tag}"
+def counter(dirname, name):
+    f = sorted(glob.glob(f"{O}/{dirname}/*/*counter_collection.csv"))[-1]
+    acc = {}
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != name: continue
+        k = r["Kernel_Name"]
+        s, n = acc.get(k, (0.0, 0))
+        acc[k] = (s + float(r["Counter_Value"]), n + 1)
+    return {k: s / n for k, (s, n) in acc.items()}
+fetch, write = counter("fetch", "FETCH_SIZE"), counter("write", "WRITE_SIZE")
+rows, allk = [], {}
+for k in sorted(fetch):
+    if "psm_" not in k: continue
+    hb = (2 * fetch[k] + write.get(k, 0.0)) * 1024.0
+    rows.append((k, fetch[k], write.get(k, 0.0), hb))
+    allk[k[:40]] = {"FETCH_SIZE_KB": fetch[k], "WRITE_SIZE_KB": write.get(k, 0.0), "hbm_bytes": hb}
+os.makedirs("profiles", exist_ok=True)
+with open(f"profiles/{tag}_pmc_summary.csv", "w") as f:
+    f.write("kernel,FETCH_SIZE_KB_per_launch,WRITE_SIZE_KB_per_launch,hbm_bytes_per_launch(2*FETCH+WRITE)\n")
+    for r in rows: f.write('"%s",%.3f,%.3f,%.1f\n' % r)
+enc = [r for r in rows if "psm_encode_kernel" in r[0]][0]
+json.dump({"kernel": enc[0], "FETCH_SIZE_KB": enc[1], "WRITE_SIZE_KB": enc[2],
+           "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B for 16-B/lane coalesced streams -> doubled (MI355X_MICROARCH.md HBM section); WRITE_SIZE exact",
+           "hbm_bytes_per_launch": enc[3],
+           "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline (second pass with --pmc WRITE_SIZE)",
+           "profile_tag": tag, "all_kernels": allk}, open("profiles/pmc_encode.json", "w"), indent=1)
+st = sorted(glob.glob(f"{O}/stats/*/*kernel_stats.csv"))[-1]
+shutil.copy(st, f"profiles/{tag}_kernel_stats.csv")
+open(f"profiles/{tag}_bench.json.log", "w").write(open(f"{O}/bench.log").read().strip().splitlines()[-1] + "\n")
+for r in list(csv.DictReader(open(st)))[:10]:
+    print(f"{r['Name'][:60]:60s} calls={int(r['Calls']):6d} avg_us={float(r['AverageNs'])/1e3:8.2f}")
