@@ -131,6 +131,19 @@ int psm_num_blocks(const psm_handle* h);
  * Synchronous, like py_func. */
 int psm_solve_grid(psm_handle* h, const float* grid, int32_t n_cases,
                    const float* out_scale, float* fields);
+/* Host buffers, asynchronous: a ring of PSM_RING_SLOTS pinned staging slots.  psm_submit_grid
+ * copies `grid` into the slot (the caller's buffer is free on return), enqueues H2D on a copy
+ * stream, the solve on the compute stream and D2H on a second copy stream, and returns a
+ * ticket; psm_wait_grid blocks until that ticket's field has arrived and copies it to
+ * `fields`.  With several tickets in flight the copies of neighbouring tickets overlap the
+ * kernels (the reference's py_func is synchronous, PM:249-517; this is the form for a caller
+ * that owns several independent cases or time steps, e.g. an ensemble of PISO runs).
+ * Tickets must be waited for in submission order before their slot is needed again:
+ * PSM_ERR_STATE if PSM_RING_SLOTS tickets are already in flight. */
+#define PSM_RING_SLOTS 4
+int psm_submit_grid(psm_handle* h, const float* grid, int32_t n_cases,
+                    const float* out_scale, int64_t* ticket);
+int psm_wait_grid(psm_handle* h, int64_t ticket, float* fields);
 /* Device buffers (HIP pointers on cfg.device), asynchronous on `stream`
  * (hipStream_t; NULL = the handle's own stream).  out_scale is a HOST pointer
  * (or NULL) read before return. */

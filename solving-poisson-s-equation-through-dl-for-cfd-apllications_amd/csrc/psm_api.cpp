@@ -77,6 +77,17 @@ struct psm_handle {
   int normalise_sdf = 0, fill_input = 0;
   float *d_grid_stage = nullptr, *d_fields_stage = nullptr;
   float *h_grid = nullptr, *h_fields = nullptr;
+  // host-buffer submission ring (psm_submit_grid / psm_wait_grid): pinned in/out + device in/out per slot
+  struct Slot {
+    float *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr;
+    hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr;
+    int64_t ticket = -1;       // ticket in flight in this slot, -1 = free
+    int n_cases = 0;
+  };
+  static constexpr int SLOTS = PSM_RING_SLOTS;
+  Slot slot[SLOTS];
+  int64_t next_ticket = 0;
+  hipStream_t stream_in = nullptr, stream_out = nullptr;
   // row-scale upload ring (pinned)
   static constexpr int RING = 8;
   float* h_scale[RING] = {};
@@ -137,6 +148,16 @@ void destroy_graphs(psm_handle* h) {
 }
 
 void free_plan(psm_handle* h) {
+  for (auto& s : h->slot) {
+    if (s.h_in) (void)hipHostFree(s.h_in);
+    if (s.h_out) (void)hipHostFree(s.h_out);
+    if (s.d_in) (void)hipFree(s.d_in);
+    if (s.d_out) (void)hipFree(s.d_out);
+    if (s.ev_in) (void)hipEventDestroy(s.ev_in);
+    if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+    if (s.ev_out) (void)hipEventDestroy(s.ev_out);
+    s = psm_handle::Slot{};
+  }
   destroy_graphs(h);
   dev_free(h->d_part); dev_free(h->d_xin); dev_free(h->d_act[0]); dev_free(h->d_act[1]); dev_free(h->d_res);
   dev_free(h->d_pred); dev_free(h->d_row_base); dev_free(h->d_row_scale); dev_free(h->d_ones); dev_free(h->d_strips);
@@ -506,6 +527,8 @@ void psm_destroy(psm_handle* h) {
   }
   for (auto& p : h->timed_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->stream_in) (void)hipStreamDestroy(h->stream_in);
+  if (h->stream_out) (void)hipStreamDestroy(h->stream_out);
   delete h;
 }
 
@@ -745,6 +768,70 @@ int psm_solve_grid(psm_handle* h, const float* grid, int32_t n_cases, const floa
   HIPCHK(h, hipMemcpyAsync(h->h_fields, h->d_fields_stage, gout, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   memcpy(fields, h->h_fields, gout);
+  return PSM_OK;
+}
+
+// ---- host-buffer ring: H2D of ticket k+1 and D2H of ticket k-1 overlap the kernels of ticket k ----
+static int ring_init(psm_handle* h) {
+  if (h->slot[0].h_in) return PSM_OK;
+  const size_t npix = (size_t)h->Ny * h->Nx;
+  const size_t gin = (size_t)h->cfg.max_cases * npix * h->cfg.c_in, gout = (size_t)h->cfg.max_cases * npix * h->cfg.c_out;
+  if (!h->stream_in) HIPCHK(h, hipStreamCreateWithFlags(&h->stream_in, hipStreamNonBlocking));
+  if (!h->stream_out) HIPCHK(h, hipStreamCreateWithFlags(&h->stream_out, hipStreamNonBlocking));
+  for (auto& s : h->slot) {
+    HIPCHK(h, hipHostMalloc((void**)&s.h_in, gin * sizeof(float), hipHostMallocDefault));
+    HIPCHK(h, hipHostMalloc((void**)&s.h_out, gout * sizeof(float), hipHostMallocDefault));
+    int rc;
+    if ((rc = dev_alloc(h, &s.d_in, gin))) return rc;
+    if ((rc = dev_alloc(h, &s.d_out, gout))) return rc;
+    HIPCHK(h, hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming));
+    s.ticket = -1;
+  }
+  return PSM_OK;
+}
+
+int psm_submit_grid(psm_handle* h, const float* grid, int32_t n_cases, const float* out_scale, int64_t* ticket) {
+  if (!h) return PSM_ERR_ARG;
+  if (!h->planned) return fail(h, PSM_ERR_STATE, "psm_plan_grid has not been called");
+  if (!grid || !ticket) return fail(h, PSM_ERR_ARG, "null argument");
+  if (n_cases < 1 || n_cases > h->cfg.max_cases) return fail(h, PSM_ERR_ARG, "n_cases outside [1, max_cases]");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  int rc = ring_init(h);
+  if (rc) return rc;
+  psm_handle::Slot& s = h->slot[h->next_ticket % psm_handle::SLOTS];
+  if (s.ticket >= 0)
+    return fail(h, PSM_ERR_STATE, "submission ring full: psm_wait_grid the oldest ticket first (PSM_RING_SLOTS in flight)");
+  const size_t npix = (size_t)h->Ny * h->Nx;
+  const size_t gin = (size_t)n_cases * npix * h->cfg.c_in * sizeof(float);
+  const size_t gout = (size_t)n_cases * npix * h->cfg.c_out * sizeof(float);
+  memcpy(s.h_in, grid, gin);                                   // caller's buffer is free on return
+  HIPCHK(h, hipMemcpyAsync(s.d_in, s.h_in, gin, hipMemcpyHostToDevice, h->stream_in));
+  HIPCHK(h, hipEventRecord(s.ev_in, h->stream_in));
+  HIPCHK(h, hipStreamWaitEvent(h->stream, s.ev_in, 0));
+  rc = solve_device(h, s.d_in, n_cases, out_scale, s.d_out, h->stream, nullptr);
+  if (rc) return rc;
+  HIPCHK(h, hipEventRecord(s.ev_done, h->stream));
+  HIPCHK(h, hipStreamWaitEvent(h->stream_out, s.ev_done, 0));
+  HIPCHK(h, hipMemcpyAsync(s.h_out, s.d_out, gout, hipMemcpyDeviceToHost, h->stream_out));
+  HIPCHK(h, hipEventRecord(s.ev_out, h->stream_out));
+  s.ticket = h->next_ticket;
+  s.n_cases = n_cases;
+  *ticket = h->next_ticket++;
+  return PSM_OK;
+}
+
+int psm_wait_grid(psm_handle* h, int64_t ticket, float* fields) {
+  if (!h) return PSM_ERR_ARG;
+  if (!fields) return fail(h, PSM_ERR_ARG, "null buffer");
+  if (ticket < 0) return fail(h, PSM_ERR_ARG, "unknown ticket");
+  psm_handle::Slot& s = h->slot[ticket % psm_handle::SLOTS];
+  if (!s.h_in || s.ticket != ticket) return fail(h, PSM_ERR_ARG, "unknown ticket (never submitted or already waited for)");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipEventSynchronize(s.ev_out));
+  memcpy(fields, s.h_out, (size_t)s.n_cases * h->Ny * h->Nx * h->cfg.c_out * sizeof(float));
+  s.ticket = -1;
   return PSM_OK;
 }
 

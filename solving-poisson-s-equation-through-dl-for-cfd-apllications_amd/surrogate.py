@@ -59,6 +59,7 @@ class GridSurrogate:
         h = C.c_void_p()
         _lib.check(self.lib.psm_create(C.byref(cfg), C.byref(h)))
         self.h = h
+        self._ticket_cases = {}
         try:
             ci, mi, co, mo = _f64(model.comp_in), _f64(model.mean_in), _f64(model.comp_out), _f64(model.mean_out)
             if ci.shape != (model.p_in, model.S ** 2 * model.c_in) or co.shape != (model.p_out, model.S ** 2 * model.c_out):
@@ -115,6 +116,33 @@ class GridSurrogate:
             sc = _f32(np.broadcast_to(out_scale, (n,)))
         self._chk(self.lib.psm_solve_grid(self.h, _p(g, C.c_float), n, _p(sc, C.c_float) if sc is not None else None,
                                           _p(out, C.c_float)))
+        return out
+
+    def submit(self, grid: np.ndarray, out_scale: Optional[Sequence[float]] = None) -> int:
+        """Asynchronous host-buffer solve (psm_submit_grid): returns a ticket; up to PSM_RING_SLOTS (4) in
+        flight, copies of neighbouring tickets overlap the kernels.  `grid` may be reused on return."""
+        g = np.asarray(grid)
+        if g.ndim == 3:
+            g = g[None]
+        if g.ndim != 4 or g.shape[1:3] != (self.ny, self.nx) or g.shape[3] < self.model.c_in:
+            raise ValueError(f"grid must be [n,{self.ny},{self.nx},>={self.model.c_in}]")
+        g = _f32(g[..., :self.model.c_in])
+        n = g.shape[0]
+        sc = _f32(np.broadcast_to(out_scale, (n,))) if out_scale is not None else None
+        t = C.c_int64(-1)
+        self._chk(self.lib.psm_submit_grid(self.h, _p(g, C.c_float), n, _p(sc, C.c_float) if sc is not None else None,
+                                           C.byref(t)))
+        self._ticket_cases[t.value] = n
+        return t.value
+
+    def wait(self, ticket: int) -> np.ndarray:
+        """Field(s) of a ticket returned by :meth:`submit` -> [n,Ny,Nx,c_out] f32 (blocks until it has arrived)."""
+        n = self._ticket_cases.get(ticket)
+        if n is None:
+            raise ValueError("unknown ticket")
+        out = np.empty((n, self.ny, self.nx, self.model.c_out), np.float32)
+        self._chk(self.lib.psm_wait_grid(self.h, ticket, _p(out, C.c_float)))
+        del self._ticket_cases[ticket]
         return out
 
     def solve_device(self, d_grid: int, n_cases: int, d_fields: int, stream: int = 0,

@@ -97,6 +97,33 @@ def test_config2_deltas_sequence():
             assert np.abs(fields - sol.fields).max() <= 1e-4 * np.abs(sol.fields).max()
 
 
+def test_submission_ring_equals_synchronous_solves():
+    """psm_submit_grid / psm_wait_grid (pinned ring, copies overlapping the kernels): the same fields,
+    bit for bit, as the synchronous host entry on a sequence of different time steps with per-step
+    out_scale; a full ring is refused, an unknown ticket too."""
+    model = synthetic.make_model("deltas")
+    grids = [synthetic.delta_grid(256, 256, seed=2, step=s).astype(np.float32) for s in range(10)]
+    scales = [0.51 * (1.0 + 0.1 * s) ** 2 for s in range(10)]
+    with GridSurrogate(model, 256, 256) as sur:
+        ref = [sur.solve(g, out_scale=[sc]) for g, sc in zip(grids, scales)]
+        got, pending = [], []
+        for g, sc in zip(grids, scales):
+            if len(pending) == 4:                       # PSM_RING_SLOTS
+                with pytest.raises(_lib.PsmError) as e:
+                    sur.submit(g, out_scale=[sc])
+                assert e.value.code == -2               # PSM_ERR_STATE
+                got.append(sur.wait(pending.pop(0)))
+            buf = g.copy()
+            pending.append(sur.submit(buf, out_scale=[sc]))
+            buf[:] = np.nan                             # the caller's buffer is free on return
+        while pending:
+            got.append(sur.wait(pending.pop(0)))
+        for a, b in zip(got, ref):
+            np.testing.assert_array_equal(a, b)
+        with pytest.raises(ValueError):
+            sur.wait(12345)
+
+
 def test_config3_case_batch_equals_single_cases():
     """BASELINE config 3 (per-GPU shard): 8 random-obstacle cases in one call."""
     model = synthetic.make_model("deltas")

@@ -17,7 +17,7 @@ with psm_amd.GridSurrogate(model,256,256) as sur:
     a=np.median(np.array(acc[10:]),axis=0)
     print("encode  : stage(A loads,B issue,LDS,barrier)=%.2f  mfma+store=%.2f"%(a[0],a[1]))
     print("reduce  : loads+sum=%.2f"%a[8])
-    print("dense   : loads+mfma=%.2f  reduce+store=%.2f"%(a[12],a[13]))
+    print("dense1  : loads+mfma=%.2f  reduce+store=%.2f"%(a[48],a[49]))
     print("decode  : stage=%.2f  mfma=%.2f  store=%.2f"%(a[20],a[21],a[22]))
     print("strips  : loads=%.2f  slots=%.2f"%(a[28],a[29]))
     print("assemble: phase1=%.2f  pre=%.2f  chain=%.2f  post=%.2f  paste=%.2f"%tuple(a[36:41]))
