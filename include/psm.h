@@ -178,6 +178,17 @@ int psm_set_geometry(psm_handle* h, int64_t n_cells, int32_t ny, int32_t nx,
  * Synchronous. */
 int psm_solve(psm_handle* h, const double* cells, int64_t n, int32_t rank, double* p_out);
 
+/* Input features of the pressureSM_Poisson surrogate (pressureSM_Poisson/SM_call.py:588-711): from the
+ * interpolated dimensional grids ux, uy, dux, duy [ny,nx] float64 (zero outside the flow) and the raw
+ * signed-distance image sdfunct [ny,nx] (0 inside solids) to the normalised grid image
+ * grid_out [ny,nx,4] float32 = (arcsinh-smoothed Poisson source term, dUx/U, dUy/U, sdf), each divided by
+ * its max_abs.  np.gradient differences masked at solid neighbours (:602-632), Poisson term (:635),
+ * smart_arcsin_smooth_transform (:22-69, :646), NaN -> 0 (:704), rescale (:707-710).
+ * params[7] = {L (= phi), U (= U_max_norm), k, max_abs_Poisson_term_1, max_abs_delta_Ux,
+ * max_abs_delta_Uy, max_abs_dist}.  Host buffers, synchronous; the result feeds psm_solve_grid of a
+ * deltas-variant handle with c_in = 4. */
+int psm_poisson_features(psm_handle* h, const double* ux, const double* uy, const double* dux, const double* duy,
+                         const double* sdfunct, int32_t ny, int32_t nx, const double* params, float* grid_out);
 /* scipy.ndimage.gaussian_filter(field, sigma=(sigma_y, sigma_x), order=0) as used at
  * SM_call.py:353-363 (sigma (10,10) on the assembled field, (50,50) on the deltaU-change
  * weight) and Eval_dual_Dense_onlycil.py:366-367: mode 'reflect', truncate 4.  Host buffers

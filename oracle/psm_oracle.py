@@ -737,3 +737,58 @@ def integration_center(sdfunct, x_min, x_max, X0_min, delta, row=200):
     xl = np.linspace(x_min, x_max, sdfunct.shape[1])
     solid = sdfunct[row, :] == 0
     return int(((xl[solid].max() + xl[solid].min()) / 2 - X0_min) / delta), int(row)
+
+
+# --------------------------------------------------------------------------------------
+# pressureSM_Poisson input features (Improved_SM/.../pressureSM_Poisson/SM_call.py = SMP)
+# --------------------------------------------------------------------------------------
+def arcsinh_smooth_transform(field, k):
+    """SMP:22-69 (`smart_arcsin_smooth_transform`, scale_output=False): central range
+    [mean-k*std, mean+k*std] of the WHOLE field mapped to [-1,1], linear tails, then arcsinh."""
+    field = np.asarray(field, np.float64)
+    mean, std = np.mean(field), np.std(field)
+    lo, hi = mean - k * std, mean + k * std
+    with np.errstate(all="ignore"):
+        below = -1.0 - (field - lo) / lo                    # SMP:50
+        above = 1.0 + (field - hi) / hi                     # SMP:52
+        mid = 2.0 * (field - lo) / (hi - lo) - 1.0          # SMP:54
+    scaled = np.where(field < lo, below, np.where(field > hi, above, mid))
+    return np.arcsinh(scaled)                               # SMP:60
+
+
+def masked_gradient(grid):
+    """SMP:602-621 followed by SMP:629-632: `np.gradient` (unit spacing), zero wherever the cell
+    or one of its four direct neighbours is NaN.  Returns (d/dy, d/dx)."""
+    g = np.asarray(grid, np.float64)
+    nan = np.isnan(g)
+    bad = nan.copy()
+    bad[1:, :] |= nan[:-1, :]
+    bad[:-1, :] |= nan[1:, :]
+    bad[:, 1:] |= nan[:, :-1]
+    bad[:, :-1] |= nan[:, 1:]
+    with np.errstate(all="ignore"):
+        gy, gx = np.gradient(g)
+    gy[bad] = 0.0
+    gx[bad] = 0.0
+    return gy, gx
+
+
+def poisson_features(ux, uy, dux, duy, sdfunct, L, U, k, max_abs):
+    """SMP:588-711: grid image [Ny,Nx,4] fed to the deltas layout with C_in = 4.
+    ux, uy, dux, duy: interpolated (dimensional) grids, zero outside the flow; sdfunct: raw
+    signed-distance image (0 inside solids); max_abs = (Poisson_term_1, delta_Ux, delta_Uy, dist)."""
+    ux = np.array(ux, np.float64); uy = np.array(uy, np.float64)
+    solid = np.asarray(sdfunct) == 0
+    ux[solid] = np.nan                                       # SMP:624-625
+    uy[solid] = np.nan
+    dUx_dy, dUx_dx = masked_gradient(ux)
+    dUy_dy, dUy_dx = masked_gradient(uy)
+    term = (dUx_dx * dUx_dx + 2 * dUx_dy * dUy_dx + dUy_dy * dUy_dy) * L ** 2 / U ** 2    # SMP:635
+    grid = np.zeros(ux.shape + (4,))
+    grid[..., 0] = arcsinh_smooth_transform(term, k)         # SMP:646, 698
+    grid[..., 1] = np.asarray(dux, np.float64) / U           # SMP:641, 699
+    grid[..., 2] = np.asarray(duy, np.float64) / U
+    grid[..., 3] = np.asarray(sdfunct, np.float64)
+    grid[np.isnan(grid)] = 0                                 # SMP:704
+    grid /= np.asarray(max_abs, np.float64)                  # SMP:707-710
+    return grid, term

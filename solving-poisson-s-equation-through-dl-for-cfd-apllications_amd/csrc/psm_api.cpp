@@ -986,6 +986,42 @@ int psm_gaussian_filter(psm_handle* h, const float* in, int32_t ny, int32_t nx, 
   return PSM_OK;
 }
 
+int psm_poisson_features(psm_handle* h, const double* ux, const double* uy, const double* dux, const double* duy,
+                         const double* sdfunct, int32_t ny, int32_t nx, const double* params, float* grid_out) {
+  if (!h) return PSM_ERR_ARG;
+  if (!ux || !uy || !dux || !duy || !sdfunct || !params || !grid_out) return fail(h, PSM_ERR_ARG, "null argument");
+  if (ny < 2 || nx < 2 || (int64_t)ny * nx > ((int64_t)1 << 26)) return fail(h, PSM_ERR_ARG, "grid must be at least 2x2 (np.gradient)");
+  if (!(params[1] != 0.0)) return fail(h, PSM_ERR_ARG, "U must be non-zero");
+  for (int q = 3; q < 7; ++q)
+    if (!(params[q] != 0.0)) return fail(h, PSM_ERR_ARG, "max_abs scales must be non-zero");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  hipStream_t st = h->stream;
+  const size_t n = (size_t)ny * nx, nwg = (n + 255) / 256;
+  double *d_in = nullptr, *d_term = nullptr, *d_part = nullptr;
+  float* d_grid = nullptr;
+  int rc;
+  if ((rc = dev_alloc(h, &d_in, 5 * n)) || (rc = dev_alloc(h, &d_term, n)) || (rc = dev_alloc(h, &d_part, 2 * nwg)) ||
+      (rc = dev_alloc(h, &d_grid, 4 * n))) {
+    dev_free(d_in); dev_free(d_term); dev_free(d_part); dev_free(d_grid);
+    return rc;
+  }
+  const double* src[5] = {ux, uy, dux, duy, sdfunct};
+  hipError_t e = hipSuccess;
+  for (int q = 0; q < 5 && e == hipSuccess; ++q)
+    e = hipMemcpyAsync(d_in + q * n, src[q], n * sizeof(double), hipMemcpyHostToDevice, st);
+  PsmFeatureArgs fa{};
+  fa.ux = d_in; fa.uy = d_in + n; fa.dux = d_in + 2 * n; fa.duy = d_in + 3 * n; fa.sdf = d_in + 4 * n;
+  fa.term = d_term; fa.partial = d_part; fa.grid = d_grid; fa.ny = ny; fa.nx = nx;
+  fa.L = params[0]; fa.U = params[1]; fa.k = params[2];
+  for (int q = 0; q < 4; ++q) fa.max_abs[q] = params[3 + q];
+  if (e == hipSuccess) e = psm_launch_poisson_features(fa, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(grid_out, d_grid, 4 * n * sizeof(float), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  dev_free(d_in); dev_free(d_term); dev_free(d_part); dev_free(d_grid);
+  if (e != hipSuccess) return fail(h, PSM_ERR_HIP, std::string("poisson features: ") + hipGetErrorString(e));
+  return PSM_OK;
+}
+
 int psm_set_integration(psm_handle* h, int32_t ny, int32_t nx, const double* sdfunct, int32_t cy, int32_t cx, double dx, double dy) {
   if (!h) return PSM_ERR_ARG;
   if (!sdfunct || ny < 2 || nx < 3) return fail(h, PSM_ERR_ARG, "bad integration geometry");

@@ -52,3 +52,15 @@ struct PsmIntegArgs {
   float dx, dy;
 };
 hipError_t psm_launch_integrate(const PsmIntegArgs& a, hipStream_t st);
+
+// ---- pressureSM_Poisson input features (SMP:588-711), see psm_features.hip
+struct PsmFeatureArgs {
+  const double *ux, *uy, *dux, *duy, *sdf;   // [ny][nx] float64 (dimensional grids, zero outside the flow; raw SDF)
+  double* term;                              // [ny][nx] scratch: the Poisson source term
+  double* partial;                           // [2 * workgroups] (sum, sum of squares)
+  float* grid;                               // [ny][nx][4] float32 NHWC
+  int ny, nx;
+  double L, U, k;
+  double max_abs[4];                         // Poisson_term_1, delta_Ux, delta_Uy, dist
+};
+hipError_t psm_launch_poisson_features(const PsmFeatureArgs& a, hipStream_t st);

@@ -178,6 +178,20 @@ class GridSurrogate:
                                                 float(sigma[1]), _p(out, C.c_float)))
         return out
 
+    def poisson_features(self, ux, uy, dux, duy, sdfunct, L, U, k, max_abs) -> np.ndarray:
+        """pressureSM_Poisson input image (SM_call.py:588-711): float64 grids [Ny,Nx] -> grid [Ny,Nx,4] float32."""
+        arrs = [_f64(np.asarray(a)) for a in (ux, uy, dux, duy, sdfunct)]
+        ny, nx = arrs[0].shape
+        if any(a.shape != (ny, nx) for a in arrs):
+            raise ValueError("ux, uy, dux, duy, sdfunct must share one [Ny,Nx] shape")
+        params = _f64(np.array([L, U, k, *max_abs], np.float64))
+        if params.shape != (7,):
+            raise ValueError("max_abs must hold 4 scales")
+        out = np.empty((ny, nx, 4), np.float32)
+        self._chk(self.lib.psm_poisson_features(self.h, *[_p(a, C.c_double) for a in arrs], ny, nx,
+                                                _p(params, C.c_double), _p(out, C.c_float)))
+        return out
+
     def set_integration(self, sdfunct: np.ndarray, center_y: int, center_x: int, dx: float, dy: float):
         """Geometry of the gradP -> p integration (Eval_dual_Dense_onlycil.py:592-628)."""
         sd = _f64(sdfunct)
@@ -322,6 +336,11 @@ class Evaluation:
         sur = self._surrogate(shape_y, shape_x)
         grid = _grid_from_blocks(np.asarray(self.x_array, np.float32), blocks, shape_y, shape_x)
         result = sur.reassemble(grid, np.asarray(array))[..., 0]
+        return self._post_steps(sur, result, apply_filter, deltaU_change_grid, deltaP_prev_grid, apply_deltaU_change_wgt)
+
+    @staticmethod
+    def _post_steps(sur, result, apply_filter, deltaU_change_grid, deltaP_prev_grid, apply_deltaU_change_wgt):
+        """Tail of ``assemble_prediction`` (SM_call.py:352-363): optional Gaussian filter and deltaU-change weighting."""
         filter_tuple = (10, 10)                                   # SM_call.py:353
         if apply_filter:
             result = sur.gaussian_filter(result, filter_tuple)
@@ -331,6 +350,46 @@ class Evaluation:
             change_in_deltap = (result - np.asarray(deltaP_prev_grid, np.float32)) * w
             change_in_deltap = sur.gaussian_filter(change_in_deltap, filter_tuple)
         return result, change_in_deltap
+
+
+class EvaluationPoisson(Evaluation):
+    """``pressureSM_Poisson.SM_call.Evaluation`` (pressureSM_Poisson/SM_call.py:71-118): the deltas layout fed with
+    four channels (arcsinh-smoothed Poisson source term, dUx, dUy, SDF; mask = channel 3).
+
+    ``max_abs`` = (max_abs_Poisson_term_1, max_abs_delta_Ux, max_abs_delta_Uy, max_abs_dist, max_abs_delta_p),
+    the constants the reference reads from its ``maxs`` file."""
+    variant = "deltas"
+
+    def __init__(self, delta, shape, overlap, var_p, var_in, dataset_path, model_path, max_num_PC,
+                 standardization_method, k, phis_fn, model: SurrogateModel = None, device: int = 0,
+                 max_abs=(1.0, 1.0, 1.0, 1.0, 1.0)):
+        super().__init__(delta, shape, overlap, var_p, var_in, dataset_path, model_path, max_num_PC,
+                         standardization_method, model, device)
+        if model.c_in != 4 or model.sdf_ch != 3:
+            raise ValueError("the Poisson surrogate takes 4 input channels with the SDF in channel 3")
+        self.k, self.phis_fn = k, phis_fn
+        (self.max_abs_Poisson_term_1, self.max_abs_delta_Ux, self.max_abs_delta_Uy, self.max_abs_dist,
+         self.max_abs_delta_p) = [float(v) for v in max_abs]
+
+    def build_features(self, ux_grid, uy_grid, delta_ux_grid, delta_uy_grid, sdfunct, phi, U_max_norm) -> np.ndarray:
+        """SM_call.py:588-711 (after the interpolation to the grid): -> grid [Ny,Nx,4] float32."""
+        ny, nx = np.shape(ux_grid)
+        sur = self._surrogate(ny, nx)
+        return sur.poisson_features(ux_grid, uy_grid, delta_ux_grid, delta_uy_grid, sdfunct, phi, U_max_norm, self.k,
+                                    (self.max_abs_Poisson_term_1, self.max_abs_delta_Ux, self.max_abs_delta_Uy,
+                                     self.max_abs_dist))
+
+    def timeStep_grid(self, ux_grid, uy_grid, delta_ux_grid, delta_uy_grid, sdfunct, phi, U_max_norm,
+                      deltaU_change_grid=None, deltaP_prev_grid=None, apply_filter=False,
+                      apply_deltaU_change_wgt=True) -> np.ndarray:
+        """Grid-native body of ``timeStep`` (SM_call.py:588-848): features, surrogate, assembly, post-steps
+        -> field_deltap [Ny,Nx] (``deltaP_prev_grid + change_in_deltap`` with the weighting, :843-848)."""
+        grid = self.build_features(ux_grid, uy_grid, delta_ux_grid, delta_uy_grid, sdfunct, phi, U_max_norm)
+        sur = self._surrogate(grid.shape[0], grid.shape[1])
+        res = sur.solve(grid, out_scale=[self.max_abs_delta_p * U_max_norm ** 2])[0, :, :, 0]     # :816
+        wgt = apply_deltaU_change_wgt and deltaU_change_grid is not None and deltaP_prev_grid is not None
+        res, change = self._post_steps(sur, res, apply_filter, deltaU_change_grid, deltaP_prev_grid, wgt)
+        return np.asarray(deltaP_prev_grid, np.float32) + change if wgt else res
 
 
 class EvaluationGradP(Evaluation):

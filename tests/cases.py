@@ -107,3 +107,19 @@ def build_integration_case():
     gradP = np.stack([gx, gy], -1)
     gradP[sdfunct == 0] = 0.0
     return dict(gradP=gradP, sdfunct=sdfunct, X0=X0, delta=delta, min_x=x_min, max_x=x_max, min_y=y_min, max_y=y_max)
+
+
+def build_poisson_case():
+    """pressureSM_Poisson feature builder (SM_call.py:588-711): dimensional velocity / delta-velocity grids
+    (zero outside the flow), raw SDF image, scales."""
+    Ny, Nx = 160, 200
+    g = synthetic.channel_grid(Ny, Nx, seed=51, obstacle="circle")
+    d = synthetic.delta_grid(Ny, Nx, seed=52, step=3)
+    sdf = g[..., 2] * 0.3
+    ux, uy = 1.3 * g[..., 0], 1.3 * g[..., 1]
+    dux, duy = 0.05 * d[..., 0], 0.05 * d[..., 1]
+    for a in (ux, uy, dux, duy):
+        a[sdf == 0] = 0.0
+    U = float(np.sqrt(ux ** 2 + uy ** 2).max())
+    return dict(ux=ux, uy=uy, dux=dux, duy=duy, sdfunct=sdf, L=0.25, U=U, k=0.5,
+                max_abs=(2.7, 0.031, 0.027, 0.29))

@@ -270,6 +270,36 @@ def run_init_helpers(array, delta):
 # --------------------------------------------------------------------------
 # cases (inputs are regenerated from these specs by tests/cases.py)
 # --------------------------------------------------------------------------
+def run_poisson_features(c):
+    """pressureSM_Poisson/SM_call.py timeStep: the nested gradient function, the NaN masking, the Poisson
+    source term, `smart_arcsin_smooth_transform` and the grid fill / rescale (SMP:602-646, 696-710)."""
+    SMP = f"{REF}/Improved_SM/deltaU_to_deltaP/source/pressureSM_Poisson/SM_call.py"
+    tree = _tree(SMP)
+    glb = {"np": np}
+    fn = _find_fn(tree, "smart_arcsin_smooth_transform")
+    mod = ast.Module(body=[fn], type_ignores=[]); ast.fix_missing_locations(mod)
+    exec(compile(mod, SMP, "exec"), glb)
+    body = _find_fn(tree, "timeStep", "Evaluation").body
+    drop = DROP + ("axes[", "im1 =", "im2 =", "import matplotlib", "(fig, axes)", "fig, axes")
+    def sl(first, last):
+        i0 = next(i for i, st in enumerate(body) if _src(st).startswith(first))
+        i1 = next(i for i, st in enumerate(body) if i >= i0 and _src(st).startswith(last))
+        return [st for st in body[i0:i1 + 1] if not any(d in _src(st) for d in drop)]
+    Ny, Nx = c["ux"].shape
+    me = types.SimpleNamespace(sdfunct=c["sdfunct"][:, :, None].copy(), k=c["k"], grid_shape_y=Ny, grid_shape_x=Nx,
+                               max_abs_Poisson_term_1=c["max_abs"][0], max_abs_delta_Ux=c["max_abs"][1],
+                               max_abs_delta_Uy=c["max_abs"][2], max_abs_dist=c["max_abs"][3], max_abs_delta_p=1.0)
+    loc = {"self": me, "ux_grid": c["ux"].copy(), "uy_grid": c["uy"].copy(), "delta_ux_grid": c["dux"].copy(),
+           "delta_uy_grid": c["duy"].copy(), "L": c["L"], "U": c["U"],
+           "delta_p_grid": np.zeros((Ny, Nx)), "p_grid": np.zeros((Ny, Nx))}
+    with np.errstate(all="ignore"):
+        _run(sl("def gradient_with_nan_direct_neighbors", "Poisson_term_1_f = smart_arcsin_smooth_transform"), glb, loc, SMP)
+        _run(sl("grid = np.zeros(shape=(1, self.grid_shape_y, self.grid_shape_x, 6))", "grid[0, :, :, 4] /= self.max_abs_delta_p"), glb, loc, SMP)
+    term = np.asarray(loc["Poisson_term_1"], np.float64)
+    return dict(grid=np.asarray(loc["grid"][0, :, :, :4], np.float32), term_crop=term[48:112, 40:104].copy(),
+                term_sum=np.float64(term.sum()), term_abs_sum=np.float64(np.abs(term).sum()))
+
+
 def main():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import cases
@@ -331,6 +361,11 @@ def main():
     np.savez_compressed(os.path.join(HERE, "gradp_integration_320x384.npz"), p=np.asarray(loc["result"], np.float32),
                         center_p_x=np.int64(loc["center_p_x"]), center_p_y=np.int64(loc["center_p_y"]))
     print("gradp_integration: center", int(loc["center_p_x"]), int(loc["center_p_y"]), "|p|max=%.4f" % np.abs(loc["result"]).max())
+
+    # ---- pressureSM_Poisson feature builder
+    out = run_poisson_features(cases.build_poisson_case())
+    np.savez_compressed(os.path.join(HERE, "poisson_features_160x200.npz"), **out)
+    print("poisson_features: |grid|max per channel", np.abs(out["grid"]).max(axis=(0, 1)))
 
     for name in cases.GOLDEN_CASES:
         grid, model = cases.build(name)
