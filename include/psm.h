@@ -161,12 +161,13 @@ int psm_reassemble(psm_handle* h, const float* grid, const float* block_pred, fl
  *                              reference: np.zeros in SMD:161, np.empty in PM:225) and are
  *                              scattered in order like the NumPy fancy assignment (last wins)
  *   sdfunct         [ny*nx]    signed-distance image (PM:227,240)
- *   vtx_g2m/wts_g2m [n_cells,3] grid -> mesh (PM:211)
+ *   vtx_g2m/wts_g2m [n_cells,3] grid -> mesh (PM:211); both NULL for a caller that only goes mesh -> grid
+ *                              (the offline evaluators, SM_call.py:89-180): psm_solve is then refused
  *   maxs            [4]        max_abs_Ux, max_abs_Uy, max_abs_dist, max_abs_p (PM:109)
  *   normalise_sdf   0: SDF channel as is (PM:292), 1: divided by max_abs_dist (SMD:443)
  *   fill_input      0: interpolate (PM:280), 1: interpolate_fill (SMD:421-423)
  *   wall_threshold  cells whose interpolated SDF is below it keep the previous p (0.05, PM:494)
- * It also fixes the grid shape (psm_plan_grid).  Requires c_in == 3, c_out == 1. */
+ * It also fixes the grid shape (psm_plan_grid).  psm_solve additionally requires c_in == 3, c_out == 1. */
 int psm_set_geometry(psm_handle* h, int64_t n_cells, int32_t ny, int32_t nx,
                      const int32_t* vtx_m2g, const double* wts_m2g, const int32_t* indices,
                      const double* sdfunct, const int32_t* vtx_g2m, const double* wts_g2m,
@@ -177,6 +178,13 @@ int psm_set_geometry(psm_handle* h, int64_t n_cells, int32_t ny, int32_t nx,
  * accepted for signature compatibility (the MPI funnel, PM:258/511, stays with the caller).
  * Synchronous. */
 int psm_solve(psm_handle* h, const double* cells, int64_t n, int32_t rank, double* p_out);
+/* Generic mesh -> grid step of the evaluators (interpolate_fill + scatter, SM_call.py:419-436,
+ * pressureSM_Poisson/SM_call.py:580-600): values [n_cells, k] float64 row-major (k columns of cell
+ * data) -> grid_out [ny*nx, k] float64 holding, per image cell, the interpolated value of the grid
+ * point NumPy's `grid[...][tuple(indices.T)] = v` leaves there (last writer), 0 where nothing is
+ * written; fill != 0: NaN where a barycentric weight is negative (utils.interpolate_fill).  Uses the
+ * tables of psm_set_geometry.  Host buffers, synchronous. */
+int psm_mesh_to_grid(psm_handle* h, const double* values, int64_t n_cells, int32_t k, int32_t fill, double* grid_out);
 
 /* Input features of the pressureSM_Poisson surrogate (pressureSM_Poisson/SM_call.py:588-711): from the
  * interpolated dimensional grids ux, uy, dux, duy [ny,nx] float64 (zero outside the flow) and the raw

@@ -792,3 +792,38 @@ def poisson_features(ux, uy, dux, duy, sdfunct, L, U, k, max_abs):
     grid[np.isnan(grid)] = 0                                 # SMP:704
     grid /= np.asarray(max_abs, np.float64)                  # SMP:707-710
     return grid, term
+
+
+# --------------------------------------------------------------------------------------
+# dataset-driven evaluator front end (pressureSM_deltas/SM_call.py:381-451)
+# --------------------------------------------------------------------------------------
+def evaluator_grid_deltas(cells, vert, weights, indices, sdfunct, maxs):
+    """SMD:381-451: one un-padded dataset frame cells[N,11] (0 Ux, 1 Uy, 2 p, 3 Cx, 4 Cy, 5-6 delta_U,
+    7 delta_p, 8-9 delta_U_prev, 10 delta_p_prev) -> (grid[Ny,Nx,5] normalised, deltaU_change_grid,
+    deltaP_prev_grid, U_max_norm), or None for an irrelevant time step (SMD:413-421)."""
+    d = np.asarray(cells)        # dtype kept: the dataset is float32 and the reference normalises in float32
+    Ux, Uy, p = d[:, 0:1], d[:, 1:2], d[:, 2:3]
+    delta_U, delta_p = d[:, 5:7], d[:, 7:8]
+    delta_U_prev, delta_p_prev = d[:, 8:10], d[:, 10:11]
+    changed = np.abs(delta_U - delta_U_prev).sum(axis=-1)
+    changed = changed / changed.max()
+    U = np.max(np.sqrt(np.square(Ux) + np.square(Uy)))
+    dU = np.max(np.sqrt(np.square(delta_U[:, 0:1]) + np.square(delta_U[:, 1:2])))
+    if (dU / U) < 1e-4:
+        return None
+    ny, nx = sdfunct.shape[:2]
+    idx = tuple(np.asarray(indices).T)
+
+    def to_grid(v):
+        g = np.zeros((ny, nx))
+        g[idx] = interpolate_fill(np.asarray(v).reshape(-1), vert, weights)     # NumPy order: last write wins
+        return g
+    grid = np.zeros((ny, nx, 5))
+    grid[..., 0] = to_grid(delta_U[:, 0] / U)
+    grid[..., 1] = to_grid(delta_U[:, 1] / U)
+    grid[..., 2] = np.asarray(sdfunct).reshape(ny, nx)
+    grid[..., 3] = to_grid(delta_p / pow(U, 2.0))
+    grid[..., 4] = to_grid(p)
+    grid[np.isnan(grid)] = 0
+    grid[..., 0] /= maxs[0]; grid[..., 1] /= maxs[1]; grid[..., 2] /= maxs[2]; grid[..., 3] /= maxs[3]
+    return grid, to_grid(changed), to_grid(delta_p_prev), float(U)

@@ -62,7 +62,7 @@ struct psm_handle {
   float *d_offs = nullptr, *d_shift = nullptr;
   unsigned long long* d_stamps = nullptr;
   // mesh-side tables (psm_set_geometry)
-  bool have_geometry = false;
+  bool have_geometry = false, have_g2m = false;
   int64_t n_cells = 0;
   int32_t *d_vtx_m2g = nullptr, *d_src_of_cell = nullptr, *d_vtx_g2m = nullptr, *d_cell_of_point = nullptr;
   double *d_wts_m2g = nullptr, *d_sdf = nullptr, *d_wts_g2m = nullptr, *d_cells = nullptr, *d_p = nullptr, *d_umax = nullptr;
@@ -867,9 +867,10 @@ int psm_set_geometry(psm_handle* h, int64_t n_cells, int32_t ny, int32_t nx, con
                      const int32_t* indices, const double* sdfunct, const int32_t* vtx_g2m, const double* wts_g2m,
                      const double* maxs, int32_t normalise_sdf, int32_t fill_input, double wall_threshold) {
   if (!h) return PSM_ERR_ARG;
-  if (!vtx_m2g || !wts_m2g || !indices || !sdfunct || !vtx_g2m || !wts_g2m || !maxs) return fail(h, PSM_ERR_ARG, "null geometry table");
+  if (!vtx_m2g || !wts_m2g || !indices || !sdfunct || !maxs) return fail(h, PSM_ERR_ARG, "null geometry table");
+  if ((vtx_g2m == nullptr) != (wts_g2m == nullptr)) return fail(h, PSM_ERR_ARG, "vtx_g2m and wts_g2m go together");
+  const bool g2m = vtx_g2m != nullptr;
   if (n_cells < 1 || n_cells > (int64_t)1 << 30) return fail(h, PSM_ERR_ARG, "bad cell count");
-  if (h->cfg.c_in != 3 || h->cfg.c_out != 1) return fail(h, PSM_ERR_UNSUPPORTED, "the mesh entry needs c_in == 3 and c_out == 1 (python_module.py:288-292)");
   const int64_t ng = (int64_t)ny * nx;
   for (int64_t t = 0; t < ng; ++t) {
     for (int j = 0; j < 3; ++j)
@@ -877,7 +878,7 @@ int psm_set_geometry(psm_handle* h, int64_t n_cells, int32_t ny, int32_t nx, con
     if (indices[t * 2] < 0 || indices[t * 2] >= ny || indices[t * 2 + 1] < 0 || indices[t * 2 + 1] >= nx)
       return fail(h, PSM_ERR_ARG, "indices outside the grid");
   }
-  for (int64_t n = 0; n < n_cells; ++n)
+  for (int64_t n = 0; g2m && n < n_cells; ++n)
     for (int j = 0; j < 3; ++j)
       if (vtx_g2m[n * 3 + j] < 0 || vtx_g2m[n * 3 + j] >= ng) return fail(h, PSM_ERR_ARG, "grid->mesh vertex index out of range");
   int rc = psm_plan_grid(h, ny, nx);
@@ -896,13 +897,16 @@ int psm_set_geometry(psm_handle* h, int64_t n_cells, int32_t ny, int32_t nx, con
   }
   // sdf_mesh = interpolate_fill(sdfunct.flatten(), vert_NPtoOF, weights_NPtoOF) < threshold  (PM:492-494)
   std::vector<uint8_t> nw(n_cells, 0);
-  for (int64_t n = 0; n < n_cells; ++n) {
+  for (int64_t n = 0; g2m && n < n_cells; ++n) {
     double acc = 0.0; bool neg = false;
     for (int j = 0; j < 3; ++j) { acc += sdfunct[vtx_g2m[n * 3 + j]] * wts_g2m[n * 3 + j]; neg = neg || wts_g2m[n * 3 + j] < 0.0; }
     nw[n] = (!neg && acc < wall_threshold) ? 1 : 0;     // NaN (fill) compares false
   }
-  std::vector<int32_t> v1(vtx_m2g, vtx_m2g + ng * 3), v2(vtx_g2m, vtx_g2m + n_cells * 3);
-  std::vector<double> w1(wts_m2g, wts_m2g + ng * 3), w2(wts_g2m, wts_g2m + n_cells * 3), sd(sdfunct, sdfunct + ng);
+  std::vector<int32_t> v1(vtx_m2g, vtx_m2g + ng * 3), v2;
+  std::vector<double> w1(wts_m2g, wts_m2g + ng * 3), w2, sd(sdfunct, sdfunct + ng);
+  if (g2m) { v2.assign(vtx_g2m, vtx_g2m + n_cells * 3); w2.assign(wts_g2m, wts_g2m + n_cells * 3); }
+  else { v2.assign((size_t)n_cells * 3, 0); w2.assign((size_t)n_cells * 3, 0.0); }
+  h->have_g2m = g2m;
   if ((rc = dev_upload(h, &h->d_vtx_m2g, v1))) return rc;
   if ((rc = dev_upload(h, &h->d_wts_m2g, w1))) return rc;
   if ((rc = dev_upload(h, &h->d_src_of_cell, src))) return rc;
@@ -924,6 +928,8 @@ int psm_solve(psm_handle* h, const double* cells, int64_t n, int32_t rank, doubl
   (void)rank;
   if (!h) return PSM_ERR_ARG;
   if (!h->have_geometry) return fail(h, PSM_ERR_STATE, "psm_set_geometry has not been called");
+  if (h->cfg.c_in != 3 || h->cfg.c_out != 1) return fail(h, PSM_ERR_UNSUPPORTED, "the mesh entry needs c_in == 3 and c_out == 1 (python_module.py:288-292)");
+  if (!h->have_g2m) return fail(h, PSM_ERR_STATE, "psm_set_geometry was called without the grid->mesh tables");
   if (!cells || !p_out) return fail(h, PSM_ERR_ARG, "null buffer");
   if (n != h->n_cells) return fail(h, PSM_ERR_ARG, "cell count differs from the geometry");
   HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -983,6 +989,27 @@ int psm_gaussian_filter(psm_handle* h, const float* in, int32_t ny, int32_t nx, 
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   dev_free(d_a); dev_free(d_b); dev_free(d_w);
   if (e != hipSuccess) return fail(h, PSM_ERR_HIP, std::string("gaussian filter: ") + hipGetErrorString(e));
+  return PSM_OK;
+}
+
+int psm_mesh_to_grid(psm_handle* h, const double* values, int64_t n, int32_t k, int32_t fill, double* grid_out) {
+  if (!h) return PSM_ERR_ARG;
+  if (!h->have_geometry) return fail(h, PSM_ERR_STATE, "psm_set_geometry has not been called");
+  if (!values || !grid_out) return fail(h, PSM_ERR_ARG, "null buffer");
+  if (n != h->n_cells) return fail(h, PSM_ERR_ARG, "cell count differs from the geometry");
+  if (k < 1 || k > 16) return fail(h, PSM_ERR_ARG, "1..16 columns");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  hipStream_t st = h->stream;
+  const size_t ng = (size_t)h->Ny * h->Nx;
+  double *d_v = nullptr, *d_o = nullptr;
+  int rc;
+  if ((rc = dev_alloc(h, &d_v, (size_t)n * k)) || (rc = dev_alloc(h, &d_o, ng * k))) { dev_free(d_v); dev_free(d_o); return rc; }
+  hipError_t e = hipMemcpyAsync(d_v, values, (size_t)n * k * sizeof(double), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = psm_launch_interp_to_grid(d_v, k, h->d_vtx_m2g, h->d_wts_m2g, h->d_src_of_cell, fill, d_o, (int64_t)ng, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(grid_out, d_o, ng * k * sizeof(double), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  dev_free(d_v); dev_free(d_o);
+  if (e != hipSuccess) return fail(h, PSM_ERR_HIP, std::string("mesh_to_grid: ") + hipGetErrorString(e));
   return PSM_OK;
 }
 

@@ -14,20 +14,28 @@
 namespace {
 constexpr int FT = 256;
 
-__device__ __forceinline__ double grad_term(const double* __restrict__ ux, const double* __restrict__ uy,
-                                            const double* __restrict__ sdf, int y, int x, int ny, int nx, double scale) {
-  const int64_t o = (int64_t)y * nx + x;
-  const bool bad = sdf[o] == 0.0 || (y > 0 && sdf[o - nx] == 0.0) || (y < ny - 1 && sdf[o + nx] == 0.0) ||
-                   (x > 0 && sdf[o - 1] == 0.0) || (x < nx - 1 && sdf[o + 1] == 0.0);
-  if (bad) return 0.0;
-  // np.gradient: central (f[i+1]-f[i-1])/2 inside, first-order one-sided on the border
+// d/dy and d/dx of one field at (y, x) like SMP:602-632: np.gradient (central inside, first-order
+// one-sided on the border), both zero when the cell or a direct neighbour is NaN -- a cell is NaN
+// when it is solid (sdfunct == 0, SMP:624-625) or already NaN in the interpolated field.
+__device__ __forceinline__ void masked_grad(const double* __restrict__ u, const double* __restrict__ sdf, int y, int x,
+                                            int ny, int nx, double& d_dy, double& d_dx) {
+  auto nanat = [&](int yy, int xx) { const int64_t o = (int64_t)yy * nx + xx; const double v = u[o]; return sdf[o] == 0.0 || v != v; };
+  const bool bad = nanat(y, x) || (y > 0 && nanat(y - 1, x)) || (y < ny - 1 && nanat(y + 1, x)) ||
+                   (x > 0 && nanat(y, x - 1)) || (x < nx - 1 && nanat(y, x + 1));
+  d_dy = 0.0; d_dx = 0.0;
+  if (bad) return;
   const int ym = y > 0 ? y - 1 : y, yp = y < ny - 1 ? y + 1 : y;
   const int xm = x > 0 ? x - 1 : x, xp = x < nx - 1 ? x + 1 : x;
   const double hy = (y > 0 && y < ny - 1) ? 2.0 : 1.0, hx = (x > 0 && x < nx - 1) ? 2.0 : 1.0;
-  const double dUx_dy = (ux[(int64_t)yp * nx + x] - ux[(int64_t)ym * nx + x]) / hy;
-  const double dUx_dx = (ux[(int64_t)y * nx + xp] - ux[(int64_t)y * nx + xm]) / hx;
-  const double dUy_dy = (uy[(int64_t)yp * nx + x] - uy[(int64_t)ym * nx + x]) / hy;
-  const double dUy_dx = (uy[(int64_t)y * nx + xp] - uy[(int64_t)y * nx + xm]) / hx;
+  d_dy = (u[(int64_t)yp * nx + x] - u[(int64_t)ym * nx + x]) / hy;
+  d_dx = (u[(int64_t)y * nx + xp] - u[(int64_t)y * nx + xm]) / hx;
+}
+
+__device__ __forceinline__ double grad_term(const double* __restrict__ ux, const double* __restrict__ uy,
+                                            const double* __restrict__ sdf, int y, int x, int ny, int nx, double scale) {
+  double dUx_dy, dUx_dx, dUy_dy, dUy_dx;
+  masked_grad(ux, sdf, y, x, ny, nx, dUx_dy, dUx_dx);
+  masked_grad(uy, sdf, y, x, ny, nx, dUy_dy, dUy_dx);
   return (dUx_dx * dUx_dx + 2 * dUx_dy * dUy_dx + dUy_dy * dUy_dy) * scale;
 }
 

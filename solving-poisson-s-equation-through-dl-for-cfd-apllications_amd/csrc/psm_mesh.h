@@ -34,6 +34,8 @@ struct PsmToMeshArgs {
 hipError_t psm_launch_umax(const double* cells, int64_t n, double* umax, hipStream_t st);
 hipError_t psm_launch_to_grid(const PsmToGridArgs& a, hipStream_t st);
 hipError_t psm_launch_to_mesh(const PsmToMeshArgs& a, hipStream_t st);
+hipError_t psm_launch_interp_to_grid(const double* values, int k, const int32_t* vtx, const double* wts, const int32_t* src_of_cell,
+                                     int fill, double* out, int64_t n_grid, hipStream_t st);
 // one pass of the separable Gaussian filter (axis 0 = rows direction, 1 = columns)
 hipError_t psm_launch_gauss1d(const float* in, float* out, int ny, int nx, int axis, int radius, const float* wts, hipStream_t st);
 

@@ -92,6 +92,36 @@ hipError_t psm_launch_to_grid(const PsmToGridArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(psm_to_grid_kernel, dim3((unsigned)((a.n_grid + 255) / 256)), dim3(256), 0, st, a);
   return hipGetLastError();
 }
+// k columns of mesh values -> grid image, float64: out[cell][c] = interpolate(_fill)(values[:, c]) of the
+// grid point that NumPy's fancy assignment leaves in that cell (last writer), 0 for cells never written
+// (np.zeros base image); NaNs of interpolate_fill are kept (the caller's `grid[np.isnan(grid)] = 0`).
+__global__ __launch_bounds__(256) void psm_interp_to_grid_kernel(const double* values, int k, const int32_t* vtx, const double* wts,
+                                                                 const int32_t* src_of_cell, int fill, double* out, int64_t n_grid) {
+  const int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (cell >= n_grid) return;
+  const int src = src_of_cell[cell];
+  if (src < 0) {
+    for (int c = 0; c < k; ++c) out[cell * k + c] = 0.0;
+    return;
+  }
+  const int32_t* v = vtx + (int64_t)src * 3;
+  const double* w = wts + (int64_t)src * 3;
+  const bool neg = (w[0] < 0.0) || (w[1] < 0.0) || (w[2] < 0.0);
+  for (int c = 0; c < k; ++c) {
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) s += values[(int64_t)v[j] * k + c] * w[j];      // np.einsum('nj,nj->n', take(values, vtx), wts)
+    out[cell * k + c] = (fill && neg) ? NAN : s;
+  }
+}
+
+hipError_t psm_launch_interp_to_grid(const double* values, int k, const int32_t* vtx, const double* wts, const int32_t* src_of_cell,
+                                     int fill, double* out, int64_t n_grid, hipStream_t st) {
+  hipLaunchKernelGGL(psm_interp_to_grid_kernel, dim3((unsigned)((n_grid + 255) / 256)), dim3(256), 0, st, values, k, vtx, wts,
+                     src_of_cell, fill, out, n_grid);
+  return hipGetLastError();
+}
+
 hipError_t psm_launch_to_mesh(const PsmToMeshArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(psm_to_mesh_kernel, dim3((unsigned)((a.n_cells + 255) / 256)), dim3(256), 0, st, a);
   return hipGetLastError();

@@ -9,9 +9,20 @@
   reader for exactly that subset; anything else raises ``H5FormatError``.
 * ``maxs`` / ``maxs_PCA`` text files (python_module.py:106-110, SM_call.py:70-72).
 * ``mean_std.npz`` / ``min_max_values.npz`` scalers (utils.py:299,313).
+* The padded simulation dataset (``sim_data[sim, t, max_cells, C]``, ``top_bound`` / ``obst_bound``
+  ``[sim, t, max_points, 2]``, float32, contiguous, pad value -100.0; written by
+  data_generation.py:64-74 with ``create_dataset(name, shape, np.float32)``, read by
+  utils.read_dataset, utils.py:57-71): memory-mapped, one frame copied per request.
+* PCA artefacts: the reference pickles scikit-learn / dask-ml ``IncrementalPCA`` objects
+  (``ipca_input.pkl``, ``ipca_p.pkl``; SM_call.py:81-82); ``load_pca`` reads such a pickle (needs
+  scikit-learn importable, as the reference does) or the dependency-free ``.npz`` export
+  (``components_``, ``mean_``, ``explained_variance_ratio_``) written by ``save_pca_npz``.
 """
 from __future__ import annotations
 
+import mmap
+import os
+import pickle
 import re
 import struct
 from typing import Dict, List, Tuple
@@ -86,8 +97,8 @@ class _H5:
         return self.u64(heap_addr + 8 + 8 + 8)
 
     def _cstr(self, o) -> str:
-        e = self.b.index(b"\0", o)
-        return self.b[o:e].decode("ascii")
+        e = self.b.find(b"\0", o)
+        return bytes(self.b[o:e]).decode("ascii")
 
     def _group_tables(self, hdr_addr):
         """B-tree / heap addresses of an old-style group from its symbol-table message."""
@@ -119,7 +130,7 @@ class _H5:
         walk(btree)
         return names
 
-    def dataset(self, hdr_addr) -> np.ndarray:
+    def dataset(self, hdr_addr, copy: bool = True) -> np.ndarray:
         shape = dtype = None
         data_addr = data_size = None
         for mtype, body, _ in self.messages(hdr_addr):
@@ -156,8 +167,10 @@ class _H5:
         if shape is None or dtype is None or data_addr is None or data_addr == _UNDEF:
             raise H5FormatError("not a plain numeric contiguous dataset")
         count = int(np.prod(shape)) if shape else 1
+        if self.base + data_addr + count * dtype.itemsize > len(self.b):
+            raise H5FormatError("dataset extends past the end of the file")
         a = np.frombuffer(self.b, dtype=dtype, count=count, offset=self.base + data_addr)
-        return a.reshape(shape).copy()
+        return a.reshape(shape).copy() if copy else a.reshape(shape)
 
     def walk(self, entry=None, prefix=""):
         """Yield (path, symbol entry) for every leaf that is not a group."""
@@ -247,3 +260,123 @@ def select_num_pc(explained_variance_ratio: np.ndarray, var: float, max_num_pc: 
     if max_num_pc is None:
         return k
     return k if (k > 1 and k <= max_num_pc) else int(max_num_pc)
+
+
+# --------------------------------------------------------------------------
+# padded simulation dataset (utils.read_dataset, utils.py:57-71)
+# --------------------------------------------------------------------------
+PAD_VALUE = -100.0
+
+
+def first_index(array, item) -> int:
+    """utils.index (utils.py:94-104): index of the first element equal to ``item``.  The reference
+    returns None when there is none (and then fails on ``[0]``); here: ``len(array)`` (no padding)."""
+    hit = np.flatnonzero(np.asarray(array) == item)
+    return int(hit[0]) if hit.size else int(np.shape(array)[0])
+
+
+class PaddedDataset:
+    """Memory-mapped view of the reference's HDF5 dataset file.
+
+    Column order of ``sim_data`` (SM_call.py:386-402): 0 Ux, 1 Uy, 2 p, 3 Cx, 4 Cy, 5-6 delta_U,
+    7 delta_p, 8-9 delta_U_prev, 10 delta_p_prev (U_to_gradP / Chapter 4 files carry fewer columns)."""
+
+    def __init__(self, path: str):
+        self.path = path
+        self._f = open(path, "rb")
+        try:
+            self._mm = mmap.mmap(self._f.fileno(), 0, access=mmap.ACCESS_READ)
+        except (ValueError, OSError):
+            self._f.close()
+            raise H5FormatError("cannot map the dataset file")
+        h = _H5(self._mm)
+        self._views = {}
+        for p, e in h.walk():
+            try:
+                self._views[p.lstrip("/")] = h.dataset(e["hdr"], copy=False)
+            except H5FormatError:
+                continue
+        for need in ("sim_data", "top_bound", "obst_bound"):
+            if need not in self._views:
+                self.close()
+                raise H5FormatError(f"dataset {need!r} not found (or not contiguous float data)")
+
+    def __getitem__(self, name):
+        return self._views[name]
+
+    @property
+    def shape(self):
+        return self._views["sim_data"].shape
+
+    def read(self, sim: int, time: int):
+        """utils.read_dataset(path, sim, time): -> (data[1,1,max_cells,C], top[1,1,m,2], obst[1,1,m,2]) copies."""
+        out = []
+        for name in ("sim_data", "top_bound", "obst_bound"):
+            v = self._views[name]
+            if not (0 <= sim < v.shape[0] and 0 <= time < v.shape[1]):
+                raise IndexError(f"{name}: sim/time ({sim}, {time}) outside {v.shape[:2]}")
+            out.append(np.array(v[sim:sim + 1, time:time + 1, ...]))
+        return tuple(out)
+
+    def close(self):
+        self._views = {}
+        try:
+            self._mm.close()
+        except (BufferError, ValueError):
+            pass                      # a caller still holds a view: the mapping goes with it
+        self._f.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def read_dataset(path: str, sim: int, time: int):
+    """Same call as the reference's ``utils.read_dataset`` (utils.py:57-71)."""
+    with PaddedDataset(path) as d:
+        return d.read(sim, time)
+
+
+# --------------------------------------------------------------------------
+# PCA artefacts
+# --------------------------------------------------------------------------
+class PCAArtifacts:
+    """What the path needs of a fitted (Incremental)PCA: ``transform(X) = (X - mean_) @ components_.T``."""
+
+    def __init__(self, components, mean, explained_variance_ratio):
+        self.components_ = np.ascontiguousarray(components, np.float64)
+        self.mean_ = np.ascontiguousarray(mean, np.float64)
+        self.explained_variance_ratio_ = np.ascontiguousarray(explained_variance_ratio, np.float64)
+        if self.components_.ndim != 2 or self.mean_.shape != (self.components_.shape[1],):
+            raise ValueError("PCA artefact: components_ [P,K] and mean_ [K] expected")
+        if self.explained_variance_ratio_.shape != (self.components_.shape[0],):
+            raise ValueError("PCA artefact: explained_variance_ratio_ [P] expected")
+
+
+def load_pca(path: str) -> PCAArtifacts:
+    """``.npz`` export or the reference's pickle (``pk.load(open("ipca_input.pkl","rb"))``, SM_call.py:81).
+    A whitened PCA is refused: the path assumes the plain projection."""
+    if path.endswith(".npz"):
+        d = np.load(path)
+        return PCAArtifacts(d["components_"], d["mean_"], d["explained_variance_ratio_"])
+    with open(path, "rb") as f:
+        obj = pickle.load(f)          # needs the pickled class importable (scikit-learn / dask-ml), like the reference
+    if getattr(obj, "whiten", False):
+        raise ValueError("whitened PCA objects are not supported")
+    return PCAArtifacts(obj.components_, obj.mean_, obj.explained_variance_ratio_)
+
+
+def save_pca_npz(path: str, pca) -> None:
+    np.savez(path, components_=np.asarray(pca.components_), mean_=np.asarray(pca.mean_),
+             explained_variance_ratio_=np.asarray(pca.explained_variance_ratio_))
+
+
+def find_pca(directory: str, stem: str) -> str:
+    """``<stem>.pkl`` (reference name) or ``<stem>.npz`` in ``directory``."""
+    for ext in (".pkl", ".npz"):
+        p = os.path.join(directory, stem + ext)
+        if os.path.exists(p):
+            return p
+    raise FileNotFoundError(f"{stem}.pkl / {stem}.npz not found in {directory!r}")

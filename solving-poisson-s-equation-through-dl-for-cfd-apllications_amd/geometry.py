@@ -96,3 +96,39 @@ def build_geometry(array, top, obst, delta: float = 5e-3, every: int = 10, round
     sdfunct[ii[ok], jj[ok]] = sdf[ok]
     return GeometryTables(ny, nx, vtx_m2g, np.ascontiguousarray(wts_m2g), indices, sdfunct, vtx_g2m,
                           np.ascontiguousarray(wts_g2m), domain_bool, float(x0), float(y0), delta)
+
+
+def build_geometry_evaluator(points, p_values, top, obst, delta: float, every: int = 5) -> GeometryTables:
+    """``Evaluation.computeOnlyOnce`` (pressureSM_deltas/SM_call.py:89-180): like ``build_geometry`` with the
+    evaluator's differences -- bounds rounded to 3 digits (:103-107), the box test mixes the ``top`` patch with
+    the data bounds (:119-122), every 5th boundary point for the SDF (:139-140), ``p`` decides which grid
+    points are interpolable (:165-169), and there is no grid -> mesh direction."""
+    from scipy.spatial import ConvexHull
+    from scipy.spatial.distance import cdist
+    points = np.asarray(points, np.float64)
+    top, obst = np.asarray(top, np.float64), np.asarray(obst, np.float64)
+    x_min, x_max = round(float(np.min(points[:, 0])), 3), round(float(np.max(points[:, 0])), 3)
+    y_min, y_max = round(float(np.min(points[:, 1])), 3), round(float(np.max(points[:, 1])), 3)
+    X0, Y0 = create_uniform_grid(x_min, x_max, y_min, y_max, delta)
+    xy0 = np.stack([X0, Y0], axis=-1)
+    vtx, wts = interp_weights(points, xy0)
+    max_x, max_y = max(top[:, 0].max(), x_max), min(top[:, 1].max(), y_max)          # SM_call.py:119
+    min_x, min_y = max(top[:, 0].min(), x_min), min(top[:, 1].min(), y_min)          # SM_call.py:120
+    inside_box = (xy0[:, 0] <= max_x) & (xy0[:, 0] >= min_x) & (xy0[:, 1] <= max_y) & (xy0[:, 1] >= min_y)
+    hull = ConvexHull(obst)
+    inside_obst = np.all(xy0 @ hull.equations[:, :2].T + hull.equations[:, 2] < 0.0, axis=1)
+    domain_bool = inside_box & ~inside_obst
+    sdf = np.minimum(cdist(xy0, obst[::every]).min(axis=1), cdist(xy0, top[::every]).min(axis=1)) * domain_bool
+    ny, nx = int(round((y_max - y_min) / delta)), int(round((x_max - x_min) / delta))
+    x0, y0 = np.min(X0), np.min(Y0)
+    p_interp = np.einsum("nj,nj->n", np.take(np.asarray(p_values, np.float64), vtx), wts)
+    p_interp[np.any(wts < 0, axis=1)] = np.nan
+    ok = domain_bool & ~np.isnan(p_interp)
+    jj = np.rint((X0 - x0) / delta).astype(np.int64)
+    ii = np.rint((Y0 - y0) / delta).astype(np.int64)
+    indices = np.zeros((X0.shape[0], 2), np.int32)
+    indices[ok, 0], indices[ok, 1] = ii[ok], jj[ok]
+    sdfunct = np.zeros((ny, nx))
+    sdfunct[ii[ok], jj[ok]] = sdf[ok]
+    return GeometryTables(ny, nx, vtx, np.ascontiguousarray(wts), indices, sdfunct, None, None, domain_bool,
+                          float(x0), float(y0), delta)

@@ -19,6 +19,7 @@ over.  Error behaviour follows the reference where it has one (``ValueError(
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import numpy as np
@@ -289,6 +290,40 @@ def _grid_from_blocks(x_array: np.ndarray, blocks: np.ndarray, ny: int, nx: int)
     return g
 
 
+def load_artifacts(variant, model_path, directory, var_p, var_in, max_num_PC, standardization_method, shape, overlap,
+                   c_in: int = 3):
+    """What the reference's ``Evaluation.__init__`` loads (SM_call.py:70-87; Eval_dual_Dense_onlycil.py:51-66):
+    ``maxs`` (+ ``maxs_PCA`` for 'max_abs'), the Keras network of ``model_path`` (Dense stack, HDF5), the two
+    pickled PCA objects (``ipca_input``, ``ipca_p``: ``.pkl`` like the reference or the ``.npz`` export) with the
+    component-count rule of :86-87, and the scaler file of the chosen standardisation (:507-519).
+    -> (SurrogateModel, maxs)."""
+    from . import formats
+    maxs = formats.read_maxs(os.path.join(directory, "maxs"))
+    weights = formats.read_keras_dense_weights(model_path)
+    pin = formats.load_pca(formats.find_pca(directory, "ipca_input"))
+    pout = formats.load_pca(formats.find_pca(directory, "ipca_p"))
+    pc_p = formats.select_num_pc(pout.explained_variance_ratio_, var_p, max_num_PC)
+    pc_in = formats.select_num_pc(pin.explained_variance_ratio_, var_in, max_num_PC)
+    c_out = 2 if variant == "gradp" else 1
+    if pin.components_.shape[1] != shape * shape * c_in or pout.components_.shape[1] != shape * shape * c_out:
+        raise ValueError("PCA artefacts do not match the block shape / channel count")
+    if weights[0][0].shape[0] != pc_in or weights[-1][0].shape[1] != pc_p:
+        raise ValueError(f"network is {weights[0][0].shape[0]} -> {weights[-1][0].shape[1]} but the PCA rule gives "
+                         f"{pc_in} -> {pc_p} components")
+    m = SurrogateModel(variant, c_in, c_out, pin.components_[:pc_in], pin.mean_, pout.components_[:pc_p], pout.mean_,
+                       list(weights), scaler_kind=standardization_method, S=shape)
+    m.ov = int(overlap) if overlap else None                 # deltas: overlap in cells; gradp: `avance`
+    if standardization_method == "max_abs":
+        mp = formats.read_maxs(os.path.join(directory, "maxs_PCA"))      # Eval_dual_Dense_onlycil.py:52-55
+        m.in_a, m.out_a = float(mp[0]), float(mp[1])
+    else:
+        fn = "mean_std.npz" if standardization_method == "std" else "min_max_values.npz"
+        a, b, c, d = formats.read_scaler_npz(os.path.join(directory, fn), standardization_method)
+        m.in_a, m.in_b, m.out_a, m.out_b = (np.asarray(a, np.float64)[:pc_in], np.asarray(b, np.float64)[:pc_in],
+                                            np.asarray(c, np.float64)[:pc_p], np.asarray(d, np.float64)[:pc_p])
+    return m, maxs
+
+
 class Evaluation:
     """``pressureSM_deltas.SM_call.Evaluation`` (SM_call.py:26-87) on the GPU path.
 
@@ -296,12 +331,18 @@ class Evaluation:
     directory (``maxs``, the Keras model, ``ipca_*.pkl``, ``mean_std.npz``)."""
     variant = "deltas"
 
+    c_in_expected = 3
+
     def __init__(self, delta, shape, overlap, var_p, var_in, dataset_path, model_path, max_num_PC,
-                 standardization_method, model: SurrogateModel = None, device: int = 0):
+                 standardization_method, model: SurrogateModel = None, device: int = 0, artifact_dir: str = None):
         if standardization_method not in ("std", "min_max", "max_abs"):
             raise ValueError("Standardization method not valid")
+        self.maxs = None
         if model is None:
-            raise NotImplementedError("loading artefacts from dataset_path/model_path is not built yet: pass model=")
+            # like the reference: `maxs`, `ipca_input.pkl`, `ipca_p.pkl` and the scaler files are read from
+            # the working directory (SM_call.py:70-87, 507-519), the network from model_path (:74-79)
+            model, self.maxs = load_artifacts(self.variant, model_path, artifact_dir or os.getcwd(), var_p, var_in,
+                                              max_num_PC, standardization_method, shape, overlap, self.c_in_expected)
         self.delta, self.shape, self.overlap = delta, shape, overlap
         self.var_p, self.var_in, self.dataset_path, self.max_num_PC = var_p, var_in, dataset_path, max_num_PC
         self.standardization_method = standardization_method
@@ -318,6 +359,77 @@ class Evaluation:
                 self._sur.close()
             self._sur = GridSurrogate(self.artifacts, ny, nx, 1, self.device)
         return self._sur
+
+    # ---- dataset-driven entry points (same names and arguments as the reference) -------------------
+    def computeOnlyOnce(self, sim):
+        """SM_call.py:89-180: geometry of simulation ``sim`` (frame 0 of the dataset) -> interpolation tables,
+        SDF image, index map; handed to the GPU library (psm_set_geometry).  Returns 0."""
+        from . import formats
+        from .geometry import build_geometry_evaluator
+        data, top_b, obst_b = formats.read_dataset(self.dataset_path, sim, 0)
+        self.indice = formats.first_index(data[0, 0, :, 0], formats.PAD_VALUE)
+        cells = np.asarray(data[0, 0, :self.indice], np.float64)
+        top = np.asarray(top_b[0, 0, :formats.first_index(top_b[0, 0, :, 0], formats.PAD_VALUE)], np.float64)
+        obst = np.asarray(obst_b[0, 0, :formats.first_index(obst_b[0, 0, :, 0], formats.PAD_VALUE)], np.float64)
+        t = build_geometry_evaluator(cells[:, 3:5], cells[:, 2], top, obst, self.delta)
+        self.grid_shape_y, self.grid_shape_x = t.ny, t.nx
+        self.vert, self.weights, self.indices, self.sdfunct = t.vtx_m2g, t.wts_m2g, t.indices, t.sdfunct[:, :, None]
+        sur = self._surrogate(t.ny, t.nx)
+        v1, w1 = np.ascontiguousarray(t.vtx_m2g, np.int32), _f64(t.wts_m2g)
+        idx, sdf = np.ascontiguousarray(t.indices, np.int32), _f64(t.sdfunct)
+        mx = _f64(np.asarray(self.maxs if self.maxs is not None else (1.0, 1.0, 1.0, 1.0), np.float64)[:4])
+        sur._chk(sur.lib.psm_set_geometry(sur.h, int(self.indice), t.ny, t.nx, _p(v1, C.c_int32), _p(w1, C.c_double),
+                                          _p(idx, C.c_int32), _p(sdf, C.c_double), None, None, _p(mx, C.c_double), 1, 1, 0.05))
+        self.tables = t
+        return 0
+
+    def _mesh_to_grid(self, columns: np.ndarray) -> np.ndarray:
+        """interpolate_fill + scatter of k cell columns on the GPU (psm_mesh_to_grid) -> [Ny,Nx,k] float64."""
+        sur = self._surrogate(self.grid_shape_y, self.grid_shape_x)
+        v = _f64(columns)
+        out = np.empty((self.grid_shape_y, self.grid_shape_x, v.shape[1]), np.float64)
+        sur._chk(sur.lib.psm_mesh_to_grid(sur.h, _p(v, C.c_double), v.shape[0], v.shape[1], 1, _p(out, C.c_double)))
+        return out
+
+    def timeStep(self, sim, time, plot_intermediate_fields=False, save_plots=False, show_plots=False, apply_filter=False):
+        """SM_call.py:367-575 without the plots and error prints: frame (sim, time) of the dataset -> assembled
+        delta-p image [Ny,Nx] (dimensional, like ``deltap_res``), or 0 for an irrelevant time step (:417-421).
+        Also kept: ``self.cfd_results`` (the frame's own delta-p image) and ``self.no_flow_bool``."""
+        from . import formats
+        if getattr(self, "tables", None) is None:
+            raise RuntimeError("computeOnlyOnce has not been called")
+        data, _, _ = formats.read_dataset(self.dataset_path, sim, time)
+        d = data[0, 0, :self.indice]                  # float32 like the file: the reference normalises in float32
+        Ux, Uy, p = d[:, 0:1], d[:, 1:2], d[:, 2:3]
+        delta_U, delta_p = d[:, 5:7], d[:, 7:8]
+        delta_U_prev, delta_p_prev = d[:, 8:10], d[:, 10:11]
+        deltaU_changed = np.abs(delta_U - delta_U_prev).sum(axis=-1)                     # :400-401
+        deltaU_changed = deltaU_changed / deltaU_changed.max()
+        U_max_norm = np.max(np.sqrt(np.square(Ux) + np.square(Uy)))                      # :407
+        deltaU_max_norm = np.max(np.sqrt(np.square(delta_U[:, 0:1]) + np.square(delta_U[:, 1:2])))
+        if (deltaU_max_norm / U_max_norm) < 1e-4:                                       # :413-421
+            return 0
+        cols = np.concatenate([delta_U / U_max_norm, delta_p / pow(U_max_norm, 2.0), p, deltaU_changed[:, None], delta_p_prev],
+                              axis=1).astype(np.float64)
+        g = self._mesh_to_grid(cols)                                                    # :423-431
+        max_abs_Ux, max_abs_Uy, max_abs_dist, max_abs_p = [float(v) for v in self.maxs[:4]]
+        grid = np.zeros((self.grid_shape_y, self.grid_shape_x, 5))
+        grid[..., 0:2] = g[..., 0:2]
+        grid[..., 2] = self.sdfunct[..., 0]
+        grid[..., 3:5] = g[..., 2:4]
+        grid[np.isnan(grid)] = 0                                                        # :439
+        grid[..., 0] /= max_abs_Ux; grid[..., 1] /= max_abs_Uy                          # :442-445
+        grid[..., 2] /= max_abs_dist; grid[..., 3] /= max_abs_p
+        self.grid = grid
+        self.deltaU_change_grid, self.deltaP_prev_grid = g[..., 4], g[..., 5]            # :448-451 (NaNs kept)
+        self.max_abs_p = max_abs_p
+        res = self.timeStep_grid(grid[..., :3], U_max_norm, max_abs_p)                   # :452-572
+        if apply_filter:
+            res = self._surrogate(*grid.shape[:2]).gaussian_filter(res, (10, 10))
+        self.cfd_results = grid[..., 3] * max_abs_p * pow(U_max_norm, 2.0)               # :580 (float32 square, like the reference)
+        self.no_flow_bool = grid[..., 2] == 0
+        self.U_max_norm = float(U_max_norm)
+        return res
 
     def timeStep_grid(self, grid: np.ndarray, U_max_norm: float = 1.0, max_abs_p: float = 1.0) -> np.ndarray:
         """Grid-native body of ``timeStep`` (SM_call.py:452-575): -> deltap_res [Ny,Nx]."""

@@ -123,3 +123,47 @@ def build_poisson_case():
     U = float(np.sqrt(ux ** 2 + uy ** 2).max())
     return dict(ux=ux, uy=uy, dux=dux, duy=duy, sdfunct=sdf, L=0.25, U=U, k=0.5,
                 max_abs=(2.7, 0.031, 0.027, 0.29))
+
+
+DATASET_MAXS = (0.062, 0.055, 0.31, 0.047)
+
+
+def build_dataset_case(directory: str):
+    """Everything `Evaluation(delta, shape, overlap, var_p, var_in, dataset_path, model_path, ...)` reads from
+    disk, written into `directory` in the reference's formats (tests/h5write.py for HDF5): the padded
+    dataset (1 sim x 3 frames, 11 columns, pad -100), `maxs`, pickled scikit-learn PCA objects, `mean_std.npz`
+    and a Keras-style Dense `.h5`.  Returns the in-memory truth for the oracle."""
+    import pickle
+    from sklearn.decomposition import PCA
+    import h5write
+    frames = [synthetic.channel_mesh(step=s) for s in range(4)]
+    top, obst = frames[0][1], frames[0][2]
+    N = frames[0][0].shape[0]
+    T, max_cells, max_pts = 3, N + 41, max(len(top), len(obst)) + 13
+    sim = np.full((1, T, max_cells, 11), -100.0, np.float32)
+    for t in range(T):
+        cur, prev = frames[t + 1][0], frames[t][0]
+        pp = frames[t - 1][0] if t > 0 else frames[0][0] * 0.999
+        sim[0, t, :N, 0:2] = cur[:, 0:2]; sim[0, t, :N, 2] = cur[:, 4]; sim[0, t, :N, 3:5] = cur[:, 2:4]
+        sim[0, t, :N, 5:7] = cur[:, 0:2] - prev[:, 0:2]; sim[0, t, :N, 7] = cur[:, 4] - prev[:, 4]
+        sim[0, t, :N, 8:10] = prev[:, 0:2] - pp[:, 0:2]; sim[0, t, :N, 10] = prev[:, 4] - pp[:, 4]
+    tb = np.full((1, T, max_pts, 2), -100.0, np.float32); ob = tb.copy()
+    tb[0, :, :len(top)] = top; ob[0, :, :len(obst)] = obst
+    h5write.write_h5(os.path.join(directory, "dataset.hdf5"), {"sim_data": sim, "top_bound": tb, "obst_bound": ob})
+    np.savetxt(os.path.join(directory, "maxs"), np.array(DATASET_MAXS))
+    P, PC = 32, 24                                               # stored components, components the rule keeps
+    full = synthetic.make_model("deltas", p_in=P, p_out=P, seed_pca=2024, seed_w=3, scaler_kind="std")
+    model = synthetic.make_model("deltas", p_in=PC, p_out=PC, seed_pca=2024, seed_w=3, scaler_kind="std")
+    model.comp_in, model.comp_out = full.comp_in[:PC], full.comp_out[:PC]
+    model.mean_in, model.mean_out = full.mean_in, full.mean_out
+    evr = np.array([0.0395] * PC + [0.004] * (P - PC))            # cumulative ratio first exceeds 0.95 at index 24
+    for stem, comp, mean in (("ipca_input", full.comp_in, full.mean_in), ("ipca_p", full.comp_out, full.mean_out)):
+        o = PCA(n_components=P)
+        o.components_, o.mean_, o.explained_variance_ratio_ = comp, mean, evr
+        o.explained_variance_, o.n_components_, o.n_features_in_ = evr.copy(), P, comp.shape[1]
+        with open(os.path.join(directory, stem + ".pkl"), "wb") as f:
+            pickle.dump(o, f)
+    np.savez(os.path.join(directory, "mean_std.npz"), mean_in=model.in_a, std_in=model.in_b, mean_out=model.out_a, std_out=model.out_b)
+    h5write.write_keras_dense(os.path.join(directory, "model.h5"), model.weights)
+    return dict(sim=sim, top=top, obst=obst, N=N, model=model, dataset_path=os.path.join(directory, "dataset.hdf5"),
+                model_path=os.path.join(directory, "model.h5"))

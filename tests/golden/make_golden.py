@@ -300,6 +300,33 @@ def run_poisson_features(c):
                 term_sum=np.float64(term.sum()), term_abs_sum=np.float64(np.abs(term).sum()))
 
 
+def run_evaluator_grid(cells, tables, maxs):
+    """pressureSM_deltas/SM_call.py timeStep from the column split to the weighting images (:381-451), with the
+    reference's own `utils.interpolate_fill` (utils.py:75-90); the interpolation tables come from the build's
+    geometry step (computeOnlyOnce needs shapely)."""
+    UTL = f"{REF}/Improved_SM/deltaU_to_deltaP/source/pressureSM_deltas/utils.py"
+    ns = {"np": np}
+    fn = _find_fn(_tree(UTL), "interpolate_fill")
+    fn.decorator_list = []
+    mod = ast.Module(body=[fn], type_ignores=[]); ast.fix_missing_locations(mod)
+    exec(compile(mod, UTL, "exec"), ns)
+    utils = types.SimpleNamespace(interpolate_fill=ns["interpolate_fill"])
+    body = _find_fn(_tree(SMD), "timeStep", "Evaluation").body
+    i0 = next(i for i, st in enumerate(body) if _src(st).startswith("i = 0"))
+    i1 = next(i for i, st in enumerate(body) if _src(st).startswith("deltaP_prev_grid[tuple(self.indices.T)]"))
+    stmts = [st for st in body[i0:i1 + 1] if "print(" not in _src(st)]
+    me = types.SimpleNamespace(indice=cells.shape[0], vert=tables.vtx_m2g, weights=tables.wts_m2g, indices=tables.indices,
+                               sdfunct=tables.sdfunct[:, :, None], grid_shape_y=tables.ny, grid_shape_x=tables.nx,
+                               max_abs_Ux=maxs[0], max_abs_Uy=maxs[1], max_abs_dist=maxs[2], max_abs_p=maxs[3])
+    loc = {"self": me, "data": cells[None, None].astype(np.float32)}
+    with np.errstate(all="ignore"):
+        _run(stmts, {"np": np, "utils": utils, "pow": pow}, loc, SMD)
+    g = np.asarray(loc["grid"][0], np.float64)
+    return dict(grid_crop=g[40:100, 120:200].copy(), grid_sum=g.sum(axis=(0, 1)), grid_abs_sum=np.abs(g).sum(axis=(0, 1)),
+                dU_crop=np.asarray(loc["deltaU_change_grid"])[40:100, 120:200].copy(),
+                dPprev_crop=np.asarray(loc["deltaP_prev_grid"])[40:100, 120:200].copy(), U_max_norm=np.float64(loc["U_max_norm"]))
+
+
 def main():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import cases
@@ -361,6 +388,17 @@ def main():
     np.savez_compressed(os.path.join(HERE, "gradp_integration_320x384.npz"), p=np.asarray(loc["result"], np.float32),
                         center_p_x=np.int64(loc["center_p_x"]), center_p_y=np.int64(loc["center_p_y"]))
     print("gradp_integration: center", int(loc["center_p_x"]), int(loc["center_p_y"]), "|p|max=%.4f" % np.abs(loc["result"]).max())
+
+    # ---- dataset-driven evaluator front end (SMD:381-451) on frame 1 of the synthetic dataset
+    from psm_amd import geometry
+    with tempfile.TemporaryDirectory() as td:
+        dc = cases.build_dataset_case(td)
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    cells0 = np.asarray(dc["sim"][0, 0, :dc["N"]], np.float64)
+    tabs = geometry.build_geometry_evaluator(cells0[:, 3:5], cells0[:, 2], f32(dc["top"]), f32(dc["obst"]), 5e-3)
+    out = run_evaluator_grid(np.asarray(dc["sim"][0, 1, :dc["N"]], np.float64), tabs, cases.DATASET_MAXS)
+    np.savez_compressed(os.path.join(HERE, "evaluator_grid_138x300.npz"), **out)
+    print("evaluator_grid: U_max_norm=%.6f |grid| sums" % out["U_max_norm"], out["grid_abs_sum"])
 
     # ---- pressureSM_Poisson feature builder
     out = run_poisson_features(cases.build_poisson_case())

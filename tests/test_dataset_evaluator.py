@@ -1,0 +1,118 @@
+"""`Evaluation(delta, shape, overlap, var_p, var_in, dataset_path, model_path, max_num_PC, standardization_method)`
+driven from files in the reference's formats: padded HDF5 dataset, `maxs`, pickled PCA
+objects, `mean_std.npz`, Keras-style Dense `.h5` -- `computeOnlyOnce(sim)` + `timeStep(sim, time, ...)`
+(pressureSM_deltas/SM_call.py:89-180, 367-575) against the oracle chain on the same frame."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from oracle import psm_oracle as orc
+from psm_amd import Evaluation, formats, geometry, surrogate
+from test_oracle_golden import oracle_model
+
+
+@pytest.fixture(scope="module")
+def ds(tmp_path_factory):
+    d = tmp_path_factory.mktemp("artefacts")
+    return str(d), cases.build_dataset_case(str(d))
+
+
+def test_dataset_reader_and_padding(ds):
+    d, c = ds
+    with formats.PaddedDataset(c["dataset_path"]) as f:
+        assert f.shape == c["sim"].shape
+        data, top, obst = f.read(0, 1)
+    assert data.shape == (1, 1) + c["sim"].shape[2:] and data.dtype == np.float32
+    np.testing.assert_array_equal(data[0, 0], c["sim"][0, 1])
+    assert formats.first_index(data[0, 0, :, 0], formats.PAD_VALUE) == c["N"]
+    assert formats.first_index(top[0, 0, :, 0], formats.PAD_VALUE) == len(c["top"])
+    assert formats.first_index(np.arange(5.0), -100.0) == 5            # no padding: build-defined (reference: TypeError)
+    with pytest.raises(IndexError):
+        formats.read_dataset(c["dataset_path"], 1, 0)
+    with pytest.raises(formats.H5FormatError):
+        formats.PaddedDataset(c["model_path"])                          # a valid HDF5 file without `sim_data`
+
+
+def test_artifact_loader_follows_the_reference_rules(ds):
+    d, c = ds
+    m, maxs = surrogate.load_artifacts("deltas", c["model_path"], d, 0.95, 0.95, 128, "std", 128, 32)
+    assert (m.p_in, m.p_out) == (24, 24)                                # argmax(cumsum > var) = 24, within (1, max_num_PC]
+    np.testing.assert_array_equal(m.comp_in, c["model"].comp_in)
+    np.testing.assert_array_equal(m.mean_out, c["model"].mean_out)
+    np.testing.assert_allclose(maxs, cases.DATASET_MAXS)
+    np.testing.assert_array_equal(m.in_b, c["model"].in_b)
+    for (W, b), (W2, b2) in zip(m.weights, c["model"].weights):
+        np.testing.assert_array_equal(W, W2); np.testing.assert_array_equal(b, b2)
+    with pytest.raises(ValueError, match="network is 24 -> 24"):         # max_num_PC below the rule's count -> max_num_PC
+        surrogate.load_artifacts("deltas", c["model_path"], d, 0.95, 0.95, 16, "std", 128, 32)
+    # the dependency-free export carries the same three arrays
+    formats.save_pca_npz(os.path.join(d, "copy.npz"), formats.load_pca(os.path.join(d, "ipca_p.pkl")))
+    a, b = formats.load_pca(os.path.join(d, "copy.npz")), formats.load_pca(os.path.join(d, "ipca_p.pkl"))
+    np.testing.assert_array_equal(a.components_, b.components_)
+    np.testing.assert_array_equal(a.explained_variance_ratio_, b.explained_variance_ratio_)
+
+
+def _tables(c):
+    cells = np.asarray(c["sim"][0, 0, :c["N"]], np.float64)
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)          # the dataset stores float32
+    return geometry.build_geometry_evaluator(cells[:, 3:5], cells[:, 2], f32(c["top"]), f32(c["obst"]), 5e-3)
+
+
+def test_evaluator_geometry_rules(ds):
+    """computeOnlyOnce's own rules (SM_call.py:103-169) on the host tables: 3-digit bounds, every 5th boundary
+    point, `p` decides interpolability, zero-initialised indices."""
+    d, c = ds
+    t = _tables(c)
+    assert (t.ny, t.nx) == (138, 300)          # bounds rounded to 3 digits (python_module.py rounds to 2: 140)
+    assert t.vtx_g2m is None
+    inside = t.indices.any(axis=1)
+    assert np.all(t.sdfunct[t.indices[inside, 0], t.indices[inside, 1]] >= 0)
+    assert (t.sdfunct > 0).sum() > 0.8 * t.ny * t.nx and (t.sdfunct == 0).sum() > 100      # obstacle + rim
+
+
+def test_oracle_front_end_matches_reference_run(ds):
+    """oracle.evaluator_grid_deltas against the reference's own statements (SM_call.py:381-451 with
+    utils.interpolate_fill), executed by make_golden.py on frame 1 of this dataset: bit for bit."""
+    d, c = ds
+    gold = cases.load_golden("evaluator_grid_138x300")
+    t = _tables(c)
+    g, dU, dP, U = orc.evaluator_grid_deltas(c["sim"][0, 1, :c["N"]], t.vtx_m2g, t.wts_m2g, t.indices, t.sdfunct, cases.DATASET_MAXS)
+    assert U == float(gold["U_max_norm"])
+    np.testing.assert_array_equal(g[40:100, 120:200], gold["grid_crop"])
+    np.testing.assert_allclose(g.sum(axis=(0, 1)), gold["grid_sum"], rtol=1e-13)
+    np.testing.assert_allclose(np.abs(g).sum(axis=(0, 1)), gold["grid_abs_sum"], rtol=1e-13)
+    np.testing.assert_array_equal(dU[40:100, 120:200], gold["dU_crop"])
+    np.testing.assert_array_equal(dP[40:100, 120:200], gold["dPprev_crop"])
+
+
+@pytest.mark.gpu
+def test_evaluation_from_files_end_to_end(ds):
+    d, c = ds
+    ev = Evaluation(5e-3, 128, 32, 0.95, 0.95, c["dataset_path"], c["model_path"], 128, "std", artifact_dir=d)
+    assert (ev.pc_in, ev.pc_p) == (24, 24)
+    assert ev.computeOnlyOnce(0) == 0
+    assert ev.indice == c["N"] and (ev.grid_shape_y, ev.grid_shape_x) == (138, 300)
+    t = _tables(c)
+    om = oracle_model(c["model"])
+    for time in (0, 2):
+        res = ev.timeStep(0, time, False, False, False, False)
+        cells = c["sim"][0, time, :c["N"]]                                     # float32, like the file
+        grid, dU, dPprev, U = orc.evaluator_grid_deltas(cells, t.vtx_m2g, t.wts_m2g, t.indices, t.sdfunct, cases.DATASET_MAXS)
+        # interpolation + scatter on the GPU (float64) against the oracle's NumPy statements
+        assert np.abs(ev.grid - grid).max() <= 1e-12 * np.abs(grid).max()
+        np.testing.assert_allclose(ev.deltaU_change_grid, dU, rtol=0, atol=1e-12, equal_nan=True)
+        np.testing.assert_allclose(ev.deltaP_prev_grid, dPprev, rtol=0, atol=1e-12, equal_nan=True)
+        om.out_scale = cases.DATASET_MAXS[3] * U ** 2
+        sol = orc.solve_grid(grid[..., :3], om)
+        assert np.abs(res - sol.fields[..., 0]).max() <= 1e-4 * np.abs(sol.fields).max()
+        assert np.abs(ev.cfd_results - grid[..., 3] * cases.DATASET_MAXS[3] * pow(np.float32(U), 2.0)).max() <= 1e-12
+    # a frame whose velocity hardly changed is skipped like SM_call.py:413-421
+    sim2 = c["sim"].copy(); sim2[0, 1, :c["N"], 5:7] *= 1e-7
+    import h5write
+    p2 = os.path.join(d, "still.hdf5")
+    tb, ob = formats.read_dataset(c["dataset_path"], 0, 0)[1:]
+    h5write.write_h5(p2, {"sim_data": sim2, "top_bound": np.repeat(tb, 3, axis=1), "obst_bound": np.repeat(ob, 3, axis=1)})
+    ev.dataset_path = p2
+    assert isinstance(ev.timeStep(0, 1, False, False, False, False), int)
