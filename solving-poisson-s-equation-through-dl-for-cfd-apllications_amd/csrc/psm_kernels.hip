@@ -459,14 +459,14 @@ hipError_t psm_launch_dense(const PsmDenseArgs& a, hipStream_t st) {
 // flight under the first MFMAs (counted vmcnt).
 typedef float v4f __attribute__((ext_vector_type(4)));
 template <int MTC>
-__global__ __launch_bounds__(256) void psm_decode128_kernel(PsmDecodeArgs a, int m_base) {
+__global__ __launch_bounds__(256) void psm_decode128_kernel(PsmDecodeArgs a, int m_first, int m_end) {
   constexpr int LDR = 128, LDA = LDR + 4, Q = LDR / 4, GD = LDR / 8, NA = MTC * 32 * Q / 256;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int ct = min(blockIdx.x * 4 + wave, a.n_coltiles - 1);
   const bool live = (blockIdx.x * 4 + wave) < a.n_coltiles;
-  auto load_tile = [&](v4f (&x)[NA]) {
+  auto load_tile = [&](v4f (&x)[NA], int m_base) {
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
       const int idx = tid + 256 * u, row = idx / Q, q = idx - row * Q;
@@ -483,46 +483,54 @@ __global__ __launch_bounds__(256) void psm_decode128_kernel(PsmDecodeArgs a, int
   };
   PSM_STAMP(0, 20);
   v4f x[NA];
-  load_tile(x);
-  const float rs = a.row_scale[min(m_base + (tid & (MTC * 32 - 1)), a.Mpad - 1)];
+  load_tile(x, m_first);
+  float rs = a.row_scale[min(m_first + min(tid, MTC * 32 - 1), a.Mpad - 1)];
   __builtin_amdgcn_sched_barrier(0);
-  float4 b[GD];
+  float4 b[GD];                                  // this wave's weight slice: loaded once, kept for every row chunk
   const float4* bp = a.bpack + ((int64_t)ct * GD) * 64 + lane;
 #pragma unroll
   for (int g = 0; g < GD; ++g) b[g] = bp[g * 64];
   const int col = ct * 32 + i;
   const float mu = a.mean[col];
   __builtin_amdgcn_sched_barrier(0);
-  write_tile(x);
-  float* lrs = lds + MTC * 32 * LDA;           // [MTC*32] out_scale per block row
-  if (tid < MTC * 32) lrs[tid] = rs;
-  __syncthreads();
-  PSM_STAMP(0, 21);
-  f32x16 acc[MTC];
-#pragma unroll
-  for (int mt = 0; mt < MTC; ++mt) {
-    acc[mt] = (f32x16){0};
-    const float* arow = &lds[(mt * 32 + i) * LDA + 4 * h];
-    float4 av = *reinterpret_cast<const float4*>(arow);
-#pragma unroll
-    for (int g = 0; g < GD; ++g) {
-      const float4 an = *reinterpret_cast<const float4*>(arow + 8 * (g + 1 < GD ? g + 1 : g));
-      acc[mt] = MFMA32(av.x, b[g].x, acc[mt]);
-      acc[mt] = MFMA32(av.y, b[g].y, acc[mt]);
-      acc[mt] = MFMA32(av.z, b[g].z, acc[mt]);
-      acc[mt] = MFMA32(av.w, b[g].w, acc[mt]);
-      av = an;
+  float* lrs = lds + MTC * 32 * LDA;             // [MTC*32] out_scale per block row
+  for (int m_base = m_first; m_base < m_end; m_base += MTC * 32) {
+    if (m_base != m_first) {                     // later chunks (many block rows): only the activation tile is new
+      __syncthreads();                           // every wave is done with the previous tile
+      load_tile(x, m_base);
+      rs = a.row_scale[min(m_base + min(tid, MTC * 32 - 1), a.Mpad - 1)];
     }
-  }
-  PSM_STAMP(0, 22);
-  if (!live) return;
+    write_tile(x);
+    if (tid < MTC * 32) lrs[tid] = rs;
+    __syncthreads();
+    PSM_STAMP(0, 21);
+    f32x16 acc[MTC];
 #pragma unroll
-  for (int mt = 0; mt < MTC; ++mt) {
+    for (int mt = 0; mt < MTC; ++mt) {
+      acc[mt] = (f32x16){0};
+      const float* arow = &lds[(mt * 32 + i) * LDA + 4 * h];
+      float4 av = *reinterpret_cast<const float4*>(arow);
 #pragma unroll
-    for (int rg = 0; rg < 16; ++rg) {
-      const int rr = mt * 32 + acc_row(rg, h);
-      const int m = m_base + rr;
-      if (m < a.M) a.pred[(int64_t)m * a.K_out + col] = (acc[mt][rg] + mu) * lrs[rr];
+      for (int g = 0; g < GD; ++g) {
+        const float4 an = *reinterpret_cast<const float4*>(arow + 8 * (g + 1 < GD ? g + 1 : g));
+        acc[mt] = MFMA32(av.x, b[g].x, acc[mt]);
+        acc[mt] = MFMA32(av.y, b[g].y, acc[mt]);
+        acc[mt] = MFMA32(av.z, b[g].z, acc[mt]);
+        acc[mt] = MFMA32(av.w, b[g].w, acc[mt]);
+        av = an;
+      }
+    }
+    PSM_STAMP(0, 22);
+    if (live) {
+#pragma unroll
+      for (int mt = 0; mt < MTC; ++mt) {
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+          const int rr = mt * 32 + acc_row(rg, h);
+          const int m = m_base + rr;
+          if (m < a.M) a.pred[(int64_t)m * a.K_out + col] = (acc[mt][rg] + mu) * lrs[rr];
+        }
+      }
     }
   }
   PSM_STAMP(0, 23);
@@ -587,6 +595,17 @@ __global__ __launch_bounds__(256) void psm_decode_kernel(PsmDecodeArgs a, int m_
 
 hipError_t psm_launch_decode(const PsmDecodeArgs& a, hipStream_t st) {
   const int nwg = (a.n_coltiles + 3) / 4;
+  if (a.ld_res == 128) {
+    // <= 128 components: ONE launch for any number of block rows; a workgroup keeps its weight slice in
+    // registers and walks the rows in chunks of MTC*32 (chunk size chosen to waste the fewest padded tiles)
+    const int tiles = a.Mpad / 32, iters = (tiles + 3) / 4, mtc = (tiles + iters - 1) / iters;
+    const size_t lds128 = (size_t)mtc * 32 * (a.ld_res + 4) * sizeof(float) + (size_t)mtc * 32 * sizeof(float);
+    if (mtc == 4) hipLaunchKernelGGL((psm_decode128_kernel<4>), dim3(nwg), dim3(256), lds128, st, a, 0, a.Mpad);
+    else if (mtc == 3) hipLaunchKernelGGL((psm_decode128_kernel<3>), dim3(nwg), dim3(256), lds128, st, a, 0, a.Mpad);
+    else if (mtc == 2) hipLaunchKernelGGL((psm_decode128_kernel<2>), dim3(nwg), dim3(256), lds128, st, a, 0, a.Mpad);
+    else hipLaunchKernelGGL((psm_decode128_kernel<1>), dim3(nwg), dim3(256), lds128, st, a, 0, a.Mpad);
+    return hipGetLastError();
+  }
   int m_base = 0;
   while (m_base < a.Mpad) {
     const int tiles = (a.Mpad - m_base) / 32;
@@ -594,13 +613,7 @@ hipError_t psm_launch_decode(const PsmDecodeArgs& a, hipStream_t st) {
     const size_t lds = (size_t)mtc * 32 * (a.ld_res + 4) * sizeof(float);
     const bool g16 = (a.Gd % 16 == 0);
 #define DEC(M_, G_) hipLaunchKernelGGL((psm_decode_kernel<M_, G_>), dim3(nwg), dim3(256), lds, st, a, m_base)
-    if (a.ld_res == 128) {
-      const size_t lds128 = lds + (size_t)mtc * 32 * sizeof(float);
-      if (mtc == 4) hipLaunchKernelGGL((psm_decode128_kernel<4>), dim3(nwg), dim3(256), lds128, st, a, m_base);
-      else if (mtc == 2) hipLaunchKernelGGL((psm_decode128_kernel<2>), dim3(nwg), dim3(256), lds128, st, a, m_base);
-      else hipLaunchKernelGGL((psm_decode128_kernel<1>), dim3(nwg), dim3(256), lds128, st, a, m_base);
-    }
-    else if (mtc == 4) { if (g16) DEC(4, 16); else DEC(4, 4); }
+    if (mtc == 4) { if (g16) DEC(4, 16); else DEC(4, 4); }
     else if (mtc == 2) { if (g16) DEC(2, 16); else DEC(2, 4); }
     else { if (g16) DEC(1, 16); else DEC(1, 4); }
 #undef DEC
@@ -1004,6 +1017,10 @@ hipError_t psm_launch_chain(const PsmChainArgs& a, int n_cases, hipStream_t st) 
 // depend on the offsets (gathered while the strip partials are in flight) and a weighted
 // sum of the offsets:  shift = sum_k(3 pred[A_k] - pred[B_k])/(3L) - sum_b w_b offs_b.
 // ---------------------------------------------------------------------------
+// Workgroup barrier that only drains LDS traffic: __syncthreads() also waits for every outstanding
+// global load (vmcnt(0)), which would serialise the gathers below with the chain.
+#define PSM_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 template <int C>
 __global__ __launch_bounds__(256) void psm_assemble_kernel(PsmChainArgs a, PsmPasteArgs p) {
   constexpr int NB = 128 / PSM_STRIP_BAND;
@@ -1046,8 +1063,11 @@ __global__ __launch_bounds__(256) void psm_assemble_kernel(PsmChainArgs a, PsmPa
 #pragma unroll
     for (int q = 0; q < NB; ++q) cp[q] = a.colpart[((int64_t)cs * NB + q) * 128 + (tid & 127)];
   }
+  const float w_shift = a.shiftW[min(wave, C - 1) * B + min(lane, B - 1)];   // used after the chain (waves < C)
   __builtin_amdgcn_sched_barrier(0);
-  // ---- phase 1b: dependent gathers from the decoded blocks
+  // ---- phase 1b: dependent gathers from the decoded blocks.  They are NOT waited for before the
+  // chain: the barriers below are LDS-only (s_waitcnt lgkmcnt(0); s_barrier), so these loads land
+  // while the offset chain runs.
   const int o = pix < p.npix ? o_raw : -1;
   const float* predc = a.pred + ((int64_t)cs * B * SS) * C;
   float src[C], ga[C], gb[C];
@@ -1093,7 +1113,19 @@ __global__ __launch_bounds__(256) void psm_assemble_kernel(PsmChainArgs a, PsmPa
       scnt[B * NS + tid] = cn;
     }
   }
-  // offset-independent part of the shift
+  PSM_LDS_BARRIER();
+  PSM_STAMP(0, 37);
+  float t_shift = 0.f;
+  if (wave < C) {
+    PSM_STAMP(0, 38);
+    psm_chain_wave(a.cp, smean + wave * nst, scnt, a.blocks, wave, lane, offs + wave * B);
+    PSM_STAMP(0, 39);
+    // shift of this field: weighted sum of the offsets (B <= 64 on this path); same-wave LDS
+    // writes above are visible to the wave's own later reads
+    const float t = (lane < B && w_shift != 0.f) ? w_shift * offs[wave * B + lane] : 0.f;
+    t_shift = wave_sum(t);
+  }
+  // offset-independent part of the shift (the gathers have landed under the chain)
   float pp[C];
 #pragma unroll
   for (int f = 0; f < C; ++f) {
@@ -1108,23 +1140,12 @@ __global__ __launch_bounds__(256) void psm_assemble_kernel(PsmChainArgs a, PsmPa
 #pragma unroll
     for (int f = 0; f < C; ++f) wred[f * 4 + wave] = pp[f];
   }
-  __syncthreads();
-  PSM_STAMP(0, 37);
-  if (wave < C) {
-    PSM_STAMP(0, 38);
-    psm_chain_wave(a.cp, smean + wave * nst, scnt, a.blocks, wave, lane, offs + wave * B);
-    PSM_STAMP(0, 39);
-    // shift of this field: weighted sum of the offsets (B <= 64 on this path); same-wave LDS
-    // writes above are visible to the wave's own later reads
-    const float w = lane < B ? a.shiftW[wave * B + lane] : 0.f;
-    float t = (w != 0.f) ? w * offs[wave * B + lane] : 0.f;
-    t = wave_sum(t);
-    if (lane == 0) {
-      const float part = (wred[wave * 4 + 0] + wred[wave * 4 + 1]) + (wred[wave * 4 + 2] + wred[wave * 4 + 3]);
-      wred[4 * C + wave] = part / (float)a.shiftL[wave] / 3.f - t;
-    }
+  PSM_LDS_BARRIER();
+  if (wave < C && lane == 0) {
+    const float part = (wred[wave * 4 + 0] + wred[wave * 4 + 1]) + (wred[wave * 4 + 2] + wred[wave * 4 + 3]);
+    wred[4 * C + wave] = part / (float)a.shiftL[wave] / 3.f - t_shift;
   }
-  __syncthreads();
+  PSM_LDS_BARRIER();
   PSM_STAMP(0, 40);
   if (blockIdx.x == 0) {       // introspection copies (psm_read_stage)
     for (int idx = tid; idx < C * B; idx += 256) a.offs[(int64_t)cs * C * B + idx] = offs[idx];
