@@ -103,6 +103,71 @@ __global__ __launch_bounds__(256) void psm_encode_kernel(PsmEncodeArgs a) {
     }
   };
 
+  if (NT <= 4 && a.Mpad > 32) {
+    // many block rows (case batches): 64-row chunks double-buffered in LDS.  The rows of chunk c+1 are
+    // requested before the MFMAs of chunk c and written to the other buffer after them, so the
+    // staging round trip hides under the matrix work; the weight slice stays in registers throughout.
+    // Barriers are LDS-only (the partial-sum stores need not drain between chunks).
+    constexpr int CH = 64;
+    const int t = min(wave, NT - 1);
+    float4 xa[8], xb[8];
+    load_rows(xa, 0, 0);
+    load_rows(xb, 0, 32);
+    __builtin_amdgcn_sched_barrier(0);
+    float4 b[G];
+    {
+      const float4* p = a.bpack + (((int64_t)s * NT + t) * G) * 64 + lane;
+#pragma unroll
+      for (int g = 0; g < G; ++g) b[g] = p[g * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    write_rows(xa, 0, 0);
+    write_rows(xb, 0, 32);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    int buf = 0;
+    for (int m0 = 0; m0 < a.Mpad; m0 += CH) {
+      const bool more = m0 + CH < a.Mpad;
+      if (more) { load_rows(xa, m0 + CH, 0); load_rows(xb, m0 + CH, 32); }
+      const int tiles = min(2, (a.Mpad - m0) / 32);
+      for (int mt = 0; mt < tiles; ++mt) {
+        f32x16 acc = {0};
+        const float* arow = &lds[(buf * CH + mt * 32 + i) * LDA + 4 * h];
+        float4 av = *reinterpret_cast<const float4*>(arow);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const float4 an = *reinterpret_cast<const float4*>(arow + 8 * (g + 1 < G ? g + 1 : g));
+          acc = MFMA32(av.x, b[g].x, acc);
+          acc = MFMA32(av.y, b[g].y, acc);
+          acc = MFMA32(av.z, b[g].z, acc);
+          acc = MFMA32(av.w, b[g].w, acc);
+          av = an;
+        }
+        if (wave < NT) {
+          float* out = a.part + ((int64_t)s * a.Mpad + m0 + mt * 32) * a.ldp + t * 32 + i;
+#pragma unroll
+          for (int rg = 0; rg < 16; ++rg) out[(int64_t)acc_row(rg, h) * a.ldp] = acc[rg];
+        }
+      }
+      if (more) {
+        // rows of the next chunk into the other buffer (row index relative to that buffer)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int row = wave + 4 * u;
+          const float k0 = (m0 + CH + row) < a.M ? 1.f : 0.f, k1 = (m0 + CH + 32 + row) < a.M ? 1.f : 0.f;
+          const float4 v0 = make_float4((xa[u].x - mu.x) * k0, (xa[u].y - mu.y) * k0, (xa[u].z - mu.z) * k0, (xa[u].w - mu.w) * k0);
+          const float4 v1 = make_float4((xb[u].x - mu.x) * k1, (xb[u].y - mu.y) * k1, (xb[u].z - mu.z) * k1, (xb[u].w - mu.w) * k1);
+          if (lane < Q) {
+            *reinterpret_cast<float4*>(&lds[((buf ^ 1) * CH + row) * LDA + 4 * lane]) = v0;
+            *reinterpret_cast<float4*>(&lds[((buf ^ 1) * CH + 32 + row) * LDA + 4 * lane]) = v1;
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      buf ^= 1;
+    }
+    return;
+  }
+
   if (NT <= 4 && a.Mpad <= 32 * PSM_MT_CHUNK) {
     // common case (<= 128 components, <= 128 block rows): straight-line so that the weight
     // stream stays in flight behind the first MFMAs (counted vmcnt).  Every wave computes (a
@@ -152,7 +217,7 @@ __global__ __launch_bounds__(256) void psm_encode_kernel(PsmEncodeArgs a) {
 
 hipError_t psm_launch_encode(const PsmEncodeArgs& a, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
   const int n_slices = a.S * a.S / PSM_PIX_PER_SLICE;
-  const int rows = a.Mpad < 32 * PSM_MT_CHUNK ? a.Mpad : 32 * PSM_MT_CHUNK;
+  const int rows = a.Mpad <= 32 ? 32 : 32 * PSM_MT_CHUNK;        // one tile, or 2 x 64-row buffers / a 128-row chunk
   const size_t lds = (size_t)rows * (PSM_PIX_PER_SLICE * a.c_in + 4) * sizeof(float);
   // With events: hipExtLaunchKernelGGL stamps them with the dispatch's own begin / end times
   // (the source rocprofv3 reads), not with separate marker packets around the launch.

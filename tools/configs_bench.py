@@ -13,9 +13,11 @@ def run(name, model, ny, nx, n_cases, steps=1500, warm=150, precision="f32"):
         d_out = torch.empty((n_cases, ny, nx, model.c_out), dtype=torch.float32, device="cuda")
         st = torch.cuda.current_stream().cuda_stream
         for i in range(warm): sur.solve_device(d_in.data_ptr(), n_cases, d_out.data_ptr(), st)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for i in range(steps): sur.solve_device(d_in.data_ptr(), n_cases, d_out.data_ptr(), st)
-        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        dt = 1e9
+        for rep in range(3):                      # best of 3: single runs show sporadic slow phases on a shared box
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for i in range(steps): sur.solve_device(d_in.data_ptr(), n_cases, d_out.data_ptr(), st)
+            torch.cuda.synchronize(); dt = min(dt, time.perf_counter() - t0)
         prof = sur.profile(d_in.data_ptr(), n_cases, d_out.data_ptr())
     print(f"{name:34s} B={sur.B:3d} cases/step={n_cases:3d}  {dt/steps*1e6:8.1f} us/step  {n_cases*steps/dt:10.0f} solves/s  "
           + " ".join(f"{k}={v*1e3:.1f}" for k, v in prof.items()))
