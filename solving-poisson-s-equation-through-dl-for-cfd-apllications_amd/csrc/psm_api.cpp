@@ -383,7 +383,8 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
   for (int f = 0; f < 2; ++f) ca.shiftL[f] = (int)h->plan.shiftA[f].size();
   ca.Lmax = h->Lmax; ca.offs = h->d_offs; ca.shift = h->d_shift; ca.n_strips = h->n_strips; ca.c_out = h->cfg.c_out; ca.stamps = h->d_stamps;
   PsmPasteArgs pa{h->d_pred, h->d_owner, h->d_offs, h->d_shift, d_fields, h->B, h->S, h->cfg.c_out, h->Ny * h->Nx};
-  if (h->fused_assemble) {       // few blocks: every paste workgroup re-runs the chain (one launch less)
+  if (h->fused_assemble && n_cases < 4) {   // few blocks, few cases: every paste workgroup re-runs the chain (one launch
+                                            // less); for case batches one chain workgroup per case + a streaming paste
     tm.before(PSM_K_CHAIN);
     tm.after(PSM_K_CHAIN);
     tm.before(PSM_K_PASTE);

@@ -526,6 +526,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 template <int MTC>
 __global__ __launch_bounds__(256) void psm_decode128_kernel(PsmDecodeArgs a, int m_first, int m_end) {
   constexpr int LDR = 128, LDA = LDR + 4, Q = LDR / 4, GD = LDR / 8, NA = MTC * 32 * Q / 256;
+  m_first += (int)blockIdx.y * MTC * 32;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
@@ -559,7 +560,8 @@ __global__ __launch_bounds__(256) void psm_decode128_kernel(PsmDecodeArgs a, int
   const float mu = a.mean[col];
   __builtin_amdgcn_sched_barrier(0);
   float* lrs = lds + MTC * 32 * LDA;             // [MTC*32] out_scale per block row
-  for (int m_base = m_first; m_base < m_end; m_base += MTC * 32) {
+  const int m_step = MTC * 32 * (int)gridDim.y;    // row chunks are dealt round-robin to the gridDim.y row groups
+  for (int m_base = m_first; m_base < m_end; m_base += m_step) {
     if (m_base != m_first) {                     // later chunks (many block rows): only the activation tile is new
       __syncthreads();                           // every wave is done with the previous tile
       load_tile(x, m_base);
@@ -665,10 +667,15 @@ hipError_t psm_launch_decode(const PsmDecodeArgs& a, hipStream_t st) {
     // registers and walks the rows in chunks of MTC*32 (chunk size chosen to waste the fewest padded tiles)
     const int tiles = a.Mpad / 32, iters = (tiles + 3) / 4, mtc = (tiles + iters - 1) / iters;
     const size_t lds128 = (size_t)mtc * 32 * (a.ld_res + 4) * sizeof(float) + (size_t)mtc * 32 * sizeof(float);
-    if (mtc == 4) hipLaunchKernelGGL((psm_decode128_kernel<4>), dim3(nwg), dim3(256), lds128, st, a, 0, a.Mpad);
-    else if (mtc == 3) hipLaunchKernelGGL((psm_decode128_kernel<3>), dim3(nwg), dim3(256), lds128, st, a, 0, a.Mpad);
-    else if (mtc == 2) hipLaunchKernelGGL((psm_decode128_kernel<2>), dim3(nwg), dim3(256), lds128, st, a, 0, a.Mpad);
-    else hipLaunchKernelGGL((psm_decode128_kernel<1>), dim3(nwg), dim3(256), lds128, st, a, 0, a.Mpad);
+    // one output channel gives only 128 column workgroups: with several row chunks, deal them to two or
+    // more row groups so that all 256 CUs work (each group re-reads the weight slice: 8 MB more traffic)
+    int groups = 1;
+    while (nwg * groups < 256 && groups * 2 <= iters) groups *= 2;
+    const dim3 grid(nwg, groups);
+    if (mtc == 4) hipLaunchKernelGGL((psm_decode128_kernel<4>), grid, dim3(256), lds128, st, a, 0, a.Mpad);
+    else if (mtc == 3) hipLaunchKernelGGL((psm_decode128_kernel<3>), grid, dim3(256), lds128, st, a, 0, a.Mpad);
+    else if (mtc == 2) hipLaunchKernelGGL((psm_decode128_kernel<2>), grid, dim3(256), lds128, st, a, 0, a.Mpad);
+    else hipLaunchKernelGGL((psm_decode128_kernel<1>), grid, dim3(256), lds128, st, a, 0, a.Mpad);
     return hipGetLastError();
   }
   int m_base = 0;
