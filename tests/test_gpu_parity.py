@@ -247,6 +247,39 @@ def test_reassembly_properties_full_size():
             assert np.abs(f0[..., c] - ref).max() <= 2e-4
 
 
+def test_full_solve_on_large_grids():
+    """The launch paths the 256x256 configs do not reach, against the oracle: gradp 512x512 (182 blocks: more than
+    128 block rows -> un-fused reduce, 32-row dense tiles, chunked encode/decode, separate chain + paste launches)
+    and the shipped 400x3000 Chapter-5 shape (104 blocks)."""
+    for variant, ny, nx, B in (("gradp", 512, 512, 182), ("chapter5", 400, 3000, 104)):
+        model = synthetic.make_model(variant, p_in=16, p_out=24, seed_pca=90 + ny, seed_w=4)
+        grid = synthetic.channel_grid(ny, nx, seed=6, extra_channels=0).astype(np.float32)
+        with GridSurrogate(model, ny, nx) as sur:
+            assert sur.B == B
+            fields = sur.solve(grid)[0]
+            sol = orc.solve_grid(grid.astype(np.float64), oracle_model(model))
+            check_against_oracle(sur, grid, model, sol)
+        assert np.abs(fields - sol.fields).max() <= 1e-4 * np.abs(sol.fields).max()
+
+
+def test_more_than_64_block_columns_uses_the_serial_chain():
+    """gradp strip 160 x 2240: 67 block columns (> one wavefront) -> the single-lane form of the offset chain
+    (psm_chain_v, the host replay's code) inside the chain kernel."""
+    ny, nx = 160, 2240
+    model = synthetic.make_model("gradp", p_in=8, p_out=8)
+    lay = orc.block_layout("gradp", ny, nx)
+    assert lay.n_x + 1 > 64
+    grid = synthetic.channel_grid(ny, nx, seed=12).astype(np.float32)
+    rng = np.random.default_rng(1)
+    bp = rng.standard_normal((lay.B, 128, 128, 2)).astype(np.float32)
+    xb = orc.extract_blocks(grid.astype(np.float64), lay, 3)
+    with GridSurrogate(model, ny, nx) as sur:
+        f = sur.reassemble(grid, bp)
+    for c, which in enumerate(("dp_dx", "dp_dy")):
+        ref = orc.assemble_gradp(which, bp[..., c], xb, lay).field
+        assert np.abs(f[..., c] - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max())
+
+
 def test_reference_shaped_assemble_prediction():
     """Evaluation.assemble_prediction with the reference's argument list (SM_call.py:182,
     Eval_dual_Dense_onlycil.py:255) on label-like blocks, against the golden label fields."""
