@@ -96,8 +96,13 @@ def main():
     import psm_amd
     from psm_amd import dist as pdist
     rank, world, local_rank = pdist.env_world()
+    # Rehearsal switches (not used by the driver): several ranks on ONE card need the gloo backend and a
+    # forced device index, e.g. PSM_BENCH_BACKEND=gloo PSM_BENCH_DEVICE=0 torchrun --nproc-per-node 2 bench.py
+    backend = os.environ.get("PSM_BENCH_BACKEND", "nccl")
+    local_rank = int(os.environ.get("PSM_BENCH_DEVICE", local_rank))
     torch.cuda.set_device(local_rank)
-    pdist.init("nccl", torch.device("cuda", local_rank))
+    pdist.init(backend, torch.device("cuda", local_rank))
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     import psm_amd
     from psm_amd import synthetic
@@ -118,7 +123,7 @@ def main():
         k = i % len(d_in)
         sur.solve_device(d_in[k].data_ptr(), NC, d_out[k].data_ptr(), stream)
 
-    dt_max = pdist.timed_region(step, args.steps, args.warmup, torch.cuda.synchronize, "cuda")
+    dt_max = pdist.timed_region(step, args.steps, args.warmup, torch.cuda.synchronize, red_dev)
 
     # ---- roofline of the dominant kernel: instrumented pass over the same K steps
     ab = algorithmic_bytes(model, NY, NX, 2 if precision == "bf16" else 4)
