@@ -827,3 +827,33 @@ def evaluator_grid_deltas(cells, vert, weights, indices, sdfunct, maxs):
     grid[np.isnan(grid)] = 0
     grid[..., 0] /= maxs[0]; grid[..., 1] /= maxs[1]; grid[..., 2] /= maxs[2]; grid[..., 3] /= maxs[3]
     return grid, to_grid(changed), to_grid(delta_p_prev), float(U)
+
+
+def evaluator_grid_gradp(cells, vert, weights, indices, sdfunct, maxs, min_x, max_x, min_y, max_y):
+    """UGP:429-467: one un-padded dataset frame (0 Ux, 1 Uy, 2 p, 3 Cx, 4 Cy, 6 dP/dx, 7 dP/dy) ->
+    (grid[Ny,Nx,6] normalised, U_max_norm).  dtype of ``cells`` and of the extents is kept (float32 in
+    the reference: file data and ``np.max(top[:,0])``)."""
+    d = np.asarray(cells)
+    Ux, Uy, p, dPdx, dPdy = d[:, 0:1], d[:, 1:2], d[:, 2:3], d[:, 6:7], d[:, 7:8]
+    U = np.max(np.sqrt(np.square(Ux) + np.square(Uy)))
+    dPdx_adim = dPdx * (max_x - min_x) / pow(U, 2.0)
+    dPdy_adim = dPdy * (max_y - min_y) / pow(U, 2.0)
+    p_adim = p / pow(U, 2.0)
+    ny, nx = sdfunct.shape[:2]
+    idx = tuple(np.asarray(indices).T)
+
+    def to_grid(v):
+        g = np.zeros((ny, nx))
+        g[idx] = interpolate_fill(np.asarray(v).reshape(-1), vert, weights)
+        return g
+    grid = np.zeros((ny, nx, 6))
+    grid[..., 0] = to_grid(Ux / U)
+    grid[..., 1] = to_grid(Uy / U)
+    grid[..., 2] = np.asarray(sdfunct).reshape(ny, nx)
+    grid[..., 3] = to_grid(dPdx_adim)
+    grid[..., 4] = to_grid(dPdy_adim)
+    grid[..., 5] = to_grid(p_adim)
+    grid[np.isnan(grid)] = 0
+    for ch in range(5):
+        grid[..., ch] /= maxs[ch]
+    return grid, float(U)

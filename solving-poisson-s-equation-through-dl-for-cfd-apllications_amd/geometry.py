@@ -29,6 +29,7 @@ class GeometryTables:
     x0: float = 0.0
     y0: float = 0.0
     delta: float = 5e-3
+    box: tuple = None        # (min_x, max_x, min_y, max_y) of the inside-domain test (evaluators)
 
 
 def create_uniform_grid(x_min, x_max, y_min, y_max, delta):
@@ -98,7 +99,8 @@ def build_geometry(array, top, obst, delta: float = 5e-3, every: int = 10, round
                           np.ascontiguousarray(wts_g2m), domain_bool, float(x0), float(y0), delta)
 
 
-def build_geometry_evaluator(points, p_values, top, obst, delta: float, every: int = 5) -> GeometryTables:
+def build_geometry_evaluator(points, p_values, top, obst, delta: float, every: int = 5, round_digits: int = 3,
+                             box: str = "mixed") -> GeometryTables:
     """``Evaluation.computeOnlyOnce`` (pressureSM_deltas/SM_call.py:89-180): like ``build_geometry`` with the
     evaluator's differences -- bounds rounded to 3 digits (:103-107), the box test mixes the ``top`` patch with
     the data bounds (:119-122), every 5th boundary point for the SDF (:139-140), ``p`` decides which grid
@@ -107,13 +109,16 @@ def build_geometry_evaluator(points, p_values, top, obst, delta: float, every: i
     from scipy.spatial.distance import cdist
     points = np.asarray(points, np.float64)
     top, obst = np.asarray(top, np.float64), np.asarray(obst, np.float64)
-    x_min, x_max = round(float(np.min(points[:, 0])), 3), round(float(np.max(points[:, 0])), 3)
-    y_min, y_max = round(float(np.min(points[:, 1])), 3), round(float(np.max(points[:, 1])), 3)
+    x_min, x_max = round(float(np.min(points[:, 0])), round_digits), round(float(np.max(points[:, 0])), round_digits)
+    y_min, y_max = round(float(np.min(points[:, 1])), round_digits), round(float(np.max(points[:, 1])), round_digits)
     X0, Y0 = create_uniform_grid(x_min, x_max, y_min, y_max, delta)
     xy0 = np.stack([X0, Y0], axis=-1)
     vtx, wts = interp_weights(points, xy0)
-    max_x, max_y = max(top[:, 0].max(), x_max), min(top[:, 1].max(), y_max)          # SM_call.py:119
-    min_x, min_y = max(top[:, 0].min(), x_min), min(top[:, 1].min(), y_min)          # SM_call.py:120
+    if box == "mixed":
+        max_x, max_y = max(top[:, 0].max(), x_max), min(top[:, 1].max(), y_max)      # SM_call.py:119
+        min_x, min_y = max(top[:, 0].min(), x_min), min(top[:, 1].min(), y_min)      # SM_call.py:120
+    else:
+        max_x, max_y, min_x, min_y = top[:, 0].max(), top[:, 1].max(), top[:, 0].min(), top[:, 1].min()
     inside_box = (xy0[:, 0] <= max_x) & (xy0[:, 0] >= min_x) & (xy0[:, 1] <= max_y) & (xy0[:, 1] >= min_y)
     hull = ConvexHull(obst)
     inside_obst = np.all(xy0 @ hull.equations[:, :2].T + hull.equations[:, 2] < 0.0, axis=1)
@@ -130,5 +135,7 @@ def build_geometry_evaluator(points, p_values, top, obst, delta: float, every: i
     indices[ok, 0], indices[ok, 1] = ii[ok], jj[ok]
     sdfunct = np.zeros((ny, nx))
     sdfunct[ii[ok], jj[ok]] = sdf[ok]
-    return GeometryTables(ny, nx, vtx, np.ascontiguousarray(wts), indices, sdfunct, None, None, domain_bool,
-                          float(x0), float(y0), delta)
+    t = GeometryTables(ny, nx, vtx, np.ascontiguousarray(wts), indices, sdfunct, None, None, domain_bool,
+                       float(x0), float(y0), delta)
+    t.box = (float(min_x), float(max_x), float(min_y), float(max_y))
+    return t

@@ -509,10 +509,77 @@ class EvaluationGradP(Evaluation):
     variant = "gradp"
 
     def __init__(self, delta, shape, avance, var_p, var_in, hdf5_path, model_path, max_number_PC,
-                 model: SurrogateModel = None, device: int = 0):
+                 model: SurrogateModel = None, device: int = 0, artifact_dir: str = None):
         super().__init__(delta, shape, avance, var_p, var_in, hdf5_path, model_path, max_number_PC,
-                         model.scaler_kind if model is not None else "max_abs", model, device)
+                         model.scaler_kind if model is not None else "max_abs", model, device, artifact_dir)
         self.avance = avance
+        self.hdf5_path = hdf5_path
+
+    def computeOnlyOnce(self, sim):
+        """Eval_dual_Dense_onlycil.py:160-253: 2-digit bounds, box = the ``top`` patch, every 2nd boundary point,
+        column 5 decides interpolability.  Returns 0."""
+        from . import formats
+        from .geometry import build_geometry_evaluator
+        data, top_b, obst_b = formats.read_dataset(self.hdf5_path, sim, 0)
+        self.indice = formats.first_index(data[0, 0, :, 0], formats.PAD_VALUE)
+        cells = np.asarray(data[0, 0, :self.indice], np.float64)
+        top32 = top_b[0, 0, :formats.first_index(top_b[0, 0, :, 0], formats.PAD_VALUE)]
+        obst32 = obst_b[0, 0, :formats.first_index(obst_b[0, 0, :, 0], formats.PAD_VALUE)]
+        t = build_geometry_evaluator(cells[:, 3:5], cells[:, 5], np.asarray(top32, np.float64), np.asarray(obst32, np.float64),
+                                     self.delta, every=2, round_digits=2, box="top")
+        # float32 like `np.max(top[:,0])` of the float32 file data (:192): used in float32 arithmetic by timeStep
+        self.max_x, self.max_y = np.max(top32[:, 0]), np.max(top32[:, 1])
+        self.min_x, self.min_y = np.min(top32[:, 0]), np.min(top32[:, 1])
+        self.grid_shape_y, self.grid_shape_x = t.ny, t.nx
+        self.vert, self.weights, self.indices, self.sdfunct = t.vtx_m2g, t.wts_m2g, t.indices, t.sdfunct[:, :, None]
+        self.X0_min = t.x0
+        sur = self._surrogate(t.ny, t.nx)
+        v1, w1 = np.ascontiguousarray(t.vtx_m2g, np.int32), _f64(t.wts_m2g)
+        idx, sdf = np.ascontiguousarray(t.indices, np.int32), _f64(t.sdfunct)
+        mx = _f64(np.asarray(self.maxs, np.float64)[:4])
+        sur._chk(sur.lib.psm_set_geometry(sur.h, int(self.indice), t.ny, t.nx, _p(v1, C.c_int32), _p(w1, C.c_double),
+                                          _p(idx, C.c_int32), _p(sdf, C.c_double), None, None, _p(mx, C.c_double), 1, 1, 0.05))
+        self.tables = t
+        return 0
+
+    def timeStep(self, sim, time, plot_intermediate_fields=False, save_plots=False, show_plots=False, apply_filter=False):
+        """Eval_dual_Dense_onlycil.py:418-640 without plots and error prints: frame (sim, time) -> the integrated
+        pressure image [Ny,Nx] (``field``).  Kept: ``self.grid`` (6 channels), ``self.gradP`` [Ny,Nx,2]."""
+        from . import formats
+        if getattr(self, "tables", None) is None:
+            raise RuntimeError("computeOnlyOnce has not been called")
+        data, _, _ = formats.read_dataset(self.hdf5_path, sim, time)
+        d = data[0, 0, :self.indice]                                  # float32, normalised in float32 like the reference
+        Ux, Uy, p, dPdx, dPdy = d[:, 0:1], d[:, 1:2], d[:, 2:3], d[:, 6:7], d[:, 7:8]
+        U_max_norm = np.max(np.sqrt(np.square(Ux) + np.square(Uy)))                       # :438
+        cols = np.concatenate([Ux / U_max_norm, Uy / U_max_norm,                        # :443-444
+                               dPdx * (self.max_x - self.min_x) / pow(U_max_norm, 2.0),   # :440
+                               dPdy * (self.max_y - self.min_y) / pow(U_max_norm, 2.0),   # :441
+                               p / pow(U_max_norm, 2.0)], axis=1).astype(np.float64)      # :442
+        g = self._mesh_to_grid(cols)
+        mx = [float(v) for v in self.maxs[:5]]
+        grid = np.zeros((self.grid_shape_y, self.grid_shape_x, 6))
+        grid[..., 0:2] = g[..., 0:2]
+        grid[..., 2] = self.sdfunct[..., 0]
+        grid[..., 3:6] = g[..., 2:5]
+        grid[np.isnan(grid)] = 0                                                          # :461
+        for ch in range(5):
+            grid[..., ch] /= mx[ch]                                                       # :463-467
+        self.grid = grid
+        self.U_max_norm = float(U_max_norm)
+        sur = self._surrogate(*grid.shape[:2])
+        gradP = sur.solve(grid[..., :3])[0]                                               # :470-544
+        if apply_filter:                                                                 # :366-367, per field
+            gradP = np.stack([sur.gaussian_filter(gradP[..., c], (10, 10)) for c in range(2)], axis=-1)
+        self.gradP = gradP
+        xl = np.linspace(self.min_x, self.max_x, grid.shape[1])                            # :591-592
+        yl = np.linspace(self.min_y, self.max_y, grid.shape[0])
+        solid = self.sdfunct[200, :, 0] == 0                                              # :594 (row 200 is hard-wired)
+        center_p_x = int(((xl[solid].max() + xl[solid].min()) / 2 - self.X0_min) / self.delta)
+        center_p_y = 200
+        sur.set_integration(self.sdfunct[..., 0], center_p_y, center_p_x, float(np.diff(xl)[0]), float(np.diff(yl)[0]))
+        self.center_p_x, self.center_p_y = center_p_x, center_p_y
+        return sur.integrate_gradp(gradP)                                                 # :597-628
 
     def timeStep_grid(self, grid: np.ndarray) -> np.ndarray:
         """Eval_dual_Dense_onlycil.py:470-547: -> [Ny,Nx,2] = (res_dPdx, res_dPdy)."""

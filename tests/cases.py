@@ -167,3 +167,47 @@ def build_dataset_case(directory: str):
     h5write.write_keras_dense(os.path.join(directory, "model.h5"), model.weights)
     return dict(sim=sim, top=top, obst=obst, N=N, model=model, dataset_path=os.path.join(directory, "dataset.hdf5"),
                 model_path=os.path.join(directory, "model.h5"))
+
+
+GRADP_MAXS = (1.0, 0.41, 0.33, 2.9, 2.4)
+
+
+def build_gradp_dataset_case(directory: str):
+    """Artefact directory of the U_to_gradP evaluator (Eval_dual_Dense_onlycil.py:30-66, 160-253, 418-640): a 320x300
+    grid whose obstacle crosses the hard-wired row 200; dataset columns 0 Ux, 1 Uy, 2 p, 3 Cx, 4 Cy, 5 (test column),
+    6 dP/dx, 7 dP/dy; `maxs` (5 values), `maxs_PCA`, pickled PCA objects, Keras-style `.h5`."""
+    import pickle
+    from sklearn.decomposition import PCA
+    import h5write
+    T = 2
+    frames = [synthetic.channel_mesh(Lx=1.5, Ly=1.6, h=0.008, cy=0.2, R=0.1, step=s) for s in range(T)]
+    top, obst = frames[0][1], frames[0][2]
+    N = frames[0][0].shape[0]
+    max_cells, max_pts = N + 29, max(len(top), len(obst)) + 7
+    sim = np.full((1, T, max_cells, 8), -100.0, np.float32)
+    for t in range(T):
+        a = frames[t][0]
+        X, Y = a[:, 2], a[:, 3]
+        sim[0, t, :N, 0:2] = a[:, 0:2]; sim[0, t, :N, 2] = a[:, 4]; sim[0, t, :N, 3:5] = a[:, 2:4]
+        sim[0, t, :N, 5] = np.cos(3 * X) * np.sin(2 * Y)
+        sim[0, t, :N, 6] = -0.4 / 1.5 - 0.5 * np.sin(5 * X + 0.15 * t) * (2 * Y / 1.6)      # d/dx of channel_mesh's p
+        sim[0, t, :N, 7] = 0.1 * np.cos(5 * X + 0.15 * t) * (2 / 1.6)                       # d/dy
+    tb = np.full((1, T, max_pts, 2), -100.0, np.float32); ob = tb.copy()
+    tb[0, :, :len(top)] = top; ob[0, :, :len(obst)] = obst
+    h5write.write_h5(os.path.join(directory, "dataset.hdf5"), {"sim_data": sim, "top_bound": tb, "obst_bound": ob})
+    np.savetxt(os.path.join(directory, "maxs"), np.array(GRADP_MAXS))
+    P, PC = 32, 24
+    full = synthetic.make_model("gradp", p_in=P, p_out=P, seed_pca=3030, seed_w=9)
+    model = synthetic.make_model("gradp", p_in=PC, p_out=PC, seed_pca=3030, seed_w=9)
+    model.comp_in, model.comp_out = full.comp_in[:PC], full.comp_out[:PC]
+    model.mean_in, model.mean_out = full.mean_in, full.mean_out
+    np.savetxt(os.path.join(directory, "maxs_PCA"), np.array([model.in_a, model.out_a]))
+    evr = np.array([0.0395] * PC + [0.004] * (P - PC))
+    for stem, comp, mean in (("ipca_input", full.comp_in, full.mean_in), ("ipca_p", full.comp_out, full.mean_out)):
+        o = PCA(n_components=P)
+        o.components_, o.mean_, o.explained_variance_ratio_ = comp, mean, evr
+        with open(os.path.join(directory, stem + ".pkl"), "wb") as f:
+            pickle.dump(o, f)
+    h5write.write_keras_dense(os.path.join(directory, "model.h5"), model.weights)
+    return dict(sim=sim, top=top, obst=obst, N=N, model=model, dataset_path=os.path.join(directory, "dataset.hdf5"),
+                model_path=os.path.join(directory, "model.h5"))

@@ -327,6 +327,29 @@ def run_evaluator_grid(cells, tables, maxs):
                 dPprev_crop=np.asarray(loc["deltaP_prev_grid"])[40:100, 120:200].copy(), U_max_norm=np.float64(loc["U_max_norm"]))
 
 
+def run_evaluator_grid_gradp(cells32, tables, maxs, ext):
+    """Eval_dual_Dense_onlycil.py timeStep from the column split to the rescaled 6-channel grid (:429-467), with the
+    class's own `interpolate_fill` method; tables from the build's geometry step."""
+    tree = _tree(UGP)
+    interp = _method(tree, "Evaluation", "interpolate_fill", {"np": np}, UGP)
+    Ev = type("Ev", (), {"interpolate_fill": interp})
+    me = Ev()
+    me.indice, me.vert, me.weights, me.indices = cells32.shape[0], tables.vtx_m2g, tables.wts_m2g, tables.indices
+    me.sdfunct, me.grid_shape_y, me.grid_shape_x = tables.sdfunct[:, :, None], tables.ny, tables.nx
+    me.min_x, me.max_x, me.min_y, me.max_y = ext
+    me.max_abs_Ux, me.max_abs_Uy, me.max_abs_dist, me.max_abs_dPdx, me.max_abs_dPdy = maxs
+    body = _find_fn(tree, "timeStep", "Evaluation").body
+    i0 = next(i for i, st in enumerate(body) if _src(st).startswith("i = 0"))
+    i1 = next(i for i, st in enumerate(body) if _src(st).startswith("grid[0, :, :, 4:5] = grid[0, :, :, 4:5] / self.max_abs_dPdy"))
+    stmts = [st for st in body[i0:i1 + 1] if "print(" not in _src(st)]
+    loc = {"self": me, "data": cells32[None, None]}
+    with np.errstate(all="ignore"):
+        _run(stmts, {"np": np, "pow": pow}, loc, UGP)
+    g = np.asarray(loc["grid"][0], np.float64)
+    return dict(grid_crop=g[170:230, 60:140].copy(), grid_sum=g.sum(axis=(0, 1)), grid_abs_sum=np.abs(g).sum(axis=(0, 1)),
+                U_max_norm=np.float64(loc["U_max_norm"]))
+
+
 def main():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import cases
@@ -399,6 +422,18 @@ def main():
     out = run_evaluator_grid(np.asarray(dc["sim"][0, 1, :dc["N"]], np.float64), tabs, cases.DATASET_MAXS)
     np.savez_compressed(os.path.join(HERE, "evaluator_grid_138x300.npz"), **out)
     print("evaluator_grid: U_max_norm=%.6f |grid| sums" % out["U_max_norm"], out["grid_abs_sum"])
+
+    # ---- U_to_gradP evaluator front end (UGP:429-467) on frame 1 of its synthetic dataset
+    with tempfile.TemporaryDirectory() as td:
+        gc = cases.build_gradp_dataset_case(td)
+    cells0 = np.asarray(gc["sim"][0, 0, :gc["N"]], np.float64)
+    top32 = np.asarray(gc["top"], np.float32)
+    tabs = geometry.build_geometry_evaluator(cells0[:, 3:5], cells0[:, 5], f32(gc["top"]), f32(gc["obst"]), 5e-3, every=2,
+                                             round_digits=2, box="top")
+    ext = (np.min(top32[:, 0]), np.max(top32[:, 0]), np.min(top32[:, 1]), np.max(top32[:, 1]))
+    out = run_evaluator_grid_gradp(gc["sim"][0, 1, :gc["N"]], tabs, cases.GRADP_MAXS, ext)
+    np.savez_compressed(os.path.join(HERE, "evaluator_grid_gradp_320x300.npz"), **out)
+    print("evaluator_grid_gradp: U_max_norm=%.6f |grid| sums" % out["U_max_norm"], out["grid_abs_sum"])
 
     # ---- pressureSM_Poisson feature builder
     out = run_poisson_features(cases.build_poisson_case())

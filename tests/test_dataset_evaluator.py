@@ -116,3 +116,56 @@ def test_evaluation_from_files_end_to_end(ds):
     h5write.write_h5(p2, {"sim_data": sim2, "top_bound": np.repeat(tb, 3, axis=1), "obst_bound": np.repeat(ob, 3, axis=1)})
     ev.dataset_path = p2
     assert isinstance(ev.timeStep(0, 1, False, False, False, False), int)
+
+
+# ---------------------------------------------------------------------------------------------
+# U_to_gradP evaluator (Eval_dual_Dense_onlycil.py)
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def gds(tmp_path_factory):
+    d = tmp_path_factory.mktemp("artefacts_gradp")
+    return str(d), cases.build_gradp_dataset_case(str(d))
+
+
+def _gradp_tables(c):
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    cells = np.asarray(c["sim"][0, 0, :c["N"]], np.float64)
+    t = geometry.build_geometry_evaluator(cells[:, 3:5], cells[:, 5], f32(c["top"]), f32(c["obst"]), 5e-3, every=2,
+                                          round_digits=2, box="top")
+    top32 = np.asarray(c["top"], np.float32)
+    return t, (np.min(top32[:, 0]), np.max(top32[:, 0]), np.min(top32[:, 1]), np.max(top32[:, 1]))
+
+
+def test_oracle_gradp_front_end_matches_reference_run(gds):
+    d, c = gds
+    gold = cases.load_golden("evaluator_grid_gradp_320x300")
+    t, ext = _gradp_tables(c)
+    assert (t.ny, t.nx) == (320, 300) and (t.sdfunct[200] == 0).sum() > 10       # the obstacle crosses the hard-wired row
+    g, U = orc.evaluator_grid_gradp(c["sim"][0, 1, :c["N"]], t.vtx_m2g, t.wts_m2g, t.indices, t.sdfunct, cases.GRADP_MAXS, *ext)
+    assert U == float(gold["U_max_norm"])
+    np.testing.assert_array_equal(g[170:230, 60:140], gold["grid_crop"])
+    np.testing.assert_allclose(g.sum(axis=(0, 1)), gold["grid_sum"], rtol=1e-13)
+    np.testing.assert_allclose(np.abs(g).sum(axis=(0, 1)), gold["grid_abs_sum"], rtol=1e-13)
+
+
+@pytest.mark.gpu
+def test_gradp_evaluation_from_files_end_to_end(gds):
+    """EvaluationGradP(delta, shape, avance, var_p, var_in, hdf5_path, model_path, max_number_PC): files -> geometry ->
+    6-channel grid -> surrogate (both gradient fields) -> four-quadrant integration, against the oracle chain."""
+    from psm_amd import EvaluationGradP
+    d, c = gds
+    ev = EvaluationGradP(5e-3, 128, 96, 0.95, 0.95, c["dataset_path"], c["model_path"], 128, artifact_dir=d)
+    assert (ev.pc_in, ev.pc_p) == (24, 24) and ev.artifacts.scaler_kind == "max_abs"
+    assert ev.computeOnlyOnce(0) == 0
+    t, ext = _gradp_tables(c)
+    assert (ev.grid_shape_y, ev.grid_shape_x) == (320, 300)
+    p = ev.timeStep(0, 1, False, False, False, False)
+    grid, U = orc.evaluator_grid_gradp(c["sim"][0, 1, :c["N"]], t.vtx_m2g, t.wts_m2g, t.indices, t.sdfunct, cases.GRADP_MAXS, *ext)
+    assert np.abs(ev.grid - grid).max() <= 1e-12 * np.abs(grid).max()
+    sol = orc.solve_grid(grid[..., :3], oracle_model(c["model"]))
+    assert np.abs(ev.gradP - sol.fields).max() <= 1e-4 * np.abs(sol.fields).max()
+    xl = np.linspace(ext[0], ext[1], 300); yl = np.linspace(ext[2], ext[3], 320)
+    cx, cy = orc.integration_center(t.sdfunct, ext[0], ext[1], t.x0, 5e-3)
+    assert (cx, cy) == (ev.center_p_x, ev.center_p_y)
+    ref = orc.integrate_gradp(sol.fields, t.sdfunct, np.diff(xl)[0], np.diff(yl)[0], cy, cx)
+    assert np.abs(p - ref).max() <= 2e-4 * np.abs(ref).max()
