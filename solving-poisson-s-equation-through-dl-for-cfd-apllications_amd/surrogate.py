@@ -291,7 +291,7 @@ def _grid_from_blocks(x_array: np.ndarray, blocks: np.ndarray, ny: int, nx: int)
 
 
 def load_artifacts(variant, model_path, directory, var_p, var_in, max_num_PC, standardization_method, shape, overlap,
-                   c_in: int = 3):
+                   c_in: int = 3, sdf_ch: int = 2):
     """What the reference's ``Evaluation.__init__`` loads (SM_call.py:70-87; Eval_dual_Dense_onlycil.py:51-66):
     ``maxs`` (+ ``maxs_PCA`` for 'max_abs'), the Keras network of ``model_path`` (Dense stack, HDF5), the two
     pickled PCA objects (``ipca_input``, ``ipca_p``: ``.pkl`` like the reference or the ``.npz`` export) with the
@@ -313,6 +313,7 @@ def load_artifacts(variant, model_path, directory, var_p, var_in, max_num_PC, st
     m = SurrogateModel(variant, c_in, c_out, pin.components_[:pc_in], pin.mean_, pout.components_[:pc_p], pout.mean_,
                        list(weights), scaler_kind=standardization_method, S=shape)
     m.ov = int(overlap) if overlap else None                 # deltas: overlap in cells; gradp: `avance`
+    m.sdf_ch = sdf_ch
     if standardization_method == "max_abs":
         mp = formats.read_maxs(os.path.join(directory, "maxs_PCA"))      # Eval_dual_Dense_onlycil.py:52-55
         m.in_a, m.out_a = float(mp[0]), float(mp[1])
@@ -331,7 +332,7 @@ class Evaluation:
     directory (``maxs``, the Keras model, ``ipca_*.pkl``, ``mean_std.npz``)."""
     variant = "deltas"
 
-    c_in_expected = 3
+    c_in_expected, sdf_ch_expected = 3, 2
 
     def __init__(self, delta, shape, overlap, var_p, var_in, dataset_path, model_path, max_num_PC,
                  standardization_method, model: SurrogateModel = None, device: int = 0, artifact_dir: str = None):
@@ -342,7 +343,8 @@ class Evaluation:
             # like the reference: `maxs`, `ipca_input.pkl`, `ipca_p.pkl` and the scaler files are read from
             # the working directory (SM_call.py:70-87, 507-519), the network from model_path (:74-79)
             model, self.maxs = load_artifacts(self.variant, model_path, artifact_dir or os.getcwd(), var_p, var_in,
-                                              max_num_PC, standardization_method, shape, overlap, self.c_in_expected)
+                                              max_num_PC, standardization_method, shape, overlap, self.c_in_expected,
+                                              self.sdf_ch_expected)
         self.delta, self.shape, self.overlap = delta, shape, overlap
         self.var_p, self.var_in, self.dataset_path, self.max_num_PC = var_p, var_in, dataset_path, max_num_PC
         self.standardization_method = standardization_method
@@ -471,17 +473,47 @@ class EvaluationPoisson(Evaluation):
     ``max_abs`` = (max_abs_Poisson_term_1, max_abs_delta_Ux, max_abs_delta_Uy, max_abs_dist, max_abs_delta_p),
     the constants the reference reads from its ``maxs`` file."""
     variant = "deltas"
+    c_in_expected, sdf_ch_expected = 4, 3
 
     def __init__(self, delta, shape, overlap, var_p, var_in, dataset_path, model_path, max_num_PC,
                  standardization_method, k, phis_fn, model: SurrogateModel = None, device: int = 0,
-                 max_abs=(1.0, 1.0, 1.0, 1.0, 1.0)):
+                 max_abs=None, artifact_dir: str = None):
         super().__init__(delta, shape, overlap, var_p, var_in, dataset_path, model_path, max_num_PC,
-                         standardization_method, model, device)
+                         standardization_method, model, device, artifact_dir)
+        model = self.artifacts
         if model.c_in != 4 or model.sdf_ch != 3:
             raise ValueError("the Poisson surrogate takes 4 input channels with the SDF in channel 3")
         self.k, self.phis_fn = k, phis_fn
+        if max_abs is None:                                     # the five values of the `maxs` file (SM_call.py:124)
+            max_abs = self.maxs if self.maxs is not None else (1.0, 1.0, 1.0, 1.0, 1.0)
         (self.max_abs_Poisson_term_1, self.max_abs_delta_Ux, self.max_abs_delta_Uy, self.max_abs_dist,
          self.max_abs_delta_p) = [float(v) for v in max_abs]
+
+    def timeStep(self, sim, time, plot_intermediate_fields=False, save_plots=False, show_plots=False, apply_filter=False,
+                 phi=1.0):
+        """pressureSM_Poisson/SM_call.py:519-848 without plots and error prints: frame (sim, time) of the dataset ->
+        ``field_deltap`` [Ny,Nx] = previous delta-p image + weighted change (:843-848), or 0 for an irrelevant step."""
+        from . import formats
+        if getattr(self, "tables", None) is None:
+            raise RuntimeError("computeOnlyOnce has not been called")
+        data, _, _ = formats.read_dataset(self.dataset_path, sim, time)
+        d = data[0, 0, :self.indice]
+        Ux, Uy, p = d[:, 0:1], d[:, 1:2], d[:, 2:3]
+        delta_U, delta_p = d[:, 5:7], d[:, 7:8]
+        delta_U_prev, delta_p_prev = d[:, 8:10], d[:, 10:11]
+        deltaU_changed = np.abs(delta_U - delta_U_prev).sum(axis=-1)
+        deltaU_changed = deltaU_changed / deltaU_changed.max()
+        U_max_norm = np.max(np.sqrt(np.square(Ux) + np.square(Uy)))
+        deltaU_max_norm = np.max(np.sqrt(np.square(delta_U[:, 0:1]) + np.square(delta_U[:, 1:2])))
+        if (deltaU_max_norm / U_max_norm) < 1e-4 or deltaU_max_norm < 1e-6 or U_max_norm < 1e-6:      # :562-567
+            return 0
+        cols = np.concatenate([Ux, Uy, delta_U, delta_p, p, deltaU_changed[:, None], delta_p_prev], axis=1).astype(np.float64)
+        g = self._mesh_to_grid(cols)                                                                 # :577-600, NaNs kept
+        U = float(U_max_norm)
+        self.U_max_norm = U
+        return self.timeStep_grid(g[..., 0], g[..., 1], g[..., 2], g[..., 3], self.sdfunct[..., 0], phi, U,
+                                  deltaU_change_grid=g[..., 6], deltaP_prev_grid=g[..., 7], apply_filter=apply_filter,
+                                  apply_deltaU_change_wgt=True)                                       # :831
 
     def build_features(self, ux_grid, uy_grid, delta_ux_grid, delta_uy_grid, sdfunct, phi, U_max_norm) -> np.ndarray:
         """SM_call.py:588-711 (after the interpolation to the grid): -> grid [Ny,Nx,4] float32."""

@@ -128,7 +128,10 @@ def build_poisson_case():
 DATASET_MAXS = (0.062, 0.055, 0.31, 0.047)
 
 
-def build_dataset_case(directory: str):
+POISSON_MAXS = (1.7, 0.062, 0.055, 0.31, 0.047)
+
+
+def build_dataset_case(directory: str, poisson: bool = False):
     """Everything `Evaluation(delta, shape, overlap, var_p, var_in, dataset_path, model_path, ...)` reads from
     disk, written into `directory` in the reference's formats (tests/h5write.py for HDF5): the padded
     dataset (1 sim x 3 frames, 11 columns, pad -100), `maxs`, pickled scikit-learn PCA objects, `mean_std.npz`
@@ -150,10 +153,12 @@ def build_dataset_case(directory: str):
     tb = np.full((1, T, max_pts, 2), -100.0, np.float32); ob = tb.copy()
     tb[0, :, :len(top)] = top; ob[0, :, :len(obst)] = obst
     h5write.write_h5(os.path.join(directory, "dataset.hdf5"), {"sim_data": sim, "top_bound": tb, "obst_bound": ob})
-    np.savetxt(os.path.join(directory, "maxs"), np.array(DATASET_MAXS))
+    np.savetxt(os.path.join(directory, "maxs"), np.array(POISSON_MAXS if poisson else DATASET_MAXS))
     P, PC = 32, 24                                               # stored components, components the rule keeps
-    full = synthetic.make_model("deltas", p_in=P, p_out=P, seed_pca=2024, seed_w=3, scaler_kind="std")
-    model = synthetic.make_model("deltas", p_in=PC, p_out=PC, seed_pca=2024, seed_w=3, scaler_kind="std")
+    cin = 4 if poisson else 3
+    full = synthetic.make_model("deltas", p_in=P, p_out=P, seed_pca=2024, seed_w=3, scaler_kind="std", c_in=cin)
+    model = synthetic.make_model("deltas", p_in=PC, p_out=PC, seed_pca=2024, seed_w=3, scaler_kind="std", c_in=cin)
+    model.sdf_ch = 3 if poisson else 2
     model.comp_in, model.comp_out = full.comp_in[:PC], full.comp_out[:PC]
     model.mean_in, model.mean_out = full.mean_in, full.mean_out
     evr = np.array([0.0395] * PC + [0.004] * (P - PC))            # cumulative ratio first exceeds 0.95 at index 24

@@ -169,3 +169,41 @@ def test_gradp_evaluation_from_files_end_to_end(gds):
     assert (cx, cy) == (ev.center_p_x, ev.center_p_y)
     ref = orc.integrate_gradp(sol.fields, t.sdfunct, np.diff(xl)[0], np.diff(yl)[0], cy, cx)
     assert np.abs(p - ref).max() <= 2e-4 * np.abs(ref).max()
+
+
+# ---------------------------------------------------------------------------------------------
+# pressureSM_Poisson evaluator
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_poisson_evaluation_from_files_end_to_end(tmp_path):
+    """EvaluationPoisson(..., k, phis_fn) from files: interpolation of the raw columns (NaNs of interpolate_fill kept),
+    feature image, 4-channel surrogate (mask = channel 3), assembly, deltaU-change weighting (SM_call.py:519-848)."""
+    import scipy.ndimage as ndi
+    from psm_amd import EvaluationPoisson
+    d = str(tmp_path)
+    c = cases.build_dataset_case(d, poisson=True)
+    ev = EvaluationPoisson(5e-3, 128, 32, 0.95, 0.95, c["dataset_path"], c["model_path"], 128, "std", 0.5, None, artifact_dir=d)
+    assert ev.artifacts.c_in == 4 and ev.artifacts.sdf_ch == 3 and ev.max_abs_delta_p == cases.POISSON_MAXS[4]
+    assert ev.computeOnlyOnce(0) == 0
+    got = ev.timeStep(0, 1, False, False, False, False, 0.16)
+    t = _tables(c)
+    cells = c["sim"][0, 1, :c["N"]]
+    idx = tuple(t.indices.T)
+
+    def to_grid(v):
+        g = np.zeros((t.ny, t.nx))
+        g[idx] = orc.interpolate_fill(np.asarray(v).reshape(-1), t.vtx_m2g, t.wts_m2g)
+        return g
+    dU, dUp = cells[:, 5:7], cells[:, 8:10]
+    changed = np.abs(dU - dUp).sum(axis=-1); changed = changed / changed.max()
+    U = float(np.max(np.sqrt(np.square(cells[:, 0:1]) + np.square(cells[:, 1:2]))))
+    grid, _ = orc.poisson_features(to_grid(cells[:, 0]), to_grid(cells[:, 1]), to_grid(dU[:, 0]), to_grid(dU[:, 1]), t.sdfunct,
+                                   0.16, U, 0.5, cases.POISSON_MAXS[:4])
+    om = oracle_model(c["model"])
+    om.out_scale = cases.POISSON_MAXS[4] * U ** 2
+    sol = orc.solve_grid(grid, om)
+    prev, w = to_grid(cells[:, 10]), ndi.gaussian_filter(to_grid(changed), sigma=(50, 50), order=0)
+    want = prev + ndi.gaussian_filter((sol.fields[..., 0] - prev) * w, sigma=(10, 10), order=0)
+    ok = ~np.isnan(want)
+    assert ok.mean() > 0.1 and np.array_equal(np.isnan(got), ~ok)
+    assert np.abs(got[ok] - want[ok]).max() <= 2e-4 * max(np.abs(want[ok]).max(), np.abs(sol.fields).max())
