@@ -431,7 +431,21 @@ class Evaluation:
         self.cfd_results = grid[..., 3] * max_abs_p * pow(U_max_norm, 2.0)               # :580 (float32 square, like the reference)
         self.no_flow_bool = grid[..., 2] == 0
         self.U_max_norm = float(U_max_norm)
+        self._record_errors(res, self.cfd_results, self.no_flow_bool)
         return res
+
+    def _record_errors(self, field, truth, no_flow_bool):
+        """SM_call.py:696-724: normalised bias / squared error of the assembled field over the flow cells,
+        appended to ``pred_minus_true`` / ``pred_minus_true_squared`` (what ``call_SM_main`` averages)."""
+        true_masked, pred_masked = truth[~no_flow_bool], field[~no_flow_bool]
+        norm = np.max(true_masked) - np.min(true_masked)
+        diff = pred_masked - true_masked
+        diff = diff[~np.isnan(diff)]
+        for name in ("pred_minus_true", "pred_minus_true_squared"):
+            if not hasattr(self, name):
+                setattr(self, name, [])
+        self.pred_minus_true.append(np.mean(diff) / norm)
+        self.pred_minus_true_squared.append(np.mean(diff ** 2) / norm ** 2)
 
     def timeStep_grid(self, grid: np.ndarray, U_max_norm: float = 1.0, max_abs_p: float = 1.0) -> np.ndarray:
         """Grid-native body of ``timeStep`` (SM_call.py:452-575): -> deltap_res [Ny,Nx]."""
@@ -464,6 +478,35 @@ class Evaluation:
             change_in_deltap = (result - np.asarray(deltaP_prev_grid, np.float32)) * w
             change_in_deltap = sur.gaussian_filter(change_in_deltap, filter_tuple)
         return result, change_in_deltap
+
+
+def call_SM_main(delta, model_name, shape, overlap_ratio, var_p, var_in, max_num_PC, dataset_path,
+                 plot_intermediate_fields=False, standardization_method="std", save_plots=False, show_plots=False,
+                 apply_filter=False, create_GIF=False, n_sims=1, n_ts=1, device: int = 0, artifact_dir: str = None):
+    """``pressureSM_deltas.SM_call.call_SM_main`` (SM_call.py:778-900): evaluate ``n_ts`` frames of ``n_sims``
+    simulations of the dataset and return the error summary the reference prints -- per simulation and overall
+    BIAS / STDE / RMSE [%] of delta-p over the flow cells (plots and GIFs are not produced)."""
+    overlap = int(overlap_ratio * shape)
+    ev = Evaluation(delta, shape, overlap, var_p, var_in, dataset_path, model_name, max_num_PC, standardization_method,
+                    device=device, artifact_dir=artifact_dir)
+    ev.pred_minus_true, ev.pred_minus_true_squared = [], []
+
+    def summary(b, s):
+        bias, rmse = np.mean(b) * 100, np.sqrt(np.mean(s)) * 100
+        return {"BIAS": float(bias), "RMSE": float(rmse), "STDE": float(np.sqrt(max(rmse ** 2 - bias ** 2, 0.0)))}
+    out = {"sims": []}
+    for sim in range(n_sims):
+        n0 = len(ev.pred_minus_true)
+        ev.computeOnlyOnce(sim)
+        for time in range(n_ts):
+            ev.timeStep(sim, time, plot_intermediate_fields, save_plots, show_plots, apply_filter)
+        if len(ev.pred_minus_true) > n0:
+            out["sims"].append(summary(ev.pred_minus_true[n0:], ev.pred_minus_true_squared[n0:]))
+        else:
+            out["sims"].append(None)                       # every frame of this simulation was irrelevant
+    if ev.pred_minus_true:
+        out["overall"] = summary(ev.pred_minus_true, ev.pred_minus_true_squared)
+    return out
 
 
 class EvaluationPoisson(Evaluation):

@@ -108,6 +108,15 @@ def test_evaluation_from_files_end_to_end(ds):
         sol = orc.solve_grid(grid[..., :3], om)
         assert np.abs(res - sol.fields[..., 0]).max() <= 1e-4 * np.abs(sol.fields).max()
         assert np.abs(ev.cfd_results - grid[..., 3] * cases.DATASET_MAXS[3] * pow(np.float32(U), 2.0)).max() <= 1e-12
+    # the driver with the reference's argument list (SM_call.py:778): same frames, error summary over the flow cells
+    from psm_amd import call_SM_main
+    rep = call_SM_main(5e-3, c["model_path"], 128, 0.25, 0.95, 0.95, 128, c["dataset_path"], False, "std", False, False, False,
+                       False, 1, 3, artifact_dir=d)
+    assert len(rep["sims"]) == 1 and set(rep["overall"]) == {"BIAS", "RMSE", "STDE"}
+    flow = ~ev.no_flow_bool
+    diff = (res - ev.cfd_results)[flow]
+    norm = ev.cfd_results[flow].max() - ev.cfd_results[flow].min()
+    assert np.isclose(ev.pred_minus_true[-1], diff.mean() / norm) and rep["overall"]["RMSE"] > 0
     # a frame whose velocity hardly changed is skipped like SM_call.py:413-421
     sim2 = c["sim"].copy(); sim2[0, 1, :c["N"], 5:7] *= 1e-7
     import h5write
