@@ -1,0 +1,54 @@
+/* psm_unet.h -- C-ABI of the convolutional surrogate path (libpsm_hip.so).
+ *
+ * The project's north star names a CNN / U-Net forward pass (Conv2D + bias + ReLU, 2x2 max-pool, 2x
+ * nearest-neighbour upsample, skip concatenation, 1x1 head).  The reference repository contains NO such
+ * network -- its CNN folders are empty placeholders (Thesis_Work/Chapter4/README.md:3) and the model named
+ * "U-Net" at Thesis_Work/Chapter5/parallelized/test_case/python_module.py:131 is a Dense stack -- so there is
+ * no reference interface to cite line by line and PARITY IS UNPINNED: the network is the build-defined "UNet-S"
+ * of SURVEY.md §8 (row a-conv) / oracle/unet_oracle.py.  What the entry points keep from the reference is the
+ * calling convention of its Keras models: NHWC float32 images in, NHWC float32 images out, kernels in Keras'
+ * Conv2D layout [kh, kw, c_in, c_out] with 'same' zero padding (the layout `model.load_weights` /
+ * `load_model` would deliver, python_module.py:170, SM_call.py:74-79), normalised grid images exactly like
+ * those psm_solve_grid takes (python_module.py:288-297).
+ *
+ * Network: levels l = 0..L-1 with widths w_l; encoder level = [2x2 max-pool] conv3x3+ReLU conv3x3+ReLU;
+ * decoder level = concat(upsample2x(below), encoder_l) conv3x3+ReLU conv3x3+ReLU; head = conv1x1, linear.
+ * Convolution index order (psm_unet_conv_shape / psm_unet_set_conv): enc0a, enc0b, enc1a, ... enc{L-1}b,
+ * dec{L-2}a, dec{L-2}b, ... dec0a, dec0b, head.  Status codes and error text as in psm.h. */
+#ifndef PSM_UNET_H
+#define PSM_UNET_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct psm_unet psm_unet;
+
+/* widths[n_levels]: channel counts per level (multiples of 16, <= 1024); c_in 1..16, c_out 1..16. */
+int psm_unet_create(int32_t c_in, int32_t c_out, int32_t n_levels, const int32_t* widths, int32_t device, psm_unet** out);
+void psm_unet_destroy(psm_unet* u);
+const char* psm_unet_last_error(const psm_unet* u);
+int psm_unet_num_convs(const psm_unet* u);
+/* kernel edge (3 or 1), input and output channels of convolution `idx`. */
+int psm_unet_conv_shape(const psm_unet* u, int32_t idx, int32_t* k, int32_t* c_in, int32_t* c_out);
+/* weight [k, k, c_in, c_out] float32 (Keras Conv2D kernel), bias [c_out]. */
+int psm_unet_set_conv(psm_unet* u, int32_t idx, const float* weight, const float* bias);
+/* Fixes the image size (ny, nx multiples of 2^(n_levels-1)) and the largest case batch; allocates activations. */
+int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases);
+/* Host buffers: grid [n, ny, nx, c_in] -> field [n, ny, nx, c_out], synchronous. */
+int psm_unet_forward(psm_unet* u, const float* grid, int32_t n_cases, float* field);
+/* Device buffers, asynchronous on `stream` (hipStream_t; NULL = the handle's stream). */
+int psm_unet_forward_device(psm_unet* u, const float* d_grid, int32_t n_cases, float* d_field, void* stream);
+int psm_unet_synchronize(psm_unet* u);
+/* Output activation of convolution `idx` of the last forward pass (introspection for parity tests):
+ * dst [n_cases * (ny >> level) * (nx >> level) * c_out] floats. */
+int psm_unet_read_activation(psm_unet* u, int32_t idx, float* dst, int64_t dst_floats);
+/* Algorithmic work of one forward pass of one case at the planned size. */
+int64_t psm_unet_flops(const psm_unet* u);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -3,7 +3,8 @@
 The directory name carries hyphens (it is fixed by the project layout), so the
 package is imported through the root-level alias module ``psm_amd``.
 """
-from . import _lib, dist, formats, geometry, hostinfo, surrogate, synthetic  # noqa: F401
+from . import _lib, dist, formats, geometry, hostinfo, surrogate, synthetic, unet  # noqa: F401
+from .unet import UNetSurrogate  # noqa: F401
 from .surrogate import Evaluation, EvaluationGradP, EvaluationPoisson, GridSurrogate, SolverModule, call_SM_main  # noqa: F401
 from .synthetic import SurrogateModel  # noqa: F401
 

@@ -13,6 +13,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PSM_LIB") or os.path.join(HERE, "libpsm_hip.so")   # PSM_LIB: diagnostic builds only
 HEADER = os.path.join(os.path.dirname(HERE), "include", "psm.h")
+HEADER_UNET = os.path.join(os.path.dirname(HERE), "include", "psm_unet.h")
 
 PSM_ABI_VERSION = 2
 VARIANTS = {"chapter5": 0, "deltas": 1, "gradp": 2}
@@ -78,6 +79,24 @@ SIGNATURES = {
     "psm_abi_version": (C.c_int, []),
 }
 
+# include/psm_unet.h (convolutional path)
+_up = C.c_void_p
+_i32ptr = C.POINTER(C.c_int32)
+SIGNATURES_UNET = {
+    "psm_unet_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _i32ptr, C.c_int32, C.POINTER(_up)]),
+    "psm_unet_destroy": (None, [_up]),
+    "psm_unet_last_error": (C.c_char_p, [_up]),
+    "psm_unet_num_convs": (C.c_int, [_up]),
+    "psm_unet_conv_shape": (C.c_int, [_up, C.c_int32, _i32ptr, _i32ptr, _i32ptr]),
+    "psm_unet_set_conv": (C.c_int, [_up, C.c_int32, _f32p, _f32p]),
+    "psm_unet_plan": (C.c_int, [_up, C.c_int32, C.c_int32, C.c_int32]),
+    "psm_unet_forward": (C.c_int, [_up, _f32p, C.c_int32, _f32p]),
+    "psm_unet_forward_device": (C.c_int, [_up, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "psm_unet_synchronize": (C.c_int, [_up]),
+    "psm_unet_read_activation": (C.c_int, [_up, C.c_int32, _f32p, C.c_int64]),
+    "psm_unet_flops": (C.c_int64, [_up]),
+}
+
 _lib = None
 
 
@@ -94,7 +113,7 @@ def load():
         lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     except OSError as e:
         raise PsmLibraryError(f"cannot load {LIB_PATH}: {e}") from e
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(SIGNATURES_UNET.items()):
         try:
             fn = getattr(lib, name)
         except AttributeError as e:

@@ -1,0 +1,31 @@
+// psm_unet.h -- launchers of the convolutional surrogate path (SURVEY.md §8 row a-conv; see psm_unet.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+enum { PSM_SRC_SAME = 0, PSM_SRC_UPSAMPLE = 1, PSM_SRC_MAXPOOL = 2 };
+
+struct PsmConvArgs {
+  const float* in0;            // primary input, NHWC: [H][W][c0] (SAME), [H/2][W/2][c0] (UPSAMPLE), [2H][2W][c0] (MAXPOOL)
+  const float* in1;            // optional skip input [H][W][c1], concatenated AFTER in0's channels (c1 = 0: none)
+  const float4* wpack;         // [co_group][chunk][tap 9][ct NCT][lane 64] float4, see pack_conv3x3 (psm_unet_api.cpp)
+  const float* bias;           // [cout_pad]
+  float* out;                  // [H][W][cout]
+  int c0, c1, n_chunks;        // channel chunks of 16 over the concatenated, zero-padded input
+  int mode0;
+  int H, W;                    // resolution of the convolution (its output)
+  int H0, W0;                  // resolution of in0
+  int cout, relu;
+  int64_t in0_case, in1_case, out_case;   // per-case strides (elements)
+};
+
+struct PsmHeadArgs {           // 1x1 convolution on a thin activation (c_in <= 64), linear
+  const float* in; const float* w; const float* bias; float* out;   // w [c_in][c_out]
+  int64_t n_pix; int c_in, c_out;
+};
+
+// arrangement: 0 = pixel-major (8 rows x 16 columns per workgroup, each wave 2 rows x NCT channel tiles),
+//              1 = channel-major (2 rows x 16 columns, 4 waves = 4 channel tiles of 16)
+hipError_t psm_launch_conv3x3(const PsmConvArgs& a, int arrangement, int nct, int n_cases, hipStream_t st);
+hipError_t psm_launch_head1x1(const PsmHeadArgs& a, hipStream_t st);

@@ -1,0 +1,289 @@
+// psm_unet_api.cpp -- handle, layer schedule, weight packing and C-ABI of the convolutional path
+// (include/psm_unet.h; kernels in psm_unet.hip).
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/psm.h"
+#include "../../include/psm_unet.h"
+#include "psm_unet.h"
+
+namespace {
+struct Conv {
+  int k = 3, cin = 0, cout = 0, level = 0;
+  int src = 0;          // 0 input image, 1 previous conv, 2 max-pool of previous conv, 3 upsample(previous) ++ skip
+  int skip = -1;        // conv index whose output is concatenated (src == 3)
+  int relu = 1;
+  // launch configuration and packed operands
+  int arrangement = 0, nct = 1, n_chunks = 0, groups = 1;
+  std::vector<float> W, b;     // host copies (HWIO), kept for re-packing at plan time
+  bool set = false;
+  float4* d_w = nullptr;
+  float* d_b = nullptr;
+  float* d_w1 = nullptr;       // head: [cin][cout]
+  float* d_out = nullptr;      // [max_cases][H][W][cout]
+};
+thread_local std::string g_err;
+}  // namespace
+
+struct psm_unet {
+  int c_in = 0, c_out = 0, L = 0, device = 0;
+  std::vector<int> widths;
+  std::vector<Conv> convs;
+  int ny = 0, nx = 0, max_cases = 0, last_cases = 0;
+  bool planned = false;
+  float *d_in = nullptr, *d_field = nullptr, *h_in = nullptr, *h_out = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+};
+
+namespace {
+int fail(psm_unet* u, int code, const std::string& m) { if (u) u->err = m; else g_err = m; return code; }
+#define UCHK(u, expr)                                                                                   \
+  do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail((u), PSM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+void free_dev(void* p) { if (p) (void)hipFree(p); }
+
+// MFMA operand order: wpack[cog][chunk g][tap][ct][lane][j] = W[tap][16g + 4*(lane>>4) + j][16*(cog*nct + ct) + (lane&15)]
+std::vector<float> pack_conv3x3(const Conv& c) {
+  const int chunks = c.n_chunks, nct = c.nct, groups = c.groups;
+  std::vector<float> p((size_t)groups * chunks * 9 * nct * 64 * 4, 0.f);
+  for (int cog = 0; cog < groups; ++cog)
+    for (int g = 0; g < chunks; ++g)
+      for (int tap = 0; tap < 9; ++tap)
+        for (int ct = 0; ct < nct; ++ct)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 4; ++j) {
+              const int ci = 16 * g + 4 * (lane >> 4) + j, co = 16 * (cog * nct + ct) + (lane & 15);
+              if (ci < c.cin && co < c.cout)
+                p[(((((size_t)cog * chunks + g) * 9 + tap) * nct + ct) * 64 + lane) * 4 + j] =
+                    c.W[((size_t)tap * c.cin + ci) * c.cout + co];
+            }
+  return p;
+}
+
+// workgroup count first (fill 256 CUs), then the most reuse per workgroup
+void choose_config(Conv& c, int H, int W) {
+  const int ctiles = (c.cout + 15) / 16;
+  struct Cand { int arr, nct, th; };
+  const Cand cands[4] = {{0, 4, 8}, {0, 2, 8}, {0, 1, 8}, {1, 4, 2}};
+  long best_score = -1;
+  for (const Cand& k : cands) {
+    if (k.nct > ctiles) continue;                       // never compute padded channel tiles
+    const int groups = (ctiles + k.nct - 1) / k.nct;
+    const long wgs = (long)((W + 15) / 16) * ((H + k.th - 1) / k.th) * groups;
+    const long reuse = (long)k.nct * k.th;
+    const long score = wgs >= 256 ? 1000000 + reuse * 1000 + (k.arr ? 1 : 0) : wgs * 10 + (k.arr ? 1 : 0);
+    if (score > best_score) { best_score = score; c.arrangement = k.arr; c.nct = k.nct; c.groups = groups; }
+  }
+  c.n_chunks = (c.cin + 15) / 16;
+}
+
+int upload_conv(psm_unet* u, Conv& c) {
+  free_dev(c.d_w); c.d_w = nullptr; free_dev(c.d_b); c.d_b = nullptr; free_dev(c.d_w1); c.d_w1 = nullptr;
+  std::vector<float> bias((size_t)((c.cout + 15) / 16 + 4) * 16, 0.f);
+  std::memcpy(bias.data(), c.b.data(), c.cout * sizeof(float));
+  UCHK(u, hipMalloc((void**)&c.d_b, bias.size() * sizeof(float)));
+  UCHK(u, hipMemcpy(c.d_b, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+  if (c.k == 3) {
+    const std::vector<float> p = pack_conv3x3(c);
+    UCHK(u, hipMalloc((void**)&c.d_w, p.size() * sizeof(float)));
+    UCHK(u, hipMemcpy(c.d_w, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
+  } else {
+    UCHK(u, hipMalloc((void**)&c.d_w1, c.W.size() * sizeof(float)));
+    UCHK(u, hipMemcpy(c.d_w1, c.W.data(), c.W.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  return PSM_OK;
+}
+
+int forward(psm_unet* u, const float* d_grid, int n, float* d_field, hipStream_t st) {
+  for (size_t i = 0; i < u->convs.size(); ++i) {
+    Conv& c = u->convs[i];
+    const int H = u->ny >> c.level, W = u->nx >> c.level;
+    float* out = (i + 1 == u->convs.size()) ? d_field : c.d_out;
+    if (c.k == 1) {
+      PsmHeadArgs ha{u->convs[i - 1].d_out, c.d_w1, c.d_b, out, (int64_t)n * H * W, c.cin, c.cout};
+      UCHK(u, psm_launch_head1x1(ha, st));
+      continue;
+    }
+    PsmConvArgs a{};
+    a.wpack = c.d_w; a.bias = c.d_b; a.out = out; a.n_chunks = c.n_chunks; a.H = H; a.W = W; a.cout = c.cout; a.relu = c.relu;
+    a.out_case = (int64_t)H * W * c.cout;
+    if (c.src == 0) { a.in0 = d_grid; a.c0 = c.cin; a.mode0 = PSM_SRC_SAME; a.H0 = H; a.W0 = W; }
+    else {
+      const Conv& pv = u->convs[i - 1];
+      a.in0 = pv.d_out; a.c0 = pv.cout;
+      if (c.src == 1) { a.mode0 = PSM_SRC_SAME; a.H0 = H; a.W0 = W; }
+      else if (c.src == 2) { a.mode0 = PSM_SRC_MAXPOOL; a.H0 = 2 * H; a.W0 = 2 * W; }
+      else { a.mode0 = PSM_SRC_UPSAMPLE; a.H0 = H / 2; a.W0 = W / 2; a.in1 = u->convs[c.skip].d_out; a.c1 = u->convs[c.skip].cout;
+             a.in1_case = (int64_t)H * W * a.c1; }
+    }
+    a.in0_case = (int64_t)a.H0 * a.W0 * a.c0;
+    UCHK(u, psm_launch_conv3x3(a, c.arrangement, c.nct, n, st));
+  }
+  u->last_cases = n;
+  return PSM_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char* psm_unet_last_error(const psm_unet* u) { return u ? u->err.c_str() : g_err.c_str(); }
+
+int psm_unet_create(int32_t c_in, int32_t c_out, int32_t n_levels, const int32_t* widths, int32_t device, psm_unet** out) {
+  if (!out || !widths) return fail(nullptr, PSM_ERR_ARG, "null argument");
+  *out = nullptr;
+  if (c_in < 1 || c_in > 16 || c_out < 1 || c_out > 16) return fail(nullptr, PSM_ERR_ARG, "c_in / c_out must be 1..16");
+  if (n_levels < 2 || n_levels > 7) return fail(nullptr, PSM_ERR_ARG, "n_levels must be 2..7");
+  for (int l = 0; l < n_levels; ++l)
+    if (widths[l] < 16 || widths[l] > 1024 || widths[l] % 16) return fail(nullptr, PSM_ERR_ARG, "widths must be multiples of 16 in [16, 1024]");
+  if (widths[0] > 64) return fail(nullptr, PSM_ERR_ARG, "first-level width above 64 is not supported by the 1x1 head");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, PSM_ERR_NO_DEVICE, "no HIP device: the convolutional path has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(nullptr, PSM_ERR_ARG, "device ordinal out of range");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(nullptr, PSM_ERR_HIP, "hipGetDeviceProperties failed");
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    return fail(nullptr, PSM_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+  psm_unet* u = new psm_unet();
+  u->c_in = c_in; u->c_out = c_out; u->L = n_levels; u->device = device;
+  u->widths.assign(widths, widths + n_levels);
+  std::vector<int> enc_last(n_levels);
+  for (int l = 0; l < n_levels; ++l) {
+    Conv a; a.cin = l == 0 ? c_in : widths[l - 1]; a.cout = widths[l]; a.level = l; a.src = l == 0 ? 0 : 2;
+    Conv b; b.cin = widths[l]; b.cout = widths[l]; b.level = l; b.src = 1;
+    u->convs.push_back(a); u->convs.push_back(b);
+    enc_last[l] = (int)u->convs.size() - 1;
+  }
+  for (int l = n_levels - 2; l >= 0; --l) {
+    Conv a; a.cin = widths[l + 1] + widths[l]; a.cout = widths[l]; a.level = l; a.src = 3; a.skip = enc_last[l];
+    Conv b; b.cin = widths[l]; b.cout = widths[l]; b.level = l; b.src = 1;
+    u->convs.push_back(a); u->convs.push_back(b);
+  }
+  Conv h; h.k = 1; h.cin = widths[0]; h.cout = c_out; h.level = 0; h.src = 1; h.relu = 0;
+  u->convs.push_back(h);
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&u->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete u;
+    return fail(nullptr, PSM_ERR_HIP, "cannot create a stream on the device");
+  }
+  *out = u;
+  return PSM_OK;
+}
+
+void psm_unet_destroy(psm_unet* u) {
+  if (!u) return;
+  (void)hipSetDevice(u->device);
+  if (u->stream) (void)hipStreamSynchronize(u->stream);
+  for (Conv& c : u->convs) { free_dev(c.d_w); free_dev(c.d_b); free_dev(c.d_w1); free_dev(c.d_out); }
+  free_dev(u->d_in); free_dev(u->d_field);
+  if (u->h_in) (void)hipHostFree(u->h_in);
+  if (u->h_out) (void)hipHostFree(u->h_out);
+  if (u->stream) (void)hipStreamDestroy(u->stream);
+  delete u;
+}
+
+int psm_unet_num_convs(const psm_unet* u) { return u ? (int)u->convs.size() : PSM_ERR_ARG; }
+
+int psm_unet_conv_shape(const psm_unet* u, int32_t idx, int32_t* k, int32_t* c_in, int32_t* c_out) {
+  if (!u || idx < 0 || idx >= (int)u->convs.size() || !k || !c_in || !c_out) return PSM_ERR_ARG;
+  *k = u->convs[idx].k; *c_in = u->convs[idx].cin; *c_out = u->convs[idx].cout;
+  return PSM_OK;
+}
+
+int psm_unet_set_conv(psm_unet* u, int32_t idx, const float* weight, const float* bias) {
+  if (!u) return PSM_ERR_ARG;
+  if (idx < 0 || idx >= (int)u->convs.size()) return fail(u, PSM_ERR_ARG, "convolution index out of range");
+  if (!weight || !bias) return fail(u, PSM_ERR_ARG, "null weights");
+  Conv& c = u->convs[idx];
+  c.W.assign(weight, weight + (size_t)c.k * c.k * c.cin * c.cout);
+  c.b.assign(bias, bias + c.cout);
+  c.set = true;
+  if (u->planned) { UCHK(u, hipSetDevice(u->device)); return upload_conv(u, c); }
+  return PSM_OK;
+}
+
+int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
+  if (!u) return PSM_ERR_ARG;
+  for (const Conv& c : u->convs) if (!c.set) return fail(u, PSM_ERR_STATE, "model incomplete: call psm_unet_set_conv for every convolution first");
+  const int m = 1 << (u->L - 1);
+  if (ny < m || nx < m || ny % m || nx % m) return fail(u, PSM_ERR_ARG, "ny and nx must be multiples of 2^(n_levels-1)");
+  if (max_cases < 1 || (int64_t)ny * nx * max_cases > ((int64_t)1 << 28)) return fail(u, PSM_ERR_ARG, "bad case batch");
+  UCHK(u, hipSetDevice(u->device));
+  UCHK(u, hipStreamSynchronize(u->stream));
+  u->ny = ny; u->nx = nx; u->max_cases = max_cases;
+  for (Conv& c : u->convs) {
+    const int H = ny >> c.level, W = nx >> c.level;
+    if (c.k == 3) choose_config(c, H, W);
+    int rc = upload_conv(u, c);
+    if (rc) return rc;
+    free_dev(c.d_out); c.d_out = nullptr;
+    UCHK(u, hipMalloc((void**)&c.d_out, (size_t)max_cases * H * W * c.cout * sizeof(float)));
+  }
+  free_dev(u->d_in); free_dev(u->d_field);
+  if (u->h_in) { (void)hipHostFree(u->h_in); u->h_in = nullptr; }
+  if (u->h_out) { (void)hipHostFree(u->h_out); u->h_out = nullptr; }
+  const size_t npix = (size_t)ny * nx * max_cases;
+  UCHK(u, hipMalloc((void**)&u->d_in, npix * u->c_in * sizeof(float)));
+  UCHK(u, hipMalloc((void**)&u->d_field, npix * u->c_out * sizeof(float)));
+  UCHK(u, hipHostMalloc((void**)&u->h_in, npix * u->c_in * sizeof(float), hipHostMallocDefault));
+  UCHK(u, hipHostMalloc((void**)&u->h_out, npix * u->c_out * sizeof(float), hipHostMallocDefault));
+  u->planned = true;
+  return PSM_OK;
+}
+
+int psm_unet_forward_device(psm_unet* u, const float* d_grid, int32_t n_cases, float* d_field, void* stream) {
+  if (!u) return PSM_ERR_ARG;
+  if (!u->planned) return fail(u, PSM_ERR_STATE, "psm_unet_plan has not been called");
+  if (!d_grid || !d_field) return fail(u, PSM_ERR_ARG, "null buffer");
+  if (n_cases < 1 || n_cases > u->max_cases) return fail(u, PSM_ERR_ARG, "n_cases outside [1, max_cases]");
+  UCHK(u, hipSetDevice(u->device));
+  return forward(u, d_grid, n_cases, d_field, stream ? (hipStream_t)stream : u->stream);
+}
+
+int psm_unet_forward(psm_unet* u, const float* grid, int32_t n_cases, float* field) {
+  if (!u) return PSM_ERR_ARG;
+  if (!u->planned) return fail(u, PSM_ERR_STATE, "psm_unet_plan has not been called");
+  if (!grid || !field) return fail(u, PSM_ERR_ARG, "null buffer");
+  if (n_cases < 1 || n_cases > u->max_cases) return fail(u, PSM_ERR_ARG, "n_cases outside [1, max_cases]");
+  UCHK(u, hipSetDevice(u->device));
+  const size_t npix = (size_t)u->ny * u->nx * n_cases;
+  std::memcpy(u->h_in, grid, npix * u->c_in * sizeof(float));
+  UCHK(u, hipMemcpyAsync(u->d_in, u->h_in, npix * u->c_in * sizeof(float), hipMemcpyHostToDevice, u->stream));
+  int rc = forward(u, u->d_in, n_cases, u->d_field, u->stream);
+  if (rc) return rc;
+  UCHK(u, hipMemcpyAsync(u->h_out, u->d_field, npix * u->c_out * sizeof(float), hipMemcpyDeviceToHost, u->stream));
+  UCHK(u, hipStreamSynchronize(u->stream));
+  std::memcpy(field, u->h_out, npix * u->c_out * sizeof(float));
+  return PSM_OK;
+}
+
+int psm_unet_synchronize(psm_unet* u) {
+  if (!u) return PSM_ERR_ARG;
+  UCHK(u, hipSetDevice(u->device));
+  UCHK(u, hipStreamSynchronize(u->stream));
+  return PSM_OK;
+}
+
+int psm_unet_read_activation(psm_unet* u, int32_t idx, float* dst, int64_t dst_floats) {
+  if (!u || !dst) return PSM_ERR_ARG;
+  if (!u->planned || u->last_cases < 1) return fail(u, PSM_ERR_STATE, "no forward pass yet");
+  if (idx < 0 || idx + 1 >= (int)u->convs.size()) return fail(u, PSM_ERR_ARG, "activation index out of range (the head's output is the field)");
+  const Conv& c = u->convs[idx];
+  const int64_t n = (int64_t)u->last_cases * (u->ny >> c.level) * (u->nx >> c.level) * c.cout;
+  if (dst_floats < n) return fail(u, PSM_ERR_ARG, "destination too small");
+  UCHK(u, hipSetDevice(u->device));
+  UCHK(u, hipStreamSynchronize(u->stream));
+  UCHK(u, hipMemcpy(dst, c.d_out, n * sizeof(float), hipMemcpyDeviceToHost));
+  return PSM_OK;
+}
+
+int64_t psm_unet_flops(const psm_unet* u) {
+  if (!u || !u->planned) return 0;
+  int64_t t = 0;
+  for (const Conv& c : u->convs) t += 2LL * (u->ny >> c.level) * (u->nx >> c.level) * c.k * c.k * c.cin * c.cout;
+  return t;
+}
+
+}  // extern "C"

@@ -1,0 +1,116 @@
+"""Host-side mirror of the convolutional surrogate path (include/psm_unet.h) -- the CNN / U-Net forward pass the
+project's north star names.  The reference repository has no such network, so the class
+follows the calling convention of the reference's Keras models (NHWC float32 images, Conv2D kernels
+[kh, kw, c_in, c_out], 'same' padding) and the build-defined UNet-S layer list of oracle/unet_oracle.py.
+Everything numeric runs in the HIP library; there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+
+from . import _lib
+
+WIDTHS_S = (16, 32, 64, 128, 256)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a, t=C.c_float):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class UNetSurrogate:
+    """weights: [(kernel[k,k,c_in,c_out] f32, bias[c_out] f32)] in the order enc0a, enc0b, ..., dec0a, dec0b, head."""
+
+    def __init__(self, weights, ny: int, nx: int, c_in: int = 3, c_out: int = 1, widths: Sequence[int] = WIDTHS_S,
+                 max_cases: int = 1, device: int = 0):
+        self.lib = _lib.load()
+        self.ny, self.nx, self.c_in, self.c_out, self.max_cases = int(ny), int(nx), int(c_in), int(c_out), int(max_cases)
+        w = np.ascontiguousarray(widths, np.int32)
+        h = C.c_void_p()
+        rc = self.lib.psm_unet_create(c_in, c_out, len(w), _p(w, C.c_int32), device, C.byref(h))
+        if rc:
+            raise _lib.PsmError(rc, (self.lib.psm_unet_last_error(None) or b"").decode())
+        self.h = h
+        try:
+            n = self.lib.psm_unet_num_convs(self.h)
+            if len(weights) != n:
+                raise ValueError(f"{n} convolutions expected, {len(weights)} given")
+            self.shapes = []
+            for i, (W, b) in enumerate(weights):
+                k, ci, co = C.c_int32(), C.c_int32(), C.c_int32()
+                self._chk(self.lib.psm_unet_conv_shape(self.h, i, C.byref(k), C.byref(ci), C.byref(co)))
+                if tuple(np.shape(W)) != (k.value, k.value, ci.value, co.value) or tuple(np.shape(b)) != (co.value,):
+                    raise ValueError(f"convolution {i}: kernel {np.shape(W)} / bias {np.shape(b)}, expected "
+                                     f"{(k.value, k.value, ci.value, co.value)} / {(co.value,)}")
+                self.shapes.append((k.value, ci.value, co.value))
+                self._chk(self.lib.psm_unet_set_conv(self.h, i, _p(_f32(W)), _p(_f32(b))))
+            self._chk(self.lib.psm_unet_plan(self.h, self.ny, self.nx, self.max_cases))
+        except Exception:
+            self.close()
+            raise
+
+    def _chk(self, rc):
+        if rc:
+            raise _lib.PsmError(rc, (self.lib.psm_unet_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.psm_unet_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def forward(self, grid: np.ndarray) -> np.ndarray:
+        """grid [Ny,Nx,c_in] or [n,Ny,Nx,c_in] -> field [n,Ny,Nx,c_out] float32."""
+        g = np.asarray(grid)
+        if g.ndim == 3:
+            g = g[None]
+        if g.ndim != 4 or g.shape[1:] != (self.ny, self.nx, self.c_in):
+            raise ValueError(f"grid must be [n,{self.ny},{self.nx},{self.c_in}]")
+        g = _f32(g)
+        out = np.empty((g.shape[0], self.ny, self.nx, self.c_out), np.float32)
+        self._chk(self.lib.psm_unet_forward(self.h, _p(g), g.shape[0], _p(out)))
+        return out
+
+    def forward_device(self, d_grid: int, n_cases: int, d_field: int, stream: int = 0):
+        self._chk(self.lib.psm_unet_forward_device(self.h, d_grid, n_cases, d_field, stream))
+
+    def synchronize(self):
+        self._chk(self.lib.psm_unet_synchronize(self.h))
+
+    def activation(self, idx: int, n_cases: int = 1) -> np.ndarray:
+        """Output of convolution ``idx`` of the last forward pass -> [n, H_l, W_l, c_out]."""
+        k, ci, co = self.shapes[idx]
+        level = self._level(idx)
+        shape = (n_cases, self.ny >> level, self.nx >> level, co)
+        out = np.empty(shape, np.float32)
+        self._chk(self.lib.psm_unet_read_activation(self.h, idx, _p(out), out.size))
+        return out
+
+    def _level(self, idx: int) -> int:
+        L = (len(self.shapes) - 1 + 2) // 4 + 0          # 2L + 2(L-1) + 1 convolutions
+        L = (len(self.shapes) + 1) // 4
+        if idx < 2 * L:
+            return idx // 2
+        if idx == len(self.shapes) - 1:
+            return 0
+        return L - 2 - (idx - 2 * L) // 2
+
+    @property
+    def flops(self) -> int:
+        return int(self.lib.psm_unet_flops(self.h))

@@ -8,8 +8,8 @@ import pytest
 from psm_amd import _lib
 
 
-def declared_functions():
-    txt = open(_lib.HEADER).read()
+def declared_functions(header=None):
+    txt = open(header or _lib.HEADER).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(psm_[a-z_0-9]+)\s*\(", txt)))
 
@@ -20,9 +20,14 @@ def test_header_and_binding_agree():
     assert sorted(_lib.SIGNATURES) == names
 
 
+def test_unet_header_and_binding_agree():
+    names = declared_functions(_lib.HEADER_UNET)
+    assert names and sorted(_lib.SIGNATURES_UNET) == names
+
+
 def test_library_exports_every_declared_symbol():
     lib = _lib.load()
-    for name in declared_functions():
+    for name in declared_functions() + declared_functions(_lib.HEADER_UNET):
         assert hasattr(lib, name), name
     assert lib.psm_abi_version() == _lib.PSM_ABI_VERSION
 

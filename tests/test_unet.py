@@ -1,0 +1,86 @@
+"""Convolutional surrogate path (SURVEY.md §8 row a-conv; parity UNPINNED: the reference has no such network).
+CPU: the NumPy oracle of the build-defined UNet-S against torch's conv2d / max_pool2d / interpolate.
+GPU: the HIP kernels (psm_unet_*, through the C-ABI) against the oracle, layer by layer and end to end.
+
+Tolerance: the device computes exact float32 products with float32 accumulation (v_mfma_f32_16x16x4_f32), the
+oracle accumulates in float64 and rounds every activation to float32: per-layer max-abs <= 2e-5 * max|activation|,
+final field <= 1e-4 * max|field| (19 layers deep)."""
+import numpy as np
+import pytest
+
+from oracle import unet_oracle as uo
+from psm_amd import synthetic
+
+
+def _torch_forward(g, W):
+    import torch
+    import torch.nn.functional as F
+    x = torch.from_numpy(g).permute(2, 0, 1)[None]
+
+    def conv(x, i, relu):
+        w, b = W[i]
+        y = F.conv2d(x, torch.from_numpy(w).permute(3, 2, 0, 1), torch.from_numpy(b), padding=w.shape[0] // 2)
+        return F.relu(y) if relu else y
+    enc, i = [], 0
+    for l in range(5):
+        if l > 0:
+            x = F.max_pool2d(x, 2)
+        x = conv(x, i, True); x = conv(x, i + 1, True); i += 2
+        enc.append(x)
+    for l in range(3, -1, -1):
+        x = torch.cat([F.interpolate(x, scale_factor=2, mode="nearest"), enc[l]], 1)
+        x = conv(x, i, True); x = conv(x, i + 1, True); i += 2
+    return conv(x, i, False)[0].permute(1, 2, 0).numpy()
+
+
+def test_spec_and_flops():
+    specs = uo.unet_specs()
+    assert len(specs) == 19 and [s.name for s in specs][:4] == ["enc0a", "enc0b", "enc1a", "enc1b"]
+    assert specs[10].name == "dec3a" and specs[10].c_in == 256 + 128 and specs[-1].k == 1
+    assert abs(uo.unet_flops(256, 256) / 1e9 - 7.0) < 0.01                  # 7.0 GFLOP per solve
+
+
+def test_oracle_matches_torch_cpu():
+    W = uo.he_weights(uo.unet_specs(), seed=7)
+    g = synthetic.channel_grid(64, 96, seed=3).astype(np.float32)
+    y = uo.unet_forward(g, W)
+    t = _torch_forward(g, W)
+    assert y.shape == (64, 96, 1)
+    assert np.abs(y - t).max() <= 2e-5 * np.abs(t).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ny,nx,n", [(256, 256, 1), (96, 160, 2), (16, 48, 1)])
+def test_gpu_unet_matches_oracle_layer_by_layer(ny, nx, n):
+    from psm_amd import UNetSurrogate
+    specs = uo.unet_specs()
+    W = uo.he_weights(specs, seed=11)
+    grids = np.stack([synthetic.channel_grid(ny, nx, seed=20 + k).astype(np.float32) for k in range(n)])
+    with UNetSurrogate(W, ny, nx, max_cases=n) as net:
+        assert net.flops == uo.unet_flops(ny, nx)
+        out = net.forward(grids)
+        assert out.shape == (n, ny, nx, 1)
+        for k in range(n):
+            ref, acts = uo.unet_forward(grids[k], W, return_all=True)
+            for i in range(len(specs) - 1):
+                a = net.activation(i, n)[k]
+                assert a.shape == acts[i].shape, specs[i].name
+                assert np.abs(a - acts[i]).max() <= 2e-5 * max(np.abs(acts[i]).max(), 1e-6), specs[i].name
+            assert np.abs(out[k] - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+@pytest.mark.gpu
+def test_gpu_unet_other_widths_and_errors():
+    from psm_amd import UNetSurrogate, _lib
+    widths = (32, 48, 80)                                   # three levels, channel counts that are not powers of two
+    specs = uo.unet_specs(4, widths, 2)
+    W = uo.he_weights(specs, seed=5)
+    g = np.random.default_rng(0).standard_normal((40, 72, 4)).astype(np.float32)
+    with UNetSurrogate(W, 40, 72, c_in=4, c_out=2, widths=widths) as net:
+        out = net.forward(g)[0]
+    ref = uo.unet_forward(g, W, widths)
+    assert np.abs(out - ref).max() <= 1e-4 * np.abs(ref).max()
+    with pytest.raises(_lib.PsmError):
+        UNetSurrogate(W, 42, 72, c_in=4, c_out=2, widths=widths)           # 42 is not a multiple of 4
+    with pytest.raises(ValueError):
+        UNetSurrogate(W[:-1], 40, 72, c_in=4, c_out=2, widths=widths)
