@@ -45,6 +45,9 @@ int psm_unet_synchronize(psm_unet* u);
 /* Output activation of convolution `idx` of the last forward pass (introspection for parity tests):
  * dst [n_cases * (ny >> level) * (nx >> level) * c_out] floats. */
 int psm_unet_read_activation(psm_unet* u, int32_t idx, float* dst, int64_t dst_floats);
+/* One forward pass with a HIP event between the layers: ms [num_convs] (each includes ~3 us of event overhead),
+ * wgs [num_convs] workgroups launched per layer (may be NULL).  Introspection for tuning. */
+int psm_unet_profile(psm_unet* u, const float* d_grid, int32_t n_cases, float* d_field, float* ms, int32_t* wgs);
 /* Algorithmic work of one forward pass of one case at the planned size. */
 int64_t psm_unet_flops(const psm_unet* u);
 

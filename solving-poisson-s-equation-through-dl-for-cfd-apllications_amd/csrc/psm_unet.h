@@ -13,6 +13,13 @@ struct PsmConvArgs {
   const float* bias;           // [cout_pad]
   float* out;                  // [H][W][cout]
   int c0, c1, n_chunks;        // channel chunks of 16 over the concatenated, zero-padded input
+  // split-K producers: an input may arrive as `ks` partial-sum slabs (no bias, no ReLU yet); the loader adds
+  // them in slab order, then the producer's bias and ReLU -- deterministic, and no reduction launch
+  int ks0, ks1;                // slabs of in0 / in1 (1: a finished activation)
+  int64_t slab0, slab1;        // slab strides (elements)
+  const float* pbias0; const float* pbias1;   // producer biases (ks > 1), ReLU implied
+  int ksplit;                  // this layer's own split: workgroup z handles chunks [z*cps, (z+1)*cps) and writes slab z
+  int64_t out_slab;
   int mode0;
   int H, W;                    // resolution of the convolution (its output)
   int H0, W0;                  // resolution of in0

@@ -25,43 +25,61 @@ constexpr int TW = 16;            // tile width (pixels) = MFMA rows
 constexpr int CC = 16;            // input channels per chunk
 constexpr int LDC = CC + 4;       // LDS pixel stride (floats): 16-B slots rotate from pixel to pixel
 
+// one finished value group: sum of the producer's partial-sum slabs (+ its bias, ReLU) or the plain activation
+template <bool ALIGNED4>
+__device__ __forceinline__ f32x4 read4(const float* p, int ks, int64_t slab, const float* pbias, int ch, int nvalid) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (ALIGNED4) {
+    v = *reinterpret_cast<const f32x4*>(p);
+    for (int s = 1; s < ks; ++s) v += *reinterpret_cast<const f32x4*>(p + s * slab);
+    if (ks > 1) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(pbias + ch);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j] + b[j], 0.f);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < nvalid) {
+        float t = p[j];
+        for (int s = 1; s < ks; ++s) t += p[s * slab + j];
+        v[j] = ks > 1 ? fmaxf(t + pbias[ch + j], 0.f) : t;
+      }
+    }
+  }
+  return v;
+}
+
 // four consecutive channels [ch, ch+4) of the concatenated input at output-resolution pixel (y, x)
 template <bool ALIGNED4>
 __device__ __forceinline__ f32x4 fetch4(const PsmConvArgs& a, const float* in0, const float* in1, int y, int x, int ch) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   if (y < 0 || y >= a.H || x < 0 || x >= a.W) return v;                       // zero padding
-  if (ALIGNED4) {
-    if (ch < a.c0) {
-      if (a.mode0 == PSM_SRC_SAME) {
-        v = *reinterpret_cast<const f32x4*>(in0 + ((int64_t)y * a.W0 + x) * a.c0 + ch);
-      } else if (a.mode0 == PSM_SRC_UPSAMPLE) {
-        v = *reinterpret_cast<const f32x4*>(in0 + ((int64_t)(y >> 1) * a.W0 + (x >> 1)) * a.c0 + ch);
-      } else {
-        const float* p = in0 + ((int64_t)(2 * y) * a.W0 + 2 * x) * a.c0 + ch;
-        const f32x4 q0 = *reinterpret_cast<const f32x4*>(p), q1 = *reinterpret_cast<const f32x4*>(p + a.c0);
-        const f32x4 q2 = *reinterpret_cast<const f32x4*>(p + (int64_t)a.W0 * a.c0);
-        const f32x4 q3 = *reinterpret_cast<const f32x4*>(p + (int64_t)a.W0 * a.c0 + a.c0);
+  if (ch < a.c0) {
+    const int nv = min(4, a.c0 - ch);
+    if (a.mode0 == PSM_SRC_SAME) {
+      v = read4<ALIGNED4>(in0 + ((int64_t)y * a.W0 + x) * a.c0 + ch, a.ks0, a.slab0, a.pbias0, ch, nv);
+    } else if (a.mode0 == PSM_SRC_UPSAMPLE) {
+      v = read4<ALIGNED4>(in0 + ((int64_t)(y >> 1) * a.W0 + (x >> 1)) * a.c0 + ch, a.ks0, a.slab0, a.pbias0, ch, nv);
+    } else {
+      const float* p = in0 + ((int64_t)(2 * y) * a.W0 + 2 * x) * a.c0 + ch;
+      const f32x4 q0 = read4<ALIGNED4>(p, a.ks0, a.slab0, a.pbias0, ch, nv);
+      const f32x4 q1 = read4<ALIGNED4>(p + a.c0, a.ks0, a.slab0, a.pbias0, ch, nv);
+      const f32x4 q2 = read4<ALIGNED4>(p + (int64_t)a.W0 * a.c0, a.ks0, a.slab0, a.pbias0, ch, nv);
+      const f32x4 q3 = read4<ALIGNED4>(p + (int64_t)a.W0 * a.c0 + a.c0, a.ks0, a.slab0, a.pbias0, ch, nv);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaxf(q0[j], q1[j]), fmaxf(q2[j], q3[j]));
-      }
-    } else if (ch - a.c0 < a.c1) {
-      v = *reinterpret_cast<const f32x4*>(in1 + ((int64_t)y * a.W + x) * a.c1 + (ch - a.c0));
+      for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaxf(q0[j], q1[j]), fmaxf(q2[j], q3[j]));
     }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = ch + j;
-      if (c < a.c0) {
-        if (a.mode0 == PSM_SRC_SAME) v[j] = in0[((int64_t)y * a.W0 + x) * a.c0 + c];
-        else if (a.mode0 == PSM_SRC_UPSAMPLE) v[j] = in0[((int64_t)(y >> 1) * a.W0 + (x >> 1)) * a.c0 + c];
-        else {
-          const float* p = in0 + ((int64_t)(2 * y) * a.W0 + 2 * x) * a.c0 + c;
-          v[j] = fmaxf(fmaxf(p[0], p[a.c0]), fmaxf(p[(int64_t)a.W0 * a.c0], p[(int64_t)a.W0 * a.c0 + a.c0]));
+    if (!ALIGNED4 && nv < 4 && a.c1 > 0) {           // a group straddling the concatenation seam (unaligned widths only)
+      for (int j = nv; j < 4; ++j)
+        if (ch + j - a.c0 < a.c1) {
+          const f32x4 t = read4<false>(in1 + ((int64_t)y * a.W + x) * a.c1 + (ch + j - a.c0), a.ks1, a.slab1, a.pbias1, ch + j - a.c0, 1);
+          v[j] = t[0];
         }
-      } else if (c - a.c0 < a.c1) {
-        v[j] = in1[((int64_t)y * a.W + x) * a.c1 + (c - a.c0)];
-      }
     }
+  } else if (ch - a.c0 < a.c1) {
+    const int c = ch - a.c0;
+    v = read4<ALIGNED4>(in1 + ((int64_t)y * a.W + x) * a.c1 + c, a.ks1, a.slab1, a.pbias1, c, min(4, a.c1 - c));
   }
   return v;
 }
@@ -73,7 +91,8 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
   __shared__ __attribute__((aligned(16))) f32x4 w_tile[9 * NCT * 64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cs = blockIdx.z / co_groups, cog = blockIdx.z - cs * co_groups;
+  const int zz = blockIdx.z / a.ksplit, split = blockIdx.z - zz * a.ksplit;
+  const int cs = zz / co_groups, cog = zz - cs * co_groups;
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
   const float* in0 = a.in0 + (int64_t)cs * a.in0_case;
   const float* in1 = a.in1 ? a.in1 + (int64_t)cs * a.in1_case : nullptr;
@@ -87,7 +106,9 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
 #pragma unroll
     for (int n = 0; n < WN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float4* wsrc = a.wpack + (int64_t)cog * a.n_chunks * (9 * NCT * 64);
-  for (int g = 0; g < a.n_chunks; ++g) {
+  const int cps = (a.n_chunks + a.ksplit - 1) / a.ksplit;          // chunks per split
+  const int g_end = min(a.n_chunks, (split + 1) * cps);
+  for (int g = split * cps; g < g_end; ++g) {
     // ---- stage the chunk: weights (contiguous 9*NCT KiB) and the input tile with its halo
     for (int q = tid; q < 9 * NCT * 64; q += 256) {
       const float4 w = wsrc[(int64_t)g * (9 * NCT * 64) + q];
@@ -122,12 +143,13 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
     }
     __syncthreads();
   }
-  // ---- epilogue: bias + ReLU, NHWC store
-  float* out = a.out + (int64_t)cs * a.out_case;
+  // ---- epilogue: bias + ReLU (split-K: the raw partial sum into this split's slab), NHWC store
+  float* out = a.out + (int64_t)cs * a.out_case + (int64_t)split * a.out_slab;
+  const bool fin = a.ksplit == 1;
 #pragma unroll
   for (int n = 0; n < WN; ++n) {
     const int co = (cog * NCT + ct_w + n) * 16 + (lane & 15);
-    const float b = co < a.cout ? a.bias[co] : 0.f;
+    const float b = (fin && co < a.cout) ? a.bias[co] : 0.f;
 #pragma unroll
     for (int m = 0; m < WM; ++m) {
       const int y = y0 + row_w + m;
@@ -135,7 +157,7 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
       for (int r = 0; r < 4; ++r) {
         const int x = x0 + 4 * kq + r;
         float v = acc[m][n][r] + b;
-        if (a.relu) v = fmaxf(v, 0.f);
+        if (fin && a.relu) v = fmaxf(v, 0.f);
         if (y < a.H && x < a.W && co < a.cout) out[((int64_t)y * a.W + x) * a.cout + co] = v;
       }
     }
@@ -160,7 +182,7 @@ hipError_t psm_launch_conv3x3(const PsmConvArgs& a, int arrangement, int nct, in
   const bool al = (a.c0 % 4 == 0) && (a.c1 % 4 == 0);
   if (arrangement == 0) {          // pixel-major: 8 rows x 16 columns, every wave 2 rows x all NCT channel tiles
     const int groups = (cout_tiles + nct - 1) / nct;
-    const dim3 grid((a.W + TW - 1) / TW, (a.H + 7) / 8, n_cases * groups);
+    const dim3 grid((a.W + TW - 1) / TW, (a.H + 7) / 8, n_cases * groups * a.ksplit);
 #define PIX(N)                                                                                              \
     do {                                                                                                    \
       if (al) hipLaunchKernelGGL((psm_conv3x3_kernel<8, 2, N, N, true>), grid, dim3(256), 0, st, a, groups);  \
@@ -171,7 +193,7 @@ hipError_t psm_launch_conv3x3(const PsmConvArgs& a, int arrangement, int nct, in
   } else {                         // channel-major: 2 rows x 16 columns, 4 waves = 4 channel tiles
     if (nct != 4) return hipErrorInvalidValue;
     const int groups = (cout_tiles + 3) / 4;
-    const dim3 grid((a.W + TW - 1) / TW, (a.H + 1) / 2, n_cases * groups);
+    const dim3 grid((a.W + TW - 1) / TW, (a.H + 1) / 2, n_cases * groups * a.ksplit);
     if (al) hipLaunchKernelGGL((psm_conv3x3_kernel<2, 2, 4, 1, true>), grid, dim3(256), 0, st, a, groups);
     else hipLaunchKernelGGL((psm_conv3x3_kernel<2, 2, 4, 1, false>), grid, dim3(256), 0, st, a, groups);
   }

@@ -1,5 +1,6 @@
 // psm_unet_api.cpp -- handle, layer schedule, weight packing and C-ABI of the convolutional path
 // (include/psm_unet.h; kernels in psm_unet.hip).
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -17,13 +18,14 @@ struct Conv {
   int skip = -1;        // conv index whose output is concatenated (src == 3)
   int relu = 1;
   // launch configuration and packed operands
-  int arrangement = 0, nct = 1, n_chunks = 0, groups = 1;
+  int arrangement = 0, nct = 1, n_chunks = 0, groups = 1, ksplit = 1;
   std::vector<float> W, b;     // host copies (HWIO), kept for re-packing at plan time
   bool set = false;
   float4* d_w = nullptr;
   float* d_b = nullptr;
   float* d_w1 = nullptr;       // head: [cin][cout]
-  float* d_out = nullptr;      // [max_cases][H][W][cout]
+  float* d_out = nullptr;      // [ksplit][max_cases][H][W][cout] (ksplit > 1: partial-sum slabs, finished by the consumer's loader)
+  int64_t slab = 0;
 };
 thread_local std::string g_err;
 }  // namespace
@@ -65,7 +67,7 @@ std::vector<float> pack_conv3x3(const Conv& c) {
 }
 
 // workgroup count first (fill 256 CUs), then the most reuse per workgroup
-void choose_config(Conv& c, int H, int W) {
+void choose_config(Conv& c, int H, int W, bool can_split) {
   const int ctiles = (c.cout + 15) / 16;
   struct Cand { int arr, nct, th; };
   const Cand cands[4] = {{0, 4, 8}, {0, 2, 8}, {0, 1, 8}, {1, 4, 2}};
@@ -79,6 +81,12 @@ void choose_config(Conv& c, int H, int W) {
     if (score > best_score) { best_score = score; c.arrangement = k.arr; c.nct = k.nct; c.groups = groups; }
   }
   c.n_chunks = (c.cin + 15) / 16;
+  // split the input channels over workgroups until the chip is filled (partial-sum slabs, see psm_unet.h); only
+  // layers whose output feeds another convolution can be split, at most 8 ways, at least 2 chunks per split
+  const int th = c.arrangement ? 2 : 8;
+  const long wgs = (long)((W + 15) / 16) * ((H + th - 1) / th) * c.groups;
+  c.ksplit = 1;
+  while (can_split && wgs * c.ksplit < 256 && c.ksplit < 8 && c.n_chunks / (c.ksplit * 2) >= 2) c.ksplit *= 2;
 }
 
 int upload_conv(psm_unet* u, Conv& c) {
@@ -98,8 +106,9 @@ int upload_conv(psm_unet* u, Conv& c) {
   return PSM_OK;
 }
 
-int forward(psm_unet* u, const float* d_grid, int n, float* d_field, hipStream_t st) {
+int forward(psm_unet* u, const float* d_grid, int n, float* d_field, hipStream_t st, hipEvent_t* ev = nullptr) {
   for (size_t i = 0; i < u->convs.size(); ++i) {
+    if (ev) UCHK(u, hipEventRecord(ev[i], st));
     Conv& c = u->convs[i];
     const int H = u->ny >> c.level, W = u->nx >> c.level;
     float* out = (i + 1 == u->convs.size()) ? d_field : c.d_out;
@@ -111,18 +120,21 @@ int forward(psm_unet* u, const float* d_grid, int n, float* d_field, hipStream_t
     PsmConvArgs a{};
     a.wpack = c.d_w; a.bias = c.d_b; a.out = out; a.n_chunks = c.n_chunks; a.H = H; a.W = W; a.cout = c.cout; a.relu = c.relu;
     a.out_case = (int64_t)H * W * c.cout;
+    a.ksplit = c.ksplit; a.out_slab = c.slab; a.ks0 = 1; a.ks1 = 1;
     if (c.src == 0) { a.in0 = d_grid; a.c0 = c.cin; a.mode0 = PSM_SRC_SAME; a.H0 = H; a.W0 = W; }
     else {
       const Conv& pv = u->convs[i - 1];
-      a.in0 = pv.d_out; a.c0 = pv.cout;
+      a.in0 = pv.d_out; a.c0 = pv.cout; a.ks0 = pv.ksplit; a.slab0 = pv.slab; a.pbias0 = pv.d_b;
       if (c.src == 1) { a.mode0 = PSM_SRC_SAME; a.H0 = H; a.W0 = W; }
       else if (c.src == 2) { a.mode0 = PSM_SRC_MAXPOOL; a.H0 = 2 * H; a.W0 = 2 * W; }
       else { a.mode0 = PSM_SRC_UPSAMPLE; a.H0 = H / 2; a.W0 = W / 2; a.in1 = u->convs[c.skip].d_out; a.c1 = u->convs[c.skip].cout;
+             a.ks1 = u->convs[c.skip].ksplit; a.slab1 = u->convs[c.skip].slab; a.pbias1 = u->convs[c.skip].d_b;
              a.in1_case = (int64_t)H * W * a.c1; }
     }
     a.in0_case = (int64_t)a.H0 * a.W0 * a.c0;
     UCHK(u, psm_launch_conv3x3(a, c.arrangement, c.nct, n, st));
   }
+  if (ev) UCHK(u, hipEventRecord(ev[u->convs.size()], st));
   u->last_cases = n;
   return PSM_OK;
 }
@@ -215,11 +227,14 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
   u->ny = ny; u->nx = nx; u->max_cases = max_cases;
   for (Conv& c : u->convs) {
     const int H = ny >> c.level, W = nx >> c.level;
-    if (c.k == 3) choose_config(c, H, W);
+    const size_t ci = &c - u->convs.data();
+    const bool feeds_conv3 = ci + 1 < u->convs.size() && u->convs[ci + 1].k == 3;
+    if (c.k == 3) choose_config(c, H, W, feeds_conv3 && getenv("PSM_UNET_NO_SPLIT") == nullptr);
     int rc = upload_conv(u, c);
     if (rc) return rc;
     free_dev(c.d_out); c.d_out = nullptr;
-    UCHK(u, hipMalloc((void**)&c.d_out, (size_t)max_cases * H * W * c.cout * sizeof(float)));
+    c.slab = (int64_t)max_cases * H * W * c.cout;
+    UCHK(u, hipMalloc((void**)&c.d_out, (size_t)c.ksplit * c.slab * sizeof(float)));
   }
   free_dev(u->d_in); free_dev(u->d_field);
   if (u->h_in) { (void)hipHostFree(u->h_in); u->h_in = nullptr; }
@@ -276,7 +291,39 @@ int psm_unet_read_activation(psm_unet* u, int32_t idx, float* dst, int64_t dst_f
   UCHK(u, hipSetDevice(u->device));
   UCHK(u, hipStreamSynchronize(u->stream));
   UCHK(u, hipMemcpy(dst, c.d_out, n * sizeof(float), hipMemcpyDeviceToHost));
+  if (c.ksplit > 1) {            // partial-sum slabs: finish like the consumer's loader (slab order, bias, ReLU)
+    std::vector<float> tmp(n);
+    for (int s = 1; s < c.ksplit; ++s) {
+      UCHK(u, hipMemcpy(tmp.data(), c.d_out + (int64_t)s * c.slab, n * sizeof(float), hipMemcpyDeviceToHost));
+      for (int64_t q = 0; q < n; ++q) dst[q] += tmp[q];
+    }
+    for (int64_t q = 0; q < n; ++q) { const float v = dst[q] + c.b[q % c.cout]; dst[q] = v > 0.f ? v : 0.f; }
+  }
   return PSM_OK;
+}
+
+int psm_unet_profile(psm_unet* u, const float* d_grid, int32_t n_cases, float* d_field, float* ms, int32_t* wgs) {
+  if (!u || !ms) return PSM_ERR_ARG;
+  if (!u->planned) return fail(u, PSM_ERR_STATE, "psm_unet_plan has not been called");
+  if (!d_grid || !d_field || n_cases < 1 || n_cases > u->max_cases) return fail(u, PSM_ERR_ARG, "bad arguments");
+  UCHK(u, hipSetDevice(u->device));
+  std::vector<hipEvent_t> ev(u->convs.size() + 1);
+  for (auto& e : ev) UCHK(u, hipEventCreate(&e));
+  int rc = forward(u, d_grid, n_cases, d_field, u->stream, ev.data());
+  if (rc == PSM_OK) {
+    hipError_t e = hipStreamSynchronize(u->stream);
+    if (e != hipSuccess) rc = fail(u, PSM_ERR_HIP, hipGetErrorString(e));
+  }
+  for (size_t i = 0; rc == PSM_OK && i < u->convs.size(); ++i) {
+    (void)hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
+    if (wgs) {
+      const Conv& c = u->convs[i];
+      const int H = u->ny >> c.level, W = u->nx >> c.level;
+      wgs[i] = c.k == 3 ? ((W + 15) / 16) * ((H + (c.arrangement ? 1 : 7)) / (c.arrangement ? 2 : 8)) * c.groups * c.ksplit * n_cases : 0;
+    }
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return rc;
 }
 
 int64_t psm_unet_flops(const psm_unet* u) {

@@ -111,6 +111,13 @@ class UNetSurrogate:
             return 0
         return L - 2 - (idx - 2 * L) // 2
 
+    def profile(self, d_grid: int, n_cases: int, d_field: int):
+        """-> (ms per convolution, workgroups per convolution) of one instrumented forward pass."""
+        ms = np.zeros(len(self.shapes), np.float32)
+        wg = np.zeros(len(self.shapes), np.int32)
+        self._chk(self.lib.psm_unet_profile(self.h, d_grid, n_cases, d_field, _p(ms), _p(wg, C.c_int32)))
+        return ms, wg
+
     @property
     def flops(self) -> int:
         return int(self.lib.psm_unet_flops(self.h))
