@@ -25,70 +25,95 @@ constexpr int TW = 16;            // tile width (pixels) = MFMA rows
 constexpr int CC = 16;            // input channels per chunk
 constexpr int LDC = CC + 4;       // LDS pixel stride (floats): 16-B slots rotate from pixel to pixel
 
-// one finished value group: sum of the producer's partial-sum slabs (+ its bias, ReLU) or the plain activation
-template <bool ALIGNED4>
-__device__ __forceinline__ f32x4 read4(const float* p, int ks, int64_t slab, const float* pbias, int ch, int nvalid) {
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (ALIGNED4) {
-    v = *reinterpret_cast<const f32x4*>(p);
-    for (int s = 1; s < ks; ++s) v += *reinterpret_cast<const f32x4*>(p + s * slab);
-    if (ks > 1) {
-      const f32x4 b = *reinterpret_cast<const f32x4*>(pbias + ch);
+// One finished group of four channels.  Straight-line on purpose (clamped addresses, selects, fully unrolled
+// slab sums): every load of a chunk's staging must be in flight together -- a load inside a branch or a
+// runtime loop costs a drained vmcnt, i.e. one full memory round trip each.
+//   KSM == 1: the producer stored finished activations;  KSM == 8: it may have stored up to 8 partial-sum
+//   slabs (split-K): they are added in slab order, then the producer's bias and ReLU.
+template <int KSM>
+__device__ __forceinline__ f32x4 read4(const float* p, int ks, int64_t slab, const float* pbias, int ch) {
+  f32x4 v = *reinterpret_cast<const f32x4*>(p);
+  if (KSM > 1) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j] + b[j], 0.f);
+    for (int s = 1; s < KSM; ++s) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(p + (int64_t)min(s, ks - 1) * slab);
+      const float keep = s < ks ? 1.f : 0.f;
+      v += t * keep;
     }
-  } else {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(pbias + ch);
+    const bool fin = ks > 1;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (j < nvalid) {
-        float t = p[j];
-        for (int s = 1; s < ks; ++s) t += p[s * slab + j];
-        v[j] = ks > 1 ? fmaxf(t + pbias[ch + j], 0.f) : t;
-      }
-    }
+    for (int j = 0; j < 4; ++j) v[j] = fin ? fmaxf(v[j] + b[j], 0.f) : v[j];
   }
   return v;
 }
 
-// four consecutive channels [ch, ch+4) of the concatenated input at output-resolution pixel (y, x)
-template <bool ALIGNED4>
+// four consecutive channels [ch, ch+4) of the concatenated input at output-resolution pixel (y, x);
+// channel counts are multiples of 4 here, so a group never straddles the concatenation seam
+template <int SRC, int KSM>
 __device__ __forceinline__ f32x4 fetch4(const PsmConvArgs& a, const float* in0, const float* in1, int y, int x, int ch) {
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (y < 0 || y >= a.H || x < 0 || x >= a.W) return v;                       // zero padding
-  if (ch < a.c0) {
-    const int nv = min(4, a.c0 - ch);
-    if (a.mode0 == PSM_SRC_SAME) {
-      v = read4<ALIGNED4>(in0 + ((int64_t)y * a.W0 + x) * a.c0 + ch, a.ks0, a.slab0, a.pbias0, ch, nv);
-    } else if (a.mode0 == PSM_SRC_UPSAMPLE) {
-      v = read4<ALIGNED4>(in0 + ((int64_t)(y >> 1) * a.W0 + (x >> 1)) * a.c0 + ch, a.ks0, a.slab0, a.pbias0, ch, nv);
-    } else {
-      const float* p = in0 + ((int64_t)(2 * y) * a.W0 + 2 * x) * a.c0 + ch;
-      const f32x4 q0 = read4<ALIGNED4>(p, a.ks0, a.slab0, a.pbias0, ch, nv);
-      const f32x4 q1 = read4<ALIGNED4>(p + a.c0, a.ks0, a.slab0, a.pbias0, ch, nv);
-      const f32x4 q2 = read4<ALIGNED4>(p + (int64_t)a.W0 * a.c0, a.ks0, a.slab0, a.pbias0, ch, nv);
-      const f32x4 q3 = read4<ALIGNED4>(p + (int64_t)a.W0 * a.c0 + a.c0, a.ks0, a.slab0, a.pbias0, ch, nv);
+  const bool inside = (y >= 0) && (y < a.H) && (x >= 0) && (x < a.W);
+  const int yc = min(max(y, 0), a.H - 1), xc = min(max(x, 0), a.W - 1);
+  const bool first = ch < a.c0;
+  const int ch0 = min(ch, a.c0 - 4);
+  f32x4 v;
+  if (SRC == PSM_SRC_SAME) {
+    v = read4<KSM>(in0 + ((int64_t)yc * a.W0 + xc) * a.c0 + ch0, a.ks0, a.slab0, a.pbias0, ch0);
+  } else if (SRC == PSM_SRC_UPSAMPLE) {
+    v = read4<KSM>(in0 + ((int64_t)(yc >> 1) * a.W0 + (xc >> 1)) * a.c0 + ch0, a.ks0, a.slab0, a.pbias0, ch0);
+  } else {
+    const float* p = in0 + ((int64_t)(2 * yc) * a.W0 + 2 * xc) * a.c0 + ch0;
+    const f32x4 q0 = read4<KSM>(p, a.ks0, a.slab0, a.pbias0, ch0);
+    const f32x4 q1 = read4<KSM>(p + a.c0, a.ks0, a.slab0, a.pbias0, ch0);
+    const f32x4 q2 = read4<KSM>(p + (int64_t)a.W0 * a.c0, a.ks0, a.slab0, a.pbias0, ch0);
+    const f32x4 q3 = read4<KSM>(p + (int64_t)a.W0 * a.c0 + a.c0, a.ks0, a.slab0, a.pbias0, ch0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaxf(q0[j], q1[j]), fmaxf(q2[j], q3[j]));
-    }
-    if (!ALIGNED4 && nv < 4 && a.c1 > 0) {           // a group straddling the concatenation seam (unaligned widths only)
-      for (int j = nv; j < 4; ++j)
-        if (ch + j - a.c0 < a.c1) {
-          const f32x4 t = read4<false>(in1 + ((int64_t)y * a.W + x) * a.c1 + (ch + j - a.c0), a.ks1, a.slab1, a.pbias1, ch + j - a.c0, 1);
-          v[j] = t[0];
-        }
-    }
-  } else if (ch - a.c0 < a.c1) {
-    const int c = ch - a.c0;
-    v = read4<ALIGNED4>(in1 + ((int64_t)y * a.W + x) * a.c1 + c, a.ks1, a.slab1, a.pbias1, c, min(4, a.c1 - c));
+    for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaxf(q0[j], q1[j]), fmaxf(q2[j], q3[j]));
+  }
+  bool ok = inside && first;
+  if (SRC == PSM_SRC_UPSAMPLE) {                      // the only source with a skip input concatenated behind it
+    const int c = min(max(ch - a.c0, 0), a.c1 - 4);
+    const f32x4 s = read4<KSM>(in1 + ((int64_t)yc * a.W + xc) * a.c1 + c, a.ks1, a.slab1, a.pbias1, c);
+    const bool second = !first && (ch - a.c0) < a.c1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = first ? v[j] : s[j];
+    ok = inside && (first || second);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0.f;
+  return v;
+}
+
+// stem (c_in not a multiple of 4, e.g. the 3-channel grid image): scalar loads, same-resolution source only
+__device__ __forceinline__ f32x4 fetch4_stem(const PsmConvArgs& a, const float* in0, int y, int x, int ch) {
+  const bool inside = (y >= 0) && (y < a.H) && (x >= 0) && (x < a.W);
+  const int yc = min(max(y, 0), a.H - 1), xc = min(max(x, 0), a.W - 1);
+  const float* p = in0 + ((int64_t)yc * a.W0 + xc) * a.c0;
+  f32x4 v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float t = p[min(ch + j, a.c0 - 1)];
+    v[j] = (inside && ch + j < a.c0) ? t : 0.f;
   }
   return v;
 }
 
-// TH: tile rows; WM: rows per wave; NCT: channel tiles per workgroup; WN: channel tiles per wave
-template <int TH, int WM, int NCT, int WN, bool ALIGNED4>
+// TH: tile rows; WM: rows per wave; NCT: channel tiles per workgroup; WN: channel tiles per wave.
+// Software pipeline over the channel chunks, both operands double-buffered in LDS: the input tile (through the
+// source transform) and the weights (9 x NCT KiB, already in MFMA operand order) of chunk g+1 are requested
+// into a handful of registers per thread before the MFMAs of chunk g and written to the other LDS buffers
+// after them; one LDS-only barrier per chunk.  Cooperative staging keeps the register count low (the weights
+// of a chunk are 2.25 x NCT float4 per thread), so that several workgroups share a CU and hide each other's
+// prologue -- holding a wave's own weight slice in registers (9 x WN float4 per lane, twice for the
+// pipeline) measured slower at every batch size.
+template <int TH, int WM, int NCT, int WN, int SRC, int KSM>     // SRC: PSM_SRC_* or -1 = unaligned stem
 __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_groups) {
-  __shared__ __attribute__((aligned(16))) float in_tile[(TH + 2) * (TW + 2) * LDC];
-  __shared__ __attribute__((aligned(16))) f32x4 w_tile[9 * NCT * 64];
+  constexpr int TILE = (TH + 2) * (TW + 2) * LDC;                   // floats per input-tile buffer
+  constexpr int NF = ((TH + 2) * (TW + 2) * (CC / 4) + 255) / 256;  // 4-channel input fetches per thread and chunk
+  constexpr int WQ = 9 * NCT * 64;                                  // float4 per weight chunk
+  constexpr int NWF = (WQ + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float in_tile[2 * TILE];
+  __shared__ __attribute__((aligned(16))) f32x4 w_tile[2 * WQ];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int zz = blockIdx.z / a.ksplit, split = blockIdx.z - zz * a.ksplit;
@@ -96,7 +121,6 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
   const float* in0 = a.in0 + (int64_t)cs * a.in0_case;
   const float* in1 = a.in1 ? a.in1 + (int64_t)cs * a.in1_case : nullptr;
-  // wave -> (rows, channel tiles) of the workgroup tile
   const int row_w = (TH == 4 * WM) ? wave * WM : 0;           // pixel-major: waves stacked along the rows
   const int ct_w = (TH == 4 * WM) ? 0 : wave * WN;            // channel-major: waves along the channel tiles
   const int px = lane & 15, kq = lane >> 4;
@@ -105,43 +129,79 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
   for (int m = 0; m < WM; ++m)
 #pragma unroll
     for (int n = 0; n < WN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const float4* wsrc = a.wpack + (int64_t)cog * a.n_chunks * (9 * NCT * 64);
+  const float4* wsrc = a.wpack + (int64_t)cog * a.n_chunks * WQ;
   const int cps = (a.n_chunks + a.ksplit - 1) / a.ksplit;          // chunks per split
-  const int g_end = min(a.n_chunks, (split + 1) * cps);
-  for (int g = split * cps; g < g_end; ++g) {
-    // ---- stage the chunk: weights (contiguous 9*NCT KiB) and the input tile with its halo
-    for (int q = tid; q < 9 * NCT * 64; q += 256) {
-      const float4 w = wsrc[(int64_t)g * (9 * NCT * 64) + q];
-      w_tile[q] = (f32x4){w.x, w.y, w.z, w.w};
+  const int g_beg = split * cps, g_end = min(a.n_chunks, (split + 1) * cps);
+
+  auto load_w = [&](f32x4 (&w)[NWF], int g) {
+#pragma unroll
+    for (int u = 0; u < NWF; ++u) {
+      const float4 t = wsrc[(int64_t)g * WQ + min(tid + 256 * u, WQ - 1)];
+      w[u] = (f32x4){t.x, t.y, t.z, t.w};
     }
-    for (int q = tid; q < (TH + 2) * (TW + 2) * (CC / 4); q += 256) {
+  };
+  auto store_w = [&](const f32x4 (&w)[NWF], int buf) {
+#pragma unroll
+    for (int u = 0; u < NWF; ++u)
+      if (tid + 256 * u < WQ) w_tile[buf * WQ + tid + 256 * u] = w[u];
+  };
+  auto load_x = [&](f32x4 (&x)[NF], int g) {
+#pragma unroll
+    for (int u = 0; u < NF; ++u) {
+      const int q = tid + 256 * u;
       const int pos = q >> 2, c4 = q & 3;
       const int r = pos / (TW + 2), c = pos - r * (TW + 2);
-      const f32x4 v = fetch4<ALIGNED4>(a, in0, in1, y0 - 1 + r, x0 - 1 + c, g * CC + 4 * c4);
-      *reinterpret_cast<f32x4*>(&in_tile[pos * LDC + 4 * c4]) = v;
+      // fetches beyond the tile (last round) read a clamped position and are not stored
+      const int rr = min(r, TH + 1);
+      x[u] = SRC < 0 ? fetch4_stem(a, in0, y0 - 1 + rr, x0 - 1 + c, g * CC + 4 * c4)
+                     : fetch4<(SRC < 0 ? 0 : SRC), KSM>(a, in0, in1, y0 - 1 + rr, x0 - 1 + c, g * CC + 4 * c4);
     }
-    __syncthreads();
-    // ---- nine taps x (WM rows) x (WN channel tiles) x 4 MFMAs
+  };
+  auto store_x = [&](const f32x4 (&x)[NF], int buf) {
+#pragma unroll
+    for (int u = 0; u < NF; ++u) {
+      const int q = tid + 256 * u;
+      if (q < (TH + 2) * (TW + 2) * (CC / 4)) *reinterpret_cast<f32x4*>(&in_tile[buf * TILE + (q >> 2) * LDC + 4 * (q & 3)]) = x[u];
+    }
+  };
+
+  f32x4 xr[NF], wr[NWF];
+  if (g_beg < g_end) {
+    load_x(xr, g_beg);
+    load_w(wr, g_beg);
+    store_x(xr, 0);
+    store_w(wr, 0);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  int buf = 0;
+  for (int g = g_beg; g < g_end; ++g) {
+    const bool more = g + 1 < g_end;
+    if (more) { load_x(xr, g + 1); load_w(wr, g + 1); }
+    __builtin_amdgcn_sched_barrier(0);
+    const float* tile = &in_tile[buf * TILE];
+    const f32x4* wt = &w_tile[buf * WQ + ct_w * 64 + lane];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int ky = tap / 3, kx = tap - 3 * ky;
       f32x4 av[WM], bv[WN];
 #pragma unroll
       for (int m = 0; m < WM; ++m)
-        av[m] = *reinterpret_cast<const f32x4*>(&in_tile[((row_w + m + ky) * (TW + 2) + px + kx) * LDC + 4 * kq]);
+        av[m] = *reinterpret_cast<const f32x4*>(&tile[((row_w + m + ky) * (TW + 2) + px + kx) * LDC + 4 * kq]);
 #pragma unroll
-      for (int n = 0; n < WN; ++n) bv[n] = w_tile[(tap * NCT + ct_w + n) * 64 + lane];
+      for (int n = 0; n < WN; ++n) bv[n] = wt[(tap * NCT + n) * 64];
+      // consecutive MFMAs go to different accumulators (dependent-accumulator latency 40 > issue 32 cycles)
 #pragma unroll
-      for (int m = 0; m < WM; ++m)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int n = 0; n < WN; ++n) {
-          acc[m][n] = MFMA16(av[m][0], bv[n][0], acc[m][n]);
-          acc[m][n] = MFMA16(av[m][1], bv[n][1], acc[m][n]);
-          acc[m][n] = MFMA16(av[m][2], bv[n][2], acc[m][n]);
-          acc[m][n] = MFMA16(av[m][3], bv[n][3], acc[m][n]);
-        }
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+          for (int n = 0; n < WN; ++n) acc[m][n] = MFMA16(av[m][j], bv[n][j], acc[m][n]);
     }
-    __syncthreads();
+    // nothing below may be scheduled among the MFMAs: the LDS stores wait for the loads issued above
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) { store_x(xr, buf ^ 1); store_w(wr, buf ^ 1); }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    buf ^= 1;
   }
   // ---- epilogue: bias + ReLU (split-K: the raw partial sum into this split's slab), NHWC store
   float* out = a.out + (int64_t)cs * a.out_case + (int64_t)split * a.out_slab;
@@ -177,25 +237,35 @@ __global__ __launch_bounds__(256) void psm_head1x1_kernel(PsmHeadArgs a) {
 
 }  // namespace
 
+template <int TH, int WM, int NCT, int WN>
+static void launch_variant(const PsmConvArgs& a, dim3 grid, int groups, hipStream_t st) {
+  const bool stem = (a.c0 % 4 != 0) || (a.c1 % 4 != 0);
+  const bool slabs = a.ks0 > 1 || a.ks1 > 1;
+#define GO(S, K) hipLaunchKernelGGL((psm_conv3x3_kernel<TH, WM, NCT, WN, S, K>), grid, dim3(256), 0, st, a, groups)
+  if (stem) { GO(-1, 1); return; }
+  if (a.mode0 == PSM_SRC_SAME) { if (slabs) GO(PSM_SRC_SAME, 8); else GO(PSM_SRC_SAME, 1); }
+  else if (a.mode0 == PSM_SRC_UPSAMPLE) { if (slabs) GO(PSM_SRC_UPSAMPLE, 8); else GO(PSM_SRC_UPSAMPLE, 1); }
+  else { if (slabs) GO(PSM_SRC_MAXPOOL, 8); else GO(PSM_SRC_MAXPOOL, 1); }
+#undef GO
+}
+
 hipError_t psm_launch_conv3x3(const PsmConvArgs& a, int arrangement, int nct, int n_cases, hipStream_t st) {
   const int cout_tiles = (a.cout + 15) / 16;
-  const bool al = (a.c0 % 4 == 0) && (a.c1 % 4 == 0);
+  const bool stem = (a.c0 % 4 != 0) || (a.c1 % 4 != 0);
+  if (stem && (a.mode0 != PSM_SRC_SAME || a.c1 != 0 || a.ks0 != 1)) return hipErrorInvalidValue;
+  if (a.ks0 > 8 || a.ks1 > 8 || a.c0 < 1 || (!stem && a.c0 < 4)) return hipErrorInvalidValue;
+  if (a.mode0 != PSM_SRC_UPSAMPLE && a.c1 != 0) return hipErrorInvalidValue;     // skip inputs come with the upsample
   if (arrangement == 0) {          // pixel-major: 8 rows x 16 columns, every wave 2 rows x all NCT channel tiles
     const int groups = (cout_tiles + nct - 1) / nct;
     const dim3 grid((a.W + TW - 1) / TW, (a.H + 7) / 8, n_cases * groups * a.ksplit);
-#define PIX(N)                                                                                              \
-    do {                                                                                                    \
-      if (al) hipLaunchKernelGGL((psm_conv3x3_kernel<8, 2, N, N, true>), grid, dim3(256), 0, st, a, groups);  \
-      else hipLaunchKernelGGL((psm_conv3x3_kernel<8, 2, N, N, false>), grid, dim3(256), 0, st, a, groups);    \
-    } while (0)
-    if (nct == 1) PIX(1); else if (nct == 2) PIX(2); else if (nct == 4) PIX(4); else return hipErrorInvalidValue;
-#undef PIX
+    if (nct == 1) launch_variant<8, 2, 1, 1>(a, grid, groups, st);
+    else if (nct == 2) launch_variant<8, 2, 2, 2>(a, grid, groups, st);
+    else return hipErrorInvalidValue;
   } else {                         // channel-major: 2 rows x 16 columns, 4 waves = 4 channel tiles
     if (nct != 4) return hipErrorInvalidValue;
     const int groups = (cout_tiles + 3) / 4;
     const dim3 grid((a.W + TW - 1) / TW, (a.H + 1) / 2, n_cases * groups * a.ksplit);
-    if (al) hipLaunchKernelGGL((psm_conv3x3_kernel<2, 2, 4, 1, true>), grid, dim3(256), 0, st, a, groups);
-    else hipLaunchKernelGGL((psm_conv3x3_kernel<2, 2, 4, 1, false>), grid, dim3(256), 0, st, a, groups);
+    launch_variant<2, 2, 4, 1>(a, grid, groups, st);
   }
   return hipGetLastError();
 }

@@ -67,15 +67,15 @@ std::vector<float> pack_conv3x3(const Conv& c) {
 }
 
 // workgroup count first (fill 256 CUs), then the most reuse per workgroup
-void choose_config(Conv& c, int H, int W, bool can_split) {
+void choose_config(Conv& c, int H, int W, int n_cases, bool can_split) {
   const int ctiles = (c.cout + 15) / 16;
   struct Cand { int arr, nct, th; };
-  const Cand cands[4] = {{0, 4, 8}, {0, 2, 8}, {0, 1, 8}, {1, 4, 2}};
+  const Cand cands[3] = {{0, 2, 8}, {0, 1, 8}, {1, 4, 2}};
   long best_score = -1;
   for (const Cand& k : cands) {
     if (k.nct > ctiles) continue;                       // never compute padded channel tiles
     const int groups = (ctiles + k.nct - 1) / k.nct;
-    const long wgs = (long)((W + 15) / 16) * ((H + k.th - 1) / k.th) * groups;
+    const long wgs = (long)((W + 15) / 16) * ((H + k.th - 1) / k.th) * groups * n_cases;
     const long reuse = (long)k.nct * k.th;
     const long score = wgs >= 256 ? 1000000 + reuse * 1000 + (k.arr ? 1 : 0) : wgs * 10 + (k.arr ? 1 : 0);
     if (score > best_score) { best_score = score; c.arrangement = k.arr; c.nct = k.nct; c.groups = groups; }
@@ -84,7 +84,7 @@ void choose_config(Conv& c, int H, int W, bool can_split) {
   // split the input channels over workgroups until the chip is filled (partial-sum slabs, see psm_unet.h); only
   // layers whose output feeds another convolution can be split, at most 8 ways, at least 2 chunks per split
   const int th = c.arrangement ? 2 : 8;
-  const long wgs = (long)((W + 15) / 16) * ((H + th - 1) / th) * c.groups;
+  const long wgs = (long)((W + 15) / 16) * ((H + th - 1) / th) * c.groups * n_cases;
   c.ksplit = 1;
   while (can_split && wgs * c.ksplit < 256 && c.ksplit < 8 && c.n_chunks / (c.ksplit * 2) >= 2) c.ksplit *= 2;
 }
@@ -229,7 +229,7 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
     const int H = ny >> c.level, W = nx >> c.level;
     const size_t ci = &c - u->convs.data();
     const bool feeds_conv3 = ci + 1 < u->convs.size() && u->convs[ci + 1].k == 3;
-    if (c.k == 3) choose_config(c, H, W, feeds_conv3 && getenv("PSM_UNET_NO_SPLIT") == nullptr);
+    if (c.k == 3) choose_config(c, H, W, max_cases, feeds_conv3 && getenv("PSM_UNET_NO_SPLIT") == nullptr);
     int rc = upload_conv(u, c);
     if (rc) return rc;
     free_dev(c.d_out); c.d_out = nullptr;
