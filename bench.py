@@ -81,6 +81,71 @@ def cpu_baseline(model, grid, precision="f32", budget_s=12.0, max_solves=2000):
                       f"(float64 PCA/reassembly, float32 MLP) in {dt:.1f} s"}, sol
 
 
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 matrix peak (256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz)
+
+UNET_WORKLOADS = {           # the convolutional path (SURVEY.md section 8 row a-conv, parity unpinned) -- not the headline
+    "unet": (256, 256, 1, "UNet-S (build-defined: 3x3 convs x2 per level, widths 16-32-64-128-256, max-pool, nearest "
+             "upsample + skip concat, 1x1 head), 256x256x3 -> 256x256x1, batch 1, fp32, 7.0 GFLOP per solve"),
+    "unet8": (256, 256, 8, "UNet-S, 256x256x3 -> 256x256x1, 8 cases per step per GPU, fp32"),
+}
+
+
+def main_unet(args):
+    """Same protocol for the convolutional path: K forward passes back to back, input resident in HBM."""
+    import torch
+    from oracle import unet_oracle as uo
+    from psm_amd import UNetSurrogate, dist as pdist, synthetic
+    rank, world, local_rank = pdist.env_world()
+    backend = os.environ.get("PSM_BENCH_BACKEND", "nccl")
+    local_rank = int(os.environ.get("PSM_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(local_rank)
+    pdist.init(backend, torch.device("cuda", local_rank))
+    NY, NX, NC, desc = UNET_WORKLOADS[args.workload]
+    W = uo.he_weights(uo.unet_specs(), seed=7)
+    net = UNetSurrogate(W, NY, NX, max_cases=NC, device=local_rank)
+    grids = [np.stack([synthetic.channel_grid(NY, NX, seed=1 + 1000 * rank + 10 * i + k).astype(np.float32) for k in range(NC)])
+             for i in range(args.inputs)]
+    d_in = [torch.from_numpy(g).cuda() for g in grids]
+    d_out = [torch.empty((NC, NY, NX, 1), dtype=torch.float32, device="cuda") for _ in grids]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(i):
+        k = i % len(d_in)
+        net.forward_device(d_in[k].data_ptr(), NC, d_out[k].data_ptr(), stream)
+    dt_max = pdist.timed_region(step, args.steps, args.warmup, torch.cuda.synchronize, "cuda" if backend == "nccl" else "cpu")
+    flops = net.flops * NC
+    achieved = flops * args.steps / dt_max / 1e12
+    ms, _ = net.profile(d_in[0].data_ptr(), NC, d_out[0].data_ptr())
+    out = {"metric": "pressure-solves/sec (256x256 U->p inference)", "value": pdist.aggregate_throughput(NC, args.steps, world, dt_max),
+           "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": desc, "grid": [NY, NX], "cases_per_step_per_gpu": NC,
+                      "parallelism": f"case-sharded x{world} (no data-path collective)", "parity": "unpinned (no reference network)"},
+           "roofline": {"kernel": "psm_conv3x3_kernel (all 18 layers + head, whole forward pass)", "bound": "mfma", "achieved": achieved,
+                        "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                        "algorithmic_flops": flops, "per_layer_ms": [float(v) for v in ms]}}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from psm_amd import hostinfo
+        cores = hostinfo.available_cpus()
+        hostinfo.limit_blas_threads(cores)
+        g0 = grids[0][0]
+        ref = uo.unet_forward(g0, W)
+        n, t0 = 0, time.perf_counter()
+        while n < 200 and time.perf_counter() - t0 < 12.0:
+            uo.unet_forward(g0, W); n += 1
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": n / dt, "unit": "solves/s", "cores": int(cores), "kind": "port",
+                               "sample": f"{n} UNet-S forward passes of the NumPy oracle (float64 accumulation) in {dt:.1f} s"}
+        got = d_out[0][0].cpu().numpy()
+        out["l2_vs_oracle"] = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+    if rank == 0:
+        print(json.dumps(out))
+    net.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,9 +153,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inputs", type=int, default=4, help="distinct input grids rotated through (all resident in HBM)")
-    ap.add_argument("--workload", default="config1", choices=sorted(WORKLOADS),
+    ap.add_argument("--workload", default="config1", choices=sorted(WORKLOADS) + sorted(UNET_WORKLOADS),
                     help="BASELINE.json config to run (default: configs[1], the one the metric is quoted on)")
     args = ap.parse_args()
+    if args.workload in UNET_WORKLOADS:
+        return main_unet(args)
 
     import torch
     import psm_amd
