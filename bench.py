@@ -87,7 +87,10 @@ UNET_WORKLOADS = {           # the convolutional path (SURVEY.md section 8 row a
     "unet": (256, 256, 1, "UNet-S (build-defined: 3x3 convs x2 per level, widths 16-32-64-128-256, max-pool, nearest "
              "upsample + skip concat, 1x1 head), 256x256x3 -> 256x256x1, batch 1, fp32, 7.0 GFLOP per solve"),
     "unet8": (256, 256, 8, "UNet-S, 256x256x3 -> 256x256x1, 8 cases per step per GPU, fp32"),
+    "unet8_bf16": (256, 256, 8, "UNet-S, 256x256x3 -> 256x256x1, 8 cases per step per GPU, bf16 operands / f32 accumulate"),
+    "unet512_bf16": (512, 512, 1, "UNet-S, 512x512x3 -> 512x512x1 (BASELINE configs[4] shape), batch 1, bf16 operands / f32 accumulate"),
 }
+MFMA_BF16_PEAK_TFLOPS = 2516.6   # dense bf16 matrix peak (16x the f32 rate)
 
 
 def main_unet(args):
@@ -102,7 +105,9 @@ def main_unet(args):
     pdist.init(backend, torch.device("cuda", local_rank))
     NY, NX, NC, desc = UNET_WORKLOADS[args.workload]
     W = uo.he_weights(uo.unet_specs(), seed=7)
-    net = UNetSurrogate(W, NY, NX, max_cases=NC, device=local_rank)
+    prec = "bf16" if args.workload.endswith("bf16") else "f32"
+    peak = MFMA_BF16_PEAK_TFLOPS if prec == "bf16" else MFMA_F32_PEAK_TFLOPS
+    net = UNetSurrogate(W, NY, NX, max_cases=NC, device=local_rank, precision=prec)
     grids = [np.stack([synthetic.channel_grid(NY, NX, seed=1 + 1000 * rank + 10 * i + k).astype(np.float32) for k in range(NC)])
              for i in range(args.inputs)]
     d_in = [torch.from_numpy(g).cuda() for g in grids]
@@ -118,21 +123,21 @@ def main_unet(args):
     ms, _ = net.profile(d_in[0].data_ptr(), NC, d_out[0].data_ptr())
     out = {"metric": "pressure-solves/sec (256x256 U->p inference)", "value": pdist.aggregate_throughput(NC, args.steps, world, dt_max),
            "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": prec, "data": "synthetic",
            "config": {"workload": desc, "grid": [NY, NX], "cases_per_step_per_gpu": NC,
                       "parallelism": f"case-sharded x{world} (no data-path collective)", "parity": "unpinned (no reference network)"},
            "roofline": {"kernel": "psm_conv3x3_kernel (all 18 layers + head, whole forward pass)", "bound": "mfma", "achieved": achieved,
-                        "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                        "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
                         "algorithmic_flops": flops, "per_layer_ms": [float(v) for v in ms]}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from psm_amd import hostinfo
         cores = hostinfo.available_cpus()
         hostinfo.limit_blas_threads(cores)
         g0 = grids[0][0]
-        ref = uo.unet_forward(g0, W)
+        ref = uo.unet_forward(g0, W, precision=prec)
         n, t0 = 0, time.perf_counter()
         while n < 200 and time.perf_counter() - t0 < 12.0:
-            uo.unet_forward(g0, W); n += 1
+            uo.unet_forward(g0, W, precision=prec); n += 1
         dt = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": n / dt, "unit": "solves/s", "cores": int(cores), "kind": "port",
                                "sample": f"{n} UNet-S forward passes of the NumPy oracle (float64 accumulation) in {dt:.1f} s"}

@@ -35,6 +35,10 @@ int psm_unet_num_convs(const psm_unet* u);
 int psm_unet_conv_shape(const psm_unet* u, int32_t idx, int32_t* k, int32_t* c_in, int32_t* c_out);
 /* weight [k, k, c_in, c_out] float32 (Keras Conv2D kernel), bias [c_out]. */
 int psm_unet_set_conv(psm_unet* u, int32_t idx, const float* weight, const float* bias);
+/* PSM_PRECISION_F32 (default; exact f32 products) or PSM_PRECISION_BF16 (activations and weights rounded to bf16
+ * at every convolution input, f32 accumulation by v_mfma_f32_16x16x32_bf16; activations stay float32 in
+ * memory).  Call before psm_unet_plan.  Constants from psm.h. */
+int psm_unet_set_precision(psm_unet* u, int32_t precision);
 /* Fixes the image size (ny, nx multiples of 2^(n_levels-1)) and the largest case batch; allocates activations. */
 int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases);
 /* Host buffers: grid [n, ny, nx, c_in] -> field [n, ny, nx, c_out], synchronous. */

@@ -91,22 +91,34 @@ def upsample2(x: np.ndarray) -> np.ndarray:
     return np.repeat(np.repeat(x, 2, axis=0), 2, axis=1)
 
 
-def unet_forward(grid: np.ndarray, weights, widths=WIDTHS_S, return_all: bool = False):
+def bf16_round(x) -> np.ndarray:
+    """float32 -> nearest bfloat16 (ties to even), returned as float32 (what v_cvt_pk_bf16_f32 does)."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).reshape(np.shape(x))
+
+
+def unet_forward(grid: np.ndarray, weights, widths=WIDTHS_S, return_all: bool = False, precision: str = "f32"):
     """grid [H,W,c_in] float32 (H, W multiples of 2**(L-1)) -> [H,W,c_out] float32; activations are rounded to
-    float32 after every layer like the device path stores them."""
+    float32 after every layer like the device path stores them.  precision 'bf16': the input of every 3x3
+    convolution (after pooling / upsampling / concatenation) and its kernel are rounded to bf16 first, products
+    exact, accumulation wide -- the device's bf16 operand path; biases, the 1x1 head and the stored activations
+    stay float32."""
     L = len(widths)
+    rnd = bf16_round if precision == "bf16" else (lambda v: v)
+    conv3 = lambda x, Wb: conv2d_same(rnd(x), rnd(Wb[0]), Wb[1], True)
     x = np.asarray(grid, np.float32)
     acts, enc, i = [], [], 0
     for l in range(L):
         if l > 0:
             x = max_pool2(x)
         for _ in range(2):
-            x = conv2d_same(x, *weights[i], True); acts.append(x); i += 1
+            x = conv3(x, weights[i]); acts.append(x); i += 1
         enc.append(x)
     for l in range(L - 2, -1, -1):
         x = np.concatenate([upsample2(x), enc[l]], axis=-1)
         for _ in range(2):
-            x = conv2d_same(x, *weights[i], True); acts.append(x); i += 1
+            x = conv3(x, weights[i]); acts.append(x); i += 1
     x = conv2d_same(x, *weights[i], False); acts.append(x)
     return (x, acts) if return_all else x
 

@@ -18,6 +18,10 @@ struct PsmConvArgs {
   int ks0, ks1;                // slabs of in0 / in1 (1: a finished activation)
   int64_t slab0, slab1;        // slab strides (elements)
   const float* pbias0; const float* pbias1;   // producer biases (ks > 1), ReLU implied
+  // fused 1x1 head (linear): when head_w != nullptr (cout == 16, one channel tile, finished output) the epilogue also
+  // writes head_out[pixel][o] = sum_co act[co] * head_w[co][o] + head_b[o]
+  const float* head_w; const float* head_b; float* head_out; int head_cout; int64_t head_case;
+  int bf16;                    // operands rounded to bf16, chunks of 32 channels, wpack holds bf16x8 pieces
   int ksplit;                  // this layer's own split: workgroup z handles chunks [z*cps, (z+1)*cps) and writes slab z
   int64_t out_slab;
   int mode0;
@@ -36,3 +40,5 @@ struct PsmHeadArgs {           // 1x1 convolution on a thin activation (c_in <= 
 //              1 = channel-major (2 rows x 16 columns, 4 waves = 4 channel tiles of 16)
 hipError_t psm_launch_conv3x3(const PsmConvArgs& a, int arrangement, int nct, int n_cases, hipStream_t st);
 hipError_t psm_launch_head1x1(const PsmHeadArgs& a, hipStream_t st);
+// stem: first layer on the raw grid image, K = 9 * c_in flattened (c_in <= 7); wpack [ct][KG][lane] float4
+hipError_t psm_launch_conv_stem(const PsmConvArgs& a, int n_cases, hipStream_t st);

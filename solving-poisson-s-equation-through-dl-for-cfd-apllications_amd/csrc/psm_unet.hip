@@ -21,6 +21,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+// sum over the 16 lanes of a DPP row (lanes sharing l >> 4); the total lands in lane 15 of the row
+__device__ __forceinline__ float row16_sum(float v) {
+#define PSM_ROW_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, true))
+  PSM_ROW_ADD(0x111); PSM_ROW_ADD(0x112); PSM_ROW_ADD(0x114); PSM_ROW_ADD(0x118);
+#undef PSM_ROW_ADD
+  return v;
+}
+
+// fused linear 1x1 head on a finished 16-channel tile: v = activation of (pixel, channel lane & 15)
+__device__ __forceinline__ void head_epilogue(const PsmConvArgs& a, int cs, int y, int x, int lane, float v) {
+  const int co = lane & 15;
+  for (int o = 0; o < a.head_cout; ++o) {
+    const float s = row16_sum(v * a.head_w[co * a.head_cout + o]);
+    if (co == 15 && y < a.H && x < a.W)
+      a.head_out[(int64_t)cs * a.head_case + ((int64_t)y * a.W + x) * a.head_cout + o] = s + a.head_b[o];
+  }
+}
+
 constexpr int TW = 16;            // tile width (pixels) = MFMA rows
 constexpr int CC = 16;            // input channels per chunk
 constexpr int LDC = CC + 4;       // LDS pixel stride (floats): 16-B slots rotate from pixel to pixel
@@ -219,7 +237,202 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
         float v = acc[m][n][r] + b;
         if (fin && a.relu) v = fmaxf(v, 0.f);
         if (y < a.H && x < a.W && co < a.cout) out[((int64_t)y * a.W + x) * a.cout + co] = v;
+        if (NCT == 1 && a.head_w) head_epilogue(a, cs, y, x, lane, v);      // uniform branch, every lane active
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// bf16 operand variant: activations (after the source transform) and weights rounded to bf16 (RNE), exact
+// products, f32 accumulation by v_mfma_f32_16x16x32_bf16 -- 32 input channels per chunk and ONE MFMA per
+// (tap, row, channel tile): lane l holds A[pixel l&15][k = 8*(l>>4) + j] and B[k][channel l&15], j < 8
+// (one ds_read_b128 each).  Activations stay float32 in HBM (skip connections, slabs and the oracle's
+// rounding points are unchanged); same tiling, staging pipeline, split-K and epilogue as the f32 kernel.
+// ---------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <int TH, int WM, int NCT, int WN, int SRC, int KSM>
+__global__ __launch_bounds__(256) void psm_conv3x3_bf16_kernel(PsmConvArgs a, int co_groups) {
+  constexpr int CB = 32;                                            // input channels per chunk
+  constexpr int LDB = CB + 8;                                       // LDS pixel stride in bf16 (80 B: 16-B slots rotate)
+  constexpr int TILE = (TH + 2) * (TW + 2) * LDB;                   // bf16 per input-tile buffer
+  constexpr int NF = ((TH + 2) * (TW + 2) * (CB / 4) + 255) / 256;  // 4-channel fetches per thread and chunk
+  constexpr int WQ = 9 * NCT * 64;                                  // 16-byte pieces per weight chunk
+  constexpr int NWF = (WQ + 255) / 256;
+  __shared__ __attribute__((aligned(16))) __bf16 in_tile[2 * TILE];
+  __shared__ __attribute__((aligned(16))) bf16x8 w_tile[2 * WQ];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int zz = blockIdx.z / a.ksplit, split = blockIdx.z - zz * a.ksplit;
+  const int cs = zz / co_groups, cog = zz - cs * co_groups;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const float* in0 = a.in0 + (int64_t)cs * a.in0_case;
+  const float* in1 = a.in1 ? a.in1 + (int64_t)cs * a.in1_case : nullptr;
+  const int row_w = (TH == 4 * WM) ? wave * WM : 0;
+  const int ct_w = (TH == 4 * WM) ? 0 : wave * WN;
+  const int px = lane & 15, kq = lane >> 4;
+  f32x4 acc[WM][WN];
+#pragma unroll
+  for (int m = 0; m < WM; ++m)
+#pragma unroll
+    for (int n = 0; n < WN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(a.wpack) + (int64_t)cog * a.n_chunks * WQ;
+  const int cps = (a.n_chunks + a.ksplit - 1) / a.ksplit;
+  const int g_beg = split * cps, g_end = min(a.n_chunks, (split + 1) * cps);
+
+  auto load_w = [&](bf16x8 (&w)[NWF], int g) {
+#pragma unroll
+    for (int u = 0; u < NWF; ++u) w[u] = wsrc[(int64_t)g * WQ + min(tid + 256 * u, WQ - 1)];
+  };
+  auto store_w = [&](const bf16x8 (&w)[NWF], int buf) {
+#pragma unroll
+    for (int u = 0; u < NWF; ++u)
+      if (tid + 256 * u < WQ) w_tile[buf * WQ + tid + 256 * u] = w[u];
+  };
+  auto load_x = [&](f32x4 (&x)[NF], int g) {
+#pragma unroll
+    for (int u = 0; u < NF; ++u) {
+      const int q = tid + 256 * u;
+      const int pos = q >> 3, c4 = q & 7;
+      const int r = pos / (TW + 2), c = pos - r * (TW + 2);
+      const int rr = min(r, TH + 1);
+      x[u] = SRC < 0 ? fetch4_stem(a, in0, y0 - 1 + rr, x0 - 1 + c, g * CB + 4 * c4)
+                     : fetch4<(SRC < 0 ? 0 : SRC), KSM>(a, in0, in1, y0 - 1 + rr, x0 - 1 + c, g * CB + 4 * c4);
+    }
+  };
+  auto store_x = [&](const f32x4 (&x)[NF], int buf) {
+#pragma unroll
+    for (int u = 0; u < NF; ++u) {
+      const int q = tid + 256 * u;
+      if (q < (TH + 2) * (TW + 2) * (CB / 4)) {
+        bf16x4 v;
+        v[0] = (__bf16)x[u][0]; v[1] = (__bf16)x[u][1]; v[2] = (__bf16)x[u][2]; v[3] = (__bf16)x[u][3];
+        *reinterpret_cast<bf16x4*>(&in_tile[buf * TILE + (q >> 3) * LDB + 4 * (q & 7)]) = v;
+      }
+    }
+  };
+
+  f32x4 xr[NF];
+  bf16x8 wr[NWF];
+  if (g_beg < g_end) {
+    load_x(xr, g_beg);
+    load_w(wr, g_beg);
+    store_x(xr, 0);
+    store_w(wr, 0);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  int buf = 0;
+  for (int g = g_beg; g < g_end; ++g) {
+    const bool more = g + 1 < g_end;
+    if (more) { load_x(xr, g + 1); load_w(wr, g + 1); }
+    __builtin_amdgcn_sched_barrier(0);
+    const __bf16* tile = &in_tile[buf * TILE];
+    const bf16x8* wt = &w_tile[buf * WQ + ct_w * 64 + lane];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      bf16x8 av[WM], bv[WN];
+#pragma unroll
+      for (int m = 0; m < WM; ++m)
+        av[m] = *reinterpret_cast<const bf16x8*>(&tile[((row_w + m + ky) * (TW + 2) + px + kx) * LDB + 8 * kq]);
+#pragma unroll
+      for (int n = 0; n < WN; ++n) bv[n] = wt[(tap * NCT + n) * 64];
+#pragma unroll
+      for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[m], bv[n], acc[m][n], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) { store_x(xr, buf ^ 1); store_w(wr, buf ^ 1); }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    buf ^= 1;
+  }
+  float* out = a.out + (int64_t)cs * a.out_case + (int64_t)split * a.out_slab;
+  const bool fin = a.ksplit == 1;
+#pragma unroll
+  for (int n = 0; n < WN; ++n) {
+    const int co = (cog * NCT + ct_w + n) * 16 + (lane & 15);
+    const float b = (fin && co < a.cout) ? a.bias[co] : 0.f;
+#pragma unroll
+    for (int m = 0; m < WM; ++m) {
+      const int y = y0 + row_w + m;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int x = x0 + 4 * kq + r;
+        float v = acc[m][n][r] + b;
+        if (fin && a.relu) v = fmaxf(v, 0.f);
+        if (y < a.H && x < a.W && co < a.cout) out[((int64_t)y * a.W + x) * a.cout + co] = v;
+        if (NCT == 1 && a.head_w) head_epilogue(a, cs, y, x, lane, v);      // uniform branch, every lane active
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stem: the first layer reads the raw grid image (c_in = 3: not a multiple of 4, and only 27 contraction
+// terms).  Padding its three channels to a chunk of 16 would run 144-term MFMAs for 27 useful terms; here
+// K = 9 * c_in is flattened (k = tap * c_in + channel) and padded to KG groups of 16, the A operand is an
+// explicit [128 pixels][KG*16] patch matrix in LDS, gathered straight from the image (every load issued
+// up front, clamped + selected), weights go from global memory to registers in MFMA order.
+// bf16 mode: operands rounded to bf16 first (products exact in the f32 MFMA).
+// ---------------------------------------------------------------------------------------------------
+template <int KG>
+__global__ __launch_bounds__(256) void psm_conv_stem_kernel(PsmConvArgs a) {
+  constexpr int TH = 8, KP = KG * 16, LDA = KP + 4, NE = (TH * TW * KP) / 256;    // patch entries per thread
+  __shared__ __attribute__((aligned(16))) float patch[TH * TW * LDA];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cs = blockIdx.z;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const float* in0 = a.in0 + (int64_t)cs * a.in0_case;
+  const int K = 9 * a.c0;
+  float ev[NE];
+#pragma unroll
+  for (int u = 0; u < NE; ++u) {
+    const int e = tid + 256 * u, p = e / KP, kk = e - p * KP;
+    const int kc = min(kk, K - 1), tap = kc / a.c0, ci = kc - tap * a.c0;
+    const int ky = tap / 3, kx = tap - 3 * ky;
+    const int y = y0 + (p >> 4) + ky - 1, x = x0 + (p & 15) + kx - 1;
+    const bool ok = kk < K && y >= 0 && y < a.H && x >= 0 && x < a.W;
+    const float t = in0[((int64_t)min(max(y, 0), a.H - 1) * a.W + min(max(x, 0), a.W - 1)) * a.c0 + ci];
+    ev[u] = ok ? t : 0.f;
+  }
+  f32x4 bw[KG];
+  const float4* wsrc = a.wpack + lane;
+#pragma unroll
+  for (int g = 0; g < KG; ++g) { const float4 t = wsrc[g * 64]; bw[g] = (f32x4){t.x, t.y, t.z, t.w}; }
+  const float bias = a.bias[lane & 15];
+#pragma unroll
+  for (int u = 0; u < NE; ++u) {
+    const int e = tid + 256 * u, p = e / KP, kk = e - p * KP;
+    patch[p * LDA + kk] = a.bf16 ? (float)(__bf16)ev[u] : ev[u];
+  }
+  __syncthreads();
+  const int px = lane & 15, kq = lane >> 4;
+  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int g = 0; g < KG; ++g) {
+    f32x4 av[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) av[m] = *reinterpret_cast<const f32x4*>(&patch[((2 * wave + m) * TW + px) * LDA + 16 * g + 4 * kq]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[m] = MFMA16(av[m][j], bw[g][j], acc[m]);
+  }
+  float* out = a.out + (int64_t)cs * a.out_case;
+  const int co = lane & 15;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int y = y0 + 2 * wave + m;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int x = x0 + 4 * kq + r;
+      float v = acc[m][r] + bias;
+      if (a.relu) v = fmaxf(v, 0.f);
+      if (y < a.H && x < a.W && co < a.cout) out[((int64_t)y * a.W + x) * a.cout + co] = v;
     }
   }
 }
@@ -241,7 +454,11 @@ template <int TH, int WM, int NCT, int WN>
 static void launch_variant(const PsmConvArgs& a, dim3 grid, int groups, hipStream_t st) {
   const bool stem = (a.c0 % 4 != 0) || (a.c1 % 4 != 0);
   const bool slabs = a.ks0 > 1 || a.ks1 > 1;
-#define GO(S, K) hipLaunchKernelGGL((psm_conv3x3_kernel<TH, WM, NCT, WN, S, K>), grid, dim3(256), 0, st, a, groups)
+#define GO(S, K)                                                                                                         \
+  do {                                                                                                                   \
+    if (a.bf16) hipLaunchKernelGGL((psm_conv3x3_bf16_kernel<TH, WM, NCT, WN, S, K>), grid, dim3(256), 0, st, a, groups);   \
+    else hipLaunchKernelGGL((psm_conv3x3_kernel<TH, WM, NCT, WN, S, K>), grid, dim3(256), 0, st, a, groups);               \
+  } while (0)
   if (stem) { GO(-1, 1); return; }
   if (a.mode0 == PSM_SRC_SAME) { if (slabs) GO(PSM_SRC_SAME, 8); else GO(PSM_SRC_SAME, 1); }
   else if (a.mode0 == PSM_SRC_UPSAMPLE) { if (slabs) GO(PSM_SRC_UPSAMPLE, 8); else GO(PSM_SRC_UPSAMPLE, 1); }
@@ -267,6 +484,17 @@ hipError_t psm_launch_conv3x3(const PsmConvArgs& a, int arrangement, int nct, in
     const dim3 grid((a.W + TW - 1) / TW, (a.H + 1) / 2, n_cases * groups * a.ksplit);
     launch_variant<2, 2, 4, 1>(a, grid, groups, st);
   }
+  return hipGetLastError();
+}
+
+hipError_t psm_launch_conv_stem(const PsmConvArgs& a, int n_cases, hipStream_t st) {
+  const int kg = (9 * a.c0 + 15) / 16;
+  if (a.c0 < 1 || kg > 4 || a.cout > 16 || a.mode0 != PSM_SRC_SAME || a.c1 != 0 || a.ks0 != 1 || a.ksplit != 1) return hipErrorInvalidValue;
+  const dim3 grid((a.W + TW - 1) / TW, (a.H + 7) / 8, n_cases);
+  if (kg == 1) hipLaunchKernelGGL((psm_conv_stem_kernel<1>), grid, dim3(256), 0, st, a);
+  else if (kg == 2) hipLaunchKernelGGL((psm_conv_stem_kernel<2>), grid, dim3(256), 0, st, a);
+  else if (kg == 3) hipLaunchKernelGGL((psm_conv_stem_kernel<3>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((psm_conv_stem_kernel<4>), grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

@@ -1,5 +1,6 @@
 // psm_unet_api.cpp -- handle, layer schedule, weight packing and C-ABI of the convolutional path
 // (include/psm_unet.h; kernels in psm_unet.hip).
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -19,6 +20,8 @@ struct Conv {
   int relu = 1;
   // launch configuration and packed operands
   int arrangement = 0, nct = 1, n_chunks = 0, groups = 1, ksplit = 1;
+  bool stem = false;            // K = 9*c_in flattened (first layer on the raw image)
+  bool fuse_head = false;       // this layer's epilogue also computes the 1x1 head
   std::vector<float> W, b;     // host copies (HWIO), kept for re-packing at plan time
   bool set = false;
   float4* d_w = nullptr;
@@ -34,7 +37,7 @@ struct psm_unet {
   int c_in = 0, c_out = 0, L = 0, device = 0;
   std::vector<int> widths;
   std::vector<Conv> convs;
-  int ny = 0, nx = 0, max_cases = 0, last_cases = 0;
+  int ny = 0, nx = 0, max_cases = 0, last_cases = 0, bf16 = 0;
   bool planned = false;
   float *d_in = nullptr, *d_field = nullptr, *h_in = nullptr, *h_out = nullptr;
   hipStream_t stream = nullptr;
@@ -66,8 +69,50 @@ std::vector<float> pack_conv3x3(const Conv& c) {
   return p;
 }
 
+uint16_t f2bf(float f) {       // round to nearest even, like v_cvt_pk_bf16_f32
+  uint32_t u; std::memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+// bf16: wpack[cog][chunk g of 32][tap][ct][lane][j < 8] = bf16(W[tap][32g + 8*(lane>>4) + j][16*(cog*nct + ct) + (lane&15)])
+std::vector<uint16_t> pack_conv3x3_bf16(const Conv& c) {
+  const int chunks = c.n_chunks, nct = c.nct, groups = c.groups;
+  std::vector<uint16_t> p((size_t)groups * chunks * 9 * nct * 64 * 8, 0);
+  for (int cog = 0; cog < groups; ++cog)
+    for (int g = 0; g < chunks; ++g)
+      for (int tap = 0; tap < 9; ++tap)
+        for (int ct = 0; ct < nct; ++ct)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+              const int ci = 32 * g + 8 * (lane >> 4) + j, co = 16 * (cog * nct + ct) + (lane & 15);
+              if (ci < c.cin && co < c.cout)
+                p[(((((size_t)cog * chunks + g) * 9 + tap) * nct + ct) * 64 + lane) * 8 + j] =
+                    f2bf(c.W[((size_t)tap * c.cin + ci) * c.cout + co]);
+            }
+  return p;
+}
+
+// stem: wpack[g][lane][j] = W[k = 16g + 4*(lane>>4) + j -> (tap = k / c_in, ci = k % c_in)][co = lane & 15]
+std::vector<float> pack_stem(const Conv& c, bool bf16) {
+  const int K = 9 * c.cin, kg = (K + 15) / 16;
+  std::vector<float> p((size_t)kg * 64 * 4, 0.f);
+  for (int g = 0; g < kg; ++g)
+    for (int lane = 0; lane < 64; ++lane)
+      for (int j = 0; j < 4; ++j) {
+        const int k = 16 * g + 4 * (lane >> 4) + j, co = lane & 15;
+        if (k < K && co < c.cout) {
+          float w = c.W[((size_t)(k / c.cin) * c.cin + (k % c.cin)) * c.cout + co];
+          if (bf16) { const uint32_t u = (uint32_t)f2bf(w) << 16; std::memcpy(&w, &u, 4); }
+          p[((size_t)g * 64 + lane) * 4 + j] = w;
+        }
+      }
+  return p;
+}
+
 // workgroup count first (fill 256 CUs), then the most reuse per workgroup
-void choose_config(Conv& c, int H, int W, int n_cases, bool can_split) {
+void choose_config(Conv& c, int H, int W, int n_cases, bool can_split, int chunk_ch) {
   const int ctiles = (c.cout + 15) / 16;
   struct Cand { int arr, nct, th; };
   const Cand cands[3] = {{0, 2, 8}, {0, 1, 8}, {1, 4, 2}};
@@ -80,7 +125,7 @@ void choose_config(Conv& c, int H, int W, int n_cases, bool can_split) {
     const long score = wgs >= 256 ? 1000000 + reuse * 1000 + (k.arr ? 1 : 0) : wgs * 10 + (k.arr ? 1 : 0);
     if (score > best_score) { best_score = score; c.arrangement = k.arr; c.nct = k.nct; c.groups = groups; }
   }
-  c.n_chunks = (c.cin + 15) / 16;
+  c.n_chunks = (c.cin + chunk_ch - 1) / chunk_ch;
   // split the input channels over workgroups until the chip is filled (partial-sum slabs, see psm_unet.h); only
   // layers whose output feeds another convolution can be split, at most 8 ways, at least 2 chunks per split
   const int th = c.arrangement ? 2 : 8;
@@ -95,7 +140,15 @@ int upload_conv(psm_unet* u, Conv& c) {
   std::memcpy(bias.data(), c.b.data(), c.cout * sizeof(float));
   UCHK(u, hipMalloc((void**)&c.d_b, bias.size() * sizeof(float)));
   UCHK(u, hipMemcpy(c.d_b, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
-  if (c.k == 3) {
+  if (c.k == 3 && c.stem) {
+    const std::vector<float> p = pack_stem(c, u->bf16 != 0);
+    UCHK(u, hipMalloc((void**)&c.d_w, p.size() * sizeof(float)));
+    UCHK(u, hipMemcpy(c.d_w, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
+  } else if (c.k == 3 && u->bf16) {
+    const std::vector<uint16_t> p = pack_conv3x3_bf16(c);
+    UCHK(u, hipMalloc((void**)&c.d_w, p.size() * sizeof(uint16_t)));
+    UCHK(u, hipMemcpy(c.d_w, p.data(), p.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  } else if (c.k == 3) {
     const std::vector<float> p = pack_conv3x3(c);
     UCHK(u, hipMalloc((void**)&c.d_w, p.size() * sizeof(float)));
     UCHK(u, hipMemcpy(c.d_w, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -113,6 +166,7 @@ int forward(psm_unet* u, const float* d_grid, int n, float* d_field, hipStream_t
     const int H = u->ny >> c.level, W = u->nx >> c.level;
     float* out = (i + 1 == u->convs.size()) ? d_field : c.d_out;
     if (c.k == 1) {
+      if (u->convs[i - 1].fuse_head) continue;               // computed in the previous layer's epilogue
       PsmHeadArgs ha{u->convs[i - 1].d_out, c.d_w1, c.d_b, out, (int64_t)n * H * W, c.cin, c.cout};
       UCHK(u, psm_launch_head1x1(ha, st));
       continue;
@@ -120,7 +174,7 @@ int forward(psm_unet* u, const float* d_grid, int n, float* d_field, hipStream_t
     PsmConvArgs a{};
     a.wpack = c.d_w; a.bias = c.d_b; a.out = out; a.n_chunks = c.n_chunks; a.H = H; a.W = W; a.cout = c.cout; a.relu = c.relu;
     a.out_case = (int64_t)H * W * c.cout;
-    a.ksplit = c.ksplit; a.out_slab = c.slab; a.ks0 = 1; a.ks1 = 1;
+    a.ksplit = c.ksplit; a.out_slab = c.slab; a.ks0 = 1; a.ks1 = 1; a.bf16 = u->bf16;
     if (c.src == 0) { a.in0 = d_grid; a.c0 = c.cin; a.mode0 = PSM_SRC_SAME; a.H0 = H; a.W0 = W; }
     else {
       const Conv& pv = u->convs[i - 1];
@@ -132,7 +186,12 @@ int forward(psm_unet* u, const float* d_grid, int n, float* d_field, hipStream_t
              a.in1_case = (int64_t)H * W * a.c1; }
     }
     a.in0_case = (int64_t)a.H0 * a.W0 * a.c0;
-    UCHK(u, psm_launch_conv3x3(a, c.arrangement, c.nct, n, st));
+    if (c.fuse_head) {
+      const Conv& hd = u->convs[i + 1];
+      a.head_w = hd.d_w1; a.head_b = hd.d_b; a.head_out = d_field; a.head_cout = hd.cout; a.head_case = (int64_t)H * W * hd.cout;
+    }
+    if (c.stem) UCHK(u, psm_launch_conv_stem(a, n, st));
+    else UCHK(u, psm_launch_conv3x3(a, c.arrangement, c.nct, n, st));
   }
   if (ev) UCHK(u, hipEventRecord(ev[u->convs.size()], st));
   u->last_cases = n;
@@ -216,6 +275,14 @@ int psm_unet_set_conv(psm_unet* u, int32_t idx, const float* weight, const float
   return PSM_OK;
 }
 
+int psm_unet_set_precision(psm_unet* u, int32_t precision) {
+  if (!u) return PSM_ERR_ARG;
+  if (precision != PSM_PRECISION_F32 && precision != PSM_PRECISION_BF16) return fail(u, PSM_ERR_ARG, "unknown precision");
+  if (u->planned) return fail(u, PSM_ERR_STATE, "set the precision before psm_unet_plan");
+  u->bf16 = precision == PSM_PRECISION_BF16 ? 1 : 0;
+  return PSM_OK;
+}
+
 int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
   if (!u) return PSM_ERR_ARG;
   for (const Conv& c : u->convs) if (!c.set) return fail(u, PSM_ERR_STATE, "model incomplete: call psm_unet_set_conv for every convolution first");
@@ -229,7 +296,12 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
     const int H = ny >> c.level, W = nx >> c.level;
     const size_t ci = &c - u->convs.data();
     const bool feeds_conv3 = ci + 1 < u->convs.size() && u->convs[ci + 1].k == 3;
-    if (c.k == 3) choose_config(c, H, W, max_cases, feeds_conv3 && getenv("PSM_UNET_NO_SPLIT") == nullptr);
+    if (c.k == 3) choose_config(c, H, W, max_cases, feeds_conv3 && getenv("PSM_UNET_NO_SPLIT") == nullptr, u->bf16 ? 32 : 16);
+    c.stem = c.k == 3 && c.src == 0 && 9 * c.cin <= 64 && c.cout <= 16 && getenv("PSM_UNET_NO_STEM") == nullptr;
+    if (c.stem) { c.ksplit = 1; c.nct = 1; c.groups = 1; c.arrangement = 0; }
+    c.fuse_head = c.k == 3 && ci + 1 < u->convs.size() && u->convs[ci + 1].k == 1 && c.cout == 16 && !c.stem &&
+                  getenv("PSM_UNET_NO_HEAD_FUSION") == nullptr;
+    if (c.fuse_head) { c.arrangement = 0; c.nct = 1; c.groups = 1; c.ksplit = 1; }
     int rc = upload_conv(u, c);
     if (rc) return rc;
     free_dev(c.d_out); c.d_out = nullptr;

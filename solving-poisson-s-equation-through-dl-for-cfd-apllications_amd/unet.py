@@ -27,7 +27,7 @@ class UNetSurrogate:
     """weights: [(kernel[k,k,c_in,c_out] f32, bias[c_out] f32)] in the order enc0a, enc0b, ..., dec0a, dec0b, head."""
 
     def __init__(self, weights, ny: int, nx: int, c_in: int = 3, c_out: int = 1, widths: Sequence[int] = WIDTHS_S,
-                 max_cases: int = 1, device: int = 0):
+                 max_cases: int = 1, device: int = 0, precision: str = "f32"):
         self.lib = _lib.load()
         self.ny, self.nx, self.c_in, self.c_out, self.max_cases = int(ny), int(nx), int(c_in), int(c_out), int(max_cases)
         w = np.ascontiguousarray(widths, np.int32)
@@ -49,6 +49,7 @@ class UNetSurrogate:
                                      f"{(k.value, k.value, ci.value, co.value)} / {(co.value,)}")
                 self.shapes.append((k.value, ci.value, co.value))
                 self._chk(self.lib.psm_unet_set_conv(self.h, i, _p(_f32(W)), _p(_f32(b))))
+            self._chk(self.lib.psm_unet_set_precision(self.h, _lib.PRECISIONS[precision]))
             self._chk(self.lib.psm_unet_plan(self.h, self.ny, self.nx, self.max_cases))
         except Exception:
             self.close()

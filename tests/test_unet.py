@@ -84,3 +84,32 @@ def test_gpu_unet_other_widths_and_errors():
         UNetSurrogate(W, 42, 72, c_in=4, c_out=2, widths=widths)           # 42 is not a multiple of 4
     with pytest.raises(ValueError):
         UNetSurrogate(W[:-1], 40, 72, c_in=4, c_out=2, widths=widths)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ny,nx,n", [(256, 256, 1), (96, 160, 2)])
+def test_gpu_unet_bf16_matches_bf16_oracle(ny, nx, n):
+    """bf16 operand path (v_mfma_f32_16x16x32_bf16): against the oracle with the same rounding points (inputs and
+    kernels of every 3x3 convolution to bf16, wide accumulation).  An activation that sits on a bf16 rounding
+    boundary can round the other way after a 1e-7 difference upstream, so the bound is a few bf16 ulps of the
+    layer's range, not float32 epsilon; the float32 oracle is only a sanity bound."""
+    from psm_amd import UNetSurrogate
+    specs = uo.unet_specs()
+    W = uo.he_weights(specs, seed=11)
+    grids = np.stack([synthetic.channel_grid(ny, nx, seed=20 + k).astype(np.float32) for k in range(n)])
+    with UNetSurrogate(W, ny, nx, max_cases=n, precision="bf16") as net:
+        out = net.forward(grids)
+        for k in range(n):
+            ref, acts = uo.unet_forward(grids[k], W, return_all=True, precision="bf16")
+            for i in range(len(specs) - 1):
+                a = net.activation(i, n)[k]
+                err = np.linalg.norm(a - acts[i]) / max(np.linalg.norm(acts[i]), 1e-12)
+                assert err <= 1e-2, (specs[i].name, err)            # bf16 epsilon is 7.8e-3
+            assert np.linalg.norm(out[k] - ref) / np.linalg.norm(ref) <= 1e-2
+            f32 = uo.unet_forward(grids[k], W)
+            assert np.linalg.norm(out[k] - f32) / np.linalg.norm(f32) <= 5e-2
+
+
+def test_bf16_rounding_helper():
+    x = np.array([1.0, 1.00390625, 1.0078125, -3.1415927, 0.0], np.float32)       # 1 + 2^-8 ties to even -> 1.0
+    np.testing.assert_array_equal(uo.bf16_round(x), np.array([1.0, 1.0, 1.0078125, -3.140625, 0.0], np.float32))

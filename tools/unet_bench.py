@@ -8,9 +8,10 @@ from psm_amd import UNetSurrogate, synthetic
 from hipmem import DeviceArray
 ny = nx = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+prec = sys.argv[3] if len(sys.argv) > 3 else "f32"
 W = uo.he_weights(uo.unet_specs(), seed=7)
 g = np.stack([synthetic.channel_grid(ny, nx, seed=1 + k).astype(np.float32) for k in range(n)])
-with UNetSurrogate(W, ny, nx, max_cases=n) as net:
+with UNetSurrogate(W, ny, nx, max_cases=n, precision=prec) as net:
     d_in, d_out = DeviceArray(g), DeviceArray(shape=(n, ny, nx, 1))
     for i in range(50): net.forward_device(d_in.ptr, n, d_out.ptr, 0)
     net.synchronize()
@@ -22,7 +23,7 @@ with UNetSurrogate(W, ny, nx, max_cases=n) as net:
         net.synchronize()
         best = min(best, (time.perf_counter() - t0) / N)
     fl = net.flops * n
-    print(f"UNet-S {ny}x{nx} x{n}: {best*1e6:8.1f} us/step  {n/best:9.0f} solves/s  {fl/best/1e12:6.2f} TFLOP/s ({fl/best/157e12*100:.1f}% of f32 MFMA peak)")
+    print(f"UNet-S {prec} {ny}x{nx} x{n}: {best*1e6:8.1f} us/step  {n/best:9.0f} solves/s  {fl/best/1e12:6.2f} TFLOP/s ({fl/best/157e12*100:.1f}% of f32 MFMA peak)")
     ms = np.min([net.profile(d_in.ptr, n, d_out.ptr)[0] for _ in range(5)], axis=0)
     wg = net.profile(d_in.ptr, n, d_out.ptr)[1]
     for sp, t, w in zip(uo.unet_specs(), ms, wg):
