@@ -113,3 +113,23 @@ def test_gpu_unet_bf16_matches_bf16_oracle(ny, nx, n):
 def test_bf16_rounding_helper():
     x = np.array([1.0, 1.00390625, 1.0078125, -3.1415927, 0.0], np.float32)       # 1 + 2^-8 ties to even -> 1.0
     np.testing.assert_array_equal(uo.bf16_round(x), np.array([1.0, 1.0, 1.0078125, -3.140625, 0.0], np.float32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c_in,widths,c_out", [(1, (16, 32), 1), (5, (16, 32, 48), 3), (9, (16, 32), 2), (8, (32, 64), 1), (16, (16, 16), 16)])
+def test_gpu_unet_channel_count_corner_cases(c_in, widths, c_out):
+    """Stem variants (K = 9*c_in flattened for c_in <= 7, scalar-load staging for other counts that are not multiples
+    of 4, plain chunks otherwise), fused and separate 1x1 head (first width 16 vs 32), several head outputs."""
+    from psm_amd import UNetSurrogate
+    specs = uo.unet_specs(c_in, widths, c_out)
+    W = uo.he_weights(specs, seed=100 + c_in)
+    m = 1 << (len(widths) - 1)
+    ny, nx = 12 * m, 20 * m
+    g = np.random.default_rng(c_in).standard_normal((2, ny, nx, c_in)).astype(np.float32)
+    with UNetSurrogate(W, ny, nx, c_in=c_in, c_out=c_out, widths=widths, max_cases=2) as net:
+        out = net.forward(g)
+        for k in range(2):
+            ref, acts = uo.unet_forward(g[k], W, widths, return_all=True)
+            a0 = net.activation(0, 2)[k]
+            assert np.abs(a0 - acts[0]).max() <= 2e-5 * np.abs(acts[0]).max()
+            assert np.abs(out[k] - ref).max() <= 1e-4 * np.abs(ref).max()
