@@ -35,6 +35,19 @@ hipError_t psm_read_stamps(unsigned long long* out) { for (int i = 0; i < 64; ++
 
 __device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
+// streamed-once operands (PCA bases): -DPSM_NT_STREAM selects non-temporal loads (so that the 42 MB of basis data per
+// solve do not displace the small tables and dense weights from the L2s).  Measured on MI355X: SLOWER, 44.1 vs
+// 41.9 us per solve -- back-to-back solves re-read the bases from L2 / Infinity Cache, which nt gives up.  Off.
+#ifdef PSM_NT_STREAM
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 stream_load(const float4* p) {
+  const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+#else
+__device__ __forceinline__ float4 stream_load(const float4* p) { return *p; }
+#endif
+
 // ---------------------------------------------------------------------------
 // encode
 // ---------------------------------------------------------------------------
@@ -118,7 +131,7 @@ __global__ __launch_bounds__(256) void psm_encode_kernel(PsmEncodeArgs a) {
     {
       const float4* p = a.bpack + (((int64_t)s * NT + t) * G) * 64 + lane;
 #pragma unroll
-      for (int g = 0; g < G; ++g) b[g] = p[g * 64];
+      for (int g = 0; g < G; ++g) b[g] = stream_load(p + g * 64);
     }
     __builtin_amdgcn_sched_barrier(0);
     write_rows(xa, 0, 0);
@@ -182,7 +195,7 @@ __global__ __launch_bounds__(256) void psm_encode_kernel(PsmEncodeArgs a) {
     {
       const float4* p = a.bpack + (((int64_t)s * NT + t) * G) * 64 + lane;
 #pragma unroll
-      for (int g = 0; g < G; ++g) b[g] = p[g * 64];
+      for (int g = 0; g < G; ++g) b[g] = stream_load(p + g * 64);
     }
     __builtin_amdgcn_sched_barrier(0);
     write_rows(x0, 0, 0);                       // waits for the activation rows only (counted vmcnt)
@@ -206,7 +219,7 @@ __global__ __launch_bounds__(256) void psm_encode_kernel(PsmEncodeArgs a) {
       if (t != cur_t) {
         const float4* p = a.bpack + (((int64_t)s * NT + t) * G) * 64 + lane;
 #pragma unroll
-        for (int g = 0; g < G; ++g) b[g] = p[g * 64];
+        for (int g = 0; g < G; ++g) b[g] = stream_load(p + g * 64);
         cur_t = t;
       }
       for (int mt = 0; mt < rows / 32; ++mt) gemm_tile(b, mt, t, m0, true);
@@ -555,7 +568,7 @@ __global__ __launch_bounds__(256) void psm_decode128_kernel(PsmDecodeArgs a, int
   float4 b[GD];                                  // this wave's weight slice: loaded once, kept for every row chunk
   const float4* bp = a.bpack + ((int64_t)ct * GD) * 64 + lane;
 #pragma unroll
-  for (int g = 0; g < GD; ++g) b[g] = bp[g * 64];
+  for (int g = 0; g < GD; ++g) b[g] = stream_load(bp + g * 64);
   const int col = ct * 32 + i;
   const float mu = a.mean[col];
   __builtin_amdgcn_sched_barrier(0);
