@@ -36,3 +36,15 @@ shutil.copy(st, f"profiles/{tag}_kernel_stats.csv")
 open(f"profiles/{tag}_bench.json.log", "w").write(open(f"{O}/bench.log").read().strip().splitlines()[-1] + "\n")
 for r in list(csv.DictReader(open(st)))[:10]:
     print(f"{r['Name'][:60]:60s} calls={int(r['Calls']):6d} avg_us={float(r['AverageNs'])/1e3:8.2f}")
+
+# convolutional path
+import glob as _g
+us = sorted(_g.glob(f"{O}/unet_stats/*/*kernel_stats.csv"))
+if us:
+    shutil.copy(us[-1], f"profiles/{tag}_unet8_kernel_stats.csv")
+for name in ("bench_unet", "bench_unet8", "bench_unet8_bf16"):
+    p = f"{O}/{name}.log"
+    if os.path.exists(p):
+        lines = open(p).read().strip().splitlines()
+        if lines:
+            open(f"profiles/{tag}_{name}.json.log", "w").write(lines[-1] + "\n")

@@ -13,13 +13,15 @@ NAMES = {0: "encode start", 1: "encode staged", 2: "encode end", 8: "rd1 start",
          39: "assemble chain", 40: "assemble post", 41: "assemble end"}
 for l in range(4):
     NAMES[44 + 4 * l] = f"dense{l} start"; NAMES[45 + 4 * l] = f"dense{l} mfma done"; NAMES[46 + 4 * l] = f"dense{l} end"
-model = synthetic.make_model("gradp")
-grid = synthetic.channel_grid(256, 256, seed=1).astype(np.float32)
-with psm_amd.GridSurrogate(model, 256, 256) as sur:
-    d_in, d_out = DeviceArray(grid), DeviceArray(shape=(256, 256, 2))
+variant = sys.argv[1] if len(sys.argv) > 1 else "gradp"
+NC = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+model = synthetic.make_model(variant)
+grid = np.stack([synthetic.channel_grid(256, 256, seed=1 + k).astype(np.float32) for k in range(NC)])
+with psm_amd.GridSurrogate(model, 256, 256, max_cases=NC) as sur:
+    d_in, d_out = DeviceArray(grid), DeviceArray(shape=(NC, 256, 256, model.c_out))
     acc = []
     for it in range(60):
-        for k in range(20): sur.solve_device(d_in.ptr, 1, d_out.ptr, 0)
+        for k in range(20): sur.solve_device(d_in.ptr, NC, d_out.ptr, 0)
         sur.synchronize()
         out = np.zeros(64, np.float32)
         sur._chk(sur.lib.psm_read_stage(sur.h, 6, out.ctypes.data_as(C.POINTER(C.c_float)), 64))
