@@ -1,0 +1,25 @@
+"""Rate of the solver boundary psm_solve (cells[N,5] float64 -> p[N] float64; PythonComm.H contract): host buffers in,
+host buffers out, synchronous like py_func -- next to the NumPy oracle's py_func on the same case."""
+import sys, time
+import numpy as np
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import cases
+from oracle import psm_oracle as orc
+from psm_amd import SolverModule
+from test_oracle_golden import oracle_model
+array, top, obst, model, maxs = cases.build_mesh_case()
+sm = SolverModule(model, maxs)
+t0 = time.perf_counter(); sm.init_func(array, top, obst); t_init = time.perf_counter() - t0
+for _ in range(50): p = sm.py_func(array)
+N = 2000
+t0 = time.perf_counter()
+for _ in range(N): p = sm.py_func(array)
+dt = (time.perf_counter() - t0) / N
+geo = orc.init_geometry(array, top, obst)
+om = oracle_model(model)
+t0 = time.perf_counter(); n = 0
+while time.perf_counter() - t0 < 5: ref = orc.py_func_mesh(array, geo, om, maxs)[0]; n += 1
+dc = (time.perf_counter() - t0) / n
+print(f"cells {array.shape[0]}, grid {sm.tables.ny}x{sm.tables.nx}, blocks {sm._sur.B}: init_func {t_init:.2f} s (host, SciPy qhull)")
+print(f"psm_solve (py_func): {dt*1e6:7.1f} us per call = {1/dt:8.0f} solves/s ; NumPy oracle py_func {dc*1e3:6.2f} ms ({dt and dc/dt:.0f}x)")
+print("max |p - oracle| / max|p| =", np.abs(p - ref).max() / np.abs(ref).max())
