@@ -116,6 +116,55 @@ __device__ __forceinline__ f32x4 fetch4_stem(const PsmConvArgs& a, const float* 
   return v;
 }
 
+// Loop-invariant part of one 4-channel fetch (pixel position -> element offsets, padding predicate), computed once
+// per workgroup: inside the chunk loop a fetch is then one add and one (slab-summed) 16-byte load.  The address
+// arithmetic would otherwise run again for every chunk, in front of the MFMAs (~600 VALU instructions per chunk).
+struct PsmFetchPos {
+  int off0;      // element offset of channel 0 of the source pixel in in0 (for max-pool: its top-left pixel)
+  int off1;      // same in the skip input
+  bool ok;       // inside the image (else the zero padding)
+};
+
+template <int SRC>
+__device__ __forceinline__ PsmFetchPos prepare_fetch(const PsmConvArgs& a, int y, int x) {
+  PsmFetchPos f;
+  f.ok = (y >= 0) && (y < a.H) && (x >= 0) && (x < a.W);
+  const int yc = min(max(y, 0), a.H - 1), xc = min(max(x, 0), a.W - 1);
+  if (SRC == PSM_SRC_UPSAMPLE) f.off0 = ((yc >> 1) * a.W0 + (xc >> 1)) * a.c0;
+  else if (SRC == PSM_SRC_MAXPOOL) f.off0 = ((2 * yc) * a.W0 + 2 * xc) * a.c0;
+  else f.off0 = (yc * a.W0 + xc) * a.c0;
+  f.off1 = (yc * a.W + xc) * a.c1;
+  return f;
+}
+
+// channels [ch, ch+4) of a chunk that lies entirely in in0 (from0, uniform) or entirely in the skip input.  The
+// source is chosen with selects on pointer / slab parameters -- no branch around the loads.
+template <int SRC, int KSM>
+__device__ __forceinline__ f32x4 fetch4_prepared(const PsmConvArgs& a, const float* in0, const float* in1, const PsmFetchPos& f,
+                                                 int ch, bool from0) {
+  f32x4 v;
+  if (SRC == PSM_SRC_MAXPOOL) {
+    const float* p = in0 + f.off0 + ch;
+    const f32x4 q0 = read4<KSM>(p, a.ks0, a.slab0, a.pbias0, ch);
+    const f32x4 q1 = read4<KSM>(p + a.c0, a.ks0, a.slab0, a.pbias0, ch);
+    const f32x4 q2 = read4<KSM>(p + a.W0 * a.c0, a.ks0, a.slab0, a.pbias0, ch);
+    const f32x4 q3 = read4<KSM>(p + a.W0 * a.c0 + a.c0, a.ks0, a.slab0, a.pbias0, ch);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaxf(q0[j], q1[j]), fmaxf(q2[j], q3[j]));
+  } else if (SRC == PSM_SRC_UPSAMPLE) {
+    const float* p = from0 ? in0 + f.off0 + ch : in1 + f.off1 + (ch - a.c0);
+    const int ks = from0 ? a.ks0 : a.ks1;
+    const int64_t slab = from0 ? a.slab0 : a.slab1;
+    const float* pb = from0 ? a.pbias0 : a.pbias1;
+    v = read4<KSM>(p, ks, slab, pb, from0 ? ch : ch - a.c0);
+  } else {
+    v = read4<KSM>(in0 + f.off0 + ch, a.ks0, a.slab0, a.pbias0, ch);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = f.ok ? v[j] : 0.f;
+  return v;
+}
+
 // TH: tile rows; WM: rows per wave; NCT: channel tiles per workgroup; WN: channel tiles per wave.
 // Software pipeline over the channel chunks, both operands double-buffered in LDS: the input tile (through the
 // source transform) and the weights (9 x NCT KiB, already in MFMA operand order) of chunk g+1 are requested
@@ -124,7 +173,7 @@ __device__ __forceinline__ f32x4 fetch4_stem(const PsmConvArgs& a, const float* 
 // of a chunk are 2.25 x NCT float4 per thread), so that several workgroups share a CU and hide each other's
 // prologue -- holding a wave's own weight slice in registers (9 x WN float4 per lane, twice for the
 // pipeline) measured slower at every batch size.
-template <int TH, int WM, int NCT, int WN, int SRC, int KSM>     // SRC: PSM_SRC_* or -1 = unaligned stem
+template <int TH, int WM, int NCT, int WN, int SRC, int KSM>     // SRC: PSM_SRC_*, -1 = unaligned stem, 3 = upsample + skip with the seam inside a chunk
 __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_groups) {
   constexpr int TILE = (TH + 2) * (TW + 2) * LDC;                   // floats per input-tile buffer
   constexpr int NF = ((TH + 2) * (TW + 2) * (CC / 4) + 255) / 256;  // 4-channel input fetches per thread and chunk
@@ -163,16 +212,35 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
     for (int u = 0; u < NWF; ++u)
       if (tid + 256 * u < WQ) w_tile[buf * WQ + tid + 256 * u] = w[u];
   };
+  // loop-invariant fetch positions; chunks normally lie on one side of the concatenation seam (channel counts
+  // are multiples of the chunk), else the general per-lane path is taken
+  constexpr int SRCP = SRC == 3 ? PSM_SRC_UPSAMPLE : (SRC < 0 ? 0 : SRC);
+  PsmFetchPos fp[NF];
+#pragma unroll
+  for (int u = 0; u < NF; ++u) {
+    const int pos = (tid + 256 * u) >> 2;
+    const int r = min(pos / (TW + 2), TH + 1), c = pos - (pos / (TW + 2)) * (TW + 2);
+    fp[u] = prepare_fetch<SRCP>(a, y0 - 1 + r, x0 - 1 + c);
+  }
   auto load_x = [&](f32x4 (&x)[NF], int g) {
+    const bool from0 = g * CC < a.c0;                 // uniform
 #pragma unroll
     for (int u = 0; u < NF; ++u) {
       const int q = tid + 256 * u;
       const int pos = q >> 2, c4 = q & 3;
       const int r = pos / (TW + 2), c = pos - r * (TW + 2);
-      // fetches beyond the tile (last round) read a clamped position and are not stored
       const int rr = min(r, TH + 1);
-      x[u] = SRC < 0 ? fetch4_stem(a, in0, y0 - 1 + rr, x0 - 1 + c, g * CC + 4 * c4)
-                     : fetch4<(SRC < 0 ? 0 : SRC), KSM>(a, in0, in1, y0 - 1 + rr, x0 - 1 + c, g * CC + 4 * c4);
+      const int ch = g * CC + 4 * c4;
+      if (SRC < 0) x[u] = fetch4_stem(a, in0, y0 - 1 + rr, x0 - 1 + c, ch);
+      else if (SRC == 3) x[u] = fetch4<PSM_SRC_UPSAMPLE, KSM>(a, in0, in1, y0 - 1 + rr, x0 - 1 + c, ch);
+      else {
+        // channels beyond the real inputs (zero-padded tail of the last chunk) read a clamped group and are zeroed
+        const int lim = from0 ? a.c0 : a.c0 + a.c1;
+        const f32x4 t = fetch4_prepared<SRCP, KSM>(a, in0, in1, fp[u], min(ch, lim - 4), from0);
+        const bool live = ch < lim;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[u][j] = live ? t[j] : 0.f;
+      }
     }
   };
   auto store_x = [&](const f32x4 (&x)[NF], int buf) {
@@ -291,15 +359,35 @@ __global__ __launch_bounds__(256) void psm_conv3x3_bf16_kernel(PsmConvArgs a, in
     for (int u = 0; u < NWF; ++u)
       if (tid + 256 * u < WQ) w_tile[buf * WQ + tid + 256 * u] = w[u];
   };
+  // loop-invariant fetch positions; chunks normally lie on one side of the concatenation seam (channel counts
+  // are multiples of the chunk), else the general per-lane path is taken
+  constexpr int SRCP = SRC == 3 ? PSM_SRC_UPSAMPLE : (SRC < 0 ? 0 : SRC);
+  PsmFetchPos fp[NF];
+#pragma unroll
+  for (int u = 0; u < NF; ++u) {
+    const int pos = (tid + 256 * u) >> 3;
+    const int r = min(pos / (TW + 2), TH + 1), c = pos - (pos / (TW + 2)) * (TW + 2);
+    fp[u] = prepare_fetch<SRCP>(a, y0 - 1 + r, x0 - 1 + c);
+  }
   auto load_x = [&](f32x4 (&x)[NF], int g) {
+    const bool from0 = g * CB < a.c0;                 // uniform
 #pragma unroll
     for (int u = 0; u < NF; ++u) {
       const int q = tid + 256 * u;
       const int pos = q >> 3, c4 = q & 7;
       const int r = pos / (TW + 2), c = pos - r * (TW + 2);
       const int rr = min(r, TH + 1);
-      x[u] = SRC < 0 ? fetch4_stem(a, in0, y0 - 1 + rr, x0 - 1 + c, g * CB + 4 * c4)
-                     : fetch4<(SRC < 0 ? 0 : SRC), KSM>(a, in0, in1, y0 - 1 + rr, x0 - 1 + c, g * CB + 4 * c4);
+      const int ch = g * CB + 4 * c4;
+      if (SRC < 0) x[u] = fetch4_stem(a, in0, y0 - 1 + rr, x0 - 1 + c, ch);
+      else if (SRC == 3) x[u] = fetch4<PSM_SRC_UPSAMPLE, KSM>(a, in0, in1, y0 - 1 + rr, x0 - 1 + c, ch);
+      else {
+        // channels beyond the real inputs (zero-padded tail of the last chunk) read a clamped group and are zeroed
+        const int lim = from0 ? a.c0 : a.c0 + a.c1;
+        const f32x4 t = fetch4_prepared<SRCP, KSM>(a, in0, in1, fp[u], min(ch, lim - 4), from0);
+        const bool live = ch < lim;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[u][j] = live ? t[j] : 0.f;
+      }
     }
   };
   auto store_x = [&](const f32x4 (&x)[NF], int buf) {
@@ -461,7 +549,11 @@ static void launch_variant(const PsmConvArgs& a, dim3 grid, int groups, hipStrea
   } while (0)
   if (stem) { GO(-1, 1); return; }
   if (a.mode0 == PSM_SRC_SAME) { if (slabs) GO(PSM_SRC_SAME, 8); else GO(PSM_SRC_SAME, 1); }
-  else if (a.mode0 == PSM_SRC_UPSAMPLE) { if (slabs) GO(PSM_SRC_UPSAMPLE, 8); else GO(PSM_SRC_UPSAMPLE, 1); }
+  else if (a.mode0 == PSM_SRC_UPSAMPLE) {
+    const bool seam_inside = a.c1 > 0 && (a.c0 % (a.bf16 ? 32 : 16)) != 0;
+    if (seam_inside) { if (slabs) GO(3, 8); else GO(3, 1); }
+    else { if (slabs) GO(PSM_SRC_UPSAMPLE, 8); else GO(PSM_SRC_UPSAMPLE, 1); }
+  }
   else { if (slabs) GO(PSM_SRC_MAXPOOL, 8); else GO(PSM_SRC_MAXPOOL, 1); }
 #undef GO
 }
