@@ -52,6 +52,10 @@ int psm_unet_read_activation(psm_unet* u, int32_t idx, float* dst, int64_t dst_f
 /* One forward pass with a HIP event between the layers: ms [num_convs] (each includes ~3 us of event overhead),
  * wgs [num_convs] workgroups launched per layer (may be NULL).  Introspection for tuning. */
 int psm_unet_profile(psm_unet* u, const float* d_grid, int32_t n_cases, float* d_field, float* ms, int32_t* wgs);
+/* Diagnostic builds (-DPSM_STAMPS) only: runs the network up to and including convolution `idx` on the staged input of
+ * the last psm_unet_forward and returns workgroup-0 time stamps of that last layer, stamps_us[64] in microseconds
+ * after the first (-1: not reached; all -1 in the shipped library). */
+int psm_unet_debug_run_layer(psm_unet* u, int32_t idx, float* stamps_us);
 /* Algorithmic work of one forward pass of one case at the planned size. */
 int64_t psm_unet_flops(const psm_unet* u);
 

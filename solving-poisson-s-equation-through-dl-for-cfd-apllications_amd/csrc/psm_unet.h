@@ -40,5 +40,6 @@ struct PsmHeadArgs {           // 1x1 convolution on a thin activation (c_in <= 
 //              1 = channel-major (2 rows x 16 columns, 4 waves = 4 channel tiles of 16)
 hipError_t psm_launch_conv3x3(const PsmConvArgs& a, int arrangement, int nct, int n_cases, hipStream_t st);
 hipError_t psm_launch_head1x1(const PsmHeadArgs& a, hipStream_t st);
+hipError_t psm_unet_read_stamps(unsigned long long* out);   // [64]; zeros unless built with -DPSM_STAMPS
 // stem: first layer on the raw grid image, K = 9 * c_in flattened (c_in <= 7); wpack [ct][KG][lane] float4
 hipError_t psm_launch_conv_stem(const PsmConvArgs& a, int n_cases, hipStream_t st);

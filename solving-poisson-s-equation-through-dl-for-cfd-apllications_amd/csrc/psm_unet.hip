@@ -19,6 +19,16 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// Diagnostic stamps (100 MHz wall clock) of workgroup (0,0,0) -- compiled only with -DPSM_STAMPS.
+#ifdef PSM_STAMPS
+__device__ unsigned long long g_unet_stamps[64];
+#define USTAMP(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && (k) < 64) g_unet_stamps[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+hipError_t psm_unet_read_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_unet_stamps), sizeof(g_unet_stamps)); }
+#else
+#define USTAMP(k) do { } while (0)
+hipError_t psm_unet_read_stamps(unsigned long long* out) { for (int i = 0; i < 64; ++i) out[i] = 0; return hipSuccess; }
+#endif
+
 namespace {
 
 // sum over the 16 lanes of a DPP row (lanes sharing l >> 4); the total lands in lane 15 of the row
@@ -251,6 +261,7 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
     }
   };
 
+  USTAMP(0);
   f32x4 xr[NF], wr[NWF];
   if (g_beg < g_end) {
     load_x(xr, g_beg);
@@ -259,11 +270,14 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
     store_w(wr, 0);
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  USTAMP(1);
   int buf = 0;
   for (int g = g_beg; g < g_end; ++g) {
     const bool more = g + 1 < g_end;
     if (more) { load_x(xr, g + 1); load_w(wr, g + 1); }
-    __builtin_amdgcn_sched_barrier(0);
+    // no scheduling fence here: the load issue (TA-bound: ~30 wave-wide loads x 4 waves per chunk) may interleave
+    // with the MFMAs below, which hold the vector issue for only 8 of their 32 cycles
+    USTAMP(2 + 4 * (g - g_beg));
     const float* tile = &in_tile[buf * TILE];
     const f32x4* wt = &w_tile[buf * WQ + ct_w * 64 + lane];
 #pragma unroll
@@ -285,8 +299,11 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
     }
     // nothing below may be scheduled among the MFMAs: the LDS stores wait for the loads issued above
     __builtin_amdgcn_sched_barrier(0);
+    USTAMP(3 + 4 * (g - g_beg));
     if (more) { store_x(xr, buf ^ 1); store_w(wr, buf ^ 1); }
+    USTAMP(4 + 4 * (g - g_beg));
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    USTAMP(5 + 4 * (g - g_beg));
     buf ^= 1;
   }
   // ---- epilogue: bias + ReLU (split-K: the raw partial sum into this split's slab), NHWC store
@@ -309,6 +326,7 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
       }
     }
   }
+  USTAMP(63);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -415,7 +433,6 @@ __global__ __launch_bounds__(256) void psm_conv3x3_bf16_kernel(PsmConvArgs a, in
   for (int g = g_beg; g < g_end; ++g) {
     const bool more = g + 1 < g_end;
     if (more) { load_x(xr, g + 1); load_w(wr, g + 1); }
-    __builtin_amdgcn_sched_barrier(0);
     const __bf16* tile = &in_tile[buf * TILE];
     const bf16x8* wt = &w_tile[buf * WQ + ct_w * 64 + lane];
 #pragma unroll

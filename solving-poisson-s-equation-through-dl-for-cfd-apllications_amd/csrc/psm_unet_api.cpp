@@ -159,8 +159,9 @@ int upload_conv(psm_unet* u, Conv& c) {
   return PSM_OK;
 }
 
-int forward(psm_unet* u, const float* d_grid, int n, float* d_field, hipStream_t st, hipEvent_t* ev = nullptr) {
-  for (size_t i = 0; i < u->convs.size(); ++i) {
+int forward(psm_unet* u, const float* d_grid, int n, float* d_field, hipStream_t st, hipEvent_t* ev = nullptr, int n_layers = -1) {
+  const size_t n_run = n_layers < 0 ? u->convs.size() : (size_t)n_layers;
+  for (size_t i = 0; i < n_run; ++i) {
     if (ev) UCHK(u, hipEventRecord(ev[i], st));
     Conv& c = u->convs[i];
     const int H = u->ny >> c.level, W = u->nx >> c.level;
@@ -396,6 +397,27 @@ int psm_unet_profile(psm_unet* u, const float* d_grid, int32_t n_cases, float* d
   }
   for (auto& e : ev) (void)hipEventDestroy(e);
   return rc;
+}
+
+int psm_unet_debug_run_layer(psm_unet* u, int32_t idx, float* stamps_us) {
+  // diagnostic builds: re-run convolution `idx` alone on the activations of the last forward pass and return the
+  // workgroup-0 stamps in microseconds after the first one (-1: not reached)
+  if (!u || !stamps_us) return PSM_ERR_ARG;
+  if (!u->planned || u->last_cases < 1 || idx < 0 || idx >= (int)u->convs.size()) return fail(u, PSM_ERR_STATE, "run a forward pass first");
+  UCHK(u, hipSetDevice(u->device));
+  std::vector<Conv> saved;
+  // run the whole network but only stamp-read after it: stamps are overwritten by every layer, so run up to idx
+  const size_t n_all = u->convs.size();
+  (void)n_all;
+  int rc = forward(u, u->d_in, u->last_cases, u->d_field, u->stream, nullptr, idx + 1);
+  if (rc) return rc;
+  UCHK(u, hipStreamSynchronize(u->stream));
+  unsigned long long t[64];
+  UCHK(u, psm_unet_read_stamps(t));
+  unsigned long long t0 = ~0ull;
+  for (int k = 0; k < 64; ++k) if (t[k] && t[k] < t0) t0 = t[k];
+  for (int k = 0; k < 64; ++k) stamps_us[k] = t[k] ? (float)((double)(t[k] - t0) * 0.01) : -1.f;
+  return PSM_OK;
 }
 
 int64_t psm_unet_flops(const psm_unet* u) {
