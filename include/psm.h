@@ -178,6 +178,13 @@ int psm_set_geometry(psm_handle* h, int64_t n_cells, int32_t ny, int32_t nx,
  * accepted for signature compatibility (the MPI funnel, PM:258/511, stays with the caller).
  * Synchronous. */
 int psm_solve(psm_handle* h, const double* cells, int64_t n, int32_t rank, double* p_out);
+/* Optional: register the solver's own persistent buffers (the `input_vals` array of PythonComm_init.H:53 lives for the
+ * whole run; the output array likewise) so that psm_solve DMAs from / to them directly instead of through the
+ * handle's pinned staging copies (saves two host memcpys per step).  cells [n_cells,5] and / or p_out [n_cells] (either
+ * may be NULL); the caller guarantees they stay allocated, at the same address, until psm_unpin_buffers, a new
+ * psm_set_geometry or psm_destroy.  psm_solve calls with other pointers keep using the staging path. */
+int psm_pin_buffers(psm_handle* h, const double* cells, double* p_out);
+int psm_unpin_buffers(psm_handle* h);
 /* Generic mesh -> grid step of the evaluators (interpolate_fill + scatter, SM_call.py:419-436,
  * pressureSM_Poisson/SM_call.py:580-600): values [n_cells, k] float64 row-major (k columns of cell
  * data) -> grid_out [ny*nx, k] float64 holding, per image cell, the interpolated value of the grid

@@ -63,6 +63,8 @@ SIGNATURES = {
                                    C.c_int32, C.c_int32, C.c_double]),
     "psm_solve": (C.c_int, [_hp, _f64p, C.c_int64, C.c_int32, _f64p]),
     "psm_poisson_features": (C.c_int, [_hp, _f64p, _f64p, _f64p, _f64p, _f64p, C.c_int32, C.c_int32, _f64p, _f32p]),
+    "psm_pin_buffers": (C.c_int, [_hp, _f64p, _f64p]),
+    "psm_unpin_buffers": (C.c_int, [_hp]),
     "psm_mesh_to_grid": (C.c_int, [_hp, _f64p, C.c_int64, C.c_int32, C.c_int32, _f64p]),
     "psm_gaussian_filter": (C.c_int, [_hp, _f32p, C.c_int32, C.c_int32, C.c_double, C.c_double, _f32p]),
     "psm_set_integration": (C.c_int, [_hp, C.c_int32, C.c_int32, _f64p, C.c_int32, C.c_int32, C.c_double, C.c_double]),

@@ -73,6 +73,8 @@ struct psm_handle {
   int2 *d_fixups = nullptr, *d_pairs = nullptr;
   float *d_integ_buf = nullptr, *d_gradp = nullptr;
   double *h_cells = nullptr, *h_p = nullptr;
+  const double* pinned_cells = nullptr;   // caller buffers registered with psm_pin_buffers (DMA without staging copies)
+  double* pinned_p = nullptr;
   double maxs[4] = {1, 1, 1, 1};
   int normalise_sdf = 0, fill_input = 0;
   float *d_grid_stage = nullptr, *d_fields_stage = nullptr;
@@ -207,7 +209,13 @@ std::vector<float4> pack_comp_out(const double* comp, int P, int K_out, int Gd) 
   return out;
 }
 
+void unpin_buffers(psm_handle* h) {
+  if (h->pinned_cells) { (void)hipHostUnregister((void*)h->pinned_cells); h->pinned_cells = nullptr; }
+  if (h->pinned_p) { (void)hipHostUnregister((void*)h->pinned_p); h->pinned_p = nullptr; }
+}
+
 void free_geometry(psm_handle* h) {
+  unpin_buffers(h);
   dev_free(h->d_vtx_m2g); dev_free(h->d_src_of_cell); dev_free(h->d_vtx_g2m); dev_free(h->d_cell_of_point);
   dev_free(h->d_wts_m2g); dev_free(h->d_sdf); dev_free(h->d_wts_g2m); dev_free(h->d_cells); dev_free(h->d_p);
   dev_free(h->d_umax); dev_free(h->d_near_wall);
@@ -935,8 +943,12 @@ int psm_solve(psm_handle* h, const double* cells, int64_t n, int32_t rank, doubl
   if (n != h->n_cells) return fail(h, PSM_ERR_ARG, "cell count differs from the geometry");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   hipStream_t st = h->stream;
-  memcpy(h->h_cells, cells, (size_t)n * 5 * sizeof(double));
-  HIPCHK(h, hipMemcpyAsync(h->d_cells, h->h_cells, (size_t)n * 5 * sizeof(double), hipMemcpyHostToDevice, st));
+  if (cells == h->pinned_cells) {            // registered by the caller: DMA straight from its buffer
+    HIPCHK(h, hipMemcpyAsync(h->d_cells, cells, (size_t)n * 5 * sizeof(double), hipMemcpyHostToDevice, st));
+  } else {
+    memcpy(h->h_cells, cells, (size_t)n * 5 * sizeof(double));
+    HIPCHK(h, hipMemcpyAsync(h->d_cells, h->h_cells, (size_t)n * 5 * sizeof(double), hipMemcpyHostToDevice, st));
+  }
   HIPCHK(h, psm_launch_umax(h->d_cells, n, h->d_umax, st));
   PsmToGridArgs ga{};
   ga.cells = h->d_cells; ga.umax = h->d_umax; ga.vtx = h->d_vtx_m2g; ga.wts = h->d_wts_m2g; ga.src_of_cell = h->d_src_of_cell;
@@ -951,9 +963,41 @@ int psm_solve(psm_handle* h, const double* cells, int64_t n, int32_t rank, doubl
   ma.field = h->d_fields_stage; ma.near_wall = h->d_near_wall; ma.p_out = h->d_p; ma.n_cells = n; ma.max_abs_p = h->maxs[3];
   ma.c_out = h->cfg.c_out;
   HIPCHK(h, psm_launch_to_mesh(ma, st));
+  if (p_out == h->pinned_p) {
+    HIPCHK(h, hipMemcpyAsync(p_out, h->d_p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    return PSM_OK;
+  }
   HIPCHK(h, hipMemcpyAsync(h->h_p, h->d_p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
   memcpy(p_out, h->h_p, (size_t)n * sizeof(double));
+  return PSM_OK;
+}
+
+int psm_pin_buffers(psm_handle* h, const double* cells, double* p_out) {
+  if (!h) return PSM_ERR_ARG;
+  if (!h->have_geometry) return fail(h, PSM_ERR_STATE, "psm_set_geometry has not been called");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  unpin_buffers(h);
+  if (cells) {
+    hipError_t e = hipHostRegister((void*)cells, (size_t)h->n_cells * 5 * sizeof(double), hipHostRegisterDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(h, PSM_ERR_HIP, std::string("hipHostRegister(cells): ") + hipGetErrorString(e)); }
+    h->pinned_cells = cells;
+  }
+  if (p_out) {
+    hipError_t e = hipHostRegister((void*)p_out, (size_t)h->n_cells * sizeof(double), hipHostRegisterDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); unpin_buffers(h); return fail(h, PSM_ERR_HIP, std::string("hipHostRegister(p_out): ") + hipGetErrorString(e)); }
+    h->pinned_p = p_out;
+  }
+  return PSM_OK;
+}
+
+int psm_unpin_buffers(psm_handle* h) {
+  if (!h) return PSM_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  unpin_buffers(h);
   return PSM_OK;
 }
 

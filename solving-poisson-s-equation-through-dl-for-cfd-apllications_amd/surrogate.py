@@ -718,14 +718,28 @@ class SolverModule:
         self.tables = t
         return 0
 
-    def py_func(self, array_in, placeholder=0) -> np.ndarray:
+    def pin(self, array: np.ndarray, out: np.ndarray = None):
+        """psm_pin_buffers: register the caller's persistent [N,5] float64 array (and optionally a persistent output
+        array) for direct DMA; later ``py_func(array, out=out)`` calls with exactly these arrays skip the staging copies.
+        The caller keeps both arrays alive until ``unpin()`` / a new ``init_func``."""
+        if array.dtype != np.float64 or not array.flags.c_contiguous or (out is not None and (out.dtype != np.float64 or not out.flags.c_contiguous)):
+            raise ValueError("contiguous float64 arrays expected")
+        self._sur._chk(self._sur.lib.psm_pin_buffers(self._sur.h, _p(array, C.c_double), _p(out, C.c_double) if out is not None else None))
+        self._pinned = (array, out)
+
+    def unpin(self):
+        self._sur._chk(self._sur.lib.psm_unpin_buffers(self._sur.h))
+        self._pinned = None
+
+    def py_func(self, array_in, placeholder=0, out: np.ndarray = None) -> np.ndarray:
         """python_module.py:249: cells [N,5] float64 -> p [N] float64."""
         if self.tables is None:
             raise RuntimeError("init_func has not been called")
         a = _f64(array_in)
         if a.ndim != 2 or a.shape[1] != 5:
             raise ValueError("array must be [N,5] = (Ux, Uy, Cx, Cy, p)")
-        out = np.empty(a.shape[0], np.float64)
+        if out is None:
+            out = np.empty(a.shape[0], np.float64)
         self._sur._chk(self._sur.lib.psm_solve(self._sur.h, _p(a, C.c_double), a.shape[0], int(placeholder),
                                                 _p(out, C.c_double)))
         return out

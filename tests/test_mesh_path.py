@@ -74,6 +74,27 @@ def test_solver_module_init_func_py_func(mesh_case):
         sm.py_func(array2[:-5], 0)              # wrong cell count: reported, not fatal
 
 
+@pytest.mark.gpu
+def test_pinned_solver_buffers_give_the_same_pressures(mesh_case):
+    """psm_pin_buffers: the solver's persistent arrays registered for direct DMA -- bit-identical results, staging path
+    still taken for any other pointer, unpin restores it."""
+    array, top, obst, model, maxs, geo, gold = mesh_case
+    sm = SolverModule(model, maxs)
+    sm.init_func(array, top, obst)
+    ref = sm.py_func(array)
+    cells, out = np.ascontiguousarray(array, np.float64).copy(), np.empty(array.shape[0], np.float64)
+    sm.pin(cells, out)
+    for step in range(3):
+        cells[:, 0] = array[:, 0] * (1.0 + 0.01 * step)              # the solver overwrites its buffer in place
+        got = sm.py_func(cells, out=out)
+        assert got is out
+        np.testing.assert_array_equal(got, sm.py_func(cells.copy()))   # other pointer -> staging path, same numbers
+    cells[:, 0] = array[:, 0]
+    np.testing.assert_array_equal(sm.py_func(cells, out=out), ref)
+    sm.unpin()
+    np.testing.assert_array_equal(sm.py_func(cells, out=out), ref)
+
+
 def test_oracle_filters_match_reference_run():
     """assemble_prediction with apply_filter / apply_deltaU_change_wgt (SM_call.py:352-363): the oracle's
     reassembly followed by SciPy's gaussian_filter (the routine the reference calls) against the run of
