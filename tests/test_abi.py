@@ -53,3 +53,19 @@ def test_no_gpu_means_loud_failure_not_fallback():
     rc = lib.psm_create(C.byref(cfg), C.byref(h))
     assert rc == -4 and not h.value          # PSM_ERR_NO_DEVICE
     assert "no CPU fallback" in _lib.last_error()
+
+
+def test_headers_compile_as_c99():
+    """include/psm.h and include/psm_unet.h are plain C (the boundary a cgo / JNI / Fortran binding would use)."""
+    import os
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("gcc") is None:
+        pytest.skip("needs gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-c",
+                            os.path.join(root, "tests", "native", "abi_c_check.c"), "-o", os.path.join(td, "a.o")],
+                           capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
