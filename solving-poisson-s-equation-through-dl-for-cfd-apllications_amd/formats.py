@@ -236,6 +236,54 @@ def read_keras_dense_weights(path: str) -> List[Tuple[np.ndarray, np.ndarray]]:
     return out
 
 
+def read_keras_conv_weights(path: str) -> List[Tuple[np.ndarray, np.ndarray]]:
+    """Ordered [(kernel[kh,kw,c_in,c_out] f32, bias[c_out] f32)] of the Conv2D layers of a Keras HDF5 file
+    (``model.save_weights`` / ``model.save``): layers are the groups named ``conv2d``, ``conv2d_1``, ... and are ordered
+    by that index (creation order of the layers), never by their position in the file."""
+    ds = read_h5_datasets(path)
+    layers: Dict[str, Dict[str, np.ndarray]] = {}
+    for p, a in ds.items():
+        parts = [q for q in p.split("/") if q]
+        if parts[-1] not in ("kernel:0", "bias:0"):
+            continue
+        lname = next((q for q in parts if re.fullmatch(r"conv2d(?:_\d+)?", q)), None)
+        if lname is not None:
+            layers.setdefault(lname, {})[parts[-1]] = a
+    if not layers:
+        raise H5FormatError("no conv2d layers found")
+    out = []
+    for n in sorted(layers, key=lambda s: int(s.split("_")[1]) if "_" in s else 0):
+        if "kernel:0" not in layers[n] or "bias:0" not in layers[n]:
+            raise H5FormatError(f"layer {n} lacks kernel or bias")
+        W = np.ascontiguousarray(layers[n]["kernel:0"], np.float32)
+        b = np.ascontiguousarray(layers[n]["bias:0"], np.float32)
+        if W.ndim != 4 or W.shape[0] != W.shape[1] or b.shape != (W.shape[3],):
+            raise H5FormatError(f"layer {n}: unexpected shapes {W.shape} {b.shape}")
+        out.append((W, b))
+    return out
+
+
+def unet_layout_from_weights(weights) -> Tuple[int, Tuple[int, ...], int]:
+    """(c_in, widths, c_out) of a UNet-S-shaped Conv2D stack (2 convolutions per encoder level, 2 per decoder level,
+    1x1 head), inferred from the kernel shapes; raises if the stack does not have that shape."""
+    n = len(weights)
+    if n < 7 or (n - 3) % 4 != 0:
+        raise ValueError(f"{n} convolutions do not form 2L + 2(L-1) + 1")
+    L = (n + 1) // 4
+    widths = tuple(int(weights[2 * l][0].shape[3]) for l in range(L))
+    c_in, c_out = int(weights[0][0].shape[2]), int(weights[-1][0].shape[3])
+    exp = []
+    for l in range(L):
+        exp += [(3, c_in if l == 0 else widths[l - 1], widths[l]), (3, widths[l], widths[l])]
+    for l in range(L - 2, -1, -1):
+        exp += [(3, widths[l + 1] + widths[l], widths[l]), (3, widths[l], widths[l])]
+    exp.append((1, widths[0], c_out))
+    for i, ((W, b), (k, ci, co)) in enumerate(zip(weights, exp)):
+        if tuple(W.shape) != (k, k, ci, co):
+            raise ValueError(f"convolution {i}: kernel {tuple(W.shape)}, a U-Net of widths {widths} needs {(k, k, ci, co)}")
+    return c_in, widths, c_out
+
+
 def read_maxs(path: str) -> np.ndarray:
     """``np.loadtxt`` of the one-value-per-line ``maxs`` / ``maxs_PCA`` files."""
     return np.atleast_1d(np.loadtxt(path))

@@ -55,6 +55,15 @@ class UNetSurrogate:
             self.close()
             raise
 
+    @classmethod
+    def from_keras_h5(cls, path: str, ny: int, nx: int, **kw) -> "UNetSurrogate":
+        """Conv2D kernels / biases of a Keras HDF5 file (layers conv2d, conv2d_1, ... in creation order); channel
+        counts and depth are inferred from the kernel shapes (formats.unet_layout_from_weights)."""
+        from . import formats
+        weights = formats.read_keras_conv_weights(path)
+        c_in, widths, c_out = formats.unet_layout_from_weights(weights)
+        return cls(weights, ny, nx, c_in=c_in, c_out=c_out, widths=widths, **kw)
+
     def _chk(self, rc):
         if rc:
             raise _lib.PsmError(rc, (self.lib.psm_unet_last_error(self.h) or b"").decode())

@@ -133,3 +133,41 @@ def test_gpu_unet_channel_count_corner_cases(c_in, widths, c_out):
             a0 = net.activation(0, 2)[k]
             assert np.abs(a0 - acts[0]).max() <= 2e-5 * np.abs(acts[0]).max()
             assert np.abs(out[k] - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+def _write_keras_conv_h5(path, W):
+    import h5write
+    tree = {}
+    for k, (w, b) in enumerate(W):
+        name = "conv2d" if k == 0 else f"conv2d_{k}"
+        tree[name] = {name: {"kernel:0": w, "bias:0": b}}
+    # more than 8 layers: one symbol node holds 8 members, so nest the groups two levels deep
+    names = sorted(tree, key=lambda s: int(s.split("_")[1]) if "_" in s else 0)
+    h5write.write_h5(path, {f"part{j}": {n: tree[n] for n in names[8 * j:8 * j + 8]} for j in range((len(names) + 7) // 8)})
+
+
+def test_keras_conv_reader_and_layout_inference(tmp_path):
+    from psm_amd import formats
+    widths = (16, 32, 48)
+    W = uo.he_weights(uo.unet_specs(4, widths, 2), seed=3)
+    p = str(tmp_path / "unet.h5")
+    _write_keras_conv_h5(p, W)
+    R = formats.read_keras_conv_weights(p)
+    assert len(R) == len(W) and all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(R, W))
+    assert formats.unet_layout_from_weights(R) == (4, widths, 2)
+    with pytest.raises(ValueError):
+        formats.unet_layout_from_weights(R[:-2])
+
+
+@pytest.mark.gpu
+def test_gpu_unet_from_keras_h5(tmp_path):
+    from psm_amd import UNetSurrogate
+    widths = (16, 32, 48)
+    W = uo.he_weights(uo.unet_specs(4, widths, 2), seed=3)
+    p = str(tmp_path / "unet.h5")
+    _write_keras_conv_h5(p, W)
+    g = np.random.default_rng(2).standard_normal((32, 48, 4)).astype(np.float32)
+    with UNetSurrogate.from_keras_h5(p, 32, 48) as net:
+        out = net.forward(g)[0]
+    ref = uo.unet_forward(g, W, widths)
+    assert np.abs(out - ref).max() <= 1e-4 * np.abs(ref).max()
