@@ -350,3 +350,41 @@ def test_bf16_all_variants_small():
             f = sur.solve(grid)[0]
         emu = orc.solve_grid(grid.astype(np.float64), oracle_model(model), precision="bf16")
         assert rel_l2(f, emu.fields) <= 5e-3
+
+
+@pytest.mark.parametrize("variant,p_in,p_out,arch_layers", [("deltas", 1, 1, None), ("gradp", 3, 130, None), ("chapter5", 160, 2, None),
+                                                            ("deltas", 40, 24, 1), ("deltas", 16, 16, 20)])
+def test_extreme_component_and_layer_counts(variant, p_in, p_out, arch_layers):
+    """One retained component, more than 128 output components (generic decode path), more than 128 input components
+    (general encode path), a single Dense layer (head only) and a 20-layer stack (MLP_huger depth)."""
+    model = synthetic.make_model(variant, p_in=p_in, p_out=p_out, seed_pca=300 + p_in, seed_w=p_out)
+    if arch_layers is not None:
+        widths = [] if arch_layers == 1 else [64] * (arch_layers - 1)
+        model.weights = synthetic.he_dense_stack(p_in, widths, p_out, 9)
+    grid = synthetic.channel_grid(256, 256, seed=30).astype(np.float32)
+    with GridSurrogate(model, 256, 256) as sur:
+        fields = sur.solve(grid)[0]
+        sol = orc.solve_grid(grid.astype(np.float64), oracle_model(model))
+        check_against_oracle(sur, grid, model, sol)
+    assert np.abs(fields - sol.fields).max() <= 1e-4 * max(np.abs(sol.fields).max(), 1e-3)
+
+
+def test_all_solid_and_all_flow_grids():
+    """No flow cell at all: every masked strip is empty, the reference's np.mean([]) = NaN propagates through the
+    offsets to the whole field (NumPy semantics, reproduced); no solid cell at all: nothing is masked."""
+    model = synthetic.make_model("deltas", p_in=8, p_out=8)
+    om = oracle_model(model)
+    solid = synthetic.channel_grid(256, 256, seed=3).astype(np.float32)
+    solid[..., 2] = 0.0
+    flow = synthetic.channel_grid(256, 256, seed=3, obstacle="none").astype(np.float32)
+    flow[..., 2] = np.maximum(flow[..., 2], 1e-3)
+    with GridSurrogate(model, 256, 256) as sur:
+        for g in (solid, flow):
+            got = sur.solve(g)[0]
+            with np.errstate(all="ignore"):
+                ref = orc.solve_grid(g.astype(np.float64), om).fields
+            np.testing.assert_array_equal(np.isnan(got), np.isnan(ref))
+            ok = ~np.isnan(ref)
+            if ok.any():
+                assert np.abs(got[ok] - ref[ok]).max() <= 1e-4 * np.abs(ref[ok]).max()
+        assert np.isnan(sur.solve(solid)[0]).any()
