@@ -388,3 +388,17 @@ def test_all_solid_and_all_flow_grids():
             if ok.any():
                 assert np.abs(got[ok] - ref[ok]).max() <= 1e-4 * np.abs(ref[ok]).max()
         assert np.isnan(sur.solve(solid)[0]).any()
+
+
+def test_chapter4_channel_configuration():
+    """The Chapter-4 M_fU evaluator's shape (Thesis_Work/Chapter4/MLP/M_fU/Evaluation/Eval.py:205-223): two input channels
+    (f(U), SDF) with the flow mask in channel 1, Chapter-5 block layout, 116 -> 39 components like its model_first_.h5."""
+    model = synthetic.make_model("chapter5", p_in=116, p_out=39, c_in=2, seed_pca=404, seed_w=4)
+    model.sdf_ch = 1
+    g3 = synthetic.channel_grid(300, 400, seed=14)
+    grid = np.stack([g3[..., 0] * 0.7 + g3[..., 1] * 0.3, g3[..., 2]], axis=-1).astype(np.float32)
+    with GridSurrogate(model, 300, 400) as sur:
+        fields = sur.solve(grid)[0]
+        sol = orc.solve_grid(grid.astype(np.float64), oracle_model(model))
+        check_against_oracle(sur, grid, model, sol)
+    assert np.abs(fields - sol.fields).max() <= 1e-4 * np.abs(sol.fields).max()
