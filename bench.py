@@ -96,7 +96,6 @@ MFMA_BF16_PEAK_TFLOPS = 2516.6   # dense bf16 matrix peak (16x the f32 rate)
 def main_unet(args):
     """Same protocol for the convolutional path: K forward passes back to back, input resident in HBM."""
     import torch
-    from oracle import unet_oracle as uo
     from psm_amd import UNetSurrogate, dist as pdist, synthetic
     rank, world, local_rank = pdist.env_world()
     backend = os.environ.get("PSM_BENCH_BACKEND", "nccl")
@@ -104,7 +103,7 @@ def main_unet(args):
     torch.cuda.set_device(local_rank)
     pdist.init(backend, torch.device("cuda", local_rank))
     NY, NX, NC, desc = UNET_WORKLOADS[args.workload]
-    W = uo.he_weights(uo.unet_specs(), seed=7)
+    W = synthetic.unet_he_weights(seed=7)
     prec = "bf16" if args.workload.endswith("bf16") else "f32"
     peak = MFMA_BF16_PEAK_TFLOPS if prec == "bf16" else MFMA_F32_PEAK_TFLOPS
     net = UNetSurrogate(W, NY, NX, max_cases=NC, device=local_rank, precision=prec)
@@ -130,6 +129,7 @@ def main_unet(args):
                         "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
                         "algorithmic_flops": flops, "per_layer_ms": [float(v) for v in ms]}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import unet_oracle as uo           # cpu_baseline leg only
         from psm_amd import hostinfo
         cores = hostinfo.available_cpus()
         hostinfo.limit_blas_threads(cores)

@@ -246,3 +246,33 @@ def channel_mesh(Lx: float = 1.5, Ly: float = 0.7, h: float = 0.008, seed: int =
     th = np.linspace(0, 2 * np.pi, 240, endpoint=False)
     obst = np.stack([cx + R * np.cos(th), cy + R * np.sin(th)], 1)
     return array, top, obst
+
+
+# --------------------------------------------------------------------------
+# convolutional path: layer shapes and seeded weights of the build-defined UNet-S (include/psm_unet.h)
+# --------------------------------------------------------------------------
+UNET_WIDTHS_S = (16, 32, 64, 128, 256)
+
+
+def unet_conv_shapes(c_in: int = 3, widths=UNET_WIDTHS_S, c_out: int = 1):
+    """[(k, c_in, c_out)] in the order psm_unet_set_conv expects: enc0a, enc0b, ..., dec0a, dec0b, head."""
+    L = len(widths)
+    out = []
+    for l in range(L):
+        out += [(3, c_in if l == 0 else widths[l - 1], widths[l]), (3, widths[l], widths[l])]
+    for l in range(L - 2, -1, -1):
+        out += [(3, widths[l + 1] + widths[l], widths[l]), (3, widths[l], widths[l])]
+    out.append((1, widths[0], c_out))
+    return out
+
+
+def unet_he_weights(c_in: int = 3, widths=UNET_WIDTHS_S, c_out: int = 1, seed: int = 7):
+    """Seeded He-normal Conv2D kernels [k,k,c_in,c_out] and small biases, float32 (random-init weights of the
+    architecture: there is no trained U-Net anywhere in the reference)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for k, ci, co in unet_conv_shapes(c_in, widths, c_out):
+        W = (rng.standard_normal((k, k, ci, co)) * np.sqrt(2.0 / (k * k * ci))).astype(np.float32)
+        b = (rng.standard_normal(co) * 0.05).astype(np.float32)
+        out.append((W, b))
+    return out

@@ -33,6 +33,13 @@ def _torch_forward(g, W):
     return conv(x, i, False)[0].permute(1, 2, 0).numpy()
 
 
+def test_product_weight_generator_matches_the_oracle_spec():
+    specs = uo.unet_specs(4, (16, 32, 48), 2)
+    assert synthetic.unet_conv_shapes(4, (16, 32, 48), 2) == [(s.k, s.c_in, s.c_out) for s in specs]
+    for (a, b), (c, d) in zip(synthetic.unet_he_weights(4, (16, 32, 48), 2, seed=5), uo.he_weights(specs, seed=5)):
+        np.testing.assert_array_equal(a, c); np.testing.assert_array_equal(b, d)
+
+
 def test_spec_and_flops():
     specs = uo.unet_specs()
     assert len(specs) == 19 and [s.name for s in specs][:4] == ["enc0a", "enc0b", "enc1a", "enc1b"]

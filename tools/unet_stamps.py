@@ -3,11 +3,10 @@ MFMA start, MFMA done, LDS stores done, barrier passed -- and the end of the epi
 import ctypes as C, sys
 import numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
-from oracle import unet_oracle as uo
 from psm_amd import UNetSurrogate, synthetic
-W = uo.he_weights(uo.unet_specs(), seed=7)
+W = synthetic.unet_he_weights(seed=7)
 g = synthetic.channel_grid(256, 256, seed=1).astype(np.float32)
-specs = uo.unet_specs()
+names = ['enc0a','enc0b','enc1a','enc1b','enc2a','enc2b','enc3a','enc3b','enc4a','enc4b','dec3a','dec3b','dec2a','dec2b','dec1a','dec1b','dec0a','dec0b','head']
 with UNetSurrogate(W, 256, 256) as net:
     net.forward(g)
     for idx in [int(a) for a in sys.argv[1:]] or [1, 15]:
@@ -17,7 +16,7 @@ with UNetSurrogate(W, 256, 256) as net:
             net._chk(net.lib.psm_unet_debug_run_layer(net.h, idx, st.ctypes.data_as(C.POINTER(C.c_float))))
             acc.append(st)
         st = np.median(np.array(acc), axis=0)
-        print(f"{specs[idx].name}: start {st[0]:.2f}  prologue done {st[1]:.2f}")
+        print(f"{names[idx]}: start {st[0]:.2f}  prologue done {st[1]:.2f}")
         c = 0
         while 5 + 4 * c < 63 and st[2 + 4 * c] >= 0:
             print(f"   chunk {c}: mfma {st[2+4*c]:.2f} -> {st[3+4*c]:.2f} ({st[3+4*c]-st[2+4*c]:.2f})  stores done {st[4+4*c]:.2f}  barrier {st[5+4*c]:.2f}")
