@@ -402,3 +402,45 @@ def test_chapter4_channel_configuration():
         sol = orc.solve_grid(grid.astype(np.float64), oracle_model(model))
         check_against_oracle(sur, grid, model, sol)
     assert np.abs(fields - sol.fields).max() <= 1e-4 * np.abs(sol.fields).max()
+
+
+def test_reassembly_on_random_shapes_and_obstacles():
+    """a12 (offset chain + paste + global shift) on 24 seeded random grid shapes per variant mix, with random solid
+    bands that empty some overlap strips (the np.isnan branches) -- device result against the oracle's serial
+    restatement, NaN pattern included."""
+    rng = np.random.default_rng(2024)
+    variants = ("deltas", "gradp", "chapter5")
+    for trial in range(24):
+        variant = variants[trial % 3]
+        ny, nx = int(rng.integers(130, 520)), int(rng.integers(260, 900))
+        try:
+            lay = orc.block_layout(variant, ny, nx)
+        except Exception:
+            continue
+        model = synthetic.make_model(variant, p_in=4, p_out=4)
+        grid = synthetic.channel_grid(ny, nx, seed=100 + trial, obstacle=("circle", "rectangle", "plate", "none")[trial % 4],
+                                      cx=float(rng.uniform(0.2, 0.8)), cy=float(rng.uniform(0.2, 0.8))).astype(np.float32)
+        for _ in range(int(rng.integers(0, 3))):                       # solid bands: whole strips without a flow cell
+            y0, x0 = int(rng.integers(0, ny - 40)), int(rng.integers(0, nx - 140))
+            grid[y0:y0 + int(rng.integers(8, 40)), x0:x0 + int(rng.integers(100, 140)), :] = 0.0
+        c_out = model.c_out
+        bp = rng.standard_normal((lay.B, 128, 128, c_out)).astype(np.float32)
+        xb = orc.extract_blocks(grid.astype(np.float64), lay, 3)
+        try:
+            sur = GridSurrogate(model, ny, nx)
+        except _lib.PsmError:
+            continue                                                   # shapes the reference itself cannot process
+        with sur:
+            f = sur.reassemble(grid, bp)
+        for c in range(c_out):
+            with np.errstate(all="ignore"):
+                if variant == "gradp":
+                    ref = orc.assemble_gradp(("dp_dx", "dp_dy")[c], bp[..., c], xb, lay, degenerate="skip").field
+                elif variant == "deltas":
+                    ref = orc.assemble_deltas(bp[..., c], xb, lay, degenerate="skip").field
+                else:
+                    ref = orc.assemble_chapter5(bp[..., c], xb, lay).field
+            assert np.array_equal(np.isnan(f[..., c]), np.isnan(ref)), (variant, ny, nx, trial)
+            ok = ~np.isnan(ref)
+            if ok.any():
+                assert np.abs(f[..., c][ok] - ref[ok]).max() <= 3e-4 * max(1.0, np.abs(ref[ok]).max()), (variant, ny, nx, trial)
