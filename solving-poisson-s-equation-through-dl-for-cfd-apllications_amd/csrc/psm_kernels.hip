@@ -512,7 +512,7 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a) {
 hipError_t psm_launch_dense(const PsmDenseArgs& a, hipStream_t st) {
   const int ng = a.Kp / 128;                       // groups of 16 k per wave
   if (!a.Wp || a.Kp % 128 != 0 || (ng > 2 && ng % 4 != 0) || a.ld_in < 4) return hipErrorInvalidValue;
-  const bool r16 = a.Mpad <= 64;
+  const bool r16 = a.Mpad <= 128;     // up to 128 block rows: 16-row tiles keep >= 64 workgroups pulling <= 64 KB each
   const dim3 grid(a.ld_w / 16, a.Mpad / (r16 ? 16 : 32)), blk(512);
 #define DENSE(N)                                                                            \
   do {                                                                                      \
