@@ -16,6 +16,8 @@
 // Epilogue: bias, ReLU, NHWC store (16 consecutive channels = 64 B per pixel).
 #include "psm_unet.h"
 
+#include <type_traits>
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
@@ -175,22 +177,62 @@ __device__ __forceinline__ f32x4 fetch4_prepared(const PsmConvArgs& a, const flo
   return v;
 }
 
-// TH: tile rows; WM: rows per wave; NCT: channel tiles per workgroup; WN: channel tiles per wave.
+// raw loads of one 4-channel group (all slabs), and their combination: split so that the loads of chunk g+1 can stay
+// in flight during the MFMAs of chunk g -- a combine (or even a zeroing select) placed right behind the loads makes the
+// compiler wait for them BEFORE the MFMAs, i.e. one exposed memory round trip per chunk
+template <int KSM>
+__device__ __forceinline__ void issue4(const float* p, int ks, int64_t slab, f32x4* r) {
+  r[0] = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+  for (int s = 1; s < KSM; ++s) r[s] = *reinterpret_cast<const f32x4*>(p + (int64_t)min(s, ks - 1) * slab);
+}
+template <int KSM>
+__device__ __forceinline__ f32x4 combine4(const f32x4* r, int ks, f32x4 b) {      // same order as read4
+  f32x4 v = r[0];
+  if (KSM > 1) {
+#pragma unroll
+    for (int s = 1; s < KSM; ++s) v += r[s] * (s < ks ? 1.f : 0.f);
+    const bool fin = ks > 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = fin ? fmaxf(v[j] + b[j], 0.f) : v[j];
+  }
+  return v;
+}
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// TH: tile rows; WM: rows per wave; NCT: channel tiles per workgroup; WN: channel tiles per wave; BF: bf16 operands.
 // Software pipeline over the channel chunks, both operands double-buffered in LDS: the input tile (through the
 // source transform) and the weights (9 x NCT KiB, already in MFMA operand order) of chunk g+1 are requested
-// into a handful of registers per thread before the MFMAs of chunk g and written to the other LDS buffers
-// after them; one LDS-only barrier per chunk.  Cooperative staging keeps the register count low (the weights
-// of a chunk are 2.25 x NCT float4 per thread), so that several workgroups share a CU and hide each other's
-// prologue -- holding a wave's own weight slice in registers (9 x WN float4 per lane, twice for the
-// pipeline) measured slower at every batch size.
-template <int TH, int WM, int NCT, int WN, int SRC, int KSM>     // SRC: PSM_SRC_*, -1 = unaligned stem, 3 = upsample + skip with the seam inside a chunk
+// into registers before the MFMAs of chunk g, combined (slab sums, max-pool, padding selects) and written to the
+// other LDS buffers after them; one LDS-only barrier per chunk.  Inside a chunk the LDS operands of tap t+1 are
+// read before the MFMAs of tap t are issued.  Cooperative staging keeps the register count low, so that two
+// workgroups share a CU and hide each other's prologue.
+//   f32 (BF = false): chunks of 16 channels, v_mfma_f32_16x16x4_f32, exact f32 products.
+//   bf16 (BF = true): activations (after the source transform) and weights rounded to bf16 (RNE), chunks of 32
+//     channels, ONE v_mfma_f32_16x16x32_bf16 per (tap, row, channel tile): lane l holds A[pixel l&15][k = 8*(l>>4)+j]
+//     and B[k][channel l&15], j < 8.  Activations stay float32 in HBM (skips, slabs and the oracle's rounding
+//     points are unchanged).  Both forms use an 80-byte LDS pixel stride (16-byte slots rotate from pixel to pixel).
+template <int TH, int WM, int NCT, int WN, int SRC, int KSM, bool BF>     // SRC: PSM_SRC_*, -1 = unaligned stem, 3 = upsample + skip with the seam inside a chunk
 __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_groups) {
-  constexpr int TILE = (TH + 2) * (TW + 2) * LDC;                   // floats per input-tile buffer
-  constexpr int NF = ((TH + 2) * (TW + 2) * (CC / 4) + 255) / 256;  // 4-channel input fetches per thread and chunk
-  constexpr int WQ = 9 * NCT * 64;                                  // float4 per weight chunk
+  constexpr int CB = BF ? 32 : 16;                                  // input channels per chunk
+  constexpr int G4 = CB / 4;                                        // 4-channel fetch groups per pixel
+  constexpr int NPIX = (TH + 2) * (TW + 2);
+  constexpr int NF = (NPIX * G4 + 255) / 256;                       // 4-channel input fetches per thread and chunk
+  constexpr int WQ = 9 * NCT * 64;                                  // 16-byte pieces per weight chunk
   constexpr int NWF = (WQ + 255) / 256;
+  // both LDS buffers are rounded up to whole fetch rounds: every thread stores every round (the surplus lands in the
+  // pad), so no store sits behind a branch -- a skipped store leaves its load "pending" for the compiler, which then
+  // drains vmcnt before the register's next load, in the middle of the MFMA stream
+  constexpr int TILE = (NF * 256 / G4) * LDC;                       // floats per input-tile buffer (80 B per pixel)
+  constexpr int WQP = NWF * 256;                                    // weight-buffer stride (16-byte pieces)
+  constexpr int SRCP = SRC == 3 ? PSM_SRC_UPSAMPLE : (SRC < 0 ? 0 : SRC);
+  constexpr int NQ = SRCP == PSM_SRC_MAXPOOL ? 4 : 1;               // source pixels per fetch
+  constexpr bool DEFER = SRC >= 0 && SRC != 3 && NF * NQ * KSM <= 24;   // raw loads held across the MFMAs (<= 96 VGPRs)
+  constexpr int NRAW = DEFER ? NQ * KSM : 1;
   __shared__ __attribute__((aligned(16))) float in_tile[2 * TILE];
-  __shared__ __attribute__((aligned(16))) f32x4 w_tile[2 * WQ];
+  __shared__ __attribute__((aligned(16))) f32x4 w_tile[2 * WQP];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int zz = blockIdx.z / a.ksplit, split = blockIdx.z - zz * a.ksplit;
@@ -206,106 +248,165 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
   for (int m = 0; m < WM; ++m)
 #pragma unroll
     for (int n = 0; n < WN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const float4* wsrc = a.wpack + (int64_t)cog * a.n_chunks * WQ;
+  const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpack) + (int64_t)cog * a.n_chunks * WQ;
   const int cps = (a.n_chunks + a.ksplit - 1) / a.ksplit;          // chunks per split
   const int g_beg = split * cps, g_end = min(a.n_chunks, (split + 1) * cps);
 
-  auto load_w = [&](f32x4 (&w)[NWF], int g) {
+  f32x4 xr[NF][NRAW], xb[NF], wr[NWF];
+  auto load_w_one = [&](int g, int u) { wr[u] = wsrc[(int64_t)g * WQ + min(tid + 256 * u, WQ - 1)]; };
+  auto store_w = [&](int buf) {
 #pragma unroll
-    for (int u = 0; u < NWF; ++u) {
-      const float4 t = wsrc[(int64_t)g * WQ + min(tid + 256 * u, WQ - 1)];
-      w[u] = (f32x4){t.x, t.y, t.z, t.w};
-    }
-  };
-  auto store_w = [&](const f32x4 (&w)[NWF], int buf) {
-#pragma unroll
-    for (int u = 0; u < NWF; ++u)
-      if (tid + 256 * u < WQ) w_tile[buf * WQ + tid + 256 * u] = w[u];
+    for (int u = 0; u < NWF; ++u) w_tile[buf * WQP + tid + 256 * u] = wr[u];
   };
   // loop-invariant fetch positions; chunks normally lie on one side of the concatenation seam (channel counts
   // are multiples of the chunk), else the general per-lane path is taken
-  constexpr int SRCP = SRC == 3 ? PSM_SRC_UPSAMPLE : (SRC < 0 ? 0 : SRC);
   PsmFetchPos fp[NF];
 #pragma unroll
   for (int u = 0; u < NF; ++u) {
-    const int pos = (tid + 256 * u) >> 2;
+    const int pos = (tid + 256 * u) / G4;
     const int r = min(pos / (TW + 2), TH + 1), c = pos - (pos / (TW + 2)) * (TW + 2);
     fp[u] = prepare_fetch<SRCP>(a, y0 - 1 + r, x0 - 1 + c);
   }
-  auto load_x = [&](f32x4 (&x)[NF], int g) {
-    const bool from0 = g * CC < a.c0;                 // uniform
-#pragma unroll
-    for (int u = 0; u < NF; ++u) {
+  // request chunk g: straight-line loads only (clamped addresses); what needs the data comes in finish_x
+  auto issue_x_one = [&](int g, int u) {
+    const bool from0 = g * CB < a.c0;                 // uniform
+    const int lim = from0 ? a.c0 : a.c0 + a.c1;
+    {
       const int q = tid + 256 * u;
-      const int pos = q >> 2, c4 = q & 3;
+      const int pos = q / G4, c4 = q & (G4 - 1);
       const int r = pos / (TW + 2), c = pos - r * (TW + 2);
       const int rr = min(r, TH + 1);
-      const int ch = g * CC + 4 * c4;
-      if (SRC < 0) x[u] = fetch4_stem(a, in0, y0 - 1 + rr, x0 - 1 + c, ch);
-      else if (SRC == 3) x[u] = fetch4<PSM_SRC_UPSAMPLE, KSM>(a, in0, in1, y0 - 1 + rr, x0 - 1 + c, ch);
-      else {
-        // channels beyond the real inputs (zero-padded tail of the last chunk) read a clamped group and are zeroed
-        const int lim = from0 ? a.c0 : a.c0 + a.c1;
-        const f32x4 t = fetch4_prepared<SRCP, KSM>(a, in0, in1, fp[u], min(ch, lim - 4), from0);
+      const int ch = g * CB + 4 * c4;
+      const int chc = min(ch, lim - 4);     // channels beyond the real inputs (zero-padded tail): clamped, zeroed later
+      if constexpr (SRC < 0) xr[u][0] = fetch4_stem(a, in0, y0 - 1 + rr, x0 - 1 + c, ch);
+      else if constexpr (SRC == 3) xr[u][0] = fetch4<PSM_SRC_UPSAMPLE, KSM>(a, in0, in1, y0 - 1 + rr, x0 - 1 + c, ch);
+      else if constexpr (!DEFER) {
+        const f32x4 t = fetch4_prepared<SRCP, KSM>(a, in0, in1, fp[u], chc, from0);
         const bool live = ch < lim;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) x[u][j] = live ? t[j] : 0.f;
+        for (int j = 0; j < 4; ++j) xr[u][0][j] = live ? t[j] : 0.f;
+      } else if constexpr (SRCP == PSM_SRC_MAXPOOL) {
+        const float* p = in0 + fp[u].off0 + chc;
+        issue4<KSM>(p, a.ks0, a.slab0, &xr[u][0]);
+        issue4<KSM>(p + a.c0, a.ks0, a.slab0, &xr[u][KSM]);
+        issue4<KSM>(p + a.W0 * a.c0, a.ks0, a.slab0, &xr[u][2 * KSM]);
+        issue4<KSM>(p + a.W0 * a.c0 + a.c0, a.ks0, a.slab0, &xr[u][3 * KSM]);
+        if (KSM > 1) xb[u] = *reinterpret_cast<const f32x4*>(a.pbias0 + chc);
+      } else if constexpr (SRCP == PSM_SRC_UPSAMPLE) {
+        const float* p = from0 ? in0 + fp[u].off0 + chc : in1 + fp[u].off1 + (chc - a.c0);
+        issue4<KSM>(p, from0 ? a.ks0 : a.ks1, from0 ? a.slab0 : a.slab1, &xr[u][0]);
+        if (KSM > 1) xb[u] = *reinterpret_cast<const f32x4*>(from0 ? a.pbias0 + chc : a.pbias1 + (chc - a.c0));
+      } else {
+        issue4<KSM>(in0 + fp[u].off0 + chc, a.ks0, a.slab0, &xr[u][0]);
+        if (KSM > 1) xb[u] = *reinterpret_cast<const f32x4*>(a.pbias0 + chc);
       }
     }
   };
-  auto store_x = [&](const f32x4 (&x)[NF], int buf) {
+  // the NI = NF + NWF requests of a chunk are spread over the nine taps of the previous chunk's MFMA phase: a wave-wide
+  // 16-byte load occupies the CU's address path for 16 cycles (64 B/clk), so a chunk's 30-130 loads issued in one go
+  // hold the waves -- and the MFMAs behind them in program order -- for 0.3-1 us
+  constexpr int NI = NF + NWF;
+  auto issue_item = [&](int g, int i) {
+    if (i < NF) issue_x_one(g, i); else load_w_one(g, i - NF);
+  };
+  // combine what issue_x_one requested (slab sums + producer bias / ReLU, 2x2 max, zero padding) and write the LDS tile
+  auto finish_x = [&](int g, int buf) {
+    const bool from0 = g * CB < a.c0;
+    const int lim = from0 ? a.c0 : a.c0 + a.c1;
 #pragma unroll
     for (int u = 0; u < NF; ++u) {
       const int q = tid + 256 * u;
-      if (q < (TH + 2) * (TW + 2) * (CC / 4)) *reinterpret_cast<f32x4*>(&in_tile[buf * TILE + (q >> 2) * LDC + 4 * (q & 3)]) = x[u];
+      const int pos = q / G4, c4 = q & (G4 - 1);
+      f32x4 v = xr[u][0];
+      if constexpr (DEFER) {
+        const int ks = (SRCP == PSM_SRC_UPSAMPLE && !from0) ? a.ks1 : a.ks0;
+        v = combine4<KSM>(&xr[u][0], ks, xb[u]);
+        if constexpr (NQ == 4) {
+          const f32x4 q1 = combine4<KSM>(&xr[u][KSM], ks, xb[u]), q2 = combine4<KSM>(&xr[u][2 * KSM], ks, xb[u]),
+                      q3 = combine4<KSM>(&xr[u][3 * KSM], ks, xb[u]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaxf(v[j], q1[j]), fmaxf(q2[j], q3[j]));
+        }
+        const bool ok = fp[u].ok && (g * CB + 4 * c4 < lim);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0.f;
+      }
+      if constexpr (BF) {
+        bf16x4 h;
+        h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(&in_tile[buf * TILE + pos * LDC]) + 4 * c4) = h;
+      } else {
+        *reinterpret_cast<f32x4*>(&in_tile[buf * TILE + pos * LDC + 4 * c4]) = v;
+      }
     }
   };
 
   USTAMP(0);
-  f32x4 xr[NF], wr[NWF];
   if (g_beg < g_end) {
-    load_x(xr, g_beg);
-    load_w(wr, g_beg);
-    store_x(xr, 0);
-    store_w(wr, 0);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) issue_item(g_beg, i);
+    finish_x(g_beg, 0);
+    store_w(0);
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   USTAMP(1);
   int buf = 0;
-  for (int g = g_beg; g < g_end; ++g) {
-    const bool more = g + 1 < g_end;
-    if (more) { load_x(xr, g + 1); load_w(wr, g + 1); }
-    // no scheduling fence here: the load issue (TA-bound: ~30 wave-wide loads x 4 waves per chunk) may interleave
-    // with the MFMAs below, which hold the vector issue for only 8 of their 32 cycles
+  // one chunk; MORE (compile time): the next chunk's requests are issued among the taps and stored after them.  The
+  // last chunk is a second copy of the body rather than a run-time `more` flag: requests behind a condition the
+  // compiler cannot correlate from tap to tap get a full vmcnt(0) drain in front of each of them
+  auto run_chunk = [&](int g, auto more_tag) {
+    constexpr bool more = decltype(more_tag)::value;
     USTAMP(2 + 4 * (g - g_beg));
     const float* tile = &in_tile[buf * TILE];
-    const f32x4* wt = &w_tile[buf * WQ + ct_w * 64 + lane];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    const f32x4* wt = &w_tile[buf * WQP + ct_w * 64 + lane];
+    f32x4 av[2][WM], bv[2][WN];
+    auto lds_read = [&](int tap, int s) {
       const int ky = tap / 3, kx = tap - 3 * ky;
-      f32x4 av[WM], bv[WN];
 #pragma unroll
       for (int m = 0; m < WM; ++m)
-        av[m] = *reinterpret_cast<const f32x4*>(&tile[((row_w + m + ky) * (TW + 2) + px + kx) * LDC + 4 * kq]);
+        av[s][m] = *reinterpret_cast<const f32x4*>(&tile[((row_w + m + ky) * (TW + 2) + px + kx) * LDC + 4 * kq]);
 #pragma unroll
-      for (int n = 0; n < WN; ++n) bv[n] = wt[(tap * NCT + n) * 64];
-      // consecutive MFMAs go to different accumulators (dependent-accumulator latency 40 > issue 32 cycles)
+      for (int n = 0; n < WN; ++n) bv[s][n] = wt[(tap * NCT + n) * 64];
+    };
+    lds_read(0, 0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+    for (int tap = 0; tap < 9; ++tap) {
+      const int s = tap & 1;
+      if (tap < 8) lds_read(tap + 1, s ^ 1);           // next tap's operands are on their way during this tap's MFMAs
+      if constexpr (more) {                            // this tap's share of the next chunk's requests
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+          if ((i * 9) / NI == tap) issue_item(g + 1, i);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (BF) {
 #pragma unroll
         for (int m = 0; m < WM; ++m)
 #pragma unroll
-          for (int n = 0; n < WN; ++n) acc[m][n] = MFMA16(av[m][j], bv[n][j], acc[m][n]);
+          for (int n = 0; n < WN; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[s][m]), __builtin_bit_cast(bf16x8, bv[s][n]),
+                                                                acc[m][n], 0, 0, 0);
+      } else {
+        // consecutive MFMAs go to different accumulators (dependent-accumulator latency 40 > issue 32 cycles)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int n = 0; n < WN; ++n) acc[m][n] = MFMA16(av[s][m][j], bv[s][n][j], acc[m][n]);
+      }
+      // nothing may move across: above all not the combines / LDS stores below, which wait for the loads issued above
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // nothing below may be scheduled among the MFMAs: the LDS stores wait for the loads issued above
-    __builtin_amdgcn_sched_barrier(0);
     USTAMP(3 + 4 * (g - g_beg));
-    if (more) { store_x(xr, buf ^ 1); store_w(wr, buf ^ 1); }
+    if constexpr (more) { finish_x(g + 1, buf ^ 1); store_w(buf ^ 1); }
     USTAMP(4 + 4 * (g - g_beg));
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     USTAMP(5 + 4 * (g - g_beg));
     buf ^= 1;
-  }
+  };
+  for (int g = g_beg; g + 1 < g_end; ++g) run_chunk(g, std::true_type{});
+  if (g_beg < g_end) run_chunk(g_end - 1, std::false_type{});
   // ---- epilogue: bias + ReLU (split-K: the raw partial sum into this split's slab), NHWC store
   float* out = a.out + (int64_t)cs * a.out_case + (int64_t)split * a.out_slab;
   const bool fin = a.ksplit == 1;
@@ -327,152 +428,6 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
     }
   }
   USTAMP(63);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// bf16 operand variant: activations (after the source transform) and weights rounded to bf16 (RNE), exact
-// products, f32 accumulation by v_mfma_f32_16x16x32_bf16 -- 32 input channels per chunk and ONE MFMA per
-// (tap, row, channel tile): lane l holds A[pixel l&15][k = 8*(l>>4) + j] and B[k][channel l&15], j < 8
-// (one ds_read_b128 each).  Activations stay float32 in HBM (skip connections, slabs and the oracle's
-// rounding points are unchanged); same tiling, staging pipeline, split-K and epilogue as the f32 kernel.
-// ---------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-template <int TH, int WM, int NCT, int WN, int SRC, int KSM>
-__global__ __launch_bounds__(256) void psm_conv3x3_bf16_kernel(PsmConvArgs a, int co_groups) {
-  constexpr int CB = 32;                                            // input channels per chunk
-  constexpr int LDB = CB + 8;                                       // LDS pixel stride in bf16 (80 B: 16-B slots rotate)
-  constexpr int TILE = (TH + 2) * (TW + 2) * LDB;                   // bf16 per input-tile buffer
-  constexpr int NF = ((TH + 2) * (TW + 2) * (CB / 4) + 255) / 256;  // 4-channel fetches per thread and chunk
-  constexpr int WQ = 9 * NCT * 64;                                  // 16-byte pieces per weight chunk
-  constexpr int NWF = (WQ + 255) / 256;
-  __shared__ __attribute__((aligned(16))) __bf16 in_tile[2 * TILE];
-  __shared__ __attribute__((aligned(16))) bf16x8 w_tile[2 * WQ];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int zz = blockIdx.z / a.ksplit, split = blockIdx.z - zz * a.ksplit;
-  const int cs = zz / co_groups, cog = zz - cs * co_groups;
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-  const float* in0 = a.in0 + (int64_t)cs * a.in0_case;
-  const float* in1 = a.in1 ? a.in1 + (int64_t)cs * a.in1_case : nullptr;
-  const int row_w = (TH == 4 * WM) ? wave * WM : 0;
-  const int ct_w = (TH == 4 * WM) ? 0 : wave * WN;
-  const int px = lane & 15, kq = lane >> 4;
-  f32x4 acc[WM][WN];
-#pragma unroll
-  for (int m = 0; m < WM; ++m)
-#pragma unroll
-    for (int n = 0; n < WN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(a.wpack) + (int64_t)cog * a.n_chunks * WQ;
-  const int cps = (a.n_chunks + a.ksplit - 1) / a.ksplit;
-  const int g_beg = split * cps, g_end = min(a.n_chunks, (split + 1) * cps);
-
-  auto load_w = [&](bf16x8 (&w)[NWF], int g) {
-#pragma unroll
-    for (int u = 0; u < NWF; ++u) w[u] = wsrc[(int64_t)g * WQ + min(tid + 256 * u, WQ - 1)];
-  };
-  auto store_w = [&](const bf16x8 (&w)[NWF], int buf) {
-#pragma unroll
-    for (int u = 0; u < NWF; ++u)
-      if (tid + 256 * u < WQ) w_tile[buf * WQ + tid + 256 * u] = w[u];
-  };
-  // loop-invariant fetch positions; chunks normally lie on one side of the concatenation seam (channel counts
-  // are multiples of the chunk), else the general per-lane path is taken
-  constexpr int SRCP = SRC == 3 ? PSM_SRC_UPSAMPLE : (SRC < 0 ? 0 : SRC);
-  PsmFetchPos fp[NF];
-#pragma unroll
-  for (int u = 0; u < NF; ++u) {
-    const int pos = (tid + 256 * u) >> 3;
-    const int r = min(pos / (TW + 2), TH + 1), c = pos - (pos / (TW + 2)) * (TW + 2);
-    fp[u] = prepare_fetch<SRCP>(a, y0 - 1 + r, x0 - 1 + c);
-  }
-  auto load_x = [&](f32x4 (&x)[NF], int g) {
-    const bool from0 = g * CB < a.c0;                 // uniform
-#pragma unroll
-    for (int u = 0; u < NF; ++u) {
-      const int q = tid + 256 * u;
-      const int pos = q >> 3, c4 = q & 7;
-      const int r = pos / (TW + 2), c = pos - r * (TW + 2);
-      const int rr = min(r, TH + 1);
-      const int ch = g * CB + 4 * c4;
-      if (SRC < 0) x[u] = fetch4_stem(a, in0, y0 - 1 + rr, x0 - 1 + c, ch);
-      else if (SRC == 3) x[u] = fetch4<PSM_SRC_UPSAMPLE, KSM>(a, in0, in1, y0 - 1 + rr, x0 - 1 + c, ch);
-      else {
-        // channels beyond the real inputs (zero-padded tail of the last chunk) read a clamped group and are zeroed
-        const int lim = from0 ? a.c0 : a.c0 + a.c1;
-        const f32x4 t = fetch4_prepared<SRCP, KSM>(a, in0, in1, fp[u], min(ch, lim - 4), from0);
-        const bool live = ch < lim;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) x[u][j] = live ? t[j] : 0.f;
-      }
-    }
-  };
-  auto store_x = [&](const f32x4 (&x)[NF], int buf) {
-#pragma unroll
-    for (int u = 0; u < NF; ++u) {
-      const int q = tid + 256 * u;
-      if (q < (TH + 2) * (TW + 2) * (CB / 4)) {
-        bf16x4 v;
-        v[0] = (__bf16)x[u][0]; v[1] = (__bf16)x[u][1]; v[2] = (__bf16)x[u][2]; v[3] = (__bf16)x[u][3];
-        *reinterpret_cast<bf16x4*>(&in_tile[buf * TILE + (q >> 3) * LDB + 4 * (q & 7)]) = v;
-      }
-    }
-  };
-
-  f32x4 xr[NF];
-  bf16x8 wr[NWF];
-  if (g_beg < g_end) {
-    load_x(xr, g_beg);
-    load_w(wr, g_beg);
-    store_x(xr, 0);
-    store_w(wr, 0);
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  int buf = 0;
-  for (int g = g_beg; g < g_end; ++g) {
-    const bool more = g + 1 < g_end;
-    if (more) { load_x(xr, g + 1); load_w(wr, g + 1); }
-    const __bf16* tile = &in_tile[buf * TILE];
-    const bf16x8* wt = &w_tile[buf * WQ + ct_w * 64 + lane];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int ky = tap / 3, kx = tap - 3 * ky;
-      bf16x8 av[WM], bv[WN];
-#pragma unroll
-      for (int m = 0; m < WM; ++m)
-        av[m] = *reinterpret_cast<const bf16x8*>(&tile[((row_w + m + ky) * (TW + 2) + px + kx) * LDB + 8 * kq]);
-#pragma unroll
-      for (int n = 0; n < WN; ++n) bv[n] = wt[(tap * NCT + n) * 64];
-#pragma unroll
-      for (int m = 0; m < WM; ++m)
-#pragma unroll
-        for (int n = 0; n < WN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[m], bv[n], acc[m][n], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) { store_x(xr, buf ^ 1); store_w(wr, buf ^ 1); }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    buf ^= 1;
-  }
-  float* out = a.out + (int64_t)cs * a.out_case + (int64_t)split * a.out_slab;
-  const bool fin = a.ksplit == 1;
-#pragma unroll
-  for (int n = 0; n < WN; ++n) {
-    const int co = (cog * NCT + ct_w + n) * 16 + (lane & 15);
-    const float b = (fin && co < a.cout) ? a.bias[co] : 0.f;
-#pragma unroll
-    for (int m = 0; m < WM; ++m) {
-      const int y = y0 + row_w + m;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int x = x0 + 4 * kq + r;
-        float v = acc[m][n][r] + b;
-        if (fin && a.relu) v = fmaxf(v, 0.f);
-        if (y < a.H && x < a.W && co < a.cout) out[((int64_t)y * a.W + x) * a.cout + co] = v;
-        if (NCT == 1 && a.head_w) head_epilogue(a, cs, y, x, lane, v);      // uniform branch, every lane active
-      }
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -561,8 +516,8 @@ static void launch_variant(const PsmConvArgs& a, dim3 grid, int groups, hipStrea
   const bool slabs = a.ks0 > 1 || a.ks1 > 1;
 #define GO(S, K)                                                                                                         \
   do {                                                                                                                   \
-    if (a.bf16) hipLaunchKernelGGL((psm_conv3x3_bf16_kernel<TH, WM, NCT, WN, S, K>), grid, dim3(256), 0, st, a, groups);   \
-    else hipLaunchKernelGGL((psm_conv3x3_kernel<TH, WM, NCT, WN, S, K>), grid, dim3(256), 0, st, a, groups);               \
+    if (a.bf16) hipLaunchKernelGGL((psm_conv3x3_kernel<TH, WM, NCT, WN, S, K, true>), grid, dim3(256), 0, st, a, groups);  \
+    else hipLaunchKernelGGL((psm_conv3x3_kernel<TH, WM, NCT, WN, S, K, false>), grid, dim3(256), 0, st, a, groups);        \
   } while (0)
   if (stem) { GO(-1, 1); return; }
   if (a.mode0 == PSM_SRC_SAME) { if (slabs) GO(PSM_SRC_SAME, 8); else GO(PSM_SRC_SAME, 1); }
