@@ -41,13 +41,30 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-// fused linear 1x1 head on a finished 16-channel tile: v = activation of (pixel, channel lane & 15)
-__device__ __forceinline__ void head_epilogue(const PsmConvArgs& a, int cs, int y, int x, int lane, float v) {
-  const int co = lane & 15;
+// fused linear 1x1 head on the finished 16-channel tiles of a wave: v[m][r] = activation of (row m, pixel 4*(lane>>4)+r,
+// channel lane & 15).  The head's weight is loaded ONCE per output channel and only after every activation store has
+// been issued: a load between the stores would make each of them a full round trip (stores count in vmcnt too).
+template <int WM>
+__device__ __forceinline__ void head_epilogue(const PsmConvArgs& a, int cs, int y_first, int x0, int lane, const f32x4 (&v)[WM]) {
+  const int co = lane & 15, kq = lane >> 4;
   for (int o = 0; o < a.head_cout; ++o) {
-    const float s = row16_sum(v * a.head_w[co * a.head_cout + o]);
-    if (co == 15 && y < a.H && x < a.W)
-      a.head_out[(int64_t)cs * a.head_case + ((int64_t)y * a.W + x) * a.head_cout + o] = s + a.head_b[o];
+    const float w = a.head_w[co * a.head_cout + o], hb = a.head_b[o];
+#pragma unroll
+    for (int m = 0; m < WM; ++m) {
+      const int y = y_first + m;
+      f32x4 s;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[r] = row16_sum(v[m][r] * w) + hb;      // lane 15 of each 16-lane row holds the sums
+      float* dst = a.head_out + (int64_t)cs * a.head_case + ((int64_t)y * a.W + x0 + 4 * kq) * a.head_cout + o;
+      if (co == 15 && y < a.H) {
+        if (a.head_cout == 1 && (a.W & 3) == 0 && x0 + 4 * kq + 3 < a.W) *reinterpret_cast<f32x4*>(dst) = s;     // 4 consecutive pixels
+        else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (x0 + 4 * kq + r < a.W) dst[(int64_t)r * a.head_cout] = s[r];
+        }
+      }
+    }
   }
 }
 
@@ -214,7 +231,9 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 //     channels, ONE v_mfma_f32_16x16x32_bf16 per (tap, row, channel tile): lane l holds A[pixel l&15][k = 8*(l>>4)+j]
 //     and B[k][channel l&15], j < 8.  Activations stay float32 in HBM (skips, slabs and the oracle's rounding
 //     points are unchanged).  Both forms use an 80-byte LDS pixel stride (16-byte slots rotate from pixel to pixel).
-template <int TH, int WM, int NCT, int WN, int SRC, int KSM, bool BF>     // SRC: PSM_SRC_*, -1 = unaligned stem, 3 = upsample + skip with the seam inside a chunk
+//   NB: LDS buffers per operand -- 1 when a workgroup has a single chunk (nothing to pipeline: half the LDS, twice
+//     the workgroups per CU to cover each other's load latency), else 2.
+template <int TH, int WM, int NCT, int WN, int SRC, int KSM, bool BF, int NB>     // SRC: PSM_SRC_*, -1 = unaligned stem, 3 = upsample + skip with the seam inside a chunk
 __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_groups) {
   constexpr int CB = BF ? 32 : 16;                                  // input channels per chunk
   constexpr int G4 = CB / 4;                                        // 4-channel fetch groups per pixel
@@ -231,8 +250,8 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
   constexpr int NQ = SRCP == PSM_SRC_MAXPOOL ? 4 : 1;               // source pixels per fetch
   constexpr bool DEFER = SRC >= 0 && SRC != 3 && NF * NQ * KSM <= 24;   // raw loads held across the MFMAs (<= 96 VGPRs)
   constexpr int NRAW = DEFER ? NQ * KSM : 1;
-  __shared__ __attribute__((aligned(16))) float in_tile[2 * TILE];
-  __shared__ __attribute__((aligned(16))) f32x4 w_tile[2 * WQP];
+  __shared__ __attribute__((aligned(16))) float in_tile[NB * TILE];
+  __shared__ __attribute__((aligned(16))) f32x4 w_tile[NB * WQP];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int zz = blockIdx.z / a.ksplit, split = blockIdx.z - zz * a.ksplit;
@@ -405,7 +424,8 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
     USTAMP(5 + 4 * (g - g_beg));
     buf ^= 1;
   };
-  for (int g = g_beg; g + 1 < g_end; ++g) run_chunk(g, std::true_type{});
+  if constexpr (NB == 2)
+    for (int g = g_beg; g + 1 < g_end; ++g) run_chunk(g, std::true_type{});
   if (g_beg < g_end) run_chunk(g_end - 1, std::false_type{});
   // ---- epilogue: bias + ReLU (split-K: the raw partial sum into this split's slab), NHWC store
   float* out = a.out + (int64_t)cs * a.out_case + (int64_t)split * a.out_slab;
@@ -423,8 +443,16 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
         float v = acc[m][n][r] + b;
         if (fin && a.relu) v = fmaxf(v, 0.f);
         if (y < a.H && x < a.W && co < a.cout) out[((int64_t)y * a.W + x) * a.cout + co] = v;
-        if (NCT == 1 && a.head_w) head_epilogue(a, cs, y, x, lane, v);      // uniform branch, every lane active
+        acc[m][n][r] = v;
       }
+    }
+  }
+  if constexpr (NCT == 1 && WN == 1) {
+    if (a.head_w) {                                                         // uniform branch, every lane active
+      f32x4 hv[WM];
+#pragma unroll
+      for (int m = 0; m < WM; ++m) hv[m] = acc[m][0];
+      head_epilogue<WM>(a, cs, y0 + row_w, x0, lane, hv);
     }
   }
   USTAMP(63);
@@ -433,30 +461,30 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
 // ---------------------------------------------------------------------------------------------------
 // stem: the first layer reads the raw grid image (c_in = 3: not a multiple of 4, and only 27 contraction
 // terms).  Padding its three channels to a chunk of 16 would run 144-term MFMAs for 27 useful terms; here
-// K = 9 * c_in is flattened (k = tap * c_in + channel) and padded to KG groups of 16, the A operand is an
-// explicit [128 pixels][KG*16] patch matrix in LDS, gathered straight from the image (every load issued
-// up front, clamped + selected), weights go from global memory to registers in MFMA order.
-// bf16 mode: operands rounded to bf16 first (products exact in the f32 MFMA).
+// K = 9 * c_in is flattened (k = tap * c_in + channel) and padded to KG groups of 16.  The (8+2) x (16+2) x c_in
+// image tile goes to LDS with row-contiguous loads (every load issued up front, clamped + selected); the A
+// operand of pixel p, term k is then the LDS word at tile[p + (ky, kx)][channel] -- four ds_read_b32 per
+// k-group, addresses fixed per lane -- and the padded terms read a zero word.  Weights go from global memory to
+// registers in MFMA order.  bf16 mode: operands rounded to bf16 first (products exact in the f32 MFMA).
 // ---------------------------------------------------------------------------------------------------
 template <int KG>
 __global__ __launch_bounds__(256) void psm_conv_stem_kernel(PsmConvArgs a) {
-  constexpr int TH = 8, KP = KG * 16, LDA = KP + 4, NE = (TH * TW * KP) / 256;    // patch entries per thread
-  __shared__ __attribute__((aligned(16))) float patch[TH * TW * LDA];
+  constexpr int TH = 8, NPIX = (TH + 2) * (TW + 2), CMAX = 7, NE = (NPIX * CMAX + 255) / 256, ZERO = NE * 256;
+  __shared__ float tile[ZERO + 1];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cs = blockIdx.z;
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
   const float* in0 = a.in0 + (int64_t)cs * a.in0_case;
-  const int K = 9 * a.c0;
+  const int c0 = a.c0, K = 9 * c0, nval = NPIX * c0;
   float ev[NE];
 #pragma unroll
   for (int u = 0; u < NE; ++u) {
-    const int e = tid + 256 * u, p = e / KP, kk = e - p * KP;
-    const int kc = min(kk, K - 1), tap = kc / a.c0, ci = kc - tap * a.c0;
-    const int ky = tap / 3, kx = tap - 3 * ky;
-    const int y = y0 + (p >> 4) + ky - 1, x = x0 + (p & 15) + kx - 1;
-    const bool ok = kk < K && y >= 0 && y < a.H && x >= 0 && x < a.W;
-    const float t = in0[((int64_t)min(max(y, 0), a.H - 1) * a.W + min(max(x, 0), a.W - 1)) * a.c0 + ci];
+    const int e = min(tid + 256 * u, nval - 1), pos = e / c0, ci = e - pos * c0;
+    const int r = pos / (TW + 2), c = pos - r * (TW + 2);
+    const int y = y0 - 1 + r, x = x0 - 1 + c;
+    const bool ok = y >= 0 && y < a.H && x >= 0 && x < a.W;
+    const float t = in0[((int64_t)min(max(y, 0), a.H - 1) * a.W + min(max(x, 0), a.W - 1)) * c0 + ci];
     ev[u] = ok ? t : 0.f;
   }
   f32x4 bw[KG];
@@ -464,19 +492,30 @@ __global__ __launch_bounds__(256) void psm_conv_stem_kernel(PsmConvArgs a) {
 #pragma unroll
   for (int g = 0; g < KG; ++g) { const float4 t = wsrc[g * 64]; bw[g] = (f32x4){t.x, t.y, t.z, t.w}; }
   const float bias = a.bias[lane & 15];
-#pragma unroll
-  for (int u = 0; u < NE; ++u) {
-    const int e = tid + 256 * u, p = e / KP, kk = e - p * KP;
-    patch[p * LDA + kk] = a.bf16 ? (float)(__bf16)ev[u] : ev[u];
-  }
-  __syncthreads();
   const int px = lane & 15, kq = lane >> 4;
+  int off[KG][4];                               // LDS word of term k relative to the pixel, or the zero word
+#pragma unroll
+  for (int g = 0; g < KG; ++g)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = 16 * g + 4 * kq + j, kc = min(k, K - 1), tap = kc / c0, ci = kc - tap * c0;
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      off[g][j] = k < K ? (ky * (TW + 2) + kx) * c0 + ci : -1;
+    }
+#pragma unroll
+  for (int u = 0; u < NE; ++u) tile[tid + 256 * u] = a.bf16 ? (float)(__bf16)ev[u] : ev[u];     // surplus rounds land in the pad
+  if (tid == 0) tile[ZERO] = 0.f;
+  __syncthreads();
   f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
   for (int g = 0; g < KG; ++g) {
-    f32x4 av[2];
+    float av[2][4];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) av[m] = *reinterpret_cast<const f32x4*>(&patch[((2 * wave + m) * TW + px) * LDA + 16 * g + 4 * kq]);
+    for (int m = 0; m < 2; ++m) {
+      const int base = ((2 * wave + m) * (TW + 2) + px) * c0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) av[m][j] = tile[off[g][j] < 0 ? ZERO : base + off[g][j]];
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -514,10 +553,13 @@ template <int TH, int WM, int NCT, int WN>
 static void launch_variant(const PsmConvArgs& a, dim3 grid, int groups, hipStream_t st) {
   const bool stem = (a.c0 % 4 != 0) || (a.c1 % 4 != 0);
   const bool slabs = a.ks0 > 1 || a.ks1 > 1;
+  const bool one = (a.n_chunks + a.ksplit - 1) / a.ksplit <= 1;      // a single chunk per workgroup: single LDS buffers
 #define GO(S, K)                                                                                                         \
   do {                                                                                                                   \
-    if (a.bf16) hipLaunchKernelGGL((psm_conv3x3_kernel<TH, WM, NCT, WN, S, K, true>), grid, dim3(256), 0, st, a, groups);  \
-    else hipLaunchKernelGGL((psm_conv3x3_kernel<TH, WM, NCT, WN, S, K, false>), grid, dim3(256), 0, st, a, groups);        \
+    if (a.bf16) { if (one && K == 1) hipLaunchKernelGGL((psm_conv3x3_kernel<TH, WM, NCT, WN, S, 1, true, 1>), grid, dim3(256), 0, st, a, groups);    \
+                  else hipLaunchKernelGGL((psm_conv3x3_kernel<TH, WM, NCT, WN, S, K, true, 2>), grid, dim3(256), 0, st, a, groups); }            \
+    else { if (one && K == 1) hipLaunchKernelGGL((psm_conv3x3_kernel<TH, WM, NCT, WN, S, 1, false, 1>), grid, dim3(256), 0, st, a, groups);          \
+           else hipLaunchKernelGGL((psm_conv3x3_kernel<TH, WM, NCT, WN, S, K, false, 2>), grid, dim3(256), 0, st, a, groups); }                  \
   } while (0)
   if (stem) { GO(-1, 1); return; }
   if (a.mode0 == PSM_SRC_SAME) { if (slabs) GO(PSM_SRC_SAME, 8); else GO(PSM_SRC_SAME, 1); }

@@ -116,13 +116,16 @@ void choose_config(Conv& c, int H, int W, int n_cases, bool can_split, int chunk
   const int ctiles = (c.cout + 15) / 16;
   struct Cand { int arr, nct, th; };
   const Cand cands[3] = {{0, 2, 8}, {0, 1, 8}, {1, 4, 2}};
+  // diagnostic knobs (tools/unet_bench.py sweeps): workgroups wanted before reuse counts, deepest split
+  const long fill = getenv("PSM_UNET_FILL") ? atol(getenv("PSM_UNET_FILL")) : 256;
+  const int ks_max = getenv("PSM_UNET_KSPLIT_MAX") ? atoi(getenv("PSM_UNET_KSPLIT_MAX")) : 8;
   long best_score = -1;
   for (const Cand& k : cands) {
     if (k.nct > ctiles) continue;                       // never compute padded channel tiles
     const int groups = (ctiles + k.nct - 1) / k.nct;
     const long wgs = (long)((W + 15) / 16) * ((H + k.th - 1) / k.th) * groups * n_cases;
     const long reuse = (long)k.nct * k.th;
-    const long score = wgs >= 256 ? 1000000 + reuse * 1000 + (k.arr ? 1 : 0) : wgs * 10 + (k.arr ? 1 : 0);
+    const long score = wgs >= fill ? 1000000 + reuse * 1000 + (k.arr ? 1 : 0) : wgs * 10 + (k.arr ? 1 : 0);
     if (score > best_score) { best_score = score; c.arrangement = k.arr; c.nct = k.nct; c.groups = groups; }
   }
   c.n_chunks = (c.cin + chunk_ch - 1) / chunk_ch;
@@ -131,7 +134,7 @@ void choose_config(Conv& c, int H, int W, int n_cases, bool can_split, int chunk
   const int th = c.arrangement ? 2 : 8;
   const long wgs = (long)((W + 15) / 16) * ((H + th - 1) / th) * c.groups * n_cases;
   c.ksplit = 1;
-  while (can_split && wgs * c.ksplit < 256 && c.ksplit < 8 && c.n_chunks / (c.ksplit * 2) >= 2) c.ksplit *= 2;
+  while (can_split && wgs * c.ksplit < fill && c.ksplit < ks_max && c.n_chunks / (c.ksplit * 2) >= 2) c.ksplit *= 2;
 }
 
 int upload_conv(psm_unet* u, Conv& c) {
