@@ -36,8 +36,13 @@ struct PsmHeadArgs {           // 1x1 convolution on a thin activation (c_in <= 
   int64_t n_pix; int c_in, c_out;
 };
 
-// arrangement: 0 = pixel-major (8 rows x 16 columns per workgroup, each wave 2 rows x NCT channel tiles),
-//              1 = channel-major (2 rows x 16 columns, 4 waves = 4 channel tiles of 16)
+// arrangement (workgroup tile; 16 columns wide, 4 waves):
+//   0 = 8 rows x NCT (1 or 2) channel tiles of 16, each wave 2 rows x all channel tiles
+//   1 = 2 rows x 4 channel tiles, each wave both rows x one channel tile
+// (4 x 16 and 8 x 16 pixel tiles with 4 channel tiles per wave were measured too: within 1 us per layer at batch 1,
+// slower at 8 cases per step -- the staged bytes per MFMA are not what limits these layers; not kept)
+inline int psm_conv_tile_rows(int arrangement) { return arrangement == 0 ? 8 : arrangement == 1 ? 2 : 0; }
+inline int psm_conv_tile_nct(int arrangement, int nct) { return arrangement == 0 ? (nct == 2 ? 2 : 1) : 4; }
 hipError_t psm_launch_conv3x3(const PsmConvArgs& a, int arrangement, int nct, int n_cases, hipStream_t st);
 hipError_t psm_launch_head1x1(const PsmHeadArgs& a, hipStream_t st);
 hipError_t psm_unet_read_stamps(unsigned long long* out);   // [64]; zeros unless built with -DPSM_STAMPS

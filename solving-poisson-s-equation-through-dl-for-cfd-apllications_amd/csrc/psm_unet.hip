@@ -70,7 +70,13 @@ __device__ __forceinline__ void head_epilogue(const PsmConvArgs& a, int cs, int 
 
 constexpr int TW = 16;            // tile width (pixels) = MFMA rows
 constexpr int CC = 16;            // input channels per chunk
-constexpr int LDC = CC + 4;       // LDS pixel stride (floats): 16-B slots rotate from pixel to pixel
+constexpr int LDC = 16;           // LDS pixel stride (floats): 64 B = four 16-byte slots, no padding
+// 16-byte slot (word offset) of channel group `grp` (0..3) of LDS pixel P.  A ds_read_b128 is served in four groups of 16
+// lanes that are NOT contiguous -- {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (MI355X_MICROARCH.md, LDS): each holds
+// all 16 pixels of an MFMA row, half of them with channel group kq and half with kq+1.  Rotating the slots by two for
+// pixels with bit 2 set makes every such group hit 16 distinct slots of the 256-byte bank row, for any tile row and
+// tap shift (a padded 80-byte stride gave 2-way conflicts on 3 of 16 lanes: 40 % of the LDS cycles).
+__device__ __forceinline__ int lds_slot(int P, int grp) { return P * LDC + 4 * ((grp + ((P >> 1) & 2)) & 3); }
 
 // One finished group of four channels.  Straight-line on purpose (clamped addresses, selects, fully unrolled
 // slab sums): every load of a chunk's staging must be in flight together -- a load inside a branch or a
@@ -230,7 +236,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 //   bf16 (BF = true): activations (after the source transform) and weights rounded to bf16 (RNE), chunks of 32
 //     channels, ONE v_mfma_f32_16x16x32_bf16 per (tap, row, channel tile): lane l holds A[pixel l&15][k = 8*(l>>4)+j]
 //     and B[k][channel l&15], j < 8.  Activations stay float32 in HBM (skips, slabs and the oracle's rounding
-//     points are unchanged).  Both forms use an 80-byte LDS pixel stride (16-byte slots rotate from pixel to pixel).
+//     points are unchanged).  Both forms use a 64-byte LDS pixel with swizzled 16-byte slots (lds_slot).
 //   NB: LDS buffers per operand -- 1 when a workgroup has a single chunk (nothing to pipeline: half the LDS, twice
 //     the workgroups per CU to cover each other's load latency), else 2.
 template <int TH, int WM, int NCT, int WN, int SRC, int KSM, bool BF, int NB>     // SRC: PSM_SRC_*, -1 = unaligned stem, 3 = upsample + skip with the seam inside a chunk
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
   // both LDS buffers are rounded up to whole fetch rounds: every thread stores every round (the surplus lands in the
   // pad), so no store sits behind a branch -- a skipped store leaves its load "pending" for the compiler, which then
   // drains vmcnt before the register's next load, in the middle of the MFMA stream
-  constexpr int TILE = (NF * 256 / G4) * LDC;                       // floats per input-tile buffer (80 B per pixel)
+  constexpr int TILE = (NF * 256 / G4) * LDC;                       // floats per input-tile buffer (64 B per pixel)
   constexpr int WQP = NWF * 256;                                    // weight-buffer stride (16-byte pieces)
   constexpr int SRCP = SRC == 3 ? PSM_SRC_UPSAMPLE : (SRC < 0 ? 0 : SRC);
   constexpr int NQ = SRCP == PSM_SRC_MAXPOOL ? 4 : 1;               // source pixels per fetch
@@ -353,9 +359,9 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
       if constexpr (BF) {
         bf16x4 h;
         h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
-        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(&in_tile[buf * TILE + pos * LDC]) + 4 * c4) = h;
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(&in_tile[buf * TILE + lds_slot(pos, c4 >> 1)]) + 4 * (c4 & 1)) = h;
       } else {
-        *reinterpret_cast<f32x4*>(&in_tile[buf * TILE + pos * LDC + 4 * c4]) = v;
+        *reinterpret_cast<f32x4*>(&in_tile[buf * TILE + lds_slot(pos, c4)]) = v;
       }
     }
   };
@@ -383,7 +389,7 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
       const int ky = tap / 3, kx = tap - 3 * ky;
 #pragma unroll
       for (int m = 0; m < WM; ++m)
-        av[s][m] = *reinterpret_cast<const f32x4*>(&tile[((row_w + m + ky) * (TW + 2) + px + kx) * LDC + 4 * kq]);
+        av[s][m] = *reinterpret_cast<const f32x4*>(&tile[lds_slot((row_w + m + ky) * (TW + 2) + px + kx, kq)]);
 #pragma unroll
       for (int n = 0; n < WN; ++n) bv[s][n] = wt[(tap * NCT + n) * 64];
     };
@@ -392,12 +398,15 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
     for (int tap = 0; tap < 9; ++tap) {
       const int s = tap & 1;
       if (tap < 8) lds_read(tap + 1, s ^ 1);           // next tap's operands are on their way during this tap's MFMAs
+#if !defined(PSM_EXP) || PSM_EXP == 3
       if constexpr (more) {                            // this tap's share of the next chunk's requests
 #pragma unroll
         for (int i = 0; i < NI; ++i)
           if ((i * 9) / NI == tap) issue_item(g + 1, i);
       }
+#endif
       __builtin_amdgcn_sched_barrier(0);
+#if !defined(PSM_EXP) || PSM_EXP < 3
       if constexpr (BF) {
 #pragma unroll
         for (int m = 0; m < WM; ++m)
@@ -414,13 +423,18 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
 #pragma unroll
             for (int n = 0; n < WN; ++n) acc[m][n] = MFMA16(av[s][m][j], bv[s][n][j], acc[m][n]);
       }
+#endif
       // nothing may move across: above all not the combines / LDS stores below, which wait for the loads issued above
       __builtin_amdgcn_sched_barrier(0);
     }
     USTAMP(3 + 4 * (g - g_beg));
+#if !defined(PSM_EXP) || PSM_EXP == 3
     if constexpr (more) { finish_x(g + 1, buf ^ 1); store_w(buf ^ 1); }
+#endif
     USTAMP(4 + 4 * (g - g_beg));
+#if !defined(PSM_EXP) || PSM_EXP != 2
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
     USTAMP(5 + 4 * (g - g_beg));
     buf ^= 1;
   };
@@ -578,17 +592,16 @@ hipError_t psm_launch_conv3x3(const PsmConvArgs& a, int arrangement, int nct, in
   if (stem && (a.mode0 != PSM_SRC_SAME || a.c1 != 0 || a.ks0 != 1)) return hipErrorInvalidValue;
   if (a.ks0 > 8 || a.ks1 > 8 || a.c0 < 1 || (!stem && a.c0 < 4)) return hipErrorInvalidValue;
   if (a.mode0 != PSM_SRC_UPSAMPLE && a.c1 != 0) return hipErrorInvalidValue;     // skip inputs come with the upsample
-  if (arrangement == 0) {          // pixel-major: 8 rows x 16 columns, every wave 2 rows x all NCT channel tiles
-    const int groups = (cout_tiles + nct - 1) / nct;
-    const dim3 grid((a.W + TW - 1) / TW, (a.H + 7) / 8, n_cases * groups * a.ksplit);
-    if (nct == 1) launch_variant<8, 2, 1, 1>(a, grid, groups, st);
-    else if (nct == 2) launch_variant<8, 2, 2, 2>(a, grid, groups, st);
-    else return hipErrorInvalidValue;
-  } else {                         // channel-major: 2 rows x 16 columns, 4 waves = 4 channel tiles
-    if (nct != 4) return hipErrorInvalidValue;
-    const int groups = (cout_tiles + 3) / 4;
-    const dim3 grid((a.W + TW - 1) / TW, (a.H + 1) / 2, n_cases * groups * a.ksplit);
-    launch_variant<2, 2, 4, 1>(a, grid, groups, st);
+  const int th = psm_conv_tile_rows(arrangement);
+  if (th == 0 || nct != psm_conv_tile_nct(arrangement, nct)) return hipErrorInvalidValue;
+  const int groups = (cout_tiles + nct - 1) / nct;
+  const dim3 grid((a.W + TW - 1) / TW, (a.H + th - 1) / th, n_cases * groups * a.ksplit);
+  switch (arrangement) {
+    case 0:                        // pixel-major: 8 rows x 16 columns, every wave 2 rows x all NCT (1 or 2) channel tiles
+      if (nct == 1) launch_variant<8, 2, 1, 1>(a, grid, groups, st); else launch_variant<8, 2, 2, 2>(a, grid, groups, st);
+      break;
+    case 1: launch_variant<2, 2, 4, 1>(a, grid, groups, st); break;    // channel-major: 2 rows x 16 columns, 4 waves = 4 channel tiles
+    default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }

@@ -1,6 +1,7 @@
 // psm_unet_api.cpp -- handle, layer schedule, weight packing and C-ABI of the convolutional path
 // (include/psm_unet.h; kernels in psm_unet.hip).
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -115,7 +116,7 @@ std::vector<float> pack_stem(const Conv& c, bool bf16) {
 void choose_config(Conv& c, int H, int W, int n_cases, bool can_split, int chunk_ch) {
   const int ctiles = (c.cout + 15) / 16;
   struct Cand { int arr, nct, th; };
-  const Cand cands[3] = {{0, 2, 8}, {0, 1, 8}, {1, 4, 2}};
+  const Cand cands[3] = {{0, 2, 8}, {0, 1, 8}, {1, 4, 2}};     // arrangements 2 and 3 (psm_unet.h) only by override / autotune
   // diagnostic knobs (tools/unet_bench.py sweeps): workgroups wanted before reuse counts, deepest split
   const long fill = getenv("PSM_UNET_FILL") ? atol(getenv("PSM_UNET_FILL")) : 256;
   const int ks_max = getenv("PSM_UNET_KSPLIT_MAX") ? atoi(getenv("PSM_UNET_KSPLIT_MAX")) : 8;
@@ -131,7 +132,7 @@ void choose_config(Conv& c, int H, int W, int n_cases, bool can_split, int chunk
   c.n_chunks = (c.cin + chunk_ch - 1) / chunk_ch;
   // split the input channels over workgroups until the chip is filled (partial-sum slabs, see psm_unet.h); only
   // layers whose output feeds another convolution can be split, at most 8 ways, at least 2 chunks per split
-  const int th = c.arrangement ? 2 : 8;
+  const int th = psm_conv_tile_rows(c.arrangement);
   const long wgs = (long)((W + 15) / 16) * ((H + th - 1) / th) * c.groups * n_cases;
   c.ksplit = 1;
   while (can_split && wgs * c.ksplit < fill && c.ksplit < ks_max && c.n_chunks / (c.ksplit * 2) >= 2) c.ksplit *= 2;
@@ -301,6 +302,16 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
     const size_t ci = &c - u->convs.data();
     const bool feeds_conv3 = ci + 1 < u->convs.size() && u->convs[ci + 1].k == 3;
     if (c.k == 3) choose_config(c, H, W, max_cases, feeds_conv3 && getenv("PSM_UNET_NO_SPLIT") == nullptr, u->bf16 ? 32 : 16);
+    // diagnostic override: PSM_UNET_FORCE="layer:arrangement:nct:ksplit,..." (tools/unet_bench.py experiments)
+    if (const char* f = getenv("PSM_UNET_FORCE")) {
+      for (const char* q = f; q && *q; q = std::strchr(q, ',') ? std::strchr(q, ',') + 1 : nullptr) {
+        int li, arr, nct, ks;
+        if (std::sscanf(q, "%d:%d:%d:%d", &li, &arr, &nct, &ks) == 4 && li == (int)ci && c.k == 3 && psm_conv_tile_rows(arr) &&
+            nct == psm_conv_tile_nct(arr, nct) && nct <= (c.cout + 15) / 16 && ks >= 1 && ks <= 8 && (ks == 1 || feeds_conv3) && ks <= c.n_chunks) {
+          c.arrangement = arr; c.nct = nct; c.groups = ((c.cout + 15) / 16 + nct - 1) / nct; c.ksplit = ks;
+        }
+      }
+    }
     c.stem = c.k == 3 && c.src == 0 && 9 * c.cin <= 64 && c.cout <= 16 && getenv("PSM_UNET_NO_STEM") == nullptr;
     if (c.stem) { c.ksplit = 1; c.nct = 1; c.groups = 1; c.arrangement = 0; }
     c.fuse_head = c.k == 3 && ci + 1 < u->convs.size() && u->convs[ci + 1].k == 1 && c.cout == 16 && !c.stem &&
@@ -395,7 +406,8 @@ int psm_unet_profile(psm_unet* u, const float* d_grid, int32_t n_cases, float* d
     if (wgs) {
       const Conv& c = u->convs[i];
       const int H = u->ny >> c.level, W = u->nx >> c.level;
-      wgs[i] = c.k == 3 ? ((W + 15) / 16) * ((H + (c.arrangement ? 1 : 7)) / (c.arrangement ? 2 : 8)) * c.groups * c.ksplit * n_cases : 0;
+      const int th = psm_conv_tile_rows(c.arrangement);
+      wgs[i] = c.k == 3 ? ((W + 15) / 16) * ((H + th - 1) / th) * c.groups * c.ksplit * n_cases : 0;
     }
   }
   for (auto& e : ev) (void)hipEventDestroy(e);
