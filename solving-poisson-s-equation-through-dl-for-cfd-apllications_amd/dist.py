@@ -2,8 +2,12 @@
 
 Cases (independent geometries / time steps) are partitioned contiguously over the
 ranks, one process per GPU; the data path has no collective.  ``torch.distributed``
-(backend "nccl" = RCCL on ROCm, "gloo" in the CPU tests) is used only for the
-barrier around the timed region and the MAX-reduction of the elapsed time.
+(backend "nccl" = RCCL on ROCm, "gloo" in the CPU tests) is used for the barrier
+around the timed region and the MAX-reduction of the elapsed time, and for the
+two OPTIONAL exchanges §8e names: ``broadcast_model`` (rank 0 reads the artefacts
+once and broadcasts them, ~36 MB, at start-up) and ``gather_cases`` (one
+all-gather of the per-rank result shards when a single consumer wants the whole
+batch).  Neither is on the timed path of ``bench.py``.
 """
 from __future__ import annotations
 
@@ -73,3 +77,101 @@ def timed_region(step: Callable[[int], None], steps: int, warmup: int, sync: Cal
 def aggregate_throughput(units_per_rank_per_step: int, steps: int, world: int, dt_max: float) -> float:
     """Whole-job units per second: every rank processed the same number of units (weak scaling)."""
     return world * units_per_rank_per_step * steps / dt_max
+
+
+# ---------------------------------------------------------------------------------------------------
+# optional exchanges (SURVEY.md §8e): artefact broadcast at start-up, result all-gather
+# ---------------------------------------------------------------------------------------------------
+def _dist_ready() -> bool:
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def broadcast_arrays(arrays, src: int = 0, device="cpu"):
+    """``arrays`` (dict name -> ndarray) is given on rank ``src`` and ignored elsewhere; every rank returns the
+    dict.  One object broadcast for the manifest (names, shapes, dtypes), one byte broadcast for the payload
+    (a single large message: xGMI links are per-peer, many small broadcasts would be latency-bound)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    if not _dist_ready():
+        if arrays is None:
+            raise ValueError("no process group: the arrays must be given")
+        return dict(arrays)
+    rank = dist.get_rank()
+    manifest = [None]
+    if rank == src:
+        if arrays is None:
+            raise ValueError("the source rank must pass the arrays")
+        arrays = {k: np.ascontiguousarray(v) for k, v in arrays.items()}
+        manifest[0] = [(k, v.shape, v.dtype.str) for k, v in arrays.items()]
+    dist.broadcast_object_list(manifest, src=src)
+    total = sum(int(np.prod(sh, dtype=np.int64)) * np.dtype(dt).itemsize for _, sh, dt in manifest[0])
+    buf = torch.empty(max(total, 1), dtype=torch.uint8, device=device)
+    if rank == src and total:
+        flat = np.concatenate([v.reshape(-1).view(np.uint8) for v in arrays.values()])
+        buf[:total].copy_(torch.from_numpy(flat))
+    dist.broadcast(buf, src=src)
+    raw = buf.cpu().numpy()
+    out, off = {}, 0
+    for k, sh, dt in manifest[0]:
+        n = int(np.prod(sh, dtype=np.int64)) * np.dtype(dt).itemsize
+        out[k] = raw[off:off + n].view(np.dtype(dt)).reshape(sh).copy()
+        off += n
+    return out
+
+
+def broadcast_model(model, src: int = 0, device="cpu"):
+    """A ``synthetic.SurrogateModel`` (or None off the source rank) -> the same model on every rank."""
+    import dataclasses
+    import numpy as np
+    import torch.distributed as dist
+    from .synthetic import SurrogateModel
+    if not _dist_ready():
+        return model
+    payload, meta = None, [None]
+    if dist.get_rank() == src:
+        payload, scal = {}, {}
+        for f in dataclasses.fields(model):
+            v = getattr(model, f.name)
+            if f.name == "weights":
+                for i, (W, b) in enumerate(v):
+                    payload[f"W{i}"], payload[f"b{i}"] = np.asarray(W), np.asarray(b)
+                scal["n_layers"] = len(v)
+            elif isinstance(v, np.ndarray):
+                payload["f:" + f.name] = v
+            else:
+                scal[f.name] = v
+        meta[0] = scal
+    dist.broadcast_object_list(meta, src=src)
+    arrs = broadcast_arrays(payload, src, device)
+    scal = dict(meta[0])
+    n_layers = scal.pop("n_layers")
+    kw = dict(scal)
+    kw.update({k[2:]: v for k, v in arrs.items() if k.startswith("f:")})
+    kw["weights"] = [(arrs[f"W{i}"], arrs[f"b{i}"]) for i in range(n_layers)]
+    return SurrogateModel(**kw)
+
+
+def gather_cases(local, n_cases: int):
+    """Per-rank result shard ``local`` [count_r, ...] (torch tensor on the rank's device: CUDA under RCCL, CPU under
+    gloo; ``count_r`` from ``shard_cases``) -> the whole batch [n_cases, ...] on every rank, in case order.  Uneven
+    shards are padded to the largest for the collective (``all_gather_into_tensor`` needs equal sizes)."""
+    import torch
+    import torch.distributed as dist
+    if not _dist_ready():
+        if local.shape[0] != n_cases:
+            raise ValueError("no process group: the local shard must be the whole batch")
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    first, count = shard_cases(n_cases, world, rank)
+    if local.shape[0] != count:
+        raise ValueError(f"rank {rank} holds {local.shape[0]} cases, its shard has {count}")
+    cmax = (n_cases + world - 1) // world
+    send = local.contiguous()
+    if count < cmax:
+        send = torch.cat([send, send.new_zeros((cmax - count,) + tuple(send.shape[1:]))])
+    recv = send.new_empty((world * cmax,) + tuple(send.shape[1:]))
+    dist.all_gather_into_tensor(recv, send)
+    parts = [recv[r * cmax:r * cmax + shard_cases(n_cases, world, r)[1]] for r in range(world)]
+    return torch.cat(parts)
