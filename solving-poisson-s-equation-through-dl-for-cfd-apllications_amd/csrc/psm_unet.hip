@@ -20,6 +20,12 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// activation stores: -DPSM_NT_ACT streams them past the L2 (the consumer is the next launch, on any XCD)
+#ifdef PSM_NT_ACT
+#define PSM_ACT_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define PSM_ACT_STORE(p, v) (*(p) = (v))
+#endif
 
 // Diagnostic stamps (100 MHz wall clock) of workgroup (0,0,0) -- compiled only with -DPSM_STAMPS.
 #ifdef PSM_STAMPS
@@ -456,7 +462,7 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
         const int x = x0 + 4 * kq + r;
         float v = acc[m][n][r] + b;
         if (fin && a.relu) v = fmaxf(v, 0.f);
-        if (y < a.H && x < a.W && co < a.cout) out[((int64_t)y * a.W + x) * a.cout + co] = v;
+        if (y < a.H && x < a.W && co < a.cout) PSM_ACT_STORE(&out[((int64_t)y * a.W + x) * a.cout + co], v);
         acc[m][n][r] = v;
       }
     }
@@ -545,7 +551,7 @@ __global__ __launch_bounds__(256) void psm_conv_stem_kernel(PsmConvArgs a) {
       const int x = x0 + 4 * kq + r;
       float v = acc[m][r] + bias;
       if (a.relu) v = fmaxf(v, 0.f);
-      if (y < a.H && x < a.W && co < a.cout) out[((int64_t)y * a.W + x) * a.cout + co] = v;
+      if (y < a.H && x < a.W && co < a.cout) PSM_ACT_STORE(&out[((int64_t)y * a.W + x) * a.cout + co], v);
     }
   }
 }
