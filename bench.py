@@ -158,6 +158,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inputs", type=int, default=4, help="distinct input grids rotated through (all resident in HBM)")
+    ap.add_argument("--no-bind", action="store_true", help="do not bind the geometry: general 8-launch path")
     ap.add_argument("--workload", default="config1", choices=sorted(WORKLOADS) + sorted(UNET_WORKLOADS),
                     help="BASELINE.json config to run (default: configs[1], the one the metric is quoted on)")
     args = ap.parse_args()
@@ -190,6 +191,15 @@ def main():
     d_in = [torch.from_numpy(g).cuda() for g in grids]
     d_out = [torch.empty((NC, NY, NX, model.c_out), dtype=torch.float32, device="cuda") for _ in grids]
     stream = torch.cuda.current_stream().cuda_stream
+
+    # One case stream per GPU = one simulation: its geometry (the flow-cell pattern of the SDF channel) is bound once,
+    # outside the timed region, like the reference's computeOnlyOnce / init_func; the rotated inputs differ in the
+    # velocity channels only (checked).  --no-bind times the general path, which takes any geometry per call.
+    bound = False
+    if NC == 1 and not args.no_bind:
+        masks = [g[0, ..., model.sdf_ch] != 0 for g in grids]
+        if all(np.array_equal(masks[0], m) for m in masks[1:]):
+            bound = sur.bind_geometry(d_in[0].data_ptr(), on_device=True)
 
     def step(i):
         k = i % len(d_in)
@@ -230,7 +240,9 @@ def main():
         "vs_baseline": None, "dtype": precision, "data": "synthetic",
         "config": {"workload": wl_desc,
                    "grid": [NY, NX], "blocks": sur.B, "p_in": P, "p_out": P, "cases_per_step_per_gpu": NC,
-                   "parallelism": f"case-sharded x{world} (no data-path collective)"},
+                   "parallelism": f"case-sharded x{world} (no data-path collective)",
+                   "geometry": ("bound once per case stream (psm_bind_geometry = the reference's computeOnlyOnce / init_func split): "
+                                "6 launches per solve") if bound else "general path (any geometry per call): 8 launches per solve"},
         "roofline": roofline,
     }
 

@@ -122,6 +122,25 @@ int psm_plan_grid(psm_handle* h, int32_t ny, int32_t nx);
 /* Number of blocks per case of the current plan (len(x_list), PM:332). */
 int psm_num_blocks(const psm_handle* h);
 
+/* Bind the geometry of the planned grid for the following solves -- the drop-in counterpart of the reference's
+ * computeOnlyOnce / init_func split (SM_call.py:89-178, python_module.py:172-246: everything that depends on the
+ * obstacle only is done once per simulation).  `grid` [ny, nx, c_in] float32 (host, or device memory when
+ * on_device != 0): only its SDF channel (cfg.sdf_channel; flow cell = value != 0, SM_call.py:221) is read.
+ * Every quantity the block-offset chain needs is a masked sum of decoded values, i.e. linear in the network
+ * output with coefficients that depend on the masks and the model only; binding tabulates those coefficients, and
+ * single-case solves then take 6 launches instead of 8: the strip means come from dot products with the last
+ * hidden activation inside the head layer's launch, and the decode launch runs the offset chain and writes
+ * value - offset - shift straight into the field (the decoded blocks are never stored; psm_read_stage(PSM_STAGE_PRED)
+ * is stale while bound).  Same results as the unbound path up to float32 summation order.
+ * CONTRACT: until psm_unbind_geometry / a new bind / a model or plan change, the SDF channel of every solved grid
+ * must have the flow-cell pattern of the bound one; the other channels are free.  Case batches (n_cases > 1) and
+ * bf16 handles keep the 8-launch path.  Returns PSM_ERR_UNSUPPORTED (nothing bound, solves unaffected) for
+ * configurations outside the fused path: > 64 blocks or >= 64 block columns, > 128 output components, no hidden
+ * layer, last hidden layer wider than 1024. */
+int psm_bind_geometry(psm_handle* h, const float* grid, int32_t on_device);
+int psm_unbind_geometry(psm_handle* h);
+int psm_geometry_bound(const psm_handle* h);   /* 1 while a geometry is bound */
+
 /* ---- per-step solve: grid-native counterpart of py_func (PM:249-517) and of
  *      Evaluation.timeStep from block extraction to assemble_prediction
  *      (SMD:452-575, UGP:470-547) ------------------------------------------- */

@@ -54,6 +54,9 @@ SIGNATURES = {
     "psm_set_scaler": (C.c_int, [_hp, _f64p, _f64p, _f64p, _f64p]),
     "psm_plan_grid": (C.c_int, [_hp, C.c_int32, C.c_int32]),
     "psm_num_blocks": (C.c_int, [_hp]),
+    "psm_bind_geometry": (C.c_int, [_hp, C.c_void_p, C.c_int32]),
+    "psm_unbind_geometry": (C.c_int, [_hp]),
+    "psm_geometry_bound": (C.c_int, [_hp]),
     "psm_solve_grid": (C.c_int, [_hp, _f32p, C.c_int32, _f32p, _f32p]),
     "psm_submit_grid": (C.c_int, [_hp, _f32p, C.c_int32, _f32p, C.POINTER(C.c_int64)]),
     "psm_wait_grid": (C.c_int, [_hp, C.c_int64, _f32p]),

@@ -99,6 +99,13 @@ struct psm_handle {
   std::map<GraphKey, hipGraphExec_t> graphs;
   bool use_graph = true;
   bool fused_assemble = false;
+  // geometry-bound fast path (psm_bind_geometry): tables of psm_kernels.h PsmBindArgs
+  bool bound = false, bound_zero_fill = false;
+  int bound_rows = 0;
+  float *d_comp_nat = nullptr;          // comp_out in natural layout [ld_out][K_out] (f32 precision only)
+  float *d_g2 = nullptr, *d_c2 = nullptr, *d_cnt = nullptr, *d_dots = nullptr;
+  int32_t* d_row_of = nullptr;
+  uint32_t* d_ownbits = nullptr;
   int debug_skip = 0;                   // PSM_DEBUG_SKIP bit mask of kernel groups NOT launched (timing experiments only)
   bool fuse_reduce_dense1 = true;       // PSM_NO_FUSED_REDUCE=1 disables
   int last_cases = 0;
@@ -303,6 +310,8 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
   const int M = n_cases * h->B, Mpad = round_up(M, 32);
   Timer tm{h, st, 0, prof};
   const bool bf16 = (h->cfg.precision == PSM_PRECISION_BF16);
+  // geometry-bound fast path: one case, nothing but the encode group being timed / skipped
+  const bool use_bound = h->bound && n_cases == 1 && !bf16 && (h->timed_kernel < 0 || h->timed_kernel == PSM_K_ENCODE) && h->debug_skip == 0;
   PsmEncodeArgs ea{};
   ea.grid = d_grid; ea.mean = h->d_mean_in; ea.bpack = h->d_bpack_in; ea.part = h->d_part;
   ea.row_base = h->d_row_base; ea.row_stride = (int64_t)h->Nx * h->cfg.c_in;
@@ -363,11 +372,36 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
     }
     for (int l = l_first; l < nl; ++l) {
       PsmDenseArgs da = dense_args(l, cur, ld_cur);
-      HIPCHK(h, psm_launch_dense(da, st));
+      if (use_bound && l == nl - 1) {          // head layer + strip dots of the bound geometry in one launch
+        PsmDotsArgs dd{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, h->d_dots, h->bound_rows, h->dense[nl - 1].Kpad};
+        HIPCHK(h, psm_launch_dense_dots(da, dd, st));
+      } else {
+        HIPCHK(h, psm_launch_dense(da, st));
+      }
       cur = da.out; ld_cur = h->dense[l].ldw;
     }
   }
   tm.after(PSM_K_MLP);
+  if (use_bound) {
+    PsmDecodeArgs de{};
+    de.res = h->d_res; de.ld_res = h->ld_out; de.bpack = h->d_bpack_out; de.mean = h->d_mean_out;
+    de.row_scale = d_row_scale; de.pred = nullptr; de.M = M; de.Mpad = Mpad; de.Gd = h->Gd;
+    de.n_coltiles = h->n_coltiles; de.K_out = h->K_out;
+    PsmBoundArgs ba{};
+    ba.cp = h->plan.cp; ba.blocks = h->d_blocks; ba.dots = h->d_dots; ba.scnt = h->d_cnt; ba.ownbits = h->d_ownbits;
+    ba.blk_y0x0 = h->d_blk; ba.shiftW = h->d_shiftW;
+    for (int f = 0; f < 2; ++f) ba.shiftL[f] = (int)h->plan.shiftA[f].size();
+    ba.fields = d_fields; ba.offs = h->d_offs; ba.shift = h->d_shift; ba.Nx = h->Nx; ba.n_strips = h->n_strips; ba.B = h->B;
+    tm.before(PSM_K_DECODE);
+    if (h->bound_zero_fill)                    // cells no block covers stay 0 like the reference's np.zeros field
+      HIPCHK(h, hipMemsetAsync(d_fields, 0, (size_t)h->Ny * h->Nx * h->cfg.c_out * sizeof(float), st));
+    PSM_REPEAT(h, PSM_K_DECODE) HIPCHK(h, psm_launch_decode_paste(de, ba, h->cfg.c_out, st));
+    tm.after(PSM_K_DECODE);
+    tm.before(PSM_K_STRIPS); tm.after(PSM_K_STRIPS);
+    tm.before(PSM_K_CHAIN); tm.after(PSM_K_CHAIN);
+    tm.before(PSM_K_PASTE); tm.after(PSM_K_PASTE);
+    return PSM_OK;
+  }
 
   PsmDecodeArgs de{};
   de.res = h->d_res; de.ld_res = h->ld_out; de.bpack = h->d_bpack_out; de.mean = h->d_mean_out;
@@ -529,6 +563,7 @@ void psm_destroy(psm_handle* h) {
   free_geometry(h);
   for (auto& d : h->dense) { dev_free(d.W); dev_free(d.b); if (d.Wp) { (void)hipFree(d.Wp); d.Wp = nullptr; } }
   dev_free(h->d_mean_in); dev_free(h->d_mean_out); dev_free(h->d_bpack_in); dev_free(h->d_bpack_out);
+  dev_free(h->d_comp_nat); dev_free(h->d_g2); dev_free(h->d_c2); dev_free(h->d_cnt); dev_free(h->d_dots); dev_free(h->d_row_of); dev_free(h->d_ownbits);
   dev_free(h->d_ia); dev_free(h->d_ib); dev_free(h->d_sa); dev_free(h->d_sb);
   for (int i = 0; i < psm_handle::RING; ++i) {
     if (h->h_scale[i]) (void)hipHostFree(h->h_scale[i]);
@@ -546,6 +581,7 @@ int psm_set_pca(psm_handle* h, const double* comp_in, const double* mean_in, con
   if (!comp_in || !mean_in || !comp_out || !mean_out) return fail(h, PSM_ERR_ARG, "null PCA array");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   destroy_graphs(h);
+  h->bound = false;
   std::vector<float> mi(h->K_in), mo(h->K_out);
   for (int k = 0; k < h->K_in; ++k) mi[k] = (float)mean_in[k];
   for (int k = 0; k < h->K_out; ++k) mo[k] = (float)mean_out[k];
@@ -564,6 +600,12 @@ int psm_set_pca(psm_handle* h, const double* comp_in, const double* mean_in, con
   } else {
   if ((rc = dev_upload(h, &h->d_bpack_in, pack_comp_in(comp_in, h->cfg.p_in, h->K_in, h->cfg.c_in, h->S, h->NT)))) return rc;
   if ((rc = dev_upload(h, &h->d_bpack_out, pack_comp_out(comp_out, h->cfg.p_out, h->K_out, h->Gd)))) return rc;
+  {
+    std::vector<float> nat((size_t)h->ld_out * h->K_out, 0.f);
+    for (int p = 0; p < h->cfg.p_out; ++p)
+      for (int k = 0; k < h->K_out; ++k) nat[(size_t)p * h->K_out + k] = (float)comp_out[(int64_t)p * h->K_out + k];
+    if ((rc = dev_upload(h, &h->d_comp_nat, nat))) return rc;
+  }
   }
   h->have_pca = true;
   return PSM_OK;
@@ -578,6 +620,7 @@ int psm_set_dense(psm_handle* h, int32_t layer, int32_t n_in, int32_t n_out, con
   if (layer > 0 && h->dense[layer - 1].set && h->dense[layer - 1].n_out != n_in) return fail(h, PSM_ERR_ARG, "dense layers do not chain");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   destroy_graphs(h);
+  h->bound = false;
   DenseLayer& d = h->dense[layer];
   d.n_in = n_in; d.n_out = n_out; d.Kpad = round_up(n_in, 32); d.ldw = round_up(n_out, 32);
   std::vector<float> W((size_t)d.Kpad * d.ldw, 0.f), b(d.ldw, 0.f);
@@ -623,6 +666,7 @@ int psm_set_scaler(psm_handle* h, const double* in_a, const double* in_b, const 
   if (!in_a || !out_a) return fail(h, PSM_ERR_ARG, "null scaler array");
   if (h->cfg.scaler != PSM_SCALER_MAX_ABS && (!in_b || !out_b)) return fail(h, PSM_ERR_ARG, "null scaler array");
   HIPCHK(h, hipSetDevice(h->cfg.device));
+  h->bound = false;
   std::vector<float> ia(h->ld_in, 0.f), ib(h->ld_in, 0.f), sa(h->ld_out, 0.f), sb(h->ld_out, 0.f);
   // x_in = coeff*ia + ib ; res' = res*sa + sb  (affine forms of SMD:505-539, evaluated in f64 here)
   for (int p = 0; p < h->cfg.p_in; ++p) {
@@ -655,6 +699,7 @@ int psm_plan_grid(psm_handle* h, int32_t ny, int32_t nx) {
     if (h->dense[l - 1].n_out != h->dense[l].n_in) return fail(h, PSM_ERR_ARG, "dense layers do not chain");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->bound = false;
   free_plan(h);
   std::string err;
   int rc = psm_build_plan(h->cfg.variant, ny, nx, h->S, h->ov, h->cfg.strict_degenerate != 0, h->plan, err);
@@ -753,6 +798,68 @@ int psm_plan_grid(psm_handle* h, int32_t ny, int32_t nx) {
   h->planned = true;
   return PSM_OK;
 }
+
+// Bind the geometry (the flow-cell masks) of the planned grid: builds the tables of the 6-launch solve.
+static int bind_geometry_device(psm_handle* h, const float* d_grid) {
+  const int nl = (int)h->dense.size();
+  h->bound = false;
+  if (h->cfg.precision != PSM_PRECISION_F32) return fail(h, PSM_ERR_UNSUPPORTED, "geometry binding: float32 precision only");
+  if (!h->fused_assemble || h->ld_out > 128 || h->Gd * 8 != h->ld_out || nl < 2 || !h->d_comp_nat)
+    return fail(h, PSM_ERR_UNSUPPORTED, "geometry binding needs <= 64 blocks in < 64 columns, <= 128 output components and a hidden layer");
+  const int Kh = h->dense[nl - 1].Kpad, C = h->cfg.c_out;
+  if (Kh % 4 != 0 || Kh > 1024 || C * h->n_strips + h->n_strips > 8 * 384)
+    return fail(h, PSM_ERR_UNSUPPORTED, "geometry binding: last hidden layer wider than 1024 or too many strips");
+  const int rows = C * h->n_strips + C * h->B;
+  destroy_graphs(h);
+  int rc;
+  double *d_G = nullptr, *d_M = nullptr;
+  if ((rc = dev_alloc(h, &d_G, (size_t)rows * h->ld_out))) return rc;
+  if ((rc = dev_alloc(h, &d_M, (size_t)rows))) { dev_free(d_G); return rc; }
+  if ((rc = dev_alloc(h, &h->d_g2, (size_t)rows * Kh)) || (rc = dev_alloc(h, &h->d_c2, (size_t)rows)) || (rc = dev_alloc(h, &h->d_cnt, (size_t)rows)) ||
+      (rc = dev_alloc(h, &h->d_dots, (size_t)rows)) || (rc = dev_alloc(h, &h->d_row_of, (size_t)rows)) ||
+      (rc = dev_alloc(h, &h->d_ownbits, (size_t)h->B * (h->S * h->S / 32)))) { dev_free(d_G); dev_free(d_M); return rc; }
+  PsmBindArgs a{};
+  a.grid = d_grid; a.strips = h->d_strips; a.blk_y0x0 = h->d_blk; a.comp = h->d_comp_nat; a.mean = h->d_mean_out; a.owner = h->d_owner;
+  a.shiftOwnA = h->d_shiftOwnA; a.shiftOwnB = h->d_shiftOwnB; a.Lmax = h->Lmax;
+  for (int f = 0; f < 2; ++f) a.shiftL[f] = (int)h->plan.shiftA[f].size();
+  const DenseLayer& hd = h->dense[nl - 1];
+  a.Wh = hd.W; a.ldw = hd.ldw; a.Kh = Kh; a.bh = hd.b; a.sa = h->d_sa; a.sb = h->d_sb;
+  a.G = d_G; a.Mrow = d_M; a.g2 = h->d_g2; a.c2 = h->d_c2; a.cnt = h->d_cnt; a.row_of = h->d_row_of; a.ownbits = h->d_ownbits;
+  a.nst = h->n_strips; a.B = h->B; a.S = h->S; a.c_in = h->cfg.c_in; a.c_out = C; a.sdf_ch = h->cfg.sdf_channel;
+  a.Ny = h->Ny; a.Nx = h->Nx; a.ld_out = h->ld_out;
+  hipError_t e = psm_launch_bind(a, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  dev_free(d_G); dev_free(d_M);
+  if (e != hipSuccess) return fail(h, PSM_ERR_HIP, std::string("psm_launch_bind: ") + hipGetErrorString(e));
+  h->bound_zero_fill = false;
+  for (int32_t o : h->plan.owner) if (o < 0) { h->bound_zero_fill = true; break; }
+  h->bound_rows = rows;
+  h->bound = true;
+  return PSM_OK;
+}
+
+int psm_bind_geometry(psm_handle* h, const float* grid, int32_t on_device) {
+  if (!h) return PSM_ERR_ARG;
+  if (!h->planned) return fail(h, PSM_ERR_STATE, "psm_plan_grid has not been called");
+  if (!grid) return fail(h, PSM_ERR_ARG, "null buffer");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (on_device) return bind_geometry_device(h, grid);
+  const size_t gin = (size_t)h->Ny * h->Nx * h->cfg.c_in * sizeof(float);
+  HIPCHK(h, hipMemcpy(h->d_grid_stage, grid, gin, hipMemcpyHostToDevice));
+  return bind_geometry_device(h, h->d_grid_stage);
+}
+
+int psm_unbind_geometry(psm_handle* h) {
+  if (!h) return PSM_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  destroy_graphs(h);
+  h->bound = false;
+  return PSM_OK;
+}
+
+int psm_geometry_bound(const psm_handle* h) { return (h && h->bound) ? 1 : 0; }
 
 int psm_num_blocks(const psm_handle* h) { return (h && h->planned) ? h->B : PSM_ERR_STATE; }
 

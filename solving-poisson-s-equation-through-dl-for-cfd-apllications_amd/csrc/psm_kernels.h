@@ -81,6 +81,44 @@ struct PsmPasteArgs {
   int B, S, c_out, npix;
 };
 
+// ---- geometry-bound fast path (psm_bind_geometry): every quantity the offset chain needs is linear in the network
+// output, strip_sum(s) = scale * (act . g2[s] + c2[s]) with tables that depend on the geometry (flow-cell masks) and
+// the model only -- so the strip means come from dot products with the LAST HIDDEN activation, computed by extra
+// workgroups of the head layer's launch, and the decode launch runs the chain and pastes straight into the field:
+// 6 launches per solve instead of 8, no decoded-block buffer.
+struct PsmBindArgs {                   // table build, once per geometry
+  const float* grid;                   // [Ny][Nx][c_in]: only the SDF channel is read
+  const int32_t* strips;               // [nst][6]
+  const int32_t* blk_y0x0;             // [B][2]
+  const float* comp;                   // natural layout [ld_out][K_out] (rows >= p_out zero)
+  const float* mean;                   // [K_out]
+  const int32_t* owner;                // [Ny*Nx]
+  const int32_t* shiftOwnA; const int32_t* shiftOwnB; int shiftL[2]; int Lmax;
+  const float* Wh; int ldw; int Kh;    // head kernel, natural layout [Kh][ldw]
+  const float* bh; const float* sa; const float* sb;
+  double* G; double* Mrow;             // scratch [rows][ld_out], [rows]
+  float* g2; float* c2; float* cnt;    // [rows][Kh], [rows], [rows]
+  int32_t* row_of;                     // [rows] block whose activation row the dot uses
+  uint32_t* ownbits;                   // [B][S*S/32] bit = this block-pixel is the last paste covering its cell
+  int nst, B, S, c_in, c_out, sdf_ch, Ny, Nx, ld_out;
+};
+struct PsmDotsArgs {                   // rows: [c_out][nst] strip means, then [c_out][B] shift partial sums
+  const float* g2; const float* c2; const float* cnt; const int32_t* row_of; const float* row_scale;
+  float* out; int n_rows, Kh;
+};
+struct PsmBoundArgs {
+  PsmChainParams cp; const PsmBlock* blocks;
+  const float* dots; const float* scnt; const uint32_t* ownbits; const int32_t* blk_y0x0; const float* shiftW;
+  int shiftL[2];
+  float* fields; float* offs; float* shift;
+  int Nx, n_strips, B;
+};
+hipError_t psm_launch_bind(const PsmBindArgs& a, hipStream_t s);
+// head layer + strip dots in one launch (f32, 16-row tiles)
+hipError_t psm_launch_dense_dots(const PsmDenseArgs& a, const PsmDotsArgs& d, hipStream_t s);
+// decode + offset chain + paste in one launch: ld_res <= 128, Mpad <= 64 (one case, B <= 64, n_x < 64)
+hipError_t psm_launch_decode_paste(const PsmDecodeArgs& a, const PsmBoundArgs& p, int c_out, hipStream_t s);
+
 hipError_t psm_read_stamps(unsigned long long* out);   // [64]; zeros unless built with -DPSM_STAMPS
 // ev_start / ev_stop (optional): stamped with the dispatch's own begin / end (hipExtLaunchKernel)
 hipError_t psm_launch_encode(const PsmEncodeArgs& a, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);

@@ -441,8 +441,48 @@ hipError_t psm_launch_reduce_dense1(const PsmReduceArgs& r, const PsmDenseArgs& 
 // activation row beyond ld_in are clamped (their weights are zero rows).
 // ROWS = 16 (few block rows: twice the workgroups, each pulling 2/3 of the bytes -- the layer
 // is bound by what ONE CU can pull per round trip) or 32 (weights read once per 32 rows).
-template <int NGC, bool BF16, int ROWS>   // NGC: groups of 16 k per wave per pass
-__global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a) {
+__device__ __forceinline__ float wave_sum(float v);
+
+// DOTS (head layer of the geometry-bound path): workgroups with blockIdx.z > 0 do not compute the layer but the
+// strip dot products of psm_kernels.h (PsmDotsArgs) from the same input activation: one wave per two table rows,
+// every load issued up front (clamped), out[row] = scale * (act . g2[row] + c2[row]) / cnt[row]  (0/0 = NaN for an
+// empty strip, like np.mean([])).
+template <int NGC, bool BF16, int ROWS, bool DOTS>   // NGC: groups of 16 k per wave per pass
+__global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a, PsmDotsArgs d) {
+  if (DOTS && blockIdx.z > 0) {
+    constexpr int RPW = 2, NQ = 4;                     // rows per wave; float4 per lane and row (Kh <= 1024)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wg = ((int)(blockIdx.z - 1) * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
+    const int nq = d.Kh / 4;
+    f32x4 g[RPW][NQ], x[RPW][NQ];
+    float c2[RPW], cn[RPW], rs[RPW];
+    int row[RPW];
+#pragma unroll
+    for (int t = 0; t < RPW; ++t) {
+      row[t] = (wg * 8 + wave) * RPW + t;
+      const int rc = min(row[t], d.n_rows - 1);
+      const int blk = d.row_of[rc];
+      c2[t] = d.c2[rc]; cn[t] = d.cnt[rc]; rs[t] = d.row_scale[blk];
+#pragma unroll
+      for (int u = 0; u < NQ; ++u) {
+        const int q = min(lane + 64 * u, nq - 1);
+        g[t][u] = reinterpret_cast<const f32x4*>(d.g2)[(int64_t)rc * nq + q];
+        x[t][u] = reinterpret_cast<const f32x4*>(a.in + (int64_t)blk * a.ld_in)[q];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < RPW; ++t) {
+      float acc = 0.f;
+#pragma unroll
+      for (int u = 0; u < NQ; ++u) {
+        const float s4 = (g[t][u].x * x[t][u].x + g[t][u].y * x[t][u].y) + (g[t][u].z * x[t][u].z + g[t][u].w * x[t][u].w);
+        acc += (lane + 64 * u < nq) ? s4 : 0.f;
+      }
+      const float tot = wave_sum(acc);
+      if (lane == 0 && row[t] < d.n_rows) d.out[row[t]] = rs[t] * (tot + c2[t]) / cn[t];
+    }
+    return;
+  }
   __shared__ float red[8][2][16 * 17];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -517,15 +557,28 @@ hipError_t psm_launch_dense(const PsmDenseArgs& a, hipStream_t st) {
 #define DENSE(N)                                                                            \
   do {                                                                                      \
     if (r16) {                                                                              \
-      if (a.bf16) hipLaunchKernelGGL((psm_dense_kernel<N, true, 16>), grid, blk, 0, st, a); \
-      else hipLaunchKernelGGL((psm_dense_kernel<N, false, 16>), grid, blk, 0, st, a);       \
+      if (a.bf16) hipLaunchKernelGGL((psm_dense_kernel<N, true, 16, false>), grid, blk, 0, st, a, PsmDotsArgs{}); \
+      else hipLaunchKernelGGL((psm_dense_kernel<N, false, 16, false>), grid, blk, 0, st, a, PsmDotsArgs{});       \
     } else {                                                                                \
-      if (a.bf16) hipLaunchKernelGGL((psm_dense_kernel<N, true, 32>), grid, blk, 0, st, a); \
-      else hipLaunchKernelGGL((psm_dense_kernel<N, false, 32>), grid, blk, 0, st, a);       \
+      if (a.bf16) hipLaunchKernelGGL((psm_dense_kernel<N, true, 32, false>), grid, blk, 0, st, a, PsmDotsArgs{}); \
+      else hipLaunchKernelGGL((psm_dense_kernel<N, false, 32, false>), grid, blk, 0, st, a, PsmDotsArgs{});       \
     }                                                                                       \
   } while (0)
   if (ng == 1) DENSE(1); else if (ng == 2) DENSE(2); else DENSE(4);
 #undef DENSE
+  return hipGetLastError();
+}
+
+hipError_t psm_launch_dense_dots(const PsmDenseArgs& a, const PsmDotsArgs& d, hipStream_t st) {
+  const int ng = a.Kp / 128;
+  if (!a.Wp || a.Kp % 128 != 0 || (ng > 2 && ng % 4 != 0) || a.ld_in < 4 || a.bf16 || a.Mpad > 128) return hipErrorInvalidValue;
+  if (d.Kh < 4 || d.Kh % 4 != 0 || d.Kh > 1024 || d.Kh > a.ld_in || d.n_rows < 1) return hipErrorInvalidValue;
+  const int gx = a.ld_w / 16, gy = a.Mpad / 16;
+  const int per_plane = gx * gy * 8 * 2;            // rows per z plane: 8 waves x 2 rows per workgroup
+  const dim3 grid(gx, gy, 1 + (d.n_rows + per_plane - 1) / per_plane), blk(512);
+  if (ng == 1) hipLaunchKernelGGL((psm_dense_kernel<1, false, 16, true>), grid, blk, 0, st, a, d);
+  else if (ng == 2) hipLaunchKernelGGL((psm_dense_kernel<2, false, 16, true>), grid, blk, 0, st, a, d);
+  else hipLaunchKernelGGL((psm_dense_kernel<4, false, 16, true>), grid, blk, 0, st, a, d);
   return hipGetLastError();
 }
 
@@ -1279,5 +1332,245 @@ __global__ __launch_bounds__(256) void psm_paste_kernel(PsmPasteArgs a) {
 
 hipError_t psm_launch_paste(const PsmPasteArgs& a, int n_cases, hipStream_t st) {
   hipLaunchKernelGGL(psm_paste_kernel, dim3((a.npix + 255) / 256, n_cases), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// geometry-bound fast path (psm_bind_geometry; structs in psm_kernels.h)
+// ---------------------------------------------------------------------------
+// Table build, once per geometry.  Row layout: [c_out][nst] strips, then [c_out][B] shift rows.
+//   strip row (f, s):  G[k] = sum over the rectangle of block `data`, cells that are flow cells of block `mask`,
+//                      of comp[k][(r*S + c)*C + f];  M = the same sum of mean;  cnt = number of such cells
+//   shift row (f, b):  G[k] = sum_i 3 comp[k][A_i] - sum_i comp[k][B_i] over the shift-list entries owned by block b
+// One workgroup per row, thread = component k (double accumulation: this runs once, not per solve).
+__global__ __launch_bounds__(128) void psm_bind_rows_kernel(PsmBindArgs a) {
+  const int C = a.c_out, S = a.S, SS = S * S, K_out = SS * C;
+  const int row = blockIdx.x, n_strip_rows = C * a.nst;
+  const int tid = threadIdx.x;
+  double acc[4] = {0, 0, 0, 0};                       // components tid, tid+128, ... (ld_out <= 512)
+  double msum = 0.0, cnt = 0.0;
+  int blk_of;
+  if (row < n_strip_rows) {
+    const int f = row / a.nst, s = row - f * a.nst;
+    const int32_t* st = a.strips + 6 * s;
+    const int data = st[0], mask = st[1], r0 = st[2], r1 = st[3], c0 = st[4], c1 = st[5];
+    blk_of = data;
+    const int my0 = mask >= 0 ? a.blk_y0x0[2 * mask] : 0, mx0 = mask >= 0 ? a.blk_y0x0[2 * mask + 1] : 0;
+    for (int r = r0; r < r1; ++r)
+      for (int c = c0; c < c1; ++c) {
+        const bool on = mask < 0 || a.grid[((int64_t)(my0 + r) * a.Nx + (mx0 + c)) * a.c_in + a.sdf_ch] != 0.f;
+        if (!on) continue;                              // uniform
+        const int col = (r * S + c) * C + f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (tid + 128 * u < a.ld_out) acc[u] += (double)a.comp[(int64_t)(tid + 128 * u) * K_out + col];
+        msum += (double)a.mean[col];
+        cnt += 1.0;
+      }
+  } else {
+    const int q = row - n_strip_rows, f = q / a.B, b = q - f * a.B;
+    blk_of = b;
+    cnt = 1.0;
+    for (int pass = 0; pass < 2; ++pass) {
+      const int32_t* list = (pass == 0 ? a.shiftOwnA : a.shiftOwnB) + (int64_t)f * a.Lmax;
+      const double w = pass == 0 ? 3.0 : -1.0;
+      for (int i = 0; i < a.shiftL[f]; ++i) {
+        const int o = list[i];
+        if (o < 0 || o / SS != b) continue;            // uniform
+        const int col = (o - b * SS) * C + f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (tid + 128 * u < a.ld_out) acc[u] += w * (double)a.comp[(int64_t)(tid + 128 * u) * K_out + col];
+        msum += w * (double)a.mean[col];
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (tid + 128 * u < a.ld_out) a.G[(int64_t)row * a.ld_out + tid + 128 * u] = acc[u];
+  if (tid == 0) { a.Mrow[row] = msum; a.cnt[row] = (float)cnt; a.row_of[row] = blk_of; }
+}
+
+// fold the head layer into the rows:  g2[row][j] = sum_k Wh[j][k] sa[k] G[row][k];
+// c2[row] = sum_k (bh[k] sa[k] + sb[k]) G[row][k] + M[row]   (head: out = (act @ Wh + bh) * sa + sb)
+__global__ __launch_bounds__(256) void psm_bind_fold_kernel(PsmBindArgs a) {
+  extern __shared__ double gs[];                        // [ld_out] G row scaled by sa
+  const int row = blockIdx.x, tid = threadIdx.x;
+  double part = 0.0;
+  for (int k = tid; k < a.ld_out; k += 256) {
+    const double g = a.G[(int64_t)row * a.ld_out + k];
+    gs[k] = g * (double)a.sa[k];
+    part += ((double)a.bh[k] * (double)a.sa[k] + (double)a.sb[k]) * g;
+  }
+  __shared__ double red[256];
+  red[tid] = part;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+  if (tid == 0) a.c2[row] = (float)(red[0] + a.Mrow[row]);
+  for (int j = tid; j < a.Kh; j += 256) {
+    const float* w = a.Wh + (int64_t)j * a.ldw;
+    double acc = 0.0;
+    for (int k = 0; k < a.ld_out; ++k) acc += (double)w[k] * gs[k];
+    a.g2[(int64_t)row * a.Kh + j] = (float)acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void psm_bind_own_kernel(PsmBindArgs a) {
+  const int SS = a.S * a.S, wpb = SS / 32;
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= a.B * wpb) return;
+  const int b = w / wpb, p0 = (w - b * wpb) * 32;
+  const int y0 = a.blk_y0x0[2 * b], x0 = a.blk_y0x0[2 * b + 1];
+  uint32_t bits = 0;
+  for (int t = 0; t < 32; ++t) {
+    const int px = p0 + t, r = px / a.S, c = px - r * a.S;
+    if (a.owner[(int64_t)(y0 + r) * a.Nx + (x0 + c)] == b * SS + px) bits |= 1u << t;
+  }
+  a.ownbits[w] = bits;
+}
+
+hipError_t psm_launch_bind(const PsmBindArgs& a, hipStream_t st) {
+  if (a.ld_out > 512 || a.ld_out < 1 || (a.S * a.S) % 32 != 0) return hipErrorInvalidValue;
+  const int rows = a.c_out * a.nst + a.c_out * a.B;
+  hipLaunchKernelGGL(psm_bind_rows_kernel, dim3(rows), dim3(128), 0, st, a);
+  hipLaunchKernelGGL(psm_bind_fold_kernel, dim3(rows), dim3(256), (size_t)a.ld_out * sizeof(double), st, a);
+  hipLaunchKernelGGL(psm_bind_own_kernel, dim3((a.B * (a.S * a.S / 32) + 255) / 256), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// decode + offset chain + paste.  Waves 0-3: the decode tile of psm_decode128_kernel (one row chunk); waves 4, 5: the
+// offset chain of field 0 / 1 from the strip means the head launch left in `dots`, and the global shift
+// (shift_f = sum_b dots_shift[f][b] / (3 L_f) - sum_b w_b offs_b).  Both run while the other's loads are in flight;
+// the epilogue writes value - offset - shift for the block pixels that own their cell (ownership bits) straight
+// into the field -- the decoded blocks are never stored.
+template <int MTC, int C, int LDR>      // LDR = ld_res: output components padded to 32, 64, 96 or 128
+__global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, PsmBoundArgs p) {
+  constexpr int LDA = LDR + 4, Q = LDR / 4, GD = LDR / 8, NA = MTC * 32 * Q / 256;
+  constexpr int WPB = (128 / C) / 32;                  // ownership words per block for this workgroup's 128 columns
+  constexpr int NST = 8;                               // staging rounds of 384 floats (C*nst + nst <= 3072)
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int B = p.B, nst = p.n_strips, S = p.cp.S;
+  float* lrs = lds + MTC * 32 * LDA;                   // [MTC*32] out_scale per block row
+  float* smean = lrs + MTC * 32;                       // [C][nst]
+  float* scnt = smean + C * nst;                       // [nst]
+  float* offs = scnt + nst;                            // [C][B]
+  float* wred = offs + C * B;                          // [4] shift per field
+  uint32_t* own = reinterpret_cast<uint32_t*>(wred + 4);   // [B][WPB]
+  int* yx = reinterpret_cast<int*>(own + B * WPB);     // [B][2]
+  const bool dec = wave < 4;                           // uniform per wave
+  const int i = lane & 31, h = lane >> 5;
+  const int ct = min((int)blockIdx.x * 4 + min(wave, 3), a.n_coltiles - 1);
+  const bool live = dec && ((int)blockIdx.x * 4 + wave) < a.n_coltiles;
+  // ---- every load of the prologue, clamped and unconditional
+  const int n_stage = C * nst + nst;
+  float sv[NST];
+#pragma unroll
+  for (int u = 0; u < NST; ++u) {
+    const int idx = min(tid + 384 * u, n_stage - 1);
+    const float* src = idx < C * nst ? p.dots + idx : p.scnt + (idx - C * nst);
+    sv[u] = *src;
+  }
+  const uint32_t ow = p.ownbits[(int64_t)(min(tid, B * WPB - 1) / WPB) * (S * S / 32) + (int)blockIdx.x * WPB + (min(tid, B * WPB - 1) % WPB)];
+  const int yxv = p.blk_y0x0[min(tid, 2 * B - 1)];
+  const int cf = min(max(wave - 4, 0), C - 1);         // chain waves: their field
+  const float w_shift = p.shiftW[cf * B + min(lane, B - 1)];
+  const float s_raw = p.dots[C * nst + cf * B + min(lane, B - 1)];
+  v4f x[NA];
+#pragma unroll
+  for (int u = 0; u < NA; ++u) {                       // (the two chain waves load a clamped duplicate: 384 threads, 256 slots)
+    const int idx = min(tid, 255) + 256 * u, row = idx / Q, q = idx - row * Q;
+    x[u] = *reinterpret_cast<const v4f*>(a.res + (int64_t)min(row, a.Mpad - 1) * LDR + 4 * q);
+  }
+  const float rs = a.row_scale[min(min(tid, MTC * 32 - 1), a.Mpad - 1)];
+  __builtin_amdgcn_sched_barrier(0);
+  float4 b[GD];
+  const float4* bp = a.bpack + ((int64_t)ct * GD) * 64 + lane;
+#pragma unroll
+  for (int g = 0; g < GD; ++g) b[g] = stream_load(bp + g * 64);
+  const int col = ct * 32 + i;
+  const float mu = a.mean[col];
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- LDS staging
+#pragma unroll
+  for (int u = 0; u < NST; ++u)
+    if (tid + 384 * u < n_stage) smean[tid + 384 * u] = sv[u];       // smean and scnt are contiguous
+  if (tid < B * WPB) own[tid] = ow;
+  if (tid < 2 * B) yx[tid] = yxv;
+  if (tid < 256) {
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      const int idx = tid + 256 * u, row = idx / Q, q = idx - row * Q;
+      *reinterpret_cast<v4f*>(&lds[row * LDA + 4 * q]) = x[u];
+    }
+  }
+  if (tid < MTC * 32) lrs[tid] = rs;
+  __syncthreads();
+  f32x16 acc[MTC];
+  if (dec) {
+#pragma unroll
+    for (int mt = 0; mt < MTC; ++mt) {
+      acc[mt] = (f32x16){0};
+      const float* arow = &lds[(mt * 32 + i) * LDA + 4 * h];
+      float4 av = *reinterpret_cast<const float4*>(arow);
+#pragma unroll
+      for (int g = 0; g < GD; ++g) {
+        const float4 an = *reinterpret_cast<const float4*>(arow + 8 * (g + 1 < GD ? g + 1 : g));
+        acc[mt] = MFMA32(av.x, b[g].x, acc[mt]);
+        acc[mt] = MFMA32(av.y, b[g].y, acc[mt]);
+        acc[mt] = MFMA32(av.z, b[g].z, acc[mt]);
+        acc[mt] = MFMA32(av.w, b[g].w, acc[mt]);
+        av = an;
+      }
+    }
+  } else if (wave - 4 < C) {
+    const int f = wave - 4;
+    psm_chain_wave(p.cp, smean + f * nst, scnt, p.blocks, f, lane, offs + f * B);
+    const float t = (lane < B && w_shift != 0.f) ? w_shift * offs[f * B + lane] : 0.f;   // same-wave LDS writes are visible
+    const float t_shift = wave_sum(t);
+    const float raw = wave_sum(lane < B ? s_raw : 0.f);
+    if (lane == 0) wred[f] = raw / (float)p.shiftL[f] / 3.f - t_shift;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {       // introspection copies (psm_read_stage)
+    for (int idx = tid; idx < C * B; idx += 384) p.offs[idx] = offs[idx];
+    if (tid < C) p.shift[tid] = wred[tid];
+  }
+  if (!live) return;
+  const int px = col / C, f = col - px * C;
+  const int pxl = px - (int)blockIdx.x * (128 / C);
+  const int r = px / S, c = px - r * S;
+  const float sh = wred[f];
+#pragma unroll
+  for (int mt = 0; mt < MTC; ++mt) {
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) {
+      const int m = mt * 32 + acc_row(rg, h);
+      const int mc = min(m, B - 1);
+      const bool mine = m < B && ((own[mc * WPB + (pxl >> 5)] >> (pxl & 31)) & 1u);
+      if (mine) {
+        const int y = yx[2 * mc] + r, xx = yx[2 * mc + 1] + c;
+        p.fields[((int64_t)y * p.Nx + xx) * C + f] = (acc[mt][rg] + mu) * lrs[m] - offs[f * B + mc] - sh;
+      }
+    }
+  }
+}
+
+hipError_t psm_launch_decode_paste(const PsmDecodeArgs& a, const PsmBoundArgs& p, int c_out, hipStream_t st) {
+  if (a.ld_res > 128 || a.ld_res % 32 != 0 || a.Gd * 8 != a.ld_res || a.Mpad > 64 || a.Mpad % 32 != 0 || p.B > 64 || p.B < 1 || a.M != p.B) return hipErrorInvalidValue;
+  if ((c_out != 1 && c_out != 2) || c_out * p.n_strips + p.n_strips > 8 * 384) return hipErrorInvalidValue;
+  const int nwg = (a.n_coltiles + 3) / 4, mtc = a.Mpad / 32, wpb = (128 / c_out) / 32;
+  const size_t lds = ((size_t)mtc * 32 * (a.ld_res + 4) + (size_t)mtc * 32 + (size_t)c_out * p.n_strips + p.n_strips + (size_t)c_out * p.B + 4 +
+                      (size_t)p.B * wpb + 2 * (size_t)p.B) * sizeof(float);
+#define DP(M_, C_, L_) hipLaunchKernelGGL((psm_decode_paste_kernel<M_, C_, L_>), dim3(nwg), dim3(384), lds, st, a, p)
+#define DPL(L_)                                                        \
+  do {                                                                 \
+    if (mtc == 1) { if (c_out == 1) DP(1, 1, L_); else DP(1, 2, L_); } \
+    else { if (c_out == 1) DP(2, 1, L_); else DP(2, 2, L_); }          \
+  } while (0)
+  if (a.ld_res == 32) DPL(32); else if (a.ld_res == 64) DPL(64); else if (a.ld_res == 96) DPL(96); else DPL(128);
+#undef DPL
+#undef DP
   return hipGetLastError();
 }

@@ -1,0 +1,132 @@
+"""Geometry-bound solves (psm_bind_geometry: strip means from dot products with the last hidden activation, decode +
+offset chain + paste in one launch) against the general 8-launch path, the oracle and the golden vectors produced by the
+reference's own statements.  Needs a real MI355X.
+
+Tolerances: the bound path sums the same float32 products in another order (the strip means go through tables folded
+with the head layer), so it is compared with the general path at 2e-5 * max|field| and with the oracle / golden
+fields at the tolerances of tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+import cases
+from oracle import psm_oracle as orc
+from psm_amd import GridSurrogate, synthetic
+from test_gpu_parity import oracle_model, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def same(a, b, tol=2e-5):
+    a, b = np.asarray(a), np.asarray(b)
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    scale = max(np.nanmax(np.abs(b)), 1e-6) if np.isfinite(b).any() else 1.0
+    assert np.nanmax(np.abs(a - b), initial=0.0) <= tol * scale, (np.nanmax(np.abs(a - b)), scale)
+
+
+@pytest.mark.parametrize("name", list(cases.GOLDEN_CASES))
+def test_bound_equals_general_path_and_golden(name):
+    grid, model = cases.build(name)
+    gold = cases.load_golden(name)
+    out_scale = [model.out_scale] if model.variant == "deltas" else None
+    g32 = grid.astype(np.float32)
+    with GridSurrogate(model, grid.shape[0], grid.shape[1]) as sur:
+        general = sur.solve(g32, out_scale=out_scale)[0]
+        offs_general = sur.stage("offsets")[0].copy()
+        assert sur.bind_geometry(g32) and sur.geometry_bound
+        bound = sur.solve(g32, out_scale=out_scale)[0]
+        offs_bound = sur.stage("offsets")[0]
+        same(offs_bound, offs_general)
+        same(bound, general)
+        # other velocities on the same geometry: only the SDF channel is part of the binding
+        g2 = g32.copy()
+        rng = np.random.default_rng(5)
+        for ch in range(g2.shape[-1]):
+            if ch != model.sdf_ch:
+                g2[..., ch] = (g2[..., ch] * 0.7 + 0.05 * rng.standard_normal(g2.shape[:2])).astype(np.float32) * (g2[..., model.sdf_ch] != 0)
+        b2 = sur.solve(g2, out_scale=out_scale)[0]
+        sur.unbind_geometry()
+        assert not sur.geometry_bound
+        same(b2, sur.solve(g2, out_scale=out_scale)[0])
+    ref = gold["fields"]
+    assert np.abs(bound - ref).max() <= 2e-4 * np.abs(ref).max()
+    assert rel_l2(bound, ref) <= 5e-5
+
+
+def test_config1_bound_against_oracle():
+    """BASELINE config 1 on the bound path: 256x256 U_to_gradP, P_i = P_o = 128, MLP_small."""
+    model = synthetic.make_model("gradp")
+    grid = synthetic.channel_grid(256, 256, seed=1).astype(np.float32)
+    sol = orc.solve_grid(grid.astype(np.float64), oracle_model(model))
+    with GridSurrogate(model, 256, 256) as sur:
+        assert sur.bind_geometry(grid)
+        fields = sur.solve(grid)[0]
+        offs = sur.stage("offsets")[0]
+    for c, a in enumerate(sol.assemblies):
+        np.testing.assert_allclose(offs[c], a.offsets, rtol=0, atol=1e-4 * np.nanmax(np.abs(a.field)), equal_nan=True)
+    assert np.isfinite(fields).all()
+    assert np.abs(fields - sol.fields).max() <= 1e-4 * np.abs(sol.fields).max()
+
+
+def test_config2_sequence_on_a_bound_geometry():
+    """BASELINE config 2: sequential deltaU_to_deltaP solves on one geometry with a different out_scale per step."""
+    model = synthetic.make_model("deltas")
+    base = synthetic.channel_grid(256, 256, seed=1).astype(np.float32)
+    with GridSurrogate(model, 256, 256) as sur, GridSurrogate(model, 256, 256) as ref:
+        assert sur.bind_geometry(base)
+        for step in range(4):
+            g = synthetic.delta_grid(256, 256, seed=2, step=step).astype(np.float32)
+            g[..., model.sdf_ch] = base[..., model.sdf_ch]
+            g[..., :model.sdf_ch] *= (base[..., model.sdf_ch:model.sdf_ch + 1] != 0)
+            sc = [0.5 + 0.25 * step]
+            same(sur.solve(g, out_scale=sc)[0], ref.solve(g, out_scale=sc)[0])
+
+
+def test_all_solid_and_all_flow_grids_bound():
+    """Empty masks everywhere (every strip mean NaN) and full masks: the NaN logic of the chain only depends on the
+    counts, which the binding tabulates."""
+    for variant in ("deltas", "gradp", "chapter5"):
+        model = synthetic.make_model(variant, p_in=16, p_out=16)
+        for fill in (0.0, 1.0):
+            g = synthetic.channel_grid(256, 256, seed=3).astype(np.float32)
+            g[..., model.sdf_ch] = fill
+            if fill == 0.0:
+                g[...] = 0.0
+            with GridSurrogate(model, 256, 256) as sur:
+                general = sur.solve(g)[0]
+                assert sur.bind_geometry(g)
+                same(sur.solve(g)[0], general)
+
+
+def test_bind_lifecycle_and_unsupported_configurations():
+    model = synthetic.make_model("deltas", p_in=16, p_out=16)
+    g = synthetic.channel_grid(256, 256, seed=4).astype(np.float32)
+    with GridSurrogate(model, 256, 256, max_cases=2) as sur:
+        assert sur.bind_geometry(g)
+        one = sur.solve(g)[0]
+        two = sur.solve(np.stack([g, g]))           # case batches keep the general path
+        same(two[0], one); same(two[1], one)
+        with pytest.raises(ValueError):
+            sur.bind_geometry(g[:100])
+    big = synthetic.make_model("deltas", p_in=16, p_out=16)
+    gb = synthetic.channel_grid(128, 128 + 96 * 70, seed=5).astype(np.float32)      # > 64 block columns
+    with GridSurrogate(big, gb.shape[0], gb.shape[1]) as sur:
+        assert sur.bind_geometry(gb) is False and not sur.geometry_bound
+        assert np.isfinite(sur.solve(gb)[0]).all()
+    with GridSurrogate(model, 256, 256, precision="bf16") as sur:
+        assert sur.bind_geometry(g) is False
+    wide = synthetic.make_model("gradp", p_in=16, p_out=130)                         # > 128 output components
+    with GridSurrogate(wide, 256, 256) as sur:
+        assert sur.bind_geometry(g) is False
+
+
+def test_bound_unaligned_grid_and_device_pointer():
+    from hipmem import DeviceArray
+    model = synthetic.make_model("chapter5", p_in=24, p_out=24)
+    g = synthetic.channel_grid(300, 402, seed=6).astype(np.float32)
+    with GridSurrogate(model, 300, 402) as sur:
+        general = sur.solve(g)[0]
+        d_in, d_out = DeviceArray(g[None]), DeviceArray(shape=(1, 300, 402, 1))
+        assert sur.bind_geometry(d_in.ptr, on_device=True)
+        sur.solve_device(d_in.ptr, 1, d_out.ptr, 0)
+        sur.synchronize()
+        same(d_out.numpy()[0], general)
