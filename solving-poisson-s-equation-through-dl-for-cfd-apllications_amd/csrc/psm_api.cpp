@@ -101,6 +101,8 @@ struct psm_handle {
   bool fused_assemble = false;
   // geometry-bound fast path (psm_bind_geometry): tables of psm_kernels.h PsmBindArgs
   bool bound = false, bound_zero_fill = false;
+  int bound_scope = 0;                  // 2: every single-case solve (psm_bind_geometry); 1: psm_solve only (bound by psm_set_geometry)
+  bool in_mesh_solve = false;
   int bound_rows = 0;
   float *d_comp_nat = nullptr;          // comp_out in natural layout [ld_out][K_out] (f32 precision only)
   float *d_g2 = nullptr, *d_c2 = nullptr, *d_cnt = nullptr, *d_dots = nullptr;
@@ -311,7 +313,7 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
   Timer tm{h, st, 0, prof};
   const bool bf16 = (h->cfg.precision == PSM_PRECISION_BF16);
   // geometry-bound fast path: one case, nothing but the encode group being timed / skipped
-  const bool use_bound = h->bound && n_cases == 1 && !bf16 && (h->timed_kernel < 0 || h->timed_kernel == PSM_K_ENCODE) && h->debug_skip == 0;
+  const bool use_bound = h->bound && (h->bound_scope == 2 || h->in_mesh_solve) && n_cases == 1 && !bf16 && (h->timed_kernel < 0 || h->timed_kernel == PSM_K_ENCODE) && h->debug_skip == 0;
   PsmEncodeArgs ea{};
   ea.grid = d_grid; ea.mean = h->d_mean_in; ea.bpack = h->d_bpack_in; ea.part = h->d_part;
   ea.row_base = h->d_row_base; ea.row_stride = (int64_t)h->Nx * h->cfg.c_in;
@@ -471,7 +473,7 @@ int solve_device(psm_handle* h, const float* d_grid, int n_cases, const float* o
   h->last_cases = n_cases;
   const bool eager = prof || h->timed_kernel >= 0 || !h->use_graph;
   if (eager) return launch_all(h, d_grid, n_cases, d_fields, d_scale, st, prof);
-  GraphKey key{n_cases * 2 + (out_scale ? 1 : 0), d_grid, d_fields};
+  GraphKey key{(n_cases * 2 + (out_scale ? 1 : 0)) * 2 + ((h->bound && (h->bound_scope == 2 || h->in_mesh_solve)) ? 1 : 0), d_grid, d_fields};
   auto it = h->graphs.find(key);
   if (it == h->graphs.end()) {
     if (h->graphs.size() > 64) destroy_graphs(h);
@@ -844,6 +846,7 @@ int psm_bind_geometry(psm_handle* h, const float* grid, int32_t on_device) {
   if (!grid) return fail(h, PSM_ERR_ARG, "null buffer");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->bound_scope = 2;
   if (on_device) return bind_geometry_device(h, grid);
   const size_t gin = (size_t)h->Ny * h->Nx * h->cfg.c_in * sizeof(float);
   HIPCHK(h, hipMemcpy(h->d_grid_stage, grid, gin, hipMemcpyHostToDevice));
@@ -1037,6 +1040,21 @@ int psm_set_geometry(psm_handle* h, int64_t n_cells, int32_t ny, int32_t nx, con
   HIPCHK(h, hipHostMalloc((void**)&h->h_cells, (size_t)n_cells * 5 * sizeof(double), hipHostMallocDefault));
   HIPCHK(h, hipHostMalloc((void**)&h->h_p, (size_t)n_cells * sizeof(double), hipHostMallocDefault));
   h->have_geometry = true;
+  // The mesh entry builds its grid from THIS sdfunct at every step, so the geometry of psm_solve is fixed from here
+  // on: bind it (scope: psm_solve only -- grid-native solves on the same handle stay general until psm_bind_geometry).
+  if (h->cfg.precision == PSM_PRECISION_F32 && h->cfg.c_in == 3 && h->cfg.sdf_channel == 2 && g2m && getenv("PSM_NO_BIND") == nullptr) {
+    std::vector<float> g((size_t)ng * 3, 0.f);
+    const double sc = normalise_sdf ? 1.0 / maxs[2] : 1.0;
+    for (int64_t t = 0; t < ng; ++t) {
+      const double sdv = sdfunct[t] * sc;                    // the SDF channel exactly as psm_to_grid_kernel writes it
+      g[(size_t)t * 3 + 2] = (sdv != sdv) ? 0.f : (float)sdv;
+    }
+    HIPCHK(h, hipMemcpy(h->d_grid_stage, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice));
+    rc = bind_geometry_device(h, h->d_grid_stage);
+    if (rc == PSM_OK) h->bound_scope = 1;
+    else if (rc == PSM_ERR_UNSUPPORTED) h->err.clear();      // configuration outside the fused path: general path
+    else return rc;
+  }
   return PSM_OK;
 }
 
@@ -1063,7 +1081,9 @@ int psm_solve(psm_handle* h, const double* cells, int64_t n, int32_t rank, doubl
   ga.max_abs_ux = h->maxs[0]; ga.max_abs_uy = h->maxs[1]; ga.sdf_scale = h->normalise_sdf ? 1.0 / h->maxs[2] : 1.0;
   ga.c_in = h->cfg.c_in; ga.fill = h->fill_input;
   HIPCHK(h, psm_launch_to_grid(ga, st));
+  h->in_mesh_solve = true;
   int rc = solve_device(h, h->d_grid_stage, 1, nullptr, h->d_fields_stage, st, nullptr);
+  h->in_mesh_solve = false;
   if (rc) return rc;
   PsmToMeshArgs ma{};
   ma.cells = h->d_cells; ma.umax = h->d_umax; ma.vtx = h->d_vtx_g2m; ma.wts = h->d_wts_g2m; ma.cell_of_point = h->d_cell_of_point;

@@ -111,6 +111,7 @@ class GridSurrogate:
             raise ValueError(f"grid must be [n,{self.ny},{self.nx},>={self.model.c_in}]")
         g = _f32(g[..., :self.model.c_in])
         n = g.shape[0]
+        self._check_bound(g)
         out = np.empty((n, self.ny, self.nx, self.model.c_out), np.float32)
         sc = None
         if out_scale is not None:
@@ -129,6 +130,7 @@ class GridSurrogate:
             raise ValueError(f"grid must be [n,{self.ny},{self.nx},>={self.model.c_in}]")
         g = _f32(g[..., :self.model.c_in])
         n = g.shape[0]
+        self._check_bound(g)
         sc = _f32(np.broadcast_to(out_scale, (n,))) if out_scale is not None else None
         t = C.c_int64(-1)
         self._chk(self.lib.psm_submit_grid(self.h, _p(g, C.c_float), n, _p(sc, C.c_float) if sc is not None else None,
@@ -158,13 +160,24 @@ class GridSurrogate:
             if g.shape[-3:] != (self.ny, self.nx, self.model.c_in):
                 raise ValueError(f"grid must be [{self.ny},{self.nx},{self.model.c_in}]")
             rc = self.lib.psm_bind_geometry(self.h, g.ctypes.data_as(C.c_void_p), 0)
+        self._bound_mask = None
         if rc == -5:                    # PSM_ERR_UNSUPPORTED: configuration outside the fused path
             return False
         self._chk(rc)
+        if not on_device:
+            self._bound_mask = g[..., self.model.sdf_ch] != 0
         return True
 
     def unbind_geometry(self):
+        self._bound_mask = None
         self._chk(self.lib.psm_unbind_geometry(self.h))
+
+    def _check_bound(self, g: np.ndarray):
+        """Host-grid entries: a grid whose flow-cell pattern differs from the bound one drops the binding (the
+        device-pointer entries rely on the contract of psm_bind_geometry instead)."""
+        m = getattr(self, "_bound_mask", None)
+        if m is not None and g.shape[0] == 1 and not np.array_equal(g[0, ..., self.model.sdf_ch] != 0, m):
+            self.unbind_geometry()
 
     @property
     def geometry_bound(self) -> bool:
@@ -407,7 +420,17 @@ class Evaluation:
         sur._chk(sur.lib.psm_set_geometry(sur.h, int(self.indice), t.ny, t.nx, _p(v1, C.c_int32), _p(w1, C.c_double),
                                           _p(idx, C.c_int32), _p(sdf, C.c_double), None, None, _p(mx, C.c_double), 1, 1, 0.05))
         self.tables = t
+        self._bind_simulation_geometry(sur, t.sdfunct, float(mx[2]))
         return 0
+
+    def _bind_simulation_geometry(self, sur, sdfunct: np.ndarray, max_abs_dist: float):
+        """computeOnlyOnce fixes the obstacle for every timeStep of the simulation: bind its flow-cell pattern (the SDF
+        channel exactly as timeStep normalises it) so that the steps take the 6-launch path.  Grids of another
+        geometry passed to timeStep_grid drop the binding again (GridSurrogate._check_bound)."""
+        g = np.zeros((sur.ny, sur.nx, self.artifacts.c_in), np.float32)
+        sd = np.asarray(sdfunct, np.float64) / max_abs_dist
+        g[..., self.artifacts.sdf_ch] = np.where(np.isnan(sd), 0.0, sd).astype(np.float32)
+        sur.bind_geometry(g)
 
     def _mesh_to_grid(self, columns: np.ndarray) -> np.ndarray:
         """interpolate_fill + scatter of k cell columns on the GPU (psm_mesh_to_grid) -> [Ny,Nx,k] float64."""
@@ -639,6 +662,7 @@ class EvaluationGradP(Evaluation):
         sur._chk(sur.lib.psm_set_geometry(sur.h, int(self.indice), t.ny, t.nx, _p(v1, C.c_int32), _p(w1, C.c_double),
                                           _p(idx, C.c_int32), _p(sdf, C.c_double), None, None, _p(mx, C.c_double), 1, 1, 0.05))
         self.tables = t
+        self._bind_simulation_geometry(sur, t.sdfunct, float(mx[2]))
         return 0
 
     def timeStep(self, sim, time, plot_intermediate_fields=False, save_plots=False, show_plots=False, apply_filter=False):

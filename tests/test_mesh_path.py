@@ -75,6 +75,26 @@ def test_solver_module_init_func_py_func(mesh_case):
 
 
 @pytest.mark.gpu
+def test_init_func_binds_the_geometry_for_py_func_only(mesh_case, monkeypatch):
+    """psm_set_geometry binds the obstacle for the mesh entry (6-launch solves); the pressures equal those of the
+    general path (PSM_NO_BIND=1) to float32 summation order, and grid-native solves on the same handle stay general."""
+    array, top, obst, model, maxs, geo, gold = mesh_case
+    sm = SolverModule(model, maxs)
+    sm.init_func(array, top, obst, 0)
+    assert sm._sur.geometry_bound
+    p_bound = sm.py_func(array, 0)
+    g = cases.synthetic.channel_grid(sm.tables.ny, sm.tables.nx, seed=9).astype(np.float32)    # another geometry
+    f_grid = sm._sur.solve(g)[0]
+    monkeypatch.setenv("PSM_NO_BIND", "1")
+    sm2 = SolverModule(model, maxs)
+    sm2.init_func(array, top, obst, 0)
+    assert not sm2._sur.geometry_bound
+    p_general = sm2.py_func(array, 0)
+    assert np.abs(p_bound - p_general).max() <= 2e-5 * np.abs(p_general).max()
+    np.testing.assert_allclose(f_grid, sm2._sur.solve(g)[0], rtol=0, atol=1e-6 * np.abs(f_grid).max())
+
+
+@pytest.mark.gpu
 def test_pinned_solver_buffers_give_the_same_pressures(mesh_case):
     """psm_pin_buffers: the solver's persistent arrays registered for direct DMA -- bit-identical results, staging path
     still taken for any other pointer, unpin restores it."""
