@@ -130,3 +130,39 @@ def test_bound_unaligned_grid_and_device_pointer():
         sur.solve_device(d_in.ptr, 1, d_out.ptr, 0)
         sur.synchronize()
         same(d_out.numpy()[0], general)
+
+
+def test_bound_path_on_random_shapes_and_obstacles():
+    """Full solves on 24 seeded random grid shapes (all three variants) with random obstacles and solid bands that
+    empty some overlap strips (the np.isnan branches of the chain, p_i == 0 duplicate rows, unaligned widths):
+    geometry-bound result against the general path, NaN pattern included."""
+    from psm_amd import _lib
+    rng = np.random.default_rng(77)
+    variants = ("deltas", "gradp", "chapter5")
+    n_bound = 0
+    for trial in range(24):
+        variant = variants[trial % 3]
+        ny, nx = int(rng.integers(130, 520)), int(rng.integers(260, 900))
+        model = synthetic.make_model(variant, p_in=int(rng.integers(3, 40)), p_out=int(rng.integers(3, 130)))
+        grid = synthetic.channel_grid(ny, nx, seed=300 + trial, obstacle=("circle", "rectangle", "plate", "none")[trial % 4],
+                                      cx=float(rng.uniform(0.2, 0.8)), cy=float(rng.uniform(0.2, 0.8))).astype(np.float32)
+        for _ in range(int(rng.integers(0, 3))):
+            y0, x0 = int(rng.integers(0, ny - 40)), int(rng.integers(0, nx - 140))
+            grid[y0:y0 + int(rng.integers(8, 40)), x0:x0 + int(rng.integers(100, 140)), :] = 0.0
+        try:
+            sur = GridSurrogate(model, ny, nx)
+        except _lib.PsmError:
+            continue                                                   # shapes the reference itself cannot process
+        with sur:
+            sc = [float(rng.uniform(0.3, 2.0))]
+            general = sur.solve(grid, out_scale=sc)[0]
+            if not sur.bind_geometry(grid):
+                continue
+            n_bound += 1
+            bound = sur.solve(grid, out_scale=sc)[0]
+            offs_b = sur.stage("offsets")[0]
+        assert np.array_equal(np.isnan(bound), np.isnan(general)), (variant, ny, nx, trial)
+        ok = ~np.isnan(general)
+        if ok.any():
+            assert np.abs(bound[ok] - general[ok]).max() <= 5e-5 * max(1e-3, np.abs(general[ok]).max()), (variant, ny, nx, trial)
+    assert n_bound >= 15
