@@ -133,11 +133,15 @@ int psm_num_blocks(const psm_handle* h);
  * value - offset - shift straight into the field (the decoded blocks are never stored; psm_read_stage(PSM_STAGE_PRED)
  * is stale while bound).  Same results as the unbound path up to float32 summation order.
  * CONTRACT: until psm_unbind_geometry / a new bind / a model or plan change, the SDF channel of every solved grid
- * must have the flow-cell pattern of the bound one; the other channels are free.  Case batches (n_cases > 1) and
- * bf16 handles keep the 8-launch path.  Returns PSM_ERR_UNSUPPORTED (nothing bound, solves unaffected) for
+ * must have the flow-cell pattern of the bound one; the other channels are free.  bf16 handles and case counts
+ * other than the bound one keep the general path.  Returns PSM_ERR_UNSUPPORTED (nothing bound, solves unaffected) for
  * configurations outside the fused path: > 64 blocks or >= 64 block columns, > 128 output components, no hidden
  * layer, last hidden layer wider than 1024. */
 int psm_bind_geometry(psm_handle* h, const float* grid, int32_t on_device);
+/* The same for a case batch: grids [n_cases, ny, nx, c_in], one geometry per case slot.  Solves with exactly
+ * n_cases cases (case i on geometry i) then take 7 launches instead of 9: head + strip dots, one chain launch
+ * (a workgroup per case), decode + paste.  Other case counts keep the general path. */
+int psm_bind_geometry_cases(psm_handle* h, const float* grids, int32_t n_cases, int32_t on_device);
 int psm_unbind_geometry(psm_handle* h);
 int psm_geometry_bound(const psm_handle* h);   /* 1 while a geometry is bound */
 

@@ -55,6 +55,7 @@ SIGNATURES = {
     "psm_plan_grid": (C.c_int, [_hp, C.c_int32, C.c_int32]),
     "psm_num_blocks": (C.c_int, [_hp]),
     "psm_bind_geometry": (C.c_int, [_hp, C.c_void_p, C.c_int32]),
+    "psm_bind_geometry_cases": (C.c_int, [_hp, C.c_void_p, C.c_int32, C.c_int32]),
     "psm_unbind_geometry": (C.c_int, [_hp]),
     "psm_geometry_bound": (C.c_int, [_hp]),
     "psm_solve_grid": (C.c_int, [_hp, _f32p, C.c_int32, _f32p, _f32p]),

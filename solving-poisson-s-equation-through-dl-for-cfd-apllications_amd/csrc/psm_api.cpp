@@ -103,7 +103,8 @@ struct psm_handle {
   bool bound = false, bound_zero_fill = false;
   int bound_scope = 0;                  // 2: every single-case solve (psm_bind_geometry); 1: psm_solve only (bound by psm_set_geometry)
   bool in_mesh_solve = false;
-  int bound_rows = 0;
+  int bound_rows = 0;                   // table rows per case
+  int bound_cases = 0;                  // cases bound (solves with exactly this many cases take the bound path)
   float *d_comp_nat = nullptr;          // comp_out in natural layout [ld_out][K_out] (f32 precision only)
   float *d_g2 = nullptr, *d_c2 = nullptr, *d_cnt = nullptr, *d_dots = nullptr;
   int32_t* d_row_of = nullptr;
@@ -313,7 +314,7 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
   Timer tm{h, st, 0, prof};
   const bool bf16 = (h->cfg.precision == PSM_PRECISION_BF16);
   // geometry-bound fast path: one case, nothing but the encode group being timed / skipped
-  const bool use_bound = h->bound && (h->bound_scope == 2 || h->in_mesh_solve) && n_cases == 1 && !bf16 && (h->timed_kernel < 0 || h->timed_kernel == PSM_K_ENCODE) && h->debug_skip == 0;
+  const bool use_bound = h->bound && (h->bound_scope == 2 || h->in_mesh_solve) && n_cases == h->bound_cases && !bf16 && (h->timed_kernel < 0 || h->timed_kernel == PSM_K_ENCODE) && h->debug_skip == 0;
   PsmEncodeArgs ea{};
   ea.grid = d_grid; ea.mean = h->d_mean_in; ea.bpack = h->d_bpack_in; ea.part = h->d_part;
   ea.row_base = h->d_row_base; ea.row_stride = (int64_t)h->Nx * h->cfg.c_in;
@@ -375,7 +376,7 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
     for (int l = l_first; l < nl; ++l) {
       PsmDenseArgs da = dense_args(l, cur, ld_cur);
       if (use_bound && l == nl - 1) {          // head layer + strip dots of the bound geometry in one launch
-        PsmDotsArgs dd{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, h->d_dots, h->bound_rows, h->dense[nl - 1].Kpad};
+        PsmDotsArgs dd{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, h->d_dots, h->bound_rows * n_cases, h->dense[nl - 1].Kpad};
         HIPCHK(h, psm_launch_dense_dots(da, dd, st));
       } else {
         HIPCHK(h, psm_launch_dense(da, st));
@@ -394,14 +395,32 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
     ba.blk_y0x0 = h->d_blk; ba.shiftW = h->d_shiftW;
     for (int f = 0; f < 2; ++f) ba.shiftL[f] = (int)h->plan.shiftA[f].size();
     ba.fields = d_fields; ba.offs = h->d_offs; ba.shift = h->d_shift; ba.Nx = h->Nx; ba.n_strips = h->n_strips; ba.B = h->B;
-    tm.before(PSM_K_DECODE);
     if (h->bound_zero_fill)                    // cells no block covers stay 0 like the reference's np.zeros field
-      HIPCHK(h, hipMemsetAsync(d_fields, 0, (size_t)h->Ny * h->Nx * h->cfg.c_out * sizeof(float), st));
-    PSM_REPEAT(h, PSM_K_DECODE) HIPCHK(h, psm_launch_decode_paste(de, ba, h->cfg.c_out, st));
-    tm.after(PSM_K_DECODE);
+      HIPCHK(h, hipMemsetAsync(d_fields, 0, (size_t)n_cases * h->Ny * h->Nx * h->cfg.c_out * sizeof(float), st));
+    if (n_cases == 1) {
+      tm.before(PSM_K_DECODE);
+      PSM_REPEAT(h, PSM_K_DECODE) HIPCHK(h, psm_launch_decode_paste(de, ba, h->cfg.c_out, st));
+      tm.after(PSM_K_DECODE);
+      tm.before(PSM_K_STRIPS); tm.after(PSM_K_STRIPS);
+      tm.before(PSM_K_CHAIN); tm.after(PSM_K_CHAIN);
+      tm.before(PSM_K_PASTE); tm.after(PSM_K_PASTE);
+      return PSM_OK;
+    }
+    // case batch: the chains of all cases in one small launch, then decode + paste over all block rows
+    PsmBoundBatchArgs bb{};
+    bb.cp = h->plan.cp; bb.blocks = h->d_blocks; bb.dots = h->d_dots; bb.scnt = h->d_cnt; bb.ownbits = h->d_ownbits;
+    bb.blk_y0x0 = h->d_blk; bb.shiftW = h->d_shiftW;
+    for (int f = 0; f < 2; ++f) bb.shiftL[f] = (int)h->plan.shiftA[f].size();
+    bb.fields = d_fields; bb.offs = h->d_offs; bb.shift = h->d_shift; bb.Nx = h->Nx; bb.npix = h->Ny * h->Nx;
+    bb.n_strips = h->n_strips; bb.B = h->B; bb.rows_pc = h->bound_rows; bb.n_cases = n_cases;
+    tm.before(PSM_K_DECODE); tm.after(PSM_K_DECODE);
     tm.before(PSM_K_STRIPS); tm.after(PSM_K_STRIPS);
-    tm.before(PSM_K_CHAIN); tm.after(PSM_K_CHAIN);
-    tm.before(PSM_K_PASTE); tm.after(PSM_K_PASTE);
+    tm.before(PSM_K_CHAIN);
+    HIPCHK(h, psm_launch_chain_dots(bb, h->cfg.c_out, st));
+    tm.after(PSM_K_CHAIN);
+    tm.before(PSM_K_PASTE);
+    HIPCHK(h, psm_launch_decode_paste_batch(de, bb, h->cfg.c_out, st));
+    tm.after(PSM_K_PASTE);
     return PSM_OK;
   }
 
@@ -802,56 +821,68 @@ int psm_plan_grid(psm_handle* h, int32_t ny, int32_t nx) {
 }
 
 // Bind the geometry (the flow-cell masks) of the planned grid: builds the tables of the 6-launch solve.
-static int bind_geometry_device(psm_handle* h, const float* d_grid) {
+static int bind_geometry_device(psm_handle* h, const float* d_grid, int n_cases = 1) {
   const int nl = (int)h->dense.size();
   h->bound = false;
   if (h->cfg.precision != PSM_PRECISION_F32) return fail(h, PSM_ERR_UNSUPPORTED, "geometry binding: float32 precision only");
   if (!h->fused_assemble || h->ld_out > 128 || h->Gd * 8 != h->ld_out || nl < 2 || !h->d_comp_nat)
     return fail(h, PSM_ERR_UNSUPPORTED, "geometry binding needs <= 64 blocks in < 64 columns, <= 128 output components and a hidden layer");
   const int Kh = h->dense[nl - 1].Kpad, C = h->cfg.c_out;
-  if (Kh % 4 != 0 || Kh > 1024 || C * h->n_strips + h->n_strips > 8 * 384)
+  if (Kh % 4 != 0 || Kh > 1024 || C * h->n_strips + h->n_strips > 2560)
     return fail(h, PSM_ERR_UNSUPPORTED, "geometry binding: last hidden layer wider than 1024 or too many strips");
+  if (n_cases > 1 && round_up(n_cases * h->B, 32) > 128 * 64) return fail(h, PSM_ERR_UNSUPPORTED, "geometry binding: too many block rows");
   const int rows = C * h->n_strips + C * h->B;
+  const size_t all = (size_t)rows * n_cases;
   destroy_graphs(h);
   int rc;
   double *d_G = nullptr, *d_M = nullptr;
   if ((rc = dev_alloc(h, &d_G, (size_t)rows * h->ld_out))) return rc;
   if ((rc = dev_alloc(h, &d_M, (size_t)rows))) { dev_free(d_G); return rc; }
-  if ((rc = dev_alloc(h, &h->d_g2, (size_t)rows * Kh)) || (rc = dev_alloc(h, &h->d_c2, (size_t)rows)) || (rc = dev_alloc(h, &h->d_cnt, (size_t)rows)) ||
-      (rc = dev_alloc(h, &h->d_dots, (size_t)rows)) || (rc = dev_alloc(h, &h->d_row_of, (size_t)rows)) ||
-      (rc = dev_alloc(h, &h->d_ownbits, (size_t)h->B * (h->S * h->S / 32)))) { dev_free(d_G); dev_free(d_M); return rc; }
-  PsmBindArgs a{};
-  a.grid = d_grid; a.strips = h->d_strips; a.blk_y0x0 = h->d_blk; a.comp = h->d_comp_nat; a.mean = h->d_mean_out; a.owner = h->d_owner;
-  a.shiftOwnA = h->d_shiftOwnA; a.shiftOwnB = h->d_shiftOwnB; a.Lmax = h->Lmax;
-  for (int f = 0; f < 2; ++f) a.shiftL[f] = (int)h->plan.shiftA[f].size();
+  if ((rc = dev_alloc(h, &h->d_g2, all * Kh)) || (rc = dev_alloc(h, &h->d_c2, all)) || (rc = dev_alloc(h, &h->d_cnt, all)) ||
+      (rc = dev_alloc(h, &h->d_dots, all)) || (rc = dev_alloc(h, &h->d_row_of, all)) ||
+      (rc = dev_alloc(h, &h->d_ownbits, (size_t)n_cases * h->B * (h->S * h->S / 32)))) { dev_free(d_G); dev_free(d_M); return rc; }
   const DenseLayer& hd = h->dense[nl - 1];
-  a.Wh = hd.W; a.ldw = hd.ldw; a.Kh = Kh; a.bh = hd.b; a.sa = h->d_sa; a.sb = h->d_sb;
-  a.G = d_G; a.Mrow = d_M; a.g2 = h->d_g2; a.c2 = h->d_c2; a.cnt = h->d_cnt; a.row_of = h->d_row_of; a.ownbits = h->d_ownbits;
-  a.nst = h->n_strips; a.B = h->B; a.S = h->S; a.c_in = h->cfg.c_in; a.c_out = C; a.sdf_ch = h->cfg.sdf_channel;
-  a.Ny = h->Ny; a.Nx = h->Nx; a.ld_out = h->ld_out;
-  hipError_t e = psm_launch_bind(a, h->stream);
+  hipError_t e = hipSuccess;
+  for (int cs = 0; cs < n_cases && e == hipSuccess; ++cs) {
+    PsmBindArgs a{};
+    a.grid = d_grid + (size_t)cs * h->Ny * h->Nx * h->cfg.c_in;
+    a.strips = h->d_strips; a.blk_y0x0 = h->d_blk; a.comp = h->d_comp_nat; a.mean = h->d_mean_out; a.owner = h->d_owner;
+    a.shiftOwnA = h->d_shiftOwnA; a.shiftOwnB = h->d_shiftOwnB; a.Lmax = h->Lmax;
+    for (int f = 0; f < 2; ++f) a.shiftL[f] = (int)h->plan.shiftA[f].size();
+    a.Wh = hd.W; a.ldw = hd.ldw; a.Kh = Kh; a.bh = hd.b; a.sa = h->d_sa; a.sb = h->d_sb;
+    a.G = d_G; a.Mrow = d_M;
+    a.g2 = h->d_g2 + (size_t)cs * rows * Kh; a.c2 = h->d_c2 + (size_t)cs * rows; a.cnt = h->d_cnt + (size_t)cs * rows;
+    a.row_of = h->d_row_of + (size_t)cs * rows; a.ownbits = h->d_ownbits + (size_t)cs * h->B * (h->S * h->S / 32);
+    a.nst = h->n_strips; a.B = h->B; a.S = h->S; a.c_in = h->cfg.c_in; a.c_out = C; a.sdf_ch = h->cfg.sdf_channel;
+    a.Ny = h->Ny; a.Nx = h->Nx; a.ld_out = h->ld_out; a.row_base = cs * h->B;
+    e = psm_launch_bind(a, h->stream);            // same stream: the scratch is reused case after case
+  }
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   dev_free(d_G); dev_free(d_M);
   if (e != hipSuccess) return fail(h, PSM_ERR_HIP, std::string("psm_launch_bind: ") + hipGetErrorString(e));
   h->bound_zero_fill = false;
   for (int32_t o : h->plan.owner) if (o < 0) { h->bound_zero_fill = true; break; }
   h->bound_rows = rows;
+  h->bound_cases = n_cases;
   h->bound = true;
   return PSM_OK;
 }
 
-int psm_bind_geometry(psm_handle* h, const float* grid, int32_t on_device) {
+int psm_bind_geometry_cases(psm_handle* h, const float* grids, int32_t n_cases, int32_t on_device) {
   if (!h) return PSM_ERR_ARG;
   if (!h->planned) return fail(h, PSM_ERR_STATE, "psm_plan_grid has not been called");
-  if (!grid) return fail(h, PSM_ERR_ARG, "null buffer");
+  if (!grids) return fail(h, PSM_ERR_ARG, "null buffer");
+  if (n_cases < 1 || n_cases > h->cfg.max_cases) return fail(h, PSM_ERR_ARG, "n_cases outside [1, max_cases]");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->bound_scope = 2;
-  if (on_device) return bind_geometry_device(h, grid);
-  const size_t gin = (size_t)h->Ny * h->Nx * h->cfg.c_in * sizeof(float);
-  HIPCHK(h, hipMemcpy(h->d_grid_stage, grid, gin, hipMemcpyHostToDevice));
-  return bind_geometry_device(h, h->d_grid_stage);
+  if (on_device) return bind_geometry_device(h, grids, n_cases);
+  const size_t gin = (size_t)n_cases * h->Ny * h->Nx * h->cfg.c_in * sizeof(float);
+  HIPCHK(h, hipMemcpy(h->d_grid_stage, grids, gin, hipMemcpyHostToDevice));
+  return bind_geometry_device(h, h->d_grid_stage, n_cases);
 }
+
+int psm_bind_geometry(psm_handle* h, const float* grid, int32_t on_device) { return psm_bind_geometry_cases(h, grid, 1, on_device); }
 
 int psm_unbind_geometry(psm_handle* h) {
   if (!h) return PSM_ERR_ARG;

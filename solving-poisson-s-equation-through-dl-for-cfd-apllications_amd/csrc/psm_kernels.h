@@ -101,6 +101,7 @@ struct PsmBindArgs {                   // table build, once per geometry
   int32_t* row_of;                     // [rows] block whose activation row the dot uses
   uint32_t* ownbits;                   // [B][S*S/32] bit = this block-pixel is the last paste covering its cell
   int nst, B, S, c_in, c_out, sdf_ch, Ny, Nx, ld_out;
+  int row_base;                        // case * B: row_of holds global block rows (case batches)
 };
 struct PsmDotsArgs {                   // rows: [c_out][nst] strip means, then [c_out][B] shift partial sums
   const float* g2; const float* c2; const float* cnt; const int32_t* row_of; const float* row_scale;
@@ -113,7 +114,18 @@ struct PsmBoundArgs {
   float* fields; float* offs; float* shift;
   int Nx, n_strips, B;
 };
+struct PsmBoundBatchArgs {             // case batches: chain in its own small launch, then decode + paste
+  PsmChainParams cp; const PsmBlock* blocks;
+  const float* dots; const float* scnt;        // per case: [rows_pc] means / shift sums, [rows_pc] counts
+  const uint32_t* ownbits;                     // [cases][B][S*S/32]
+  const int32_t* blk_y0x0; const float* shiftW;
+  int shiftL[2];
+  float* fields; float* offs; float* shift;    // offs [cases][c_out][B], shift [cases][c_out]
+  int Nx, npix, n_strips, B, rows_pc, n_cases;
+};
 hipError_t psm_launch_bind(const PsmBindArgs& a, hipStream_t s);
+hipError_t psm_launch_chain_dots(const PsmBoundBatchArgs& p, int c_out, hipStream_t s);
+hipError_t psm_launch_decode_paste_batch(const PsmDecodeArgs& a, const PsmBoundBatchArgs& p, int c_out, hipStream_t s);
 // head layer + strip dots in one launch (f32, 16-row tiles)
 hipError_t psm_launch_dense_dots(const PsmDenseArgs& a, const PsmDotsArgs& d, hipStream_t s);
 // decode + offset chain + paste in one launch: ld_res <= 128, Mpad <= 64 (one case, B <= 64, n_x < 64)

@@ -571,14 +571,19 @@ hipError_t psm_launch_dense(const PsmDenseArgs& a, hipStream_t st) {
 
 hipError_t psm_launch_dense_dots(const PsmDenseArgs& a, const PsmDotsArgs& d, hipStream_t st) {
   const int ng = a.Kp / 128;
-  if (!a.Wp || a.Kp % 128 != 0 || (ng > 2 && ng % 4 != 0) || a.ld_in < 4 || a.bf16 || a.Mpad > 128) return hipErrorInvalidValue;
+  if (!a.Wp || a.Kp % 128 != 0 || (ng > 2 && ng % 4 != 0) || a.ld_in < 4 || a.bf16) return hipErrorInvalidValue;
   if (d.Kh < 4 || d.Kh % 4 != 0 || d.Kh > 1024 || d.Kh > a.ld_in || d.n_rows < 1) return hipErrorInvalidValue;
-  const int gx = a.ld_w / 16, gy = a.Mpad / 16;
+  const bool r16 = a.Mpad <= 128;                   // same tile choice as psm_launch_dense
+  const int gx = a.ld_w / 16, gy = a.Mpad / (r16 ? 16 : 32);
   const int per_plane = gx * gy * 8 * 2;            // rows per z plane: 8 waves x 2 rows per workgroup
   const dim3 grid(gx, gy, 1 + (d.n_rows + per_plane - 1) / per_plane), blk(512);
-  if (ng == 1) hipLaunchKernelGGL((psm_dense_kernel<1, false, 16, true>), grid, blk, 0, st, a, d);
-  else if (ng == 2) hipLaunchKernelGGL((psm_dense_kernel<2, false, 16, true>), grid, blk, 0, st, a, d);
-  else hipLaunchKernelGGL((psm_dense_kernel<4, false, 16, true>), grid, blk, 0, st, a, d);
+#define DD(N)                                                                                          \
+  do {                                                                                                 \
+    if (r16) hipLaunchKernelGGL((psm_dense_kernel<N, false, 16, true>), grid, blk, 0, st, a, d);       \
+    else hipLaunchKernelGGL((psm_dense_kernel<N, false, 32, true>), grid, blk, 0, st, a, d);           \
+  } while (0)
+  if (ng == 1) DD(1); else if (ng == 2) DD(2); else DD(4);
+#undef DD
   return hipGetLastError();
 }
 
@@ -1388,7 +1393,7 @@ __global__ __launch_bounds__(128) void psm_bind_rows_kernel(PsmBindArgs a) {
 #pragma unroll
   for (int u = 0; u < 4; ++u)
     if (tid + 128 * u < a.ld_out) a.G[(int64_t)row * a.ld_out + tid + 128 * u] = acc[u];
-  if (tid == 0) { a.Mrow[row] = msum; a.cnt[row] = (float)cnt; a.row_of[row] = blk_of; }
+  if (tid == 0) { a.Mrow[row] = msum; a.cnt[row] = (float)cnt; a.row_of[row] = a.row_base + blk_of; }
 }
 
 // fold the head layer into the rows:  g2[row][j] = sum_k Wh[j][k] sa[k] G[row][k];
@@ -1571,6 +1576,178 @@ hipError_t psm_launch_decode_paste(const PsmDecodeArgs& a, const PsmBoundArgs& p
   } while (0)
   if (a.ld_res == 32) DPL(32); else if (a.ld_res == 64) DPL(64); else if (a.ld_res == 96) DPL(96); else DPL(128);
 #undef DPL
+#undef DP
+  return hipGetLastError();
+}
+
+// ---- case batches on a bound geometry: the chain of every case in one small launch (one workgroup per case, wave f =
+// field f), then decode + paste for all block rows (row chunks like psm_decode128_kernel)
+template <int C>
+__global__ __launch_bounds__(256) void psm_chain_dots_kernel(PsmBoundBatchArgs p) {
+  constexpr int NST = 10;                              // staging rounds of 256 floats (C*nst + nst <= 2560)
+  extern __shared__ float sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cs = blockIdx.x;
+  const int B = p.B, nst = p.n_strips;
+  float* smean = sm;                                   // [C][nst]
+  float* scnt = smean + C * nst;                       // [nst]
+  float* offs = scnt + nst;                            // [C][B]
+  const float* dots = p.dots + (int64_t)cs * p.rows_pc;
+  const float* cnt = p.scnt + (int64_t)cs * p.rows_pc;
+  const int n_stage = C * nst + nst;
+  float sv[NST];
+#pragma unroll
+  for (int u = 0; u < NST; ++u) {
+    const int idx = min(tid + 256 * u, n_stage - 1);
+    sv[u] = idx < C * nst ? dots[idx] : cnt[idx - C * nst];
+  }
+  const int f = min(wave, C - 1);
+  const float w_shift = p.shiftW[f * B + min(lane, B - 1)];
+  const float s_raw = dots[C * nst + f * B + min(lane, B - 1)];
+#pragma unroll
+  for (int u = 0; u < NST; ++u)
+    if (tid + 256 * u < n_stage) smean[tid + 256 * u] = sv[u];
+  __syncthreads();
+  if (wave < C) {
+    psm_chain_wave(p.cp, smean + wave * nst, scnt, p.blocks, wave, lane, offs + wave * B);
+    const float t = (lane < B && w_shift != 0.f) ? w_shift * offs[wave * B + lane] : 0.f;
+    const float t_shift = wave_sum(t);
+    const float raw = wave_sum(lane < B ? s_raw : 0.f);
+    if (lane < B) p.offs[((int64_t)cs * C + wave) * B + lane] = offs[wave * B + lane];
+    if (lane == 0) p.shift[cs * C + wave] = raw / (float)p.shiftL[wave] / 3.f - t_shift;
+  }
+}
+
+hipError_t psm_launch_chain_dots(const PsmBoundBatchArgs& p, int c_out, hipStream_t st) {
+  if ((c_out != 1 && c_out != 2) || c_out * p.n_strips + p.n_strips > 2560 || p.B > 64 || p.B < 1) return hipErrorInvalidValue;
+  const size_t lds = ((size_t)c_out * p.n_strips + p.n_strips + (size_t)c_out * p.B) * sizeof(float);
+  if (c_out == 1) hipLaunchKernelGGL((psm_chain_dots_kernel<1>), dim3(p.n_cases), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((psm_chain_dots_kernel<2>), dim3(p.n_cases), dim3(256), lds, st, p);
+  return hipGetLastError();
+}
+
+template <int MTC, int C, int LDR>
+__global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeArgs a, PsmBoundBatchArgs p, int m_end) {
+  constexpr int LDA = LDR + 4, Q = LDR / 4, GD = LDR / 8, NA = MTC * 32 * Q / 256;
+  constexpr int WPB = (128 / C) / 32, R = MTC * 32;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int B = p.B, S = p.cp.S, wps = S * S / 32;
+  float* lrs = lds + R * LDA;                          // [R] out_scale per block row
+  float* lsub = lrs + R;                               // [R][C] offset + shift of the row's block
+  uint32_t* lown = reinterpret_cast<uint32_t*>(lsub + R * C);   // [R][WPB]
+  int* lcb = reinterpret_cast<int*>(lown + R * WPB);   // [R][2] case, block
+  int* yx = lcb + 2 * R;                               // [B][2]
+  const int ct = min((int)blockIdx.x * 4 + wave, a.n_coltiles - 1);
+  const bool live = ((int)blockIdx.x * 4 + wave) < a.n_coltiles;
+  const int m_first = (int)blockIdx.y * R, m_step = R * (int)gridDim.y;
+  auto load_tile = [&](v4f (&x)[NA], int m_base) {
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      const int idx = tid + 256 * u, row = idx / Q, q = idx - row * Q;
+      x[u] = *reinterpret_cast<const v4f*>(a.res + (int64_t)min(m_base + row, a.Mpad - 1) * LDR + 4 * q);
+    }
+  };
+  // per-row operands of the epilogue (thread = row of the chunk): scale, offset + shift, ownership words
+  struct RowOps { float rs, sub[C]; uint32_t own[WPB]; int cs, b; };
+  auto load_rows = [&](RowOps& o, int m_base) {
+    const int m = min(m_base + min(tid, R - 1), a.M - 1);
+    o.cs = m / B; o.b = m - o.cs * B;
+    o.rs = a.row_scale[m];
+#pragma unroll
+    for (int f = 0; f < C; ++f) o.sub[f] = p.offs[((int64_t)o.cs * C + f) * B + o.b] + p.shift[o.cs * C + f];
+#pragma unroll
+    for (int w = 0; w < WPB; ++w) o.own[w] = p.ownbits[((int64_t)o.cs * B + o.b) * wps + (int)blockIdx.x * WPB + w];
+  };
+  v4f x[NA];
+  RowOps ro;
+  load_tile(x, m_first);
+  load_rows(ro, m_first);
+  const int yxv = p.blk_y0x0[min(tid, 2 * B - 1)];
+  __builtin_amdgcn_sched_barrier(0);
+  float4 b[GD];
+  const float4* bp = a.bpack + ((int64_t)ct * GD) * 64 + lane;
+#pragma unroll
+  for (int g = 0; g < GD; ++g) b[g] = stream_load(bp + g * 64);
+  const int col = ct * 32 + i;
+  const float mu = a.mean[col];
+  __builtin_amdgcn_sched_barrier(0);
+  if (tid < 2 * B) yx[tid] = yxv;
+  const int px = col / C, f = col - px * C;
+  const int pxl = px - (int)blockIdx.x * (128 / C);
+  const int r = px / S, c = px - r * S;
+  for (int m_base = m_first; m_base < m_end; m_base += m_step) {
+    if (m_base != m_first) {
+      __syncthreads();                                 // every wave is done with the previous chunk
+      load_tile(x, m_base);
+      load_rows(ro, m_base);
+    }
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      const int idx = tid + 256 * u, row = idx / Q, q = idx - row * Q;
+      *reinterpret_cast<v4f*>(&lds[row * LDA + 4 * q]) = x[u];
+    }
+    if (tid < R) {
+      lrs[tid] = ro.rs;
+#pragma unroll
+      for (int ff = 0; ff < C; ++ff) lsub[tid * C + ff] = ro.sub[ff];
+#pragma unroll
+      for (int w = 0; w < WPB; ++w) lown[tid * WPB + w] = ro.own[w];
+      lcb[2 * tid] = ro.cs; lcb[2 * tid + 1] = ro.b;
+    }
+    __syncthreads();
+    f32x16 acc[MTC];
+#pragma unroll
+    for (int mt = 0; mt < MTC; ++mt) {
+      acc[mt] = (f32x16){0};
+      const float* arow = &lds[(mt * 32 + i) * LDA + 4 * h];
+      float4 av = *reinterpret_cast<const float4*>(arow);
+#pragma unroll
+      for (int g = 0; g < GD; ++g) {
+        const float4 an = *reinterpret_cast<const float4*>(arow + 8 * (g + 1 < GD ? g + 1 : g));
+        acc[mt] = MFMA32(av.x, b[g].x, acc[mt]);
+        acc[mt] = MFMA32(av.y, b[g].y, acc[mt]);
+        acc[mt] = MFMA32(av.z, b[g].z, acc[mt]);
+        acc[mt] = MFMA32(av.w, b[g].w, acc[mt]);
+        av = an;
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int mt = 0; mt < MTC; ++mt) {
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+          const int rr = mt * 32 + acc_row(rg, h);
+          const bool mine = (m_base + rr) < a.M && ((lown[rr * WPB + (pxl >> 5)] >> (pxl & 31)) & 1u);
+          if (mine) {
+            const int cs = lcb[2 * rr], bb = lcb[2 * rr + 1];
+            const int y = yx[2 * bb] + r, xx = yx[2 * bb + 1] + c;
+            p.fields[((int64_t)cs * p.npix + (int64_t)y * p.Nx + xx) * C + f] = (acc[mt][rg] + mu) * lrs[rr] - lsub[rr * C + f];
+          }
+        }
+      }
+    }
+  }
+}
+
+hipError_t psm_launch_decode_paste_batch(const PsmDecodeArgs& a, const PsmBoundBatchArgs& p, int c_out, hipStream_t st) {
+  if (a.ld_res > 128 || a.ld_res % 32 != 0 || a.Gd * 8 != a.ld_res || a.Mpad % 32 != 0 || p.B > 64 || p.B < 1 || a.M != p.B * p.n_cases) return hipErrorInvalidValue;
+  if (c_out != 1 && c_out != 2) return hipErrorInvalidValue;
+  const int nwg = (a.n_coltiles + 3) / 4;
+  const int tiles = a.Mpad / 32, iters = (tiles + 3) / 4, mtc = (tiles + iters - 1) / iters, wpb = (128 / c_out) / 32, R = mtc * 32;
+  const size_t lds = ((size_t)R * (a.ld_res + 4) + R + (size_t)R * c_out + (size_t)R * wpb + 2 * (size_t)R + 2 * (size_t)p.B) * sizeof(float);
+  int groups = 1;
+  while (nwg * groups < 256 && groups * 2 <= iters) groups *= 2;
+  const dim3 grid(nwg, groups);
+#define DP(M_, C_, L_) hipLaunchKernelGGL((psm_decode_paste_batch_kernel<M_, C_, L_>), grid, dim3(256), lds, st, a, p, a.Mpad)
+#define DPM(C_, L_)                                                                 \
+  do {                                                                              \
+    if (mtc == 4) DP(4, C_, L_); else if (mtc == 3) DP(3, C_, L_); else if (mtc == 2) DP(2, C_, L_); else DP(1, C_, L_); \
+  } while (0)
+#define DPL(L_) do { if (c_out == 1) DPM(1, L_); else DPM(2, L_); } while (0)
+  if (a.ld_res == 32) DPL(32); else if (a.ld_res == 64) DPL(64); else if (a.ld_res == 96) DPL(96); else DPL(128);
+#undef DPL
+#undef DPM
 #undef DP
   return hipGetLastError();
 }

@@ -148,18 +148,21 @@ class GridSurrogate:
         del self._ticket_cases[ticket]
         return out
 
-    def bind_geometry(self, grid, on_device: bool = False) -> bool:
+    def bind_geometry(self, grid, on_device: bool = False, n_cases: int = 1) -> bool:
         """Bind the obstacle geometry (SDF channel of ``grid`` [ny, nx, c_in], or a device pointer with
-        ``on_device``) for the following single-case solves: 6 launches instead of 8 (``psm_bind_geometry``; the
+        ``on_device``; a case batch [n, ny, nx, c_in] binds one geometry per case slot) for the following solves with
+        the same number of cases: 6 launches instead of 8 (7 instead of 9 for batches; ``psm_bind_geometry_cases``; the
         reference's computeOnlyOnce / init_func split).  Returns False -- and leaves the solves on the general
         path -- for configurations the fused path does not cover."""
         if on_device:
-            rc = self.lib.psm_bind_geometry(self.h, C.c_void_p(int(grid)), 1)
+            rc = self.lib.psm_bind_geometry_cases(self.h, C.c_void_p(int(grid)), int(n_cases), 1)
         else:
             g = np.ascontiguousarray(np.asarray(grid)[..., :self.model.c_in], np.float32)
-            if g.shape[-3:] != (self.ny, self.nx, self.model.c_in):
-                raise ValueError(f"grid must be [{self.ny},{self.nx},{self.model.c_in}]")
-            rc = self.lib.psm_bind_geometry(self.h, g.ctypes.data_as(C.c_void_p), 0)
+            if g.ndim == 3:
+                g = g[None]
+            if g.ndim != 4 or g.shape[1:] != (self.ny, self.nx, self.model.c_in):
+                raise ValueError(f"grid must be [{self.ny},{self.nx},{self.model.c_in}] or [n,{self.ny},{self.nx},{self.model.c_in}]")
+            rc = self.lib.psm_bind_geometry_cases(self.h, g.ctypes.data_as(C.c_void_p), g.shape[0], 0)
         self._bound_mask = None
         if rc == -5:                    # PSM_ERR_UNSUPPORTED: configuration outside the fused path
             return False
@@ -176,7 +179,7 @@ class GridSurrogate:
         """Host-grid entries: a grid whose flow-cell pattern differs from the bound one drops the binding (the
         device-pointer entries rely on the contract of psm_bind_geometry instead)."""
         m = getattr(self, "_bound_mask", None)
-        if m is not None and g.shape[0] == 1 and not np.array_equal(g[0, ..., self.model.sdf_ch] != 0, m):
+        if m is not None and g.shape[0] == m.shape[0] and not np.array_equal(g[..., self.model.sdf_ch] != 0, m):
             self.unbind_geometry()
 
     @property

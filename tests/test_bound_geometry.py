@@ -166,3 +166,27 @@ def test_bound_path_on_random_shapes_and_obstacles():
         if ok.any():
             assert np.abs(bound[ok] - general[ok]).max() <= 5e-5 * max(1e-3, np.abs(general[ok]).max()), (variant, ny, nx, trial)
     assert n_bound >= 15
+
+
+@pytest.mark.parametrize("variant,n", [("deltas", 8), ("gradp", 3), ("chapter5", 5), ("deltas", 40)])
+def test_bound_case_batch_equals_general_path(variant, n):
+    """BASELINE config 3 shape: a batch of random-obstacle cases, one geometry per case slot (7 launches instead of 9)."""
+    model = synthetic.make_model(variant, p_in=32, p_out=32)
+    grids = synthetic.random_obstacle_cases(n, 256, 256, seed=3).astype(np.float32)
+    sc = list(np.linspace(0.5, 1.5, n).astype(np.float32))
+    with GridSurrogate(model, 256, 256, max_cases=n) as sur:
+        general = sur.solve(grids, out_scale=sc)
+        assert sur.bind_geometry(grids)
+        bound = sur.solve(grids, out_scale=sc)
+        for k in range(n):
+            same(bound[k], general[k])
+        # fewer cases than bound: the general path, still right
+        same(sur.solve(grids[:2], out_scale=sc[:2])[1], general[1])
+        # velocities change, geometries stay
+        g2 = grids.copy()
+        g2[..., :model.sdf_ch] *= 0.5
+        b2 = sur.solve(g2, out_scale=sc)
+        sur.unbind_geometry()
+        r2 = sur.solve(g2, out_scale=sc)
+        for k in range(n):
+            same(b2[k], r2[k])
