@@ -1453,21 +1453,22 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
   constexpr int LDA = LDR + 4, Q = LDR / 4, GD = LDR / 8, NA = MTC * 32 * Q / 256;
   constexpr int WPB = (128 / C) / 32;                  // ownership words per block for this workgroup's 128 columns
   constexpr int NST = 8;                               // staging rounds of 384 floats (C*nst + nst <= 3072)
+  constexpr int R = MTC * 32;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int B = p.B, nst = p.n_strips, S = p.cp.S;
-  float* lrs = lds + MTC * 32 * LDA;                   // [MTC*32] out_scale per block row
-  float* smean = lrs + MTC * 32;                       // [C][nst]
+  // per block row, one 32-byte record for the epilogue: {y0, x0, out_scale, -, ownership words (WPB <= 4)}
+  float* rec = lds + R * LDA;                          // [R][8]
+  float* smean = rec + R * 8;                          // [C][nst]
   float* scnt = smean + C * nst;                       // [nst]
   float* offs = scnt + nst;                            // [C][B]
   float* wred = offs + C * B;                          // [4] shift per field
-  uint32_t* own = reinterpret_cast<uint32_t*>(wred + 4);   // [B][WPB]
-  int* yx = reinterpret_cast<int*>(own + B * WPB);     // [B][2]
   const bool dec = wave < 4;                           // uniform per wave
   const int i = lane & 31, h = lane >> 5;
   const int ct = min((int)blockIdx.x * 4 + min(wave, 3), a.n_coltiles - 1);
   const bool live = dec && ((int)blockIdx.x * 4 + wave) < a.n_coltiles;
+  PSM_STAMP(0, 20);
   // ---- every load of the prologue, clamped and unconditional
   const int n_stage = C * nst + nst;
   float sv[NST];
@@ -1477,8 +1478,12 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
     const float* src = idx < C * nst ? p.dots + idx : p.scnt + (idx - C * nst);
     sv[u] = *src;
   }
-  const uint32_t ow = p.ownbits[(int64_t)(min(tid, B * WPB - 1) / WPB) * (S * S / 32) + (int)blockIdx.x * WPB + (min(tid, B * WPB - 1) % WPB)];
-  const int yxv = p.blk_y0x0[min(tid, 2 * B - 1)];
+  const int rb = min(tid, B - 1);                      // threads < B: the record of block row tid
+  uint32_t ow[WPB];
+#pragma unroll
+  for (int w = 0; w < WPB; ++w) ow[w] = p.ownbits[(int64_t)rb * (S * S / 32) + (int)blockIdx.x * WPB + w];
+  const int y0v = p.blk_y0x0[2 * rb], x0v = p.blk_y0x0[2 * rb + 1];
+  const float rs = a.row_scale[min(rb, a.Mpad - 1)];
   const int cf = min(max(wave - 4, 0), C - 1);         // chain waves: their field
   const float w_shift = p.shiftW[cf * B + min(lane, B - 1)];
   const float s_raw = p.dots[C * nst + cf * B + min(lane, B - 1)];
@@ -1488,7 +1493,6 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
     const int idx = min(tid, 255) + 256 * u, row = idx / Q, q = idx - row * Q;
     x[u] = *reinterpret_cast<const v4f*>(a.res + (int64_t)min(row, a.Mpad - 1) * LDR + 4 * q);
   }
-  const float rs = a.row_scale[min(min(tid, MTC * 32 - 1), a.Mpad - 1)];
   __builtin_amdgcn_sched_barrier(0);
   float4 b[GD];
   const float4* bp = a.bpack + ((int64_t)ct * GD) * 64 + lane;
@@ -1497,12 +1501,16 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
   const int col = ct * 32 + i;
   const float mu = a.mean[col];
   __builtin_amdgcn_sched_barrier(0);
-  // ---- LDS staging
+  // ---- LDS staging; the barrier drains LDS traffic only, so the basis loads above stay in flight behind it
 #pragma unroll
   for (int u = 0; u < NST; ++u)
     if (tid + 384 * u < n_stage) smean[tid + 384 * u] = sv[u];       // smean and scnt are contiguous
-  if (tid < B * WPB) own[tid] = ow;
-  if (tid < 2 * B) yx[tid] = yxv;
+  if (tid < B) {
+    float* rr = rec + tid * 8;
+    rr[0] = __int_as_float(y0v); rr[1] = __int_as_float(x0v); rr[2] = rs; rr[3] = 0.f;
+#pragma unroll
+    for (int w = 0; w < WPB; ++w) rr[4 + w] = __uint_as_float(ow[w]);
+  }
   if (tid < 256) {
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
@@ -1510,8 +1518,8 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
       *reinterpret_cast<v4f*>(&lds[row * LDA + 4 * q]) = x[u];
     }
   }
-  if (tid < MTC * 32) lrs[tid] = rs;
-  __syncthreads();
+  PSM_LDS_BARRIER();
+  PSM_STAMP(0, 21);
   f32x16 acc[MTC];
   if (dec) {
 #pragma unroll
@@ -1536,8 +1544,14 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
     const float t_shift = wave_sum(t);
     const float raw = wave_sum(lane < B ? s_raw : 0.f);
     if (lane == 0) wred[f] = raw / (float)p.shiftL[f] / 3.f - t_shift;
+    if (blockIdx.x == 0 && f == 0 && lane == 0) {
+#ifdef PSM_STAMPS
+      g_psm_stamps[39] = __builtin_amdgcn_s_memrealtime();
+#endif
+    }
   }
-  __syncthreads();
+  PSM_STAMP(0, 22);
+  PSM_LDS_BARRIER();
   if (blockIdx.x == 0) {       // introspection copies (psm_read_stage)
     for (int idx = tid; idx < C * B; idx += 384) p.offs[idx] = offs[idx];
     if (tid < C) p.shift[tid] = wred[tid];
@@ -1547,27 +1561,39 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
   const int pxl = px - (int)blockIdx.x * (128 / C);
   const int r = px / S, c = px - r * S;
   const float sh = wred[f];
+  // epilogue in two passes so that the LDS reads of all 16 rows are in flight together: records and offsets first
+  // (straight-line), then the owned values are stored
 #pragma unroll
   for (int mt = 0; mt < MTC; ++mt) {
+    v4f ra[16], rb4[16];
+    float of[16];
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) {
+      const int mc = min(mt * 32 + acc_row(rg, h), B - 1);
+      ra[rg] = *reinterpret_cast<const v4f*>(rec + mc * 8);
+      rb4[rg] = *reinterpret_cast<const v4f*>(rec + mc * 8 + 4);
+      of[rg] = offs[f * B + mc];
+    }
 #pragma unroll
     for (int rg = 0; rg < 16; ++rg) {
       const int m = mt * 32 + acc_row(rg, h);
-      const int mc = min(m, B - 1);
-      const bool mine = m < B && ((own[mc * WPB + (pxl >> 5)] >> (pxl & 31)) & 1u);
+      const uint32_t word = __float_as_uint(rb4[rg][pxl >> 5]);
+      const bool mine = m < B && ((word >> (pxl & 31)) & 1u);
       if (mine) {
-        const int y = yx[2 * mc] + r, xx = yx[2 * mc + 1] + c;
-        p.fields[((int64_t)y * p.Nx + xx) * C + f] = (acc[mt][rg] + mu) * lrs[m] - offs[f * B + mc] - sh;
+        const int y = __float_as_int(ra[rg][0]) + r, xx = __float_as_int(ra[rg][1]) + c;
+        p.fields[((int64_t)y * p.Nx + xx) * C + f] = (acc[mt][rg] + mu) * ra[rg][2] - of[rg] - sh;
       }
     }
   }
+  PSM_STAMP(0, 23);
 }
 
 hipError_t psm_launch_decode_paste(const PsmDecodeArgs& a, const PsmBoundArgs& p, int c_out, hipStream_t st) {
   if (a.ld_res > 128 || a.ld_res % 32 != 0 || a.Gd * 8 != a.ld_res || a.Mpad > 64 || a.Mpad % 32 != 0 || p.B > 64 || p.B < 1 || a.M != p.B) return hipErrorInvalidValue;
   if ((c_out != 1 && c_out != 2) || c_out * p.n_strips + p.n_strips > 8 * 384) return hipErrorInvalidValue;
   const int nwg = (a.n_coltiles + 3) / 4, mtc = a.Mpad / 32, wpb = (128 / c_out) / 32;
-  const size_t lds = ((size_t)mtc * 32 * (a.ld_res + 4) + (size_t)mtc * 32 + (size_t)c_out * p.n_strips + p.n_strips + (size_t)c_out * p.B + 4 +
-                      (size_t)p.B * wpb + 2 * (size_t)p.B) * sizeof(float);
+  (void)wpb;
+  const size_t lds = ((size_t)mtc * 32 * (a.ld_res + 4) + (size_t)mtc * 32 * 8 + (size_t)c_out * p.n_strips + p.n_strips + (size_t)c_out * p.B + 4) * sizeof(float);
 #define DP(M_, C_, L_) hipLaunchKernelGGL((psm_decode_paste_kernel<M_, C_, L_>), dim3(nwg), dim3(384), lds, st, a, p)
 #define DPL(L_)                                                        \
   do {                                                                 \
@@ -1734,7 +1760,8 @@ hipError_t psm_launch_decode_paste_batch(const PsmDecodeArgs& a, const PsmBoundB
   if (a.ld_res > 128 || a.ld_res % 32 != 0 || a.Gd * 8 != a.ld_res || a.Mpad % 32 != 0 || p.B > 64 || p.B < 1 || a.M != p.B * p.n_cases) return hipErrorInvalidValue;
   if (c_out != 1 && c_out != 2) return hipErrorInvalidValue;
   const int nwg = (a.n_coltiles + 3) / 4;
-  const int tiles = a.Mpad / 32, iters = (tiles + 3) / 4, mtc = (tiles + iters - 1) / iters, wpb = (128 / c_out) / 32, R = mtc * 32;
+  // at most 3 tiles of 32 rows per chunk: the 4-tile form of this kernel spills (acc + tile + row operands)
+  const int tiles = a.Mpad / 32, iters = (tiles + 2) / 3, mtc = (tiles + iters - 1) / iters, wpb = (128 / c_out) / 32, R = mtc * 32;
   const size_t lds = ((size_t)R * (a.ld_res + 4) + R + (size_t)R * c_out + (size_t)R * wpb + 2 * (size_t)R + 2 * (size_t)p.B) * sizeof(float);
   int groups = 1;
   while (nwg * groups < 256 && groups * 2 <= iters) groups *= 2;
@@ -1742,7 +1769,7 @@ hipError_t psm_launch_decode_paste_batch(const PsmDecodeArgs& a, const PsmBoundB
 #define DP(M_, C_, L_) hipLaunchKernelGGL((psm_decode_paste_batch_kernel<M_, C_, L_>), grid, dim3(256), lds, st, a, p, a.Mpad)
 #define DPM(C_, L_)                                                                 \
   do {                                                                              \
-    if (mtc == 4) DP(4, C_, L_); else if (mtc == 3) DP(3, C_, L_); else if (mtc == 2) DP(2, C_, L_); else DP(1, C_, L_); \
+    if (mtc == 3) DP(3, C_, L_); else if (mtc == 2) DP(2, C_, L_); else DP(1, C_, L_); \
   } while (0)
 #define DPL(L_) do { if (c_out == 1) DPM(1, L_); else DPM(2, L_); } while (0)
   if (a.ld_res == 32) DPL(32); else if (a.ld_res == 64) DPL(64); else if (a.ld_res == 96) DPL(96); else DPL(128);

@@ -15,10 +15,12 @@ for l in range(4):
     NAMES[44 + 4 * l] = f"dense{l} start"; NAMES[45 + 4 * l] = f"dense{l} mfma done"; NAMES[46 + 4 * l] = f"dense{l} end"
 variant = sys.argv[1] if len(sys.argv) > 1 else "gradp"
 NC = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+BIND = len(sys.argv) > 3 and sys.argv[3] == "bind"     # geometry-bound path: decode slots = decode+chain+paste, 39 = chain done
 model = synthetic.make_model(variant)
 grid = np.stack([synthetic.channel_grid(256, 256, seed=1 + k).astype(np.float32) for k in range(NC)])
 with psm_amd.GridSurrogate(model, 256, 256, max_cases=NC) as sur:
     d_in, d_out = DeviceArray(grid), DeviceArray(shape=(NC, 256, 256, model.c_out))
+    if BIND: assert sur.bind_geometry(d_in.ptr, on_device=True, n_cases=NC)
     acc = []
     for it in range(60):
         for k in range(20): sur.solve_device(d_in.ptr, NC, d_out.ptr, 0)
