@@ -1539,6 +1539,8 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
     }
   } else if (wave - 4 < C) {
     const int f = wave - 4;
+    // (the chain shares its SIMD with an MFMA wave and in effect runs after that wave's 2 us of MFMAs -- 3.7 us to the
+    // chain's end instead of 1.6 alone; s_setprio(3) here changes nothing: the vector ALU itself is taken)
     psm_chain_wave(p.cp, smean + f * nst, scnt, p.blocks, f, lane, offs + f * B);
     const float t = (lane < B && w_shift != 0.f) ? w_shift * offs[f * B + lane] : 0.f;   // same-wave LDS writes are visible
     const float t_shift = wave_sum(t);
