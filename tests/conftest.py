@@ -22,7 +22,7 @@ def pytest_sessionstart(session):
     lib = os.environ.get("PSM_LIB") or os.path.join(pkg, "libpsm_hip.so")
     hipcc = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(lib) and os.path.exists(hipcc):
-        subprocess.run(["make", "-C", os.path.join(pkg, "csrc")], check=True, env=dict(os.environ, HIPCC=hipcc),
+        subprocess.run(["make", "-j4", "-C", os.path.join(pkg, "csrc")], check=True, env=dict(os.environ, HIPCC=hipcc),
                        stdout=subprocess.DEVNULL)
 
 
