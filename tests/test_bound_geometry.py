@@ -107,6 +107,18 @@ def test_bind_lifecycle_and_unsupported_configurations():
         same(two[0], one); same(two[1], one)
         with pytest.raises(ValueError):
             sur.bind_geometry(g[:100])
+        # a new plan or a model change drops the binding (its tables belong to the old block layout / head layer)
+        assert sur.bind_geometry(g) and sur.geometry_bound
+        sur._chk(sur.lib.psm_plan_grid(sur.h, 256, 256))
+        assert not sur.geometry_bound
+        same(sur.solve(g)[0], one)
+        assert sur.bind_geometry(g)
+        W, b = model.weights[-1]
+        import ctypes as C
+        W2 = np.ascontiguousarray(W * 0.5, np.float32); b2 = np.ascontiguousarray(b, np.float32)
+        sur._chk(sur.lib.psm_set_dense(sur.h, len(model.weights) - 1, W2.shape[0], W2.shape[1],
+                                       W2.ctypes.data_as(C.POINTER(C.c_float)), b2.ctypes.data_as(C.POINTER(C.c_float))))
+        assert not sur.geometry_bound
     big = synthetic.make_model("deltas", p_in=16, p_out=16)
     gb = synthetic.channel_grid(128, 128 + 96 * 70, seed=5).astype(np.float32)      # > 64 block columns
     with GridSurrogate(big, gb.shape[0], gb.shape[1]) as sur:

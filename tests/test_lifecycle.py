@@ -79,5 +79,9 @@ def test_calls_in_the_wrong_order_are_reported():
         t = C.c_int64()
         assert lib.psm_submit_grid(h, g.ctypes.data_as(C.POINTER(C.c_float)), 1, None, C.byref(t)) == -2
         assert lib.psm_wait_grid(h, 0, out.ctypes.data_as(C.POINTER(C.c_float))) == -1
+        assert lib.psm_bind_geometry(h, g.ctypes.data_as(C.c_void_p), 0) == -2          # no plan yet
+        assert lib.psm_bind_geometry_cases(h, g.ctypes.data_as(C.c_void_p), 1, 0) == -2
+        assert lib.psm_geometry_bound(h) == 0 and lib.psm_unbind_geometry(h) == 0
+        assert lib.psm_bind_geometry(None, g.ctypes.data_as(C.c_void_p), 0) == -1
     finally:
         lib.psm_destroy(h)
