@@ -202,3 +202,46 @@ def test_bound_case_batch_equals_general_path(variant, n):
         r2 = sur.solve(g2, out_scale=sc)
         for k in range(n):
             same(b2[k], r2[k])
+
+
+def test_bound_device_api_graph_profile_and_timing_agree(monkeypatch):
+    """Stream launches, hipGraph replay (PSM_GRAPH=1), the event-profiled pass and the encode-timing pass all run the
+    bound sequence and give bit-identical fields; re-binding another geometry replaces the captured graph."""
+    from hipmem import DeviceArray
+    model = synthetic.make_model("gradp", p_in=64, p_out=64)
+    grid = synthetic.channel_grid(256, 256, seed=1).astype(np.float32)
+    other = synthetic.channel_grid(256, 256, seed=2, cx=0.6).astype(np.float32)
+    with GridSurrogate(model, 256, 256) as sur:
+        assert sur.bind_geometry(grid)
+        host = sur.solve(grid)[0]
+        d_in, d_out = DeviceArray(grid), DeviceArray(shape=(256, 256, 2), dtype=np.float32)
+        for _ in range(3):
+            sur.solve_device(d_in.ptr, 1, d_out.ptr, 0)
+        sur.synchronize()
+        np.testing.assert_array_equal(d_out.numpy(), host)
+        ms = sur.profile(d_in.ptr, 1, d_out.ptr)
+        np.testing.assert_array_equal(d_out.numpy(), host)
+        assert ms["encode"] > 0 and ms["decode"] > 0
+        sur.enable_kernel_timing("encode")
+        sur.solve_device(d_in.ptr, 1, d_out.ptr, 0)
+        total, n = sur.kernel_timing("encode")
+        sur.enable_kernel_timing("encode", False)
+        assert n == 1 and total > 0
+        np.testing.assert_array_equal(d_out.numpy(), host)
+        sur.unbind_geometry()
+        general_other = sur.solve(other)[0]
+    monkeypatch.setenv("PSM_GRAPH", "1")
+    with GridSurrogate(model, 256, 256) as sur:
+        assert sur.bind_geometry(grid)
+        for _ in range(3):
+            sur.solve_device(d_in.ptr, 1, d_out.ptr, 0)
+        sur.synchronize()
+        np.testing.assert_array_equal(d_out.numpy(), host)
+        d_in2 = DeviceArray(other)
+        assert sur.bind_geometry(other)                 # new tables: the captured graph must not be replayed
+        for _ in range(2):
+            sur.solve_device(d_in2.ptr, 1, d_out.ptr, 0)
+        sur.synchronize()
+        same(d_out.numpy(), general_other)
+        d_in2.free()
+    d_in.free(); d_out.free()
