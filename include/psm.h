@@ -133,8 +133,10 @@ int psm_num_blocks(const psm_handle* h);
  * value - offset - shift straight into the field (the decoded blocks are never stored; psm_read_stage(PSM_STAGE_PRED)
  * is stale while bound).  Same results as the unbound path up to float32 summation order.
  * CONTRACT: until psm_unbind_geometry / a new bind / a model or plan change, the SDF channel of every solved grid
- * must have the flow-cell pattern of the bound one; the other channels are free.  bf16 handles and case counts
- * other than the bound one keep the general path.  Returns PSM_ERR_UNSUPPORTED (nothing bound, solves unaffected) for
+ * must have the flow-cell pattern of the bound one; the other channels are free.  Case counts other than the bound
+ * one keep the general path.  bf16 handles bind single cases: the decode rounds the network output to bf16, so their
+ * strip dots are taken from the rounded output in a small launch of their own (7 launches; same rounding points as
+ * the general bf16 path).  Returns PSM_ERR_UNSUPPORTED (nothing bound, solves unaffected) for
  * configurations outside the fused path: > 64 blocks or >= 64 block columns, > 128 output components, no hidden
  * layer, last hidden layer wider than 1024. */
 int psm_bind_geometry(psm_handle* h, const float* grid, int32_t on_device);

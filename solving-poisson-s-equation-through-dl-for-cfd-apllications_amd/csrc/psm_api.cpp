@@ -314,7 +314,7 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
   Timer tm{h, st, 0, prof};
   const bool bf16 = (h->cfg.precision == PSM_PRECISION_BF16);
   // geometry-bound fast path: one case, nothing but the encode group being timed / skipped
-  const bool use_bound = h->bound && (h->bound_scope == 2 || h->in_mesh_solve) && n_cases == h->bound_cases && !bf16 && (h->timed_kernel < 0 || h->timed_kernel == PSM_K_ENCODE) && h->debug_skip == 0;
+  const bool use_bound = h->bound && (h->bound_scope == 2 || h->in_mesh_solve) && n_cases == h->bound_cases && (!bf16 || n_cases == 1) && (h->timed_kernel < 0 || h->timed_kernel == PSM_K_ENCODE) && h->debug_skip == 0;
   PsmEncodeArgs ea{};
   ea.grid = d_grid; ea.mean = h->d_mean_in; ea.bpack = h->d_bpack_in; ea.part = h->d_part;
   ea.row_base = h->d_row_base; ea.row_stride = (int64_t)h->Nx * h->cfg.c_in;
@@ -375,7 +375,7 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
     }
     for (int l = l_first; l < nl; ++l) {
       PsmDenseArgs da = dense_args(l, cur, ld_cur);
-      if (use_bound && l == nl - 1) {          // head layer + strip dots of the bound geometry in one launch
+      if (use_bound && !bf16 && l == nl - 1) { // head layer + strip dots of the bound geometry in one launch
         PsmDotsArgs dd{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, h->d_dots, h->bound_rows * n_cases, h->dense[nl - 1].Kpad};
         HIPCHK(h, psm_launch_dense_dots(da, dd, st));
       } else {
@@ -399,7 +399,11 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
       HIPCHK(h, hipMemsetAsync(d_fields, 0, (size_t)n_cases * h->Ny * h->Nx * h->cfg.c_out * sizeof(float), st));
     if (n_cases == 1) {
       tm.before(PSM_K_DECODE);
-      PSM_REPEAT(h, PSM_K_DECODE) HIPCHK(h, psm_launch_decode_paste(de, ba, h->cfg.c_out, st));
+      if (bf16) {                               // strip dots from the bf16-rounded res (own small launch)
+        PsmDotsArgs dd{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, h->d_dots, h->bound_rows, h->ld_out};
+        HIPCHK(h, psm_launch_res_dots(dd, h->d_res, h->ld_out, st));
+      }
+      PSM_REPEAT(h, PSM_K_DECODE) HIPCHK(h, psm_launch_decode_paste(de, ba, h->cfg.c_out, st, bf16 ? 1 : 0));
       tm.after(PSM_K_DECODE);
       tm.before(PSM_K_STRIPS); tm.after(PSM_K_STRIPS);
       tm.before(PSM_K_CHAIN); tm.after(PSM_K_CHAIN);
@@ -618,6 +622,16 @@ int psm_set_pca(psm_handle* h, const double* comp_in, const double* mean_in, con
     dev_free(h->d_bpack_in); dev_free(h->d_bpack_out);
     h->d_bpack_in = reinterpret_cast<float4*>(di);
     h->d_bpack_out = reinterpret_cast<float4*>(dox);
+    {                                                    // natural-layout copy of the ROUNDED basis (psm_bind_geometry)
+      std::vector<float> nat((size_t)h->ld_out * h->K_out, 0.f);
+      for (int p = 0; p < h->cfg.p_out; ++p)
+        for (int k = 0; k < h->K_out; ++k) {
+          const uint32_t u = (uint32_t)f2bf(comp_out[(int64_t)p * h->K_out + k]) << 16;
+          float v; memcpy(&v, &u, 4);
+          nat[(size_t)p * h->K_out + k] = v;
+        }
+      if ((rc = dev_upload(h, &h->d_comp_nat, nat))) return rc;
+    }
   } else {
   if ((rc = dev_upload(h, &h->d_bpack_in, pack_comp_in(comp_in, h->cfg.p_in, h->K_in, h->cfg.c_in, h->S, h->NT)))) return rc;
   if ((rc = dev_upload(h, &h->d_bpack_out, pack_comp_out(comp_out, h->cfg.p_out, h->K_out, h->Gd)))) return rc;
@@ -824,10 +838,12 @@ int psm_plan_grid(psm_handle* h, int32_t ny, int32_t nx) {
 static int bind_geometry_device(psm_handle* h, const float* d_grid, int n_cases = 1) {
   const int nl = (int)h->dense.size();
   h->bound = false;
-  if (h->cfg.precision != PSM_PRECISION_F32) return fail(h, PSM_ERR_UNSUPPORTED, "geometry binding: float32 precision only");
-  if (!h->fused_assemble || h->ld_out > 128 || h->Gd * 8 != h->ld_out || nl < 2 || !h->d_comp_nat)
+  const bool bf16 = h->cfg.precision == PSM_PRECISION_BF16;
+  if (bf16 && n_cases > 1) return fail(h, PSM_ERR_UNSUPPORTED, "geometry binding: bf16 handles bind single cases only");
+  if (!h->fused_assemble || h->ld_out > 128 || nl < 2 || !h->d_comp_nat)
     return fail(h, PSM_ERR_UNSUPPORTED, "geometry binding needs <= 64 blocks in < 64 columns, <= 128 output components and a hidden layer");
-  const int Kh = h->dense[nl - 1].Kpad, C = h->cfg.c_out;
+  // bf16: the decode rounds `res`, so the head layer cannot be folded into the tables: rows over the ld_out components
+  const int Kh = bf16 ? h->ld_out : h->dense[nl - 1].Kpad, C = h->cfg.c_out;
   if (Kh % 4 != 0 || Kh > 1024 || C * h->n_strips + h->n_strips > 2560)
     return fail(h, PSM_ERR_UNSUPPORTED, "geometry binding: last hidden layer wider than 1024 or too many strips");
   if (n_cases > 1 && round_up(n_cases * h->B, 32) > 128 * 64) return fail(h, PSM_ERR_UNSUPPORTED, "geometry binding: too many block rows");
@@ -855,7 +871,7 @@ static int bind_geometry_device(psm_handle* h, const float* d_grid, int n_cases 
     a.row_of = h->d_row_of + (size_t)cs * rows; a.ownbits = h->d_ownbits + (size_t)cs * h->B * (h->S * h->S / 32);
     a.nst = h->n_strips; a.B = h->B; a.S = h->S; a.c_in = h->cfg.c_in; a.c_out = C; a.sdf_ch = h->cfg.sdf_channel;
     a.Ny = h->Ny; a.Nx = h->Nx; a.ld_out = h->ld_out; a.row_base = cs * h->B;
-    e = psm_launch_bind(a, h->stream);            // same stream: the scratch is reused case after case
+    e = bf16 ? psm_launch_bind_unfolded(a, h->stream) : psm_launch_bind(a, h->stream);   // same stream: the scratch is reused case after case
   }
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   dev_free(d_G); dev_free(d_M);
@@ -1073,7 +1089,7 @@ int psm_set_geometry(psm_handle* h, int64_t n_cells, int32_t ny, int32_t nx, con
   h->have_geometry = true;
   // The mesh entry builds its grid from THIS sdfunct at every step, so the geometry of psm_solve is fixed from here
   // on: bind it (scope: psm_solve only -- grid-native solves on the same handle stay general until psm_bind_geometry).
-  if (h->cfg.precision == PSM_PRECISION_F32 && h->cfg.c_in == 3 && h->cfg.sdf_channel == 2 && g2m && getenv("PSM_NO_BIND") == nullptr) {
+  if (h->cfg.c_in == 3 && h->cfg.sdf_channel == 2 && g2m && getenv("PSM_NO_BIND") == nullptr) {
     std::vector<float> g((size_t)ng * 3, 0.f);
     const double sc = normalise_sdf ? 1.0 / maxs[2] : 1.0;
     for (int64_t t = 0; t < ng; ++t) {

@@ -129,7 +129,10 @@ hipError_t psm_launch_decode_paste_batch(const PsmDecodeArgs& a, const PsmBoundB
 // head layer + strip dots in one launch (f32, 16-row tiles)
 hipError_t psm_launch_dense_dots(const PsmDenseArgs& a, const PsmDotsArgs& d, hipStream_t s);
 // decode + offset chain + paste in one launch: ld_res <= 128, Mpad <= 64 (one case, B <= 64, n_x < 64)
-hipError_t psm_launch_decode_paste(const PsmDecodeArgs& a, const PsmBoundArgs& p, int c_out, hipStream_t s);
+hipError_t psm_launch_decode_paste(const PsmDecodeArgs& a, const PsmBoundArgs& p, int c_out, hipStream_t s, int bf16 = 0);
+// bf16 handles: tables without the head layer folded in (Kh = ld_out), dots from the bf16-rounded `res`
+hipError_t psm_launch_bind_unfolded(const PsmBindArgs& a, hipStream_t s);
+hipError_t psm_launch_res_dots(const PsmDotsArgs& d, const float* res, int ld_res, hipStream_t s);
 
 hipError_t psm_read_stamps(unsigned long long* out);   // [64]; zeros unless built with -DPSM_STAMPS
 // ev_start / ev_stop (optional): stamped with the dispatch's own begin / end (hipExtLaunchKernel)

@@ -1448,9 +1448,14 @@ hipError_t psm_launch_bind(const PsmBindArgs& a, hipStream_t st) {
 // (shift_f = sum_b dots_shift[f][b] / (3 L_f) - sum_b w_b offs_b).  Both run while the other's loads are in flight;
 // the epilogue writes value - offset - shift for the block pixels that own their cell (ownership bits) straight
 // into the field -- the decoded blocks are never stored.
-template <int MTC, int C, int LDR>      // LDR = ld_res: output components padded to 32, 64, 96 or 128
+typedef __bf16 pk_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 pk_bf16x4 __attribute__((ext_vector_type(4)));
+// BF (bf16 handles): the tile is rounded to bf16 on its way into LDS and multiplied with the bf16 basis by
+// v_mfma_f32_32x32x16_bf16, exactly like psm_decode_bf16_kernel (psm_bf16.hip) -- same rounding points.
+template <int MTC, int C, int LDR, bool BF>      // LDR = ld_res: output components padded to 32, 64, 96 or 128
 __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, PsmBoundArgs p) {
-  constexpr int LDA = LDR + 4, Q = LDR / 4, GD = LDR / 8, NA = MTC * 32 * Q / 256;
+  constexpr int LDA = BF ? (LDR + 8) / 2 : LDR + 4;    // tile row stride in floats (bf16: LDR + 8 halves)
+  constexpr int Q = LDR / 4, GD = BF ? LDR / 16 : LDR / 8, NA = MTC * 32 * Q / 256;
   constexpr int WPB = (128 / C) / 32;                  // ownership words per block for this workgroup's 128 columns
   constexpr int NST = 8;                               // staging rounds of 384 floats (C*nst + nst <= 3072)
   constexpr int R = MTC * 32;
@@ -1494,7 +1499,7 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
     x[u] = *reinterpret_cast<const v4f*>(a.res + (int64_t)min(row, a.Mpad - 1) * LDR + 4 * q);
   }
   __builtin_amdgcn_sched_barrier(0);
-  float4 b[GD];
+  float4 b[GD];                                        // bf16: 8 halves per 16-byte piece
   const float4* bp = a.bpack + ((int64_t)ct * GD) * 64 + lane;
 #pragma unroll
   for (int g = 0; g < GD; ++g) b[g] = stream_load(bp + g * 64);
@@ -1515,7 +1520,13 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
       const int idx = tid + 256 * u, row = idx / Q, q = idx - row * Q;
-      *reinterpret_cast<v4f*>(&lds[row * LDA + 4 * q]) = x[u];
+      if constexpr (BF) {
+        pk_bf16x4 v;
+        v[0] = (__bf16)x[u][0]; v[1] = (__bf16)x[u][1]; v[2] = (__bf16)x[u][2]; v[3] = (__bf16)x[u][3];
+        *reinterpret_cast<pk_bf16x4*>(reinterpret_cast<__bf16*>(&lds[row * LDA]) + 4 * q) = v;
+      } else {
+        *reinterpret_cast<v4f*>(&lds[row * LDA + 4 * q]) = x[u];
+      }
     }
   }
   PSM_LDS_BARRIER();
@@ -1525,16 +1536,25 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
 #pragma unroll
     for (int mt = 0; mt < MTC; ++mt) {
       acc[mt] = (f32x16){0};
-      const float* arow = &lds[(mt * 32 + i) * LDA + 4 * h];
-      float4 av = *reinterpret_cast<const float4*>(arow);
+      if constexpr (BF) {
+        const __bf16* arow = reinterpret_cast<const __bf16*>(&lds[(mt * 32 + i) * LDA]) + 8 * h;
 #pragma unroll
-      for (int g = 0; g < GD; ++g) {
-        const float4 an = *reinterpret_cast<const float4*>(arow + 8 * (g + 1 < GD ? g + 1 : g));
-        acc[mt] = MFMA32(av.x, b[g].x, acc[mt]);
-        acc[mt] = MFMA32(av.y, b[g].y, acc[mt]);
-        acc[mt] = MFMA32(av.z, b[g].z, acc[mt]);
-        acc[mt] = MFMA32(av.w, b[g].w, acc[mt]);
-        av = an;
+        for (int g = 0; g < GD; ++g) {
+          const pk_bf16x8 av = *reinterpret_cast<const pk_bf16x8*>(arow + 16 * g);
+          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(pk_bf16x8, b[g]), acc[mt], 0, 0, 0);
+        }
+      } else {
+        const float* arow = &lds[(mt * 32 + i) * LDA + 4 * h];
+        float4 av = *reinterpret_cast<const float4*>(arow);
+#pragma unroll
+        for (int g = 0; g < GD; ++g) {
+          const float4 an = *reinterpret_cast<const float4*>(arow + 8 * (g + 1 < GD ? g + 1 : g));
+          acc[mt] = MFMA32(av.x, b[g].x, acc[mt]);
+          acc[mt] = MFMA32(av.y, b[g].y, acc[mt]);
+          acc[mt] = MFMA32(av.z, b[g].z, acc[mt]);
+          acc[mt] = MFMA32(av.w, b[g].w, acc[mt]);
+          av = an;
+        }
       }
     }
   } else if (wave - 4 < C) {
@@ -1590,13 +1610,17 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
   PSM_STAMP(0, 23);
 }
 
-hipError_t psm_launch_decode_paste(const PsmDecodeArgs& a, const PsmBoundArgs& p, int c_out, hipStream_t st) {
-  if (a.ld_res > 128 || a.ld_res % 32 != 0 || a.Gd * 8 != a.ld_res || a.Mpad > 64 || a.Mpad % 32 != 0 || p.B > 64 || p.B < 1 || a.M != p.B) return hipErrorInvalidValue;
+hipError_t psm_launch_decode_paste(const PsmDecodeArgs& a, const PsmBoundArgs& p, int c_out, hipStream_t st, int bf16) {
+  if (a.ld_res > 128 || a.ld_res % 32 != 0 || a.Mpad > 64 || a.Mpad % 32 != 0 || p.B > 64 || p.B < 1 || a.M != p.B) return hipErrorInvalidValue;
   if ((c_out != 1 && c_out != 2) || c_out * p.n_strips + p.n_strips > 8 * 384) return hipErrorInvalidValue;
   const int nwg = (a.n_coltiles + 3) / 4, mtc = a.Mpad / 32, wpb = (128 / c_out) / 32;
   (void)wpb;
   const size_t lds = ((size_t)mtc * 32 * (a.ld_res + 4) + (size_t)mtc * 32 * 8 + (size_t)c_out * p.n_strips + p.n_strips + (size_t)c_out * p.B + 4) * sizeof(float);
-#define DP(M_, C_, L_) hipLaunchKernelGGL((psm_decode_paste_kernel<M_, C_, L_>), dim3(nwg), dim3(384), lds, st, a, p)
+#define DP(M_, C_, L_)                                                                                              \
+  do {                                                                                                              \
+    if (bf16) hipLaunchKernelGGL((psm_decode_paste_kernel<M_, C_, L_, true>), dim3(nwg), dim3(384), lds, st, a, p);    \
+    else hipLaunchKernelGGL((psm_decode_paste_kernel<M_, C_, L_, false>), dim3(nwg), dim3(384), lds, st, a, p);        \
+  } while (0)
 #define DPL(L_)                                                        \
   do {                                                                 \
     if (mtc == 1) { if (c_out == 1) DP(1, 1, L_); else DP(1, 2, L_); } \
@@ -1778,5 +1802,45 @@ hipError_t psm_launch_decode_paste_batch(const PsmDecodeArgs& a, const PsmBoundB
 #undef DPL
 #undef DPM
 #undef DP
+  return hipGetLastError();
+}
+
+// ---- bf16 handles on a bound geometry: the decode rounds `res` to bf16, which is not linear, so the strip dots
+// cannot be folded through the head layer; they are taken from the rounded `res` itself in a small launch of their
+// own (one wave per table row):  out[row] = scale * (bf16(res[b]) . G[row] + M[row]) / cnt[row]
+__global__ __launch_bounds__(256) void psm_res_dots_kernel(PsmDotsArgs d, const float* res, int ld_res) {
+  const int lane = threadIdx.x & 63, row = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int rc = min(row, d.n_rows - 1);
+  const int blk = d.row_of[rc];
+  float acc = 0.f;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {                        // ld_res <= 128
+    const int k = min(lane + 64 * u, ld_res - 1);
+    const float x = (float)(__bf16)res[(int64_t)blk * ld_res + k];
+    const float g = d.g2[(int64_t)rc * ld_res + k];
+    acc += (lane + 64 * u < ld_res) ? x * g : 0.f;
+  }
+  const float tot = wave_sum(acc);
+  if (lane == 0 && row < d.n_rows) d.out[row] = d.row_scale[blk] * (tot + d.c2[rc]) / d.cnt[rc];
+}
+
+hipError_t psm_launch_res_dots(const PsmDotsArgs& d, const float* res, int ld_res, hipStream_t st) {
+  if (ld_res > 128 || ld_res < 1 || d.n_rows < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(psm_res_dots_kernel, dim3((d.n_rows + 3) / 4), dim3(256), 0, st, d, res, ld_res);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void psm_bind_copy_kernel(PsmBindArgs a) {   // un-folded tables: g2 = G, c2 = M
+  const int row = blockIdx.x;
+  for (int k = threadIdx.x; k < a.ld_out; k += 256) a.g2[(int64_t)row * a.ld_out + k] = (float)a.G[(int64_t)row * a.ld_out + k];
+  if (threadIdx.x == 0) a.c2[row] = (float)a.Mrow[row];
+}
+
+hipError_t psm_launch_bind_unfolded(const PsmBindArgs& a, hipStream_t st) {
+  if (a.ld_out > 512 || a.ld_out < 1 || (a.S * a.S) % 32 != 0) return hipErrorInvalidValue;
+  const int rows = a.c_out * a.nst + a.c_out * a.B;
+  hipLaunchKernelGGL(psm_bind_rows_kernel, dim3(rows), dim3(128), 0, st, a);
+  hipLaunchKernelGGL(psm_bind_copy_kernel, dim3(rows), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(psm_bind_own_kernel, dim3((a.B * (a.S * a.S / 32) + 255) / 256), dim3(256), 0, st, a);
   return hipGetLastError();
 }

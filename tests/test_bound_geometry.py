@@ -124,8 +124,9 @@ def test_bind_lifecycle_and_unsupported_configurations():
     with GridSurrogate(big, gb.shape[0], gb.shape[1]) as sur:
         assert sur.bind_geometry(gb) is False and not sur.geometry_bound
         assert np.isfinite(sur.solve(gb)[0]).all()
-    with GridSurrogate(model, 256, 256, precision="bf16") as sur:
-        assert sur.bind_geometry(g) is False
+    with GridSurrogate(model, 256, 256, precision="bf16", max_cases=2) as sur:
+        assert sur.bind_geometry(np.stack([g, g])) is False          # bf16 handles bind single cases only
+        assert sur.bind_geometry(g) is True
     wide = synthetic.make_model("gradp", p_in=16, p_out=130)                         # > 128 output components
     with GridSurrogate(wide, 256, 256) as sur:
         assert sur.bind_geometry(g) is False
@@ -245,3 +246,24 @@ def test_bound_device_api_graph_profile_and_timing_agree(monkeypatch):
         same(d_out.numpy(), general_other)
         d_in2.free()
     d_in.free(); d_out.free()
+
+
+@pytest.mark.parametrize("variant,ny,nx", [("deltas", 512, 512), ("gradp", 256, 256), ("chapter5", 300, 400)])
+def test_bf16_bound_equals_bf16_general_path(variant, ny, nx):
+    """BASELINE config 4 precision on a bound geometry (7 launches: the strip dots come from the bf16-rounded res in a
+    launch of their own, so the rounding points are those of the bf16 decode): same fields as the general bf16 path
+    up to float32 summation order, and within the bf16 tolerance of the float64 oracle."""
+    model = synthetic.make_model(variant, p_in=48, p_out=40)
+    grid = synthetic.channel_grid(ny, nx, seed=4, noise=0.05).astype(np.float32)
+    with GridSurrogate(model, ny, nx, precision="bf16") as sur:
+        general = sur.solve(grid)[0]
+        assert sur.bind_geometry(grid)
+        bound = sur.solve(grid)[0]
+        g2 = grid.copy(); g2[..., :model.sdf_ch] *= 0.8
+        b2 = sur.solve(g2)[0]
+        sur.unbind_geometry()
+        r2 = sur.solve(g2)[0]
+    same(bound, general, tol=5e-5)
+    same(b2, r2, tol=5e-5)
+    sol = orc.solve_grid(grid.astype(np.float64), oracle_model(model))
+    assert rel_l2(bound, sol.fields) <= 2e-2
