@@ -122,6 +122,22 @@ struct psm_handle {
 
 namespace {
 
+// The synchronous entries last ~100 us: they poll the stream / event instead of sleeping in hip*Synchronize (the
+// wake-up of a blocked thread alone costs 10-20 us per call); PSM_SYNC_BLOCK=1 restores the blocking waits.
+bool sync_blocks() { static const bool b = getenv("PSM_SYNC_BLOCK") != nullptr; return b; }
+hipError_t wait_stream(hipStream_t st) {
+  if (sync_blocks()) return hipStreamSynchronize(st);
+  hipError_t e;
+  while ((e = hipStreamQuery(st)) == hipErrorNotReady) { }
+  return e;
+}
+hipError_t wait_event(hipEvent_t ev) {
+  if (sync_blocks()) return hipEventSynchronize(ev);
+  hipError_t e;
+  while ((e = hipEventQuery(ev)) == hipErrorNotReady) { }
+  return e;
+}
+
 int fail(psm_handle* h, int code, const std::string& msg) {
   if (h) h->err = msg; else g_create_error = msg;
   return code;
@@ -932,7 +948,7 @@ int psm_solve_grid(psm_handle* h, const float* grid, int32_t n_cases, const floa
   int rc = solve_device(h, h->d_grid_stage, n_cases, out_scale, h->d_fields_stage, h->stream, nullptr);
   if (rc) return rc;
   HIPCHK(h, hipMemcpyAsync(h->h_fields, h->d_fields_stage, gout, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, wait_stream(h->stream));
   memcpy(fields, h->h_fields, gout);
   return PSM_OK;
 }
@@ -995,7 +1011,7 @@ int psm_wait_grid(psm_handle* h, int64_t ticket, float* fields) {
   psm_handle::Slot& s = h->slot[ticket % psm_handle::SLOTS];
   if (!s.h_in || s.ticket != ticket) return fail(h, PSM_ERR_ARG, "unknown ticket (never submitted or already waited for)");
   HIPCHK(h, hipSetDevice(h->cfg.device));
-  HIPCHK(h, hipEventSynchronize(s.ev_out));
+  HIPCHK(h, wait_event(s.ev_out));
   memcpy(fields, s.h_out, (size_t)s.n_cases * h->Ny * h->Nx * h->cfg.c_out * sizeof(float));
   s.ticket = -1;
   return PSM_OK;
@@ -1139,11 +1155,11 @@ int psm_solve(psm_handle* h, const double* cells, int64_t n, int32_t rank, doubl
   HIPCHK(h, psm_launch_to_mesh(ma, st));
   if (p_out == h->pinned_p) {
     HIPCHK(h, hipMemcpyAsync(p_out, h->d_p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipStreamSynchronize(st));
+    HIPCHK(h, wait_stream(st));
     return PSM_OK;
   }
   HIPCHK(h, hipMemcpyAsync(h->h_p, h->d_p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipStreamSynchronize(st));
+  HIPCHK(h, wait_stream(st));
   memcpy(p_out, h->h_p, (size_t)n * sizeof(double));
   return PSM_OK;
 }
