@@ -75,6 +75,7 @@ struct psm_handle {
   double *h_cells = nullptr, *h_p = nullptr;
   const double* pinned_cells = nullptr;   // caller buffers registered with psm_pin_buffers (DMA without staging copies)
   double* pinned_p = nullptr;
+  double* pinned_p_dev = nullptr;       // device-side address of the registered output (the last kernel writes p straight into it)
   double maxs[4] = {1, 1, 1, 1};
   int normalise_sdf = 0, fill_input = 0;
   float *d_grid_stage = nullptr, *d_fields_stage = nullptr;
@@ -237,7 +238,7 @@ std::vector<float4> pack_comp_out(const double* comp, int P, int K_out, int Gd) 
 
 void unpin_buffers(psm_handle* h) {
   if (h->pinned_cells) { (void)hipHostUnregister((void*)h->pinned_cells); h->pinned_cells = nullptr; }
-  if (h->pinned_p) { (void)hipHostUnregister((void*)h->pinned_p); h->pinned_p = nullptr; }
+  if (h->pinned_p) { (void)hipHostUnregister((void*)h->pinned_p); h->pinned_p = nullptr; h->pinned_p_dev = nullptr; }
 }
 
 void free_geometry(psm_handle* h) {
@@ -1152,9 +1153,11 @@ int psm_solve(psm_handle* h, const double* cells, int64_t n, int32_t rank, doubl
   ma.cells = h->d_cells; ma.umax = h->d_umax; ma.vtx = h->d_vtx_g2m; ma.wts = h->d_wts_g2m; ma.cell_of_point = h->d_cell_of_point;
   ma.field = h->d_fields_stage; ma.near_wall = h->d_near_wall; ma.p_out = h->d_p; ma.n_cells = n; ma.max_abs_p = h->maxs[3];
   ma.c_out = h->cfg.c_out;
+  const bool direct = p_out == h->pinned_p && h->pinned_p_dev != nullptr;
+  if (direct) ma.p_out = h->pinned_p_dev;                 // 8 bytes per cell over PCIe from the kernel itself: no D2H copy
   HIPCHK(h, psm_launch_to_mesh(ma, st));
   if (p_out == h->pinned_p) {
-    HIPCHK(h, hipMemcpyAsync(p_out, h->d_p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (!direct) HIPCHK(h, hipMemcpyAsync(p_out, h->d_p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(h, wait_stream(st));
     return PSM_OK;
   }
@@ -1179,6 +1182,9 @@ int psm_pin_buffers(psm_handle* h, const double* cells, double* p_out) {
     hipError_t e = hipHostRegister((void*)p_out, (size_t)h->n_cells * sizeof(double), hipHostRegisterDefault);
     if (e != hipSuccess) { (void)hipGetLastError(); unpin_buffers(h); return fail(h, PSM_ERR_HIP, std::string("hipHostRegister(p_out): ") + hipGetErrorString(e)); }
     h->pinned_p = p_out;
+    void* dp = nullptr;                                   // mapped address: lets psm_to_mesh_kernel store p into the host array
+    if (hipHostGetDevicePointer(&dp, (void*)p_out, 0) == hipSuccess && getenv("PSM_NO_DIRECT_OUT") == nullptr) h->pinned_p_dev = (double*)dp;
+    else (void)hipGetLastError();
   }
   return PSM_OK;
 }
