@@ -1138,9 +1138,25 @@ int psm_solve(psm_handle* h, const double* cells, int64_t n, int32_t rank, doubl
     memcpy(h->h_cells, cells, (size_t)n * 5 * sizeof(double));
     HIPCHK(h, hipMemcpyAsync(h->d_cells, h->h_cells, (size_t)n * 5 * sizeof(double), hipMemcpyHostToDevice, st));
   }
-  HIPCHK(h, psm_launch_umax(h->d_cells, n, h->d_umax, st));
+  // U_max = max sqrt(Ux^2 + Uy^2) (PM:270) on the host while the copy above is in flight: sqrt is monotonic and
+  // correctly rounded on both sides, so sqrt(max(Ux^2 + Uy^2)) is the kernel's value bit for bit (NaN propagates
+  // like np.max); one launch less.  PSM_DEVICE_UMAX=1 keeps the device reduction.
+  static const bool dev_umax = getenv("PSM_DEVICE_UMAX") != nullptr;
+  double umax_val = 0.0;
+  if (dev_umax) {
+    HIPCHK(h, psm_launch_umax(h->d_cells, n, h->d_umax, st));
+  } else {
+    double m2 = 0.0; bool nan = false;
+    for (int64_t i = 0; i < n; ++i) {
+      const double ux = cells[i * 5], uy = cells[i * 5 + 1];
+      const double v = ux * ux + uy * uy;
+      nan = nan || (v != v);
+      m2 = v > m2 ? v : m2;
+    }
+    umax_val = nan ? std::nan("") : std::sqrt(m2);
+  }
   PsmToGridArgs ga{};
-  ga.cells = h->d_cells; ga.umax = h->d_umax; ga.vtx = h->d_vtx_m2g; ga.wts = h->d_wts_m2g; ga.src_of_cell = h->d_src_of_cell;
+  ga.cells = h->d_cells; ga.umax = dev_umax ? h->d_umax : nullptr; ga.umax_val = umax_val; ga.vtx = h->d_vtx_m2g; ga.wts = h->d_wts_m2g; ga.src_of_cell = h->d_src_of_cell;
   ga.sdf = h->d_sdf; ga.grid = h->d_grid_stage; ga.n_grid = (int64_t)h->Ny * h->Nx;
   ga.max_abs_ux = h->maxs[0]; ga.max_abs_uy = h->maxs[1]; ga.sdf_scale = h->normalise_sdf ? 1.0 / h->maxs[2] : 1.0;
   ga.c_in = h->cfg.c_in; ga.fill = h->fill_input;
@@ -1150,7 +1166,7 @@ int psm_solve(psm_handle* h, const double* cells, int64_t n, int32_t rank, doubl
   h->in_mesh_solve = false;
   if (rc) return rc;
   PsmToMeshArgs ma{};
-  ma.cells = h->d_cells; ma.umax = h->d_umax; ma.vtx = h->d_vtx_g2m; ma.wts = h->d_wts_g2m; ma.cell_of_point = h->d_cell_of_point;
+  ma.cells = h->d_cells; ma.umax = dev_umax ? h->d_umax : nullptr; ma.umax_val = umax_val; ma.vtx = h->d_vtx_g2m; ma.wts = h->d_wts_g2m; ma.cell_of_point = h->d_cell_of_point;
   ma.field = h->d_fields_stage; ma.near_wall = h->d_near_wall; ma.p_out = h->d_p; ma.n_cells = n; ma.max_abs_p = h->maxs[3];
   ma.c_out = h->cfg.c_out;
   const bool direct = p_out == h->pinned_p && h->pinned_p_dev != nullptr;

@@ -6,7 +6,8 @@
 
 struct PsmToGridArgs {
   const double* cells;          // [N,5] Ux,Uy,Cx,Cy,p
-  const double* umax;           // device scalar
+  const double* umax;           // device scalar, or nullptr: umax_val (computed by the host while the H2D copy runs)
+  double umax_val;
   const int32_t* vtx;           // [n_grid,3] mesh->grid simplices (interp_weights, PM:52-62)
   const double* wts;            // [n_grid,3]
   const int32_t* src_of_cell;   // [n_grid] last grid point scattered into each cell (NumPy fancy assignment order), -1 none
@@ -19,7 +20,8 @@ struct PsmToGridArgs {
 
 struct PsmToMeshArgs {
   const double* cells;          // [N,5]
-  const double* umax;
+  const double* umax;           // device scalar, or nullptr: umax_val
+  double umax_val;
   const int32_t* vtx;           // [N,3] grid->mesh simplices
   const double* wts;            // [N,3]
   const int32_t* cell_of_point; // [n_grid] flat cell index of indices[point]

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void psm_to_grid_kernel(PsmToGridArgs a) {
   const int src = a.src_of_cell[cell];     // grid point whose value lands in this cell (-1: never written -> 0)
   float ux = 0.f, uy = 0.f;
   if (src >= 0) {
-    const double inv = 1.0 / *a.umax;
+    const double inv = 1.0 / (a.umax ? *a.umax : a.umax_val);
     const int32_t* v = a.vtx + (int64_t)src * 3;
     const double* w = a.wts + (int64_t)src * 3;
     double sx = 0.0, sy = 0.0;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void psm_to_mesh_kernel(PsmToMeshArgs a) {
     acc += (double)a.field[(int64_t)cell * a.c_out] * w[j];
     neg = neg || (w[j] < 0.0);
   }
-  const double um = *a.umax;
+  const double um = a.umax ? *a.umax : a.umax_val;
   double p = acc * a.max_abs_p * (um * um);                         // PM:490
   const double prev = a.cells[n * 5 + 4];
   if (a.near_wall[n] || neg || acc != acc) p = prev;                // PM:494, 496 (interpolate_fill -> NaN)
