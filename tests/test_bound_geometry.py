@@ -267,3 +267,25 @@ def test_bf16_bound_equals_bf16_general_path(variant, ny, nx):
     same(b2, r2, tol=5e-5)
     sol = orc.solve_grid(grid.astype(np.float64), oracle_model(model))
     assert rel_l2(bound, sol.fields) <= 2e-2
+
+
+def test_bound_four_channels_narrow_hidden_layer_and_min_max_scaler():
+    """pressureSM_Poisson shape (C_in = 4, SDF in channel 3, min_max scaler) and an architecture whose last hidden layer
+    is not 512 wide (MLP_small_unet ends 256 -> 512; MLP_big ends ... -> 256): the folded tables follow the head's width."""
+    m4 = synthetic.make_model("deltas", p_in=48, p_out=32, c_in=4, scaler_kind="min_max")
+    m4.sdf_ch = 3
+    g3 = synthetic.channel_grid(256, 320, seed=5)
+    g4 = np.concatenate([g3[..., :1] * g3[..., 1:2], g3], axis=-1).astype(np.float32)
+    with GridSurrogate(m4, 256, 320) as sur:
+        general = sur.solve(g4)[0]
+        assert sur.bind_geometry(g4)
+        same(sur.solve(g4)[0], general)
+    sol = orc.solve_grid(g4.astype(np.float64), oracle_model(m4))
+    assert np.abs(general - sol.fields).max() <= 1e-4 * np.abs(sol.fields).max()
+    for arch in ("MLP_big", "MLP_small_unet"):
+        model = synthetic.make_model("gradp", p_in=20, p_out=24, arch=arch)
+        grid = synthetic.channel_grid(256, 256, seed=6).astype(np.float32)
+        with GridSurrogate(model, 256, 256) as sur:
+            general = sur.solve(grid)[0]
+            assert sur.bind_geometry(grid)
+            same(sur.solve(grid)[0], general)
