@@ -153,7 +153,9 @@ class GridSurrogate:
         ``on_device``; a case batch [n, ny, nx, c_in] binds one geometry per case slot) for the following solves with
         the same number of cases: 6 launches instead of 8 (7 instead of 9 for batches; ``psm_bind_geometry_cases``; the
         reference's computeOnlyOnce / init_func split).  Returns False -- and leaves the solves on the general
-        path -- for configurations the fused path does not cover."""
+        path -- for configurations the fused path does not cover.  CONTRACT (as in psm.h): until unbind_geometry the
+        SDF channel of every solved grid keeps the bound flow-cell pattern (``check_bound = True`` verifies it on the
+        host-grid entries)."""
         if on_device:
             rc = self.lib.psm_bind_geometry_cases(self.h, C.c_void_p(int(grid)), int(n_cases), 1)
         else:
@@ -175,9 +177,14 @@ class GridSurrogate:
         self._bound_mask = None
         self._chk(self.lib.psm_unbind_geometry(self.h))
 
+    # Host-grid entries can verify the contract of psm_bind_geometry: with ``check_bound = True`` a grid whose flow-cell
+    # pattern differs from the bound one drops the binding.  Off by default (the comparison costs ~30 us per call, more
+    # than the binding saves); the evaluators, whose timeStep_grid takes arbitrary grids, switch it on.
+    check_bound = False
+
     def _check_bound(self, g: np.ndarray):
-        """Host-grid entries: a grid whose flow-cell pattern differs from the bound one drops the binding (the
-        device-pointer entries rely on the contract of psm_bind_geometry instead)."""
+        if not self.check_bound:
+            return
         m = getattr(self, "_bound_mask", None)
         if m is not None and g.shape[0] == m.shape[0] and not np.array_equal(g[..., self.model.sdf_ch] != 0, m):
             self.unbind_geometry()
@@ -400,6 +407,7 @@ class Evaluation:
             if self._sur is not None:
                 self._sur.close()
             self._sur = GridSurrogate(self.artifacts, ny, nx, 1, self.device)
+            self._sur.check_bound = True          # timeStep_grid takes arbitrary grids: a foreign geometry drops the binding
         return self._sur
 
     # ---- dataset-driven entry points (same names and arguments as the reference) -------------------

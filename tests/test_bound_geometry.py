@@ -107,6 +107,14 @@ def test_bind_lifecycle_and_unsupported_configurations():
         same(two[0], one); same(two[1], one)
         with pytest.raises(ValueError):
             sur.bind_geometry(g[:100])
+        # opt-in contract check of the host-grid entries: a grid of another geometry drops the binding
+        other = synthetic.channel_grid(256, 256, seed=8, cx=0.65).astype(np.float32)
+        assert sur.bind_geometry(g)
+        sur.check_bound = True
+        got = sur.solve(other)[0]
+        assert not sur.geometry_bound
+        sur.check_bound = False
+        same(got, sur.solve(other)[0])
         # a new plan or a model change drops the binding (its tables belong to the old block layout / head layer)
         assert sur.bind_geometry(g) and sur.geometry_bound
         sur._chk(sur.lib.psm_plan_grid(sur.h, 256, 256))

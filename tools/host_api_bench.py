@@ -10,7 +10,9 @@ from hipmem import DeviceArray
 model = synthetic.make_model("gradp")
 grids = [synthetic.channel_grid(256, 256, seed=1 + i).astype(np.float32) for i in range(4)]
 N = 3000
+BIND = len(sys.argv) > 1 and sys.argv[1] == "bind"     # the 4 rotated grids share one geometry: bind it (6 launches per solve)
 with psm_amd.GridSurrogate(model, 256, 256) as sur:
+    if BIND: assert sur.bind_geometry(grids[0]); print("geometry bound")
     d_in, d_out = DeviceArray(grids[0]), DeviceArray(shape=(256, 256, 2))
     for i in range(300): sur.solve_device(d_in.ptr, 1, d_out.ptr, 0)
     sur.synchronize()
