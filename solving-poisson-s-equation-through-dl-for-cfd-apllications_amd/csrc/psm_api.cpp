@@ -414,7 +414,7 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
     ba.fields = d_fields; ba.offs = h->d_offs; ba.shift = h->d_shift; ba.Nx = h->Nx; ba.n_strips = h->n_strips; ba.B = h->B;
     if (h->bound_zero_fill)                    // cells no block covers stay 0 like the reference's np.zeros field
       HIPCHK(h, hipMemsetAsync(d_fields, 0, (size_t)n_cases * h->Ny * h->Nx * h->cfg.c_out * sizeof(float), st));
-    if (n_cases == 1) {
+    if (n_cases == 1 && h->B <= 64) {
       tm.before(PSM_K_DECODE);
       if (bf16) {                               // strip dots from the bf16-rounded res (own small launch)
         PsmDotsArgs dd{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, h->d_dots, h->bound_rows, h->ld_out};
@@ -857,11 +857,14 @@ static int bind_geometry_device(psm_handle* h, const float* d_grid, int n_cases 
   h->bound = false;
   const bool bf16 = h->cfg.precision == PSM_PRECISION_BF16;
   if (bf16 && n_cases > 1) return fail(h, PSM_ERR_UNSUPPORTED, "geometry binding: bf16 handles bind single cases only");
-  if (!h->fused_assemble || h->ld_out > 128 || nl < 2 || !h->d_comp_nat)
-    return fail(h, PSM_ERR_UNSUPPORTED, "geometry binding needs <= 64 blocks in < 64 columns, <= 128 output components and a hidden layer");
+  // the chain runs row-parallel in one wave (lane = block column); more than 64 blocks take the two-launch form of the
+  // case batches (chain launch + chunked decode + paste), f32 only
+  const bool small = h->B <= 64;
+  if (h->plan.cp.n_x >= 64 || h->B > 4096 || (!small && bf16) || h->ld_out > 128 || nl < 2 || !h->d_comp_nat || getenv("PSM_NO_FUSED_ASSEMBLE") != nullptr)
+    return fail(h, PSM_ERR_UNSUPPORTED, "geometry binding needs < 64 block columns (bf16: <= 64 blocks), <= 128 output components and a hidden layer");
   // bf16: the decode rounds `res`, so the head layer cannot be folded into the tables: rows over the ld_out components
   const int Kh = bf16 ? h->ld_out : h->dense[nl - 1].Kpad, C = h->cfg.c_out;
-  if (Kh % 4 != 0 || Kh > 1024 || C * h->n_strips + h->n_strips > 2560)
+  if (Kh % 4 != 0 || Kh > 1024 || (small && C * h->n_strips + h->n_strips > 2560) || (size_t)(C * h->n_strips + h->n_strips + C * h->B) * 4 > 60 * 1024)
     return fail(h, PSM_ERR_UNSUPPORTED, "geometry binding: last hidden layer wider than 1024 or too many strips");
   if (n_cases > 1 && round_up(n_cases * h->B, 32) > 128 * 64) return fail(h, PSM_ERR_UNSUPPORTED, "geometry binding: too many block rows");
   const int rows = C * h->n_strips + C * h->B;

@@ -1636,7 +1636,6 @@ hipError_t psm_launch_decode_paste(const PsmDecodeArgs& a, const PsmBoundArgs& p
 // field f), then decode + paste for all block rows (row chunks like psm_decode128_kernel)
 template <int C>
 __global__ __launch_bounds__(256) void psm_chain_dots_kernel(PsmBoundBatchArgs p) {
-  constexpr int NST = 10;                              // staging rounds of 256 floats (C*nst + nst <= 2560)
   extern __shared__ float sm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cs = blockIdx.x;
   const int B = p.B, nst = p.n_strips;
@@ -1646,32 +1645,35 @@ __global__ __launch_bounds__(256) void psm_chain_dots_kernel(PsmBoundBatchArgs p
   const float* dots = p.dots + (int64_t)cs * p.rows_pc;
   const float* cnt = p.scnt + (int64_t)cs * p.rows_pc;
   const int n_stage = C * nst + nst;
-  float sv[NST];
+  for (int base = 0; base < n_stage; base += 256 * 8) {            // 8 loads in flight per thread and round
+    float sv[8];
 #pragma unroll
-  for (int u = 0; u < NST; ++u) {
-    const int idx = min(tid + 256 * u, n_stage - 1);
-    sv[u] = idx < C * nst ? dots[idx] : cnt[idx - C * nst];
+    for (int u = 0; u < 8; ++u) {
+      const int idx = min(base + tid + 256 * u, n_stage - 1);
+      sv[u] = idx < C * nst ? dots[idx] : cnt[idx - C * nst];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (base + tid + 256 * u < n_stage) smean[base + tid + 256 * u] = sv[u];
   }
-  const int f = min(wave, C - 1);
-  const float w_shift = p.shiftW[f * B + min(lane, B - 1)];
-  const float s_raw = dots[C * nst + f * B + min(lane, B - 1)];
-#pragma unroll
-  for (int u = 0; u < NST; ++u)
-    if (tid + 256 * u < n_stage) smean[tid + 256 * u] = sv[u];
   __syncthreads();
   if (wave < C) {
     psm_chain_wave(p.cp, smean + wave * nst, scnt, p.blocks, wave, lane, offs + wave * B);
-    const float t = (lane < B && w_shift != 0.f) ? w_shift * offs[wave * B + lane] : 0.f;
-    const float t_shift = wave_sum(t);
-    const float raw = wave_sum(lane < B ? s_raw : 0.f);
-    if (lane < B) p.offs[((int64_t)cs * C + wave) * B + lane] = offs[wave * B + lane];
-    if (lane == 0) p.shift[cs * C + wave] = raw / (float)p.shiftL[wave] / 3.f - t_shift;
+    float t = 0.f, raw = 0.f;
+    for (int b = lane; b < B; b += 64) {                            // same-wave LDS writes above are visible
+      const float w = p.shiftW[wave * B + b];
+      t += w != 0.f ? w * offs[wave * B + b] : 0.f;                   // skipped blocks have NaN offsets and weight 0
+      raw += dots[C * nst + wave * B + b];
+      p.offs[((int64_t)cs * C + wave) * B + b] = offs[wave * B + b];
+    }
+    const float t_shift = wave_sum(t), raw_all = wave_sum(raw);
+    if (lane == 0) p.shift[cs * C + wave] = raw_all / (float)p.shiftL[wave] / 3.f - t_shift;
   }
 }
 
 hipError_t psm_launch_chain_dots(const PsmBoundBatchArgs& p, int c_out, hipStream_t st) {
-  if ((c_out != 1 && c_out != 2) || c_out * p.n_strips + p.n_strips > 2560 || p.B > 64 || p.B < 1) return hipErrorInvalidValue;
   const size_t lds = ((size_t)c_out * p.n_strips + p.n_strips + (size_t)c_out * p.B) * sizeof(float);
+  if ((c_out != 1 && c_out != 2) || lds > 60 * 1024 || p.B < 1) return hipErrorInvalidValue;
   if (c_out == 1) hipLaunchKernelGGL((psm_chain_dots_kernel<1>), dim3(p.n_cases), dim3(256), lds, st, p);
   else hipLaunchKernelGGL((psm_chain_dots_kernel<2>), dim3(p.n_cases), dim3(256), lds, st, p);
   return hipGetLastError();
@@ -1715,7 +1717,6 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
   RowOps ro;
   load_tile(x, m_first);
   load_rows(ro, m_first);
-  const int yxv = p.blk_y0x0[min(tid, 2 * B - 1)];
   __builtin_amdgcn_sched_barrier(0);
   float4 b[GD];
   const float4* bp = a.bpack + ((int64_t)ct * GD) * 64 + lane;
@@ -1724,7 +1725,7 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
   const int col = ct * 32 + i;
   const float mu = a.mean[col];
   __builtin_amdgcn_sched_barrier(0);
-  if (tid < 2 * B) yx[tid] = yxv;
+  for (int t = tid; t < 2 * B; t += 256) yx[t] = p.blk_y0x0[t];      // B may exceed 128 here (single cases with many blocks)
   const int px = col / C, f = col - px * C;
   const int pxl = px - (int)blockIdx.x * (128 / C);
   const int r = px / S, c = px - r * S;
@@ -1783,7 +1784,7 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
 }
 
 hipError_t psm_launch_decode_paste_batch(const PsmDecodeArgs& a, const PsmBoundBatchArgs& p, int c_out, hipStream_t st) {
-  if (a.ld_res > 128 || a.ld_res % 32 != 0 || a.Gd * 8 != a.ld_res || a.Mpad % 32 != 0 || p.B > 64 || p.B < 1 || a.M != p.B * p.n_cases) return hipErrorInvalidValue;
+  if (a.ld_res > 128 || a.ld_res % 32 != 0 || a.Gd * 8 != a.ld_res || a.Mpad % 32 != 0 || p.B > 4096 || p.B < 1 || a.M != p.B * p.n_cases) return hipErrorInvalidValue;
   if (c_out != 1 && c_out != 2) return hipErrorInvalidValue;
   const int nwg = (a.n_coltiles + 3) / 4;
   // at most 3 tiles of 32 rows per chunk: the 4-tile form of this kernel spills (acc + tile + row operands)

@@ -297,3 +297,24 @@ def test_bound_four_channels_narrow_hidden_layer_and_min_max_scaler():
             general = sur.solve(grid)[0]
             assert sur.bind_geometry(grid)
             same(sur.solve(grid)[0], general)
+
+
+@pytest.mark.parametrize("variant,ny,nx", [("chapter5", 400, 3000), ("gradp", 512, 512), ("deltas", 300, 2100)])
+def test_bound_with_more_than_64_blocks(variant, ny, nx):
+    """The reference's shipped case is a 400 x 3000 grid (104 blocks in the Chapter-5 layout, python_module.py:306-329);
+    U_to_gradP at 512 x 512 has 182.  More than 64 blocks take the two-launch bound form (chain launch + chunked
+    decode + paste): 7 launches instead of 9."""
+    model = synthetic.make_model(variant, p_in=45, p_out=48)
+    grid = synthetic.channel_grid(ny, nx, seed=12).astype(np.float32)
+    with GridSurrogate(model, ny, nx) as sur:
+        assert sur.B > 64
+        general = sur.solve(grid)[0]
+        offs_general = sur.stage("offsets")[0].copy()
+        assert sur.bind_geometry(grid)
+        bound = sur.solve(grid)[0]
+        same(sur.stage("offsets")[0], offs_general)
+        same(bound, general)
+        g2 = grid.copy(); g2[..., :model.sdf_ch] *= 0.6
+        b2 = sur.solve(g2)[0]
+        sur.unbind_geometry()
+        same(b2, sur.solve(g2)[0])
