@@ -134,12 +134,12 @@ int psm_num_blocks(const psm_handle* h);
  * is stale while bound).  Same results as the unbound path up to float32 summation order.
  * CONTRACT: until psm_unbind_geometry / a new bind / a model or plan change, the SDF channel of every solved grid
  * must have the flow-cell pattern of the bound one; the other channels are free.  Case counts other than the bound
- * one keep the general path.  bf16 handles bind single cases: the decode rounds the network output to bf16, so their
+ * one keep the general path.  bf16 handles: the decode rounds the network output to bf16, so their
  * strip dots are taken from the rounded output in a small launch of their own (7 launches; same rounding points as
  * the general bf16 path).  Grids of more than 64 blocks (the reference's shipped 400 x 3000 case has 104) take a
  * two-launch form of the end: one chain launch, then decode + paste in row chunks (7 launches instead of 9).
  * Returns PSM_ERR_UNSUPPORTED (nothing bound, solves unaffected) for configurations outside these paths: >= 64 block
- * columns, > 128 output components, no hidden layer, last hidden layer wider than 1024, bf16 with > 64 blocks. */
+ * columns, > 128 output components, no hidden layer, last hidden layer wider than 1024. */
 int psm_bind_geometry(psm_handle* h, const float* grid, int32_t on_device);
 /* The same for a case batch: grids [n_cases, ny, nx, c_in], one geometry per case slot.  Solves with exactly
  * n_cases cases (case i on geometry i) then take 7 launches instead of 9: head + strip dots, one chain launch

@@ -331,7 +331,7 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
   Timer tm{h, st, 0, prof};
   const bool bf16 = (h->cfg.precision == PSM_PRECISION_BF16);
   // geometry-bound fast path: one case, nothing but the encode group being timed / skipped
-  const bool use_bound = h->bound && (h->bound_scope == 2 || h->in_mesh_solve) && n_cases == h->bound_cases && (!bf16 || n_cases == 1) && (h->timed_kernel < 0 || h->timed_kernel == PSM_K_ENCODE) && h->debug_skip == 0;
+  const bool use_bound = h->bound && (h->bound_scope == 2 || h->in_mesh_solve) && n_cases == h->bound_cases && (h->timed_kernel < 0 || h->timed_kernel == PSM_K_ENCODE) && h->debug_skip == 0;
   PsmEncodeArgs ea{};
   ea.grid = d_grid; ea.mean = h->d_mean_in; ea.bpack = h->d_bpack_in; ea.part = h->d_part;
   ea.row_base = h->d_row_base; ea.row_stride = (int64_t)h->Nx * h->cfg.c_in;
@@ -437,10 +437,14 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
     tm.before(PSM_K_DECODE); tm.after(PSM_K_DECODE);
     tm.before(PSM_K_STRIPS); tm.after(PSM_K_STRIPS);
     tm.before(PSM_K_CHAIN);
+    if (bf16) {                                 // strip dots from the bf16-rounded res (own small launch)
+      PsmDotsArgs dd{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, h->d_dots, h->bound_rows * n_cases, h->ld_out};
+      HIPCHK(h, psm_launch_res_dots(dd, h->d_res, h->ld_out, st));
+    }
     HIPCHK(h, psm_launch_chain_dots(bb, h->cfg.c_out, st));
     tm.after(PSM_K_CHAIN);
     tm.before(PSM_K_PASTE);
-    HIPCHK(h, psm_launch_decode_paste_batch(de, bb, h->cfg.c_out, st));
+    HIPCHK(h, psm_launch_decode_paste_batch(de, bb, h->cfg.c_out, st, bf16 ? 1 : 0));
     tm.after(PSM_K_PASTE);
     return PSM_OK;
   }
@@ -856,12 +860,11 @@ static int bind_geometry_device(psm_handle* h, const float* d_grid, int n_cases 
   const int nl = (int)h->dense.size();
   h->bound = false;
   const bool bf16 = h->cfg.precision == PSM_PRECISION_BF16;
-  if (bf16 && n_cases > 1) return fail(h, PSM_ERR_UNSUPPORTED, "geometry binding: bf16 handles bind single cases only");
   // the chain runs row-parallel in one wave (lane = block column); more than 64 blocks take the two-launch form of the
   // case batches (chain launch + chunked decode + paste), f32 only
   const bool small = h->B <= 64;
-  if (h->plan.cp.n_x >= 64 || h->B > 4096 || (!small && bf16) || h->ld_out > 128 || nl < 2 || !h->d_comp_nat || getenv("PSM_NO_FUSED_ASSEMBLE") != nullptr)
-    return fail(h, PSM_ERR_UNSUPPORTED, "geometry binding needs < 64 block columns (bf16: <= 64 blocks), <= 128 output components and a hidden layer");
+  if (h->plan.cp.n_x >= 64 || h->B > 4096 || h->ld_out > 128 || nl < 2 || !h->d_comp_nat || getenv("PSM_NO_FUSED_ASSEMBLE") != nullptr)
+    return fail(h, PSM_ERR_UNSUPPORTED, "geometry binding needs < 64 block columns, <= 128 output components and a hidden layer");
   // bf16: the decode rounds `res`, so the head layer cannot be folded into the tables: rows over the ld_out components
   const int Kh = bf16 ? h->ld_out : h->dense[nl - 1].Kpad, C = h->cfg.c_out;
   if (Kh % 4 != 0 || Kh > 1024 || (small && C * h->n_strips + h->n_strips > 2560) || (size_t)(C * h->n_strips + h->n_strips + C * h->B) * 4 > 60 * 1024)

@@ -125,7 +125,7 @@ struct PsmBoundBatchArgs {             // case batches: chain in its own small l
 };
 hipError_t psm_launch_bind(const PsmBindArgs& a, hipStream_t s);
 hipError_t psm_launch_chain_dots(const PsmBoundBatchArgs& p, int c_out, hipStream_t s);
-hipError_t psm_launch_decode_paste_batch(const PsmDecodeArgs& a, const PsmBoundBatchArgs& p, int c_out, hipStream_t s);
+hipError_t psm_launch_decode_paste_batch(const PsmDecodeArgs& a, const PsmBoundBatchArgs& p, int c_out, hipStream_t s, int bf16 = 0);
 // head layer + strip dots in one launch (f32, 16-row tiles)
 hipError_t psm_launch_dense_dots(const PsmDenseArgs& a, const PsmDotsArgs& d, hipStream_t s);
 // decode + offset chain + paste in one launch: ld_res <= 128, Mpad <= 64 (one case, B <= 64, n_x < 64)

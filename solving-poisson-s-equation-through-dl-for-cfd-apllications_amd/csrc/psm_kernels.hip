@@ -1679,9 +1679,10 @@ hipError_t psm_launch_chain_dots(const PsmBoundBatchArgs& p, int c_out, hipStrea
   return hipGetLastError();
 }
 
-template <int MTC, int C, int LDR>
+template <int MTC, int C, int LDR, bool BF>
 __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeArgs a, PsmBoundBatchArgs p, int m_end) {
-  constexpr int LDA = LDR + 4, Q = LDR / 4, GD = LDR / 8, NA = MTC * 32 * Q / 256;
+  constexpr int LDA = BF ? (LDR + 8) / 2 : LDR + 4;    // tile row stride in floats (bf16: LDR + 8 halves)
+  constexpr int Q = LDR / 4, GD = BF ? LDR / 16 : LDR / 8, NA = MTC * 32 * Q / 256;
   constexpr int WPB = (128 / C) / 32, R = MTC * 32;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1738,7 +1739,13 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
       const int idx = tid + 256 * u, row = idx / Q, q = idx - row * Q;
-      *reinterpret_cast<v4f*>(&lds[row * LDA + 4 * q]) = x[u];
+      if constexpr (BF) {
+        pk_bf16x4 v;
+        v[0] = (__bf16)x[u][0]; v[1] = (__bf16)x[u][1]; v[2] = (__bf16)x[u][2]; v[3] = (__bf16)x[u][3];
+        *reinterpret_cast<pk_bf16x4*>(reinterpret_cast<__bf16*>(&lds[row * LDA]) + 4 * q) = v;
+      } else {
+        *reinterpret_cast<v4f*>(&lds[row * LDA + 4 * q]) = x[u];
+      }
     }
     if (tid < R) {
       lrs[tid] = ro.rs;
@@ -1753,16 +1760,25 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
 #pragma unroll
     for (int mt = 0; mt < MTC; ++mt) {
       acc[mt] = (f32x16){0};
-      const float* arow = &lds[(mt * 32 + i) * LDA + 4 * h];
-      float4 av = *reinterpret_cast<const float4*>(arow);
+      if constexpr (BF) {
+        const __bf16* arow = reinterpret_cast<const __bf16*>(&lds[(mt * 32 + i) * LDA]) + 8 * h;
 #pragma unroll
-      for (int g = 0; g < GD; ++g) {
-        const float4 an = *reinterpret_cast<const float4*>(arow + 8 * (g + 1 < GD ? g + 1 : g));
-        acc[mt] = MFMA32(av.x, b[g].x, acc[mt]);
-        acc[mt] = MFMA32(av.y, b[g].y, acc[mt]);
-        acc[mt] = MFMA32(av.z, b[g].z, acc[mt]);
-        acc[mt] = MFMA32(av.w, b[g].w, acc[mt]);
-        av = an;
+        for (int g = 0; g < GD; ++g) {
+          const pk_bf16x8 av = *reinterpret_cast<const pk_bf16x8*>(arow + 16 * g);
+          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(pk_bf16x8, b[g]), acc[mt], 0, 0, 0);
+        }
+      } else {
+        const float* arow = &lds[(mt * 32 + i) * LDA + 4 * h];
+        float4 av = *reinterpret_cast<const float4*>(arow);
+#pragma unroll
+        for (int g = 0; g < GD; ++g) {
+          const float4 an = *reinterpret_cast<const float4*>(arow + 8 * (g + 1 < GD ? g + 1 : g));
+          acc[mt] = MFMA32(av.x, b[g].x, acc[mt]);
+          acc[mt] = MFMA32(av.y, b[g].y, acc[mt]);
+          acc[mt] = MFMA32(av.z, b[g].z, acc[mt]);
+          acc[mt] = MFMA32(av.w, b[g].w, acc[mt]);
+          av = an;
+        }
       }
     }
     if (live) {
@@ -1783,8 +1799,8 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
   }
 }
 
-hipError_t psm_launch_decode_paste_batch(const PsmDecodeArgs& a, const PsmBoundBatchArgs& p, int c_out, hipStream_t st) {
-  if (a.ld_res > 128 || a.ld_res % 32 != 0 || a.Gd * 8 != a.ld_res || a.Mpad % 32 != 0 || p.B > 4096 || p.B < 1 || a.M != p.B * p.n_cases) return hipErrorInvalidValue;
+hipError_t psm_launch_decode_paste_batch(const PsmDecodeArgs& a, const PsmBoundBatchArgs& p, int c_out, hipStream_t st, int bf16) {
+  if (a.ld_res > 128 || a.ld_res % 32 != 0 || a.Mpad % 32 != 0 || p.B > 4096 || p.B < 1 || a.M != p.B * p.n_cases) return hipErrorInvalidValue;
   if (c_out != 1 && c_out != 2) return hipErrorInvalidValue;
   const int nwg = (a.n_coltiles + 3) / 4;
   // at most 3 tiles of 32 rows per chunk: the 4-tile form of this kernel spills (acc + tile + row operands)
@@ -1793,7 +1809,11 @@ hipError_t psm_launch_decode_paste_batch(const PsmDecodeArgs& a, const PsmBoundB
   int groups = 1;
   while (nwg * groups < 256 && groups * 2 <= iters) groups *= 2;
   const dim3 grid(nwg, groups);
-#define DP(M_, C_, L_) hipLaunchKernelGGL((psm_decode_paste_batch_kernel<M_, C_, L_>), grid, dim3(256), lds, st, a, p, a.Mpad)
+#define DP(M_, C_, L_)                                                                                                          \
+  do {                                                                                                                          \
+    if (bf16) hipLaunchKernelGGL((psm_decode_paste_batch_kernel<M_, C_, L_, true>), grid, dim3(256), lds, st, a, p, a.Mpad);      \
+    else hipLaunchKernelGGL((psm_decode_paste_batch_kernel<M_, C_, L_, false>), grid, dim3(256), lds, st, a, p, a.Mpad);          \
+  } while (0)
 #define DPM(C_, L_)                                                                 \
   do {                                                                              \
     if (mtc == 3) DP(3, C_, L_); else if (mtc == 2) DP(2, C_, L_); else DP(1, C_, L_); \

@@ -133,7 +133,7 @@ def test_bind_lifecycle_and_unsupported_configurations():
         assert sur.bind_geometry(gb) is False and not sur.geometry_bound
         assert np.isfinite(sur.solve(gb)[0]).all()
     with GridSurrogate(model, 256, 256, precision="bf16", max_cases=2) as sur:
-        assert sur.bind_geometry(np.stack([g, g])) is False          # bf16 handles bind single cases only
+        assert sur.bind_geometry(np.stack([g, g])) is True
         assert sur.bind_geometry(g) is True
     wide = synthetic.make_model("gradp", p_in=16, p_out=130)                         # > 128 output components
     with GridSurrogate(wide, 256, 256) as sur:
@@ -318,3 +318,16 @@ def test_bound_with_more_than_64_blocks(variant, ny, nx):
         b2 = sur.solve(g2)[0]
         sur.unbind_geometry()
         same(b2, sur.solve(g2)[0])
+
+
+@pytest.mark.parametrize("variant,ny,nx,n", [("deltas", 256, 256, 8), ("gradp", 512, 512, 1), ("chapter5", 400, 1500, 2)])
+def test_bf16_bound_batches_and_many_blocks(variant, ny, nx, n):
+    """bf16 handles on the two-launch bound form (case batches, more than 64 blocks): the general bf16 path's fields."""
+    model = synthetic.make_model(variant, p_in=40, p_out=40)
+    grids = np.stack([synthetic.channel_grid(ny, nx, seed=30 + k, cx=0.3 + 0.05 * k).astype(np.float32) for k in range(n)])
+    with GridSurrogate(model, ny, nx, max_cases=n, precision="bf16") as sur:
+        general = sur.solve(grids)
+        assert sur.bind_geometry(grids)
+        bound = sur.solve(grids)
+    for k in range(n):
+        same(bound[k], general[k], tol=5e-5)
