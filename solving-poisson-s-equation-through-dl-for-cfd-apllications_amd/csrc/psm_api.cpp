@@ -65,7 +65,7 @@ struct psm_handle {
   bool have_geometry = false, have_g2m = false;
   int64_t n_cells = 0;
   int32_t *d_vtx_m2g = nullptr, *d_src_of_cell = nullptr, *d_vtx_g2m = nullptr, *d_cell_of_point = nullptr;
-  double *d_wts_m2g = nullptr, *d_sdf = nullptr, *d_wts_g2m = nullptr, *d_cells = nullptr, *d_p = nullptr, *d_umax = nullptr;
+  double *d_wts_m2g = nullptr, *d_sdf = nullptr, *d_wts_g2m = nullptr, *d_cells = nullptr, *d_p = nullptr, *d_umax = nullptr, *d_umax_part = nullptr;
   uint8_t* d_near_wall = nullptr;
   // U_to_gradP integration (psm_set_integration)
   bool have_integ = false;
@@ -245,7 +245,7 @@ void free_geometry(psm_handle* h) {
   unpin_buffers(h);
   dev_free(h->d_vtx_m2g); dev_free(h->d_src_of_cell); dev_free(h->d_vtx_g2m); dev_free(h->d_cell_of_point);
   dev_free(h->d_wts_m2g); dev_free(h->d_sdf); dev_free(h->d_wts_g2m); dev_free(h->d_cells); dev_free(h->d_p);
-  dev_free(h->d_umax); dev_free(h->d_near_wall);
+  dev_free(h->d_umax); dev_free(h->d_umax_part); dev_free(h->d_near_wall);
   dev_free(h->d_fixups); dev_free(h->d_pairs); dev_free(h->d_integ_buf); dev_free(h->d_gradp);
   h->have_integ = false;
   if (h->h_cells) { (void)hipHostFree(h->h_cells); h->h_cells = nullptr; }
@@ -1107,6 +1107,7 @@ int psm_set_geometry(psm_handle* h, int64_t n_cells, int32_t ny, int32_t nx, con
   if ((rc = dev_alloc(h, &h->d_cells, (size_t)n_cells * 5))) return rc;
   if ((rc = dev_alloc(h, &h->d_p, (size_t)n_cells))) return rc;
   if ((rc = dev_alloc(h, &h->d_umax, (size_t)1))) return rc;
+  if ((rc = dev_alloc(h, &h->d_umax_part, (size_t)256))) return rc;
   HIPCHK(h, hipHostMalloc((void**)&h->h_cells, (size_t)n_cells * 5 * sizeof(double), hipHostMallocDefault));
   HIPCHK(h, hipHostMalloc((void**)&h->h_p, (size_t)n_cells * sizeof(double), hipHostMallocDefault));
   h->have_geometry = true;
@@ -1147,9 +1148,16 @@ int psm_solve(psm_handle* h, const double* cells, int64_t n, int32_t rank, doubl
   // U_max = max sqrt(Ux^2 + Uy^2) (PM:270) on the host while the copy above is in flight: sqrt is monotonic and
   // correctly rounded on both sides, so sqrt(max(Ux^2 + Uy^2)) is the kernel's value bit for bit (NaN propagates
   // like np.max); one launch less.  PSM_DEVICE_UMAX=1 keeps the device reduction.
-  static const bool dev_umax = getenv("PSM_DEVICE_UMAX") != nullptr;
+  // Large meshes (the host pass would take longer than the copy it hides under): parallel device reduction, whose
+  // per-workgroup maxima every psm_to_grid workgroup folds itself.
+  static const bool dev_umax_env = getenv("PSM_DEVICE_UMAX") != nullptr;
+  const bool big = n > 32768;
+  const bool dev_umax = dev_umax_env && !big;
   double umax_val = 0.0;
-  if (dev_umax) {
+  int n_partials = 0;
+  if (big) {
+    HIPCHK(h, psm_launch_umax_partial(h->d_cells, n, h->d_umax_part, &n_partials, st));
+  } else if (dev_umax) {
     HIPCHK(h, psm_launch_umax(h->d_cells, n, h->d_umax, st));
   } else {
     double m2 = 0.0; bool nan = false;
@@ -1162,7 +1170,8 @@ int psm_solve(psm_handle* h, const double* cells, int64_t n, int32_t rank, doubl
     umax_val = nan ? std::nan("") : std::sqrt(m2);
   }
   PsmToGridArgs ga{};
-  ga.cells = h->d_cells; ga.umax = dev_umax ? h->d_umax : nullptr; ga.umax_val = umax_val; ga.vtx = h->d_vtx_m2g; ga.wts = h->d_wts_m2g; ga.src_of_cell = h->d_src_of_cell;
+  ga.cells = h->d_cells; ga.umax = dev_umax ? h->d_umax : nullptr; ga.umax_val = umax_val;
+  if (big) { ga.umax_partials = h->d_umax_part; ga.n_partials = n_partials; ga.umax_out = h->d_umax; } ga.vtx = h->d_vtx_m2g; ga.wts = h->d_wts_m2g; ga.src_of_cell = h->d_src_of_cell;
   ga.sdf = h->d_sdf; ga.grid = h->d_grid_stage; ga.n_grid = (int64_t)h->Ny * h->Nx;
   ga.max_abs_ux = h->maxs[0]; ga.max_abs_uy = h->maxs[1]; ga.sdf_scale = h->normalise_sdf ? 1.0 / h->maxs[2] : 1.0;
   ga.c_in = h->cfg.c_in; ga.fill = h->fill_input;
@@ -1172,7 +1181,7 @@ int psm_solve(psm_handle* h, const double* cells, int64_t n, int32_t rank, doubl
   h->in_mesh_solve = false;
   if (rc) return rc;
   PsmToMeshArgs ma{};
-  ma.cells = h->d_cells; ma.umax = dev_umax ? h->d_umax : nullptr; ma.umax_val = umax_val; ma.vtx = h->d_vtx_g2m; ma.wts = h->d_wts_g2m; ma.cell_of_point = h->d_cell_of_point;
+  ma.cells = h->d_cells; ma.umax = (dev_umax || big) ? h->d_umax : nullptr; ma.umax_val = umax_val; ma.vtx = h->d_vtx_g2m; ma.wts = h->d_wts_g2m; ma.cell_of_point = h->d_cell_of_point;
   ma.field = h->d_fields_stage; ma.near_wall = h->d_near_wall; ma.p_out = h->d_p; ma.n_cells = n; ma.max_abs_p = h->maxs[3];
   ma.c_out = h->cfg.c_out;
   const bool direct = p_out == h->pinned_p && h->pinned_p_dev != nullptr;

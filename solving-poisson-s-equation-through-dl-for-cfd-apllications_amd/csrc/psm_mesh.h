@@ -8,6 +8,9 @@ struct PsmToGridArgs {
   const double* cells;          // [N,5] Ux,Uy,Cx,Cy,p
   const double* umax;           // device scalar, or nullptr: umax_val (computed by the host while the H2D copy runs)
   double umax_val;
+  const double* umax_partials;  // large meshes: per-workgroup partial maxima of psm_umax_partial_kernel (reduced here by every
+  int n_partials;               // workgroup; workgroup 0 also stores the result to umax_out for psm_to_mesh_kernel), or nullptr
+  double* umax_out;
   const int32_t* vtx;           // [n_grid,3] mesh->grid simplices (interp_weights, PM:52-62)
   const double* wts;            // [n_grid,3]
   const int32_t* src_of_cell;   // [n_grid] last grid point scattered into each cell (NumPy fancy assignment order), -1 none
@@ -34,6 +37,8 @@ struct PsmToMeshArgs {
 };
 
 hipError_t psm_launch_umax(const double* cells, int64_t n, double* umax, hipStream_t st);
+// parallel form for large meshes: partials[0 .. *n_partials) (capacity 256), reduced by psm_to_grid_kernel
+hipError_t psm_launch_umax_partial(const double* cells, int64_t n, double* partials, int* n_partials, hipStream_t st);
 hipError_t psm_launch_to_grid(const PsmToGridArgs& a, hipStream_t st);
 hipError_t psm_launch_to_mesh(const PsmToMeshArgs& a, hipStream_t st);
 hipError_t psm_launch_interp_to_grid(const double* values, int k, const int32_t* vtx, const double* wts, const int32_t* src_of_cell,

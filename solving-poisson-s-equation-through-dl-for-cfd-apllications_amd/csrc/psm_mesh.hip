@@ -11,6 +11,8 @@
 // All of them are HBM-bound gathers; interpolation is done in float64 like the reference.
 #include "psm_mesh.h"
 
+#include <algorithm>
+
 __global__ __launch_bounds__(1024) void psm_umax_kernel(const double* cells, int64_t n, double* umax) {
   __shared__ double red[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -33,13 +35,44 @@ __global__ __launch_bounds__(1024) void psm_umax_kernel(const double* cells, int
   }
 }
 
+// np.max semantics on doubles: NaN propagates
+__device__ __forceinline__ double nanmax2(double a, double b) { return (b > a || b != b) ? b : a; }
+
+__global__ __launch_bounds__(1024) void psm_umax_partial_kernel(const double* cells, int64_t n, double* partials) {
+  __shared__ double red[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double m = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 1024 + tid; i < n; i += (int64_t)gridDim.x * 1024) {
+    const double ux = cells[i * 5], uy = cells[i * 5 + 1];
+    m = nanmax2(m, sqrt(ux * ux + uy * uy));
+  }
+  for (int o = 32; o > 0; o >>= 1) m = nanmax2(m, __shfl_down(m, o, 64));
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  if (tid == 0) {
+    double r = red[0];
+    for (int w = 1; w < 16; ++w) r = nanmax2(r, red[w]);
+    partials[blockIdx.x] = r;
+  }
+}
+
 __global__ __launch_bounds__(256) void psm_to_grid_kernel(PsmToGridArgs a) {
+  __shared__ double um_s[4];
+  double umax_v = a.umax ? *a.umax : a.umax_val;
+  if (a.umax_partials) {                      // uniform: every workgroup reduces the <= 256 partial maxima itself
+    double m = a.umax_partials[min((int)threadIdx.x, a.n_partials - 1)];
+    for (int o = 32; o > 0; o >>= 1) m = nanmax2(m, __shfl_down(m, o, 64));
+    if ((threadIdx.x & 63) == 0) um_s[threadIdx.x >> 6] = m;
+    __syncthreads();
+    umax_v = nanmax2(nanmax2(um_s[0], um_s[1]), nanmax2(um_s[2], um_s[3]));
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.umax_out = umax_v;
+  }
   const int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (cell >= a.n_grid) return;
   const int src = a.src_of_cell[cell];     // grid point whose value lands in this cell (-1: never written -> 0)
   float ux = 0.f, uy = 0.f;
   if (src >= 0) {
-    const double inv = 1.0 / (a.umax ? *a.umax : a.umax_val);
+    const double inv = 1.0 / umax_v;
     const int32_t* v = a.vtx + (int64_t)src * 3;
     const double* w = a.wts + (int64_t)src * 3;
     double sx = 0.0, sy = 0.0;
@@ -82,6 +115,13 @@ __global__ __launch_bounds__(256) void psm_to_mesh_kernel(PsmToMeshArgs a) {
   const double prev = a.cells[n * 5 + 4];
   if (a.near_wall[n] || neg || acc != acc) p = prev;                // PM:494, 496 (interpolate_fill -> NaN)
   a.p_out[n] = p;
+}
+
+hipError_t psm_launch_umax_partial(const double* cells, int64_t n, double* partials, int* n_partials, hipStream_t st) {
+  const int nwg = (int)std::min<int64_t>(256, (n + 4095) / 4096);
+  *n_partials = nwg;
+  hipLaunchKernelGGL(psm_umax_partial_kernel, dim3(nwg), dim3(1024), 0, st, cells, n, partials);
+  return hipGetLastError();
 }
 
 hipError_t psm_launch_umax(const double* cells, int64_t n, double* umax, hipStream_t st) {
