@@ -122,7 +122,14 @@ __global__ __launch_bounds__(256) void psm_encode_kernel(PsmEncodeArgs a) {
     // staging round trip hides under the matrix work; the weight slice stays in registers throughout.
     // Barriers are LDS-only (the partial-sum stores need not drain between chunks).
     constexpr int CH = 64;
-    const int t = min(wave, NT - 1);
+    // wave -> (component tile t, first row tile, row-tile step): with one or two component tiles (<= 64 components, e.g.
+    // the reference's 45-component network) the waves split the two 32-row tiles of a chunk between them instead of
+    // recomputing the last component tile (which halved the useful MFMA rate of this path)
+    int t, mt_first, mt_step;
+    bool store;
+    if (NT == 2) { t = wave & 1; mt_first = wave >> 1; mt_step = 2; store = true; }
+    else if (NT == 1) { t = 0; mt_first = wave & 1; mt_step = 2; store = wave < 2; }
+    else { t = min(wave, NT - 1); mt_first = 0; mt_step = 1; store = wave < NT; }
     float4 xa[8], xb[8];
     load_rows(xa, 0, 0);
     load_rows(xb, 0, 32);
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(256) void psm_encode_kernel(PsmEncodeArgs a) {
       const bool more = m0 + CH < a.Mpad;
       if (more) { load_rows(xa, m0 + CH, 0); load_rows(xb, m0 + CH, 32); }
       const int tiles = min(2, (a.Mpad - m0) / 32);
-      for (int mt = 0; mt < tiles; ++mt) {
+      for (int mt = mt_first; mt < tiles; mt += mt_step) {
         f32x16 acc = {0};
         const float* arow = &lds[(buf * CH + mt * 32 + i) * LDA + 4 * h];
         float4 av = *reinterpret_cast<const float4*>(arow);
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(256) void psm_encode_kernel(PsmEncodeArgs a) {
           acc = MFMA32(av.w, b[g].w, acc);
           av = an;
         }
-        if (wave < NT) {
+        if (store) {
           float* out = a.part + ((int64_t)s * a.Mpad + m0 + mt * 32) * a.ldp + t * 32 + i;
 #pragma unroll
           for (int rg = 0; rg < 16; ++rg) out[(int64_t)acc_row(rg, h) * a.ldp] = acc[rg];

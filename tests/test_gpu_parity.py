@@ -444,3 +444,18 @@ def test_reassembly_on_random_shapes_and_obstacles():
             ok = ~np.isnan(ref)
             if ok.any():
                 assert np.abs(f[..., c][ok] - ref[ok]).max() <= 3e-4 * max(1.0, np.abs(ref[ok]).max()), (variant, ny, nx, trial)
+
+
+@pytest.mark.parametrize("p_in", [45, 20, 70])
+def test_streamed_encode_with_few_component_tiles(p_in):
+    """Many block rows (> 32: the streamed 64-row-chunk form of the encode kernel) with 2, 1 and 3 tiles of 32 input
+    components -- the reference's own network has 45: the waves split the row tiles between them; coefficients and
+    fields against the oracle, case by case."""
+    model = synthetic.make_model("deltas", p_in=p_in, p_out=32)
+    grids = synthetic.random_obstacle_cases(5, 256, 256, seed=13).astype(np.float32)
+    with GridSurrogate(model, 256, 256, max_cases=5) as sur:
+        fields = sur.solve(grids)
+        for k in (0, 4):
+            sol = orc.solve_grid(grids[k].astype(np.float64), oracle_model(model))
+            check_against_oracle(sur, grids[k], model, sol, n_cases=5, case=k)
+            assert np.abs(fields[k] - sol.fields).max() <= 1e-4 * np.abs(sol.fields).max()

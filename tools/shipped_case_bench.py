@@ -22,4 +22,7 @@ for bind in (False, True):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for i in range(1000): sur.solve_device(d_in.data_ptr(), 1, d_out.data_ptr(), st)
             torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) / 1000)
+        profs = [sur.profile(d_in.data_ptr(), 1, d_out.data_ptr()) for _ in range(5)]
+        prof = {k: min(p[k] for p in profs) for k in profs[0]}
+        print('   groups (event-separated, us): ' + ' '.join(f'{k}={v*1e3:.1f}' for k, v in prof.items()))
         print(f"400x3000 chapter5, B={sur.B}, {'geometry bound' if bind else 'general path  '}: {best*1e6:7.1f} us per solve = {1/best:8.0f} solves/s")
