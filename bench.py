@@ -187,7 +187,14 @@ def main():
         grids = [synthetic.channel_grid(NY, NX, seed=1 + 1000 * rank + i, noise=0.05 if NY > 256 else 0.02).astype(np.float32)[None]
                  for i in range(args.inputs)]
     else:
-        grids = [synthetic.random_obstacle_cases(NC, NY, NX, seed=3 + 1000 * rank + i).astype(np.float32) for i in range(args.inputs)]
+        # an ensemble of NC geometries per rank, each advancing in time: the rotated inputs are the same cases with other
+        # velocity fields (the SDF channel -- the geometry -- stays)
+        base = synthetic.random_obstacle_cases(NC, NY, NX, seed=3 + 1000 * rank).astype(np.float32)
+        grids = []
+        for i in range(args.inputs):
+            g = base.copy()
+            g[..., :model.sdf_ch] *= np.float32(1.0 + 0.05 * i)
+            grids.append(g)
     d_in = [torch.from_numpy(g).cuda() for g in grids]
     d_out = [torch.empty((NC, NY, NX, model.c_out), dtype=torch.float32, device="cuda") for _ in grids]
     stream = torch.cuda.current_stream().cuda_stream
@@ -196,10 +203,10 @@ def main():
     # outside the timed region, like the reference's computeOnlyOnce / init_func; the rotated inputs differ in the
     # velocity channels only (checked).  --no-bind times the general path, which takes any geometry per call.
     bound = False
-    if NC == 1 and not args.no_bind:
-        masks = [g[0, ..., model.sdf_ch] != 0 for g in grids]
+    if not args.no_bind:
+        masks = [g[..., model.sdf_ch] != 0 for g in grids]
         if all(np.array_equal(masks[0], m) for m in masks[1:]):
-            bound = sur.bind_geometry(d_in[0].data_ptr(), on_device=True)
+            bound = sur.bind_geometry(d_in[0].data_ptr(), on_device=True, n_cases=NC)
 
     def step(i):
         k = i % len(d_in)
@@ -243,7 +250,7 @@ def main():
                    "grid": [NY, NX], "blocks": sur.B, "p_in": P, "p_out": P, "cases_per_step_per_gpu": NC,
                    "parallelism": f"case-sharded x{world} (no data-path collective)",
                    "geometry": ("bound once per case stream (psm_bind_geometry = the reference's computeOnlyOnce / init_func split): "
-                                "6 launches per solve") if bound else "general path (any geometry per call): 8 launches per solve"},
+                                "6 launches per solve, 7 for case batches") if bound else "general path (any geometry per call): 8 launches per solve (9 for case batches)"},
         "roofline": roofline,
     }
 
