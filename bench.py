@@ -146,8 +146,8 @@ def main_unet(args):
     if rank == 0:
         print(json.dumps(out))
     net.close()
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 
@@ -264,8 +264,8 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     sur.close()
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 

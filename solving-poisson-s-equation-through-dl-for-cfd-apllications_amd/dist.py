@@ -34,7 +34,8 @@ def env_world() -> Tuple[int, int, int]:
 def init(backend: str, device=None):
     import torch.distributed as dist
     rank, world, _ = env_world()
-    if world > 1 and not dist.is_initialized():
+    # PSM_DIST_FORCE=1: initialise the process group for a single rank too (rehearsal of the RCCL path on a one-GPU box)
+    if (world > 1 or (os.environ.get("PSM_DIST_FORCE") and "MASTER_ADDR" in os.environ)) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         kw = {"device_id": device} if (device is not None and backend == "nccl") else {}
