@@ -100,6 +100,10 @@ struct psm_handle {
   std::map<GraphKey, hipGraphExec_t> graphs;
   bool use_graph = true;
   bool fused_assemble = false;
+  // scratch of the helper entries (gaussian filter, mesh -> grid, Poisson features, gradp integration): one device and one
+  // pinned host buffer, grown on demand and reused -- a hipMalloc / hipFree pair per call cost more than the kernels
+  void *scr_dev = nullptr, *scr_pin = nullptr;
+  size_t scr_dev_cap = 0, scr_pin_cap = 0;
   // geometry-bound fast path (psm_bind_geometry): tables of psm_kernels.h PsmBindArgs
   bool bound = false, bound_zero_fill = false;
   int bound_scope = 0;                  // 2: every single-case solve (psm_bind_geometry); 1: psm_solve only (bound by psm_set_geometry)
@@ -139,6 +143,15 @@ hipError_t wait_event(hipEvent_t ev) {
   return e;
 }
 
+int fail(psm_handle* h, int code, const std::string& msg);
+// carve helpers: 256-byte aligned pieces of the two scratch buffers
+struct Carver {
+  char* base; size_t off = 0;
+  template <typename T> T* take(size_t n) { T* p = reinterpret_cast<T*>(base + off); off += (n * sizeof(T) + 255) & ~(size_t)255; return p; }
+};
+inline size_t carve_size(std::initializer_list<size_t> bytes) { size_t t = 0; for (size_t b : bytes) t += (b + 255) & ~(size_t)255; return t; }
+int scratch_reserve(psm_handle* h, size_t dev_bytes, size_t pin_bytes);
+
 int fail(psm_handle* h, int code, const std::string& msg) {
   if (h) h->err = msg; else g_create_error = msg;
   return code;
@@ -170,6 +183,24 @@ int dev_upload(psm_handle* h, T** p, const std::vector<T>& v) {
 
 template <typename T>
 void dev_free(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+int scratch_reserve(psm_handle* h, size_t dev_bytes, size_t pin_bytes) {
+  if (dev_bytes > h->scr_dev_cap) {
+    if (h->scr_dev) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->scr_dev); h->scr_dev = nullptr; h->scr_dev_cap = 0; }
+    const size_t cap = dev_bytes + dev_bytes / 2;
+    hipError_t e = hipMalloc(&h->scr_dev, cap);
+    if (e != hipSuccess) return fail(h, PSM_ERR_NOMEM, std::string("hipMalloc(scratch): ") + hipGetErrorString(e));
+    h->scr_dev_cap = cap;
+  }
+  if (pin_bytes > h->scr_pin_cap) {
+    if (h->scr_pin) { (void)hipStreamSynchronize(h->stream); (void)hipHostFree(h->scr_pin); h->scr_pin = nullptr; h->scr_pin_cap = 0; }
+    const size_t cap = pin_bytes + pin_bytes / 2;
+    hipError_t e = hipHostMalloc(&h->scr_pin, cap, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(h, PSM_ERR_NOMEM, std::string("hipHostMalloc(scratch): ") + hipGetErrorString(e));
+    h->scr_pin_cap = cap;
+  }
+  return PSM_OK;
+}
 
 void destroy_graphs(psm_handle* h) {
   for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
@@ -609,6 +640,8 @@ void psm_destroy(psm_handle* h) {
   free_geometry(h);
   for (auto& d : h->dense) { dev_free(d.W); dev_free(d.b); if (d.Wp) { (void)hipFree(d.Wp); d.Wp = nullptr; } }
   dev_free(h->d_mean_in); dev_free(h->d_mean_out); dev_free(h->d_bpack_in); dev_free(h->d_bpack_out);
+  if (h->scr_dev) (void)hipFree(h->scr_dev);
+  if (h->scr_pin) (void)hipHostFree(h->scr_pin);
   dev_free(h->d_comp_nat); dev_free(h->d_g2); dev_free(h->d_c2); dev_free(h->d_cnt); dev_free(h->d_dots); dev_free(h->d_row_of); dev_free(h->d_ownbits);
   dev_free(h->d_ia); dev_free(h->d_ib); dev_free(h->d_sa); dev_free(h->d_sb);
   for (int i = 0; i < psm_handle::RING; ++i) {
@@ -1047,7 +1080,7 @@ int psm_reassemble(psm_handle* h, const float* grid, const float* block_pred, fl
   PsmPasteArgs pa{h->d_pred, h->d_owner, h->d_offs, h->d_shift, h->d_fields_stage, h->B, h->S, h->cfg.c_out, h->Ny * h->Nx};
   HIPCHK(h, psm_launch_paste(pa, 1, st));
   HIPCHK(h, hipMemcpyAsync(fields, h->d_fields_stage, npix * h->cfg.c_out * sizeof(float), hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipStreamSynchronize(st));
+  HIPCHK(h, wait_stream(st));
   h->last_cases = 1;
   return PSM_OK;
 }
@@ -1250,16 +1283,19 @@ int psm_gaussian_filter(psm_handle* h, const float* in, int32_t ny, int32_t nx, 
   const int ry = weights(sigma_y, wy), rx = weights(sigma_x, wx);
   std::vector<float> wall(wy);
   wall.insert(wall.end(), wx.begin(), wx.end());
-  if ((rc = dev_alloc(h, &d_a, n)) || (rc = dev_alloc(h, &d_b, n)) || (rc = dev_upload(h, &d_w, wall))) {
-    dev_free(d_a); dev_free(d_b); dev_free(d_w);
-    return rc;
-  }
-  hipError_t e = hipMemcpyAsync(d_a, in, n * sizeof(float), hipMemcpyHostToDevice, st);
+  const size_t nb = n * sizeof(float), wb = wall.size() * sizeof(float);
+  if ((rc = scratch_reserve(h, carve_size({nb, nb, wb}), carve_size({nb, wb})))) return rc;
+  Carver cd{(char*)h->scr_dev}, cp{(char*)h->scr_pin};
+  d_a = cd.take<float>(n); d_b = cd.take<float>(n); d_w = cd.take<float>(wall.size());
+  float* p_io = cp.take<float>(n); float* p_w = cp.take<float>(wall.size());
+  memcpy(p_io, in, nb); memcpy(p_w, wall.data(), wb);
+  hipError_t e = hipMemcpyAsync(d_a, p_io, nb, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_w, p_w, wb, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = psm_launch_gauss1d(d_a, d_b, ny, nx, 0, ry, d_w, st);
   if (e == hipSuccess) e = psm_launch_gauss1d(d_b, d_a, ny, nx, 1, rx, d_w + wy.size(), st);
-  if (e == hipSuccess) e = hipMemcpyAsync(out, d_a, n * sizeof(float), hipMemcpyDeviceToHost, st);
-  if (e == hipSuccess) e = hipStreamSynchronize(st);
-  dev_free(d_a); dev_free(d_b); dev_free(d_w);
+  if (e == hipSuccess) e = hipMemcpyAsync(p_io, d_a, nb, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = wait_stream(st);
+  if (e == hipSuccess) memcpy(out, p_io, nb);
   if (e != hipSuccess) return fail(h, PSM_ERR_HIP, std::string("gaussian filter: ") + hipGetErrorString(e));
   return PSM_OK;
 }
@@ -1273,14 +1309,18 @@ int psm_mesh_to_grid(psm_handle* h, const double* values, int64_t n, int32_t k, 
   HIPCHK(h, hipSetDevice(h->cfg.device));
   hipStream_t st = h->stream;
   const size_t ng = (size_t)h->Ny * h->Nx;
-  double *d_v = nullptr, *d_o = nullptr;
   int rc;
-  if ((rc = dev_alloc(h, &d_v, (size_t)n * k)) || (rc = dev_alloc(h, &d_o, ng * k))) { dev_free(d_v); dev_free(d_o); return rc; }
-  hipError_t e = hipMemcpyAsync(d_v, values, (size_t)n * k * sizeof(double), hipMemcpyHostToDevice, st);
+  const size_t vb = (size_t)n * k * sizeof(double), ob = ng * k * sizeof(double);
+  if ((rc = scratch_reserve(h, carve_size({vb, ob}), carve_size({vb, ob})))) return rc;
+  Carver cd{(char*)h->scr_dev}, cp{(char*)h->scr_pin};
+  double* d_v = cd.take<double>((size_t)n * k); double* d_o = cd.take<double>(ng * k);
+  double* p_v = cp.take<double>((size_t)n * k); double* p_o = cp.take<double>(ng * k);
+  memcpy(p_v, values, vb);
+  hipError_t e = hipMemcpyAsync(d_v, p_v, vb, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = psm_launch_interp_to_grid(d_v, k, h->d_vtx_m2g, h->d_wts_m2g, h->d_src_of_cell, fill, d_o, (int64_t)ng, st);
-  if (e == hipSuccess) e = hipMemcpyAsync(grid_out, d_o, ng * k * sizeof(double), hipMemcpyDeviceToHost, st);
-  if (e == hipSuccess) e = hipStreamSynchronize(st);
-  dev_free(d_v); dev_free(d_o);
+  if (e == hipSuccess) e = hipMemcpyAsync(p_o, d_o, ob, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = wait_stream(st);
+  if (e == hipSuccess) memcpy(grid_out, p_o, ob);
   if (e != hipSuccess) return fail(h, PSM_ERR_HIP, std::string("mesh_to_grid: ") + hipGetErrorString(e));
   return PSM_OK;
 }
@@ -1296,27 +1336,25 @@ int psm_poisson_features(psm_handle* h, const double* ux, const double* uy, cons
   HIPCHK(h, hipSetDevice(h->cfg.device));
   hipStream_t st = h->stream;
   const size_t n = (size_t)ny * nx, nwg = (n + 255) / 256;
-  double *d_in = nullptr, *d_term = nullptr, *d_part = nullptr;
-  float* d_grid = nullptr;
   int rc;
-  if ((rc = dev_alloc(h, &d_in, 5 * n)) || (rc = dev_alloc(h, &d_term, n)) || (rc = dev_alloc(h, &d_part, 2 * nwg)) ||
-      (rc = dev_alloc(h, &d_grid, 4 * n))) {
-    dev_free(d_in); dev_free(d_term); dev_free(d_part); dev_free(d_grid);
-    return rc;
-  }
+  const size_t ib = 5 * n * sizeof(double), gb = 4 * n * sizeof(float);
+  if ((rc = scratch_reserve(h, carve_size({ib, n * sizeof(double), 2 * nwg * sizeof(double), gb}), carve_size({ib, gb})))) return rc;
+  Carver cd{(char*)h->scr_dev}, cp{(char*)h->scr_pin};
+  double* d_in = cd.take<double>(5 * n); double* d_term = cd.take<double>(n); double* d_part = cd.take<double>(2 * nwg);
+  float* d_grid = cd.take<float>(4 * n);
+  double* p_in = cp.take<double>(5 * n); float* p_grid = cp.take<float>(4 * n);
   const double* src[5] = {ux, uy, dux, duy, sdfunct};
-  hipError_t e = hipSuccess;
-  for (int q = 0; q < 5 && e == hipSuccess; ++q)
-    e = hipMemcpyAsync(d_in + q * n, src[q], n * sizeof(double), hipMemcpyHostToDevice, st);
+  for (int q = 0; q < 5; ++q) memcpy(p_in + q * n, src[q], n * sizeof(double));
+  hipError_t e = hipMemcpyAsync(d_in, p_in, ib, hipMemcpyHostToDevice, st);
   PsmFeatureArgs fa{};
   fa.ux = d_in; fa.uy = d_in + n; fa.dux = d_in + 2 * n; fa.duy = d_in + 3 * n; fa.sdf = d_in + 4 * n;
   fa.term = d_term; fa.partial = d_part; fa.grid = d_grid; fa.ny = ny; fa.nx = nx;
   fa.L = params[0]; fa.U = params[1]; fa.k = params[2];
   for (int q = 0; q < 4; ++q) fa.max_abs[q] = params[3 + q];
   if (e == hipSuccess) e = psm_launch_poisson_features(fa, st);
-  if (e == hipSuccess) e = hipMemcpyAsync(grid_out, d_grid, 4 * n * sizeof(float), hipMemcpyDeviceToHost, st);
-  if (e == hipSuccess) e = hipStreamSynchronize(st);
-  dev_free(d_in); dev_free(d_term); dev_free(d_part); dev_free(d_grid);
+  if (e == hipSuccess) e = hipMemcpyAsync(p_grid, d_grid, gb, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = wait_stream(st);
+  if (e == hipSuccess) memcpy(grid_out, p_grid, gb);
   if (e != hipSuccess) return fail(h, PSM_ERR_HIP, std::string("poisson features: ") + hipGetErrorString(e));
   return PSM_OK;
 }
@@ -1380,10 +1418,16 @@ int psm_integrate_gradp(psm_handle* h, const float* gradp, float* p_out) {
   HIPCHK(h, hipSetDevice(h->cfg.device));
   hipStream_t st = h->stream;
   const size_t n = (size_t)h->integ.ny * h->integ.nx;
-  HIPCHK(h, hipMemcpyAsync(h->d_gradp, gradp, n * 2 * sizeof(float), hipMemcpyHostToDevice, st));
+  int rc;
+  if ((rc = scratch_reserve(h, 0, carve_size({n * 2 * sizeof(float), n * sizeof(float)})))) return rc;
+  Carver cp{(char*)h->scr_pin};
+  float* p_g = cp.take<float>(n * 2); float* p_p = cp.take<float>(n);
+  memcpy(p_g, gradp, n * 2 * sizeof(float));
+  HIPCHK(h, hipMemcpyAsync(h->d_gradp, p_g, n * 2 * sizeof(float), hipMemcpyHostToDevice, st));
   HIPCHK(h, psm_launch_integrate(h->integ, st));
-  HIPCHK(h, hipMemcpyAsync(p_out, h->integ.p_out, n * sizeof(float), hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipStreamSynchronize(st));
+  HIPCHK(h, hipMemcpyAsync(p_p, h->integ.p_out, n * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, wait_stream(st));
+  memcpy(p_out, p_p, n * sizeof(float));
   return PSM_OK;
 }
 
