@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PSM_ABI_VERSION 2
+#define PSM_ABI_VERSION 3
 
 /* block layout + reassembly variant */
 #define PSM_VARIANT_CHAPTER5 0 /* PM:303-332, 373-472 */
@@ -121,6 +121,8 @@ int psm_set_scaler(psm_handle* h, const double* in_a, const double* in_b,
 int psm_plan_grid(psm_handle* h, int32_t ny, int32_t nx);
 /* Number of blocks per case of the current plan (len(x_list), PM:332). */
 int psm_num_blocks(const psm_handle* h);
+/* shape[4] = {ny, nx, c_in, c_out} of the current plan. */
+int psm_grid_shape(const psm_handle* h, int32_t* shape);
 
 /* Bind the geometry of the planned grid for the following solves -- the drop-in counterpart of the reference's
  * computeOnlyOnce / init_func split (SM_call.py:89-178, python_module.py:172-246: everything that depends on the
@@ -157,18 +159,37 @@ int psm_geometry_bound(const psm_handle* h);   /* 1 while a geometry is bound */
  * Synchronous, like py_func. */
 int psm_solve_grid(psm_handle* h, const float* grid, int32_t n_cases,
                    const float* out_scale, float* fields);
-/* Host buffers, asynchronous: a ring of PSM_RING_SLOTS pinned staging slots.  psm_submit_grid
- * copies `grid` into the slot (the caller's buffer is free on return), enqueues H2D on a copy
- * stream, the solve on the compute stream and D2H on a second copy stream, and returns a
- * ticket; psm_wait_grid blocks until that ticket's field has arrived and copies it to
- * `fields`.  With several tickets in flight the copies of neighbouring tickets overlap the
- * kernels (the reference's py_func is synchronous, PM:249-517; this is the form for a caller
- * that owns several independent cases or time steps, e.g. an ensemble of PISO runs).
- * Tickets must be waited for in submission order before their slot is needed again:
- * PSM_ERR_STATE if PSM_RING_SLOTS tickets are already in flight. */
+/* Host buffers, asynchronous: a ring of PSM_RING_SLOTS slots, each with its own pinned host buffers, device buffers,
+ * scratch, stream and hipGraph (H2D copy -> kernels -> D2H copy = ONE graph replay per ticket), so the copies of
+ * neighbouring tickets run on the DMA engines while another ticket's kernels compute (the reference's py_func is
+ * synchronous, PM:249-517; this is the form for a caller that owns several independent cases or time steps, e.g. an
+ * ensemble of PISO runs).  A slot must have been waited for before it comes round again: PSM_ERR_STATE if
+ * PSM_RING_SLOTS tickets are already in flight.  A geometry bound with psm_bind_geometry applies to the ring as well.
+ *
+ * Three ways in, fastest first:
+ *  (1) zero-copy: psm_ring_acquire hands out the next slot's pinned buffers; the caller packs its grid
+ *      [n_cases, ny, nx, c_in] straight into *grid_in (the pack of PythonComm.H:2-9 written to pinned memory instead of
+ *      `input_vals`), psm_ring_submit enqueues the ticket, psm_ring_wait returns when *fields_out
+ *      [n_cases, ny, nx, c_out] holds the result.  *fields_out stays valid until the ticket that reuses the slot
+ *      (PSM_RING_SLOTS tickets later) is submitted.
+ *  (2) caller-registered memory: after psm_host_register(range) psm_submit_grid_io DMAs straight from `grid` and,
+ *      when `fields` lies in a registered range too, straight into `fields` (psm_wait_grid(h, t, NULL) then only
+ *      waits).  The caller keeps the ranges allocated until psm_host_unregister / psm_destroy and must not touch
+ *      `grid` before the wait returns.  psm_solve_grid uses registered ranges the same way.
+ *  (3) pageable memory: psm_submit_grid copies `grid` into the slot (the caller's buffer is free on return) and
+ *      psm_wait_grid copies the field out. */
 #define PSM_RING_SLOTS 4
+int psm_ring_acquire(psm_handle* h, int64_t* ticket, float** grid_in, float** fields_out);
+int psm_ring_submit(psm_handle* h, int64_t ticket, int32_t n_cases, const float* out_scale);
+int psm_ring_wait(psm_handle* h, int64_t ticket);
+int psm_host_register(psm_handle* h, void* ptr, size_t bytes);
+int psm_host_unregister(psm_handle* h, void* ptr);
+/* fields may be NULL (destination given to psm_wait_grid instead). */
+int psm_submit_grid_io(psm_handle* h, const float* grid, int32_t n_cases, const float* out_scale, float* fields,
+                       int64_t* ticket);
 int psm_submit_grid(psm_handle* h, const float* grid, int32_t n_cases,
                     const float* out_scale, int64_t* ticket);
+/* fields == NULL: the destination given to psm_submit_grid_io. */
 int psm_wait_grid(psm_handle* h, int64_t ticket, float* fields);
 /* Device buffers (HIP pointers on cfg.device), asynchronous on `stream`
  * (hipStream_t; NULL = the handle's own stream).  out_scale is a HOST pointer
@@ -265,6 +286,25 @@ int psm_profile_solve(psm_handle* h, const float* d_grid, int32_t n_cases,
  * event pair adds to a single launch. */
 int psm_enable_kernel_timing(psm_handle* h, int32_t kernel, int32_t on);
 int psm_get_kernel_timing(psm_handle* h, int32_t kernel, double* total_ms, int64_t* launches);
+
+/* Dispatch-level time of EVERY kernel of the solve path: `steps` solves of d_grid through the launch sequence of
+ * psm_solve_grid_device on the handle's stream, each dispatch stamped with its own begin / end by
+ * hipExtLaunchKernelGGL (the timestamps rocprofv3 --kernel-trace reads).  names [cap][64] receives the kernel
+ * names in first-launch order, total_ms / launches [cap] their accumulated duration and dispatch count,
+ * *n_kernels the number of distinct kernels (may exceed cap). */
+int psm_time_kernels(psm_handle* h, const float* d_grid, int32_t n_cases, float* d_fields, int32_t steps, char* names,
+                     double* total_ms, int64_t* launches, int32_t cap, int32_t* n_kernels);
+/* Host-buffer throughput measured from a C++ loop on the calling thread (no per-call binding overhead), through the
+ * public entries only: `steps` solves of the `n_inputs` host grids [n_inputs][n_cases, ny, nx, c_in] in rotation after
+ * `warmup` untimed ones; *seconds = wall time of the timed solves (steady_clock, first submission to last result).
+ *   mode 0  psm_solve_grid, pageable caller memory (the synchronous py_func contract)
+ *   mode 1  psm_submit_grid / psm_wait_grid ring, pageable caller memory, `depth` tickets in flight
+ *   mode 2  psm_submit_grid_io ring on caller-registered memory (grids and result buffers registered for the run)
+ *   mode 3  psm_ring_acquire / submit / wait: the slots' pinned buffers hold the inputs (packed before the timed
+ *           region, like a solver that writes its fields straight into the slot), results are left in the slots
+ * last_fields (optional) receives the result of the last solve [n_cases, ny, nx, c_out]. */
+int psm_bench_host(psm_handle* h, const float* grids, int32_t n_inputs, int32_t n_cases, int32_t mode, int32_t depth,
+                   int32_t steps, int32_t warmup, double* seconds, float* last_fields);
 
 /* Median elapsed time (ms) of `n` EMPTY HIP event pairs recorded back to back on the launch
  * stream: the cost of the event timing itself, to be subtracted from per-launch event times. */

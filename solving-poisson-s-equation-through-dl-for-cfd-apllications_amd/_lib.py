@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("PSM_LIB") or os.path.join(HERE, "libpsm_hip.so")   # 
 HEADER = os.path.join(os.path.dirname(HERE), "include", "psm.h")
 HEADER_UNET = os.path.join(os.path.dirname(HERE), "include", "psm_unet.h")
 
-PSM_ABI_VERSION = 2
+PSM_ABI_VERSION = 3
 VARIANTS = {"chapter5": 0, "deltas": 1, "gradp": 2}
 SCALERS = {"max_abs": 0, "std": 1, "min_max": 2}
 PRECISIONS = {"f32": 0, "bf16": 1}
@@ -59,6 +59,13 @@ SIGNATURES = {
     "psm_unbind_geometry": (C.c_int, [_hp]),
     "psm_geometry_bound": (C.c_int, [_hp]),
     "psm_solve_grid": (C.c_int, [_hp, _f32p, C.c_int32, _f32p, _f32p]),
+    "psm_grid_shape": (C.c_int, [_hp, _i32p]),
+    "psm_ring_acquire": (C.c_int, [_hp, C.POINTER(C.c_int64), C.POINTER(_f32p), C.POINTER(_f32p)]),
+    "psm_ring_submit": (C.c_int, [_hp, C.c_int64, C.c_int32, _f32p]),
+    "psm_ring_wait": (C.c_int, [_hp, C.c_int64]),
+    "psm_host_register": (C.c_int, [_hp, C.c_void_p, C.c_size_t]),
+    "psm_host_unregister": (C.c_int, [_hp, C.c_void_p]),
+    "psm_submit_grid_io": (C.c_int, [_hp, _f32p, C.c_int32, _f32p, _f32p, C.POINTER(C.c_int64)]),
     "psm_submit_grid": (C.c_int, [_hp, _f32p, C.c_int32, _f32p, C.POINTER(C.c_int64)]),
     "psm_wait_grid": (C.c_int, [_hp, C.c_int64, _f32p]),
     "psm_solve_grid_device": (C.c_int, [_hp, C.c_void_p, C.c_int32, _f32p, C.c_void_p, C.c_void_p]),
@@ -79,6 +86,10 @@ SIGNATURES = {
     "psm_enable_kernel_timing": (C.c_int, [_hp, C.c_int32, C.c_int32]),
     "psm_get_kernel_timing": (C.c_int, [_hp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "psm_event_pair_overhead": (C.c_int, [_hp, C.c_int32, C.POINTER(C.c_double)]),
+    "psm_time_kernels": (C.c_int, [_hp, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_char_p, C.POINTER(C.c_double),
+                                   C.POINTER(C.c_int64), C.c_int32, _i32p]),
+    "psm_bench_host": (C.c_int, [_hp, _f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                 C.POINTER(C.c_double), _f32p]),
     "psm_layout": (C.c_int, [C.c_int32] * 5 + [_i32p, C.c_int32, _i32p, _i32p]),
     "psm_owner_map": (C.c_int, [C.c_int32] * 6 + [_i32p]),
     "psm_debug_reassemble_host": (C.c_int, [C.c_int32] * 9 + [_f32p, _f32p, _f32p, _f32p, _f32p]),

@@ -4,7 +4,11 @@
 // usable device psm_create fails with PSM_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <sched.h>
+
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -35,6 +39,17 @@ struct GraphKey {
   int n; const void* g; void* f;
   bool operator<(const GraphKey& o) const { return std::tie(n, g, f) < std::tie(o.n, o.g, o.f); }
 };
+
+// Everything ONE in-flight solve writes.  The handle owns one for the synchronous / device entries (ws0) and one per
+// ring slot, so that the solves of neighbouring tickets run on their own streams without sharing scratch.
+struct Workspace {
+  float *d_part = nullptr, *d_xin = nullptr, *d_act[2] = {nullptr, nullptr}, *d_res = nullptr, *d_pred = nullptr;
+  float *d_row_scale = nullptr;
+  float4* d_spart = nullptr;
+  float2* d_colpart = nullptr;
+  float *d_offs = nullptr, *d_shift = nullptr;
+  float* d_dots = nullptr;            // strip dots of the geometry-bound path (allocated by the bind)
+};
 }  // namespace
 
 struct psm_handle {
@@ -50,16 +65,13 @@ struct psm_handle {
   bool planned = false;
   PsmPlan plan;
   int Ny = 0, Nx = 0, B = 0, Mcap = 0, Mpad_cap = 0, n_strips = 0, Lmax = 0, max_width = 0;
-  float *d_part = nullptr, *d_xin = nullptr, *d_act[2] = {nullptr, nullptr}, *d_res = nullptr, *d_pred = nullptr;
+  Workspace ws0;
   int64_t* d_row_base = nullptr;
-  float *d_row_scale = nullptr, *d_ones = nullptr;
+  float* d_ones = nullptr;
   int32_t *d_strips = nullptr, *d_blk = nullptr, *d_owner = nullptr, *d_shiftA = nullptr, *d_shiftB = nullptr, *d_shiftOwnA = nullptr, *d_shiftOwnB = nullptr;
   float* d_shiftW = nullptr;
   PsmBlock* d_blocks = nullptr;
-  float4* d_spart = nullptr;
-  float2* d_colpart = nullptr;
   int n_bands = 0;
-  float *d_offs = nullptr, *d_shift = nullptr;
   unsigned long long* d_stamps = nullptr;
   // mesh-side tables (psm_set_geometry)
   bool have_geometry = false, have_g2m = false;
@@ -81,16 +93,27 @@ struct psm_handle {
   float *d_grid_stage = nullptr, *d_fields_stage = nullptr;
   float *h_grid = nullptr, *h_fields = nullptr;
   // host-buffer submission ring (psm_submit_grid / psm_wait_grid): pinned in/out + device in/out per slot
+  // One ring slot = pinned host buffers + device buffers + its own workspace, stream and graphs: the H2D copy, the
+  // kernels and the D2H copy of a ticket run in order on the slot's stream, different slots overlap freely.
   struct Slot {
-    float *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr;
-    hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr;
-    int64_t ticket = -1;       // ticket in flight in this slot, -1 = free
+    float *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr, *h_rs = nullptr;
+    Workspace ws;
+    hipStream_t st = nullptr;
+    hipEvent_t ev_out = nullptr;
+    hipGraphExec_t g_full = nullptr, g_kern = nullptr;   // H2D + kernels + D2H on the slot's own buffers / the kernels alone
+    int g_full_key = -1, g_kern_key = -1;
+    int state = 0;             // 0 free, 1 acquired (the caller is packing), 2 in flight
+    int64_t ticket = -1;
     int n_cases = 0;
+    float* user_out = nullptr; // where psm_wait_grid copies to when the caller gave the pointer at submission
+    bool direct_out = false;   // the D2H went straight into user_out (registered memory)
   };
   static constexpr int SLOTS = PSM_RING_SLOTS;
   Slot slot[SLOTS];
+  bool ring_ready = false;
+  int ring_graph = 1;          // PSM_RING_GRAPH=0: plain launches on the slot streams
   int64_t next_ticket = 0;
-  hipStream_t stream_in = nullptr, stream_out = nullptr;
+  std::vector<std::pair<char*, size_t>> host_regs;   // psm_host_register
   // row-scale upload ring (pinned)
   static constexpr int RING = 8;
   float* h_scale[RING] = {};
@@ -111,7 +134,8 @@ struct psm_handle {
   int bound_rows = 0;                   // table rows per case
   int bound_cases = 0;                  // cases bound (solves with exactly this many cases take the bound path)
   float *d_comp_nat = nullptr;          // comp_out in natural layout [ld_out][K_out] (f32 precision only)
-  float *d_g2 = nullptr, *d_c2 = nullptr, *d_cnt = nullptr, *d_dots = nullptr;
+  float *d_g2 = nullptr, *d_c2 = nullptr, *d_cnt = nullptr;
+  size_t bound_dots = 0;                // floats of Workspace::d_dots
   int32_t* d_row_of = nullptr;
   uint32_t* d_ownbits = nullptr;
   int debug_skip = 0;                   // PSM_DEBUG_SKIP bit mask of kernel groups NOT launched (timing experiments only)
@@ -128,19 +152,47 @@ struct psm_handle {
 namespace {
 
 // The synchronous entries last ~100 us: they poll the stream / event instead of sleeping in hip*Synchronize (the
-// wake-up of a blocked thread alone costs 10-20 us per call); PSM_SYNC_BLOCK=1 restores the blocking waits.
-bool sync_blocks() { static const bool b = getenv("PSM_SYNC_BLOCK") != nullptr; return b; }
-hipError_t wait_stream(hipStream_t st) {
-  if (sync_blocks()) return hipStreamSynchronize(st);
+// wake-up of a blocked thread alone costs 10-20 us per call) -- but only for a bounded time (PSM_SPIN_US, default
+// 300 us), after which the thread blocks, and never when this process shares its cores with more MPI / torchrun
+// ranks than it has cores (a spinning rank would then steal the time of another rank's solver thread).
+// PSM_SYNC_BLOCK=1 forces blocking waits, PSM_SYNC_BLOCK=0 forces the bounded spin.
+int local_ranks_from_env() {
+  for (const char* k : {"OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS", "PMI_LOCAL_SIZE", "SLURM_NTASKS_PER_NODE", "LOCAL_WORLD_SIZE"}) {
+    const char* v = getenv(k);
+    if (v && atoi(v) > 0) return atoi(v);
+  }
+  return 1;
+}
+bool sync_blocks() {
+  static const bool b = [] {
+    const char* e = getenv("PSM_SYNC_BLOCK");
+    if (e) return e[0] != '0';
+    cpu_set_t set;
+    int cores = 0;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) cores = CPU_COUNT(&set);
+    if (cores <= 0) cores = (int)std::thread::hardware_concurrency();
+    return local_ranks_from_env() > cores;       // oversubscribed: sleep instead of spinning
+  }();
+  return b;
+}
+double spin_budget_us() { static const double v = [] { const char* e = getenv("PSM_SPIN_US"); return e ? atof(e) : 300.0; }(); return v; }
+template <typename Query, typename Block>
+hipError_t bounded_wait(Query query, Block block) {
+  if (sync_blocks()) return block();
+  const auto t0 = std::chrono::steady_clock::now();
   hipError_t e;
-  while ((e = hipStreamQuery(st)) == hipErrorNotReady) { }
+  int n = 0;
+  while ((e = query()) == hipErrorNotReady) {
+    if ((++n & 63) == 0 && std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > spin_budget_us())
+      return block();
+  }
   return e;
 }
+hipError_t wait_stream(hipStream_t st) {
+  return bounded_wait([&] { return hipStreamQuery(st); }, [&] { return hipStreamSynchronize(st); });
+}
 hipError_t wait_event(hipEvent_t ev) {
-  if (sync_blocks()) return hipEventSynchronize(ev);
-  hipError_t e;
-  while ((e = hipEventQuery(ev)) == hipErrorNotReady) { }
-  return e;
+  return bounded_wait([&] { return hipEventQuery(ev); }, [&] { return hipEventSynchronize(ev); });
 }
 
 int fail(psm_handle* h, int code, const std::string& msg);
@@ -202,27 +254,67 @@ int scratch_reserve(psm_handle* h, size_t dev_bytes, size_t pin_bytes) {
   return PSM_OK;
 }
 
+void ring_drop_graphs(psm_handle* h);
 void destroy_graphs(psm_handle* h) {
   for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
   h->graphs.clear();
+  ring_drop_graphs(h);
+}
+
+void ws_free(Workspace& w) {
+  dev_free(w.d_part); dev_free(w.d_xin); dev_free(w.d_act[0]); dev_free(w.d_act[1]); dev_free(w.d_res); dev_free(w.d_pred);
+  dev_free(w.d_row_scale); dev_free(w.d_spart); dev_free(w.d_colpart); dev_free(w.d_offs); dev_free(w.d_shift); dev_free(w.d_dots);
+}
+
+int ws_alloc(psm_handle* h, Workspace& w) {
+  int rc;
+  if ((rc = dev_alloc(h, &w.d_part, (size_t)h->n_slices * h->Mpad_cap * h->ld_in))) return rc;
+  if ((rc = dev_alloc(h, &w.d_xin, (size_t)h->Mpad_cap * h->ld_in))) return rc;
+  if ((rc = dev_alloc(h, &w.d_act[0], (size_t)h->Mpad_cap * h->max_width))) return rc;
+  if ((rc = dev_alloc(h, &w.d_act[1], (size_t)h->Mpad_cap * h->max_width))) return rc;
+  if ((rc = dev_alloc(h, &w.d_res, (size_t)h->Mpad_cap * h->ld_out))) return rc;
+  if ((rc = dev_alloc(h, &w.d_pred, (size_t)h->Mcap * h->K_out))) return rc;
+  if ((rc = dev_alloc(h, &w.d_row_scale, (size_t)h->Mpad_cap))) return rc;
+  if ((rc = dev_alloc(h, &w.d_spart, (size_t)h->cfg.max_cases * h->B * h->n_bands * h->plan.cp.NS))) return rc;
+  if (h->cfg.variant == PSM_VARIANT_GRADP)
+    if ((rc = dev_alloc(h, &w.d_colpart, (size_t)h->cfg.max_cases * h->n_bands * 128))) return rc;
+  if ((rc = dev_alloc(h, &w.d_offs, (size_t)h->cfg.max_cases * h->cfg.c_out * h->B))) return rc;
+  if ((rc = dev_alloc(h, &w.d_shift, (size_t)h->cfg.max_cases * h->cfg.c_out))) return rc;
+  // padding rows / columns of the slabs and activations are read by the kernels: they must stay zero
+  HIPCHK(h, hipMemset(w.d_part, 0, (size_t)h->n_slices * h->Mpad_cap * h->ld_in * sizeof(float)));
+  HIPCHK(h, hipMemset(w.d_act[0], 0, (size_t)h->Mpad_cap * h->max_width * sizeof(float)));
+  HIPCHK(h, hipMemset(w.d_act[1], 0, (size_t)h->Mpad_cap * h->max_width * sizeof(float)));
+  if (h->bound && h->bound_dots) { if ((rc = dev_alloc(h, &w.d_dots, h->bound_dots))) return rc; }
+  return PSM_OK;
+}
+
+void ring_drop_graphs(psm_handle* h) {
+  for (auto& s : h->slot) {
+    if (s.g_full) { (void)hipGraphExecDestroy(s.g_full); s.g_full = nullptr; }
+    if (s.g_kern) { (void)hipGraphExecDestroy(s.g_kern); s.g_kern = nullptr; }
+    s.g_full_key = s.g_kern_key = -1;
+  }
 }
 
 void free_plan(psm_handle* h) {
+  ring_drop_graphs(h);
   for (auto& s : h->slot) {
+    if (s.st) { (void)hipStreamSynchronize(s.st); (void)hipStreamDestroy(s.st); }
     if (s.h_in) (void)hipHostFree(s.h_in);
     if (s.h_out) (void)hipHostFree(s.h_out);
+    if (s.h_rs) (void)hipHostFree(s.h_rs);
     if (s.d_in) (void)hipFree(s.d_in);
     if (s.d_out) (void)hipFree(s.d_out);
-    if (s.ev_in) (void)hipEventDestroy(s.ev_in);
-    if (s.ev_done) (void)hipEventDestroy(s.ev_done);
     if (s.ev_out) (void)hipEventDestroy(s.ev_out);
+    ws_free(s.ws);
     s = psm_handle::Slot{};
   }
+  h->ring_ready = false;
   destroy_graphs(h);
-  dev_free(h->d_part); dev_free(h->d_xin); dev_free(h->d_act[0]); dev_free(h->d_act[1]); dev_free(h->d_res);
-  dev_free(h->d_pred); dev_free(h->d_row_base); dev_free(h->d_row_scale); dev_free(h->d_ones); dev_free(h->d_strips);
+  ws_free(h->ws0);
+  dev_free(h->d_row_base); dev_free(h->d_ones); dev_free(h->d_strips);
   dev_free(h->d_blk); dev_free(h->d_owner); dev_free(h->d_shiftA); dev_free(h->d_shiftB); dev_free(h->d_shiftOwnA); dev_free(h->d_shiftOwnB); dev_free(h->d_shiftW); dev_free(h->d_blocks);
-  dev_free(h->d_spart); dev_free(h->d_colpart); dev_free(h->d_offs); dev_free(h->d_shift); dev_free(h->d_stamps); dev_free(h->d_grid_stage); dev_free(h->d_fields_stage);
+  dev_free(h->d_stamps); dev_free(h->d_grid_stage); dev_free(h->d_fields_stage);
   if (h->h_grid) { (void)hipHostFree(h->h_grid); h->h_grid = nullptr; }
   if (h->h_fields) { (void)hipHostFree(h->h_fields); h->h_fields = nullptr; }
   h->planned = false;
@@ -356,7 +448,7 @@ struct Timer {                      // optional event pair around one kernel gro
   }
 };
 
-int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields, const float* d_row_scale,
+int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, float* d_fields, const float* d_row_scale,
                hipStream_t st, hipEvent_t* prof) {
   const int M = n_cases * h->B, Mpad = round_up(M, 32);
   Timer tm{h, st, 0, prof};
@@ -364,7 +456,7 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
   // geometry-bound fast path: one case, nothing but the encode group being timed / skipped
   const bool use_bound = h->bound && (h->bound_scope == 2 || h->in_mesh_solve) && n_cases == h->bound_cases && (h->timed_kernel < 0 || h->timed_kernel == PSM_K_ENCODE) && h->debug_skip == 0;
   PsmEncodeArgs ea{};
-  ea.grid = d_grid; ea.mean = h->d_mean_in; ea.bpack = h->d_bpack_in; ea.part = h->d_part;
+  ea.grid = d_grid; ea.mean = h->d_mean_in; ea.bpack = h->d_bpack_in; ea.part = w.d_part;
   ea.row_base = h->d_row_base; ea.row_stride = (int64_t)h->Nx * h->cfg.c_in;
   ea.M = M; ea.Mpad = Mpad; ea.NT = h->NT; ea.ldp = h->ld_in; ea.S = h->S; ea.c_in = h->cfg.c_in;
   bool aligned = ((h->Nx * h->cfg.c_in) % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_grid) & 15) == 0) &&
@@ -384,7 +476,7 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
     tm.after(PSM_K_ENCODE);
   }
 
-  PsmReduceArgs ra{h->d_part, h->d_xin, h->d_ia, h->d_ib, h->n_slices, Mpad, h->ld_in};
+  PsmReduceArgs ra{w.d_part, w.d_xin, h->d_ia, h->d_ib, h->n_slices, Mpad, h->ld_in};
   const int nl = (int)h->dense.size();
   auto dense_args = [&](int l, const float* cur, int ld_cur) {
     const DenseLayer& d = h->dense[l];
@@ -392,7 +484,7 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
     PsmDenseArgs da{};
     da.in = cur; da.ld_in = ld_cur; da.W = d.W; da.ld_w = d.ldw; da.bias = d.b; da.Wp = d.Wp; da.Kp = d.Kp;
     da.sa = h->d_sa; da.sb = h->d_sb;
-    da.out = head ? h->d_res : h->d_act[l & 1]; da.ld_out = d.ldw;
+    da.out = head ? w.d_res : w.d_act[l & 1]; da.ld_out = d.ldw;
     da.Kpad = d.Kpad; da.Mpad = Mpad; da.relu = head ? 0 : 1; da.head = head ? 1 : 0;
     da.bf16 = (h->cfg.precision == PSM_PRECISION_BF16) ? 1 : 0;
     da.layer = l;
@@ -413,7 +505,7 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
     tm.before(PSM_K_MLP);
   }
   PSM_REPEAT(h, PSM_K_MLP) {
-    const float* cur = h->d_xin; int ld_cur = h->ld_in;
+    const float* cur = w.d_xin; int ld_cur = h->ld_in;
     l_first = 0;
     if (fuse1) {
       PsmDenseArgs d0 = dense_args(0, cur, ld_cur);
@@ -424,7 +516,7 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
     for (int l = l_first; l < nl; ++l) {
       PsmDenseArgs da = dense_args(l, cur, ld_cur);
       if (use_bound && !bf16 && l == nl - 1) { // head layer + strip dots of the bound geometry in one launch
-        PsmDotsArgs dd{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, h->d_dots, h->bound_rows * n_cases, h->dense[nl - 1].Kpad};
+        PsmDotsArgs dd{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, w.d_dots, h->bound_rows * n_cases, h->dense[nl - 1].Kpad};
         HIPCHK(h, psm_launch_dense_dots(da, dd, st));
       } else {
         HIPCHK(h, psm_launch_dense(da, st));
@@ -435,21 +527,21 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
   tm.after(PSM_K_MLP);
   if (use_bound) {
     PsmDecodeArgs de{};
-    de.res = h->d_res; de.ld_res = h->ld_out; de.bpack = h->d_bpack_out; de.mean = h->d_mean_out;
+    de.res = w.d_res; de.ld_res = h->ld_out; de.bpack = h->d_bpack_out; de.mean = h->d_mean_out;
     de.row_scale = d_row_scale; de.pred = nullptr; de.M = M; de.Mpad = Mpad; de.Gd = h->Gd;
     de.n_coltiles = h->n_coltiles; de.K_out = h->K_out;
     PsmBoundArgs ba{};
-    ba.cp = h->plan.cp; ba.blocks = h->d_blocks; ba.dots = h->d_dots; ba.scnt = h->d_cnt; ba.ownbits = h->d_ownbits;
+    ba.cp = h->plan.cp; ba.blocks = h->d_blocks; ba.dots = w.d_dots; ba.scnt = h->d_cnt; ba.ownbits = h->d_ownbits;
     ba.blk_y0x0 = h->d_blk; ba.shiftW = h->d_shiftW;
     for (int f = 0; f < 2; ++f) ba.shiftL[f] = (int)h->plan.shiftA[f].size();
-    ba.fields = d_fields; ba.offs = h->d_offs; ba.shift = h->d_shift; ba.Nx = h->Nx; ba.n_strips = h->n_strips; ba.B = h->B;
+    ba.fields = d_fields; ba.offs = w.d_offs; ba.shift = w.d_shift; ba.Nx = h->Nx; ba.n_strips = h->n_strips; ba.B = h->B;
     if (h->bound_zero_fill)                    // cells no block covers stay 0 like the reference's np.zeros field
       HIPCHK(h, hipMemsetAsync(d_fields, 0, (size_t)n_cases * h->Ny * h->Nx * h->cfg.c_out * sizeof(float), st));
     if (n_cases == 1 && h->B <= 64) {
       tm.before(PSM_K_DECODE);
       if (bf16) {                               // strip dots from the bf16-rounded res (own small launch)
-        PsmDotsArgs dd{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, h->d_dots, h->bound_rows, h->ld_out};
-        HIPCHK(h, psm_launch_res_dots(dd, h->d_res, h->ld_out, st));
+        PsmDotsArgs dd{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, w.d_dots, h->bound_rows, h->ld_out};
+        HIPCHK(h, psm_launch_res_dots(dd, w.d_res, h->ld_out, st));
       }
       PSM_REPEAT(h, PSM_K_DECODE) HIPCHK(h, psm_launch_decode_paste(de, ba, h->cfg.c_out, st, bf16 ? 1 : 0));
       tm.after(PSM_K_DECODE);
@@ -460,17 +552,17 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
     }
     // case batch: the chains of all cases in one small launch, then decode + paste over all block rows
     PsmBoundBatchArgs bb{};
-    bb.cp = h->plan.cp; bb.blocks = h->d_blocks; bb.dots = h->d_dots; bb.scnt = h->d_cnt; bb.ownbits = h->d_ownbits;
+    bb.cp = h->plan.cp; bb.blocks = h->d_blocks; bb.dots = w.d_dots; bb.scnt = h->d_cnt; bb.ownbits = h->d_ownbits;
     bb.blk_y0x0 = h->d_blk; bb.shiftW = h->d_shiftW;
     for (int f = 0; f < 2; ++f) bb.shiftL[f] = (int)h->plan.shiftA[f].size();
-    bb.fields = d_fields; bb.offs = h->d_offs; bb.shift = h->d_shift; bb.Nx = h->Nx; bb.npix = h->Ny * h->Nx;
+    bb.fields = d_fields; bb.offs = w.d_offs; bb.shift = w.d_shift; bb.Nx = h->Nx; bb.npix = h->Ny * h->Nx;
     bb.n_strips = h->n_strips; bb.B = h->B; bb.rows_pc = h->bound_rows; bb.n_cases = n_cases;
     tm.before(PSM_K_DECODE); tm.after(PSM_K_DECODE);
     tm.before(PSM_K_STRIPS); tm.after(PSM_K_STRIPS);
     tm.before(PSM_K_CHAIN);
     if (bf16) {                                 // strip dots from the bf16-rounded res (own small launch)
-      PsmDotsArgs dd{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, h->d_dots, h->bound_rows * n_cases, h->ld_out};
-      HIPCHK(h, psm_launch_res_dots(dd, h->d_res, h->ld_out, st));
+      PsmDotsArgs dd{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, w.d_dots, h->bound_rows * n_cases, h->ld_out};
+      HIPCHK(h, psm_launch_res_dots(dd, w.d_res, h->ld_out, st));
     }
     HIPCHK(h, psm_launch_chain_dots(bb, h->cfg.c_out, st));
     tm.after(PSM_K_CHAIN);
@@ -481,15 +573,15 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
   }
 
   PsmDecodeArgs de{};
-  de.res = h->d_res; de.ld_res = h->ld_out; de.bpack = h->d_bpack_out; de.mean = h->d_mean_out;
-  de.row_scale = d_row_scale; de.pred = h->d_pred; de.M = M; de.Mpad = Mpad; de.Gd = h->Gd;
+  de.res = w.d_res; de.ld_res = h->ld_out; de.bpack = h->d_bpack_out; de.mean = h->d_mean_out;
+  de.row_scale = d_row_scale; de.pred = w.d_pred; de.M = M; de.Mpad = Mpad; de.Gd = h->Gd;
   de.n_coltiles = h->n_coltiles; de.K_out = h->K_out;
   tm.before(PSM_K_DECODE);
   PSM_REPEAT(h, PSM_K_DECODE) HIPCHK(h, bf16 ? psm_launch_decode_bf16(de, st) : psm_launch_decode(de, st));
   tm.after(PSM_K_DECODE);
 
   PsmStripArgs sa{};
-  sa.pred = h->d_pred; sa.grid = d_grid; sa.strips = h->d_strips; sa.blk_y0x0 = h->d_blk; sa.spart = h->d_spart; sa.colpart = h->d_colpart; sa.NS = h->plan.cp.NS; sa.n_bands = h->n_bands;
+  sa.pred = w.d_pred; sa.grid = d_grid; sa.strips = h->d_strips; sa.blk_y0x0 = h->d_blk; sa.spart = w.d_spart; sa.colpart = w.d_colpart; sa.NS = h->plan.cp.NS; sa.n_bands = h->n_bands;
   sa.B = h->B; sa.S = h->S; sa.c_in = h->cfg.c_in; sa.c_out = h->cfg.c_out;
   sa.sdf_ch = h->cfg.sdf_channel; sa.Ny = h->Ny; sa.Nx = h->Nx;
   tm.before(PSM_K_STRIPS);
@@ -497,11 +589,11 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
   tm.after(PSM_K_STRIPS);
 
   PsmChainArgs ca{};
-  ca.cp = h->plan.cp; ca.blocks = h->d_blocks; ca.spart = h->d_spart; ca.colpart = h->d_colpart; ca.n_bands = h->n_bands; ca.pred = h->d_pred; ca.owner = h->d_owner;
+  ca.cp = h->plan.cp; ca.blocks = h->d_blocks; ca.spart = w.d_spart; ca.colpart = w.d_colpart; ca.n_bands = h->n_bands; ca.pred = w.d_pred; ca.owner = h->d_owner;
   ca.shiftA = h->d_shiftA; ca.shiftB = h->d_shiftB; ca.shiftOwnA = h->d_shiftOwnA; ca.shiftOwnB = h->d_shiftOwnB; ca.shiftW = h->d_shiftW;
   for (int f = 0; f < 2; ++f) ca.shiftL[f] = (int)h->plan.shiftA[f].size();
-  ca.Lmax = h->Lmax; ca.offs = h->d_offs; ca.shift = h->d_shift; ca.n_strips = h->n_strips; ca.c_out = h->cfg.c_out; ca.stamps = h->d_stamps;
-  PsmPasteArgs pa{h->d_pred, h->d_owner, h->d_offs, h->d_shift, d_fields, h->B, h->S, h->cfg.c_out, h->Ny * h->Nx};
+  ca.Lmax = h->Lmax; ca.offs = w.d_offs; ca.shift = w.d_shift; ca.n_strips = h->n_strips; ca.c_out = h->cfg.c_out; ca.stamps = h->d_stamps;
+  PsmPasteArgs pa{w.d_pred, h->d_owner, w.d_offs, w.d_shift, d_fields, h->B, h->S, h->cfg.c_out, h->Ny * h->Nx};
   if (h->fused_assemble && n_cases < 4) {   // few blocks, few cases: every paste workgroup re-runs the chain (one launch
                                             // less); for case batches one chain workgroup per case + a streaming paste
     tm.before(PSM_K_CHAIN);
@@ -520,7 +612,7 @@ int launch_all(psm_handle* h, const float* d_grid, int n_cases, float* d_fields,
   return PSM_OK;
 }
 
-int prepare_scale(psm_handle* h, const float* out_scale, int n_cases, hipStream_t st, const float** d_scale) {
+int prepare_scale(psm_handle* h, Workspace& w, const float* out_scale, int n_cases, hipStream_t st, const float** d_scale) {
   if (!out_scale) { *d_scale = h->d_ones; return PSM_OK; }
   const int M = n_cases * h->B;
   const int slot = h->scale_pos;
@@ -528,9 +620,9 @@ int prepare_scale(psm_handle* h, const float* out_scale, int n_cases, hipStream_
   HIPCHK(h, hipEventSynchronize(h->scale_ev[slot]));
   for (int c = 0; c < n_cases; ++c)
     for (int b = 0; b < h->B; ++b) h->h_scale[slot][c * h->B + b] = out_scale[c];
-  HIPCHK(h, hipMemcpyAsync(h->d_row_scale, h->h_scale[slot], (size_t)M * sizeof(float), hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpyAsync(w.d_row_scale, h->h_scale[slot], (size_t)M * sizeof(float), hipMemcpyHostToDevice, st));
   HIPCHK(h, hipEventRecord(h->scale_ev[slot], st));
-  *d_scale = h->d_row_scale;
+  *d_scale = w.d_row_scale;
   return PSM_OK;
 }
 
@@ -543,18 +635,18 @@ int solve_device(psm_handle* h, const float* d_grid, int n_cases, const float* o
   HIPCHK(h, hipSetDevice(h->cfg.device));
   if (!st) st = h->stream;
   const float* d_scale = nullptr;
-  int rc = prepare_scale(h, out_scale, n_cases, st, &d_scale);
+  int rc = prepare_scale(h, h->ws0, out_scale, n_cases, st, &d_scale);
   if (rc) return rc;
   h->last_cases = n_cases;
   const bool eager = prof || h->timed_kernel >= 0 || !h->use_graph;
-  if (eager) return launch_all(h, d_grid, n_cases, d_fields, d_scale, st, prof);
+  if (eager) return launch_all(h, h->ws0, d_grid, n_cases, d_fields, d_scale, st, prof);
   GraphKey key{(n_cases * 2 + (out_scale ? 1 : 0)) * 2 + ((h->bound && (h->bound_scope == 2 || h->in_mesh_solve)) ? 1 : 0), d_grid, d_fields};
   auto it = h->graphs.find(key);
   if (it == h->graphs.end()) {
     if (h->graphs.size() > 64) destroy_graphs(h);
     hipGraph_t graph = nullptr;
     HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
-    rc = launch_all(h, d_grid, n_cases, d_fields, d_scale, h->stream, nullptr);
+    rc = launch_all(h, h->ws0, d_grid, n_cases, d_fields, d_scale, h->stream, nullptr);
     hipError_t e = hipStreamEndCapture(h->stream, &graph);
     if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (e != hipSuccess) return fail(h, PSM_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
@@ -642,7 +734,7 @@ void psm_destroy(psm_handle* h) {
   dev_free(h->d_mean_in); dev_free(h->d_mean_out); dev_free(h->d_bpack_in); dev_free(h->d_bpack_out);
   if (h->scr_dev) (void)hipFree(h->scr_dev);
   if (h->scr_pin) (void)hipHostFree(h->scr_pin);
-  dev_free(h->d_comp_nat); dev_free(h->d_g2); dev_free(h->d_c2); dev_free(h->d_cnt); dev_free(h->d_dots); dev_free(h->d_row_of); dev_free(h->d_ownbits);
+  dev_free(h->d_comp_nat); dev_free(h->d_g2); dev_free(h->d_c2); dev_free(h->d_cnt); dev_free(h->d_row_of); dev_free(h->d_ownbits);
   dev_free(h->d_ia); dev_free(h->d_ib); dev_free(h->d_sa); dev_free(h->d_sb);
   for (int i = 0; i < psm_handle::RING; ++i) {
     if (h->h_scale[i]) (void)hipHostFree(h->h_scale[i]);
@@ -650,8 +742,7 @@ void psm_destroy(psm_handle* h) {
   }
   for (auto& p : h->timed_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
-  if (h->stream_in) (void)hipStreamDestroy(h->stream_in);
-  if (h->stream_out) (void)hipStreamDestroy(h->stream_out);
+  for (auto& r : h->host_regs) (void)hipHostUnregister(r.first);
   delete h;
 }
 
@@ -800,19 +891,8 @@ int psm_plan_grid(psm_handle* h, int32_t ny, int32_t nx) {
   h->max_width = h->ld_in;
   for (auto& d : h->dense) h->max_width = std::max(h->max_width, d.ldw);
   const size_t npix = (size_t)ny * nx;
-  if ((rc = dev_alloc(h, &h->d_part, (size_t)h->n_slices * h->Mpad_cap * h->ld_in))) return rc;
-  if ((rc = dev_alloc(h, &h->d_xin, (size_t)h->Mpad_cap * h->ld_in))) return rc;
-  if ((rc = dev_alloc(h, &h->d_act[0], (size_t)h->Mpad_cap * h->max_width))) return rc;
-  if ((rc = dev_alloc(h, &h->d_act[1], (size_t)h->Mpad_cap * h->max_width))) return rc;
-  if ((rc = dev_alloc(h, &h->d_res, (size_t)h->Mpad_cap * h->ld_out))) return rc;
-  if ((rc = dev_alloc(h, &h->d_pred, (size_t)h->Mcap * h->K_out))) return rc;
-  if ((rc = dev_alloc(h, &h->d_row_scale, (size_t)h->Mpad_cap))) return rc;
   h->n_bands = h->S / PSM_STRIP_BAND;
-  if ((rc = dev_alloc(h, &h->d_spart, (size_t)h->cfg.max_cases * h->B * h->n_bands * h->plan.cp.NS))) return rc;
-  if (h->cfg.variant == PSM_VARIANT_GRADP)
-    if ((rc = dev_alloc(h, &h->d_colpart, (size_t)h->cfg.max_cases * h->n_bands * 128))) return rc;
-  if ((rc = dev_alloc(h, &h->d_offs, (size_t)h->cfg.max_cases * h->cfg.c_out * h->B))) return rc;
-  if ((rc = dev_alloc(h, &h->d_shift, (size_t)h->cfg.max_cases * h->cfg.c_out))) return rc;
+  if ((rc = ws_alloc(h, h->ws0))) return rc;
   if ((rc = dev_alloc(h, &h->d_stamps, (size_t)16))) return rc;
   HIPCHK(h, hipMemset(h->d_stamps, 0, 16 * sizeof(unsigned long long)));
   if ((rc = dev_alloc(h, &h->d_grid_stage, (size_t)h->cfg.max_cases * npix * h->cfg.c_in))) return rc;
@@ -868,9 +948,6 @@ int psm_plan_grid(psm_handle* h, int32_t ny, int32_t nx) {
     if ((rc = dev_upload(h, &h->d_shiftOwnB, oB))) return rc;
     if ((rc = dev_upload(h, &h->d_shiftW, w))) return rc;
   }
-  HIPCHK(h, hipMemset(h->d_part, 0, (size_t)h->n_slices * h->Mpad_cap * h->ld_in * sizeof(float)));
-  HIPCHK(h, hipMemset(h->d_act[0], 0, (size_t)h->Mpad_cap * h->max_width * sizeof(float)));
-  HIPCHK(h, hipMemset(h->d_act[1], 0, (size_t)h->Mpad_cap * h->max_width * sizeof(float)));
   HIPCHK(h, hipDeviceSynchronize());
   {
     const char* ds = getenv("PSM_DEBUG_SKIP");
@@ -911,7 +988,7 @@ static int bind_geometry_device(psm_handle* h, const float* d_grid, int n_cases 
   if ((rc = dev_alloc(h, &d_G, (size_t)rows * h->ld_out))) return rc;
   if ((rc = dev_alloc(h, &d_M, (size_t)rows))) { dev_free(d_G); return rc; }
   if ((rc = dev_alloc(h, &h->d_g2, all * Kh)) || (rc = dev_alloc(h, &h->d_c2, all)) || (rc = dev_alloc(h, &h->d_cnt, all)) ||
-      (rc = dev_alloc(h, &h->d_dots, all)) || (rc = dev_alloc(h, &h->d_row_of, all)) ||
+      (rc = dev_alloc(h, &h->ws0.d_dots, all)) || (rc = dev_alloc(h, &h->d_row_of, all)) ||
       (rc = dev_alloc(h, &h->d_ownbits, (size_t)n_cases * h->B * (h->S * h->S / 32)))) { dev_free(d_G); dev_free(d_M); return rc; }
   const DenseLayer& hd = h->dense[nl - 1];
   hipError_t e = hipSuccess;
@@ -936,7 +1013,10 @@ static int bind_geometry_device(psm_handle* h, const float* d_grid, int n_cases 
   for (int32_t o : h->plan.owner) if (o < 0) { h->bound_zero_fill = true; break; }
   h->bound_rows = rows;
   h->bound_cases = n_cases;
+  h->bound_dots = all;
   h->bound = true;
+  if (h->ring_ready)
+    for (auto& s : h->slot) { if ((rc = dev_alloc(h, &s.ws.d_dots, all))) { h->bound = false; return rc; } }
   return PSM_OK;
 }
 
@@ -969,11 +1049,18 @@ int psm_geometry_bound(const psm_handle* h) { return (h && h->bound) ? 1 : 0; }
 
 int psm_num_blocks(const psm_handle* h) { return (h && h->planned) ? h->B : PSM_ERR_STATE; }
 
+int psm_grid_shape(const psm_handle* h, int32_t* shape) {
+  if (!h || !shape || !h->planned) return PSM_ERR_STATE;
+  shape[0] = h->Ny; shape[1] = h->Nx; shape[2] = h->cfg.c_in; shape[3] = h->cfg.c_out;
+  return PSM_OK;
+}
+
 int psm_solve_grid_device(psm_handle* h, const float* d_grid, int32_t n_cases, const float* out_scale,
                           float* d_fields, void* stream) {
   return solve_device(h, d_grid, n_cases, out_scale, d_fields, (hipStream_t)stream, nullptr);
 }
 
+static bool host_registered(const psm_handle* h, const void* p, size_t bytes);
 int psm_solve_grid(psm_handle* h, const float* grid, int32_t n_cases, const float* out_scale, float* fields) {
   if (!h) return PSM_ERR_ARG;
   if (!h->planned) return fail(h, PSM_ERR_STATE, "psm_plan_grid has not been called");
@@ -983,78 +1070,235 @@ int psm_solve_grid(psm_handle* h, const float* grid, int32_t n_cases, const floa
   const size_t npix = (size_t)h->Ny * h->Nx;
   const size_t gin = (size_t)n_cases * npix * h->cfg.c_in * sizeof(float);
   const size_t gout = (size_t)n_cases * npix * h->cfg.c_out * sizeof(float);
-  memcpy(h->h_grid, grid, gin);
-  HIPCHK(h, hipMemcpyAsync(h->d_grid_stage, h->h_grid, gin, hipMemcpyHostToDevice, h->stream));
+  const bool reg_in = host_registered(h, grid, gin), reg_out = host_registered(h, fields, gout);
+  if (!reg_in) memcpy(h->h_grid, grid, gin);
+  HIPCHK(h, hipMemcpyAsync(h->d_grid_stage, reg_in ? grid : h->h_grid, gin, hipMemcpyHostToDevice, h->stream));
   int rc = solve_device(h, h->d_grid_stage, n_cases, out_scale, h->d_fields_stage, h->stream, nullptr);
   if (rc) return rc;
-  HIPCHK(h, hipMemcpyAsync(h->h_fields, h->d_fields_stage, gout, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(reg_out ? fields : h->h_fields, h->d_fields_stage, gout, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, wait_stream(h->stream));
-  memcpy(fields, h->h_fields, gout);
+  if (!reg_out) memcpy(fields, h->h_fields, gout);
   return PSM_OK;
 }
 
-// ---- host-buffer ring: H2D of ticket k+1 and D2H of ticket k-1 overlap the kernels of ticket k ----
+// ---- host-buffer ring ------------------------------------------------------------------------------------------
+// Every slot owns pinned host buffers, device buffers, a workspace and a stream; the H2D copy, the kernels and the D2H
+// copy of one ticket are ONE hipGraph replay on that stream (one host call per solve), and the slots overlap freely:
+// the copies of ticket k+1 / k-1 run on the DMA engines while the kernels of ticket k compute.
+static bool host_registered(const psm_handle* h, const void* p, size_t bytes) {
+  const char* c = (const char*)p;
+  for (auto& r : h->host_regs) if (c >= r.first && c + bytes <= r.first + r.second) return true;
+  return false;
+}
+
 static int ring_init(psm_handle* h) {
-  if (h->slot[0].h_in) return PSM_OK;
+  if (h->ring_ready) return PSM_OK;
   const size_t npix = (size_t)h->Ny * h->Nx;
   const size_t gin = (size_t)h->cfg.max_cases * npix * h->cfg.c_in, gout = (size_t)h->cfg.max_cases * npix * h->cfg.c_out;
-  if (!h->stream_in) HIPCHK(h, hipStreamCreateWithFlags(&h->stream_in, hipStreamNonBlocking));
-  if (!h->stream_out) HIPCHK(h, hipStreamCreateWithFlags(&h->stream_out, hipStreamNonBlocking));
+  const char* rg = getenv("PSM_RING_GRAPH");
+  h->ring_graph = (rg && rg[0] == '0') ? 0 : 1;
   for (auto& s : h->slot) {
     HIPCHK(h, hipHostMalloc((void**)&s.h_in, gin * sizeof(float), hipHostMallocDefault));
     HIPCHK(h, hipHostMalloc((void**)&s.h_out, gout * sizeof(float), hipHostMallocDefault));
+    HIPCHK(h, hipHostMalloc((void**)&s.h_rs, (size_t)h->Mpad_cap * sizeof(float), hipHostMallocDefault));
     int rc;
     if ((rc = dev_alloc(h, &s.d_in, gin))) return rc;
     if ((rc = dev_alloc(h, &s.d_out, gout))) return rc;
-    HIPCHK(h, hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
-    HIPCHK(h, hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+    if ((rc = ws_alloc(h, s.ws))) return rc;
+    HIPCHK(h, hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
     HIPCHK(h, hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming));
-    s.ticket = -1;
+    s.state = 0; s.ticket = -1;
   }
+  HIPCHK(h, hipDeviceSynchronize());
+  h->ring_ready = true;
   return PSM_OK;
 }
 
-int psm_submit_grid(psm_handle* h, const float* grid, int32_t n_cases, const float* out_scale, int64_t* ticket) {
+// key of a captured slot graph: everything the captured launch sequence depends on
+static int ring_key(const psm_handle* h, int n_cases, bool scale) {
+  const bool bound = h->bound && h->bound_scope == 2 && n_cases == h->bound_cases;
+  return (n_cases * 2 + (scale ? 1 : 0)) * 2 + (bound ? 1 : 0);
+}
+
+// Capture (copies +) kernels of one ticket on the slot's stream.  full: H2D from s.h_in, D2H into s.h_out.
+static int ring_capture(psm_handle* h, psm_handle::Slot& s, int n_cases, bool scale, bool full, hipGraphExec_t* out) {
+  const size_t npix = (size_t)h->Ny * h->Nx;
+  const size_t gin = (size_t)n_cases * npix * h->cfg.c_in * sizeof(float), gout = (size_t)n_cases * npix * h->cfg.c_out * sizeof(float);
+  hipGraph_t graph = nullptr;
+  HIPCHK(h, hipStreamBeginCapture(s.st, hipStreamCaptureModeRelaxed));
+  hipError_t e = hipSuccess;
+  if (full) e = hipMemcpyAsync(s.d_in, s.h_in, gin, hipMemcpyHostToDevice, s.st);
+  if (e == hipSuccess && scale) e = hipMemcpyAsync(s.ws.d_row_scale, s.h_rs, (size_t)n_cases * h->B * sizeof(float), hipMemcpyHostToDevice, s.st);
+  int rc = PSM_OK;
+  if (e == hipSuccess) rc = launch_all(h, s.ws, s.d_in, n_cases, s.d_out, scale ? s.ws.d_row_scale : h->d_ones, s.st, nullptr);
+  if (e == hipSuccess && rc == PSM_OK && full) e = hipMemcpyAsync(s.h_out, s.d_out, gout, hipMemcpyDeviceToHost, s.st);
+  hipError_t e2 = hipStreamEndCapture(s.st, &graph);
+  if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+  if (e != hipSuccess || e2 != hipSuccess) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return fail(h, PSM_ERR_HIP, std::string("ring capture: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+  }
+  e = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) return fail(h, PSM_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+  return PSM_OK;
+}
+
+// Enqueue one ticket.  src / dst: where the DMA reads the grid from / writes the field to (pinned or registered host
+// memory); the slot's own buffers take the one-replay form.
+static int ring_launch(psm_handle* h, psm_handle::Slot& s, int n_cases, const float* out_scale, const float* src, float* dst) {
+  const size_t npix = (size_t)h->Ny * h->Nx;
+  const size_t gin = (size_t)n_cases * npix * h->cfg.c_in * sizeof(float), gout = (size_t)n_cases * npix * h->cfg.c_out * sizeof(float);
+  const bool scale = out_scale != nullptr;
+  if (scale)
+    for (int c = 0; c < n_cases; ++c)
+      for (int b = 0; b < h->B; ++b) s.h_rs[c * h->B + b] = out_scale[c];
+  const bool own = (src == s.h_in && dst == s.h_out);
+  const int key = ring_key(h, n_cases, scale);
+  int rc;
+  if (h->ring_graph && h->timed_kernel < 0 && own) {
+    if (!s.g_full || s.g_full_key != key) {
+      if (s.g_full) { (void)hipGraphExecDestroy(s.g_full); s.g_full = nullptr; }
+      if ((rc = ring_capture(h, s, n_cases, scale, true, &s.g_full))) return rc;
+      s.g_full_key = key;
+    }
+    HIPCHK(h, hipGraphLaunch(s.g_full, s.st));
+  } else {
+    HIPCHK(h, hipMemcpyAsync(s.d_in, src, gin, hipMemcpyHostToDevice, s.st));
+    if (h->ring_graph && h->timed_kernel < 0) {
+      if (!s.g_kern || s.g_kern_key != key) {
+        if (s.g_kern) { (void)hipGraphExecDestroy(s.g_kern); s.g_kern = nullptr; }
+        if ((rc = ring_capture(h, s, n_cases, scale, false, &s.g_kern))) return rc;
+        s.g_kern_key = key;
+      }
+      HIPCHK(h, hipGraphLaunch(s.g_kern, s.st));
+    } else {
+      if (scale) HIPCHK(h, hipMemcpyAsync(s.ws.d_row_scale, s.h_rs, (size_t)n_cases * h->B * sizeof(float), hipMemcpyHostToDevice, s.st));
+      if ((rc = launch_all(h, s.ws, s.d_in, n_cases, s.d_out, scale ? s.ws.d_row_scale : h->d_ones, s.st, nullptr))) return rc;
+    }
+    HIPCHK(h, hipMemcpyAsync(dst, s.d_out, gout, hipMemcpyDeviceToHost, s.st));
+  }
+  HIPCHK(h, hipEventRecord(s.ev_out, s.st));
+  return PSM_OK;
+}
+
+static int ring_check(psm_handle* h, int32_t n_cases) {
+  if (!h->planned) return fail(h, PSM_ERR_STATE, "psm_plan_grid has not been called");
+  if (n_cases < 1 || n_cases > h->cfg.max_cases) return fail(h, PSM_ERR_ARG, "n_cases outside [1, max_cases]");
+  return PSM_OK;
+}
+
+int psm_ring_acquire(psm_handle* h, int64_t* ticket, float** grid_in, float** fields_out) {
   if (!h) return PSM_ERR_ARG;
   if (!h->planned) return fail(h, PSM_ERR_STATE, "psm_plan_grid has not been called");
-  if (!grid || !ticket) return fail(h, PSM_ERR_ARG, "null argument");
-  if (n_cases < 1 || n_cases > h->cfg.max_cases) return fail(h, PSM_ERR_ARG, "n_cases outside [1, max_cases]");
+  if (!ticket || !grid_in || !fields_out) return fail(h, PSM_ERR_ARG, "null argument");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   int rc = ring_init(h);
   if (rc) return rc;
   psm_handle::Slot& s = h->slot[h->next_ticket % psm_handle::SLOTS];
-  if (s.ticket >= 0)
-    return fail(h, PSM_ERR_STATE, "submission ring full: psm_wait_grid the oldest ticket first (PSM_RING_SLOTS in flight)");
-  const size_t npix = (size_t)h->Ny * h->Nx;
-  const size_t gin = (size_t)n_cases * npix * h->cfg.c_in * sizeof(float);
-  const size_t gout = (size_t)n_cases * npix * h->cfg.c_out * sizeof(float);
-  memcpy(s.h_in, grid, gin);                                   // caller's buffer is free on return
-  HIPCHK(h, hipMemcpyAsync(s.d_in, s.h_in, gin, hipMemcpyHostToDevice, h->stream_in));
-  HIPCHK(h, hipEventRecord(s.ev_in, h->stream_in));
-  HIPCHK(h, hipStreamWaitEvent(h->stream, s.ev_in, 0));
-  rc = solve_device(h, s.d_in, n_cases, out_scale, s.d_out, h->stream, nullptr);
-  if (rc) return rc;
-  HIPCHK(h, hipEventRecord(s.ev_done, h->stream));
-  HIPCHK(h, hipStreamWaitEvent(h->stream_out, s.ev_done, 0));
-  HIPCHK(h, hipMemcpyAsync(s.h_out, s.d_out, gout, hipMemcpyDeviceToHost, h->stream_out));
-  HIPCHK(h, hipEventRecord(s.ev_out, h->stream_out));
-  s.ticket = h->next_ticket;
-  s.n_cases = n_cases;
+  if (s.state != 0)
+    return fail(h, PSM_ERR_STATE, "submission ring full: wait for the oldest ticket first (PSM_RING_SLOTS in flight)");
+  s.state = 1; s.ticket = h->next_ticket; s.user_out = nullptr; s.direct_out = false;
   *ticket = h->next_ticket++;
+  *grid_in = s.h_in; *fields_out = s.h_out;
   return PSM_OK;
+}
+
+static int slot_of(psm_handle* h, int64_t ticket, int state, psm_handle::Slot** out) {
+  if (ticket < 0 || !h->ring_ready) return fail(h, PSM_ERR_ARG, "unknown ticket");
+  psm_handle::Slot& s = h->slot[ticket % psm_handle::SLOTS];
+  if (s.ticket != ticket || s.state != state)
+    return fail(h, PSM_ERR_ARG, state == 1 ? "unknown ticket (not acquired, or already submitted)" : "unknown ticket (never submitted or already waited for)");
+  *out = &s;
+  return PSM_OK;
+}
+
+int psm_ring_submit(psm_handle* h, int64_t ticket, int32_t n_cases, const float* out_scale) {
+  if (!h) return PSM_ERR_ARG;
+  int rc = ring_check(h, n_cases);
+  if (rc) return rc;
+  psm_handle::Slot* s = nullptr;
+  if ((rc = slot_of(h, ticket, 1, &s))) return rc;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  if ((rc = ring_launch(h, *s, n_cases, out_scale, s->h_in, s->h_out))) return rc;
+  s->state = 2; s->n_cases = n_cases;
+  return PSM_OK;
+}
+
+int psm_ring_wait(psm_handle* h, int64_t ticket) {
+  if (!h) return PSM_ERR_ARG;
+  psm_handle::Slot* s = nullptr;
+  int rc = slot_of(h, ticket, 2, &s);
+  if (rc) return rc;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, wait_event(s->ev_out));
+  s->state = 0;
+  return PSM_OK;
+}
+
+int psm_submit_grid_io(psm_handle* h, const float* grid, int32_t n_cases, const float* out_scale, float* fields, int64_t* ticket) {
+  if (!h) return PSM_ERR_ARG;
+  int rc = ring_check(h, n_cases);
+  if (rc) return rc;
+  if (!grid || !ticket) return fail(h, PSM_ERR_ARG, "null argument");
+  int64_t t; float *gi, *fo;
+  if ((rc = psm_ring_acquire(h, &t, &gi, &fo))) return rc;
+  psm_handle::Slot& s = h->slot[t % psm_handle::SLOTS];
+  const size_t npix = (size_t)h->Ny * h->Nx;
+  const size_t gin = (size_t)n_cases * npix * h->cfg.c_in * sizeof(float), gout = (size_t)n_cases * npix * h->cfg.c_out * sizeof(float);
+  const float* src = s.h_in;
+  float* dst = s.h_out;
+  if (host_registered(h, grid, gin)) src = grid;                       // DMA straight from the caller's memory
+  else memcpy(s.h_in, grid, gin);                                      // caller's buffer is free on return
+  if (fields && host_registered(h, fields, gout)) { dst = fields; s.direct_out = true; }
+  s.user_out = fields;
+  if ((rc = ring_launch(h, s, n_cases, out_scale, src, dst))) { s.state = 0; return rc; }
+  s.state = 2; s.n_cases = n_cases;
+  *ticket = t;
+  return PSM_OK;
+}
+
+int psm_submit_grid(psm_handle* h, const float* grid, int32_t n_cases, const float* out_scale, int64_t* ticket) {
+  return psm_submit_grid_io(h, grid, n_cases, out_scale, nullptr, ticket);
 }
 
 int psm_wait_grid(psm_handle* h, int64_t ticket, float* fields) {
   if (!h) return PSM_ERR_ARG;
-  if (!fields) return fail(h, PSM_ERR_ARG, "null buffer");
-  if (ticket < 0) return fail(h, PSM_ERR_ARG, "unknown ticket");
-  psm_handle::Slot& s = h->slot[ticket % psm_handle::SLOTS];
-  if (!s.h_in || s.ticket != ticket) return fail(h, PSM_ERR_ARG, "unknown ticket (never submitted or already waited for)");
+  psm_handle::Slot* s = nullptr;
+  int rc = slot_of(h, ticket, 2, &s);
+  if (rc) return rc;
+  if (!fields) fields = s->user_out;
+  if (!fields) return fail(h, PSM_ERR_ARG, "null buffer (no destination was given at submission either)");
+  if (s->direct_out && fields != s->user_out) return fail(h, PSM_ERR_ARG, "this ticket's field was DMA'd into the buffer given at submission");
   HIPCHK(h, hipSetDevice(h->cfg.device));
-  HIPCHK(h, wait_event(s.ev_out));
-  memcpy(fields, s.h_out, (size_t)s.n_cases * h->Ny * h->Nx * h->cfg.c_out * sizeof(float));
-  s.ticket = -1;
+  HIPCHK(h, wait_event(s->ev_out));
+  if (!s->direct_out) memcpy(fields, s->h_out, (size_t)s->n_cases * h->Ny * h->Nx * h->cfg.c_out * sizeof(float));
+  s->state = 0;
   return PSM_OK;
+}
+
+int psm_host_register(psm_handle* h, void* ptr, size_t bytes) {
+  if (!h) return PSM_ERR_ARG;
+  if (!ptr || bytes == 0) return fail(h, PSM_ERR_ARG, "null range");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  for (auto& r : h->host_regs) if (r.first == (char*)ptr) return fail(h, PSM_ERR_STATE, "range already registered");
+  hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+  if (e != hipSuccess) { (void)hipGetLastError(); return fail(h, PSM_ERR_HIP, std::string("hipHostRegister: ") + hipGetErrorString(e)); }
+  h->host_regs.push_back({(char*)ptr, bytes});
+  return PSM_OK;
+}
+
+int psm_host_unregister(psm_handle* h, void* ptr) {
+  if (!h) return PSM_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  for (size_t i = 0; i < h->host_regs.size(); ++i)
+    if (h->host_regs[i].first == (char*)ptr) {
+      HIPCHK(h, hipDeviceSynchronize());                  // no DMA of this handle may still touch the range
+      (void)hipHostUnregister(ptr);
+      h->host_regs.erase(h->host_regs.begin() + i);
+      return PSM_OK;
+    }
+  return fail(h, PSM_ERR_ARG, "range was not registered with this handle");
 }
 
 int psm_reassemble(psm_handle* h, const float* grid, const float* block_pred, float* fields) {
@@ -1065,19 +1309,19 @@ int psm_reassemble(psm_handle* h, const float* grid, const float* block_pred, fl
   hipStream_t st = h->stream;
   const size_t npix = (size_t)h->Ny * h->Nx;
   HIPCHK(h, hipMemcpyAsync(h->d_grid_stage, grid, npix * h->cfg.c_in * sizeof(float), hipMemcpyHostToDevice, st));
-  HIPCHK(h, hipMemcpyAsync(h->d_pred, block_pred, (size_t)h->B * h->K_out * sizeof(float), hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpyAsync(h->ws0.d_pred, block_pred, (size_t)h->B * h->K_out * sizeof(float), hipMemcpyHostToDevice, st));
   PsmStripArgs sa{};
-  sa.pred = h->d_pred; sa.grid = h->d_grid_stage; sa.strips = h->d_strips; sa.blk_y0x0 = h->d_blk; sa.spart = h->d_spart; sa.colpart = h->d_colpart; sa.NS = h->plan.cp.NS; sa.n_bands = h->n_bands;
+  sa.pred = h->ws0.d_pred; sa.grid = h->d_grid_stage; sa.strips = h->d_strips; sa.blk_y0x0 = h->d_blk; sa.spart = h->ws0.d_spart; sa.colpart = h->ws0.d_colpart; sa.NS = h->plan.cp.NS; sa.n_bands = h->n_bands;
   sa.B = h->B; sa.S = h->S; sa.c_in = h->cfg.c_in; sa.c_out = h->cfg.c_out;
   sa.sdf_ch = h->cfg.sdf_channel; sa.Ny = h->Ny; sa.Nx = h->Nx;
   HIPCHK(h, psm_launch_strips(sa, 1, st));
   PsmChainArgs ca{};
-  ca.cp = h->plan.cp; ca.blocks = h->d_blocks; ca.spart = h->d_spart; ca.colpart = h->d_colpart; ca.n_bands = h->n_bands; ca.pred = h->d_pred; ca.owner = h->d_owner;
+  ca.cp = h->plan.cp; ca.blocks = h->d_blocks; ca.spart = h->ws0.d_spart; ca.colpart = h->ws0.d_colpart; ca.n_bands = h->n_bands; ca.pred = h->ws0.d_pred; ca.owner = h->d_owner;
   ca.shiftA = h->d_shiftA; ca.shiftB = h->d_shiftB; ca.shiftOwnA = h->d_shiftOwnA; ca.shiftOwnB = h->d_shiftOwnB; ca.shiftW = h->d_shiftW;
   for (int f = 0; f < 2; ++f) ca.shiftL[f] = (int)h->plan.shiftA[f].size();
-  ca.Lmax = h->Lmax; ca.offs = h->d_offs; ca.shift = h->d_shift; ca.n_strips = h->n_strips; ca.c_out = h->cfg.c_out; ca.stamps = h->d_stamps;
+  ca.Lmax = h->Lmax; ca.offs = h->ws0.d_offs; ca.shift = h->ws0.d_shift; ca.n_strips = h->n_strips; ca.c_out = h->cfg.c_out; ca.stamps = h->d_stamps;
   HIPCHK(h, psm_launch_chain(ca, 1, st));
-  PsmPasteArgs pa{h->d_pred, h->d_owner, h->d_offs, h->d_shift, h->d_fields_stage, h->B, h->S, h->cfg.c_out, h->Ny * h->Nx};
+  PsmPasteArgs pa{h->ws0.d_pred, h->d_owner, h->ws0.d_offs, h->ws0.d_shift, h->d_fields_stage, h->B, h->S, h->cfg.c_out, h->Ny * h->Nx};
   HIPCHK(h, psm_launch_paste(pa, 1, st));
   HIPCHK(h, hipMemcpyAsync(fields, h->d_fields_stage, npix * h->cfg.c_out * sizeof(float), hipMemcpyDeviceToHost, st));
   HIPCHK(h, wait_stream(st));
@@ -1451,19 +1695,19 @@ int psm_read_stage(psm_handle* h, int32_t stage, float* dst, size_t dst_floats) 
     return PSM_OK;
   };
   switch (stage) {
-    case PSM_STAGE_X_INPUT: return rows(h->d_xin, h->ld_in, h->cfg.p_in);
-    case PSM_STAGE_RES: return rows(h->d_res, h->ld_out, h->cfg.p_out);
-    case PSM_STAGE_BLOCK_PRED: return rows(h->d_pred, h->K_out, h->K_out);
+    case PSM_STAGE_X_INPUT: return rows(h->ws0.d_xin, h->ld_in, h->cfg.p_in);
+    case PSM_STAGE_RES: return rows(h->ws0.d_res, h->ld_out, h->cfg.p_out);
+    case PSM_STAGE_BLOCK_PRED: return rows(h->ws0.d_pred, h->K_out, h->K_out);
     case PSM_STAGE_OFFSETS: {
       const size_t n = (size_t)h->last_cases * h->cfg.c_out * h->B;
       if (dst_floats < n) return fail(h, PSM_ERR_ARG, "destination too small");
-      HIPCHK(h, hipMemcpy(dst, h->d_offs, n * sizeof(float), hipMemcpyDeviceToHost));
+      HIPCHK(h, hipMemcpy(dst, h->ws0.d_offs, n * sizeof(float), hipMemcpyDeviceToHost));
       return PSM_OK;
     }
     case PSM_STAGE_SHIFT: {
       const size_t n = (size_t)h->last_cases * h->cfg.c_out;
       if (dst_floats < n) return fail(h, PSM_ERR_ARG, "destination too small");
-      HIPCHK(h, hipMemcpy(dst, h->d_shift, n * sizeof(float), hipMemcpyDeviceToHost));
+      HIPCHK(h, hipMemcpy(dst, h->ws0.d_shift, n * sizeof(float), hipMemcpyDeviceToHost));
       return PSM_OK;
     }
     case 6: {   // diagnostic builds only: raw stamps of workgroup 0, microseconds after the earliest one
@@ -1532,6 +1776,60 @@ int psm_get_kernel_timing(psm_handle* h, int32_t kernel, double* total_ms, int64
   }
   h->timed_events.clear();
   *total_ms = h->timed_total_ms; *launches = h->timed_launches;
+  return PSM_OK;
+}
+
+// Dispatch-level time of EVERY kernel of the solve path: `steps` solves through the same launch sequence as
+// psm_solve_grid_device, each dispatch stamped by hipExtLaunchKernelGGL (its own begin / end, what rocprofv3 reads).
+int psm_time_kernels(psm_handle* h, const float* d_grid, int32_t n_cases, float* d_fields, int32_t steps, char* names,
+                     double* total_ms, int64_t* launches, int32_t cap, int32_t* n_kernels) {
+  if (!h || !names || !total_ms || !launches || !n_kernels || cap < 1 || steps < 1) return PSM_ERR_ARG;
+  if (!h->planned) return fail(h, PSM_ERR_STATE, "psm_plan_grid has not been called");
+  if (h->timed_kernel >= 0) return fail(h, PSM_ERR_STATE, "psm_enable_kernel_timing is active");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  PsmLaunchProbe probe;
+  std::vector<std::string> seen;
+  std::vector<double> ms;
+  std::vector<int64_t> cnt;
+  auto drain = [&]() -> int {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (auto& r : probe.recs) {
+      float t = 0.f;
+      std::string nm(r.name);                       // "(psm_x_kernel<A, B>)" -> "psm_x_kernel"
+      while (!nm.empty() && (nm[0] == '(' || nm[0] == ' ')) nm.erase(0, 1);
+      const size_t cut = nm.find_first_of("<)");
+      if (cut != std::string::npos) nm.resize(cut);
+      if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) {
+        size_t k = 0;
+        while (k < seen.size() && seen[k] != nm) ++k;
+        if (k == seen.size()) { seen.push_back(nm); ms.push_back(0.0); cnt.push_back(0); }
+        ms[k] += t; cnt[k] += 1;
+      }
+      probe.pool.push_back(r.e0); probe.pool.push_back(r.e1);
+    }
+    probe.recs.clear();
+    return PSM_OK;
+  };
+  const bool graph = h->use_graph;
+  h->use_graph = false;                              // plain launches: every dispatch carries its own events
+  int rc = PSM_OK;
+  psm_launch_probe = &probe;
+  for (int i = 0; i < steps && rc == PSM_OK; ++i) {
+    rc = solve_device(h, d_grid, n_cases, nullptr, d_fields, h->stream, nullptr);
+    if (rc == PSM_OK && (i % 64) == 63) rc = drain();
+  }
+  psm_launch_probe = nullptr;
+  h->use_graph = graph;
+  if (rc == PSM_OK) rc = drain(); else (void)hipStreamSynchronize(h->stream);
+  for (auto& r : probe.recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  for (auto e : probe.pool) (void)hipEventDestroy(e);
+  if (rc) return rc;
+  *n_kernels = (int32_t)seen.size();
+  for (int k = 0; k < (int)seen.size() && k < cap; ++k) {
+    snprintf(names + (size_t)k * 64, 64, "%s", seen[k].c_str());
+    total_ms[k] = ms[k]; launches[k] = cnt[k];
+  }
   return PSM_OK;
 }
 

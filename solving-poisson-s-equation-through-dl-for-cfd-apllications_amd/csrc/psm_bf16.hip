@@ -120,7 +120,7 @@ hipError_t psm_launch_encode_bf16(const PsmEncodeArgs& a, hipStream_t st, hipEve
   const size_t lds = (size_t)rows * (PSM_PIX_PER_SLICE * a.c_in + 8) * 2;
 #define ENC2(C, AL)                                                                                          \
   if (ev_start) hipExtLaunchKernelGGL((psm_encode_bf16_kernel<C, AL>), dim3(n_slices), dim3(256), (std::uint32_t)lds, st, ev_start, ev_stop, 0, a); \
-  else hipLaunchKernelGGL((psm_encode_bf16_kernel<C, AL>), dim3(n_slices), dim3(256), lds, st, a)
+  else PSM_LAUNCH((psm_encode_bf16_kernel<C, AL>), dim3(n_slices), dim3(256), lds, st, a)
 #define ENC(C) case C: if (a.aligned) { ENC2(C, true); } else { ENC2(C, false); } break;
   switch (a.c_in) {
     ENC(1) ENC(2) ENC(3) ENC(4)
@@ -195,9 +195,9 @@ hipError_t psm_launch_decode_bf16(const PsmDecodeArgs& a, hipStream_t st) {
     const int tiles = (a.Mpad - m_base) / 32;
     const int mtc = tiles >= 4 ? 4 : (tiles >= 2 ? 2 : 1);
     const size_t lds = (size_t)mtc * 32 * (a.ld_res + 8) * 2 + (size_t)mtc * 32 * sizeof(float);
-    if (mtc == 4) hipLaunchKernelGGL((psm_decode_bf16_kernel<4>), dim3(nwg), dim3(256), lds, st, a, m_base);
-    else if (mtc == 2) hipLaunchKernelGGL((psm_decode_bf16_kernel<2>), dim3(nwg), dim3(256), lds, st, a, m_base);
-    else hipLaunchKernelGGL((psm_decode_bf16_kernel<1>), dim3(nwg), dim3(256), lds, st, a, m_base);
+    if (mtc == 4) PSM_LAUNCH((psm_decode_bf16_kernel<4>), dim3(nwg), dim3(256), lds, st, a, m_base);
+    else if (mtc == 2) PSM_LAUNCH((psm_decode_bf16_kernel<2>), dim3(nwg), dim3(256), lds, st, a, m_base);
+    else PSM_LAUNCH((psm_decode_bf16_kernel<1>), dim3(nwg), dim3(256), lds, st, a, m_base);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     m_base += mtc * 32;

@@ -17,6 +17,8 @@
 // lane half h) so that one 16-byte read per lane feeds four MFMAs; both operands use it.
 #include "psm_kernels.h"
 
+thread_local PsmLaunchProbe* psm_launch_probe = nullptr;
+
 #include <hip/hip_ext.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -243,7 +245,7 @@ hipError_t psm_launch_encode(const PsmEncodeArgs& a, hipStream_t st, hipEvent_t 
   // (the source rocprofv3 reads), not with separate marker packets around the launch.
 #define ENC2(C, AL)                                                                                          \
   if (ev_start) hipExtLaunchKernelGGL((psm_encode_kernel<C, AL>), dim3(n_slices), dim3(256), (std::uint32_t)lds, st, ev_start, ev_stop, 0, a); \
-  else hipLaunchKernelGGL((psm_encode_kernel<C, AL>), dim3(n_slices), dim3(256), lds, st, a)
+  else PSM_LAUNCH((psm_encode_kernel<C, AL>), dim3(n_slices), dim3(256), lds, st, a)
 #define ENC(C) case C: if (a.aligned) { ENC2(C, true); } else { ENC2(C, false); } break;
   switch (a.c_in) {
     ENC(1) ENC(2) ENC(3) ENC(4)
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(1024) void psm_reduce_kernel(PsmReduceArgs a) {
 
 hipError_t psm_launch_reduce(const PsmReduceArgs& a, hipStream_t st) {
   const int64_t total = (int64_t)a.Mpad * a.ldp;
-  hipLaunchKernelGGL(psm_reduce_kernel, dim3((unsigned)(total / 64)), dim3(1024), 0, st, a);
+  PSM_LAUNCH(psm_reduce_kernel, dim3((unsigned)(total / 64)), dim3(1024), 0, st, a);
   return hipGetLastError();
 }
 
@@ -423,8 +425,8 @@ __global__ __launch_bounds__(1024) void psm_reduce_dense1_kernel(PsmReduceArgs r
 hipError_t psm_launch_reduce_dense1(const PsmReduceArgs& r, const PsmDenseArgs& d, hipStream_t st) {
   if (r.ldp > 512 || d.ld_w > 1024 || (d.ld_w / 2) % 1 != 0) return hipErrorInvalidValue;
   const dim3 grid(r.Mpad, 2);
-  if (d.bf16) hipLaunchKernelGGL((psm_reduce_dense1_kernel<true>), grid, dim3(1024), 0, st, r, d);
-  else hipLaunchKernelGGL((psm_reduce_dense1_kernel<false>), grid, dim3(1024), 0, st, r, d);
+  if (d.bf16) PSM_LAUNCH((psm_reduce_dense1_kernel<true>), grid, dim3(1024), 0, st, r, d);
+  else PSM_LAUNCH((psm_reduce_dense1_kernel<false>), grid, dim3(1024), 0, st, r, d);
   return hipGetLastError();
 }
 
@@ -564,11 +566,11 @@ hipError_t psm_launch_dense(const PsmDenseArgs& a, hipStream_t st) {
 #define DENSE(N)                                                                            \
   do {                                                                                      \
     if (r16) {                                                                              \
-      if (a.bf16) hipLaunchKernelGGL((psm_dense_kernel<N, true, 16, false>), grid, blk, 0, st, a, PsmDotsArgs{}); \
-      else hipLaunchKernelGGL((psm_dense_kernel<N, false, 16, false>), grid, blk, 0, st, a, PsmDotsArgs{});       \
+      if (a.bf16) PSM_LAUNCH((psm_dense_kernel<N, true, 16, false>), grid, blk, 0, st, a, PsmDotsArgs{}); \
+      else PSM_LAUNCH((psm_dense_kernel<N, false, 16, false>), grid, blk, 0, st, a, PsmDotsArgs{});       \
     } else {                                                                                \
-      if (a.bf16) hipLaunchKernelGGL((psm_dense_kernel<N, true, 32, false>), grid, blk, 0, st, a, PsmDotsArgs{}); \
-      else hipLaunchKernelGGL((psm_dense_kernel<N, false, 32, false>), grid, blk, 0, st, a, PsmDotsArgs{});       \
+      if (a.bf16) PSM_LAUNCH((psm_dense_kernel<N, true, 32, false>), grid, blk, 0, st, a, PsmDotsArgs{}); \
+      else PSM_LAUNCH((psm_dense_kernel<N, false, 32, false>), grid, blk, 0, st, a, PsmDotsArgs{});       \
     }                                                                                       \
   } while (0)
   if (ng == 1) DENSE(1); else if (ng == 2) DENSE(2); else DENSE(4);
@@ -586,8 +588,8 @@ hipError_t psm_launch_dense_dots(const PsmDenseArgs& a, const PsmDotsArgs& d, hi
   const dim3 grid(gx, gy, 1 + (d.n_rows + per_plane - 1) / per_plane), blk(512);
 #define DD(N)                                                                                          \
   do {                                                                                                 \
-    if (r16) hipLaunchKernelGGL((psm_dense_kernel<N, false, 16, true>), grid, blk, 0, st, a, d);       \
-    else hipLaunchKernelGGL((psm_dense_kernel<N, false, 32, true>), grid, blk, 0, st, a, d);           \
+    if (r16) PSM_LAUNCH((psm_dense_kernel<N, false, 16, true>), grid, blk, 0, st, a, d);       \
+    else PSM_LAUNCH((psm_dense_kernel<N, false, 32, true>), grid, blk, 0, st, a, d);           \
   } while (0)
   if (ng == 1) DD(1); else if (ng == 2) DD(2); else DD(4);
 #undef DD
@@ -750,10 +752,10 @@ hipError_t psm_launch_decode(const PsmDecodeArgs& a, hipStream_t st) {
     int groups = 1;
     while (nwg * groups < 256 && groups * 2 <= iters) groups *= 2;
     const dim3 grid(nwg, groups);
-    if (mtc == 4) hipLaunchKernelGGL((psm_decode128_kernel<4>), grid, dim3(256), lds128, st, a, 0, a.Mpad);
-    else if (mtc == 3) hipLaunchKernelGGL((psm_decode128_kernel<3>), grid, dim3(256), lds128, st, a, 0, a.Mpad);
-    else if (mtc == 2) hipLaunchKernelGGL((psm_decode128_kernel<2>), grid, dim3(256), lds128, st, a, 0, a.Mpad);
-    else hipLaunchKernelGGL((psm_decode128_kernel<1>), grid, dim3(256), lds128, st, a, 0, a.Mpad);
+    if (mtc == 4) PSM_LAUNCH((psm_decode128_kernel<4>), grid, dim3(256), lds128, st, a, 0, a.Mpad);
+    else if (mtc == 3) PSM_LAUNCH((psm_decode128_kernel<3>), grid, dim3(256), lds128, st, a, 0, a.Mpad);
+    else if (mtc == 2) PSM_LAUNCH((psm_decode128_kernel<2>), grid, dim3(256), lds128, st, a, 0, a.Mpad);
+    else PSM_LAUNCH((psm_decode128_kernel<1>), grid, dim3(256), lds128, st, a, 0, a.Mpad);
     return hipGetLastError();
   }
   int m_base = 0;
@@ -762,7 +764,7 @@ hipError_t psm_launch_decode(const PsmDecodeArgs& a, hipStream_t st) {
     const int mtc = tiles >= 4 ? 4 : (tiles >= 2 ? 2 : 1);
     const size_t lds = (size_t)mtc * 32 * (a.ld_res + 4) * sizeof(float);
     const bool g16 = (a.Gd % 16 == 0);
-#define DEC(M_, G_) hipLaunchKernelGGL((psm_decode_kernel<M_, G_>), dim3(nwg), dim3(256), lds, st, a, m_base)
+#define DEC(M_, G_) PSM_LAUNCH((psm_decode_kernel<M_, G_>), dim3(nwg), dim3(256), lds, st, a, m_base)
     if (mtc == 4) { if (g16) DEC(4, 16); else DEC(4, 4); }
     else if (mtc == 2) { if (g16) DEC(2, 16); else DEC(2, 4); }
     else { if (g16) DEC(1, 16); else DEC(1, 4); }
@@ -959,8 +961,8 @@ __global__ __launch_bounds__(256) void psm_strips_kernel(PsmStripArgs a) {
 
 hipError_t psm_launch_strips(const PsmStripArgs& a, int n_cases, hipStream_t st) {
   if (a.S != 128) return hipErrorInvalidValue;
-  if (a.c_out == 1) hipLaunchKernelGGL((psm_strips_kernel<1>), dim3(a.B, a.n_bands, n_cases), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((psm_strips_kernel<2>), dim3(a.B, a.n_bands, n_cases), dim3(256), 0, st, a);
+  if (a.c_out == 1) PSM_LAUNCH((psm_strips_kernel<1>), dim3(a.B, a.n_bands, n_cases), dim3(256), 0, st, a);
+  else PSM_LAUNCH((psm_strips_kernel<2>), dim3(a.B, a.n_bands, n_cases), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
@@ -1156,7 +1158,7 @@ __global__ __launch_bounds__(512) void psm_chain_kernel(PsmChainArgs a) {
 hipError_t psm_launch_chain(const PsmChainArgs& a, int n_cases, hipStream_t st) {
   const size_t lds = ((size_t)a.c_out * a.n_strips + a.n_strips + (size_t)a.c_out * a.cp.B + (size_t)a.c_out * PSM_MAX_COLS + 8) * sizeof(float);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(psm_chain_kernel, dim3(n_cases), dim3(512), lds, st, a);
+  PSM_LAUNCH(psm_chain_kernel, dim3(n_cases), dim3(512), lds, st, a);
   return hipGetLastError();
 }
 
@@ -1317,8 +1319,8 @@ __global__ __launch_bounds__(256) void psm_assemble_kernel(PsmChainArgs a, PsmPa
 hipError_t psm_launch_assemble(const PsmChainArgs& a, const PsmPasteArgs& p, int n_cases, hipStream_t st) {
   const size_t lds = ((size_t)a.c_out * a.n_strips + a.n_strips + (size_t)a.c_out * a.cp.B + 6 * a.c_out + 8) * sizeof(float);
   const dim3 grid((p.npix + 255) / 256, n_cases);
-  if (a.c_out == 1) hipLaunchKernelGGL((psm_assemble_kernel<1>), grid, dim3(256), lds, st, a, p);
-  else hipLaunchKernelGGL((psm_assemble_kernel<2>), grid, dim3(256), lds, st, a, p);
+  if (a.c_out == 1) PSM_LAUNCH((psm_assemble_kernel<1>), grid, dim3(256), lds, st, a, p);
+  else PSM_LAUNCH((psm_assemble_kernel<2>), grid, dim3(256), lds, st, a, p);
   return hipGetLastError();
 }
 
@@ -1343,7 +1345,7 @@ __global__ __launch_bounds__(256) void psm_paste_kernel(PsmPasteArgs a) {
 }
 
 hipError_t psm_launch_paste(const PsmPasteArgs& a, int n_cases, hipStream_t st) {
-  hipLaunchKernelGGL(psm_paste_kernel, dim3((a.npix + 255) / 256, n_cases), dim3(256), 0, st, a);
+  PSM_LAUNCH(psm_paste_kernel, dim3((a.npix + 255) / 256, n_cases), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
@@ -1444,9 +1446,9 @@ __global__ __launch_bounds__(256) void psm_bind_own_kernel(PsmBindArgs a) {
 hipError_t psm_launch_bind(const PsmBindArgs& a, hipStream_t st) {
   if (a.ld_out > 512 || a.ld_out < 1 || (a.S * a.S) % 32 != 0) return hipErrorInvalidValue;
   const int rows = a.c_out * a.nst + a.c_out * a.B;
-  hipLaunchKernelGGL(psm_bind_rows_kernel, dim3(rows), dim3(128), 0, st, a);
-  hipLaunchKernelGGL(psm_bind_fold_kernel, dim3(rows), dim3(256), (size_t)a.ld_out * sizeof(double), st, a);
-  hipLaunchKernelGGL(psm_bind_own_kernel, dim3((a.B * (a.S * a.S / 32) + 255) / 256), dim3(256), 0, st, a);
+  PSM_LAUNCH(psm_bind_rows_kernel, dim3(rows), dim3(128), 0, st, a);
+  PSM_LAUNCH(psm_bind_fold_kernel, dim3(rows), dim3(256), (size_t)a.ld_out * sizeof(double), st, a);
+  PSM_LAUNCH(psm_bind_own_kernel, dim3((a.B * (a.S * a.S / 32) + 255) / 256), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
@@ -1625,8 +1627,8 @@ hipError_t psm_launch_decode_paste(const PsmDecodeArgs& a, const PsmBoundArgs& p
   const size_t lds = ((size_t)mtc * 32 * (a.ld_res + 4) + (size_t)mtc * 32 * 8 + (size_t)c_out * p.n_strips + p.n_strips + (size_t)c_out * p.B + 4) * sizeof(float);
 #define DP(M_, C_, L_)                                                                                              \
   do {                                                                                                              \
-    if (bf16) hipLaunchKernelGGL((psm_decode_paste_kernel<M_, C_, L_, true>), dim3(nwg), dim3(384), lds, st, a, p);    \
-    else hipLaunchKernelGGL((psm_decode_paste_kernel<M_, C_, L_, false>), dim3(nwg), dim3(384), lds, st, a, p);        \
+    if (bf16) PSM_LAUNCH((psm_decode_paste_kernel<M_, C_, L_, true>), dim3(nwg), dim3(384), lds, st, a, p);    \
+    else PSM_LAUNCH((psm_decode_paste_kernel<M_, C_, L_, false>), dim3(nwg), dim3(384), lds, st, a, p);        \
   } while (0)
 #define DPL(L_)                                                        \
   do {                                                                 \
@@ -1681,8 +1683,8 @@ __global__ __launch_bounds__(256) void psm_chain_dots_kernel(PsmBoundBatchArgs p
 hipError_t psm_launch_chain_dots(const PsmBoundBatchArgs& p, int c_out, hipStream_t st) {
   const size_t lds = ((size_t)c_out * p.n_strips + p.n_strips + (size_t)c_out * p.B) * sizeof(float);
   if ((c_out != 1 && c_out != 2) || lds > 60 * 1024 || p.B < 1) return hipErrorInvalidValue;
-  if (c_out == 1) hipLaunchKernelGGL((psm_chain_dots_kernel<1>), dim3(p.n_cases), dim3(256), lds, st, p);
-  else hipLaunchKernelGGL((psm_chain_dots_kernel<2>), dim3(p.n_cases), dim3(256), lds, st, p);
+  if (c_out == 1) PSM_LAUNCH((psm_chain_dots_kernel<1>), dim3(p.n_cases), dim3(256), lds, st, p);
+  else PSM_LAUNCH((psm_chain_dots_kernel<2>), dim3(p.n_cases), dim3(256), lds, st, p);
   return hipGetLastError();
 }
 
@@ -1818,8 +1820,8 @@ hipError_t psm_launch_decode_paste_batch(const PsmDecodeArgs& a, const PsmBoundB
   const dim3 grid(nwg, groups);
 #define DP(M_, C_, L_)                                                                                                          \
   do {                                                                                                                          \
-    if (bf16) hipLaunchKernelGGL((psm_decode_paste_batch_kernel<M_, C_, L_, true>), grid, dim3(256), lds, st, a, p, a.Mpad);      \
-    else hipLaunchKernelGGL((psm_decode_paste_batch_kernel<M_, C_, L_, false>), grid, dim3(256), lds, st, a, p, a.Mpad);          \
+    if (bf16) PSM_LAUNCH((psm_decode_paste_batch_kernel<M_, C_, L_, true>), grid, dim3(256), lds, st, a, p, a.Mpad);      \
+    else PSM_LAUNCH((psm_decode_paste_batch_kernel<M_, C_, L_, false>), grid, dim3(256), lds, st, a, p, a.Mpad);          \
   } while (0)
 #define DPM(C_, L_)                                                                 \
   do {                                                                              \
@@ -1854,7 +1856,7 @@ __global__ __launch_bounds__(256) void psm_res_dots_kernel(PsmDotsArgs d, const 
 
 hipError_t psm_launch_res_dots(const PsmDotsArgs& d, const float* res, int ld_res, hipStream_t st) {
   if (ld_res > 128 || ld_res < 1 || d.n_rows < 1) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(psm_res_dots_kernel, dim3((d.n_rows + 3) / 4), dim3(256), 0, st, d, res, ld_res);
+  PSM_LAUNCH(psm_res_dots_kernel, dim3((d.n_rows + 3) / 4), dim3(256), 0, st, d, res, ld_res);
   return hipGetLastError();
 }
 
@@ -1867,8 +1869,8 @@ __global__ __launch_bounds__(256) void psm_bind_copy_kernel(PsmBindArgs a) {   /
 hipError_t psm_launch_bind_unfolded(const PsmBindArgs& a, hipStream_t st) {
   if (a.ld_out > 512 || a.ld_out < 1 || (a.S * a.S) % 32 != 0) return hipErrorInvalidValue;
   const int rows = a.c_out * a.nst + a.c_out * a.B;
-  hipLaunchKernelGGL(psm_bind_rows_kernel, dim3(rows), dim3(128), 0, st, a);
-  hipLaunchKernelGGL(psm_bind_copy_kernel, dim3(rows), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(psm_bind_own_kernel, dim3((a.B * (a.S * a.S / 32) + 255) / 256), dim3(256), 0, st, a);
+  PSM_LAUNCH(psm_bind_rows_kernel, dim3(rows), dim3(128), 0, st, a);
+  PSM_LAUNCH(psm_bind_copy_kernel, dim3(rows), dim3(256), 0, st, a);
+  PSM_LAUNCH(psm_bind_own_kernel, dim3((a.B * (a.S * a.S / 32) + 255) / 256), dim3(256), 0, st, a);
   return hipGetLastError();
 }

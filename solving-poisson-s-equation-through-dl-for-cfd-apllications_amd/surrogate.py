@@ -120,9 +120,11 @@ class GridSurrogate:
                                           _p(out, C.c_float)))
         return out
 
-    def submit(self, grid: np.ndarray, out_scale: Optional[Sequence[float]] = None) -> int:
-        """Asynchronous host-buffer solve (psm_submit_grid): returns a ticket; up to PSM_RING_SLOTS (4) in
-        flight, copies of neighbouring tickets overlap the kernels.  `grid` may be reused on return."""
+    def submit(self, grid: np.ndarray, out_scale: Optional[Sequence[float]] = None, out: Optional[np.ndarray] = None) -> int:
+        """Asynchronous host-buffer solve (psm_submit_grid_io): returns a ticket; up to PSM_RING_SLOTS (4) in
+        flight, each on its own stream (H2D copy, kernels and D2H copy of one ticket are one graph replay).  A pageable
+        ``grid`` may be reused on return; a grid / ``out`` array inside a range registered with :meth:`host_register` is
+        DMA'd from / into directly and must be left alone until :meth:`wait` returns."""
         g = np.asarray(grid)
         if g.ndim == 3:
             g = g[None]
@@ -132,21 +134,55 @@ class GridSurrogate:
         n = g.shape[0]
         self._check_bound(g)
         sc = _f32(np.broadcast_to(out_scale, (n,))) if out_scale is not None else None
+        if out is not None and (out.dtype != np.float32 or not out.flags.c_contiguous or out.size != n * self.ny * self.nx * self.model.c_out):
+            raise ValueError("out must be a contiguous float32 array [n,Ny,Nx,c_out]")
         t = C.c_int64(-1)
-        self._chk(self.lib.psm_submit_grid(self.h, _p(g, C.c_float), n, _p(sc, C.c_float) if sc is not None else None,
-                                           C.byref(t)))
-        self._ticket_cases[t.value] = n
+        self._chk(self.lib.psm_submit_grid_io(self.h, _p(g, C.c_float), n, _p(sc, C.c_float) if sc is not None else None,
+                                              _p(out, C.c_float) if out is not None else None, C.byref(t)))
+        self._ticket_cases[t.value] = (n, out, g)               # keeps the arrays alive while the DMA may touch them
         return t.value
 
     def wait(self, ticket: int) -> np.ndarray:
         """Field(s) of a ticket returned by :meth:`submit` -> [n,Ny,Nx,c_out] f32 (blocks until it has arrived)."""
-        n = self._ticket_cases.get(ticket)
-        if n is None:
+        rec = self._ticket_cases.get(ticket)
+        if rec is None:
             raise ValueError("unknown ticket")
-        out = np.empty((n, self.ny, self.nx, self.model.c_out), np.float32)
-        self._chk(self.lib.psm_wait_grid(self.h, ticket, _p(out, C.c_float)))
+        n, out, _ = rec
+        if out is None:
+            out = np.empty((n, self.ny, self.nx, self.model.c_out), np.float32)
+            self._chk(self.lib.psm_wait_grid(self.h, ticket, _p(out, C.c_float)))
+        else:
+            self._chk(self.lib.psm_wait_grid(self.h, ticket, None))
+            out = out.reshape(n, self.ny, self.nx, self.model.c_out)
         del self._ticket_cases[ticket]
         return out
+
+    # -- zero-copy ring: the caller packs straight into the slot's pinned memory
+    def ring_acquire(self):
+        """-> (ticket, grid_in [max_cases,Ny,Nx,c_in], fields_out [max_cases,Ny,Nx,c_out]): NumPy views of the next
+        slot's pinned buffers (psm_ring_acquire)."""
+        t, gi, fo = C.c_int64(-1), C.POINTER(C.c_float)(), C.POINTER(C.c_float)()
+        self._chk(self.lib.psm_ring_acquire(self.h, C.byref(t), C.byref(gi), C.byref(fo)))
+        gin = np.ctypeslib.as_array(gi, shape=(self.max_cases, self.ny, self.nx, self.model.c_in))
+        fout = np.ctypeslib.as_array(fo, shape=(self.max_cases, self.ny, self.nx, self.model.c_out))
+        return t.value, gin, fout
+
+    def ring_submit(self, ticket: int, n_cases: int = 1, out_scale: Optional[Sequence[float]] = None):
+        sc = _f32(np.broadcast_to(out_scale, (n_cases,))) if out_scale is not None else None
+        self._chk(self.lib.psm_ring_submit(self.h, ticket, n_cases, _p(sc, C.c_float) if sc is not None else None))
+
+    def ring_wait(self, ticket: int):
+        self._chk(self.lib.psm_ring_wait(self.h, ticket))
+
+    def host_register(self, arr: np.ndarray):
+        """Register a caller-owned contiguous array for direct DMA (psm_host_register); keep it alive until
+        :meth:`host_unregister` / close."""
+        if not arr.flags.c_contiguous:
+            raise ValueError("contiguous array expected")
+        self._chk(self.lib.psm_host_register(self.h, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+
+    def host_unregister(self, arr: np.ndarray):
+        self._chk(self.lib.psm_host_unregister(self.h, arr.ctypes.data_as(C.c_void_p)))
 
     def bind_geometry(self, grid, on_device: bool = False, n_cases: int = 1) -> bool:
         """Bind the obstacle geometry (SDF channel of ``grid`` [ny, nx, c_in], or a device pointer with

@@ -21,6 +21,27 @@ def run_bench(*extra):
     return json.loads(lines[0])
 
 
+def test_gpus_n_starts_n_ranks_without_a_launcher():
+    """`bench.py --gpus 2` with no torchrun environment spawns its two ranks itself (gloo, no GPU work: --dry-run)
+    and reports the world size the process group saw."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PSM_BENCH_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "5", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size_reported"] == 2 and d["dry_run"] is True and d["steps"] == 5
+
+
+def test_world_size_must_match_gpus():
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", PSM_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+    assert out.returncode != 0 and "world size" in (out.stderr + out.stdout)
+
+
 @pytest.mark.gpu
 def test_default_bench_line():
     d = run_bench()
@@ -30,8 +51,19 @@ def test_default_bench_line():
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
     assert d["value"] > 1000 and abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     assert "configs[1]" in d["config"]["workload"] and d["config"]["geometry"].startswith("bound once")
+    assert "device-resident" in d["config"]["value_is"] and d["config"]["degenerate"].startswith("build-defined skip")
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # the roofline kernel is the one with the largest measured time of the instrumented pass
+    top = max(r["kernels"], key=lambda k: k["avg_us"] * k["launches_per_solve"])
+    assert r["kernel"] == top["name"] and len(r["kernels"]) >= 4
+    # the H2D / D2H-inclusive solve, and BASELINE configs[3]
+    e = d["end_to_end"]
+    assert d["value_end_to_end"] > 1000 and e["matches_device_resident_result"] is True
+    assert {"sync_pageable", "ring_pageable_depth3", "ring_registered_depth3", "ring_zero_copy_depth3"} <= set(e["solves_per_s_per_rank"])
+    cbat = d["case_batch"]
+    assert "configs[3]" in cbat["workload"] and cbat["cases_per_step_per_gpu"] == 8 and cbat["value"] > 1000
+    assert cbat["gathered_shape"] == [8, 256, 256, 1]
     cb = d["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] == "port" and cb["value"] > 0
     assert d["l2_vs_oracle"] < 1e-5
