@@ -1796,10 +1796,10 @@ int psm_time_kernels(psm_handle* h, const float* d_grid, int32_t n_cases, float*
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (auto& r : probe.recs) {
       float t = 0.f;
-      std::string nm(r.name);                       // "(psm_x_kernel<A, B>)" -> "psm_x_kernel"
-      while (!nm.empty() && (nm[0] == '(' || nm[0] == ' ')) nm.erase(0, 1);
-      const size_t cut = nm.find_first_of("<)");
-      if (cut != std::string::npos) nm.resize(cut);
+      std::string nm(r.name);                       // "(psm_x_kernel<A, B>)" -> "psm_x_kernel<A, B>": the launcher's template
+      while (!nm.empty() && (nm[0] == '(' || nm[0] == ' ')) nm.erase(0, 1);     // expression, distinct per instantiation family
+      while (!nm.empty() && (nm.back() == ')' || nm.back() == ' ')) nm.pop_back();
+      if (nm.size() > 63) nm.resize(63);
       if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) {
         size_t k = 0;
         while (k < seen.size() && seen[k] != nm) ++k;

@@ -24,6 +24,11 @@ GOLDEN_CASES = {
     "chapter5_128x128_real": dict(variant="chapter5", Ny=128, Nx=128, real_weights=True),
     "chapter5_300x400":   dict(variant="chapter5", Ny=300, Nx=400, seed=31, p=32),
     "chapter5_nan_300x400": dict(variant="chapter5", Ny=300, Nx=400, seed=32, p=24, band=(116, 128, 156, 284), obstacle="none"),
+    # Thesis_Work/Chapter4 evaluators run with their own trained models (BASELINE configs[0] as written):
+    # `avance = int(0.75 * 128)` = 96 (M_u/Evaluation/Eval_dual_Dense_onlycil.py:499), stride 32
+    "chapter4_Mu_128x128": dict(variant="chapter5", Ny=128, Nx=128, chapter4="M_u"),                 # cavity-like vortex, 4 blocks
+    "chapter4_Mu_232x312": dict(variant="chapter5", Ny=232, Nx=312, seed=61, chapter4="M_u"),        # channel + cylinder, 35 blocks
+    "chapter4_MfU_200x280": dict(variant="chapter5", Ny=200, Nx=280, seed=62, chapter4="M_fU"),      # f(U), SDF -> p: 2 input channels
 }
 
 
@@ -33,10 +38,37 @@ def real_chapter5_weights():
     return [(d[f"W{i}"], d[f"b{i}"]) for i in range(n)], d["maxs"], d["maxs_PCA"]
 
 
+def real_chapter4_weights(which: str):
+    """Trained Chapter-4 networks of the reference as data (tests/golden/chapter4_weights.npz, written by
+    make_golden.py with the build's own HDF5 reader): 'M_u' = M_u/trained_models/cil.h5 (32 -> 3x512 -> 32),
+    'M_fU' = M_fU/Evaluation/model_first_.h5 (116 -> 3x512 -> 39) with that directory's maxs / maxs_PCA files."""
+    d = np.load(os.path.join(GOLDEN_DIR, "chapter4_weights.npz"))
+    n = len([k for k in d.files if k.startswith(which + "_W")])
+    return [(d[f"{which}_W{i}"], d[f"{which}_b{i}"]) for i in range(n)], d["MfU_maxs"], d["MfU_maxs_PCA"]
+
+
 def build(name: str):
     """-> (grid[Ny,Nx,C] float64, SurrogateModel) for a GOLDEN_CASES entry."""
     sp = GOLDEN_CASES[name]
     v, Ny, Nx = sp["variant"], sp["Ny"], sp["Nx"]
+    if sp.get("chapter4"):
+        which = sp["chapter4"]
+        W, maxs, maxs_pca = real_chapter4_weights(which)
+        c_in = 3 if which == "M_u" else 2
+        model = synthetic.make_model("chapter5", p_in=W[0][0].shape[0], p_out=W[-1][0].shape[1], weights=W, c_in=c_in,
+                                     seed_pca=4000 + c_in)
+        model.ov, model.sdf_ch = 96, c_in - 1                # avance = int(0.75 * shape)
+        if "seed" in sp:
+            g = synthetic.channel_grid(Ny, Nx, seed=sp["seed"], extra_channels=1, cx=0.35, r=0.16)
+        else:
+            g = np.concatenate([synthetic.cavity_grid(Ny), np.zeros((Ny, Ny, 1))], axis=-1)
+            g[..., 3] = np.cos(2 * np.pi * np.arange(Ny) / Ny)[None, :] * np.sin(np.pi * np.arange(Ny) / Ny)[:, None]
+        if which == "M_fU":                                  # (f(U), SDF, p): 3 channels, 2 of them inputs
+            fu = g[..., 0] ** 2 - 0.5 * g[..., 1]
+            fu[g[..., 2] == 0] = 0.0
+            g = np.stack([fu / np.abs(fu).max(), g[..., 2], g[..., 3]], axis=-1)
+            model.in_a, model.out_a = 0.6, 12.0              # that directory's maxs_PCA holds a copy of `maxs`: synthetic scalers
+        return g, model
     if sp.get("real_weights"):
         # BASELINE config 0: real trained MLP (45->512x3->48) of the reference's
         # Chapter-5 test case, its maxs_PCA scalers, synthetic PCA seed 1234.

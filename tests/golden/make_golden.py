@@ -213,6 +213,29 @@ def run_chapter5(grid3, model):
                 n_blocks=np.int64(loc["N"]))
 
 
+C4E = f"{REF}/Thesis_Work/Chapter4/MLP/M_u/Evaluation/Eval_dual_Dense_onlycil.py"
+C4F = f"{REF}/Thesis_Work/Chapter4/MLP/M_fU/Evaluation/Eval.py"
+C4_MODELS = {"M_u": f"{REF}/Thesis_Work/Chapter4/MLP/M_u/trained_models/cil.h5",
+             "M_fU": f"{REF}/Thesis_Work/Chapter4/MLP/M_fU/Evaluation/model_first_.h5"}
+
+
+def run_chapter4(grid, model, which):
+    """Thesis_Work/Chapter4 evaluators (M_u/Evaluation/Eval_dual_Dense_onlycil.py:236-414, M_fU/Evaluation/Eval.py:
+    227-411): `timeStep` from the block extraction to the final shift, avance = int(0.75 * shape)."""
+    path = C4E if which == "M_u" else C4F
+    tree = _tree(path)
+    body = _find_fn(tree, "timeStep", "Evaluation").body
+    stmts = _slice(body, lambda s: s.startswith("x_list = []"), lambda s: s.startswith("result_array -= np.mean("))
+    me = types.SimpleNamespace(avance=model.ov, shape=model.S, pcainput=sk_pca(model.comp_in, model.mean_in),
+                               pcap=sk_pca(model.comp_out, model.mean_out), pc_in=model.p_in, pc_p=model.p_out,
+                               max_abs_input_PCA=model.in_a, max_abs_p_PCA=model.out_a, model=dense_callable(model.weights))
+    loc = {"self": me, "grid": grid[None].astype(np.float64).copy()}
+    with np.errstate(all="ignore"):
+        _run(stmts, {"np": np}, loc, path)
+    return dict(x_input=np.asarray(loc["x_input"], np.float64), fields=np.asarray(loc["result_array"])[0],
+                n_blocks=np.int64(loc["N"]))
+
+
 def run_py_func_mesh(array, geo, model, maxs):
     """PM.py_func, the whole rank-0 body from the gathered cell array to the final p
     (python_module.py:264-496), with the one-time tables of init_func supplied (their
@@ -364,6 +387,16 @@ def main():
     np.savez_compressed(os.path.join(HERE, "chapter5_weights.npz"), maxs=maxs, maxs_PCA=maxs_pca, **flat)
     print("chapter5_weights.npz", [w.shape for w, _ in W])
 
+    # trained Chapter-4 networks (read with the build's own HDF5 reader) + the M_fU evaluator's scale files
+    flat = {}
+    for which, path in C4_MODELS.items():
+        for i, (w, b) in enumerate(formats.read_keras_dense_weights(path)):
+            flat[f"{which}_W{i}"], flat[f"{which}_b{i}"] = w, b
+    c4dir = f"{REF}/Thesis_Work/Chapter4/MLP/M_fU/Evaluation"
+    np.savez_compressed(os.path.join(HERE, "chapter4_weights.npz"), MfU_maxs=formats.read_maxs(f"{c4dir}/maxs"),
+                        MfU_maxs_PCA=formats.read_maxs(f"{c4dir}/maxs_PCA"), **flat)
+    print("chapter4_weights.npz", sorted(k for k in flat if k.endswith("W0")), [flat[k].shape for k in sorted(flat) if "_W" in k])
+
     # ---- mesh-side boundary (py_func on one rank) --------------------------------
     from oracle import psm_oracle as orc
     array, top, obst, model, maxs = cases.build_mesh_case()
@@ -442,7 +475,9 @@ def main():
 
     for name in cases.GOLDEN_CASES:
         grid, model = cases.build(name)
-        if model.variant == "gradp":
+        if cases.GOLDEN_CASES[name].get("chapter4"):
+            out = run_chapter4(grid, model, cases.GOLDEN_CASES[name]["chapter4"])
+        elif model.variant == "gradp":
             out = run_gradp(grid, model, keep_labels=(name == "gradp_272x288"))
         elif model.variant == "deltas":
             out = run_deltas(grid, model, U_max_norm=cases.GOLDEN_CASES[name].get("U_max_norm", 1.0),
