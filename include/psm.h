@@ -200,6 +200,13 @@ int psm_solve_grid_device(psm_handle* h, const float* d_grid, int32_t n_cases,
  * of caller-supplied decoded blocks block_pred[B, S*S*c_out] for ONE case, host
  * buffers, synchronous.  grid supplies the flow mask (its sdf channel). */
 int psm_reassemble(psm_handle* h, const float* grid, const float* block_pred, float* fields);
+/* Evaluation only (a8): the label blocks of the planned layout with the per-block mean over the flow cells removed,
+ *   y_array[b, ..., c][x_array[b, ..., sdf] != 0] -= mean(same selection)          (SMD:487-488, UGP:509-511)
+ * grid [ny, nx, c_in] supplies the flow mask, labels [ny, nx, c_out] the label image(s); blocks_out
+ * [B, S*S*c_out] has the layout psm_reassemble takes, so that labels -> psm_label_blocks -> psm_reassemble is the
+ * reference's self-check of the assembly ("it should be almost perfect in that case", SMD:577-580; live form
+ * UGP:546-547 test_dPdx / test_dPdy).  Host buffers, synchronous. */
+int psm_label_blocks(psm_handle* h, const float* grid, const float* labels, float* blocks_out);
 /* ---- mesh-side entry: the contract of PythonComm_init.H / PythonComm.H ------------
  * psm_set_geometry installs the one-time tables that init_func builds (PM:195-243):
  *   vtx_m2g/wts_m2g [ny*nx,3]  simplices + barycentric weights, mesh -> grid (interp_weights, PM:210)

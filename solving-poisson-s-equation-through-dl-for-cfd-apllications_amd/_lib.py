@@ -70,6 +70,7 @@ SIGNATURES = {
     "psm_wait_grid": (C.c_int, [_hp, C.c_int64, _f32p]),
     "psm_solve_grid_device": (C.c_int, [_hp, C.c_void_p, C.c_int32, _f32p, C.c_void_p, C.c_void_p]),
     "psm_reassemble": (C.c_int, [_hp, _f32p, _f32p, _f32p]),
+    "psm_label_blocks": (C.c_int, [_hp, _f32p, _f32p, _f32p]),
     "psm_set_geometry": (C.c_int, [_hp, C.c_int64, C.c_int32, C.c_int32, _i32p, _f64p, _i32p, _f64p, _i32p, _f64p, _f64p,
                                    C.c_int32, C.c_int32, C.c_double]),
     "psm_solve": (C.c_int, [_hp, _f64p, C.c_int64, C.c_int32, _f64p]),

@@ -97,6 +97,7 @@ struct psm_handle {
   // kernels and the D2H copy of a ticket run in order on the slot's stream, different slots overlap freely.
   struct Slot {
     float *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr, *h_rs = nullptr;
+    float *m_in = nullptr, *m_out = nullptr, *m_rs = nullptr;   // device-side addresses of the pinned buffers (mapped)
     Workspace ws;
     hipStream_t st = nullptr;
     hipEvent_t ev_out = nullptr;
@@ -112,8 +113,11 @@ struct psm_handle {
   Slot slot[SLOTS];
   bool ring_ready = false;
   int ring_graph = 1;          // PSM_RING_GRAPH=0: plain launches on the slot streams
+  int ring_dma = 0;            // PSM_RING_DMA=1: hipMemcpyAsync copies around the kernels instead of the GPU pulling the
+                               // grid from / storing the field to the mapped pinned buffers itself
   int64_t next_ticket = 0;
-  std::vector<std::pair<char*, size_t>> host_regs;   // psm_host_register
+  struct HostReg { char* base; size_t bytes; char* dev; };
+  std::vector<HostReg> host_regs;                    // psm_host_register
   // row-scale upload ring (pinned)
   static constexpr int RING = 8;
   float* h_scale[RING] = {};
@@ -742,7 +746,7 @@ void psm_destroy(psm_handle* h) {
   }
   for (auto& p : h->timed_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
-  for (auto& r : h->host_regs) (void)hipHostUnregister(r.first);
+  for (auto& r : h->host_regs) (void)hipHostUnregister(r.base);
   delete h;
 }
 
@@ -1087,8 +1091,15 @@ int psm_solve_grid(psm_handle* h, const float* grid, int32_t n_cases, const floa
 // the copies of ticket k+1 / k-1 run on the DMA engines while the kernels of ticket k compute.
 static bool host_registered(const psm_handle* h, const void* p, size_t bytes) {
   const char* c = (const char*)p;
-  for (auto& r : h->host_regs) if (c >= r.first && c + bytes <= r.first + r.second) return true;
+  for (auto& r : h->host_regs) if (c >= r.base && c + bytes <= r.base + r.bytes) return true;
   return false;
+}
+// device-side address of a host pointer inside a registered range (nullptr: not registered / not mapped)
+static float* host_mapped(const psm_handle* h, const void* p, size_t bytes) {
+  const char* c = (const char*)p;
+  for (auto& r : h->host_regs)
+    if (c >= r.base && c + bytes <= r.base + r.bytes) return r.dev ? (float*)(r.dev + (c - r.base)) : nullptr;
+  return nullptr;
 }
 
 static int ring_init(psm_handle* h) {
@@ -1097,10 +1108,18 @@ static int ring_init(psm_handle* h) {
   const size_t gin = (size_t)h->cfg.max_cases * npix * h->cfg.c_in, gout = (size_t)h->cfg.max_cases * npix * h->cfg.c_out;
   const char* rg = getenv("PSM_RING_GRAPH");
   h->ring_graph = (rg && rg[0] == '0') ? 0 : 1;
+  const char* rd = getenv("PSM_RING_DMA");
+  h->ring_dma = (rd && rd[0] == '1') ? 1 : 0;
   for (auto& s : h->slot) {
-    HIPCHK(h, hipHostMalloc((void**)&s.h_in, gin * sizeof(float), hipHostMallocDefault));
-    HIPCHK(h, hipHostMalloc((void**)&s.h_out, gout * sizeof(float), hipHostMallocDefault));
-    HIPCHK(h, hipHostMalloc((void**)&s.h_rs, (size_t)h->Mpad_cap * sizeof(float), hipHostMallocDefault));
+    HIPCHK(h, hipHostMalloc((void**)&s.h_in, gin * sizeof(float), hipHostMallocMapped));
+    HIPCHK(h, hipHostMalloc((void**)&s.h_out, gout * sizeof(float), hipHostMallocMapped));
+    HIPCHK(h, hipHostMalloc((void**)&s.h_rs, (size_t)h->Mpad_cap * sizeof(float), hipHostMallocMapped));
+    if (hipHostGetDevicePointer((void**)&s.m_in, s.h_in, 0) != hipSuccess || hipHostGetDevicePointer((void**)&s.m_out, s.h_out, 0) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&s.m_rs, s.h_rs, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      s.m_in = s.m_out = s.m_rs = nullptr;
+      h->ring_dma = 1;                                   // no mapped view of pinned memory: DMA copies
+    }
     int rc;
     if ((rc = dev_alloc(h, &s.d_in, gin))) return rc;
     if ((rc = dev_alloc(h, &s.d_out, gout))) return rc;
@@ -1117,65 +1136,91 @@ static int ring_init(psm_handle* h) {
 // key of a captured slot graph: everything the captured launch sequence depends on
 static int ring_key(const psm_handle* h, int n_cases, bool scale) {
   const bool bound = h->bound && h->bound_scope == 2 && n_cases == h->bound_cases;
-  return (n_cases * 2 + (scale ? 1 : 0)) * 2 + (bound ? 1 : 0);
+  return ((n_cases * 2 + (scale ? 1 : 0)) * 2 + (bound ? 1 : 0)) * 2 + (h->ring_dma ? 1 : 0);
 }
 
-// Capture (copies +) kernels of one ticket on the slot's stream.  full: H2D from s.h_in, D2H into s.h_out.
-static int ring_capture(psm_handle* h, psm_handle::Slot& s, int n_cases, bool scale, bool full, hipGraphExec_t* out) {
+// The launch sequence of one ticket on the slot's stream.
+//  pull form (src_dev / dst_dev = device-side addresses of pinned or registered host memory): a stage-in kernel pulls the
+//    grid over PCIe into s.d_in (and expands the out_scale), the solve's last kernel stores the field straight into
+//    dst_dev -- kernels only;
+//  DMA form (src_dev == nullptr): hipMemcpyAsync H2D from src, kernels, hipMemcpyAsync D2H into dst (copies optional:
+//    with_copies = false enqueues the kernels alone).
+static int ring_sequence(psm_handle* h, psm_handle::Slot& s, int n_cases, bool scale, const float* src_dev, float* dst_dev,
+                         const float* src, float* dst, bool with_copies) {
   const size_t npix = (size_t)h->Ny * h->Nx;
-  const size_t gin = (size_t)n_cases * npix * h->cfg.c_in * sizeof(float), gout = (size_t)n_cases * npix * h->cfg.c_out * sizeof(float);
-  hipGraph_t graph = nullptr;
-  HIPCHK(h, hipStreamBeginCapture(s.st, hipStreamCaptureModeRelaxed));
-  hipError_t e = hipSuccess;
-  if (full) e = hipMemcpyAsync(s.d_in, s.h_in, gin, hipMemcpyHostToDevice, s.st);
-  if (e == hipSuccess && scale) e = hipMemcpyAsync(s.ws.d_row_scale, s.h_rs, (size_t)n_cases * h->B * sizeof(float), hipMemcpyHostToDevice, s.st);
-  int rc = PSM_OK;
-  if (e == hipSuccess) rc = launch_all(h, s.ws, s.d_in, n_cases, s.d_out, scale ? s.ws.d_row_scale : h->d_ones, s.st, nullptr);
-  if (e == hipSuccess && rc == PSM_OK && full) e = hipMemcpyAsync(s.h_out, s.d_out, gout, hipMemcpyDeviceToHost, s.st);
-  hipError_t e2 = hipStreamEndCapture(s.st, &graph);
-  if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-  if (e != hipSuccess || e2 != hipSuccess) {
-    if (graph) (void)hipGraphDestroy(graph);
-    return fail(h, PSM_ERR_HIP, std::string("ring capture: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+  const size_t nin = (size_t)n_cases * npix * h->cfg.c_in, nout = (size_t)n_cases * npix * h->cfg.c_out;
+  const int M = n_cases * h->B;
+  if (src_dev) {
+    HIPCHK(h, psm_launch_stage_in(src_dev, s.d_in, nin, scale ? s.m_rs : nullptr, s.ws.d_row_scale, M, h->B, s.st));
+    return launch_all(h, s.ws, s.d_in, n_cases, dst_dev, scale ? s.ws.d_row_scale : h->d_ones, s.st, nullptr);
   }
-  e = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
-  (void)hipGraphDestroy(graph);
-  if (e != hipSuccess) return fail(h, PSM_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+  if (with_copies) HIPCHK(h, hipMemcpyAsync(s.d_in, src, nin * sizeof(float), hipMemcpyHostToDevice, s.st));
+  if (scale) HIPCHK(h, hipMemcpyAsync(s.ws.d_row_scale, s.h_rs, (size_t)M * sizeof(float), hipMemcpyHostToDevice, s.st));
+  int rc = launch_all(h, s.ws, s.d_in, n_cases, s.d_out, scale ? s.ws.d_row_scale : h->d_ones, s.st, nullptr);
+  if (rc) return rc;
+  if (with_copies) HIPCHK(h, hipMemcpyAsync(dst, s.d_out, nout * sizeof(float), hipMemcpyDeviceToHost, s.st));
   return PSM_OK;
 }
 
-// Enqueue one ticket.  src / dst: where the DMA reads the grid from / writes the field to (pinned or registered host
-// memory); the slot's own buffers take the one-replay form.
+static int ring_capture(psm_handle* h, psm_handle::Slot& s, int n_cases, bool scale, const float* src_dev, float* dst_dev,
+                        bool with_copies, hipGraphExec_t* out) {
+  hipGraph_t graph = nullptr;
+  HIPCHK(h, hipStreamBeginCapture(s.st, hipStreamCaptureModeRelaxed));
+  const std::string keep = h->err;
+  int rc = ring_sequence(h, s, n_cases, scale, src_dev, dst_dev, s.h_in, s.h_out, with_copies);
+  hipError_t e2 = hipStreamEndCapture(s.st, &graph);
+  if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+  if (e2 != hipSuccess) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return fail(h, PSM_ERR_HIP, std::string("ring capture: ") + hipGetErrorString(e2));
+  }
+  hipError_t e = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) return fail(h, PSM_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+  h->err = keep;
+  return PSM_OK;
+}
+
+// Enqueue one ticket.  src / dst: where the grid is read from / the field is written to (the slot's pinned buffers or
+// registered caller memory).
 static int ring_launch(psm_handle* h, psm_handle::Slot& s, int n_cases, const float* out_scale, const float* src, float* dst) {
   const size_t npix = (size_t)h->Ny * h->Nx;
   const size_t gin = (size_t)n_cases * npix * h->cfg.c_in * sizeof(float), gout = (size_t)n_cases * npix * h->cfg.c_out * sizeof(float);
   const bool scale = out_scale != nullptr;
-  if (scale)
-    for (int c = 0; c < n_cases; ++c)
-      for (int b = 0; b < h->B; ++b) s.h_rs[c * h->B + b] = out_scale[c];
   const bool own = (src == s.h_in && dst == s.h_out);
+  const float* src_dev = nullptr;
+  float* dst_dev = nullptr;
+  if (!h->ring_dma) {                                    // pull form needs device-side views of both host buffers
+    src_dev = src == s.h_in ? s.m_in : host_mapped(h, src, gin);
+    dst_dev = dst == s.h_out ? s.m_out : host_mapped(h, dst, gout);
+    if (!src_dev || !dst_dev) src_dev = nullptr, dst_dev = nullptr;
+  }
+  if (scale) {
+    if (src_dev) for (int c = 0; c < n_cases; ++c) s.h_rs[c] = out_scale[c];
+    else
+      for (int c = 0; c < n_cases; ++c)
+        for (int b = 0; b < h->B; ++b) s.h_rs[c * h->B + b] = out_scale[c];
+  }
   const int key = ring_key(h, n_cases, scale);
+  const bool graphs = h->ring_graph && h->timed_kernel < 0;
   int rc;
-  if (h->ring_graph && h->timed_kernel < 0 && own) {
+  if (graphs && own) {                                   // the whole ticket is one replay
     if (!s.g_full || s.g_full_key != key) {
       if (s.g_full) { (void)hipGraphExecDestroy(s.g_full); s.g_full = nullptr; }
-      if ((rc = ring_capture(h, s, n_cases, scale, true, &s.g_full))) return rc;
+      if ((rc = ring_capture(h, s, n_cases, scale, src_dev, dst_dev, true, &s.g_full))) return rc;
       s.g_full_key = key;
     }
     HIPCHK(h, hipGraphLaunch(s.g_full, s.st));
-  } else {
+  } else if (src_dev || !graphs) {                       // caller memory, pull form (pointers differ per ticket) / plain launches
+    if ((rc = ring_sequence(h, s, n_cases, scale, src_dev, dst_dev, src, dst, true))) return rc;
+  } else {                                               // caller memory, DMA copies around a replay of the kernels
     HIPCHK(h, hipMemcpyAsync(s.d_in, src, gin, hipMemcpyHostToDevice, s.st));
-    if (h->ring_graph && h->timed_kernel < 0) {
-      if (!s.g_kern || s.g_kern_key != key) {
-        if (s.g_kern) { (void)hipGraphExecDestroy(s.g_kern); s.g_kern = nullptr; }
-        if ((rc = ring_capture(h, s, n_cases, scale, false, &s.g_kern))) return rc;
-        s.g_kern_key = key;
-      }
-      HIPCHK(h, hipGraphLaunch(s.g_kern, s.st));
-    } else {
-      if (scale) HIPCHK(h, hipMemcpyAsync(s.ws.d_row_scale, s.h_rs, (size_t)n_cases * h->B * sizeof(float), hipMemcpyHostToDevice, s.st));
-      if ((rc = launch_all(h, s.ws, s.d_in, n_cases, s.d_out, scale ? s.ws.d_row_scale : h->d_ones, s.st, nullptr))) return rc;
+    if (!s.g_kern || s.g_kern_key != key) {
+      if (s.g_kern) { (void)hipGraphExecDestroy(s.g_kern); s.g_kern = nullptr; }
+      if ((rc = ring_capture(h, s, n_cases, scale, nullptr, nullptr, false, &s.g_kern))) return rc;
+      s.g_kern_key = key;
     }
+    HIPCHK(h, hipGraphLaunch(s.g_kern, s.st));
     HIPCHK(h, hipMemcpyAsync(dst, s.d_out, gout, hipMemcpyDeviceToHost, s.st));
   }
   HIPCHK(h, hipEventRecord(s.ev_out, s.st));
@@ -1281,10 +1326,12 @@ int psm_host_register(psm_handle* h, void* ptr, size_t bytes) {
   if (!h) return PSM_ERR_ARG;
   if (!ptr || bytes == 0) return fail(h, PSM_ERR_ARG, "null range");
   HIPCHK(h, hipSetDevice(h->cfg.device));
-  for (auto& r : h->host_regs) if (r.first == (char*)ptr) return fail(h, PSM_ERR_STATE, "range already registered");
-  hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+  for (auto& r : h->host_regs) if (r.base == (char*)ptr) return fail(h, PSM_ERR_STATE, "range already registered");
+  hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterMapped);
   if (e != hipSuccess) { (void)hipGetLastError(); return fail(h, PSM_ERR_HIP, std::string("hipHostRegister: ") + hipGetErrorString(e)); }
-  h->host_regs.push_back({(char*)ptr, bytes});
+  void* dev = nullptr;
+  if (hipHostGetDevicePointer(&dev, ptr, 0) != hipSuccess) { (void)hipGetLastError(); dev = nullptr; }   // DMA copies only
+  h->host_regs.push_back({(char*)ptr, bytes, (char*)dev});
   return PSM_OK;
 }
 
@@ -1292,7 +1339,7 @@ int psm_host_unregister(psm_handle* h, void* ptr) {
   if (!h) return PSM_ERR_ARG;
   HIPCHK(h, hipSetDevice(h->cfg.device));
   for (size_t i = 0; i < h->host_regs.size(); ++i)
-    if (h->host_regs[i].first == (char*)ptr) {
+    if (h->host_regs[i].base == (char*)ptr) {
       HIPCHK(h, hipDeviceSynchronize());                  // no DMA of this handle may still touch the range
       (void)hipHostUnregister(ptr);
       h->host_regs.erase(h->host_regs.begin() + i);
@@ -1326,6 +1373,30 @@ int psm_reassemble(psm_handle* h, const float* grid, const float* block_pred, fl
   HIPCHK(h, hipMemcpyAsync(fields, h->d_fields_stage, npix * h->cfg.c_out * sizeof(float), hipMemcpyDeviceToHost, st));
   HIPCHK(h, wait_stream(st));
   h->last_cases = 1;
+  return PSM_OK;
+}
+
+int psm_label_blocks(psm_handle* h, const float* grid, const float* labels, float* blocks_out) {
+  if (!h) return PSM_ERR_ARG;
+  if (!h->planned) return fail(h, PSM_ERR_STATE, "psm_plan_grid has not been called");
+  if (!grid || !labels || !blocks_out) return fail(h, PSM_ERR_ARG, "null buffer");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  hipStream_t st = h->stream;
+  const size_t npix = (size_t)h->Ny * h->Nx;
+  const size_t gb = npix * h->cfg.c_in * sizeof(float), lb = npix * h->cfg.c_out * sizeof(float), ob = (size_t)h->B * h->K_out * sizeof(float);
+  int rc;
+  if ((rc = scratch_reserve(h, carve_size({gb, lb, ob}), carve_size({gb, lb, ob})))) return rc;
+  Carver cd{(char*)h->scr_dev}, cp{(char*)h->scr_pin};
+  float* d_g = cd.take<float>(npix * h->cfg.c_in); float* d_l = cd.take<float>(npix * h->cfg.c_out); float* d_o = cd.take<float>((size_t)h->B * h->K_out);
+  float* p_g = cp.take<float>(npix * h->cfg.c_in); float* p_l = cp.take<float>(npix * h->cfg.c_out); float* p_o = cp.take<float>((size_t)h->B * h->K_out);
+  memcpy(p_g, grid, gb); memcpy(p_l, labels, lb);
+  hipError_t e = hipMemcpyAsync(d_g, p_g, gb, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_l, p_l, lb, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = psm_launch_label_blocks(d_g, d_l, h->d_blk, d_o, h->B, h->S, h->cfg.c_in, h->cfg.c_out, h->cfg.sdf_channel, h->Nx, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(p_o, d_o, ob, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = wait_stream(st);
+  if (e != hipSuccess) return fail(h, PSM_ERR_HIP, std::string("label blocks: ") + hipGetErrorString(e));
+  memcpy(blocks_out, p_o, ob);
   return PSM_OK;
 }
 

@@ -172,3 +172,6 @@ hipError_t psm_launch_chain(const PsmChainArgs& a, int n_cases, hipStream_t s);
 hipError_t psm_launch_paste(const PsmPasteArgs& a, int n_cases, hipStream_t s);
 // chain + shift + paste in one launch; valid when B <= 64 and n_x < 64
 hipError_t psm_launch_assemble(const PsmChainArgs& a, const PsmPasteArgs& p, int n_cases, hipStream_t s);
+// ring stage-in: grid from mapped pinned host memory -> device, + per-case out_scale (host, may be null) -> per-row scale
+hipError_t psm_launch_stage_in(const float* src_host, float* dst, size_t n_floats, const float* scale_host, float* row_scale,
+                               int n_rows, int B, hipStream_t s);

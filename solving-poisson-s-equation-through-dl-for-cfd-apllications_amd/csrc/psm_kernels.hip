@@ -1874,3 +1874,34 @@ hipError_t psm_launch_bind_unfolded(const PsmBindArgs& a, hipStream_t st) {
   PSM_LAUNCH(psm_bind_own_kernel, dim3((a.B * (a.S * a.S / 32) + 255) / 256), dim3(256), 0, st, a);
   return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------
+// Ring stage-in: the grid of one ticket is pulled from (mapped) pinned host memory by the GPU itself -- 16-byte loads over
+// PCIe, enough of them in flight to fill the link -- instead of a DMA-engine copy in front of the kernels: the whole
+// ticket is then kernel nodes only (one cheap graph replay, no engine hand-over signals).  The same launch expands the
+// per-case out_scale of the ticket (host, pinned) to the per-block-row scale the decode reads.
+__global__ __launch_bounds__(256) void psm_stage_in_kernel(const float4* src, float4* dst, size_t n16, const float* tail_src,
+                                                           float* tail_dst, int n_tail, const float* scale_host, float* row_scale,
+                                                           int n_rows, int B) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  // four independent 16-byte loads per lane and round: 192 workgroups x 256 lanes x 64 B = 3 MiB in flight at most
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  }
+  for (; i < n16; i += stride) dst[i] = src[i];
+  if (blockIdx.x == 0) {
+    for (int t = threadIdx.x; t < n_tail; t += 256) tail_dst[t] = tail_src[t];
+    if (scale_host) for (int r = threadIdx.x; r < n_rows; r += 256) row_scale[r] = scale_host[r / B];
+  }
+}
+
+hipError_t psm_launch_stage_in(const float* src_host, float* dst, size_t n_floats, const float* scale_host, float* row_scale,
+                               int n_rows, int B, hipStream_t st) {
+  const size_t n16 = n_floats / 4;
+  const int n_tail = (int)(n_floats - 4 * n16);
+  PSM_LAUNCH(psm_stage_in_kernel, dim3(192), dim3(256), 0, st, reinterpret_cast<const float4*>(src_host), reinterpret_cast<float4*>(dst), n16,
+             src_host + 4 * n16, dst + 4 * n16, n_tail, scale_host, row_scale, n_rows, B);
+  return hipGetLastError();
+}

@@ -46,6 +46,10 @@ hipError_t psm_launch_interp_to_grid(const double* values, int k, const int32_t*
 // one pass of the separable Gaussian filter (axis 0 = rows direction, 1 = columns)
 hipError_t psm_launch_gauss1d(const float* in, float* out, int ny, int nx, int axis, int radius, const float* wts, hipStream_t st);
 
+// label blocks [B][S*S*c_out] with the per-block flow-cell mean removed (SM_call.py:487-488, UGP:509-511)
+hipError_t psm_launch_label_blocks(const float* grid, const float* labels, const int32_t* blk_y0x0, float* out, int B, int S,
+                                   int c_in, int c_out, int sdf_ch, int Nx, hipStream_t st);
+
 // ---- U_to_gradP integration (UGP:371-416, 592-628)
 constexpr int PSM_INTEG_MAX_FIX = 4;   // distinct indices the "reset" quirk may touch per row
 struct PsmIntegArgs {

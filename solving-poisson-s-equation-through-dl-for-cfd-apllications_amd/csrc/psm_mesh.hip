@@ -196,6 +196,43 @@ hipError_t psm_launch_gauss1d(const float* in, float* out, int ny, int nx, int a
 }
 
 // ---------------------------------------------------------------------------
+// a8 (evaluation only): label blocks with the per-block mean over the flow cells removed --
+//   y_array[step, ..., c][x_array[step, ..., sdf] != 0] -= mean(y_array[step, ..., c][x_array[step, ..., sdf] != 0])
+// (SM_call.py:487-488; Eval_dual_Dense_onlycil.py:509-511).  One workgroup per (block, channel); float64 sums like the
+// float64 grid of the reference.  A block without flow cells keeps its values (the reference's empty-slice mean is
+// NaN but is assigned to an empty selection).
+__global__ __launch_bounds__(256) void psm_label_blocks_kernel(const float* grid, const float* labels, const int32_t* blk_y0x0,
+                                                               float* out, int S, int c_in, int c_out, int sdf_ch, int Nx) {
+  const int b = blockIdx.x, c = blockIdx.y, t = threadIdx.x;
+  const int y0 = blk_y0x0[2 * b], x0 = blk_y0x0[2 * b + 1];
+  __shared__ double ssum[256];
+  __shared__ double scnt[256];
+  double sum = 0.0, cnt = 0.0;
+  for (int i = t; i < S * S; i += 256) {
+    const int64_t pix = (int64_t)(y0 + i / S) * Nx + x0 + i % S;
+    if (grid[pix * c_in + sdf_ch] != 0.f) { sum += (double)labels[pix * c_out + c]; cnt += 1.0; }
+  }
+  ssum[t] = sum; scnt[t] = cnt;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) { ssum[t] += ssum[t + s]; scnt[t] += scnt[t + s]; }
+    __syncthreads();
+  }
+  const double mean = scnt[0] > 0.0 ? ssum[0] / scnt[0] : 0.0;
+  for (int i = t; i < S * S; i += 256) {
+    const int64_t pix = (int64_t)(y0 + i / S) * Nx + x0 + i % S;
+    const double v = (double)labels[pix * c_out + c];
+    out[((int64_t)b * S * S + i) * c_out + c] = (float)(grid[pix * c_in + sdf_ch] != 0.f ? v - mean : v);
+  }
+}
+
+hipError_t psm_launch_label_blocks(const float* grid, const float* labels, const int32_t* blk_y0x0, float* out, int B, int S,
+                                   int c_in, int c_out, int sdf_ch, int Nx, hipStream_t st) {
+  hipLaunchKernelGGL(psm_label_blocks_kernel, dim3(B, c_out), dim3(256), 0, st, grid, labels, blk_y0x0, out, S, c_in, c_out, sdf_ch, Nx);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // U_to_gradP: integration of (dp/dx, dp/dy) into p over four quadrants
 // (integrate_field UGP:371-416, stitching UGP:597-628).  For a quadrant with reference corner
 // column `ij` and row `ii` the reference's double loop reduces to

@@ -30,15 +30,19 @@ from psm_amd import formats  # noqa: E402
 from psm_amd.surrogate import SolverModule  # noqa: E402
 from psm_amd.synthetic import SurrogateModel  # noqa: E402
 
+comm, rank, nprocs = None, 0, 1
 try:                                                        # python_module.py:13-16
     import mpi4py
-    mpi4py.rc.initialize = False
+    mpi4py.rc.initialize = False                            # OpenFOAM's Pstream owns MPI_Init / MPI_Finalize
     mpi4py.rc.finalize = False
     from mpi4py import MPI
-    comm = MPI.COMM_WORLD
-    rank, nprocs = comm.Get_rank(), comm.Get_size()
-except ImportError:                                         # serial solver
-    comm, rank, nprocs = None, 0, 1
+    # The serial solvers (singleCore/DLPoissonSolver_*) never call MPI_Init: touching COMM_WORLD there would abort the
+    # run on a host that merely has mpi4py installed.  Only an MPI that the solver has initialised is used.
+    if MPI.Is_initialized():
+        comm = MPI.COMM_WORLD
+        rank, nprocs = comm.Get_rank(), comm.Get_size()
+except ImportError:                                         # serial solver, no mpi4py
+    pass
 
 
 def load_case(directory: str = "."):

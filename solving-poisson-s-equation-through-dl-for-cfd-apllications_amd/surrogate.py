@@ -252,6 +252,17 @@ class GridSurrogate:
         self._chk(self.lib.psm_reassemble(self.h, _p(g, C.c_float), _p(bp, C.c_float), _p(out, C.c_float)))
         return out
 
+    def label_blocks(self, grid: np.ndarray, labels: np.ndarray) -> np.ndarray:
+        """Label blocks of the planned layout with the per-block flow-cell mean removed (SM_call.py:487-488;
+        Eval_dual_Dense_onlycil.py:509-511): labels [Ny,Nx,c_out] (or [Ny,Nx]) -> [B,S,S,c_out] float32."""
+        g = _f32(np.asarray(grid)[..., :self.model.c_in])
+        lab = _f32(np.asarray(labels).reshape(self.ny, self.nx, self.model.c_out))
+        if g.shape != (self.ny, self.nx, self.model.c_in):
+            raise ValueError("grid has the wrong shape")
+        out = np.empty((self.B, self.model.S, self.model.S, self.model.c_out), np.float32)
+        self._chk(self.lib.psm_label_blocks(self.h, _p(g, C.c_float), _p(lab, C.c_float), _p(out, C.c_float)))
+        return out
+
     def gaussian_filter(self, field: np.ndarray, sigma=(10.0, 10.0)) -> np.ndarray:
         """scipy.ndimage.gaussian_filter(field, sigma, order=0) on the GPU (SM_call.py:353-363)."""
         f = _f32(field)
@@ -545,6 +556,16 @@ class Evaluation:
         """Grid-native body of ``timeStep`` (SM_call.py:452-575): -> deltap_res [Ny,Nx]."""
         sur = self._surrogate(grid.shape[0], grid.shape[1])
         return sur.solve(grid, out_scale=[max_abs_p * U_max_norm ** 2])[0, :, :, 0]
+
+    def label_self_check(self, grid: np.ndarray, labels: np.ndarray) -> np.ndarray:
+        """The reference's own check of the assembly algorithm: the CFD labels, de-meaned per block over the flow cells
+        (SM_call.py:487-488; Eval_dual_Dense_onlycil.py:509-511), pushed through the same reassembly as the prediction
+        ("it should be almost perfect in that case", SM_call.py:577-580; live as test_dPdx / test_dPdy at
+        Eval_dual_Dense_onlycil.py:546-547).  ``grid`` [Ny,Nx,>=c_in] normalised input image (flow mask = its SDF
+        channel), ``labels`` [Ny,Nx,c_out] -> assembled label field(s) [Ny,Nx,c_out]; also keeps ``self.y_array``."""
+        sur = self._surrogate(grid.shape[0], grid.shape[1])
+        self.y_array = sur.label_blocks(grid, labels)
+        return sur.reassemble(grid, self.y_array)
 
     def assemble_prediction(self, array, indices_list, n_x, n_y, apply_filter, shape_x, shape_y,
                             deltaU_change_grid=None, deltaP_prev_grid=None, apply_deltaU_change_wgt=False):

@@ -56,10 +56,13 @@ def _three_ways(sur, grids, scales, n_cases=1):
     return outs
 
 
-@pytest.mark.parametrize("graph", ["1", "0"])
+@pytest.mark.parametrize("graph,dma", [("1", "0"), ("0", "0"), ("1", "1"), ("0", "1")])
 @pytest.mark.parametrize("bind", [False, True])
-def test_every_way_into_the_ring_equals_the_synchronous_entry(bind, graph, monkeypatch):
+def test_every_way_into_the_ring_equals_the_synchronous_entry(bind, graph, dma, monkeypatch):
+    """graph: one replay per ticket / plain launches; dma: the GPU pulls the grid from and stores the field to the mapped
+    pinned buffers itself (0, default) / hipMemcpyAsync copies around the kernels (1)."""
     monkeypatch.setenv("PSM_RING_GRAPH", graph)
+    monkeypatch.setenv("PSM_RING_DMA", dma)
     model = synthetic.make_model("gradp", p_in=48, p_out=40)
     grids = [synthetic.channel_grid(256, 256, seed=1 + s).astype(np.float32)[None] for s in range(9)]
     # the ring test rotates VELOCITY fields of one geometry (a case stream); scales change per step
