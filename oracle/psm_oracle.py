@@ -605,15 +605,40 @@ def interp_weights(xyz, uvw):
 
 
 def _inside_convex_hull(pts, cloud):
-    """Strictly inside the convex hull of ``cloud`` (the reference: shapely convex_hull +
-    matplotlib Path.contains_points, PM:83-90)."""
+    """PM:83-90: shapely ``MultiPoint(cloud).convex_hull`` (un-vendored; its exterior ring is GEOS's clockwise
+    closed ring) + matplotlib ``Path.contains_points`` (un-vendored; published algorithm: the crossings test of
+    matplotlib/src/_path.h ``point_in_path_impl``, radius 0).  Scalar restatement, one point at a time."""
     from scipy.spatial import ConvexHull
-    hv = cloud[ConvexHull(cloud).vertices]            # counter-clockwise
-    inside = np.ones(len(pts), bool)
-    for a, b in zip(hv, np.roll(hv, -1, axis=0)):
-        cross = (b[0] - a[0]) * (pts[:, 1] - a[1]) - (b[1] - a[1]) * (pts[:, 0] - a[0])
-        inside &= cross > 0
-    return inside
+    ring = [tuple(cloud[i]) for i in ConvexHull(cloud).vertices][::-1]     # qhull: counter-clockwise -> clockwise
+    ring.append(ring[0])
+    out = np.zeros(len(pts), bool)
+    for i, (tx, ty) in enumerate(pts):
+        if not (np.isfinite(tx) and np.isfinite(ty)):
+            continue
+        inside = False
+        for (x0, y0), (x1, y1) in zip(ring, ring[1:] + ring[:1]):
+            f0, f1 = y0 >= ty, y1 >= ty
+            if f0 != f1 and (((y1 - ty) * (x0 - x1) >= (x1 - tx) * (y0 - y1)) == f1):
+                inside = not inside
+        out[i] = inside
+    return out
+
+
+def interp_weights_idw(xyz, uvw):
+    """pressureSM_deltas/utils.py:22-55 (= pressureSM_Poisson/SM_call.py:139-172): ``interp_weights`` whose targets
+    outside the hull take the 3 nearest source points with weights 1/max(d^2, 1e-6), normalised (sklearn KDTree in
+    the reference; the neighbour set is unique up to exact distance ties)."""
+    vertices, wts = interp_weights(xyz, uvw)
+    from scipy.spatial import Delaunay
+    outside = np.flatnonzero(Delaunay(xyz).find_simplex(uvw) == -1)
+    vertices, wts = vertices.copy(), wts.copy()
+    for t in outside:
+        d2 = ((np.asarray(xyz) - np.asarray(uvw)[t]) ** 2).sum(axis=1)
+        nn = np.argsort(d2, kind="stable")[:3]
+        w = 1.0 / np.maximum(np.sqrt(d2[nn]) ** 2, 1e-6)
+        vertices[t] = nn
+        wts[t] = w / w.sum()
+    return vertices, wts
 
 
 def domain_dist(top, obst, xy0, every=10):

@@ -1,6 +1,8 @@
 // psm_hostbench.cpp -- psm_bench_host: host-buffer throughput of the surrogate measured from a C++ loop that uses the
 // PUBLIC C-ABI only (include/psm.h), i.e. exactly what a C++ solver calling the library would execute per step.
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -26,6 +28,11 @@ extern "C" int psm_bench_host(psm_handle* h, const float* grids, int32_t n_input
   std::vector<int64_t> ticket((size_t)steps + wu);
   std::vector<float*> slot_out(PSM_RING_SLOTS, nullptr);
   const float* last = nullptr;
+  // PSM_BENCH_VERBOSE=1: where the calling thread spends its time (submission calls / waits), to stderr
+  const bool verbose = std::getenv("PSM_BENCH_VERBOSE") != nullptr;
+  double t_submit = 0.0, t_wait = 0.0;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
   auto run = [&](int first, int count) -> int {
     int r = PSM_OK;
     if (mode == 0) {
@@ -36,12 +43,15 @@ extern "C" int psm_bench_host(psm_handle* h, const float* grids, int32_t n_input
     }
     for (int i = first; i < first + count + depth && r == PSM_OK; ++i) {
       const int w = i - depth;                            // ticket to retire before the next submission
+      const auto tw0 = now();
       if (w >= first) {
         float* o = outs + (size_t)(w % PSM_RING_SLOTS) * gout;
         if (mode == 1) { r = psm_wait_grid(h, ticket[w], o); last = o; }
         else if (mode == 2) { r = psm_wait_grid(h, ticket[w], nullptr); last = o; }
         else { r = psm_ring_wait(h, ticket[w]); last = slot_out[ticket[w] % PSM_RING_SLOTS]; }
       }
+      const auto tw1 = now();
+      t_wait += us(tw0, tw1);
       if (r != PSM_OK || i >= first + count) continue;
       const float* g = grids + (size_t)(i % n_inputs) * gin;
       if (mode == 1) r = psm_submit_grid(h, g, n_cases, nullptr, &ticket[i]);
@@ -55,14 +65,19 @@ extern "C" int psm_bench_host(psm_handle* h, const float* grids, int32_t n_input
           r = psm_ring_submit(h, ticket[i], n_cases, nullptr);
         }
       }
+      t_submit += us(tw1, now());
     }
     return r;
   };
   if (wu > 0) rc = run(0, wu);
   if (rc == PSM_OK) {
     const auto t0 = std::chrono::steady_clock::now();
+    t_submit = t_wait = 0.0;
     rc = run(wu, steps);
     *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (verbose && mode != 0)
+      std::fprintf(stderr, "psm_bench_host mode %d depth %d: %.1f us per solve = %.1f us in submission calls + %.1f us waiting\n",
+                   mode, depth, *seconds * 1e6 / steps, t_submit / steps, t_wait / steps);
   }
   if (rc == PSM_OK && last_fields && last) std::memcpy(last_fields, last, gout * sizeof(float));
   if (mode == 2) { psm_host_unregister(h, (void*)grids); psm_host_unregister(h, outs); }

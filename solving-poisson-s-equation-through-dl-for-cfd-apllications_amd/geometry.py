@@ -4,8 +4,10 @@ in both directions, signed-distance image and the grid-point -> image-cell index
 
 This is the host (Python) side of the boundary, like in the reference; it uses the same
 third-party routine the reference uses for the triangulation (SciPy's qhull ``Delaunay``).
-shapely / matplotlib.path (convex hull + point-in-polygon, python_module.py:83-90) are replaced
-by ``scipy.spatial.ConvexHull`` half-plane tests.  The tables go to the GPU library through
+shapely (``MultiPoint.convex_hull``, python_module.py:83-85) is replaced by ``scipy.spatial.ConvexHull`` with the ring
+handed over in GEOS's clockwise order, and ``matplotlib.path.Path.contains_points`` (python_module.py:89-90) by a
+restatement of its crossings test (``points_in_ring``; pinned against matplotlib itself by
+tests/golden/domain_dist_case.npz, on-edge points included).  The tables go to the GPU library through
 ``psm_set_geometry``; the per-step work happens there.
 """
 from __future__ import annotations
@@ -40,10 +42,14 @@ def create_uniform_grid(x_min, x_max, y_min, y_max, delta):
     return XX0.flatten(), YY0.flatten()
 
 
-def interp_weights(xyz, uvw):
+def interp_weights(xyz, uvw, idw_fallback: bool = False):
     """python_module.py:52-62: simplex vertices and barycentric weights of ``uvw`` in the
     Delaunay triangulation of ``xyz`` (points outside the hull: simplex -1, i.e. the last
-    simplex, with at least one negative weight)."""
+    simplex, with at least one negative weight).
+
+    ``idw_fallback`` = the Improved_SM form (pressureSM_deltas/utils.py:22-55, pressureSM_Poisson/SM_call.py:139-172):
+    targets outside the hull take their 3 nearest source points with inverse-square-distance weights
+    (``1 / max(d**2, 1e-6)``, normalised) instead -- all positive, so ``interpolate_fill`` keeps them."""
     from scipy.spatial import Delaunay
     tri = Delaunay(xyz)
     simplex = tri.find_simplex(uvw)
@@ -52,19 +58,53 @@ def interp_weights(xyz, uvw):
     d = 2
     delta = uvw - temp[:, d]
     bary = np.einsum("njk,nk->nj", temp[:, :d, :], delta)
-    return vertices.astype(np.int32), np.hstack((bary, 1 - bary.sum(axis=1, keepdims=True)))
+    wts = np.hstack((bary, 1 - bary.sum(axis=1, keepdims=True)))
+    if idw_fallback:
+        out = simplex == -1
+        if out.any():
+            from scipy.spatial import cKDTree
+            nndist, nni = cKDTree(np.asarray(xyz)).query(np.asarray(uvw)[out], k=3)
+            w = 1.0 / np.maximum(nndist ** 2, 1e-6)
+            vertices[out] = nni
+            wts[out] = w / w.sum(axis=-1)[:, None]
+    return vertices.astype(np.int32), wts
+
+
+def convex_hull_ring(points):
+    """Closed ring of the convex hull of ``points`` as ``shapely.geometry.MultiPoint(points).convex_hull.exterior``
+    hands it over (python_module.py:83-86): clockwise (the orientation of GEOS's ConvexHull, e.g. the Shapely manual's
+    ``POLYGON ((1 0, 0 0, 0 2, 2 2, 3 1, 1 0))``), first vertex repeated at the end.  SciPy's qhull vertices are
+    counter-clockwise."""
+    from scipy.spatial import ConvexHull
+    hv = np.asarray(points, np.float64)[ConvexHull(points).vertices][::-1]
+    return np.vstack([hv, hv[:1]])
+
+
+def points_in_ring(ring, pts):
+    """``matplotlib.path.Path(ring).contains_points(pts)`` with the default ``radius=0`` (python_module.py:89-90),
+    restated: matplotlib's crossings test (src/_path.h ``point_in_path_impl``) toggles for every edge v0 -> v1 whose
+    end points lie on different sides of the +x ray (``yflag = (v.y >= ty)``) when
+    ``((v1.y - ty) * (v0.x - v1.x) >= (v1.x - tx) * (v0.y - v1.y)) == yflag1``; a path without CLOSEPOLY is closed by the
+    edge back to its first vertex."""
+    ring = np.asarray(ring, np.float64)
+    tx, ty = np.asarray(pts, np.float64)[:, 0], np.asarray(pts, np.float64)[:, 1]
+    inside = np.zeros(len(tx), bool)
+    n = len(ring)
+    for k in range(n):
+        v0, v1 = ring[k], ring[(k + 1) % n]
+        f0, f1 = v0[1] >= ty, v1[1] >= ty
+        hit = ((v1[1] - ty) * (v0[0] - v1[0]) >= (v1[0] - tx) * (v0[1] - v1[1])) == f1
+        inside ^= (f0 != f1) & hit
+    return inside & np.isfinite(tx) & np.isfinite(ty)
 
 
 def domain_dist(top, obst, xy0, every: int = 10):
     """python_module.py:72-99: inside the bounding box of the ``top`` patch and outside the convex
     hull of the obstacle; SDF = distance to the nearest of every ``every``-th boundary point."""
-    from scipy.spatial import ConvexHull
     from scipy.spatial.distance import cdist
     max_x, max_y, min_x, min_y = np.max(top[:, 0]), np.max(top[:, 1]), np.min(top[:, 0]), np.min(top[:, 1])
     inside_box = (xy0[:, 0] <= max_x) & (xy0[:, 0] >= min_x) & (xy0[:, 1] <= max_y) & (xy0[:, 1] >= min_y)
-    hull = ConvexHull(obst)
-    # hull.equations: [normal_x, normal_y, offset], normal.x + offset <= 0 inside
-    inside_obst = np.all(xy0 @ hull.equations[:, :2].T + hull.equations[:, 2] < 0.0, axis=1)
+    inside_obst = points_in_ring(convex_hull_ring(obst), xy0)
     domain_bool = inside_box & ~inside_obst
     t, o = top[::every], obst[::every]
     sdf = np.minimum(cdist(xy0, o).min(axis=1), cdist(xy0, t).min(axis=1)) * domain_bool
@@ -100,12 +140,13 @@ def build_geometry(array, top, obst, delta: float = 5e-3, every: int = 10, round
 
 
 def build_geometry_evaluator(points, p_values, top, obst, delta: float, every: int = 5, round_digits: int = 3,
-                             box: str = "mixed") -> GeometryTables:
+                             box: str = "mixed", idw_fallback: bool = False) -> GeometryTables:
     """``Evaluation.computeOnlyOnce`` (pressureSM_deltas/SM_call.py:89-180): like ``build_geometry`` with the
     evaluator's differences -- bounds rounded to 3 digits (:103-107), the box test mixes the ``top`` patch with
     the data bounds (:119-122), every 5th boundary point for the SDF (:139-140), ``p`` decides which grid
-    points are interpolable (:165-169), and there is no grid -> mesh direction."""
-    from scipy.spatial import ConvexHull
+    points are interpolable (:165-169), and there is no grid -> mesh direction.  ``idw_fallback``: the deltas and
+    Poisson evaluators interpolate with ``utils.interp_weights`` (nearest-neighbour IDW outside the mesh hull,
+    utils.py:47-53); the U_to_gradP evaluator's own method (Eval_dual_Dense_onlycil.py:69-85) has no fallback."""
     from scipy.spatial.distance import cdist
     points = np.asarray(points, np.float64)
     top, obst = np.asarray(top, np.float64), np.asarray(obst, np.float64)
@@ -113,15 +154,14 @@ def build_geometry_evaluator(points, p_values, top, obst, delta: float, every: i
     y_min, y_max = round(float(np.min(points[:, 1])), round_digits), round(float(np.max(points[:, 1])), round_digits)
     X0, Y0 = create_uniform_grid(x_min, x_max, y_min, y_max, delta)
     xy0 = np.stack([X0, Y0], axis=-1)
-    vtx, wts = interp_weights(points, xy0)
+    vtx, wts = interp_weights(points, xy0, idw_fallback)          # utils.interp_weights (SM_call.py:115) has the IDW fallback
     if box == "mixed":
         max_x, max_y = max(top[:, 0].max(), x_max), min(top[:, 1].max(), y_max)      # SM_call.py:119
         min_x, min_y = max(top[:, 0].min(), x_min), min(top[:, 1].min(), y_min)      # SM_call.py:120
     else:
         max_x, max_y, min_x, min_y = top[:, 0].max(), top[:, 1].max(), top[:, 0].min(), top[:, 1].min()
     inside_box = (xy0[:, 0] <= max_x) & (xy0[:, 0] >= min_x) & (xy0[:, 1] <= max_y) & (xy0[:, 1] >= min_y)
-    hull = ConvexHull(obst)
-    inside_obst = np.all(xy0 @ hull.equations[:, :2].T + hull.equations[:, 2] < 0.0, axis=1)
+    inside_obst = points_in_ring(convex_hull_ring(obst), xy0)
     domain_bool = inside_box & ~inside_obst
     sdf = np.minimum(cdist(xy0, obst[::every]).min(axis=1), cdist(xy0, top[::every]).min(axis=1)) * domain_bool
     ny, nx = int(round((y_max - y_min) / delta)), int(round((x_max - x_min) / delta))

@@ -468,7 +468,7 @@ class Evaluation:
         cells = np.asarray(data[0, 0, :self.indice], np.float64)
         top = np.asarray(top_b[0, 0, :formats.first_index(top_b[0, 0, :, 0], formats.PAD_VALUE)], np.float64)
         obst = np.asarray(obst_b[0, 0, :formats.first_index(obst_b[0, 0, :, 0], formats.PAD_VALUE)], np.float64)
-        t = build_geometry_evaluator(cells[:, 3:5], cells[:, 2], top, obst, self.delta)
+        t = build_geometry_evaluator(cells[:, 3:5], cells[:, 2], top, obst, self.delta, idw_fallback=True)   # utils.interp_weights
         self.grid_shape_y, self.grid_shape_x = t.ny, t.nx
         self.vert, self.weights, self.indices, self.sdfunct = t.vtx_m2g, t.wts_m2g, t.indices, t.sdfunct[:, :, None]
         sur = self._surrogate(t.ny, t.nx)

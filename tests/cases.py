@@ -157,6 +157,42 @@ def build_poisson_case():
                 max_abs=(2.7, 0.031, 0.027, 0.29))
 
 
+def build_domain_case(shape: str = "circle"):
+    """Inputs of `domain_dist` (python_module.py:72-99): `top` patch points (both channel walls), obstacle boundary
+    points, and the target points = a uniform 5e-3 grid plus the hard cases of a point-in-polygon test -- hull vertices,
+    edge mid-points, points level with a vertex, points on the bounding box.  'rectangle': obstacle edges that run
+    exactly through grid points."""
+    from psm_amd import geometry
+    delta = 5e-3
+    X0, Y0 = geometry.create_uniform_grid(0.0, 1.5, -0.35, 0.35, delta)
+    xs, ys = np.unique(X0), np.unique(Y0)
+    wall = np.linspace(0.0, 1.5, 301)
+    top = np.concatenate([np.c_[wall, np.full_like(wall, 0.35)], np.c_[wall, np.full_like(wall, -0.35)]])
+    if shape == "circle":
+        th = np.linspace(0.0, 2 * np.pi, 90, endpoint=False)
+        obst = np.c_[0.4 + 0.1 * np.cos(th), 0.013 + 0.1 * np.sin(th)]
+    else:                                                     # corners ON grid points
+        x0, x1, y0, y1 = xs[60], xs[80], ys[59], ys[79]
+        ex, ey = np.linspace(x0, x1, 21), np.linspace(y0, y1, 21)
+        obst = np.concatenate([np.c_[ex, np.full_like(ex, y0)], np.c_[ex, np.full_like(ex, y1)],
+                               np.c_[np.full_like(ey, x0), ey], np.c_[np.full_like(ey, x1), ey]])
+    ring = geometry.convex_hull_ring(obst)
+    mids = 0.5 * (ring[:-1] + ring[1:])
+    level = np.c_[np.repeat([0.05, 0.4, 0.9], len(ring) - 1), np.tile(ring[:-1, 1], 3)]       # rays through vertices
+    boxpts = np.array([[0.0, 0.35], [1.5, -0.35], [0.75, 0.35], [0.0, 0.0], [1.5, 0.1], [-0.001, 0.0], [0.7, 0.3501]])
+    xy0 = np.concatenate([np.c_[X0, Y0], ring[:-1], mids, level, boxpts])
+    return top, obst, xy0
+
+
+def build_idw_case():
+    """Inputs of the Improved_SM `interp_weights` (pressureSM_deltas/utils.py:22-55): a scattered source cloud and a
+    target lattice that reaches beyond its hull on every side (the IDW fallback branch)."""
+    rng = np.random.default_rng(909)
+    xyz = np.c_[rng.random(1500) * 1.0, rng.random(1500) * 0.6 - 0.3]
+    gx, gy = np.meshgrid(np.linspace(-0.05, 1.05, 89), np.linspace(-0.34, 0.34, 55))
+    return xyz, np.c_[gx.ravel(), gy.ravel()]
+
+
 DATASET_MAXS = (0.062, 0.055, 0.31, 0.047)
 
 

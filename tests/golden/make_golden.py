@@ -213,6 +213,45 @@ def run_chapter5(grid3, model):
                 n_blocks=np.int64(loc["N"]))
 
 
+def run_domain_dist(top, obst, xy0):
+    """python_module.py:72-99 `domain_dist`, executed: matplotlib's Path.contains_points and SciPy's cdist are the
+    real ones; shapely (not installed) is replaced by a DATA stand-in that hands over the convex hull's exterior ring
+    (SciPy qhull vertices in GEOS's clockwise closed order)."""
+    import matplotlib.path as mpltPath
+    from scipy.spatial import distance
+    from psm_amd import geometry
+
+    class MultiPoint:
+        def __init__(self, pts):
+            ring = geometry.convex_hull_ring(np.asarray(pts))
+            self.convex_hull = types.SimpleNamespace(exterior=types.SimpleNamespace(coords=types.SimpleNamespace(xy=(ring[:, 0], ring[:, 1]))))
+    glb = {"np": np, "MultiPoint": MultiPoint, "mpltPath": mpltPath, "distance": distance}
+    fn = _find_fn(_tree(PM), "domain_dist")
+    mod = ast.Module(body=[fn], type_ignores=[]); ast.fix_missing_locations(mod)
+    exec(compile(mod, PM, "exec"), glb)
+    dom, sdf = glb["domain_dist"](top, obst, xy0)
+    return np.asarray(dom, bool), np.asarray(sdf, np.float64)
+
+
+def run_interp_weights_idw(xyz, uvw):
+    """pressureSM_deltas/utils.py:22-55 `interp_weights` with its IDW fallback, executed (the file reaches KDTree
+    through the name `sklearn`, which it never imports: injected here)."""
+    import sklearn
+    import sklearn.neighbors  # noqa: F401
+    import scipy.spatial as _sp
+    try:
+        import scipy.spatial.qhull as qhull
+    except Exception:
+        qhull = types.SimpleNamespace(Delaunay=_sp.Delaunay)
+    UTL = f"{REF}/Improved_SM/deltaU_to_deltaP/source/pressureSM_deltas/utils.py"
+    fn = _find_fn(_tree(UTL), "interp_weights")
+    mod = ast.Module(body=[fn], type_ignores=[]); ast.fix_missing_locations(mod)
+    glb = {"np": np, "qhull": qhull, "sklearn": sklearn}
+    exec(compile(mod, UTL, "exec"), glb)
+    v, w = glb["interp_weights"](xyz, uvw)
+    return np.asarray(v, np.int64), np.asarray(w, np.float64)
+
+
 C4E = f"{REF}/Thesis_Work/Chapter4/MLP/M_u/Evaluation/Eval_dual_Dense_onlycil.py"
 C4F = f"{REF}/Thesis_Work/Chapter4/MLP/M_fU/Evaluation/Eval.py"
 C4_MODELS = {"M_u": f"{REF}/Thesis_Work/Chapter4/MLP/M_u/trained_models/cil.h5",
@@ -397,6 +436,23 @@ def main():
                         MfU_maxs_PCA=formats.read_maxs(f"{c4dir}/maxs_PCA"), **flat)
     print("chapter4_weights.npz", sorted(k for k in flat if k.endswith("W0")), [flat[k].shape for k in sorted(flat) if "_W" in k])
 
+    # ---- domain_dist (a3) and the IDW fallback of the Improved_SM interp_weights (a2)
+    dd = {}
+    for shape in ("circle", "rectangle"):
+        top, obst, xy0 = cases.build_domain_case(shape)
+        dom, sdf = run_domain_dist(top, obst, xy0)
+        dd[f"{shape}_domain"] = np.packbits(dom)
+        dd[f"{shape}_n"] = np.int64(len(dom))
+        dd[f"{shape}_sdf_tail"] = sdf[-400:].copy()                      # the hand-placed hard points
+        dd[f"{shape}_sdf_sum"] = np.float64(sdf.sum())
+        dd[f"{shape}_sdf_crop"] = sdf[:42000].reshape(140, 300)[40:100, 40:120].copy()
+        print(f"domain_dist {shape}: inside domain {int(dom.sum())} of {len(dom)}")
+    np.savez_compressed(os.path.join(HERE, "domain_dist_case.npz"), **dd)
+    xyz, uvw = cases.build_idw_case()
+    v, w = run_interp_weights_idw(xyz, uvw)
+    np.savez_compressed(os.path.join(HERE, "interp_weights_idw.npz"), vertices=v.astype(np.int32), weights=w)
+    print("interp_weights_idw: targets", len(uvw), "outside hull (all weights >= 0 after the fallback):", int((w >= 0).all(axis=1).sum()))
+
     # ---- mesh-side boundary (py_func on one rank) --------------------------------
     from oracle import psm_oracle as orc
     array, top, obst, model, maxs = cases.build_mesh_case()
@@ -451,7 +507,7 @@ def main():
         dc = cases.build_dataset_case(td)
     f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
     cells0 = np.asarray(dc["sim"][0, 0, :dc["N"]], np.float64)
-    tabs = geometry.build_geometry_evaluator(cells0[:, 3:5], cells0[:, 2], f32(dc["top"]), f32(dc["obst"]), 5e-3)
+    tabs = geometry.build_geometry_evaluator(cells0[:, 3:5], cells0[:, 2], f32(dc["top"]), f32(dc["obst"]), 5e-3, idw_fallback=True)
     out = run_evaluator_grid(np.asarray(dc["sim"][0, 1, :dc["N"]], np.float64), tabs, cases.DATASET_MAXS)
     np.savez_compressed(os.path.join(HERE, "evaluator_grid_138x300.npz"), **out)
     print("evaluator_grid: U_max_norm=%.6f |grid| sums" % out["U_max_norm"], out["grid_abs_sum"])

@@ -57,7 +57,7 @@ def test_artifact_loader_follows_the_reference_rules(ds):
 def _tables(c):
     cells = np.asarray(c["sim"][0, 0, :c["N"]], np.float64)
     f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)          # the dataset stores float32
-    return geometry.build_geometry_evaluator(cells[:, 3:5], cells[:, 2], f32(c["top"]), f32(c["obst"]), 5e-3)
+    return geometry.build_geometry_evaluator(cells[:, 3:5], cells[:, 2], f32(c["top"]), f32(c["obst"]), 5e-3, idw_fallback=True)
 
 
 def test_evaluator_geometry_rules(ds):
