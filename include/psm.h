@@ -178,7 +178,7 @@ int psm_solve_grid(psm_handle* h, const float* grid, int32_t n_cases,
  *      `grid` before the wait returns.  psm_solve_grid uses registered ranges the same way.
  *  (3) pageable memory: psm_submit_grid copies `grid` into the slot (the caller's buffer is free on return) and
  *      psm_wait_grid copies the field out. */
-#define PSM_RING_SLOTS 4
+#define PSM_RING_SLOTS 8
 int psm_ring_acquire(psm_handle* h, int64_t* ticket, float** grid_in, float** fields_out);
 int psm_ring_submit(psm_handle* h, int64_t ticket, int32_t n_cases, const float* out_scale);
 int psm_ring_wait(psm_handle* h, int64_t ticket);

@@ -25,6 +25,14 @@
 namespace {
 thread_local std::string g_create_error;
 
+// The ring keeps PSM_RING_SLOTS tickets in flight on their own streams, each stream with copy and kernel work; with the HIP
+// runtime's default number of hardware queues streams share queues and neighbouring tickets end up behind each other
+// (measured with 8 slots: 50 us per solve with 8 queues, 40 with 4, 34-35 with 12 / 16 / 32).  The runtime reads
+// GPU_MAX_HW_QUEUES when it initialises, so the library asks for 16 when it is loaded (before the fat-binary
+// registration of this library touches the runtime) -- unless the process has already chosen a value.  No effect when
+// HIP was initialised before the load.
+__attribute__((constructor(101))) void psm_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 struct DenseLayer {
@@ -112,9 +120,10 @@ struct psm_handle {
   static constexpr int SLOTS = PSM_RING_SLOTS;
   Slot slot[SLOTS];
   bool ring_ready = false;
+  int ring_slots = SLOTS;      // slots in rotation (PSM_RING_USE=n, n <= PSM_RING_SLOTS: experiments)
   int ring_graph = 1;          // PSM_RING_GRAPH=0: plain launches on the slot streams
-  int ring_dma = 0;            // PSM_RING_DMA=1: hipMemcpyAsync copies around the kernels instead of the GPU pulling the
-                               // grid from / storing the field to the mapped pinned buffers itself
+  int ring_dma = 1;            // PSM_RING_PULL=1 clears it: the GPU pulls the grid from / stores the field to the mapped pinned
+                               // buffers itself instead of hipMemcpyAsync (SDMA) copies around the kernels -- measured slower
   int64_t next_ticket = 0;
   struct HostReg { char* base; size_t bytes; char* dev; };
   std::vector<HostReg> host_regs;                    // psm_host_register
@@ -1108,8 +1117,10 @@ static int ring_init(psm_handle* h) {
   const size_t gin = (size_t)h->cfg.max_cases * npix * h->cfg.c_in, gout = (size_t)h->cfg.max_cases * npix * h->cfg.c_out;
   const char* rg = getenv("PSM_RING_GRAPH");
   h->ring_graph = (rg && rg[0] == '0') ? 0 : 1;
-  const char* rd = getenv("PSM_RING_DMA");
-  h->ring_dma = (rd && rd[0] == '1') ? 1 : 0;
+  const char* ru = getenv("PSM_RING_USE");
+  h->ring_slots = (ru && atoi(ru) >= 1 && atoi(ru) <= psm_handle::SLOTS) ? atoi(ru) : psm_handle::SLOTS;
+  const char* rp = getenv("PSM_RING_PULL");
+  h->ring_dma = (rp && rp[0] == '1') ? 0 : 1;
   for (auto& s : h->slot) {
     HIPCHK(h, hipHostMalloc((void**)&s.h_in, gin * sizeof(float), hipHostMallocMapped));
     HIPCHK(h, hipHostMalloc((void**)&s.h_out, gout * sizeof(float), hipHostMallocMapped));
@@ -1151,8 +1162,9 @@ static int ring_sequence(psm_handle* h, psm_handle::Slot& s, int n_cases, bool s
   const size_t nin = (size_t)n_cases * npix * h->cfg.c_in, nout = (size_t)n_cases * npix * h->cfg.c_out;
   const int M = n_cases * h->B;
   if (src_dev) {
-    HIPCHK(h, psm_launch_stage_in(src_dev, s.d_in, nin, scale ? s.m_rs : nullptr, s.ws.d_row_scale, M, h->B, s.st));
-    return launch_all(h, s.ws, s.d_in, n_cases, dst_dev, scale ? s.ws.d_row_scale : h->d_ones, s.st, nullptr);
+    static const int dbg = getenv("PSM_RING_DEBUG") ? atoi(getenv("PSM_RING_DEBUG")) : 0;   // timing experiments only: 1 no stage-in, 2 field stays on the device
+    if (!(dbg & 1)) HIPCHK(h, psm_launch_stage_in(src_dev, s.d_in, nin, scale ? s.m_rs : nullptr, s.ws.d_row_scale, M, h->B, s.st));
+    return launch_all(h, s.ws, s.d_in, n_cases, (dbg & 2) ? s.d_out : dst_dev, scale ? s.ws.d_row_scale : h->d_ones, s.st, nullptr);
   }
   if (with_copies) HIPCHK(h, hipMemcpyAsync(s.d_in, src, nin * sizeof(float), hipMemcpyHostToDevice, s.st));
   if (scale) HIPCHK(h, hipMemcpyAsync(s.ws.d_row_scale, s.h_rs, (size_t)M * sizeof(float), hipMemcpyHostToDevice, s.st));
@@ -1204,24 +1216,27 @@ static int ring_launch(psm_handle* h, psm_handle::Slot& s, int n_cases, const fl
   const int key = ring_key(h, n_cases, scale);
   const bool graphs = h->ring_graph && h->timed_kernel < 0;
   int rc;
-  if (graphs && own) {                                   // the whole ticket is one replay
+  if (src_dev && graphs && own) {                        // pull form on the slot's own buffers: the whole ticket is one replay
     if (!s.g_full || s.g_full_key != key) {
       if (s.g_full) { (void)hipGraphExecDestroy(s.g_full); s.g_full = nullptr; }
       if ((rc = ring_capture(h, s, n_cases, scale, src_dev, dst_dev, true, &s.g_full))) return rc;
       s.g_full_key = key;
     }
     HIPCHK(h, hipGraphLaunch(s.g_full, s.st));
-  } else if (src_dev || !graphs) {                       // caller memory, pull form (pointers differ per ticket) / plain launches
+  } else if (src_dev || !graphs) {                       // pull form on caller memory (pointers differ per ticket) / plain launches
     if ((rc = ring_sequence(h, s, n_cases, scale, src_dev, dst_dev, src, dst, true))) return rc;
-  } else {                                               // caller memory, DMA copies around a replay of the kernels
-    HIPCHK(h, hipMemcpyAsync(s.d_in, src, gin, hipMemcpyHostToDevice, s.st));
+  } else {
+    // Default: the two copies are hipMemcpyAsync calls on the slot's stream (DMA engines; inside a graph they would
+    // become blit kernels, which read host memory at ~20 GB/s), the kernels in between are one graph replay.
+    static const int dbg = getenv("PSM_RING_DEBUG") ? atoi(getenv("PSM_RING_DEBUG")) : 0;   // timing experiments only: 1 no H2D, 2 no D2H
+    if (!(dbg & 1)) HIPCHK(h, hipMemcpyAsync(s.d_in, src, gin, hipMemcpyHostToDevice, s.st));
     if (!s.g_kern || s.g_kern_key != key) {
       if (s.g_kern) { (void)hipGraphExecDestroy(s.g_kern); s.g_kern = nullptr; }
       if ((rc = ring_capture(h, s, n_cases, scale, nullptr, nullptr, false, &s.g_kern))) return rc;
       s.g_kern_key = key;
     }
     HIPCHK(h, hipGraphLaunch(s.g_kern, s.st));
-    HIPCHK(h, hipMemcpyAsync(dst, s.d_out, gout, hipMemcpyDeviceToHost, s.st));
+    if (!(dbg & 2)) HIPCHK(h, hipMemcpyAsync(dst, s.d_out, gout, hipMemcpyDeviceToHost, s.st));
   }
   HIPCHK(h, hipEventRecord(s.ev_out, s.st));
   return PSM_OK;
@@ -1240,7 +1255,7 @@ int psm_ring_acquire(psm_handle* h, int64_t* ticket, float** grid_in, float** fi
   HIPCHK(h, hipSetDevice(h->cfg.device));
   int rc = ring_init(h);
   if (rc) return rc;
-  psm_handle::Slot& s = h->slot[h->next_ticket % psm_handle::SLOTS];
+  psm_handle::Slot& s = h->slot[h->next_ticket % h->ring_slots];
   if (s.state != 0)
     return fail(h, PSM_ERR_STATE, "submission ring full: wait for the oldest ticket first (PSM_RING_SLOTS in flight)");
   s.state = 1; s.ticket = h->next_ticket; s.user_out = nullptr; s.direct_out = false;
@@ -1251,7 +1266,7 @@ int psm_ring_acquire(psm_handle* h, int64_t* ticket, float** grid_in, float** fi
 
 static int slot_of(psm_handle* h, int64_t ticket, int state, psm_handle::Slot** out) {
   if (ticket < 0 || !h->ring_ready) return fail(h, PSM_ERR_ARG, "unknown ticket");
-  psm_handle::Slot& s = h->slot[ticket % psm_handle::SLOTS];
+  psm_handle::Slot& s = h->slot[ticket % h->ring_slots];
   if (s.ticket != ticket || s.state != state)
     return fail(h, PSM_ERR_ARG, state == 1 ? "unknown ticket (not acquired, or already submitted)" : "unknown ticket (never submitted or already waited for)");
   *out = &s;
@@ -1288,7 +1303,7 @@ int psm_submit_grid_io(psm_handle* h, const float* grid, int32_t n_cases, const 
   if (!grid || !ticket) return fail(h, PSM_ERR_ARG, "null argument");
   int64_t t; float *gi, *fo;
   if ((rc = psm_ring_acquire(h, &t, &gi, &fo))) return rc;
-  psm_handle::Slot& s = h->slot[t % psm_handle::SLOTS];
+  psm_handle::Slot& s = h->slot[t % h->ring_slots];
   const size_t npix = (size_t)h->Ny * h->Nx;
   const size_t gin = (size_t)n_cases * npix * h->cfg.c_in * sizeof(float), gout = (size_t)n_cases * npix * h->cfg.c_out * sizeof(float);
   const float* src = s.h_in;

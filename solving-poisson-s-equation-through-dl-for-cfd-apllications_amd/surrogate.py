@@ -121,7 +121,7 @@ class GridSurrogate:
         return out
 
     def submit(self, grid: np.ndarray, out_scale: Optional[Sequence[float]] = None, out: Optional[np.ndarray] = None) -> int:
-        """Asynchronous host-buffer solve (psm_submit_grid_io): returns a ticket; up to PSM_RING_SLOTS (4) in
+        """Asynchronous host-buffer solve (psm_submit_grid_io): returns a ticket; up to PSM_RING_SLOTS (8) in
         flight, each on its own stream (H2D copy, kernels and D2H copy of one ticket are one graph replay).  A pageable
         ``grid`` may be reused on return; a grid / ``out`` array inside a range registered with :meth:`host_register` is
         DMA'd from / into directly and must be left alone until :meth:`wait` returns."""

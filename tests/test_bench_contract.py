@@ -60,7 +60,7 @@ def test_default_bench_line():
     # the H2D / D2H-inclusive solve, and BASELINE configs[3]
     e = d["end_to_end"]
     assert d["value_end_to_end"] > 1000 and e["matches_device_resident_result"] is True
-    assert {"sync_pageable", "ring_pageable_depth3", "ring_registered_depth3", "ring_zero_copy_depth3"} <= set(e["solves_per_s_per_rank"])
+    assert {"sync_pageable", "ring_pageable_depth4", "ring_registered_depth4", "ring_zero_copy_depth4"} <= set(e["solves_per_s_per_rank"])
     cbat = d["case_batch"]
     assert "configs[3]" in cbat["workload"] and cbat["cases_per_step_per_gpu"] == 8 and cbat["value"] > 1000
     assert cbat["gathered_shape"] == [8, 256, 256, 1]

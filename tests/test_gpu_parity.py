@@ -108,7 +108,7 @@ def test_submission_ring_equals_synchronous_solves():
         ref = [sur.solve(g, out_scale=[sc]) for g, sc in zip(grids, scales)]
         got, pending = [], []
         for g, sc in zip(grids, scales):
-            if len(pending) == 4:                       # PSM_RING_SLOTS
+            if len(pending) == 8:                       # PSM_RING_SLOTS
                 with pytest.raises(_lib.PsmError) as e:
                     sur.submit(g, out_scale=[sc])
                 assert e.value.code == -2               # PSM_ERR_STATE

@@ -56,13 +56,13 @@ def _three_ways(sur, grids, scales, n_cases=1):
     return outs
 
 
-@pytest.mark.parametrize("graph,dma", [("1", "0"), ("0", "0"), ("1", "1"), ("0", "1")])
+@pytest.mark.parametrize("graph,pull", [("1", "0"), ("0", "0"), ("1", "1"), ("0", "1")])
 @pytest.mark.parametrize("bind", [False, True])
-def test_every_way_into_the_ring_equals_the_synchronous_entry(bind, graph, dma, monkeypatch):
-    """graph: one replay per ticket / plain launches; dma: the GPU pulls the grid from and stores the field to the mapped
-    pinned buffers itself (0, default) / hipMemcpyAsync copies around the kernels (1)."""
+def test_every_way_into_the_ring_equals_the_synchronous_entry(bind, graph, pull, monkeypatch):
+    """graph: the kernels of a ticket are one replay / plain launches; pull: hipMemcpyAsync copies around the kernels (0,
+    default) / the GPU pulls the grid from and stores the field to the mapped pinned buffers itself (1)."""
     monkeypatch.setenv("PSM_RING_GRAPH", graph)
-    monkeypatch.setenv("PSM_RING_DMA", dma)
+    monkeypatch.setenv("PSM_RING_PULL", pull)
     model = synthetic.make_model("gradp", p_in=48, p_out=40)
     grids = [synthetic.channel_grid(256, 256, seed=1 + s).astype(np.float32)[None] for s in range(9)]
     # the ring test rotates VELOCITY fields of one geometry (a case stream); scales change per step
@@ -111,12 +111,12 @@ def test_ring_state_errors():
     g = synthetic.channel_grid(256, 256, seed=3).astype(np.float32)
     with GridSurrogate(model, 256, 256) as sur:
         ts = []
-        for _ in range(4):
+        for _ in range(8):                              # PSM_RING_SLOTS
             t, gi, fo = sur.ring_acquire()
             gi[0] = g
             ts.append(t)
         with pytest.raises(_lib.PsmError) as e:
-            sur.ring_acquire()                          # all four slots handed out
+            sur.ring_acquire()                          # all slots handed out
         assert e.value.code == -2
         with pytest.raises(_lib.PsmError):
             sur.ring_wait(ts[0])                        # acquired, not submitted
@@ -154,8 +154,8 @@ def test_bench_host_and_kernel_timing_entries():
                                             C.byref(sec), last.ctypes.data_as(C.POINTER(C.c_float))))
             assert sec.value > 0
             if mode == 3:      # the slots were packed once, during the first turn of the ring: slot s holds input s % 3
-                wu = max(warm, 4)
-                want = ref[((wu + steps - 1) % 4) % 3]
+                wu = max(warm, 8)
+                want = ref[((wu + steps - 1) % 8) % 3]
             else:
                 want = ref[(warm + steps - 1) % 3]
             np.testing.assert_array_equal(last, want, err_msg=f"mode {mode}")

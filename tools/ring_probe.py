@@ -11,7 +11,7 @@ grids = np.ascontiguousarray(np.stack([synthetic.channel_grid(256, 256, seed=1 +
 for g in grids[1:]:
     g[..., 2] = grids[0][..., 2]
 args = [int(a) for a in sys.argv[1:]]
-runs = [tuple(args[i:i + 3]) for i in range(0, len(args), 3)] or [(0, 1, 2000), (1, 3, 2000), (2, 1, 2000), (2, 2, 2000), (2, 3, 2000), (2, 4, 2000), (3, 1, 2000), (3, 2, 2000), (3, 3, 2000), (3, 4, 2000)]
+runs = [tuple(args[i:i + 3]) for i in range(0, len(args), 3)] or [(0, 1, 2000), (1, 3, 2000), (1, 6, 2000), (2, 1, 2000), (2, 2, 2000), (2, 3, 2000), (2, 4, 2000), (2, 6, 2000), (2, 8, 2000), (3, 1, 2000), (3, 2, 2000), (3, 3, 2000), (3, 4, 2000), (3, 6, 2000), (3, 8, 2000)]
 with psm_amd.GridSurrogate(model, 256, 256) as sur:
     assert sur.bind_geometry(grids[0, 0])
     for mode, depth, steps in runs:
