@@ -25,6 +25,21 @@ os.makedirs("profiles", exist_ok=True)
 with open(f"profiles/{tag}_pmc_summary.csv", "w") as f:
     f.write("kernel,FETCH_SIZE_KB_per_launch,WRITE_SIZE_KB_per_launch,hbm_bytes_per_launch(2*FETCH+WRITE)\n")
     for r in rows: f.write('"%s",%.3f,%.3f,%.1f\n' % r)
+# the form bench.py reads for roofline.traffic: kernel names as psm_time_kernels reports them, guarded by a hash of the
+# kernel sources that were profiled
+sys.path.insert(0, ".")
+import bench as _bench
+def _short(k):
+    k = k.replace("void ", "")
+    depth = 0
+    for i, ch in enumerate(k):
+        if ch == "<": depth += 1
+        elif ch == ">": depth -= 1
+        elif ch == "(" and depth == 0: return k[:i]
+    return k
+json.dump({"workload": "config1", "kernel_source_hash": _bench.kernel_source_hash(), "profile_tag": tag,
+           "unit": "HBM-side bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024; separate --pmc passes with --kernel-trace only",
+           "kernels": {_short(r[0]): r[3] for r in rows}}, open("profiles/r02_pmc.json", "w"), indent=1)
 enc = [r for r in rows if "psm_encode_kernel" in r[0]][0]
 json.dump({"kernel": enc[0], "FETCH_SIZE_KB": enc[1], "WRITE_SIZE_KB": enc[2],
            "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B for 16-B/lane coalesced streams -> doubled (MI355X_MICROARCH.md HBM section); WRITE_SIZE exact",
