@@ -227,6 +227,30 @@ int psm_set_geometry(psm_handle* h, int64_t n_cells, int32_t ny, int32_t nx,
                      const double* sdfunct, const int32_t* vtx_g2m, const double* wts_g2m,
                      const double* maxs, int32_t normalise_sdf, int32_t fill_input,
                      double wall_threshold);
+/* init_func itself (PM:172-247; called through PythonComm_init.H:53-94 with the solver's cell array and the points of
+ * its "top" and "obstacle" patches): builds the tables above IN C++ -- no interpreter, no SciPy -- and installs them
+ * like psm_set_geometry.  cells [n,5] float64 = (Ux, Uy, Cx, Cy, p) (Ux decides which grid points are interpolable,
+ * PM:231), top [n_top,2], obst [n_obst,2] boundary points; `rank` is accepted for signature compatibility (the MPI
+ * gather of PM:179-185 stays with the caller).  psm_set_case supplies what the reference reads from files / hard-codes:
+ * maxs[4] (the `maxs` file, PM:106-109), delta (5e-3, PM:195), every (boundary-point stride of the SDF, 10, PM:94-95),
+ * wall_threshold (0.05, PM:494); defaults are those values with maxs = 1.
+ * Differences from the SciPy-built tables (csrc/psm_geometry.cpp): (a) mesh -> grid: own Delaunay triangulation --
+ * identical simplices and weights for points in general position; grid points OUTSIDE the hull of the cell centres
+ * take the last simplex of the triangulator's list in both codes, which one that is differs (such points are
+ * scattered into image cell (0,0) like the reference's zero-initialised `indices`, SMD:161 -- PM:225 leaves them
+ * undefined); (b) grid -> mesh: the lattice is cut along fixed diagonals (every lattice square is cocircular: qhull's
+ * choice is not reproducible).  A caller that needs qhull's very tables passes them to psm_set_geometry. */
+int psm_set_case(psm_handle* h, const double* maxs, double delta, int32_t every, double wall_threshold);
+int psm_init_geometry(psm_handle* h, const double* cells, int64_t n, const double* top, int64_t n_top,
+                      const double* obst, int64_t n_obst, int32_t rank);
+/* The table builder alone, host only (no GPU, no handle): psm_geometry_shape gives the grid shape (and optionally
+ * bounds[4] = rounded x_min, x_max, y_min, y_max, PM:197-201) for sizing; psm_geometry_build fills caller-allocated
+ * vtx_m2g/wts_m2g [ny*nx,3], indices [ny*nx,2], sdfunct [ny*nx], vtx_g2m/wts_g2m [n,3]. */
+int psm_geometry_shape(const double* cells, int64_t n, double delta, int32_t* ny, int32_t* nx, double* bounds);
+int psm_geometry_build(const double* cells, int64_t n, const double* top, int64_t n_top, const double* obst,
+                       int64_t n_obst, double delta, int32_t every, int32_t* vtx_m2g, double* wts_m2g,
+                       int32_t* indices, double* sdfunct, int32_t* vtx_g2m, double* wts_g2m);
+const char* psm_geometry_last_error(void);
 /* py_func (PM:249-517, serial form PM1:199-444): cells [n,5] float64 = (Ux, Uy, Cx, Cy, p) as
  * packed at PythonComm.H:2-9 -> p_out [n] float64 as read at PythonComm.H:31-36.  `rank` is
  * accepted for signature compatibility (the MPI funnel, PM:258/511, stays with the caller).

@@ -73,6 +73,12 @@ SIGNATURES = {
     "psm_label_blocks": (C.c_int, [_hp, _f32p, _f32p, _f32p]),
     "psm_set_geometry": (C.c_int, [_hp, C.c_int64, C.c_int32, C.c_int32, _i32p, _f64p, _i32p, _f64p, _i32p, _f64p, _f64p,
                                    C.c_int32, C.c_int32, C.c_double]),
+    "psm_set_case": (C.c_int, [_hp, _f64p, C.c_double, C.c_int32, C.c_double]),
+    "psm_init_geometry": (C.c_int, [_hp, _f64p, C.c_int64, _f64p, C.c_int64, _f64p, C.c_int64, C.c_int32]),
+    "psm_geometry_shape": (C.c_int, [_f64p, C.c_int64, C.c_double, _i32p, _i32p, _f64p]),
+    "psm_geometry_build": (C.c_int, [_f64p, C.c_int64, _f64p, C.c_int64, _f64p, C.c_int64, C.c_double, C.c_int32, _i32p, _f64p,
+                                     _i32p, _f64p, _i32p, _f64p]),
+    "psm_geometry_last_error": (C.c_char_p, []),
     "psm_solve": (C.c_int, [_hp, _f64p, C.c_int64, C.c_int32, _f64p]),
     "psm_poisson_features": (C.c_int, [_hp, _f64p, _f64p, _f64p, _f64p, _f64p, C.c_int32, C.c_int32, _f64p, _f32p]),
     "psm_pin_buffers": (C.c_int, [_hp, _f64p, _f64p]),

@@ -98,6 +98,8 @@ struct psm_handle {
   double* pinned_p_dev = nullptr;       // device-side address of the registered output (the last kernel writes p straight into it)
   double maxs[4] = {1, 1, 1, 1};
   int normalise_sdf = 0, fill_input = 0;
+  double case_maxs[4] = {1, 1, 1, 1}, case_delta = 5e-3, case_wall = 0.05;   // psm_set_case (PM:106-109, 195, 494)
+  int case_every = 10;                                                        // PM:94-95
   float *d_grid_stage = nullptr, *d_fields_stage = nullptr;
   float *h_grid = nullptr, *h_fields = nullptr;
   // host-buffer submission ring (psm_submit_grid / psm_wait_grid): pinned in/out + device in/out per slot
@@ -1490,6 +1492,33 @@ int psm_set_geometry(psm_handle* h, int64_t n_cells, int32_t ny, int32_t nx, con
     else return rc;
   }
   return PSM_OK;
+}
+
+int psm_set_case(psm_handle* h, const double* maxs, double delta, int32_t every, double wall_threshold) {
+  if (!h) return PSM_ERR_ARG;
+  if (!maxs || !(delta > 0.0) || every < 1 || !(wall_threshold >= 0.0)) return fail(h, PSM_ERR_ARG, "bad case constants");
+  for (int k = 0; k < 4; ++k) {
+    if (!(maxs[k] != 0.0)) return fail(h, PSM_ERR_ARG, "maxs must be non-zero");
+    h->case_maxs[k] = maxs[k];
+  }
+  h->case_delta = delta; h->case_every = every; h->case_wall = wall_threshold;
+  return PSM_OK;
+}
+
+int psm_init_geometry(psm_handle* h, const double* cells, int64_t n, const double* top, int64_t n_top, const double* obst,
+                      int64_t n_obst, int32_t rank) {
+  (void)rank;
+  if (!h) return PSM_ERR_ARG;
+  if (!cells || !top || !obst) return fail(h, PSM_ERR_ARG, "null buffer");
+  int32_t ny = 0, nx = 0;
+  if (psm_geometry_shape(cells, n, h->case_delta, &ny, &nx, nullptr) != PSM_OK) return fail(h, PSM_ERR_ARG, psm_geometry_last_error());
+  const size_t ng = (size_t)ny * nx;
+  std::vector<int32_t> v1(ng * 3), idx(ng * 2), v2((size_t)n * 3);
+  std::vector<double> w1(ng * 3), sdf(ng), w2((size_t)n * 3);
+  int rc = psm_geometry_build(cells, n, top, n_top, obst, n_obst, h->case_delta, h->case_every, v1.data(), w1.data(), idx.data(),
+                              sdf.data(), v2.data(), w2.data());
+  if (rc) return fail(h, rc, psm_geometry_last_error());
+  return psm_set_geometry(h, n, ny, nx, v1.data(), w1.data(), idx.data(), sdf.data(), v2.data(), w2.data(), h->case_maxs, 0, 0, h->case_wall);
 }
 
 int psm_solve(psm_handle* h, const double* cells, int64_t n, int32_t rank, double* p_out) {

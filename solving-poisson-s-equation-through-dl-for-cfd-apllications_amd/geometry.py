@@ -179,3 +179,29 @@ def build_geometry_evaluator(points, p_values, top, obst, delta: float, every: i
                        float(x0), float(y0), delta)
     t.box = (float(min_x), float(max_x), float(min_y), float(max_y))
     return t
+
+
+def build_geometry_native(array, top, obst, delta: float = 5e-3, every: int = 10) -> GeometryTables:
+    """The same tables from the library's own C++ builder (``psm_geometry_build``, csrc/psm_geometry.cpp: no SciPy) --
+    what ``psm_init_geometry`` installs.  Differences from ``build_geometry`` are listed at psm.h ``psm_init_geometry``."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    a = np.ascontiguousarray(array, np.float64)
+    t, o = np.ascontiguousarray(top, np.float64), np.ascontiguousarray(obst, np.float64)
+    ny, nx = C.c_int32(), C.c_int32()
+    bd = np.zeros(4)
+    f64, i32 = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    if lib.psm_geometry_shape(a.ctypes.data_as(f64), a.shape[0], delta, C.byref(ny), C.byref(nx), bd.ctypes.data_as(f64)):
+        raise ValueError(lib.psm_geometry_last_error().decode())
+    ng, n = ny.value * nx.value, a.shape[0]
+    v1, w1 = np.empty((ng, 3), np.int32), np.empty((ng, 3))
+    idx, sdf = np.empty((ng, 2), np.int32), np.empty(ng)
+    v2, w2 = np.empty((n, 3), np.int32), np.empty((n, 3))
+    rc = lib.psm_geometry_build(a.ctypes.data_as(f64), n, t.ctypes.data_as(f64), t.shape[0], o.ctypes.data_as(f64), o.shape[0], delta, every,
+                                v1.ctypes.data_as(i32), w1.ctypes.data_as(f64), idx.ctypes.data_as(i32), sdf.ctypes.data_as(f64),
+                                v2.ctypes.data_as(i32), w2.ctypes.data_as(f64))
+    if rc:
+        raise ValueError(lib.psm_geometry_last_error().decode())
+    X0, Y0 = create_uniform_grid(bd[0], bd[1], bd[2], bd[3], delta)
+    return GeometryTables(ny.value, nx.value, v1, w1, idx, sdf.reshape(ny.value, nx.value), v2, w2, None, float(X0.min()), float(Y0.min()), delta)

@@ -802,8 +802,15 @@ class SolverModule:
     stays around these calls).  ``maxs`` = (max_abs_Ux, max_abs_Uy, max_abs_dist, max_abs_p) of
     the ``maxs`` file (python_module.py:106-109)."""
 
-    def __init__(self, model: SurrogateModel, maxs=(1.0, 1.0, 1.0, 1.0), device: int = 0, delta: float = 5e-3):
+    def __init__(self, model: SurrogateModel, maxs=(1.0, 1.0, 1.0, 1.0), device: int = 0, delta: float = 5e-3,
+                 geometry: str = "scipy"):
+        """``geometry``: who builds init_func's tables -- 'scipy' (this host, with the routines the reference calls:
+        qhull Delaunay in both directions) or 'native' (the library's C++ builder behind ``psm_init_geometry``, no SciPy;
+        differences listed at include/psm.h)."""
+        if geometry not in ("scipy", "native"):
+            raise ValueError("geometry must be 'scipy' or 'native'")
         self.model, self.maxs, self.device, self.delta = model, tuple(float(v) for v in maxs), device, delta
+        self.geometry = geometry
         self._sur = None
         self.tables = None
 
@@ -820,6 +827,8 @@ class SolverModule:
         """python_module.py:172: one-time tables (host, SciPy qhull like the reference), handed
         to the GPU library with psm_set_geometry.  Returns 0."""
         from .geometry import build_geometry
+        if self.geometry == "native":
+            return self._init_func_native(array, top_boundary, obst_boundary)
         t = build_geometry(np.asarray(array, np.float64), top_boundary, obst_boundary, self.delta)
         if self._sur is not None:
             self._sur.close()
@@ -832,6 +841,23 @@ class SolverModule:
             _p(idx, C.c_int32), _p(sdf, C.c_double), _p(v2, C.c_int32), _p(w2, C.c_double), _p(mx, C.c_double),
             0, 0, 0.05))
         self.tables = t
+        return 0
+
+    def _init_func_native(self, array, top_boundary, obst_boundary):
+        """psm_set_case + psm_init_geometry: the tables are built inside the library (csrc/psm_geometry.cpp)."""
+        a, t, o = _f64(array), _f64(top_boundary), _f64(obst_boundary)
+        lib = _lib.load()
+        ny, nx = C.c_int32(), C.c_int32()
+        if lib.psm_geometry_shape(_p(a, C.c_double), a.shape[0], self.delta, C.byref(ny), C.byref(nx), None):
+            raise ValueError(lib.psm_geometry_last_error().decode())
+        if self._sur is not None:
+            self._sur.close()
+        self._sur = GridSurrogate(self.model, ny.value, nx.value, 1, self.device)
+        mx = _f64(self.maxs)
+        self._sur._chk(lib.psm_set_case(self._sur.h, _p(mx, C.c_double), self.delta, 10, 0.05))
+        self._sur._chk(lib.psm_init_geometry(self._sur.h, _p(a, C.c_double), a.shape[0], _p(t, C.c_double), t.shape[0],
+                                             _p(o, C.c_double), o.shape[0], 0))
+        self.tables = "native"
         return 0
 
     def pin(self, array: np.ndarray, out: np.ndarray = None):
