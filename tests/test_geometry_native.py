@@ -210,7 +210,29 @@ def test_cpp_only_init_geometry_and_solve(tmp_path):
     sm = SolverModule(model, maxs, geometry="native")
     assert sm.init_func(array, top, obst) == 0
     np.testing.assert_array_equal(sm.py_func(array), p[0])
+    # Against the reference run (golden p, SciPy / qhull tables): the two documented differences, separately.
+    # (a) mesh -> grid built in C++, grid -> mesh tables handed over by the caller (qhull's): the only difference is the
+    #     value that the out-of-hull grid points leave in image cell (0,0) -- < 1.5 % of max|p| here;
+    # (b) grid -> mesh on fixed lattice diagonals: qhull's diagonal per lattice square is rounding noise (50/50), and this
+    #     synthetic model's field is white noise from pixel to pixel, so (b) is checked on a smooth lattice function
+    #     (test_tables_equal_the_scipy_built_ones_on_an_unstructured_mesh: < 1e-4), not on p.
+    import ctypes as C
+    from psm_amd import GridSurrogate
     gold = cases.load_golden("mesh_chapter5")["p"]
-    # reference run (SciPy tables): differs through the grid points outside the hull of the cell centres (their value
-    # lands in image cell (0,0) from whichever simplex the triangulator lists last) and the fixed lattice diagonals
-    assert np.abs(p[0] - gold).max() <= 3e-2 * np.abs(gold).max()
+    ref = geometry.build_geometry(array, top, obst)
+    with GridSurrogate(model, nat.ny, nat.nx) as sur:
+        f64, i32 = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        v1, w1 = np.ascontiguousarray(nat.vtx_m2g, np.int32), np.ascontiguousarray(nat.wts_m2g)
+        idx, sdf = np.ascontiguousarray(nat.indices, np.int32), np.ascontiguousarray(nat.sdfunct)
+        v2, w2 = np.ascontiguousarray(ref.vtx_g2m, np.int32), np.ascontiguousarray(ref.wts_g2m)
+        mx = np.ascontiguousarray(maxs, np.float64)
+        sur._chk(sur.lib.psm_set_geometry(sur.h, array.shape[0], nat.ny, nat.nx, v1.ctypes.data_as(i32), w1.ctypes.data_as(f64),
+                                          idx.ctypes.data_as(i32), sdf.ctypes.data_as(f64), v2.ctypes.data_as(i32), w2.ctypes.data_as(f64),
+                                          mx.ctypes.data_as(f64), 0, 0, 0.05))
+        pa = np.empty(array.shape[0])
+        a64 = np.ascontiguousarray(array, np.float64)
+        sur._chk(sur.lib.psm_solve(sur.h, a64.ctypes.data_as(f64), array.shape[0], 0, pa.ctypes.data_as(f64)))
+    assert ((pa == array[:, 4]) == (gold == array[:, 4])).all()
+    rel = np.abs(pa - gold).max() / np.abs(gold).max()
+    print("C++ mesh->grid tables + qhull grid->mesh tables vs the reference run: max |dp| / max|p| =", rel)
+    assert rel <= 1.5e-2
