@@ -5,7 +5,7 @@
 TAG=$1
 export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out/full_$TAG; mkdir -p $O
 cd /tmp
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline > $O/stats_bench.log 2>&1; echo "stats rc=$?"
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline --no-extras > $O/stats_bench.log 2>&1; echo "stats rc=$?"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/fetch.log 2>&1; echo "fetch rc=$?"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/write.log 2>&1; echo "write rc=$?"
 cd $R
