@@ -149,6 +149,9 @@ int psm_bind_geometry(psm_handle* h, const float* grid, int32_t on_device);
 int psm_bind_geometry_cases(psm_handle* h, const float* grids, int32_t n_cases, int32_t on_device);
 int psm_unbind_geometry(psm_handle* h);
 int psm_geometry_bound(const psm_handle* h);   /* 1 while a geometry is bound */
+/* The flow-cell pattern that was bound: mask [bound cases][ny*nx] (1 = SDF channel != 0), for callers that want to check
+ * the contract above on their side (cap = bytes available).  PSM_ERR_STATE when nothing is bound. */
+int psm_bound_mask(const psm_handle* h, uint8_t* mask, size_t cap);
 
 /* ---- per-step solve: grid-native counterpart of py_func (PM:249-517) and of
  *      Evaluation.timeStep from block extraction to assemble_prediction

@@ -58,6 +58,7 @@ SIGNATURES = {
     "psm_bind_geometry_cases": (C.c_int, [_hp, C.c_void_p, C.c_int32, C.c_int32]),
     "psm_unbind_geometry": (C.c_int, [_hp]),
     "psm_geometry_bound": (C.c_int, [_hp]),
+    "psm_bound_mask": (C.c_int, [_hp, C.POINTER(C.c_uint8), C.c_size_t]),
     "psm_solve_grid": (C.c_int, [_hp, _f32p, C.c_int32, _f32p, _f32p]),
     "psm_grid_shape": (C.c_int, [_hp, _i32p]),
     "psm_ring_acquire": (C.c_int, [_hp, C.POINTER(C.c_int64), C.POINTER(_f32p), C.POINTER(_f32p)]),

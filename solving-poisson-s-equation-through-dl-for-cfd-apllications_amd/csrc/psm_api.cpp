@@ -151,6 +151,7 @@ struct psm_handle {
   float *d_comp_nat = nullptr;          // comp_out in natural layout [ld_out][K_out] (f32 precision only)
   float *d_g2 = nullptr, *d_c2 = nullptr, *d_cnt = nullptr;
   size_t bound_dots = 0;                // floats of Workspace::d_dots
+  std::vector<uint8_t> bound_mask;      // [bound_cases][Ny*Nx] flow-cell pattern that was bound (psm_bound_mask)
   int32_t* d_row_of = nullptr;
   uint32_t* d_ownbits = nullptr;
   int debug_skip = 0;                   // PSM_DEBUG_SKIP bit mask of kernel groups NOT launched (timing experiments only)
@@ -1026,6 +1027,13 @@ static int bind_geometry_device(psm_handle* h, const float* d_grid, int n_cases 
   if (e != hipSuccess) return fail(h, PSM_ERR_HIP, std::string("psm_launch_bind: ") + hipGetErrorString(e));
   h->bound_zero_fill = false;
   for (int32_t o : h->plan.owner) if (o < 0) { h->bound_zero_fill = true; break; }
+  {                                                           // host copy of the bound flow-cell pattern (contract checks)
+    const size_t npix = (size_t)h->Ny * h->Nx, cin = h->cfg.c_in;
+    std::vector<float> g((size_t)n_cases * npix * cin);
+    HIPCHK(h, hipMemcpy(g.data(), d_grid, g.size() * sizeof(float), hipMemcpyDeviceToHost));
+    h->bound_mask.resize((size_t)n_cases * npix);
+    for (size_t q = 0; q < (size_t)n_cases * npix; ++q) h->bound_mask[q] = g[q * cin + h->cfg.sdf_channel] != 0.f ? 1 : 0;
+  }
   h->bound_rows = rows;
   h->bound_cases = n_cases;
   h->bound_dots = all;
@@ -1061,6 +1069,14 @@ int psm_unbind_geometry(psm_handle* h) {
 }
 
 int psm_geometry_bound(const psm_handle* h) { return (h && h->bound) ? 1 : 0; }
+
+int psm_bound_mask(const psm_handle* h, uint8_t* mask, size_t cap) {
+  if (!h || !mask) return PSM_ERR_ARG;
+  if (!h->bound) return PSM_ERR_STATE;
+  if (cap < h->bound_mask.size()) return PSM_ERR_ARG;
+  memcpy(mask, h->bound_mask.data(), h->bound_mask.size());
+  return PSM_OK;
+}
 
 int psm_num_blocks(const psm_handle* h) { return (h && h->planned) ? h->B : PSM_ERR_STATE; }
 

@@ -205,8 +205,10 @@ class GridSurrogate:
         if rc == -5:                    # PSM_ERR_UNSUPPORTED: configuration outside the fused path
             return False
         self._chk(rc)
-        if not on_device:
-            self._bound_mask = g[..., self.model.sdf_ch] != 0
+        n = int(n_cases) if on_device else g.shape[0]
+        m = np.empty((n, self.ny, self.nx), np.uint8)          # the pattern the library bound (also for device grids)
+        self._chk(self.lib.psm_bound_mask(self.h, m.ctypes.data_as(C.POINTER(C.c_uint8)), m.size))
+        self._bound_mask = m.astype(bool)
         return True
 
     def unbind_geometry(self):

@@ -11,6 +11,7 @@ import pytest
 import cases
 from oracle import psm_oracle as orc
 from psm_amd import GridSurrogate, synthetic
+from hipmem import DeviceArray
 from test_gpu_parity import oracle_model, rel_l2
 
 pytestmark = pytest.mark.gpu
@@ -115,6 +116,16 @@ def test_bind_lifecycle_and_unsupported_configurations():
         assert not sur.geometry_bound
         sur.check_bound = False
         same(got, sur.solve(other)[0])
+        # the same check after a bind from DEVICE memory: the library hands back the pattern it bound (psm_bound_mask)
+        d_g = DeviceArray(g)
+        assert sur.bind_geometry(d_g.ptr, on_device=True)
+        np.testing.assert_array_equal(sur._bound_mask[0], g[..., 2] != 0)
+        sur.check_bound = True
+        sur.solve(g)
+        assert sur.geometry_bound                       # same geometry: the binding stays
+        sur.solve(other)
+        assert not sur.geometry_bound
+        sur.check_bound = False
         # a new plan or a model change drops the binding (its tables belong to the old block layout / head layer)
         assert sur.bind_geometry(g) and sur.geometry_bound
         sur._chk(sur.lib.psm_plan_grid(sur.h, 256, 256))
