@@ -22,6 +22,10 @@ struct PsmConvArgs {
   // writes head_out[pixel][o] = sum_co act[co] * head_w[co][o] + head_b[o]
   const float* head_w; const float* head_b; float* head_out; int head_cout; int64_t head_case;
   int bf16;                    // operands rounded to bf16, chunks of 32 channels, wpack holds bf16x8 pieces
+  // bf16 mode only: finished activations may live in HBM as bf16 (half the bytes of the bandwidth-bound shallow layers;
+  // the consumer would round them to bf16 anyway, and rounding commutes with max-pool / upsample / concat).
+  // in_bf: in0 and in1 are bf16 [..][c] (only with ks0 == ks1 == 1); out_bf: this layer stores bf16 (only with ksplit == 1)
+  int in_bf, out_bf;
   int ksplit;                  // this layer's own split: workgroup z handles chunks [z*cps, (z+1)*cps) and writes slab z
   int64_t out_slab;
   int mode0;

@@ -230,6 +230,32 @@ __device__ __forceinline__ f32x4 combine4(const f32x4* r, int ks, f32x4 b) {    
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// element-wise maximum of two groups of 8 packed bf16 (16 bytes each): every half is widened (a shift), compared as
+// float32 and truncated back -- exact, the values are bf16 already
+__device__ __forceinline__ f32x4 bf16x8_max(f32x4 a, f32x4 b) {
+  const u32x4 ua = __builtin_bit_cast(u32x4, a), ub = __builtin_bit_cast(u32x4, b);
+  u32x4 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float lo = fmaxf(__uint_as_float(ua[j] << 16), __uint_as_float(ub[j] << 16));
+    const float hi = fmaxf(__uint_as_float(ua[j] & 0xffff0000u), __uint_as_float(ub[j] & 0xffff0000u));
+    r[j] = (__float_as_uint(hi) & 0xffff0000u) | (__float_as_uint(lo) >> 16);
+  }
+  return __builtin_bit_cast(f32x4, r);
+}
+// activation store of one value per lane (lane & 15 = channel): float32, or bf16 with the channel pair (c, c+1) packed
+// into one 4-byte store by the even lane (the odd neighbour's value arrives through a DPP quad permute)
+__device__ __forceinline__ void store_act(float* out, int64_t elem, float v, bool ok, bool out_bf, int co) {
+  if (out_bf) {
+    const float vn = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    const unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)vn) << 16);
+    if (ok && !(co & 1)) *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(out) + elem) = pk;
+  } else if (ok) {
+    PSM_ACT_STORE(&out[elem], v);
+  }
+}
 
 // TH: tile rows; WM: rows per wave; NCT: channel tiles per workgroup; WN: channel tiles per wave; BF: bf16 operands.
 // Software pipeline over the channel chunks, both operands double-buffered in LDS: the input tile (through the
@@ -245,10 +271,14 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 //     points are unchanged).  Both forms use a 64-byte LDS pixel with swizzled 16-byte slots (lds_slot).
 //   NB: LDS buffers per operand -- 1 when a workgroup has a single chunk (nothing to pipeline: half the LDS, twice
 //     the workgroups per CU to cover each other's load latency), else 2.
-template <int TH, int WM, int NCT, int WN, int SRC, int KSM, bool BF, int NB>     // SRC: PSM_SRC_*, -1 = unaligned stem, 3 = upsample + skip with the seam inside a chunk
+//   ABF (bf16 mode, finished inputs only): the inputs are bf16 in HBM; a fetch is 8 channels = 16 bytes that go to LDS as
+//     they are (max-pool: element-wise max of the four source pixels first) -- half the fetches, no conversion.
+template <int TH, int WM, int NCT, int WN, int SRC, int KSM, bool BF, int NB, bool ABF = false>     // SRC: PSM_SRC_*, -1 = unaligned stem, 3 = upsample + skip with the seam inside a chunk
 __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_groups) {
+  static_assert(!ABF || (BF && KSM == 1 && SRC >= 0 && SRC != 3), "bf16 activations: finished same / upsample / max-pool sources only");
   constexpr int CB = BF ? 32 : 16;                                  // input channels per chunk
-  constexpr int G4 = CB / 4;                                        // 4-channel fetch groups per pixel
+  constexpr int FG = ABF ? 8 : 4;                                   // channels per fetch (16 bytes: 4 float32 or 8 bf16)
+  constexpr int G4 = CB / FG;                                       // fetch groups per pixel
   constexpr int NPIX = (TH + 2) * (TW + 2);
   constexpr int NF = (NPIX * G4 + 255) / 256;                       // 4-channel input fetches per thread and chunk
   constexpr int WQ = 9 * NCT * 64;                                  // 16-byte pieces per weight chunk
@@ -260,7 +290,7 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
   constexpr int WQP = NWF * 256;                                    // weight-buffer stride (16-byte pieces)
   constexpr int SRCP = SRC == 3 ? PSM_SRC_UPSAMPLE : (SRC < 0 ? 0 : SRC);
   constexpr int NQ = SRCP == PSM_SRC_MAXPOOL ? 4 : 1;               // source pixels per fetch
-  constexpr bool DEFER = SRC >= 0 && SRC != 3 && NF * NQ * KSM <= 24;   // raw loads held across the MFMAs (<= 96 VGPRs)
+  constexpr bool DEFER = ABF || (SRC >= 0 && SRC != 3 && NF * NQ * KSM <= 24);   // raw loads held across the MFMAs (<= 96 VGPRs)
   constexpr int NRAW = DEFER ? NQ * KSM : 1;
   __shared__ __attribute__((aligned(16))) float in_tile[NB * TILE];
   __shared__ __attribute__((aligned(16))) f32x4 w_tile[NB * WQP];
@@ -307,9 +337,25 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
       const int pos = q / G4, c4 = q & (G4 - 1);
       const int r = pos / (TW + 2), c = pos - r * (TW + 2);
       const int rr = min(r, TH + 1);
-      const int ch = g * CB + 4 * c4;
-      const int chc = min(ch, lim - 4);     // channels beyond the real inputs (zero-padded tail): clamped, zeroed later
-      if constexpr (SRC < 0) xr[u][0] = fetch4_stem(a, in0, y0 - 1 + rr, x0 - 1 + c, ch);
+      const int ch = g * CB + FG * c4;
+      const int chc = min(ch, lim - FG);    // channels beyond the real inputs (zero-padded tail): clamped, zeroed later
+      if constexpr (ABF) {                  // 8 bf16 channels per 16-byte load, element offsets in halves
+        const unsigned short* h0 = reinterpret_cast<const unsigned short*>(a.in0) + (int64_t)cs * a.in0_case;
+        const unsigned short* h1 = reinterpret_cast<const unsigned short*>(a.in1) + (int64_t)cs * a.in1_case;
+        if constexpr (SRCP == PSM_SRC_MAXPOOL) {
+          const unsigned short* p = h0 + fp[u].off0 + chc;
+          xr[u][0] = *reinterpret_cast<const f32x4*>(p);
+          xr[u][1] = *reinterpret_cast<const f32x4*>(p + a.c0);
+          xr[u][2] = *reinterpret_cast<const f32x4*>(p + a.W0 * a.c0);
+          xr[u][3] = *reinterpret_cast<const f32x4*>(p + a.W0 * a.c0 + a.c0);
+        } else if constexpr (SRCP == PSM_SRC_UPSAMPLE) {
+          const unsigned short* p = from0 ? h0 + fp[u].off0 + chc : h1 + fp[u].off1 + (chc - a.c0);
+          xr[u][0] = *reinterpret_cast<const f32x4*>(p);
+        } else {
+          xr[u][0] = *reinterpret_cast<const f32x4*>(h0 + fp[u].off0 + chc);
+        }
+      }
+      else if constexpr (SRC < 0) xr[u][0] = fetch4_stem(a, in0, y0 - 1 + rr, x0 - 1 + c, ch);
       else if constexpr (SRC == 3) xr[u][0] = fetch4<PSM_SRC_UPSAMPLE, KSM>(a, in0, in1, y0 - 1 + rr, x0 - 1 + c, ch);
       else if constexpr (!DEFER) {
         const f32x4 t = fetch4_prepared<SRCP, KSM>(a, in0, in1, fp[u], chc, from0);
@@ -349,6 +395,14 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
       const int q = tid + 256 * u;
       const int pos = q / G4, c4 = q & (G4 - 1);
       f32x4 v = xr[u][0];
+      if constexpr (ABF) {
+        if constexpr (NQ == 4) v = bf16x8_max(bf16x8_max(xr[u][0], xr[u][1]), bf16x8_max(xr[u][2], xr[u][3]));
+        const bool ok = fp[u].ok && (g * CB + FG * c4 < lim);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0.f;
+        *reinterpret_cast<f32x4*>(&in_tile[buf * TILE + lds_slot(pos, c4)]) = v;      // 8 bf16 = one 16-byte slot of the pixel
+        continue;
+      }
       if constexpr (DEFER) {
         const int ks = (SRCP == PSM_SRC_UPSAMPLE && !from0) ? a.ks1 : a.ks0;
         v = combine4<KSM>(&xr[u][0], ks, xb[u]);
@@ -358,7 +412,7 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaxf(v[j], q1[j]), fmaxf(q2[j], q3[j]));
         }
-        const bool ok = fp[u].ok && (g * CB + 4 * c4 < lim);
+        const bool ok = fp[u].ok && (g * CB + FG * c4 < lim);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0.f;
       }
@@ -448,7 +502,8 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
     for (int g = g_beg; g + 1 < g_end; ++g) run_chunk(g, std::true_type{});
   if (g_beg < g_end) run_chunk(g_end - 1, std::false_type{});
   // ---- epilogue: bias + ReLU (split-K: the raw partial sum into this split's slab), NHWC store
-  float* out = a.out + (int64_t)cs * a.out_case + (int64_t)split * a.out_slab;
+  float* out = a.out_bf ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(a.out) + (int64_t)cs * a.out_case)
+                        : a.out + (int64_t)cs * a.out_case + (int64_t)split * a.out_slab;
   const bool fin = a.ksplit == 1;
 #pragma unroll
   for (int n = 0; n < WN; ++n) {
@@ -462,7 +517,7 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
         const int x = x0 + 4 * kq + r;
         float v = acc[m][n][r] + b;
         if (fin && a.relu) v = fmaxf(v, 0.f);
-        if (y < a.H && x < a.W && co < a.cout) PSM_ACT_STORE(&out[((int64_t)y * a.W + x) * a.cout + co], v);
+        store_act(out, ((int64_t)y * a.W + x) * a.cout + co, v, y < a.H && x < a.W && co < a.cout, a.out_bf != 0, co);
         acc[m][n][r] = v;
       }
     }
@@ -487,7 +542,10 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
 // k-group, addresses fixed per lane -- and the padded terms read a zero word.  Weights go from global memory to
 // registers in MFMA order.  bf16 mode: operands rounded to bf16 first (products exact in the f32 MFMA).
 // ---------------------------------------------------------------------------------------------------
-template <int KG>
+// C0 > 0: the channel count as a compile-time constant (3 for the reference's grid image): the per-element index
+// arithmetic (e / c0, k / c0, ...) is then multiplications instead of ~1000 VALU instructions of integer division per
+// thread, which -- with 8 waves per SIMD -- cost more than the layer's memory traffic; C0 == 0: run-time count.
+template <int KG, int C0>
 __global__ __launch_bounds__(256) void psm_conv_stem_kernel(PsmConvArgs a) {
   constexpr int TH = 8, NPIX = (TH + 2) * (TW + 2), CMAX = 7, NE = (NPIX * CMAX + 255) / 256, ZERO = NE * 256;
   __shared__ float tile[ZERO + 1];
@@ -496,7 +554,7 @@ __global__ __launch_bounds__(256) void psm_conv_stem_kernel(PsmConvArgs a) {
   const int cs = blockIdx.z;
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
   const float* in0 = a.in0 + (int64_t)cs * a.in0_case;
-  const int c0 = a.c0, K = 9 * c0, nval = NPIX * c0;
+  const int c0 = C0 > 0 ? C0 : a.c0, K = 9 * c0, nval = NPIX * c0;
   float ev[NE];
 #pragma unroll
   for (int u = 0; u < NE; ++u) {
@@ -541,7 +599,7 @@ __global__ __launch_bounds__(256) void psm_conv_stem_kernel(PsmConvArgs a) {
 #pragma unroll
       for (int m = 0; m < 2; ++m) acc[m] = MFMA16(av[m][j], bw[g][j], acc[m]);
   }
-  float* out = a.out + (int64_t)cs * a.out_case;
+  float* out = a.out_bf ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(a.out) + (int64_t)cs * a.out_case) : a.out + (int64_t)cs * a.out_case;
   const int co = lane & 15;
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
@@ -551,7 +609,7 @@ __global__ __launch_bounds__(256) void psm_conv_stem_kernel(PsmConvArgs a) {
       const int x = x0 + 4 * kq + r;
       float v = acc[m][r] + bias;
       if (a.relu) v = fmaxf(v, 0.f);
-      if (y < a.H && x < a.W && co < a.cout) PSM_ACT_STORE(&out[((int64_t)y * a.W + x) * a.cout + co], v);
+      store_act(out, ((int64_t)y * a.W + x) * a.cout + co, v, y < a.H && x < a.W && co < a.cout, a.out_bf != 0, co);
     }
   }
 }
@@ -576,6 +634,13 @@ static void launch_variant(const PsmConvArgs& a, dim3 grid, int groups, hipStrea
   const bool one = (a.n_chunks + a.ksplit - 1) / a.ksplit <= 1;      // a single chunk per workgroup: single LDS buffers
 #define GO(S, K)                                                                                                         \
   do {                                                                                                                   \
+    if constexpr (K == 1 && S >= 0 && S != 3) {                                                                          \
+      if (a.bf16 && a.in_bf) {                                                                                           \
+        if (one) hipLaunchKernelGGL((psm_conv3x3_kernel<TH, WM, NCT, WN, S, 1, true, 1, true>), grid, dim3(256), 0, st, a, groups);     \
+        else hipLaunchKernelGGL((psm_conv3x3_kernel<TH, WM, NCT, WN, S, 1, true, 2, true>), grid, dim3(256), 0, st, a, groups);         \
+        break;                                                                                                           \
+      }                                                                                                                  \
+    }                                                                                                                    \
     if (a.bf16) { if (one && K == 1) hipLaunchKernelGGL((psm_conv3x3_kernel<TH, WM, NCT, WN, S, 1, true, 1>), grid, dim3(256), 0, st, a, groups);    \
                   else hipLaunchKernelGGL((psm_conv3x3_kernel<TH, WM, NCT, WN, S, K, true, 2>), grid, dim3(256), 0, st, a, groups); }            \
     else { if (one && K == 1) hipLaunchKernelGGL((psm_conv3x3_kernel<TH, WM, NCT, WN, S, 1, false, 1>), grid, dim3(256), 0, st, a, groups);          \
@@ -616,10 +681,12 @@ hipError_t psm_launch_conv_stem(const PsmConvArgs& a, int n_cases, hipStream_t s
   const int kg = (9 * a.c0 + 15) / 16;
   if (a.c0 < 1 || kg > 4 || a.cout > 16 || a.mode0 != PSM_SRC_SAME || a.c1 != 0 || a.ks0 != 1 || a.ksplit != 1) return hipErrorInvalidValue;
   const dim3 grid((a.W + TW - 1) / TW, (a.H + 7) / 8, n_cases);
-  if (kg == 1) hipLaunchKernelGGL((psm_conv_stem_kernel<1>), grid, dim3(256), 0, st, a);
-  else if (kg == 2) hipLaunchKernelGGL((psm_conv_stem_kernel<2>), grid, dim3(256), 0, st, a);
-  else if (kg == 3) hipLaunchKernelGGL((psm_conv_stem_kernel<3>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((psm_conv_stem_kernel<4>), grid, dim3(256), 0, st, a);
+  if (a.c0 == 3) hipLaunchKernelGGL((psm_conv_stem_kernel<2, 3>), grid, dim3(256), 0, st, a);          // (Ux, Uy, SDF)
+  else if (a.c0 == 4) hipLaunchKernelGGL((psm_conv_stem_kernel<3, 4>), grid, dim3(256), 0, st, a);     // pressureSM_Poisson's 4 channels
+  else if (kg == 1) hipLaunchKernelGGL((psm_conv_stem_kernel<1, 0>), grid, dim3(256), 0, st, a);
+  else if (kg == 2) hipLaunchKernelGGL((psm_conv_stem_kernel<2, 0>), grid, dim3(256), 0, st, a);
+  else if (kg == 3) hipLaunchKernelGGL((psm_conv_stem_kernel<3, 0>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((psm_conv_stem_kernel<4, 0>), grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

@@ -23,6 +23,7 @@ struct Conv {
   int arrangement = 0, nct = 1, n_chunks = 0, groups = 1, ksplit = 1;
   bool stem = false;            // K = 9*c_in flattened (first layer on the raw image)
   bool fuse_head = false;       // this layer's epilogue also computes the 1x1 head
+  bool in_bf = false, out_bf = false;   // bf16 mode: inputs read / output stored as bf16 (finished activations only)
   std::vector<float> W, b;     // host copies (HWIO), kept for re-packing at plan time
   bool set = false;
   float4* d_w = nullptr;
@@ -180,6 +181,7 @@ int forward(psm_unet* u, const float* d_grid, int n, float* d_field, hipStream_t
     a.wpack = c.d_w; a.bias = c.d_b; a.out = out; a.n_chunks = c.n_chunks; a.H = H; a.W = W; a.cout = c.cout; a.relu = c.relu;
     a.out_case = (int64_t)H * W * c.cout;
     a.ksplit = c.ksplit; a.out_slab = c.slab; a.ks0 = 1; a.ks1 = 1; a.bf16 = u->bf16;
+    a.in_bf = c.in_bf ? 1 : 0; a.out_bf = c.out_bf ? 1 : 0;
     if (c.src == 0) { a.in0 = d_grid; a.c0 = c.cin; a.mode0 = PSM_SRC_SAME; a.H0 = H; a.W0 = W; }
     else {
       const Conv& pv = u->convs[i - 1];
@@ -297,10 +299,43 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
   UCHK(u, hipSetDevice(u->device));
   UCHK(u, hipStreamSynchronize(u->stream));
   u->ny = ny; u->nx = nx; u->max_cases = max_cases;
+  for (int pass = 0; pass < 2; ++pass) {
+  if (pass == 1) {
+    // bf16 activation storage (bf16 mode): a finished activation is stored as bf16 when every consumer reads bf16, i.e. is
+    // a 3x3 layer none of whose inputs arrives as split-K slabs (those loaders sum float32 slabs) and whose concatenation
+    // seam lies on a chunk boundary; a consumer with one float32 input takes all its inputs in float32.
+    const size_t n = u->convs.size();
+    std::vector<char> obf(n, 0);
+    for (size_t i = 0; i < n; ++i) obf[i] = (u->bf16 && u->convs[i].k == 3 && u->convs[i].ksplit == 1 && getenv("PSM_UNET_F32_ACT") == nullptr) ? 1 : 0;
+    for (bool changed = true; changed;) {
+      changed = false;
+      for (size_t i = 0; i < n; ++i) {
+        Conv& c = u->convs[i];
+        std::vector<int> ins;
+        if (c.src != 0) ins.push_back((int)i - 1);
+        if (c.src == 3) ins.push_back(c.skip);
+        bool ok = c.k == 3 && !c.stem && c.src != 0;
+        for (int j : ins) ok = ok && obf[j] && u->convs[j].ksplit == 1;
+        if (c.src == 3 && (u->convs[i - 1].cout % 32) != 0) ok = false;            // seam inside a 32-channel chunk
+        if (c.k == 1 && i > 0 && u->convs[i - 1].fuse_head) continue;              // fused head reads registers
+        c.in_bf = ok;
+        if (!ok) for (int j : ins) if (obf[j]) { obf[j] = 0; changed = true; }
+      }
+    }
+    for (size_t i = 0; i < n; ++i) u->convs[i].out_bf = obf[i] != 0;
+  }
   for (Conv& c : u->convs) {
     const int H = ny >> c.level, W = nx >> c.level;
     const size_t ci = &c - u->convs.data();
     const bool feeds_conv3 = ci + 1 < u->convs.size() && u->convs[ci + 1].k == 3;
+    if (pass == 1) {
+      int rc = upload_conv(u, c);
+      if (rc) return rc;
+      free_dev(c.d_out); c.d_out = nullptr;
+      c.slab = (int64_t)max_cases * H * W * c.cout;
+      UCHK(u, hipMalloc((void**)&c.d_out, (size_t)c.ksplit * c.slab * sizeof(float) + 64));
+      continue;
+    }
     if (c.k == 3) choose_config(c, H, W, max_cases, feeds_conv3 && getenv("PSM_UNET_NO_SPLIT") == nullptr, u->bf16 ? 32 : 16);
     // diagnostic override: PSM_UNET_FORCE="layer:arrangement:nct:ksplit,..." (tools/unet_bench.py experiments)
     if (const char* f = getenv("PSM_UNET_FORCE")) {
@@ -317,11 +352,7 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
     c.fuse_head = c.k == 3 && ci + 1 < u->convs.size() && u->convs[ci + 1].k == 1 && c.cout == 16 && !c.stem &&
                   getenv("PSM_UNET_NO_HEAD_FUSION") == nullptr;
     if (c.fuse_head) { c.arrangement = 0; c.nct = 1; c.groups = 1; c.ksplit = 1; }
-    int rc = upload_conv(u, c);
-    if (rc) return rc;
-    free_dev(c.d_out); c.d_out = nullptr;
-    c.slab = (int64_t)max_cases * H * W * c.cout;
-    UCHK(u, hipMalloc((void**)&c.d_out, (size_t)c.ksplit * c.slab * sizeof(float)));
+  }
   }
   free_dev(u->d_in); free_dev(u->d_field);
   if (u->h_in) { (void)hipHostFree(u->h_in); u->h_in = nullptr; }
@@ -383,6 +414,12 @@ int psm_unet_read_activation(psm_unet* u, int32_t idx, float* dst, int64_t dst_f
   if (dst_floats < n) return fail(u, PSM_ERR_ARG, "destination too small");
   UCHK(u, hipSetDevice(u->device));
   UCHK(u, hipStreamSynchronize(u->stream));
+  if (c.out_bf) {                 // stored as bf16: widen
+    std::vector<uint16_t> hb((size_t)n);
+    UCHK(u, hipMemcpy(hb.data(), c.d_out, (size_t)n * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    for (int64_t q = 0; q < n; ++q) { const uint32_t w = (uint32_t)hb[q] << 16; std::memcpy(&dst[q], &w, 4); }
+    return PSM_OK;
+  }
   UCHK(u, hipMemcpy(dst, c.d_out, n * sizeof(float), hipMemcpyDeviceToHost));
   if (c.ksplit > 1) {            // partial-sum slabs: finish like the consumer's loader (slab order, bias, ReLU)
     std::vector<float> tmp(n);
