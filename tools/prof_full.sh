@@ -10,7 +10,7 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extras > $O/write.log 2>&1; echo "write rc=$?"
 cd $R
 timeout -k 10 400 python bench.py > $O/bench.log 2>&1; tail -1 $O/bench.log | cut -c1-200
-python tools/pmc_summary.py $TAG
+
 # convolutional path: kernel stats + bench lines
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/unet_stats -- python3 $R/bench.py --workload unet8 --steps 100 --warmup 10 --no-cpu-baseline > $O/unet_stats.log 2>&1; echo "unet stats rc=$?"
@@ -18,3 +18,4 @@ cd $R
 timeout -k 10 300 python bench.py --workload unet > $O/bench_unet.log 2>&1; tail -1 $O/bench_unet.log | cut -c1-160
 timeout -k 10 300 python bench.py --workload unet8 --no-cpu-baseline > $O/bench_unet8.log 2>&1; tail -1 $O/bench_unet8.log | cut -c1-160
 timeout -k 10 300 python bench.py --workload unet8_bf16 --no-cpu-baseline > $O/bench_unet8_bf16.log 2>&1; tail -1 $O/bench_unet8_bf16.log | cut -c1-160
+python tools/pmc_summary.py $TAG
