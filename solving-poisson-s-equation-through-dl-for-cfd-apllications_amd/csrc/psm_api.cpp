@@ -479,6 +479,7 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
                  ((h->Ny * (int64_t)h->Nx * h->cfg.c_in) % 4 == 0);
   for (auto& b : h->plan.blocks) if ((b.x0 * h->cfg.c_in) % 4 != 0) aligned = false;
   ea.aligned = aligned ? 1 : 0;
+  { static const bool chunked = getenv("PSM_ENCODE_CHUNKED") != nullptr; ea.whole = chunked ? 0 : 1; }
 
   if (h->timed_kernel == PSM_K_ENCODE && !prof) {
     // dominant kernel: dispatch-level begin / end stamps (no marker packets around the launch)

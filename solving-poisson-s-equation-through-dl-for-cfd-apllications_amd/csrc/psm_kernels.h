@@ -41,6 +41,7 @@ struct PsmEncodeArgs {
   const int64_t* row_base; // [Mpad] float offset of each block's origin in grid, -1 = padding row
   int64_t row_stride;      // Nx*C_in floats
   int M, Mpad, NT, ldp, S, c_in, aligned;
+  int whole;               // 33..128 rows: stage all rows at once (PSM_ENCODE_CHUNKED=1 keeps the double-buffered chunks)
 };
 
 struct PsmReduceArgs {

@@ -118,6 +118,31 @@ __global__ __launch_bounds__(256) void psm_encode_kernel(PsmEncodeArgs a) {
     }
   };
 
+  if (NT <= 4 && a.Mpad > 32 && a.Mpad <= 32 * PSM_MT_CHUNK && a.whole) {
+    // 33..128 block rows (a per-GPU shard of a case batch: 8 cases x 9 blocks = 72 rows): ALL rows and the weight slice
+    // are requested in one go -- one memory round trip in front of the MFMAs instead of one per 64-row chunk --, staged
+    // (rows beyond M as zeros, always 128 of them: no conditional stores), then the 2-4 row tiles run back to back with
+    // the partial-sum stores of tile mt under the MFMAs of tile mt + 1.
+    const int t = min(wave, NT - 1);
+    float4 x[PSM_MT_CHUNK][8];
+#pragma unroll
+    for (int q = 0; q < PSM_MT_CHUNK; ++q) load_rows(x[q], 0, 32 * q);
+    __builtin_amdgcn_sched_barrier(0);
+    float4 b[G];
+    {
+      const float4* p = a.bpack + (((int64_t)s * NT + t) * G) * 64 + lane;
+#pragma unroll
+      for (int g = 0; g < G; ++g) b[g] = stream_load(p + g * 64);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < PSM_MT_CHUNK; ++q) write_rows(x[q], 0, 32 * q);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    gemm_tile(b, 0, t, 0, wave < NT);
+    for (int mt = 1; mt < a.Mpad / 32; ++mt) gemm_tile(b, mt, t, 0, wave < NT);
+    return;
+  }
+
   if (NT <= 4 && a.Mpad > 32) {
     // many block rows (case batches): 64-row chunks double-buffered in LDS.  The rows of chunk c+1 are
     // requested before the MFMAs of chunk c and written to the other buffer after them, so the
