@@ -259,6 +259,12 @@ const char* psm_geometry_last_error(void);
  * accepted for signature compatibility (the MPI funnel, PM:258/511, stays with the caller).
  * Synchronous. */
 int psm_solve(psm_handle* h, const double* cells, int64_t n, int32_t rank, double* p_out);
+/* The same in two halves, for ONE thread that advances several independent cases (one handle, i.e. one geometry and one
+ * stream, per case -- the "ensemble of PISO cases" of a parameter study): psm_solve_begin copies `cells` (or DMAs from
+ * the registered array) and enqueues the whole step, psm_solve_end waits for it and delivers p into the `p_out` given
+ * to begin.  One step in flight per handle; psm_solve = begin + end. */
+int psm_solve_begin(psm_handle* h, const double* cells, int64_t n, int32_t rank, double* p_out);
+int psm_solve_end(psm_handle* h);
 /* Optional: register the solver's own persistent buffers (the `input_vals` array of PythonComm_init.H:53 lives for the
  * whole run; the output array likewise) so that psm_solve DMAs from / to them directly instead of through the
  * handle's pinned staging copies (saves two host memcpys per step).  cells [n_cells,5] and / or p_out [n_cells] (either

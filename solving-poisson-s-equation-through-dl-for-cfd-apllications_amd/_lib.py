@@ -81,6 +81,8 @@ SIGNATURES = {
                                      _i32p, _f64p, _i32p, _f64p]),
     "psm_geometry_last_error": (C.c_char_p, []),
     "psm_solve": (C.c_int, [_hp, _f64p, C.c_int64, C.c_int32, _f64p]),
+    "psm_solve_begin": (C.c_int, [_hp, _f64p, C.c_int64, C.c_int32, _f64p]),
+    "psm_solve_end": (C.c_int, [_hp]),
     "psm_poisson_features": (C.c_int, [_hp, _f64p, _f64p, _f64p, _f64p, _f64p, C.c_int32, C.c_int32, _f64p, _f32p]),
     "psm_pin_buffers": (C.c_int, [_hp, _f64p, _f64p]),
     "psm_unpin_buffers": (C.c_int, [_hp]),

@@ -146,6 +146,8 @@ struct psm_handle {
   bool bound = false, bound_zero_fill = false;
   int bound_scope = 0;                  // 2: every single-case solve (psm_bind_geometry); 1: psm_solve only (bound by psm_set_geometry)
   bool in_mesh_solve = false;
+  bool mesh_inflight = false;           // psm_solve_begin enqueued, psm_solve_end not yet called
+  double* mesh_copy_out = nullptr;      // where psm_solve_end copies p to (null: it was DMA'd / stored into the caller's registered array)
   int bound_rows = 0;                   // table rows per case
   int bound_cases = 0;                  // cases bound (solves with exactly this many cases take the bound path)
   float *d_comp_nat = nullptr;          // comp_out in natural layout [ld_out][K_out] (f32 precision only)
@@ -1538,9 +1540,10 @@ int psm_init_geometry(psm_handle* h, const double* cells, int64_t n, const doubl
   return psm_set_geometry(h, n, ny, nx, v1.data(), w1.data(), idx.data(), sdf.data(), v2.data(), w2.data(), h->case_maxs, 0, 0, h->case_wall);
 }
 
-int psm_solve(psm_handle* h, const double* cells, int64_t n, int32_t rank, double* p_out) {
+int psm_solve_begin(psm_handle* h, const double* cells, int64_t n, int32_t rank, double* p_out) {
   (void)rank;
   if (!h) return PSM_ERR_ARG;
+  if (h->mesh_inflight) return fail(h, PSM_ERR_STATE, "a psm_solve_begin is already in flight on this handle: call psm_solve_end first");
   if (!h->have_geometry) return fail(h, PSM_ERR_STATE, "psm_set_geometry has not been called");
   if (h->cfg.c_in != 3 || h->cfg.c_out != 1) return fail(h, PSM_ERR_UNSUPPORTED, "the mesh entry needs c_in == 3 and c_out == 1 (python_module.py:288-292)");
   if (!h->have_g2m) return fail(h, PSM_ERR_STATE, "psm_set_geometry was called without the grid->mesh tables");
@@ -1598,14 +1601,30 @@ int psm_solve(psm_handle* h, const double* cells, int64_t n, int32_t rank, doubl
   HIPCHK(h, psm_launch_to_mesh(ma, st));
   if (p_out == h->pinned_p) {
     if (!direct) HIPCHK(h, hipMemcpyAsync(p_out, h->d_p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIPCHK(h, wait_stream(st));
-    return PSM_OK;
+    h->mesh_copy_out = nullptr;
+  } else {
+    HIPCHK(h, hipMemcpyAsync(h->h_p, h->d_p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+    h->mesh_copy_out = p_out;
   }
-  HIPCHK(h, hipMemcpyAsync(h->h_p, h->d_p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCHK(h, wait_stream(st));
-  memcpy(p_out, h->h_p, (size_t)n * sizeof(double));
+  h->mesh_inflight = true;
   return PSM_OK;
 }
+
+int psm_solve_end(psm_handle* h) {
+  if (!h) return PSM_ERR_ARG;
+  if (!h->mesh_inflight) return fail(h, PSM_ERR_STATE, "no psm_solve_begin in flight");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  h->mesh_inflight = false;
+  HIPCHK(h, wait_stream(h->stream));
+  if (h->mesh_copy_out) memcpy(h->mesh_copy_out, h->h_p, (size_t)h->n_cells * sizeof(double));
+  return PSM_OK;
+}
+
+int psm_solve(psm_handle* h, const double* cells, int64_t n, int32_t rank, double* p_out) {
+  int rc = psm_solve_begin(h, cells, n, rank, p_out);
+  return rc ? rc : psm_solve_end(h);
+}
+
 
 int psm_pin_buffers(psm_handle* h, const double* cells, double* p_out) {
   if (!h) return PSM_ERR_ARG;

@@ -875,6 +875,25 @@ class SolverModule:
         self._sur._chk(self._sur.lib.psm_unpin_buffers(self._sur.h))
         self._pinned = None
 
+    def py_func_begin(self, array_in, out: np.ndarray = None):
+        """First half of :meth:`py_func` (psm_solve_begin): enqueue the step and return; several SolverModules (cases)
+        can be advanced from one thread by calling begin on all of them, then :meth:`py_func_end` on each."""
+        if self.tables is None:
+            raise RuntimeError("init_func has not been called")
+        a = _f64(array_in)
+        if a.ndim != 2 or a.shape[1] != 5:
+            raise ValueError("array must be [N,5] = (Ux, Uy, Cx, Cy, p)")
+        if out is None:
+            out = np.empty(a.shape[0], np.float64)
+        self._sur._chk(self._sur.lib.psm_solve_begin(self._sur.h, _p(a, C.c_double), a.shape[0], 0, _p(out, C.c_double)))
+        self._inflight = (a, out)                       # keeps both arrays alive until the end call (set only once the step is in flight)
+
+    def py_func_end(self) -> np.ndarray:
+        self._sur._chk(self._sur.lib.psm_solve_end(self._sur.h))
+        a, out = self._inflight
+        self._inflight = None
+        return out
+
     def py_func(self, array_in, placeholder=0, out: np.ndarray = None) -> np.ndarray:
         """python_module.py:249: cells [N,5] float64 -> p [N] float64."""
         if self.tables is None:

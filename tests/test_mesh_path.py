@@ -6,7 +6,7 @@ import pytest
 
 import cases
 from oracle import psm_oracle as orc
-from psm_amd import SolverModule, geometry
+from psm_amd import _lib, SolverModule, geometry
 from test_oracle_golden import oracle_model
 
 
@@ -113,6 +113,33 @@ def test_pinned_solver_buffers_give_the_same_pressures(mesh_case):
     np.testing.assert_array_equal(sm.py_func(cells, out=out), ref)
     sm.unpin()
     np.testing.assert_array_equal(sm.py_func(cells, out=out), ref)
+
+
+@pytest.mark.gpu
+def test_ensemble_of_cases_advanced_from_one_thread(mesh_case):
+    """psm_solve_begin / psm_solve_end: three independent cases (one handle = one geometry and stream each) advanced
+    in lock-step from one thread -- begin on all, end on all -- give the pressures of the synchronous calls; a second
+    begin without an end, and an end without a begin, are refused."""
+    array, top, obst, model, maxs, geo, gold = mesh_case
+    mods, arrays = [], []
+    for k in range(3):
+        a = cases.build_mesh_case(step=k)[0]
+        sm = SolverModule(model, maxs)
+        sm.init_func(a, top, obst)
+        mods.append(sm); arrays.append(a)
+    ref = [sm.py_func(a) for sm, a in zip(mods, arrays)]
+    for rep in range(3):
+        for sm, a in zip(mods, arrays):
+            sm.py_func_begin(a)
+        got = [sm.py_func_end() for sm in mods]
+        for g, r in zip(got, ref):
+            np.testing.assert_array_equal(g, r)
+    mods[0].py_func_begin(arrays[0])
+    with pytest.raises(_lib.PsmError):
+        mods[0].py_func_begin(arrays[0])
+    mods[0].py_func_end()
+    with pytest.raises(_lib.PsmError):
+        mods[0].py_func_end()
 
 
 def test_oracle_filters_match_reference_run():
