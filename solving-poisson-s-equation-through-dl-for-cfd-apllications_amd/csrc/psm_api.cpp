@@ -308,6 +308,7 @@ int ws_alloc(psm_handle* h, Workspace& w) {
 
 void ring_drop_graphs(psm_handle* h) {
   for (auto& s : h->slot) {
+    if ((s.g_full || s.g_kern) && s.st) (void)hipStreamSynchronize(s.st);     // a replay of this slot may still be running
     if (s.g_full) { (void)hipGraphExecDestroy(s.g_full); s.g_full = nullptr; }
     if (s.g_kern) { (void)hipGraphExecDestroy(s.g_kern); s.g_kern = nullptr; }
     s.g_full_key = s.g_kern_key = -1;
@@ -1199,7 +1200,6 @@ static int ring_capture(psm_handle* h, psm_handle::Slot& s, int n_cases, bool sc
                         bool with_copies, hipGraphExec_t* out) {
   hipGraph_t graph = nullptr;
   HIPCHK(h, hipStreamBeginCapture(s.st, hipStreamCaptureModeRelaxed));
-  const std::string keep = h->err;
   int rc = ring_sequence(h, s, n_cases, scale, src_dev, dst_dev, s.h_in, s.h_out, with_copies);
   hipError_t e2 = hipStreamEndCapture(s.st, &graph);
   if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
@@ -1210,7 +1210,6 @@ static int ring_capture(psm_handle* h, psm_handle::Slot& s, int n_cases, bool sc
   hipError_t e = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
   (void)hipGraphDestroy(graph);
   if (e != hipSuccess) return fail(h, PSM_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
-  h->err = keep;
   return PSM_OK;
 }
 
