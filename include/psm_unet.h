@@ -39,6 +39,10 @@ int psm_unet_set_conv(psm_unet* u, int32_t idx, const float* weight, const float
  * at every convolution input, f32 accumulation by v_mfma_f32_16x16x32_bf16; activations stay float32 in
  * memory).  Call before psm_unet_plan.  Constants from psm.h. */
 int psm_unet_set_precision(psm_unet* u, int32_t precision);
+/* bf16 mode fuses the two convolutions of a wide level into one launch and keeps the first one's activation (and the
+ * last 3x3 layer's, whose 1x1 head is fused) on chip.  on != 0: those activations are stored as well, so that
+ * psm_unet_read_activation can return every layer (parity tests); off by default.  Call before psm_unet_plan. */
+int psm_unet_keep_activations(psm_unet* u, int32_t on);
 /* Fixes the image size (ny, nx multiples of 2^(n_levels-1)) and the largest case batch; allocates activations. */
 int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases);
 /* Host buffers: grid [n, ny, nx, c_in] -> field [n, ny, nx, c_out], synchronous. */
@@ -47,7 +51,8 @@ int psm_unet_forward(psm_unet* u, const float* grid, int32_t n_cases, float* fie
 int psm_unet_forward_device(psm_unet* u, const float* d_grid, int32_t n_cases, float* d_field, void* stream);
 int psm_unet_synchronize(psm_unet* u);
 /* Output activation of convolution `idx` of the last forward pass (introspection for parity tests):
- * dst [n_cases * (ny >> level) * (nx >> level) * c_out] floats. */
+ * dst [n_cases * (ny >> level) * (nx >> level) * c_out] floats.  PSM_ERR_STATE for an activation that a fused pair
+ * keeps on chip (see psm_unet_keep_activations). */
 int psm_unet_read_activation(psm_unet* u, int32_t idx, float* dst, int64_t dst_floats);
 /* One forward pass with a HIP event between the layers: ms [num_convs] (each includes ~3 us of event overhead),
  * wgs [num_convs] workgroups launched per layer (may be NULL).  Introspection for tuning. */

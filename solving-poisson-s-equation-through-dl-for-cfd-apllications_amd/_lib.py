@@ -117,6 +117,7 @@ SIGNATURES_UNET = {
     "psm_unet_conv_shape": (C.c_int, [_up, C.c_int32, _i32ptr, _i32ptr, _i32ptr]),
     "psm_unet_set_conv": (C.c_int, [_up, C.c_int32, _f32p, _f32p]),
     "psm_unet_set_precision": (C.c_int, [_up, C.c_int32]),
+    "psm_unet_keep_activations": (C.c_int, [_up, C.c_int32]),
     "psm_unet_plan": (C.c_int, [_up, C.c_int32, C.c_int32, C.c_int32]),
     "psm_unet_forward": (C.c_int, [_up, _f32p, C.c_int32, _f32p]),
     "psm_unet_forward_device": (C.c_int, [_up, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),

@@ -52,3 +52,23 @@ hipError_t psm_launch_head1x1(const PsmHeadArgs& a, hipStream_t st);
 hipError_t psm_unet_read_stamps(unsigned long long* out);   // [64]; zeros unless built with -DPSM_STAMPS
 // stem: first layer on the raw grid image, K = 9 * c_in flattened (c_in <= 7); wpack [ct][KG][lane] float4
 hipError_t psm_launch_conv_stem(const PsmConvArgs& a, int n_cases, hipStream_t st);
+
+// ---- fused level pairs (psm_unet_pair.hip): conv A + conv B of a level in one launch, bf16 mode ----------------------
+#define PSM_PAIR_TX 30          // output tile of a workgroup (the mid tile is 32 x 16: two MFMA pixel tiles wide)
+#define PSM_PAIR_TY 14
+enum { PSM_PAIR_STEM = 0, PSM_PAIR_UPCAT = 1, PSM_PAIR_POOL = 2 };
+struct PsmPairArgs {
+  const void* in0;             // STEM: float32 image [H][W][c0];  POOL: bf16 [2H][2W][c0];  UPCAT: bf16 [H/2][W/2][c0]
+  const void* in1;             // UPCAT: bf16 skip [H][W][c1]
+  const uint4* wA;             // conv A fragments (64 lanes x 16 bytes each), see pack_pair_a (psm_unet_api.cpp)
+  const uint4* wB;             // conv B fragments
+  const float* biasA; const float* biasB;
+  unsigned short* out;         // bf16 [H][W][cm], or nullptr (head only)
+  unsigned short* mid_out;     // introspection: conv A's activation, bf16 [H][W][cm], or nullptr
+  const float* head_w; const float* head_b; float* head_out; int head_cout; int64_t head_case;   // fused linear 1x1 head (cm == 16)
+  int H, W, c0, c1;
+  int tiles_x, tiles_y, n_cases;
+  int64_t in0_case, in1_case, out_case;   // per-case strides (elements)
+};
+hipError_t psm_unet_pair_read_stamps(unsigned long long* out);   // [64]: 3 workgroups x 16 stamps; zeros unless built with -DPSM_STAMPS
+hipError_t psm_launch_conv_pair(const PsmPairArgs& a, int kind, int cm, int n_cases, hipStream_t st);

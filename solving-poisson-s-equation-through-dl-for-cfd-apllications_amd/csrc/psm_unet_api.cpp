@@ -24,6 +24,10 @@ struct Conv {
   bool stem = false;            // K = 9*c_in flattened (first layer on the raw image)
   bool fuse_head = false;       // this layer's epilogue also computes the 1x1 head
   bool in_bf = false, out_bf = false;   // bf16 mode: inputs read / output stored as bf16 (finished activations only)
+  // fused level pair (psm_unet_pair.hip): 1 = first convolution of a pair (its launch computes both), 2 = second (no launch)
+  int pair = 0, pair_kind = 0;
+  uint4* d_wpa = nullptr;       // pair leader: conv A's fragments
+  uint4* d_wpb = nullptr;       // pair leader: conv B's fragments
   std::vector<float> W, b;     // host copies (HWIO), kept for re-packing at plan time
   bool set = false;
   float4* d_w = nullptr;
@@ -41,6 +45,7 @@ struct psm_unet {
   std::vector<Conv> convs;
   int ny = 0, nx = 0, max_cases = 0, last_cases = 0, bf16 = 0;
   bool planned = false;
+  bool keep_act = false;        // fused pairs also store what they would keep on chip (introspection for the parity tests)
   float *d_in = nullptr, *d_field = nullptr, *h_in = nullptr, *h_out = nullptr;
   hipStream_t stream = nullptr;
   std::string err;
@@ -113,6 +118,41 @@ std::vector<float> pack_stem(const Conv& c, bool bf16) {
   return p;
 }
 
+// Fragments of the fused-pair kernels (psm_unet_pair.hip): 64 lanes x 8 bf16 each, the MFMA's FIRST operand: lane l holds
+// W[tap][ci(l >> 4, j)][co = 16*nt + (l & 15)], j < 8.
+//   stem (flat):        step s:            k = 32 s + 8 (l >> 4) + j -> (tap = k / c_in, ci = k % c_in), zero beyond 9 c_in
+//   32-channel chunk:   [kx][ky][nt]:      ci = base + 8 (l >> 4) + j
+//   16-channel chunk:   [pair s][ky][nt]:  kx = 2 s + (l >> 5), ci = base + 8 ((l >> 4) & 1) + j, zero for kx = 3
+// Chunks: the channels of in0 then of in1 (c0 + c1 = c.cin), 32 at a time while they last, then one of 16.
+std::vector<uint16_t> pack_pair(const Conv& c, bool flat, int c0, int c1) {
+  const int NT = c.cout / 16;
+  std::vector<uint16_t> p;
+  auto frag = [&](auto&& wat) {                       // wat(kq, j, co) -> weight
+    for (int lane = 0; lane < 64; ++lane)
+      for (int j = 0; j < 8; ++j) p.push_back(f2bf(wat(lane >> 4, j, lane & 15)));
+  };
+  auto W = [&](int tap, int ci, int co) { return c.W[((size_t)tap * c.cin + ci) * c.cout + co]; };
+  if (flat) {
+    const int K = 9 * c.cin;
+    for (int s = 0; s < (K + 31) / 32; ++s)
+      frag([&](int kq, int j, int co) { const int k = 32 * s + 8 * kq + j; return k < K ? W(k / c.cin, k % c.cin, co) : 0.f; });
+    return p;
+  }
+  for (int part = 0; part < 2; ++part) {
+    const int cn = part == 0 ? c0 : c1, base = part == 0 ? 0 : c0;
+    for (int cb = 0; cb < cn; cb += 32) {
+      if (cn - cb >= 32) {
+        for (int kx = 0; kx < 3; ++kx) for (int ky = 0; ky < 3; ++ky) for (int nt = 0; nt < NT; ++nt)
+          frag([&](int kq, int j, int co) { return W(ky * 3 + kx, base + cb + 8 * kq + j, 16 * nt + co); });
+      } else {
+        for (int s = 0; s < 2; ++s) for (int ky = 0; ky < 3; ++ky) for (int nt = 0; nt < NT; ++nt)
+          frag([&](int kq, int j, int co) { const int kx = 2 * s + (kq >> 1); return kx < 3 ? W(ky * 3 + kx, base + cb + 8 * (kq & 1) + j, 16 * nt + co) : 0.f; });
+      }
+    }
+  }
+  return p;
+}
+
 // workgroup count first (fill 256 CUs), then the most reuse per workgroup
 void choose_config(Conv& c, int H, int W, int n_cases, bool can_split, int chunk_ch) {
   const int ctiles = (c.cout + 15) / 16;
@@ -141,6 +181,7 @@ void choose_config(Conv& c, int H, int W, int n_cases, bool can_split, int chunk
 
 int upload_conv(psm_unet* u, Conv& c) {
   free_dev(c.d_w); c.d_w = nullptr; free_dev(c.d_b); c.d_b = nullptr; free_dev(c.d_w1); c.d_w1 = nullptr;
+  free_dev(c.d_wpa); c.d_wpa = nullptr; free_dev(c.d_wpb); c.d_wpb = nullptr;
   std::vector<float> bias((size_t)((c.cout + 15) / 16 + 4) * 16, 0.f);
   std::memcpy(bias.data(), c.b.data(), c.cout * sizeof(float));
   UCHK(u, hipMalloc((void**)&c.d_b, bias.size() * sizeof(float)));
@@ -161,6 +202,17 @@ int upload_conv(psm_unet* u, Conv& c) {
     UCHK(u, hipMalloc((void**)&c.d_w1, c.W.size() * sizeof(float)));
     UCHK(u, hipMemcpy(c.d_w1, c.W.data(), c.W.size() * sizeof(float), hipMemcpyHostToDevice));
   }
+  if (c.pair == 1) {
+    const size_t ci = &c - u->convs.data();
+    const Conv& B = u->convs[ci + 1];
+    int c0 = c.cin, c1 = 0;
+    if (c.pair_kind == PSM_PAIR_UPCAT) { c0 = u->convs[ci - 1].cout; c1 = u->convs[c.skip].cout; }
+    const std::vector<uint16_t> pa = pack_pair(c, c.pair_kind == PSM_PAIR_STEM, c0, c1), pb = pack_pair(B, false, B.cin, 0);
+    UCHK(u, hipMalloc((void**)&c.d_wpa, pa.size() * sizeof(uint16_t)));
+    UCHK(u, hipMemcpy(c.d_wpa, pa.data(), pa.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    UCHK(u, hipMalloc((void**)&c.d_wpb, pb.size() * sizeof(uint16_t)));
+    UCHK(u, hipMemcpy(c.d_wpb, pb.data(), pb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  }
   return PSM_OK;
 }
 
@@ -171,6 +223,29 @@ int forward(psm_unet* u, const float* d_grid, int n, float* d_field, hipStream_t
     Conv& c = u->convs[i];
     const int H = u->ny >> c.level, W = u->nx >> c.level;
     float* out = (i + 1 == u->convs.size()) ? d_field : c.d_out;
+    if (c.pair == 2) continue;                                // computed by the pair's first convolution's launch
+    if (c.pair == 1) {
+      const Conv& B = u->convs[i + 1];
+      PsmPairArgs p{};
+      p.wA = c.d_wpa; p.wB = c.d_wpb; p.biasA = c.d_b; p.biasB = B.d_b;
+      p.H = H; p.W = W; p.tiles_x = (W + PSM_PAIR_TX - 1) / PSM_PAIR_TX; p.tiles_y = (H + PSM_PAIR_TY - 1) / PSM_PAIR_TY; p.n_cases = n;
+      p.out_case = (int64_t)H * W * c.cout;
+      p.out = (B.fuse_head && !u->keep_act) ? nullptr : reinterpret_cast<unsigned short*>(B.d_out);
+      p.mid_out = u->keep_act ? reinterpret_cast<unsigned short*>(c.d_out) : nullptr;
+      if (c.pair_kind == PSM_PAIR_STEM) { p.in0 = d_grid; p.c0 = c.cin; p.in0_case = (int64_t)H * W * c.cin; }
+      else {
+        const Conv& pv = u->convs[i - 1];
+        p.in0 = pv.d_out; p.c0 = pv.cout;
+        if (c.pair_kind == PSM_PAIR_POOL) p.in0_case = (int64_t)4 * H * W * pv.cout;
+        else { p.in0_case = (int64_t)(H / 2) * (W / 2) * pv.cout; p.in1 = u->convs[c.skip].d_out; p.c1 = u->convs[c.skip].cout; p.in1_case = (int64_t)H * W * p.c1; }
+      }
+      if (B.fuse_head) {
+        const Conv& hd = u->convs[i + 2];
+        p.head_w = hd.d_w1; p.head_b = hd.d_b; p.head_out = d_field; p.head_cout = hd.cout; p.head_case = (int64_t)H * W * hd.cout;
+      }
+      UCHK(u, psm_launch_conv_pair(p, c.pair_kind, c.cout, n, st));
+      continue;
+    }
     if (c.k == 1) {
       if (u->convs[i - 1].fuse_head) continue;               // computed in the previous layer's epilogue
       PsmHeadArgs ha{u->convs[i - 1].d_out, c.d_w1, c.d_b, out, (int64_t)n * H * W, c.cin, c.cout};
@@ -254,7 +329,7 @@ void psm_unet_destroy(psm_unet* u) {
   if (!u) return;
   (void)hipSetDevice(u->device);
   if (u->stream) (void)hipStreamSynchronize(u->stream);
-  for (Conv& c : u->convs) { free_dev(c.d_w); free_dev(c.d_b); free_dev(c.d_w1); free_dev(c.d_out); }
+  for (Conv& c : u->convs) { free_dev(c.d_w); free_dev(c.d_b); free_dev(c.d_w1); free_dev(c.d_out); free_dev(c.d_wpa); free_dev(c.d_wpb); }
   free_dev(u->d_in); free_dev(u->d_field);
   if (u->h_in) (void)hipHostFree(u->h_in);
   if (u->h_out) (void)hipHostFree(u->h_out);
@@ -287,6 +362,13 @@ int psm_unet_set_precision(psm_unet* u, int32_t precision) {
   if (precision != PSM_PRECISION_F32 && precision != PSM_PRECISION_BF16) return fail(u, PSM_ERR_ARG, "unknown precision");
   if (u->planned) return fail(u, PSM_ERR_STATE, "set the precision before psm_unet_plan");
   u->bf16 = precision == PSM_PRECISION_BF16 ? 1 : 0;
+  return PSM_OK;
+}
+
+int psm_unet_keep_activations(psm_unet* u, int32_t on) {
+  if (!u) return PSM_ERR_ARG;
+  if (u->planned) return fail(u, PSM_ERR_STATE, "call psm_unet_keep_activations before psm_unet_plan");
+  u->keep_act = on != 0;
   return PSM_OK;
 }
 
@@ -323,6 +405,30 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
       }
     }
     for (size_t i = 0; i < n; ++i) u->convs[i].out_bf = obf[i] != 0;
+    // fused level pairs (psm_unet_pair.hip): both 3x3 convolutions of a level in one launch, where the level is wide
+    // enough to fill the chip with 30 x 14 tiles and the shapes are ones the pair kernels are written for
+    const long pair_min = getenv("PSM_UNET_PAIR_MIN") ? atol(getenv("PSM_UNET_PAIR_MIN")) : 96;
+    for (size_t i = 0; i + 1 < n; ++i) { u->convs[i].pair = 0; u->convs[i + 1].pair = 0; }
+    for (size_t i = 0; u->bf16 && getenv("PSM_UNET_NO_PAIR") == nullptr && i + 1 < n; ++i) {
+      Conv& A = u->convs[i]; Conv& B = u->convs[i + 1];
+      if (A.k != 3 || B.k != 3 || B.src != 1 || A.level != B.level || A.pair || B.pair) continue;
+      const int cm = A.cout, H = ny >> A.level, W = nx >> A.level;
+      if (B.cin != cm || B.cout != cm || (cm != 16 && cm != 32) || A.ksplit != 1 || B.ksplit != 1) continue;
+      if (!(B.out_bf || B.fuse_head) || (B.fuse_head && cm != 16)) continue;
+      const long wgs = (long)((W + PSM_PAIR_TX - 1) / PSM_PAIR_TX) * ((H + PSM_PAIR_TY - 1) / PSM_PAIR_TY) * max_cases;
+      if (wgs < pair_min) continue;
+      int kind = -1;
+      if (A.src == 0 && cm == 16 && (A.cin == 3 || A.cin == 4)) kind = PSM_PAIR_STEM;
+      else if (A.src == 2 && A.in_bf && cm == 32 && A.cin % 16 == 0) kind = PSM_PAIR_POOL;
+      else if (A.src == 3 && A.in_bf) {
+        const int c0 = u->convs[i - 1].cout, c1 = u->convs[A.skip].cout;
+        if (cm == 16 && c0 == 32 && c1 == 16) kind = PSM_PAIR_UPCAT;
+        if (cm == 32 && c0 % 32 == 0 && c1 % 16 == 0) kind = PSM_PAIR_UPCAT;
+      }
+      if (kind < 0) continue;
+      if (cm == 32 && getenv("PSM_UNET_PAIR32") == nullptr) continue;     // the 32-channel pair kernel is not faster than two launches yet
+      A.pair = 1; A.pair_kind = kind; B.pair = 2;
+    }
   }
   for (Conv& c : u->convs) {
     const int H = ny >> c.level, W = nx >> c.level;
@@ -410,6 +516,8 @@ int psm_unet_read_activation(psm_unet* u, int32_t idx, float* dst, int64_t dst_f
   if (!u->planned || u->last_cases < 1) return fail(u, PSM_ERR_STATE, "no forward pass yet");
   if (idx < 0 || idx + 1 >= (int)u->convs.size()) return fail(u, PSM_ERR_ARG, "activation index out of range (the head's output is the field)");
   const Conv& c = u->convs[idx];
+  if (!u->keep_act && (c.pair == 1 || (c.pair == 2 && c.fuse_head)))
+    return fail(u, PSM_ERR_STATE, "this activation stays on chip (fused level pair): call psm_unet_keep_activations(u, 1) before psm_unet_plan");
   const int64_t n = (int64_t)u->last_cases * (u->ny >> c.level) * (u->nx >> c.level) * c.cout;
   if (dst_floats < n) return fail(u, PSM_ERR_ARG, "destination too small");
   UCHK(u, hipSetDevice(u->device));
@@ -451,6 +559,8 @@ int psm_unet_profile(psm_unet* u, const float* d_grid, int32_t n_cases, float* d
       const int H = u->ny >> c.level, W = u->nx >> c.level;
       const int th = psm_conv_tile_rows(c.arrangement);
       wgs[i] = c.k == 3 ? ((W + 15) / 16) * ((H + th - 1) / th) * c.groups * c.ksplit * n_cases : 0;
+      if (c.pair == 1) wgs[i] = ((W + PSM_PAIR_TX - 1) / PSM_PAIR_TX) * ((H + PSM_PAIR_TY - 1) / PSM_PAIR_TY) * n_cases;
+      if (c.pair == 2) wgs[i] = 0;
     }
   }
   for (auto& e : ev) (void)hipEventDestroy(e);
@@ -467,11 +577,13 @@ int psm_unet_debug_run_layer(psm_unet* u, int32_t idx, float* stamps_us) {
   // run the whole network but only stamp-read after it: stamps are overwritten by every layer, so run up to idx
   const size_t n_all = u->convs.size();
   (void)n_all;
+  { unsigned long long z[64] = {0}; (void)z; }
   int rc = forward(u, u->d_in, u->last_cases, u->d_field, u->stream, nullptr, idx + 1);
   if (rc) return rc;
   UCHK(u, hipStreamSynchronize(u->stream));
   unsigned long long t[64];
-  UCHK(u, psm_unet_read_stamps(t));
+  if (u->convs[idx].pair == 1) UCHK(u, psm_unet_pair_read_stamps(t));       // 3 workgroups x 16 stamps (first, middle, last)
+  else UCHK(u, psm_unet_read_stamps(t));
   unsigned long long t0 = ~0ull;
   for (int k = 0; k < 64; ++k) if (t[k] && t[k] < t0) t0 = t[k];
   for (int k = 0; k < 64; ++k) stamps_us[k] = t[k] ? (float)((double)(t[k] - t0) * 0.01) : -1.f;

@@ -27,7 +27,7 @@ class UNetSurrogate:
     """weights: [(kernel[k,k,c_in,c_out] f32, bias[c_out] f32)] in the order enc0a, enc0b, ..., dec0a, dec0b, head."""
 
     def __init__(self, weights, ny: int, nx: int, c_in: int = 3, c_out: int = 1, widths: Sequence[int] = WIDTHS_S,
-                 max_cases: int = 1, device: int = 0, precision: str = "f32"):
+                 max_cases: int = 1, device: int = 0, precision: str = "f32", keep_activations: bool = False):
         self.lib = _lib.load()
         self.ny, self.nx, self.c_in, self.c_out, self.max_cases = int(ny), int(nx), int(c_in), int(c_out), int(max_cases)
         w = np.ascontiguousarray(widths, np.int32)
@@ -50,6 +50,8 @@ class UNetSurrogate:
                 self.shapes.append((k.value, ci.value, co.value))
                 self._chk(self.lib.psm_unet_set_conv(self.h, i, _p(_f32(W)), _p(_f32(b))))
             self._chk(self.lib.psm_unet_set_precision(self.h, _lib.PRECISIONS[precision]))
+            # bf16 mode keeps the inner activation of a fused level pair on chip; True stores it too (activation(i) of every layer)
+            self._chk(self.lib.psm_unet_keep_activations(self.h, 1 if keep_activations else 0))
             self._chk(self.lib.psm_unet_plan(self.h, self.ny, self.nx, self.max_cases))
         except Exception:
             self.close()

@@ -104,7 +104,7 @@ def test_gpu_unet_bf16_matches_bf16_oracle(ny, nx, n):
     specs = uo.unet_specs()
     W = uo.he_weights(specs, seed=11)
     grids = np.stack([synthetic.channel_grid(ny, nx, seed=20 + k).astype(np.float32) for k in range(n)])
-    with UNetSurrogate(W, ny, nx, max_cases=n, precision="bf16") as net:
+    with UNetSurrogate(W, ny, nx, max_cases=n, precision="bf16", keep_activations=True) as net:
         out = net.forward(grids)
         for k in range(n):
             ref, acts = uo.unet_forward(grids[k], W, return_all=True, precision="bf16")
@@ -115,6 +115,38 @@ def test_gpu_unet_bf16_matches_bf16_oracle(ny, nx, n):
             assert np.linalg.norm(out[k] - ref) / np.linalg.norm(ref) <= 1e-2
             f32 = uo.unet_forward(grids[k], W)
             assert np.linalg.norm(out[k] - f32) / np.linalg.norm(f32) <= 5e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ny,nx,n,keep", [(96, 160, 2, True), (64, 80, 3, True), (112, 240, 1, False), (256, 256, 2, False)])
+def test_gpu_unet_bf16_fused_level_pairs(ny, nx, n, keep, monkeypatch):
+    """bf16 mode, the two convolutions of a level in one launch (psm_unet_pair.hip; forced for every eligible level with
+    PSM_UNET_PAIR_MIN=1): image sizes that are not multiples of the 30 x 14 tile, several cases.  Same rounding points
+    as the unfused path, so the same bounds against the bf16 oracle.  Without keep_activations the inner activations are
+    never stored and asking for them is an error."""
+    from psm_amd import UNetSurrogate, _lib
+    monkeypatch.setenv("PSM_UNET_PAIR_MIN", "1")
+    monkeypatch.setenv("PSM_UNET_PAIR32", "1")                     # the 32-channel pair kernels too (off by default: not faster yet)
+    specs = uo.unet_specs()
+    W = uo.he_weights(specs, seed=13)
+    grids = np.stack([synthetic.channel_grid(ny, nx, seed=40 + k).astype(np.float32) for k in range(n)])
+    with UNetSurrogate(W, ny, nx, max_cases=n, precision="bf16", keep_activations=keep) as net:
+        out = net.forward(grids)
+        for k in range(n):
+            ref, acts = uo.unet_forward(grids[k], W, return_all=True, precision="bf16")
+            for i in range(len(specs) - 1):
+                if not keep and i in (0, 2, 14, 16, 17):           # enc0a, enc1a, dec1a, dec0a and dec0b (head fused) stay on chip
+                    with pytest.raises(_lib.PsmError):
+                        net.activation(i, n)
+                    continue
+                a = net.activation(i, n)[k]
+                err = np.linalg.norm(a - acts[i]) / max(np.linalg.norm(acts[i]), 1e-12)
+                assert err <= 1e-2, (specs[i].name, err)
+            assert np.linalg.norm(out[k] - ref) / np.linalg.norm(ref) <= 1e-2
+    monkeypatch.setenv("PSM_UNET_NO_PAIR", "1")                    # and the unfused path gives the same field to bf16 rounding flips
+    with UNetSurrogate(W, ny, nx, max_cases=n, precision="bf16") as net:
+        out2 = net.forward(grids)
+    assert np.linalg.norm(out - out2) / np.linalg.norm(out2) <= 1e-2
 
 
 def test_bf16_rounding_helper():
