@@ -108,7 +108,8 @@ constexpr int LOW_COLS = 17;                                                    
 constexpr int LOW_N = (IH / 2) * LOW_COLS * 4, LOW_ROUNDS = (LOW_N + 255) / 256;      // 612 pieces, 3 rounds
 constexpr int PL = 24;                                                                   // LDS pitch of the low-resolution tile (17 used)
 constexpr int LOW_BYTES = (IH / 2) * PL * 64;                                            // 13824
-__device__ __forceinline__ void low_issue(f32x4 (&v)[LOW_ROUNDS], unsigned& okmask, const unsigned short* src, int cpx, int cb,
+template <int NV>
+__device__ __forceinline__ void low_issue(f32x4 (&v)[NV][1], unsigned& okmask, const unsigned short* src, int cpx, int cb,
                                           int H, int W, int y0, int x0, int tid) {
   const int Hs = H / 2, Ws = W / 2, yl = (y0 - 2) / 2, xl = (x0 - 2) / 2;     // y0, x0 even: exact (also for -2)
   okmask = 0;
@@ -122,25 +123,26 @@ __device__ __forceinline__ void low_issue(f32x4 (&v)[LOW_ROUNDS], unsigned& okma
     const int r = pos / LOW_COLS, c = pos - r * LOW_COLS;
     const int y = yl + r, x = xl + c;
     okmask |= (y >= 0 && y < Hs && x >= 0 && x < Ws) ? (1u << u) : 0u;
-    v[u] = *reinterpret_cast<const f32x4*>(src + ((int64_t)min(max(y, 0), Hs - 1) * Ws + min(max(x, 0), Ws - 1)) * cpx + cb + 8 * g);
+    v[u][0] = *reinterpret_cast<const f32x4*>(src + ((int64_t)min(max(y, 0), Hs - 1) * Ws + min(max(x, 0), Ws - 1)) * cpx + cb + 8 * g);
   }
 }
-__device__ __forceinline__ void low_write(char* tile, const f32x4 (&v)[LOW_ROUNDS], unsigned okmask, int tid) {
+template <int NV>
+__device__ __forceinline__ void low_write(char* tile, const f32x4 (&v)[NV][1], unsigned okmask, int tid) {
 #if defined(PSM_PAIR_EXP) && (PSM_PAIR_EXP & 2)
   return;
 #endif
 #pragma unroll
   for (int u = 0; u < LOW_ROUNDS; ++u) {
     const int q = min(tid + 256 * u, LOW_N - 1);
-    f32x4 t = v[u];
+    f32x4 t = v[u][0];
     const bool ok = (okmask >> u) & 1u;
 #pragma unroll
     for (int j = 0; j < 4; ++j) t[j] = ok ? t[j] : 0.f;
     *reinterpret_cast<f32x4*>(tile + slot64(((q >> 2) / LOW_COLS) * PL + (q >> 2) % LOW_COLS, q & 3)) = t;
   }
 }
-template <int MODE, int CH, int B0, int NR>
-__device__ __forceinline__ void tile_issue(f32x4 (&v)[NR][MODE == 2 ? 4 : 1], unsigned& okmask, const unsigned short* src, int cpx, int cb,
+template <int MODE, int CH, int B0, int NR, int NV>
+__device__ __forceinline__ void tile_issue(f32x4 (&v)[NV][MODE == 2 ? 4 : 1], unsigned& okmask, const unsigned short* src, int cpx, int cb,
                                            int H, int W, int y0, int x0, int tid) {
   using T = TileGeom<CH>;
   const int Ws = MODE == 1 ? W / 2 : (MODE == 2 ? 2 * W : W);
@@ -169,8 +171,8 @@ __device__ __forceinline__ void tile_issue(f32x4 (&v)[NR][MODE == 2 ? 4 : 1], un
     }
   }
 }
-template <int MODE, int CH, int B0, int NR>
-__device__ __forceinline__ void tile_write(char* tile, const f32x4 (&v)[NR][MODE == 2 ? 4 : 1], unsigned okmask, int tid) {
+template <int MODE, int CH, int B0, int NR, int NV>
+__device__ __forceinline__ void tile_write(char* tile, const f32x4 (&v)[NV][MODE == 2 ? 4 : 1], unsigned okmask, int tid) {
   using T = TileGeom<CH>;
 #if defined(PSM_PAIR_EXP) && (PSM_PAIR_EXP & 2)
   return;
@@ -206,33 +208,35 @@ __device__ __forceinline__ void stage_tile(char* tile, const unsigned short* src
 // NX input rows and the 3 NT weight fragments are read from LDS one step ahead of the MFMAs that use them (two register
 // stages; nothing moves across the sched_barriers, so the live set stays at two stages).
 //   xload(s, i): operand of step s, input-row slot i;   wload(s, ky, nt): weight fragment;   HALF: slot of row j is j >> 1
-template <int NT, int R, int NX, int S, bool HALF, typename XLoad, typename WLoad>
+template <int NT, int R, int NX, int S, bool HALF, bool DB, typename XLoad, typename WLoad>
 __device__ __forceinline__ void conv_steps(XLoad xload, WLoad wload, f32x4 (&acc)[R][NT]) {
-  bf16x8 xb[2][NX], wb[2][3 * NT];
+  bf16x8 xb[DB ? 2 : 1][NX], wb[DB ? 2 : 1][3 * NT];
   auto load = [&](int s, int st) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) xb[st][i] = xload(s, i);
 #pragma unroll
     for (int k = 0; k < 3 * NT; ++k) wb[st][k] = wload(s, k / NT, k % NT);
   };
-  load(0, 0);
+  if (DB) load(0, 0);
 #pragma unroll
   for (int s = 0; s < S; ++s) {
-    if (s + 1 < S) load(s + 1, (s + 1) & 1);
+    if (DB) { if (s + 1 < S) load(s + 1, (s + 1) & 1); }
+    else load(s, 0);                     // one stage (register budget): the other wave of the SIMD covers the read latency
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int m = 0; m < R; ++m) acc[m][nt] = MFMA_BF(wb[s & 1][ky * NT + nt], xb[s & 1][HALF ? (m + ky) >> 1 : m + ky], acc[m][nt]);
+        for (int m = 0; m < R; ++m)
+          acc[m][nt] = MFMA_BF(wb[DB ? (s & 1) : 0][ky * NT + nt], xb[DB ? (s & 1) : 0][HALF ? (m + ky) >> 1 : m + ky], acc[m][nt]);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 // 32-channel chunk, 64-byte pixels (swizzled slots), pitch P32: step = tap column kx; fragments [kx][ky][nt]
 template <int NT, int R, typename WGet>
 __device__ __forceinline__ void conv32(const char* tile, int r0, int xcol, int kq, WGet wget, f32x4 (&acc)[R][NT]) {
-  conv_steps<NT, R, R + 2, 3, false>(
+  conv_steps<NT, R, R + 2, 3, false, NT == 1>(
       [&](int kx, int i) { return *reinterpret_cast<const bf16x8*>(tile + r0 * (P32 * 64) + slot64(xcol + kx, kq) + i * (P32 * 64)); },
       [&](int kx, int ky, int nt) { return wget((kx * 3 + ky) * NT + nt); }, acc);
 }
@@ -241,14 +245,14 @@ __device__ __forceinline__ void conv32(const char* tile, int r0, int xcol, int k
 template <int NT, int R, typename WGet>
 __device__ __forceinline__ void conv32_up(const char* tile, int r0, int xcol, int kq, WGet wget, f32x4 (&acc)[R][NT]) {
   static_assert((R & 1) == 0, "row pairs");
-  conv_steps<NT, R, (R + 2) / 2, 3, true>(
+  conv_steps<NT, R, (R + 2) / 2, 3, true, NT == 1>(
       [&](int kx, int i) { return *reinterpret_cast<const bf16x8*>(tile + (r0 >> 1) * (PL * 64) + slot64((xcol + kx) >> 1, kq) + i * (PL * 64)); },
       [&](int kx, int ky, int nt) { return wget((kx * 3 + ky) * NT + nt); }, acc);
 }
 // 16-channel chunk, 32-byte pixels, pitch P16: step = tap pair (kx = 2s, 2s + 1); fragments [s][ky][nt]
 template <int NT, int R, typename WGet>
 __device__ __forceinline__ void conv16(const char* tile, int r0, int xcol, int kq, WGet wget, f32x4 (&acc)[R][NT]) {
-  conv_steps<NT, R, R + 2, 2, false>(
+  conv_steps<NT, R, R + 2, 2, false, NT == 1>(
       [&](int s, int i) { return *reinterpret_cast<const bf16x8*>(tile + ((r0 + i) * P16 + xcol + 2 * s) * 32 + kq * 16); },
       [&](int s, int ky, int nt) { return wget((s * 3 + ky) * NT + nt); }, acc);
 }
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(256, 2) void psm_pair_up16_kernel(PsmPairArgs a) {
   load_head(a, headw, tid);
   zero_mid_pad16(mid, tid);
   const bf16x8* wf = wl + lane;
-  f32x4 vlo[LOW_ROUNDS], v16[5][1];
+  f32x4 vlo[LOW_ROUNDS][1], v16[5][1];
   unsigned oklo, ok16;
   auto issue = [&](const TilePos& t, int tz) {
     low_issue(vlo, oklo, reinterpret_cast<const unsigned short*>(a.in0) + (int64_t)t.cs * a.in0_case, 32, 0, a.H, a.W, t.y0, t.x0, tz);
@@ -555,33 +559,53 @@ __global__ __launch_bounds__(256, 2) void psm_pair_up16_kernel(PsmPairArgs a) {
 //   KIND 2: max-pool (c0 a multiple of 16);  KIND 1: upsample ++ skip (c0 a multiple of 32, c1 a multiple of 16)
 // ====================================================================================================================
 constexpr int W32_BYTES = 18 * 1024;                     // weight fragments of one 32-channel chunk, two channel tiles
-constexpr int PAIR32_LDS = T32_BYTES + W32_BYTES;        // 57600 >= M32_BYTES + W32_BYTES
+constexpr int PAIR32_LDS = T32_BYTES + W32_BYTES;        // 64512 >= M32_BYTES + W32_BYTES
 static_assert(P32 % 8 == 0 && PL % 8 == 0, "slot swizzle by column only");
 static_assert(M32_BYTES + W32_BYTES <= PAIR32_LDS, "overlay");
+static_assert(LOW_BYTES <= T32_BYTES && T16_BYTES <= T32_BYTES, "one staging area for every chunk form");
+constexpr int WROUNDS = 5;                               // 18 fragments x 64 pieces / 256 threads, rounded up
 
-__device__ __forceinline__ void stage_weights(char* dst, const uint4* src, int n16, int tid) {      // n16 16-byte pieces
-  for (int i = tid; i < n16; i += 256) reinterpret_cast<uint4*>(dst)[i] = src[i];
-}
+// chunk forms of conv A
+enum { CK_UP32 = 0, CK_SAME32 = 1, CK_SAME16 = 2, CK_POOL32 = 3, CK_POOL16 = 4, CK_NONE = 5 };
+struct Chunk { int form, cb; };                          // form, first channel within its source
 
 template <int KIND, bool KEEP>
 __global__ __launch_bounds__(256, 2) void psm_pair32_kernel(PsmPairArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[PAIR32_LDS];
   char* tile = lds;
   char* wl = lds + T32_BYTES;
+  char* mid = lds;                                         // overlays the staging area once conv A is done with it
+  char* wbl = lds + M32_BYTES;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int px = lane & 15, kq = lane >> 4, xh = wave & 1;
   const int total = a.tiles_x * a.tiles_y * a.n_cases;
   constexpr int RA = MH / 2, RB = TY / 2;
   const int rA = RA * (wave >> 1), rB = RB * (wave >> 1);
-  f32x4 bA[2], bB[2];
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    bA[nt] = *reinterpret_cast<const f32x4*>(a.biasA + 16 * nt + 4 * kq);
-    bB[nt] = *reinterpret_cast<const f32x4*>(a.biasB + 16 * nt + 4 * kq);
-  }
   const bf16x8* wfrag = reinterpret_cast<const bf16x8*>(wl) + lane;
   auto wget = [&](int i) { return wfrag[i * 64]; };
+  // Chunk order: the skip input first (its ten staging rounds are not prefetched -- at the start of a tile there is nothing
+  // to hide them behind), then the upsample source, whose chunks (three rounds at its own resolution) are requested during
+  // the previous chunk's MFMAs.  Fragment offsets follow pack_pair's order (in0's chunks, then in1's).
+  const int n0 = (a.c0 + 31) / 32, n1 = KIND == 1 ? (a.c1 + 31) / 32 : 0;
+  const int frag0 = 18 * (a.c0 / 32) + 12 * ((a.c0 % 32) != 0);        // fragments of in0's chunks
+  auto chunk_at = [&](int ci) -> Chunk {                    // ci-th chunk in execution order (uniform)
+    if (ci < n1) { const int cb = 32 * ci; return {a.c1 - cb >= 32 ? CK_SAME32 : CK_SAME16, cb}; }
+    if (ci < n1 + n0) {
+      const int cb = 32 * (ci - n1);
+      return {KIND == 1 ? CK_UP32 : (a.c0 - cb >= 32 ? CK_POOL32 : CK_POOL16), cb};
+    }
+    return {CK_NONE, 0};
+  };
+  auto frag_of = [&](const Chunk& c) {                      // first fragment of the chunk in a.wA
+    const bool second = c.form == CK_SAME32 || c.form == CK_SAME16;
+    return (second ? frag0 : 0) + 18 * (c.cb / 32);
+  };
+  auto frags_in = [](int form) { return (form == CK_SAME16 || form == CK_POOL16) ? 12 : 18; };
+
+  f32x4 pf[LOW_ROUNDS][1];                                  // prefetched pieces of an upsample-source chunk
+  uint4 pw[WROUNDS];                                        // prefetched weight fragments
+  unsigned pok = 0;
   for (int it = 0;; ++it) {
     const int tl = tile_of(it, total);
     if (tl < 0) break;
@@ -589,48 +613,75 @@ __global__ __launch_bounds__(256, 2) void psm_pair32_kernel(PsmPairArgs a) {
     const int y0 = t.y0, x0 = t.x0;
     const unsigned short* in0 = reinterpret_cast<const unsigned short*>(a.in0) + (int64_t)t.cs * a.in0_case;
     const unsigned short* in1 = reinterpret_cast<const unsigned short*>(a.in1) + (int64_t)t.cs * a.in1_case;
+    int tz = tid;                                             // opaque copy, refreshed where it is used: the staging positions are
+    asm volatile("" : "+v"(tz));                              // recomputed there instead of living in registers across the MFMAs
+    auto issue_w = [&](const uint4* src, int nfrag) {
+#pragma unroll
+      for (int u = 0; u < WROUNDS; ++u) pw[u] = src[min(tz + 256 * u, nfrag * 64 - 1)];
+    };
+    auto write_w = [&](char* dst, int nfrag) {
+#pragma unroll
+      for (int u = 0; u < WROUNDS; ++u) reinterpret_cast<uint4*>(dst)[min(tz + 256 * u, nfrag * 64 - 1)] = pw[u];
+    };
     f32x4 acc[RA][2];
 #pragma unroll
     for (int m = 0; m < RA; ++m) { acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    const uint4* wsrc = a.wA;
-    // chunks of in0, then of in1: 32 channels each while they last, then one of 16
-    for (int part = 0; part < (KIND == 1 ? 2 : 1); ++part) {
-      const int cn = part == 0 ? a.c0 : a.c1;
-      for (int cb = 0; cb < cn; cb += 32) {
-        const bool full = cn - cb >= 32;                       // uniform
-        __syncthreads();                                       // the previous chunk's (tile's) operands are no longer being read
-        if (full) {
-          if (KIND == 2) stage_tile<2, 32>(tile, in0, a.c0, cb, a.H, a.W, y0, x0, tid);
-          else if (part == 0) stage_tile<1, 32>(tile, in0, a.c0, cb, a.H, a.W, y0, x0, tid);
-          else stage_tile<0, 32>(tile, in1, a.c1, cb, a.H, a.W, y0, x0, tid);
-          stage_weights(wl, wsrc, 18 * 64, tid);
-          wsrc += 18 * 64;
-        } else {
-          if (KIND == 2) stage_tile<2, 16>(tile, in0, a.c0, cb, a.H, a.W, y0, x0, tid);
-          else if (part == 0) stage_tile<1, 16>(tile, in0, a.c0, cb, a.H, a.W, y0, x0, tid);
-          else stage_tile<0, 16>(tile, in1, a.c1, cb, a.H, a.W, y0, x0, tid);
-          stage_weights(wl, wsrc, 12 * 64, tid);
-          wsrc += 12 * 64;
-        }
-        __syncthreads();
-        if (full) conv32<2, RA>(tile, rA, 16 * xh + px, kq, wget, acc);
-        else conv16<2, RA>(tile, rA, 16 * xh + px, kq, wget, acc);
-      }
+#ifdef PSM_STAMPS
+    const int g_it = 0;
+    int sk = 0;
+#define PSTAMP32() do { PSTAMP(sk); ++sk; } while (0)
+#else
+#define PSTAMP32() do { } while (0)
+#endif
+    PSTAMP32();
+    Chunk cur = chunk_at(0);
+    issue_w(a.wA + frag_of(cur) * 64, frags_in(cur.form));
+    if (cur.form == CK_UP32) low_issue(pf, pok, in0, a.c0, cur.cb, a.H, a.W, y0, x0, tz);
+    for (int ci = 0; cur.form != CK_NONE; ++ci) {
+      lds_barrier();                                         // the previous chunk's (tile's) operands are no longer being read
+      asm volatile("" : "+v"(tz));
+      if (cur.form == CK_UP32) low_write(tile, pf, pok, tz);
+      else if (cur.form == CK_SAME32) stage_tile<0, 32>(tile, in1, a.c1, cur.cb, a.H, a.W, y0, x0, tz);
+      else if (cur.form == CK_SAME16) stage_tile<0, 16>(tile, in1, a.c1, cur.cb, a.H, a.W, y0, x0, tz);
+      else if (cur.form == CK_POOL32) stage_tile<2, 32>(tile, in0, a.c0, cur.cb, a.H, a.W, y0, x0, tz);
+      else stage_tile<2, 16>(tile, in0, a.c0, cur.cb, a.H, a.W, y0, x0, tz);
+      write_w(wl, frags_in(cur.form));
+      PSTAMP32();
+      lds_barrier();
+      PSTAMP32();
+      const Chunk nxt = chunk_at(ci + 1);
+      asm volatile("" : "+v"(tz));
+      if (nxt.form == CK_UP32) low_issue(pf, pok, in0, a.c0, nxt.cb, a.H, a.W, y0, x0, tz);      // in flight during this chunk's MFMAs
+      if (nxt.form != CK_NONE) issue_w(a.wA + frag_of(nxt) * 64, frags_in(nxt.form)); else issue_w(a.wB, 18);
+      if (cur.form == CK_UP32) conv32_up<2, RA>(tile, rA, 16 * xh + px, kq, wget, acc);
+      else if (cur.form == CK_SAME32 || cur.form == CK_POOL32) conv32<2, RA>(tile, rA, 16 * xh + px, kq, wget, acc);
+      else conv16<2, RA>(tile, rA, 16 * xh + px, kq, wget, acc);
+      PSTAMP32();
+      cur = nxt;
     }
-    __syncthreads();                                           // every wave is done with the staging area: the mid tile goes over it
-    char* mid = lds;
-    char* wbl = lds + M32_BYTES;
+    f32x4 bA[2], bB[2];                                      // requested here: they land during the barrier and the first epilogue rows
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      bA[nt] = *reinterpret_cast<const f32x4*>(a.biasA + 16 * nt + 4 * kq);
+      bB[nt] = *reinterpret_cast<const f32x4*>(a.biasB + 16 * nt + 4 * kq);
+    }
+    lds_barrier();                                           // every wave is done with the staging area: the mid tile goes over it
+    asm volatile("" : "+v"(tz));
     mid_epilogue<2, RA, KEEP>(a, mid, t.cs, y0, x0, rA, xh, lane, bA, acc);
     zero_mid_pad32(mid, tid);
-    stage_weights(wbl, a.wB, 18 * 64, tid);
-    __syncthreads();
+    write_w(wbl, 18);
+    PSTAMP32();
+    lds_barrier();
+    PSTAMP32();
     {
       f32x4 accb[RB][2];
 #pragma unroll
       for (int m = 0; m < RB; ++m) { accb[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; accb[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
       const bf16x8* wbf = reinterpret_cast<const bf16x8*>(wbl) + lane;
       conv32<2, RB>(mid, rB, 16 * xh + px, kq, [&](int i) { return wbf[i * 64]; }, accb);
+      PSTAMP32();
       out_epilogue<2, RB, true, false>(a, t.cs, y0, x0, rB, xh, lane, bB, nullptr, accb);
+      PSTAMP32();
     }
   }
 }

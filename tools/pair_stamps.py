@@ -15,6 +15,9 @@ with UNetSurrogate(W, 256, 256, max_cases=n, precision="bf16") as net:
             net._chk(net.lib.psm_unet_debug_run_layer(net.h, idx, st.ctypes.data_as(C.POINTER(C.c_float))))
             acc.append(st)
         st = np.median(np.array(acc), axis=0)
+        if len(sys.argv) > 2 and idx in (2, 14):       # 32-channel pair: raw stamp list of the first tile
+            print(f"layer {idx}:", " ".join(f"{v:6.2f}" for v in st[:24] if v >= 0))
+            continue
         for it in range(7):
             if st[9 * it] < 0:
                 break
