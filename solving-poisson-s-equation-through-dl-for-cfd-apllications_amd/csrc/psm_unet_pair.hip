@@ -23,6 +23,7 @@
 #include "psm_unet.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 // Diagnostic stamps (100 MHz wall clock) of the first, the middle and the last workgroup -- compiled only with -DPSM_STAMPS.
 #ifdef PSM_STAMPS
@@ -83,125 +84,123 @@ __device__ __forceinline__ f32x4 bf16x8_max(f32x4 a, f32x4 b) {
   return __builtin_bit_cast(f32x4, r);
 }
 
+// four floats -> four bf16 (RNE): two v_cvt_pk_bf16_f32 (element-wise scalar conversions compile to four plus two v_perm)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u32x2 pack4(f32x4 v) {
-  bf16x4 h;
-  h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
-  return __builtin_bit_cast(u32x2, h);
+  const f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+  u32x2 r;
+  r[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2));
+  r[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(b, bf16x2));
+  return r;
 }
 
-// ---- staging: a chunk of CH channels of the (IH x pitch) input tile, from a bf16 NHWC source through MODE -------------
-//   MODE 0: same resolution (the skip input)      src [H][W][cpx]
-//   MODE 1: 2x nearest-neighbour upsample         src [H/2][W/2][cpx]
-//   MODE 2: 2x2 max-pool                          src [2H][2W][cpx]
-// tile_issue requests rounds [B0, B0 + NR) of the chunk (clamped addresses, nothing depends on the data), tile_write
-// combines (2x2 max), zeroes what lies outside the image and stores to LDS.  The persistent kernels issue the NEXT tile's
-// requests before the current tile's MFMAs and write them when the current tile no longer needs its LDS buffers.
-template <int CH> struct TileGeom {
-  static constexpr int PITCH = CH == 32 ? P32 : P16;             // LDS pitch
-  static constexpr int COLS = CH == 32 ? 34 : P16;               // staged columns
-  static constexpr int G = CH / 8;
-  static constexpr int N = COLS * IH * G;
-  static constexpr int ROUNDS = (N + 255) / 256;                 // 10 (32 channels) / 5 (16 channels)
-};
-// the upsample source at its own resolution: (IH/2) x (P32/2) low-resolution pixels of 32 channels (tile origins are even)
-constexpr int LOW_COLS = 17;                                                             // (34 + 0) / 2 low-resolution columns
-constexpr int LOW_N = (IH / 2) * LOW_COLS * 4, LOW_ROUNDS = (LOW_N + 255) / 256;      // 612 pieces, 3 rounds
-constexpr int PL = 24;                                                                   // LDS pitch of the low-resolution tile (17 used)
-constexpr int LOW_BYTES = (IH / 2) * PL * 64;                                            // 13824
-template <int NV>
-__device__ __forceinline__ void low_issue(f32x4 (&v)[NV][1], unsigned& okmask, const unsigned short* src, int cpx, int cb,
-                                          int H, int W, int y0, int x0, int tid) {
-  const int Hs = H / 2, Ws = W / 2, yl = (y0 - 2) / 2, xl = (x0 - 2) / 2;     // y0, x0 even: exact (also for -2)
-  okmask = 0;
-#if defined(PSM_PAIR_EXP) && (PSM_PAIR_EXP & 2)
-  return;
-#endif
-#pragma unroll
-  for (int u = 0; u < LOW_ROUNDS; ++u) {
-    const int q = min(tid + 256 * u, LOW_N - 1);
-    const int pos = q >> 2, g = q & 3;
-    const int r = pos / LOW_COLS, c = pos - r * LOW_COLS;
-    const int y = yl + r, x = xl + c;
-    okmask |= (y >= 0 && y < Hs && x >= 0 && x < Ws) ? (1u << u) : 0u;
-    v[u][0] = *reinterpret_cast<const f32x4*>(src + ((int64_t)min(max(y, 0), Hs - 1) * Ws + min(max(x, 0), Ws - 1)) * cpx + cb + 8 * g);
+// ---- staging, row-wise --------------------------------------------------------------------------------------------
+// A wave64 vector instruction costs 4 issue cycles, so the address arithmetic of the staging is what these kernels spend
+// their non-MFMA time on.  The mapping keeps it to a handful of instructions per tile: wave w stages tile rows w, w + 4,
+// ... (the row is wave-uniform: row pointer, row validity and the LDS row offset are scalar), and a lane keeps ONE column
+// position per instruction slot (computed once per tile): PPI = 64 / G pixels per instruction, KM instructions per row
+// for the first MAINPX columns; the few remaining columns of all rows ("side block") are one more instruction over the
+// workgroup's 256 threads.  The LDS layout is the one the convolutions read, whatever the mapping.
+//   PXB: bytes per LDS pixel (32: 16 channels, unswizzled; 64: 32 channels, swizzled slots);  NCOL x NROW staged pixels;
+//   NQ = 4: the source has twice the resolution and the piece is the element-wise maximum of its 2x2 pixels (max-pool).
+// issue(): requests only (clamped addresses), ok = which pieces lie inside the image;  write(): combine, zero, store.
+template <int PXB, int NCOL, int NROW, int PITCH, int NQ>
+struct Stage {
+  static constexpr int G = PXB / 16, PPI = 64 / G, MAINPX = (NCOL / PPI) * PPI, KM = MAINPX / PPI, RW = (NROW + 3) / 4;
+  static constexpr int SIDEW = NCOL - MAINPX, NSIDE = SIDEW * G * NROW, NP = RW * KM + (NSIDE > 0 ? 1 : 0);
+  static_assert(NSIDE <= 256 && NP <= 16, "one side instruction, ok bits in 16");
+  static __device__ __forceinline__ int lds_off(int r, int c, int g) {
+    return PXB == 64 ? r * (PITCH * 64) + slot64(c, g) : (r * PITCH + c) * 32 + g * 16;
   }
-}
-template <int NV>
-__device__ __forceinline__ void low_write(char* tile, const f32x4 (&v)[NV][1], unsigned okmask, int tid) {
+  // src: the case's source image, Hs x Ws pixels of cpx channels (NQ = 4: 2Hs x 2Ws); (ys0, xs0): source pixel of tile (0, 0)
+  // J0, JN: the row iterations of this call (registers: a max-pool chunk is staged in two halves); SIDE: with the side block
+  template <int J0 = 0, int JN = RW, bool SIDE = (NSIDE > 0)>
+  static __device__ __forceinline__ void issue(f32x4 (&v)[JN * KM + (SIDE ? 1 : 0)][NQ], unsigned& ok, const unsigned short* src, int cpx, int cb,
+                                               int Hs, int Ws, int ys0, int xs0, int wave, int lane, int tid) {
+    constexpr int NV = JN * KM + (SIDE ? 1 : 0);
+    ok = 0;
 #if defined(PSM_PAIR_EXP) && (PSM_PAIR_EXP & 2)
-  return;
+    return;
 #endif
+    const int M = NQ == 4 ? 2 : 1;                           // source pixels per tile pixel and direction
+    const int64_t row_bytes = (int64_t)M * Ws * cpx * 2;     // one source row
+    unsigned xoff[KM];
+    unsigned xok = 0;
 #pragma unroll
-  for (int u = 0; u < LOW_ROUNDS; ++u) {
-    const int q = min(tid + 256 * u, LOW_N - 1);
-    f32x4 t = v[u][0];
-    const bool ok = (okmask >> u) & 1u;
+    for (int k = 0; k < KM; ++k) {
+      const int c = PPI * k + lane / G, g = lane % G, x = xs0 + c;
+      xok |= (x >= 0 && x < Ws) ? (1u << k) : 0u;
+      xoff[k] = (unsigned)((M * min(max(x, 0), Ws - 1) * cpx + cb + 8 * g) * 2);
+    }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) t[j] = ok ? t[j] : 0.f;
-    *reinterpret_cast<f32x4*>(tile + slot64(((q >> 2) / LOW_COLS) * PL + (q >> 2) % LOW_COLS, q & 3)) = t;
-  }
-}
-template <int MODE, int CH, int B0, int NR, int NV>
-__device__ __forceinline__ void tile_issue(f32x4 (&v)[NV][MODE == 2 ? 4 : 1], unsigned& okmask, const unsigned short* src, int cpx, int cb,
-                                           int H, int W, int y0, int x0, int tid) {
-  using T = TileGeom<CH>;
-  const int Ws = MODE == 1 ? W / 2 : (MODE == 2 ? 2 * W : W);
-  okmask = 0;
-#if defined(PSM_PAIR_EXP) && (PSM_PAIR_EXP & 2)
-  return;
-#endif
+    for (int jj = 0; jj < JN; ++jj) {
+      const int j = jj, r = min(wave + 4 * (J0 + jj), NROW - 1), y = ys0 + r;          // uniform
+      const bool yok = y >= 0 && y < Hs;
+      const char* rowp = reinterpret_cast<const char*>(src) + (int64_t)(M * min(max(y, 0), Hs - 1)) * row_bytes;
 #pragma unroll
-  for (int u = 0; u < NR; ++u) {
-    const int q = min(tid + 256 * (B0 + u), T::N - 1);          // surplus threads repeat the last piece (same value, same place)
-    const int pos = q / T::G, g = q - pos * T::G;
-    const int r = pos / T::COLS, c = pos - r * T::COLS;
-    const int y = y0 - 2 + r, x = x0 - 2 + c;
-    okmask |= (y >= 0 && y < H && x >= 0 && x < W) ? (1u << u) : 0u;
-    const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
-    if (MODE == 2) {
-      const unsigned short* p = src + ((int64_t)(2 * yc) * Ws + 2 * xc) * cpx + cb + 8 * g;
-      v[u][0] = *reinterpret_cast<const f32x4*>(p);
-      v[u][MODE == 2 ? 1 : 0] = *reinterpret_cast<const f32x4*>(p + cpx);
-      v[u][MODE == 2 ? 2 : 0] = *reinterpret_cast<const f32x4*>(p + (int64_t)Ws * cpx);
-      v[u][MODE == 2 ? 3 : 0] = *reinterpret_cast<const f32x4*>(p + (int64_t)Ws * cpx + cpx);
-    } else if (MODE == 1) {
-      v[u][0] = *reinterpret_cast<const f32x4*>(src + ((int64_t)(yc >> 1) * Ws + (xc >> 1)) * cpx + cb + 8 * g);
-    } else {
-      v[u][0] = *reinterpret_cast<const f32x4*>(src + ((int64_t)yc * Ws + xc) * cpx + cb + 8 * g);
+      for (int k = 0; k < KM; ++k) {
+        const char* q = rowp + xoff[k];
+        v[j * KM + k][0] = *reinterpret_cast<const f32x4*>(q);
+        if (NQ == 4) {
+          v[j * KM + k][NQ == 4 ? 1 : 0] = *reinterpret_cast<const f32x4*>(q + cpx * 2);
+          v[j * KM + k][NQ == 4 ? 2 : 0] = *reinterpret_cast<const f32x4*>(q + row_bytes);
+          v[j * KM + k][NQ == 4 ? 3 : 0] = *reinterpret_cast<const f32x4*>(q + row_bytes + cpx * 2);
+        }
+        ok |= (yok && ((xok >> k) & 1u)) ? (1u << (j * KM + k)) : 0u;
+      }
+    }
+    if (SIDE) {
+      const int q = min(tid, NSIDE - 1), r = q / (SIDEW * G), rem = q - r * (SIDEW * G), c = MAINPX + rem / G, g = rem % G;
+      const int y = ys0 + r, x = xs0 + c;
+      ok |= (y >= 0 && y < Hs && x >= 0 && x < Ws) ? (1u << (NV - 1)) : 0u;
+      const char* qp = reinterpret_cast<const char*>(src) + (int64_t)(M * min(max(y, 0), Hs - 1)) * row_bytes +
+                       (M * min(max(x, 0), Ws - 1) * cpx + cb + 8 * g) * 2;
+      v[NV - 1][0] = *reinterpret_cast<const f32x4*>(qp);
+      if (NQ == 4) {
+        v[NV - 1][NQ == 4 ? 1 : 0] = *reinterpret_cast<const f32x4*>(qp + cpx * 2);
+        v[NV - 1][NQ == 4 ? 2 : 0] = *reinterpret_cast<const f32x4*>(qp + row_bytes);
+        v[NV - 1][NQ == 4 ? 3 : 0] = *reinterpret_cast<const f32x4*>(qp + row_bytes + cpx * 2);
+      }
     }
   }
-}
-template <int MODE, int CH, int B0, int NR, int NV>
-__device__ __forceinline__ void tile_write(char* tile, const f32x4 (&v)[NV][MODE == 2 ? 4 : 1], unsigned okmask, int tid) {
-  using T = TileGeom<CH>;
+  // interior (uniform): every staged pixel lies inside the image -- no selects
+  template <int J0 = 0, int JN = RW, bool SIDE = (NSIDE > 0)>
+  static __device__ __forceinline__ void write(char* tile, const f32x4 (&v)[JN * KM + (SIDE ? 1 : 0)][NQ], unsigned ok, bool interior, int wave, int lane, int tid) {
+    constexpr int NV = JN * KM + (SIDE ? 1 : 0);
 #if defined(PSM_PAIR_EXP) && (PSM_PAIR_EXP & 2)
-  return;
+    return;
 #endif
+    auto piece = [&](int i) {
+      f32x4 t = v[i][0];
+      if (NQ == 4) t = bf16x8_max(bf16x8_max(v[i][0], v[i][NQ == 4 ? 1 : 0]), bf16x8_max(v[i][NQ == 4 ? 2 : 0], v[i][NQ == 4 ? 3 : 0]));
+      if (!interior) {
+        const bool in = (ok >> i) & 1u;
 #pragma unroll
-  for (int u = 0; u < NR; ++u) {
-    const int q = min(tid + 256 * (B0 + u), T::N - 1);
-    const int pc = q / T::G, g = q - pc * T::G;
-    const int pos = (pc / T::COLS) * T::PITCH + pc % T::COLS;
-    f32x4 t = v[u][0];
-    if (MODE == 2) t = bf16x8_max(bf16x8_max(v[u][0], v[u][MODE == 2 ? 1 : 0]), bf16x8_max(v[u][MODE == 2 ? 2 : 0], v[u][MODE == 2 ? 3 : 0]));
-    const bool ok = (okmask >> u) & 1u;
+        for (int e = 0; e < 4; ++e) t[e] = in ? t[e] : 0.f;
+      }
+      return t;
+    };
 #pragma unroll
-    for (int j = 0; j < 4; ++j) t[j] = ok ? t[j] : 0.f;
-    *reinterpret_cast<f32x4*>(tile + (CH == 32 ? slot64(pos, g) : pos * 32 + g * 16)) = t;
+    for (int j = 0; j < JN; ++j) {
+      const int r = min(wave + 4 * (J0 + j), NROW - 1);
+#pragma unroll
+      for (int k = 0; k < KM; ++k)
+        *reinterpret_cast<f32x4*>(tile + lds_off(r, PPI * k + lane / G, lane % G)) = piece(j * KM + k);
+    }
+    if (SIDE) {
+      const int q = min(tid, NSIDE - 1), r = q / (SIDEW * G), rem = q - r * (SIDEW * G);
+      *reinterpret_cast<f32x4*>(tile + lds_off(r, MAINPX + rem / G, rem % G)) = piece(NV - 1);
+    }
   }
-}
-// request + write of a whole chunk, five rounds at a time (register budget of the chunked kernel)
-template <int MODE, int CH>
-__device__ __forceinline__ void stage_tile(char* tile, const unsigned short* src, int cpx, int cb, int H, int W, int y0, int x0, int tid) {
-  f32x4 v[5][MODE == 2 ? 4 : 1];
-  unsigned ok;
-  tile_issue<MODE, CH, 0, 5>(v, ok, src, cpx, cb, H, W, y0, x0, tid);
-  tile_write<MODE, CH, 0, 5>(tile, v, ok, tid);
-  if constexpr (TileGeom<CH>::ROUNDS > 5) {
-    tile_issue<MODE, CH, 5, 5>(v, ok, src, cpx, cb, H, W, y0, x0, tid);
-    tile_write<MODE, CH, 5, 5>(tile, v, ok, tid);
-  }
-}
+};
+constexpr int PL = 24;                                    // LDS pitch of the low-resolution tile (17 used)
+constexpr int LOW_BYTES = (IH / 2) * PL * 64;             // 13824
+typedef Stage<64, 17, IH / 2, PL, 1> StLow;               // upsample source at its own resolution, 32 channels (tile origins are even)
+typedef Stage<32, P16, IH, P16, 1> St16;                  // 16 channels, same resolution
+typedef Stage<64, 34, IH, P32, 1> St32;                   // 32 channels, same resolution
+typedef Stage<32, P16, IH, P16, 4> StPool16;              // 16 channels through the 2x2 max-pool
+typedef Stage<64, 34, IH, P32, 4> StPool32;               // 32 channels through the 2x2 max-pool
 
 // ---- one chunk of a convolution on an LDS tile --------------------------------------------------------------------
 // acc[m][nt]: row r0 + m, channel tile nt of the wave's 16-pixel half.  A chunk is S steps (tap columns); per step the
@@ -250,110 +249,11 @@ __device__ __forceinline__ void conv32_up(const char* tile, int r0, int xcol, in
       [&](int kx, int ky, int nt) { return wget((kx * 3 + ky) * NT + nt); }, acc);
 }
 // 16-channel chunk, 32-byte pixels, pitch P16: step = tap pair (kx = 2s, 2s + 1); fragments [s][ky][nt]
-template <int NT, int R, typename WGet>
+template <int NT, int R, bool DB = (NT == 1), typename WGet>
 __device__ __forceinline__ void conv16(const char* tile, int r0, int xcol, int kq, WGet wget, f32x4 (&acc)[R][NT]) {
-  conv_steps<NT, R, R + 2, 2, false, NT == 1>(
+  conv_steps<NT, R, R + 2, 2, false, DB>(
       [&](int s, int i) { return *reinterpret_cast<const bf16x8*>(tile + ((r0 + i) * P16 + xcol + 2 * s) * 32 + kq * 16); },
       [&](int s, int ky, int nt) { return wget((s * 3 + ky) * NT + nt); }, acc);
-}
-
-// ---- conv A's epilogue: bias + ReLU, zero outside the image, bf16 into the mid tile (LDS) --------------------------
-// b[nt]: the lane's four bias values (channels 16 nt + 4 (lane >> 4) ..), loaded at kernel start
-// KEEP (introspection builds of the launch): the activation is stored to HBM as well, every pixel by the tile that owns it
-template <int NT, int R, bool KEEP>
-__device__ __forceinline__ void mid_epilogue(const PsmPairArgs& a, char* mid, int cs, int y0, int x0, int r0, int xh, int lane,
-                                             const f32x4 (&b)[NT], f32x4 (&acc)[R][NT]) {
-  const int px = lane & 15, kq = lane >> 4;
-  const int col = 16 * xh + px, x = x0 - 1 + col;
-  const bool xok = x >= 0 && x < a.W;
-#pragma unroll
-  for (int m = 0; m < R; ++m) {
-    const int mr = r0 + m, y = y0 - 1 + mr;
-    const bool ok = xok && y >= 0 && y < a.H;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      f32x4 v = acc[m][nt] + b[nt];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = ok ? fmaxf(v[j], 0.f) : 0.f;
-      const u32x2 h = pack4(v);
-      if (NT == 1) *reinterpret_cast<u32x2*>(mid + (mr * P16 + col) * 32 + kq * 8) = h;
-      else *reinterpret_cast<u32x2*>(mid + slot64(mr * P32 + col, 2 * nt + (kq >> 1)) + (kq & 1) * 8) = h;
-      if (KEEP && ok && mr >= 1 && mr <= TY && col >= 1 && col <= TX)
-        *reinterpret_cast<u32x2*>(a.mid_out + (int64_t)cs * a.out_case + ((int64_t)y * a.W + x) * (16 * NT) + 16 * nt + 4 * kq) = h;
-    }
-  }
-}
-
-// ---- conv B's epilogue: bias + ReLU, bf16 NHWC store (STORE), fused linear 1x1 head (HEAD) --------------------------
-// headw (LDS): [16][head_cout] weights, then head_cout biases at [256].  The head sums a pixel's 16 channels: four in the
-// lane, then across the four lanes l, l ^ 16, l ^ 32, l ^ 48 with v_permlane32_swap / v_permlane16_swap (no LDS round trip)
-__device__ __forceinline__ float sum_lane_groups(float s) {
-  typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
-  const u32x2v p = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
-  const float t = __uint_as_float(p[0]) + __uint_as_float(p[1]);
-  const u32x2v q = __builtin_amdgcn_permlane16_swap(__float_as_uint(t), __float_as_uint(t), false, false);
-  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
-}
-template <int NT, int R, bool STORE, bool HEAD>
-__device__ __forceinline__ void out_epilogue(const PsmPairArgs& a, int cs, int y0, int x0, int r0, int xh, int lane,
-                                             const f32x4 (&b)[NT], const float* headw, f32x4 (&acc)[R][NT]) {
-  static_assert(!HEAD || NT == 1, "the fused head reads one channel tile");
-  const int px = lane & 15, kq = lane >> 4;
-  const int col = 16 * xh + px, x = x0 + col;
-  const bool xok = col < TX && x < a.W;
-#pragma unroll
-  for (int m = 0; m < R; ++m) {
-    const int y = y0 + r0 + m;
-    const bool ok = xok && y < a.H;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      f32x4 v = acc[m][nt] + b[nt];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-      acc[m][nt] = v;
-      if (STORE && ok)
-        *reinterpret_cast<u32x2*>(a.out + (int64_t)cs * a.out_case + ((int64_t)y * a.W + x) * (16 * NT) + 16 * nt + 4 * kq) = pack4(v);
-    }
-  }
-  if constexpr (HEAD) {
-    for (int o = 0; o < a.head_cout; ++o) {
-      f32x4 hw;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) hw[j] = headw[(4 * kq + j) * a.head_cout + o];
-      const float hb = headw[256 + o];
-      float s[R];
-#pragma unroll
-      for (int m = 0; m < R; ++m) {
-        const f32x4 v = acc[m][0];
-        s[m] = sum_lane_groups(v[0] * hw[0] + v[1] * hw[1] + v[2] * hw[2] + v[3] * hw[3]) + hb;
-      }
-#pragma unroll
-      for (int m = 0; m < R; ++m) {
-        const int y = y0 + r0 + m;
-        if (kq == 0 && xok && y < a.H) a.head_out[(int64_t)cs * a.head_case + ((int64_t)y * a.W + x) * a.head_cout + o] = s[m];
-      }
-    }
-  }
-}
-__device__ __forceinline__ void load_head(const PsmPairArgs& a, float* headw, int tid) {
-  if (a.head_w) {
-    if (tid < 16 * a.head_cout) headw[tid] = a.head_w[tid];
-    if (tid < a.head_cout) headw[256 + tid] = a.head_b[tid];
-  }
-}
-
-__device__ __forceinline__ void zero_mid_pad16(char* mid, int tid) {          // columns 32..34 of the 16 mid rows
-  if (tid < MH * 3) {
-    const int r = tid / 3, c = 32 + tid - 3 * r;
-    f32x4* p = reinterpret_cast<f32x4*>(mid + (r * P16 + c) * 32);
-    p[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; p[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
-}
-__device__ __forceinline__ void zero_mid_pad32(char* mid, int tid) {          // columns 32, 33
-  if (tid < MH * 2 * 4) {
-    const int pix = tid >> 2, r = pix >> 1, c = 32 + (pix & 1);
-    *reinterpret_cast<f32x4*>(mid + (r * P32 + c) * 64 + (tid & 3) * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
 }
 
 // Persistent workgroups: workgroup w runs tiles it = 0, 1, ... of its own sequence.  Consecutive workgroup ids go to
@@ -375,6 +275,122 @@ __device__ __forceinline__ TilePos tile_pos(const PsmPairArgs& a, int t) {
   return {cs, by * TY, (r - by * a.tiles_x) * TX};
 }
 
+// ---- epilogues ------------------------------------------------------------------------------------------------------
+// The bias is the accumulator's initial value.  ReLU on packed bf16: max with 0 as signed 16-bit integers (a negative float
+// has the sign bit set; rounding is sign-symmetric, so rounding first changes nothing).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2 pack4_relu(f32x4 v) {
+  const u32x2 h = pack4(v);
+  const s16x2 z = {0, 0};
+  const unsigned lo = h[0], hi = h[1];                     // (element-wise updates of h in place were miscompiled: both halves from h[0])
+  const s16x2 a = __builtin_elementwise_max(__builtin_bit_cast(s16x2, lo), z), b = __builtin_elementwise_max(__builtin_bit_cast(s16x2, hi), z);
+  u32x2 r;
+  r[0] = __builtin_bit_cast(unsigned, a); r[1] = __builtin_bit_cast(unsigned, b);
+  return r;
+}
+// conv A: ReLU, zero outside the image (border tiles only), bf16 into the mid tile (LDS).  KEEP: also to HBM, every pixel
+// by the tile that owns it (introspection).
+template <int NT, int R, bool KEEP>
+__device__ __forceinline__ void mid_epilogue(const PsmPairArgs& a, char* mid, int cs, int y0, int x0, int r0, int xh, int lane,
+                                             bool interior, f32x4 (&acc)[R][NT]) {
+  const int px = lane & 15, kq = lane >> 4;
+  const int col = 16 * xh + px, x = x0 - 1 + col;
+  const bool xok = x >= 0 && x < a.W;
+  char* base[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+    base[nt] = mid + (NT == 1 ? (r0 * P16 + col) * 32 + kq * 8 : r0 * (P32 * 64) + slot64(col, 2 * nt + (kq >> 1)) + (kq & 1) * 8);
+#pragma unroll
+  for (int m = 0; m < R; ++m) {
+    const int y = y0 - 1 + r0 + m;
+    const bool ok = xok && y >= 0 && y < a.H;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      u32x2 h = pack4_relu(acc[m][nt]);
+      if (!interior) { h[0] = ok ? h[0] : 0u; h[1] = ok ? h[1] : 0u; }
+      *reinterpret_cast<u32x2*>(base[nt] + m * (NT == 1 ? P16 * 32 : P32 * 64)) = h;
+      if (KEEP && ok && r0 + m >= 1 && r0 + m <= TY && col >= 1 && col <= TX)
+        *reinterpret_cast<u32x2*>(a.mid_out + (int64_t)cs * a.out_case + ((int64_t)y * a.W + x) * (16 * NT) + 16 * nt + 4 * kq) = h;
+    }
+  }
+}
+// conv B: ReLU, bf16 NHWC store (STORE), fused linear 1x1 head (HEAD; headw in LDS: [16][head_cout], biases at [256]).
+// The head needs the sum over a pixel's 16 channels = the four lanes l, l ^ 16, l ^ 32, l ^ 48 after the in-lane part.
+// Four rows at a time: v_permlane32_swap of two rows' partial sums + one add leaves row A's lane-pair sums in lanes
+// 0-31 and row B's in lanes 32-63; v_permlane16_swap of two such registers + one add finishes four rows in one register
+// (16-lane group g holds row {0, 2, 1, 3}[g]) -- 6 instructions and ONE store for four rows.
+template <int NT, int R, bool STORE, bool HEAD>
+__device__ __forceinline__ void out_epilogue(const PsmPairArgs& a, int cs, int y0, int x0, int r0, int xh, int lane,
+                                             const float* headw, f32x4 (&acc)[R][NT]) {
+  static_assert(!HEAD || NT == 1, "the fused head reads one channel tile");
+  const int px = lane & 15, kq = lane >> 4;
+  const int col = 16 * xh + px, x = x0 + col;
+  const bool xok = col < TX && x < a.W;
+  if constexpr (STORE) {
+    const unsigned loff = (unsigned)((((y0 + r0) * a.W + x) * (16 * NT) + 4 * kq) * 2);       // bytes within the case
+    char* obase = reinterpret_cast<char*>(a.out + (int64_t)cs * a.out_case);
+#pragma unroll
+    for (int m = 0; m < R; ++m) {
+      const bool ok = xok && y0 + r0 + m < a.H;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        if (ok) *reinterpret_cast<u32x2*>(obase + loff + (unsigned)(m * a.W * (16 * NT) * 2) + nt * 32) = pack4_relu(acc[m][nt]);
+    }
+  }
+  if constexpr (HEAD) {
+    typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+    const int grp_row = ((kq & 1) << 1) | (kq >> 1);        // row (within a group of four) whose total this lane group ends up with
+    for (int o = 0; o < a.head_cout; ++o) {
+      f32x4 hw;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) hw[j] = headw[(4 * kq + j) * a.head_cout + o];
+      const float hb = headw[256 + o];
+      float part[(R + 3) / 4 * 4];
+#pragma unroll
+      for (int m = 0; m < (R + 3) / 4 * 4; ++m) {
+        if (m < R) {
+          const f32x4 v = acc[m][0];
+          part[m] = fmaxf(v[0], 0.f) * hw[0] + fmaxf(v[1], 0.f) * hw[1] + fmaxf(v[2], 0.f) * hw[2] + fmaxf(v[3], 0.f) * hw[3];
+        } else part[m] = 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < (R + 3) / 4; ++q) {
+        const u32x2v s01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(part[4 * q]), __float_as_uint(part[4 * q + 1]), false, false);
+        const u32x2v s23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(part[4 * q + 2]), __float_as_uint(part[4 * q + 3]), false, false);
+        const float u01 = __uint_as_float(s01[0]) + __uint_as_float(s01[1]);       // lanes 0-31: row 0 (l + l^32), lanes 32-63: row 1
+        const float u23 = __uint_as_float(s23[0]) + __uint_as_float(s23[1]);
+        const u32x2v t = __builtin_amdgcn_permlane16_swap(__float_as_uint(u01), __float_as_uint(u23), false, false);
+        const float tot = __uint_as_float(t[0]) + __uint_as_float(t[1]) + hb;      // group g: row {0, 2, 1, 3}[g] of this group of four
+        const int m = 4 * q + grp_row, y = y0 + r0 + m;
+        if (xok && m < R && y < a.H) a.head_out[(int64_t)cs * a.head_case + ((int64_t)y * a.W + x) * a.head_cout + o] = tot;
+      }
+    }
+  }
+}
+__device__ __forceinline__ void load_head(const PsmPairArgs& a, float* headw, int tid) {
+  if (a.head_w) {
+    if (tid < 16 * a.head_cout) headw[tid] = a.head_w[tid];
+    if (tid < a.head_cout) headw[256 + tid] = a.head_b[tid];
+  }
+}
+__device__ __forceinline__ void zero_mid_pad16(char* mid, int tid) {          // columns 32..34 of the 16 mid rows
+  if (tid < MH * 3) {
+    const int r = tid / 3, c = 32 + tid - 3 * r;
+    f32x4* p = reinterpret_cast<f32x4*>(mid + (r * P16 + c) * 32);
+    p[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; p[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+}
+__device__ __forceinline__ void zero_mid_pad32(char* mid, int tid) {          // columns 32, 33
+  if (tid < MH * 2 * 4) {
+    const int pix = tid >> 2, r = pix >> 1, c = 32 + (pix & 1);
+    *reinterpret_cast<f32x4*>(mid + (r * P32 + c) * 64 + (tid & 3) * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+}
+// every pixel the tile stages (x0 - 2 .. x0 + 32, y0 - 2 .. y0 + 15) and computes lies inside the image
+__device__ __forceinline__ bool tile_interior(const PsmPairArgs& a, const TilePos& t) {
+  return t.x0 >= 2 && t.x0 + 33 <= a.W && t.y0 >= 2 && t.y0 + 16 <= a.H;
+}
+
 // ====================================================================================================================
 // level 0, encoder: raw image (C0 = 3 or 4 float32 channels) -> 16 -> 16.  conv A flattens k = tap*C0 + channel and
 // pads it to KS steps of 32; its operand is gathered from the bf16 image tile with per-lane fixed offsets.
@@ -383,22 +399,22 @@ template <int C0, bool KEEP>
 __global__ __launch_bounds__(256, 2) void psm_pair_stem16_kernel(PsmPairArgs a) {
   constexpr int K = 9 * C0, KS = (K + 31) / 32;
   constexpr int PI = 34;                                  // pitch of the image tile (pixels)
-  constexpr int NI = IH * PI * C0;                       // image tile values (bf16), pitch 34
-  constexpr int ROUNDS = (NI + 255) / 256;
-  __shared__ __attribute__((aligned(16))) unsigned short img[ROUNDS * 256];
+  constexpr int RW = (IH + 3) / 4;                        // image rows per wave
+  constexpr int RV = PI * C0, KR = (RV + 63) / 64;        // values per row, load instructions per row
+  __shared__ __attribute__((aligned(16))) unsigned short img[IH * RV + 64];
   __shared__ __attribute__((aligned(16))) char mid[M16_BYTES];
+  __shared__ __attribute__((aligned(16))) bf16x8 wbl[6 * 64];            // conv B's fragments
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int px = lane & 15, kq = lane >> 4, xh = wave & 1;
   const int total = a.tiles_x * a.tiles_y * a.n_cases;
-  bf16x8 wA[KS], wB[6];
+  bf16x8 wA[KS];
   const bf16x8* wa = reinterpret_cast<const bf16x8*>(a.wA) + lane;
-  const bf16x8* wb = reinterpret_cast<const bf16x8*>(a.wB) + lane;
 #pragma unroll
   for (int s = 0; s < KS; ++s) wA[s] = wa[s * 64];
-#pragma unroll
-  for (int s = 0; s < 6; ++s) wB[s] = wb[s * 64];
-  const f32x4 bA[1] = {*reinterpret_cast<const f32x4*>(a.biasA + 4 * kq)}, bB[1] = {*reinterpret_cast<const f32x4*>(a.biasB + 4 * kq)};
+  for (int i = tid; i < 6 * 64; i += 256) reinterpret_cast<uint4*>(wbl)[i] = a.wB[i];
+  const bf16x8* wbf = wbl + lane;
+  const f32x4 bA = *reinterpret_cast<const f32x4*>(a.biasA + 4 * kq), bB = *reinterpret_cast<const f32x4*>(a.biasB + 4 * kq);
   int off[KS][8];
 #pragma unroll
   for (int s = 0; s < KS; ++s)
@@ -409,41 +425,65 @@ __global__ __launch_bounds__(256, 2) void psm_pair_stem16_kernel(PsmPairArgs a) 
       off[s][j] = (16 * xh + px) * C0 + (k < K ? (ky * PI + kx) * C0 + ci : 0);      // k >= K: any finite value, its weight is zero
     }
   zero_mid_pad16(mid, tid);
-  float ev[ROUNDS];
-  auto issue = [&](const TilePos& t, int tz) {
+  // image staging, row-wise: wave w takes rows w, w + 4, ...; a lane keeps KR value positions of the row
+  float ev[RW][KR];
+  unsigned evok = 0;
+  auto issue = [&](const TilePos& t) {
     const float* in0 = reinterpret_cast<const float*>(a.in0) + (int64_t)t.cs * a.in0_case;
+    int xo[KR];
+    unsigned xok = 0;
+    evok = 0;
 #pragma unroll
-    for (int u = 0; u < ROUNDS; ++u) {
-      const int e = min(tz + 256 * u, NI - 1), pos = e / C0, ci = e - pos * C0;
-      const int r = pos / PI, c = pos - r * PI;
-      const int y = t.y0 - 2 + r, x = t.x0 - 2 + c;
-      const bool ok = y >= 0 && y < a.H && x >= 0 && x < a.W;
-      const float v = in0[((int64_t)min(max(y, 0), a.H - 1) * a.W + min(max(x, 0), a.W - 1)) * C0 + ci];
-      ev[u] = ok ? v : 0.f;
+    for (int k = 0; k < KR; ++k) {
+      const int e = min(64 * k + lane, RV - 1), c = e / C0, ci = e - c * C0, x = t.x0 - 2 + c;
+      xok |= (x >= 0 && x < a.W) ? (1u << k) : 0u;
+      xo[k] = min(max(x, 0), a.W - 1) * C0 + ci;
+    }
+#pragma unroll
+    for (int j = 0; j < RW; ++j) {
+      const int y = t.y0 - 2 + min(wave + 4 * j, IH - 1);
+      const bool yok = y >= 0 && y < a.H;
+      const float* rowp = in0 + (int64_t)min(max(y, 0), a.H - 1) * a.W * C0;
+#pragma unroll
+      for (int k = 0; k < KR; ++k) {
+        ev[j][k] = rowp[xo[k]];                         // raw: the zero padding is applied when the tile is written, not here
+        evok |= (yok && ((xok >> k) & 1u)) ? (1u << (j * KR + k)) : 0u;       // (a select here would wait for the load)
+      }
     }
   };
   int it = 0, tile = tile_of(0, total);
   if (tile < 0) return;
   TilePos cur = tile_pos(a, tile);
-  issue(cur, tid);
+  issue(cur);
+#ifdef PSM_STAMPS
+  int g_it = 0;
+#endif
   while (true) {
-    int tz = tid;                                                      // opaque copy: staging positions recomputed per tile, not kept in registers
-    asm volatile("" : "+v"(tz));
+    PSTAMP(0);
 #pragma unroll
-    for (int u = 0; u < ROUNDS; ++u) img[tz + 256 * u] = __builtin_bit_cast(unsigned short, (__bf16)ev[u]);
+    for (int j = 0; j < RW; ++j)
+#pragma unroll
+      for (int k = 0; k < KR; ++k)
+        img[min(wave + 4 * j, IH - 1) * RV + min(64 * k + lane, RV - 1)] =
+            __builtin_bit_cast(unsigned short, (__bf16)(((evok >> (j * KR + k)) & 1u) ? ev[j][k] : 0.f));
+    PSTAMP(1);
     lds_barrier();
+    PSTAMP(2);
+    const bool interior = tile_interior(a, cur);
     const int next = tile_of(++it, total);
     const TilePos nxt = tile_pos(a, next >= 0 ? next : tile);          // past the end: the same tile again (no branch around the loads)
-    issue(nxt, tz);
+    issue(nxt);
+    PSTAMP(3);
     {
       constexpr int R = MH / 2;
       const int r0 = R * (wave >> 1);
       f32x4 acc[R][1];
 #pragma unroll
-      for (int m = 0; m < R; ++m) acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int m = 0; m < R; ++m) acc[m][0] = bA;
 #pragma unroll
       for (int m = 0; m < R; ++m) {
-        const unsigned short* row = img + (r0 + m) * (PI * C0);          // rows are immediate offsets from the per-lane term offsets
+        if (m == R / 2) __builtin_amdgcn_sched_barrier(0);               // two groups of rows: bounds the gathered operands in flight
+        const unsigned short* row = img + (r0 + m) * RV;                 // rows are immediate offsets from the per-lane term offsets
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
           unsigned short h[8];
@@ -455,25 +495,33 @@ __global__ __launch_bounds__(256, 2) void psm_pair_stem16_kernel(PsmPairArgs a) 
           acc[m][0] = MFMA_BF(wA[s], __builtin_bit_cast(bf16x8, q), acc[m][0]);
         }
       }
-      mid_epilogue<1, R, KEEP>(a, mid, cur.cs, cur.y0, cur.x0, r0, xh, lane, bA, acc);
+      PSTAMP(4);
+      mid_epilogue<1, R, KEEP>(a, mid, cur.cs, cur.y0, cur.x0, r0, xh, lane, interior, acc);
     }
+    PSTAMP(5);
     lds_barrier();
+    PSTAMP(6);
     {
       constexpr int R = TY / 2;
       const int r0 = R * (wave >> 1);
       f32x4 acc[R][1];
 #pragma unroll
-      for (int m = 0; m < R; ++m) acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      conv16<1, R>(mid, r0, 16 * xh + px, kq, [&](int i) { return wB[i]; }, acc);
-      out_epilogue<1, R, true, false>(a, cur.cs, cur.y0, cur.x0, r0, xh, lane, bB, nullptr, acc);
+      for (int m = 0; m < R; ++m) acc[m][0] = bB;
+      conv16<1, R, false>(mid, r0, 16 * xh + px, kq, [&](int i) { return wbf[i * 64]; }, acc);
+      PSTAMP(7);
+      out_epilogue<1, R, true, false>(a, cur.cs, cur.y0, cur.x0, r0, xh, lane, nullptr, acc);
     }
+    PSTAMP(8);
+#ifdef PSM_STAMPS
+    ++g_it;
+#endif
     if (next < 0) break;
     tile = next; cur = nxt;
   }
 }
 
 // ====================================================================================================================
-// level 0, decoder: upsample(32 channels) ++ skip(16 channels) -> 16 -> 16 (+ head).  All weights in registers.
+// level 0, decoder: upsample(32 channels) ++ skip(16 channels) -> 16 -> 16 (+ head).  Weights in LDS.
 // ====================================================================================================================
 template <bool KEEP, bool HEAD>
 __global__ __launch_bounds__(256, 2) void psm_pair_up16_kernel(PsmPairArgs a) {
@@ -488,48 +536,47 @@ __global__ __launch_bounds__(256, 2) void psm_pair_up16_kernel(PsmPairArgs a) {
   const int total = a.tiles_x * a.tiles_y * a.n_cases;
   for (int i = tid; i < 21 * 64; i += 256)
     reinterpret_cast<uint4*>(wl)[i] = i < 15 * 64 ? a.wA[i] : a.wB[i - 15 * 64];
-  const f32x4 bA[1] = {*reinterpret_cast<const f32x4*>(a.biasA + 4 * kq)}, bB[1] = {*reinterpret_cast<const f32x4*>(a.biasB + 4 * kq)};
+  const f32x4 bA = *reinterpret_cast<const f32x4*>(a.biasA + 4 * kq), bB = *reinterpret_cast<const f32x4*>(a.biasB + 4 * kq);
   load_head(a, headw, tid);
   zero_mid_pad16(mid, tid);
   const bf16x8* wf = wl + lane;
-  f32x4 vlo[LOW_ROUNDS][1], v16[5][1];
+  f32x4 vlo[StLow::NP][1], v16[St16::NP][1];
   unsigned oklo, ok16;
-  auto issue = [&](const TilePos& t, int tz) {
-    low_issue(vlo, oklo, reinterpret_cast<const unsigned short*>(a.in0) + (int64_t)t.cs * a.in0_case, 32, 0, a.H, a.W, t.y0, t.x0, tz);
-    tile_issue<0, 16, 0, 5>(v16, ok16, reinterpret_cast<const unsigned short*>(a.in1) + (int64_t)t.cs * a.in1_case, 16, 0, a.H, a.W, t.y0, t.x0, tz);
+  auto issue = [&](const TilePos& t) {
+    StLow::issue(vlo, oklo, reinterpret_cast<const unsigned short*>(a.in0) + (int64_t)t.cs * a.in0_case, 32, 0, a.H / 2, a.W / 2,
+                 (t.y0 - 2) / 2, (t.x0 - 2) / 2, wave, lane, tid);                     // tile origins are even: exact, also for -2
+    St16::issue(v16, ok16, reinterpret_cast<const unsigned short*>(a.in1) + (int64_t)t.cs * a.in1_case, 16, 0, a.H, a.W,
+                t.y0 - 2, t.x0 - 2, wave, lane, tid);
   };
   int it = 0, tile = tile_of(0, total);
   if (tile < 0) return;
   TilePos cur = tile_pos(a, tile);
-  issue(cur, tid);
+  issue(cur);
 #ifdef PSM_STAMPS
   int g_it = 0;
 #endif
   while (true) {
-    // the per-thread staging positions are recomputed per tile from an opaque copy of tid: hoisted out of the loop they
-    // would sit in ~40 registers for the whole kernel
-    int tz = tid;
-    asm volatile("" : "+v"(tz));
+    const bool interior = tile_interior(a, cur);
     PSTAMP(0);
-    low_write(tlow, vlo, oklo, tz);
-    tile_write<0, 16, 0, 5>(t16, v16, ok16, tz);
+    StLow::write(tlow, vlo, oklo, interior, wave, lane, tid);
+    St16::write(t16, v16, ok16, interior, wave, lane, tid);
     PSTAMP(1);
     lds_barrier();
     PSTAMP(2);
     const int next = tile_of(++it, total);
     const TilePos nxt = tile_pos(a, next >= 0 ? next : tile);          // past the end: the same tile again (no branch around the loads)
-    issue(nxt, tz);
+    issue(nxt);
     {
       constexpr int R = MH / 2;
       const int r0 = R * (wave >> 1);
       f32x4 acc[R][1];
 #pragma unroll
-      for (int m = 0; m < R; ++m) acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int m = 0; m < R; ++m) acc[m][0] = bA;
       conv32_up<1, R>(tlow, r0, 16 * xh + px, kq, [&](int i) { return wf[i * 64]; }, acc);
       PSTAMP(3);
       conv16<1, R>(t16, r0, 16 * xh + px, kq, [&](int i) { return wf[(9 + i) * 64]; }, acc);
       PSTAMP(4);
-      mid_epilogue<1, R, KEEP>(a, mid, cur.cs, cur.y0, cur.x0, r0, xh, lane, bA, acc);
+      mid_epilogue<1, R, KEEP>(a, mid, cur.cs, cur.y0, cur.x0, r0, xh, lane, interior, acc);
     }
     PSTAMP(5);
     lds_barrier();
@@ -539,10 +586,10 @@ __global__ __launch_bounds__(256, 2) void psm_pair_up16_kernel(PsmPairArgs a) {
       const int r0 = R * (wave >> 1);
       f32x4 acc[R][1];
 #pragma unroll
-      for (int m = 0; m < R; ++m) acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int m = 0; m < R; ++m) acc[m][0] = bB;
       conv16<1, R>(mid, r0, 16 * xh + px, kq, [&](int i) { return wf[(15 + i) * 64]; }, acc);
       PSTAMP(7);
-      out_epilogue<1, R, KEEP || !HEAD, HEAD>(a, cur.cs, cur.y0, cur.x0, r0, xh, lane, bB, headw, acc);
+      out_epilogue<1, R, KEEP || !HEAD, HEAD>(a, cur.cs, cur.y0, cur.x0, r0, xh, lane, headw, acc);
     }
     PSTAMP(8);
 #ifdef PSM_STAMPS
@@ -572,6 +619,7 @@ struct Chunk { int form, cb; };                          // form, first channel 
 template <int KIND, bool KEEP>
 __global__ __launch_bounds__(256, 2) void psm_pair32_kernel(PsmPairArgs a) {
   __shared__ __attribute__((aligned(16))) char lds[PAIR32_LDS];
+  __shared__ __attribute__((aligned(16))) float bias_l[64];       // conv A's, then conv B's
   char* tile = lds;
   char* wl = lds + T32_BYTES;
   char* mid = lds;                                         // overlays the staging area once conv A is done with it
@@ -582,11 +630,12 @@ __global__ __launch_bounds__(256, 2) void psm_pair32_kernel(PsmPairArgs a) {
   const int total = a.tiles_x * a.tiles_y * a.n_cases;
   constexpr int RA = MH / 2, RB = TY / 2;
   const int rA = RA * (wave >> 1), rB = RB * (wave >> 1);
+  if (tid < 64) bias_l[tid] = tid < 32 ? a.biasA[tid] : a.biasB[tid - 32];
   const bf16x8* wfrag = reinterpret_cast<const bf16x8*>(wl) + lane;
   auto wget = [&](int i) { return wfrag[i * 64]; };
-  // Chunk order: the skip input first (its ten staging rounds are not prefetched -- at the start of a tile there is nothing
-  // to hide them behind), then the upsample source, whose chunks (three rounds at its own resolution) are requested during
-  // the previous chunk's MFMAs.  Fragment offsets follow pack_pair's order (in0's chunks, then in1's).
+  // Chunk order: the skip input first (its staging is not prefetched -- at the start of a tile there is nothing to hide it
+  // behind), then the upsample source, whose chunks (at its own resolution) are requested during the previous chunk's
+  // MFMAs.  Fragment offsets follow pack_pair's order (in0's chunks, then in1's).
   const int n0 = (a.c0 + 31) / 32, n1 = KIND == 1 ? (a.c1 + 31) / 32 : 0;
   const int frag0 = 18 * (a.c0 / 32) + 12 * ((a.c0 % 32) != 0);        // fragments of in0's chunks
   auto chunk_at = [&](int ci) -> Chunk {                    // ci-th chunk in execution order (uniform)
@@ -603,7 +652,7 @@ __global__ __launch_bounds__(256, 2) void psm_pair32_kernel(PsmPairArgs a) {
   };
   auto frags_in = [](int form) { return (form == CK_SAME16 || form == CK_POOL16) ? 12 : 18; };
 
-  f32x4 pf[LOW_ROUNDS][1];                                  // prefetched pieces of an upsample-source chunk
+  f32x4 pf[StLow::NP][1];                                   // prefetched pieces of an upsample-source chunk
   uint4 pw[WROUNDS];                                        // prefetched weight fragments
   unsigned pok = 0;
   for (int it = 0;; ++it) {
@@ -611,10 +660,11 @@ __global__ __launch_bounds__(256, 2) void psm_pair32_kernel(PsmPairArgs a) {
     if (tl < 0) break;
     const TilePos t = tile_pos(a, tl);
     const int y0 = t.y0, x0 = t.x0;
+    const bool interior = tile_interior(a, t);
     const unsigned short* in0 = reinterpret_cast<const unsigned short*>(a.in0) + (int64_t)t.cs * a.in0_case;
     const unsigned short* in1 = reinterpret_cast<const unsigned short*>(a.in1) + (int64_t)t.cs * a.in1_case;
-    int tz = tid;                                             // opaque copy, refreshed where it is used: the staging positions are
-    asm volatile("" : "+v"(tz));                              // recomputed there instead of living in registers across the MFMAs
+    int tz = tid, lz = lane;                                  // opaque copies, refreshed where they are used: staging positions are
+    asm volatile("" : "+v"(tz), "+v"(lz));                    // recomputed there instead of living in registers across the MFMAs
     auto issue_w = [&](const uint4* src, int nfrag) {
 #pragma unroll
       for (int u = 0; u < WROUNDS; ++u) pw[u] = src[min(tz + 256 * u, nfrag * 64 - 1)];
@@ -624,8 +674,11 @@ __global__ __launch_bounds__(256, 2) void psm_pair32_kernel(PsmPairArgs a) {
       for (int u = 0; u < WROUNDS; ++u) reinterpret_cast<uint4*>(dst)[min(tz + 256 * u, nfrag * 64 - 1)] = pw[u];
     };
     f32x4 acc[RA][2];
+    {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.biasA + 4 * kq), b1 = *reinterpret_cast<const f32x4*>(a.biasA + 16 + 4 * kq);
 #pragma unroll
-    for (int m = 0; m < RA; ++m) { acc[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+      for (int m = 0; m < RA; ++m) { acc[m][0] = b0; acc[m][1] = b1; }
+    }
 #ifdef PSM_STAMPS
     const int g_it = 0;
     int sk = 0;
@@ -634,40 +687,70 @@ __global__ __launch_bounds__(256, 2) void psm_pair32_kernel(PsmPairArgs a) {
 #define PSTAMP32() do { } while (0)
 #endif
     PSTAMP32();
-    Chunk cur = chunk_at(0);
-    issue_w(a.wA + frag_of(cur) * 64, frags_in(cur.form));
-    if (cur.form == CK_UP32) low_issue(pf, pok, in0, a.c0, cur.cb, a.H, a.W, y0, x0, tz);
-    for (int ci = 0; cur.form != CK_NONE; ++ci) {
+    {
+      const Chunk first = chunk_at(0);
+      issue_w(a.wA + frag_of(first) * 64, frags_in(first.form));
+      if constexpr (KIND == 1)
+        if (first.form == CK_UP32) StLow::issue(pf, pok, in0, a.c0, first.cb, a.H / 2, a.W / 2, (y0 - 2) / 2, (x0 - 2) / 2, wave, lz, tz);
+    }
+    // one chunk: stage it (the upsample source: write what was prefetched), request the next chunk's prefetch, MFMAs.  The
+    // form is a compile-time tag and every form runs in its own loop below: with one loop over a run-time form the
+    // accumulators went through a three-way merge and the MFMAs stopped accumulating in place (twice the registers, spills)
+    auto do_chunk = [&](auto form_tag, int cb, int ci) {
+      constexpr int FORM = decltype(form_tag)::value;
       lds_barrier();                                         // the previous chunk's (tile's) operands are no longer being read
-      asm volatile("" : "+v"(tz));
-      if (cur.form == CK_UP32) low_write(tile, pf, pok, tz);
-      else if (cur.form == CK_SAME32) stage_tile<0, 32>(tile, in1, a.c1, cur.cb, a.H, a.W, y0, x0, tz);
-      else if (cur.form == CK_SAME16) stage_tile<0, 16>(tile, in1, a.c1, cur.cb, a.H, a.W, y0, x0, tz);
-      else if (cur.form == CK_POOL32) stage_tile<2, 32>(tile, in0, a.c0, cur.cb, a.H, a.W, y0, x0, tz);
-      else stage_tile<2, 16>(tile, in0, a.c0, cur.cb, a.H, a.W, y0, x0, tz);
-      write_w(wl, frags_in(cur.form));
+      asm volatile("" : "+v"(tz), "+v"(lz));
+      if constexpr (FORM == CK_UP32) StLow::write(tile, pf, pok, interior, wave, lz, tz);
+      else if constexpr (FORM == CK_SAME32) {
+        f32x4 v[St32::NP][1]; unsigned ok;
+        St32::issue(v, ok, in1, a.c1, cb, a.H, a.W, y0 - 2, x0 - 2, wave, lz, tz);
+        St32::write(tile, v, ok, interior, wave, lz, tz);
+      } else if constexpr (FORM == CK_SAME16) {
+        f32x4 v[St16::NP][1]; unsigned ok;
+        St16::issue(v, ok, in1, a.c1, cb, a.H, a.W, y0 - 2, x0 - 2, wave, lz, tz);
+        St16::write(tile, v, ok, interior, wave, lz, tz);
+      } else if constexpr (FORM == CK_POOL32) {              // four source pixels per piece: in two halves (registers)
+        constexpr int JA = (StPool32::RW + 1) / 2, JB = StPool32::RW - JA;
+        { f32x4 v[JA * StPool32::KM][4]; unsigned ok;
+          StPool32::template issue<0, JA, false>(v, ok, in0, a.c0, cb, a.H, a.W, y0 - 2, x0 - 2, wave, lz, tz);
+          StPool32::template write<0, JA, false>(tile, v, ok, interior, wave, lz, tz); }
+        { f32x4 v[JB * StPool32::KM + 1][4]; unsigned ok;
+          StPool32::template issue<JA, JB, true>(v, ok, in0, a.c0, cb, a.H, a.W, y0 - 2, x0 - 2, wave, lz, tz);
+          StPool32::template write<JA, JB, true>(tile, v, ok, interior, wave, lz, tz); }
+      } else {
+        f32x4 v[StPool16::NP][4]; unsigned ok;
+        StPool16::issue(v, ok, in0, a.c0, cb, a.H, a.W, y0 - 2, x0 - 2, wave, lz, tz);
+        StPool16::write(tile, v, ok, interior, wave, lz, tz);
+      }
+      write_w(wl, frags_in(FORM));
       PSTAMP32();
       lds_barrier();
       PSTAMP32();
       const Chunk nxt = chunk_at(ci + 1);
-      asm volatile("" : "+v"(tz));
-      if (nxt.form == CK_UP32) low_issue(pf, pok, in0, a.c0, nxt.cb, a.H, a.W, y0, x0, tz);      // in flight during this chunk's MFMAs
+      asm volatile("" : "+v"(tz), "+v"(lz));
+      if constexpr (KIND == 1)
+        if (nxt.form == CK_UP32)                             // in flight during this chunk's MFMAs
+          StLow::issue(pf, pok, in0, a.c0, nxt.cb, a.H / 2, a.W / 2, (y0 - 2) / 2, (x0 - 2) / 2, wave, lz, tz);
       if (nxt.form != CK_NONE) issue_w(a.wA + frag_of(nxt) * 64, frags_in(nxt.form)); else issue_w(a.wB, 18);
-      if (cur.form == CK_UP32) conv32_up<2, RA>(tile, rA, 16 * xh + px, kq, wget, acc);
-      else if (cur.form == CK_SAME32 || cur.form == CK_POOL32) conv32<2, RA>(tile, rA, 16 * xh + px, kq, wget, acc);
+      if constexpr (FORM == CK_UP32) conv32_up<2, RA>(tile, rA, 16 * xh + px, kq, wget, acc);
+      else if constexpr (FORM == CK_SAME32 || FORM == CK_POOL32) conv32<2, RA>(tile, rA, 16 * xh + px, kq, wget, acc);
       else conv16<2, RA>(tile, rA, 16 * xh + px, kq, wget, acc);
       PSTAMP32();
-      cur = nxt;
-    }
-    f32x4 bA[2], bB[2];                                      // requested here: they land during the barrier and the first epilogue rows
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      bA[nt] = *reinterpret_cast<const f32x4*>(a.biasA + 16 * nt + 4 * kq);
-      bB[nt] = *reinterpret_cast<const f32x4*>(a.biasB + 16 * nt + 4 * kq);
+    };
+    {
+      int ci = 0;
+      if constexpr (KIND == 1) {
+        for (int cb = 0; cb + 32 <= a.c1; cb += 32) do_chunk(std::integral_constant<int, CK_SAME32>{}, cb, ci++);
+        if (a.c1 & 31) do_chunk(std::integral_constant<int, CK_SAME16>{}, a.c1 & ~31, ci++);
+        for (int cb = 0; cb < a.c0; cb += 32) do_chunk(std::integral_constant<int, CK_UP32>{}, cb, ci++);
+      } else {
+        for (int cb = 0; cb + 32 <= a.c0; cb += 32) do_chunk(std::integral_constant<int, CK_POOL32>{}, cb, ci++);
+        if (a.c0 & 31) do_chunk(std::integral_constant<int, CK_POOL16>{}, a.c0 & ~31, ci++);
+      }
     }
     lds_barrier();                                           // every wave is done with the staging area: the mid tile goes over it
-    asm volatile("" : "+v"(tz));
-    mid_epilogue<2, RA, KEEP>(a, mid, t.cs, y0, x0, rA, xh, lane, bA, acc);
+    asm volatile("" : "+v"(tz), "+v"(lz));
+    mid_epilogue<2, RA, KEEP>(a, mid, t.cs, y0, x0, rA, xh, lane, interior, acc);
     zero_mid_pad32(mid, tid);
     write_w(wbl, 18);
     PSTAMP32();
@@ -675,12 +758,15 @@ __global__ __launch_bounds__(256, 2) void psm_pair32_kernel(PsmPairArgs a) {
     PSTAMP32();
     {
       f32x4 accb[RB][2];
+      {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_l + 32 + 4 * kq), b1 = *reinterpret_cast<const f32x4*>(bias_l + 48 + 4 * kq);
 #pragma unroll
-      for (int m = 0; m < RB; ++m) { accb[m][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; accb[m][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        for (int m = 0; m < RB; ++m) { accb[m][0] = b0; accb[m][1] = b1; }
+      }
       const bf16x8* wbf = reinterpret_cast<const bf16x8*>(wbl) + lane;
       conv32<2, RB>(mid, rB, 16 * xh + px, kq, [&](int i) { return wbf[i * 64]; }, accb);
       PSTAMP32();
-      out_epilogue<2, RB, true, false>(a, t.cs, y0, x0, rB, xh, lane, bB, nullptr, accb);
+      out_epilogue<2, RB, true, false>(a, t.cs, y0, x0, rB, xh, lane, nullptr, accb);
       PSTAMP32();
     }
   }
@@ -694,7 +780,7 @@ hipError_t psm_launch_conv_pair(const PsmPairArgs& a, int kind, int cm, int n_ca
   if (a.head_w && (a.head_cout < 1 || a.head_cout > 16)) return hipErrorInvalidValue;
   const int total = a.tiles_x * a.tiles_y * n_cases;
   static const int wg_max = getenv("PSM_UNET_PAIR_WGS") ? atoi(getenv("PSM_UNET_PAIR_WGS")) : 512;
-  int g = total < wg_max ? total : wg_max;
+  int g = total < wg_max ? total : wg_max;                 // (three per CU for the stem kernel, 168 registers: measured, not faster)
   if ((total & 7) == 0 && g >= 8) g &= ~7;
   const dim3 grid((unsigned)g);
   const bool keep = a.mid_out != nullptr, head = a.head_w != nullptr;

@@ -21,5 +21,5 @@ with UNetSurrogate(W, 256, 256, max_cases=n, precision="bf16") as net:
         for it in range(7):
             if st[9 * it] < 0:
                 break
-            print(f"layer {idx} tile {it}: loop top {st[9*it]:6.2f} | written {st[9*it+1]:6.2f} barrier {st[9*it+2]:6.2f} | conv A1 {st[9*it+3]:6.2f} A2 {st[9*it+4]:6.2f} "
+            print(f"layer {idx} tile {it}: loop top {st[9*it]:6.2f} | written {st[9*it+1]:6.2f} barrier {st[9*it+2]:6.2f} | conv A1 (stem: next issued) {st[9*it+3]:6.2f} A2 (stem: conv A) {st[9*it+4]:6.2f} "
                   f"mid {st[9*it+5]:6.2f} barrier {st[9*it+6]:6.2f} | conv B {st[9*it+7]:6.2f} out {st[9*it+8]:6.2f}")
