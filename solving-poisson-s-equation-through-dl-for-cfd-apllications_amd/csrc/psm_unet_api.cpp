@@ -426,7 +426,7 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
         if (cm == 32 && c0 % 32 == 0 && c1 % 16 == 0) kind = PSM_PAIR_UPCAT;
       }
       if (kind < 0) continue;
-      if (cm == 32 && getenv("PSM_UNET_PAIR32") == nullptr) continue;     // the 32-channel pair kernel is not faster than two launches yet
+      if (cm == 32 && getenv("PSM_UNET_PAIR32") && atoi(getenv("PSM_UNET_PAIR32")) == 0) continue;     // diagnostic: 16-channel pairs only
       A.pair = 1; A.pair_kind = kind; B.pair = 2;
     }
   }

@@ -653,7 +653,8 @@ __global__ __launch_bounds__(256, 2) void psm_pair32_kernel(PsmPairArgs a) {
   auto frags_in = [](int form) { return (form == CK_SAME16 || form == CK_POOL16) ? 12 : 18; };
 
   f32x4 pf[StLow::NP][1];                                   // prefetched pieces of an upsample-source chunk
-  uint4 pw[WROUNDS];                                        // prefetched weight fragments
+  u32x4 pw[WROUNDS];                                        // prefetched weight fragments (a native vector type: an array of HIP's
+                                                            // uint4 structs was kept in scratch memory -- every prefetch a round trip)
   unsigned pok = 0;
   for (int it = 0;; ++it) {
     const int tl = tile_of(it, total);
@@ -667,11 +668,11 @@ __global__ __launch_bounds__(256, 2) void psm_pair32_kernel(PsmPairArgs a) {
     asm volatile("" : "+v"(tz), "+v"(lz));                    // recomputed there instead of living in registers across the MFMAs
     auto issue_w = [&](const uint4* src, int nfrag) {
 #pragma unroll
-      for (int u = 0; u < WROUNDS; ++u) pw[u] = src[min(tz + 256 * u, nfrag * 64 - 1)];
+      for (int u = 0; u < WROUNDS; ++u) pw[u] = reinterpret_cast<const u32x4*>(src)[min(tz + 256 * u, nfrag * 64 - 1)];
     };
     auto write_w = [&](char* dst, int nfrag) {
 #pragma unroll
-      for (int u = 0; u < WROUNDS; ++u) reinterpret_cast<uint4*>(dst)[min(tz + 256 * u, nfrag * 64 - 1)] = pw[u];
+      for (int u = 0; u < WROUNDS; ++u) reinterpret_cast<u32x4*>(dst)[min(tz + 256 * u, nfrag * 64 - 1)] = pw[u];
     };
     f32x4 acc[RA][2];
     {

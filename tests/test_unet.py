@@ -126,7 +126,6 @@ def test_gpu_unet_bf16_fused_level_pairs(ny, nx, n, keep, monkeypatch):
     never stored and asking for them is an error."""
     from psm_amd import UNetSurrogate, _lib
     monkeypatch.setenv("PSM_UNET_PAIR_MIN", "1")
-    monkeypatch.setenv("PSM_UNET_PAIR32", "1")                     # the 32-channel pair kernels too (off by default: not faster yet)
     specs = uo.unet_specs()
     W = uo.he_weights(specs, seed=13)
     grids = np.stack([synthetic.channel_grid(ny, nx, seed=40 + k).astype(np.float32) for k in range(n)])
