@@ -36,8 +36,9 @@ int psm_unet_conv_shape(const psm_unet* u, int32_t idx, int32_t* k, int32_t* c_i
 /* weight [k, k, c_in, c_out] float32 (Keras Conv2D kernel), bias [c_out]. */
 int psm_unet_set_conv(psm_unet* u, int32_t idx, const float* weight, const float* bias);
 /* PSM_PRECISION_F32 (default; exact f32 products) or PSM_PRECISION_BF16 (activations and weights rounded to bf16
- * at every convolution input, f32 accumulation by v_mfma_f32_16x16x32_bf16; activations stay float32 in
- * memory).  Call before psm_unet_plan.  Constants from psm.h. */
+ * at every convolution input, f32 accumulation by v_mfma_f32_16x16x32_bf16; finished activations are kept in
+ * memory as bf16 -- the value the next convolution would round them to anyway --, partial sums of split layers
+ * as float32).  Call before psm_unet_plan.  Constants from psm.h. */
 int psm_unet_set_precision(psm_unet* u, int32_t precision);
 /* bf16 mode fuses the two convolutions of a wide level into one launch and keeps the first one's activation (and the
  * last 3x3 layer's, whose 1x1 head is fused) on chip.  on != 0: those activations are stored as well, so that

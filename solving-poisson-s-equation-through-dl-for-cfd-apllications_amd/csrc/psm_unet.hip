@@ -267,7 +267,7 @@ __device__ __forceinline__ void store_act(float* out, int64_t elem, float v, boo
 //   f32 (BF = false): chunks of 16 channels, v_mfma_f32_16x16x4_f32, exact f32 products.
 //   bf16 (BF = true): activations (after the source transform) and weights rounded to bf16 (RNE), chunks of 32
 //     channels, ONE v_mfma_f32_16x16x32_bf16 per (tap, row, channel tile): lane l holds A[pixel l&15][k = 8*(l>>4)+j]
-//     and B[k][channel l&15], j < 8.  Activations stay float32 in HBM (skips, slabs and the oracle's rounding
+//     and B[k][channel l&15], j < 8.  Without ABF activations are float32 in HBM (skips, slabs and the oracle's rounding
 //     points are unchanged).  Both forms use a 64-byte LDS pixel with swizzled 16-byte slots (lds_slot).
 //   NB: LDS buffers per operand -- 1 when a workgroup has a single chunk (nothing to pipeline: half the LDS, twice
 //     the workgroups per CU to cover each other's load latency), else 2.
