@@ -26,6 +26,28 @@ def pytest_sessionstart(session):
                        stdout=subprocess.DEVNULL)
 
 
+def _install_abort_trace():
+    """SIGABRT handler that prints the native backtrace (tests/abort_trace.c): an abort raised inside the HIP runtime or
+    glibc otherwise leaves only Python frames behind.  Best effort: no gcc, no handler."""
+    import ctypes
+    import shutil
+    import subprocess
+    import tempfile
+    gcc = shutil.which("gcc")
+    if not gcc:
+        return
+    so = os.path.join(tempfile.gettempdir(), "psm_abort_trace_%d.so" % os.getuid())
+    src = os.path.join(ROOT, "tests", "abort_trace.c")
+    try:
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.run([gcc, "-O1", "-g", "-shared", "-fPIC", src, "-o", so], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        ctypes.CDLL(so).abort_trace_install()
+    except Exception:
+        pass
+
+
+_install_abort_trace()
+
 # BLAS pools sized to the CPU share of this process (a GPU box may expose 128 cores but grant 16)
 import psm_amd  # noqa: E402
 _blas_limit = psm_amd.hostinfo.limit_blas_threads()
