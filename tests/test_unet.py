@@ -148,6 +148,30 @@ def test_gpu_unet_bf16_fused_level_pairs(ny, nx, n, keep, monkeypatch):
     assert np.linalg.norm(out - out2) / np.linalg.norm(out2) <= 1e-2
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("c_in,widths,c_out", [(4, (16, 32), 1), (3, (16, 32, 64), 2), (4, (16, 32, 48), 1)])
+def test_gpu_unet_bf16_pairs_other_shapes(c_in, widths, c_out, monkeypatch):
+    """Fused level pairs on other networks: the 4-channel stem (pressureSM_Poisson's image), two head outputs, a 48-channel
+    level under the 32-channel pair (its upsample source then has 48 channels: not a multiple of 32, so that pair falls back
+    to two launches while the others stay fused)."""
+    from psm_amd import UNetSurrogate
+    monkeypatch.setenv("PSM_UNET_PAIR_MIN", "1")
+    specs = uo.unet_specs(c_in, widths, c_out)
+    W = uo.he_weights(specs, seed=50 + c_in)
+    m = 1 << (len(widths) - 1)
+    ny, nx = 18 * m, 34 * m
+    g = np.random.default_rng(c_in).standard_normal((2, ny, nx, c_in)).astype(np.float32)
+    with UNetSurrogate(W, ny, nx, c_in=c_in, c_out=c_out, widths=widths, max_cases=2, precision="bf16", keep_activations=True) as net:
+        out = net.forward(g)
+        for k in range(2):
+            ref, acts = uo.unet_forward(g[k], W, widths, return_all=True, precision="bf16")
+            for i in range(len(specs) - 1):
+                a = net.activation(i, 2)[k]
+                err = np.linalg.norm(a - acts[i]) / max(np.linalg.norm(acts[i]), 1e-12)
+                assert err <= 1e-2, (specs[i].name, err)
+            assert np.linalg.norm(out[k] - ref) / np.linalg.norm(ref) <= 1e-2
+
+
 def test_bf16_rounding_helper():
     x = np.array([1.0, 1.00390625, 1.0078125, -3.1415927, 0.0], np.float32)       # 1 + 2^-8 ties to even -> 1.0
     np.testing.assert_array_equal(uo.bf16_round(x), np.array([1.0, 1.0, 1.0078125, -3.140625, 0.0], np.float32))
