@@ -17,6 +17,9 @@
 // lane half h) so that one 16-byte read per lane feeds four MFMAs; both operands use it.
 #include "psm_kernels.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 thread_local PsmLaunchProbe* psm_launch_probe = nullptr;
 
 #include <hip/hip_ext.h>
@@ -123,10 +126,13 @@ __global__ __launch_bounds__(256) void psm_encode_kernel(PsmEncodeArgs a) {
     // are requested in one go -- one memory round trip in front of the MFMAs instead of one per 64-row chunk --, staged
     // (rows beyond M as zeros, always 128 of them: no conditional stores), then the 2-4 row tiles run back to back with
     // the partial-sum stores of tile mt under the MFMAs of tile mt + 1.
+    // The first row tile and the weight slice are requested first; the first tile's MFMAs start as soon as its rows and
+    // the first weight group have landed (counted vmcnt) and run under the rest of the stream; the other tiles are
+    // staged after them (their own LDS rows: no hazard with tile 0 being read).
     const int t = min(wave, NT - 1);
+    PSM_STAMP(0, 0);
     float4 x[PSM_MT_CHUNK][8];
-#pragma unroll
-    for (int q = 0; q < PSM_MT_CHUNK; ++q) load_rows(x[q], 0, 32 * q);
+    load_rows(x[0], 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     float4 b[G];
     {
@@ -135,11 +141,23 @@ __global__ __launch_bounds__(256) void psm_encode_kernel(PsmEncodeArgs a) {
       for (int g = 0; g < G; ++g) b[g] = stream_load(p + g * 64);
     }
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < PSM_MT_CHUNK; ++q) write_rows(x[q], 0, 32 * q);
+    write_rows(x[0], 0, 0);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    PSM_STAMP(0, 1);
+    // the other row tiles are requested only now: asked for up front, together with everything else, they delayed the
+    // first tile's rows (5.3 us to the first MFMA instead of ~3); they land under the first tile's 3 us of MFMAs
+#pragma unroll
+    for (int q = 1; q < PSM_MT_CHUNK; ++q) load_rows(x[q], 0, 32 * q);
+    __builtin_amdgcn_sched_barrier(0);
     gemm_tile(b, 0, t, 0, wave < NT);
+    PSM_STAMP(0, 3);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 1; q < PSM_MT_CHUNK; ++q) write_rows(x[q], 0, 32 * q);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    PSM_STAMP(0, 4);
     for (int mt = 1; mt < a.Mpad / 32; ++mt) gemm_tile(b, mt, t, 0, wave < NT);
+    PSM_STAMP(0, 2);
     return;
   }
 
@@ -1838,10 +1856,27 @@ hipError_t psm_launch_decode_paste_batch(const PsmDecodeArgs& a, const PsmBoundB
   if (c_out != 1 && c_out != 2) return hipErrorInvalidValue;
   const int nwg = (a.n_coltiles + 3) / 4;
   // at most 3 tiles of 32 rows per chunk: the 4-tile form of this kernel spills (acc + tile + row operands)
-  const int tiles = a.Mpad / 32, iters = (tiles + 2) / 3, mtc = (tiles + iters - 1) / iters, wpb = (128 / c_out) / 32, R = mtc * 32;
+  // Row tiles per chunk (mtc <= 3: the 4-tile form spills) and row groups (grid.y).  With 256 or more column workgroups:
+  // the most rows per pass over the weights.  With fewer (a single-field basis: 128) the rows are spread over up to
+  // 512 / nwg groups, one chunk each where possible -- 8 cases x 9 blocks of a one-field model ran as 128 workgroups of 3
+  // tiles (14.7 us), as 384 workgroups of one tile they take 10.6 us.  PSM_DECODE_MTC forces mtc (diagnostic).
+  const int tiles = a.Mpad / 32, wpb = (128 / c_out) / 32;
+  static const int mtc_force = getenv("PSM_DECODE_MTC") ? atoi(getenv("PSM_DECODE_MTC")) : 0;
+  int mtc, groups;
+  if (nwg >= 256 || mtc_force) {
+    const int it3 = (tiles + 2) / 3;
+    mtc = mtc_force ? std::min(std::max(mtc_force, 1), 3) : (tiles + it3 - 1) / it3;
+    const int iters = (tiles + mtc - 1) / mtc;
+    groups = 1;
+    while (nwg * groups < 256 && groups * 2 <= iters) groups *= 2;
+    if (mtc_force) groups = std::min(iters, std::max(1, 512 / nwg));
+  } else {
+    const int cap = std::max(1, 512 / nwg);
+    mtc = std::min(3, std::max(1, (tiles + cap - 1) / cap));
+    groups = std::min((tiles + mtc - 1) / mtc, cap);
+  }
+  const int R = mtc * 32;
   const size_t lds = ((size_t)R * (a.ld_res + 4) + R + (size_t)R * c_out + (size_t)R * wpb + 2 * (size_t)R + 2 * (size_t)p.B) * sizeof(float);
-  int groups = 1;
-  while (nwg * groups < 256 && groups * 2 <= iters) groups *= 2;
   const dim3 grid(nwg, groups);
 #define DP(M_, C_, L_)                                                                                                          \
   do {                                                                                                                          \
