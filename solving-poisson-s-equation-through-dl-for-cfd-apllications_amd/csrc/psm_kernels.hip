@@ -788,12 +788,20 @@ hipError_t psm_launch_decode(const PsmDecodeArgs& a, hipStream_t st) {
   if (a.ld_res == 128) {
     // <= 128 components: ONE launch for any number of block rows; a workgroup keeps its weight slice in
     // registers and walks the rows in chunks of MTC*32 (chunk size chosen to waste the fewest padded tiles)
-    const int tiles = a.Mpad / 32, iters = (tiles + 3) / 4, mtc = (tiles + iters - 1) / iters;
+    // one output channel gives only 128 column workgroups: the row tiles are then spread over up to 512 / nwg row groups,
+    // one chunk each where possible, so that all 256 CUs work (each group re-reads the weight slice: 8 MB more traffic
+    // per group; same rule as psm_launch_decode_paste_batch, where it was measured)
+    const int tiles = a.Mpad / 32;
+    int mtc, groups;
+    if (nwg >= 256) {
+      const int iters = (tiles + 3) / 4;
+      mtc = (tiles + iters - 1) / iters; groups = 1;
+    } else {
+      const int cap = std::max(1, 512 / nwg);
+      mtc = std::min(4, std::max(1, (tiles + cap - 1) / cap));
+      groups = std::min((tiles + mtc - 1) / mtc, cap);
+    }
     const size_t lds128 = (size_t)mtc * 32 * (a.ld_res + 4) * sizeof(float) + (size_t)mtc * 32 * sizeof(float);
-    // one output channel gives only 128 column workgroups: with several row chunks, deal them to two or
-    // more row groups so that all 256 CUs work (each group re-reads the weight slice: 8 MB more traffic)
-    int groups = 1;
-    while (nwg * groups < 256 && groups * 2 <= iters) groups *= 2;
     const dim3 grid(nwg, groups);
     if (mtc == 4) PSM_LAUNCH((psm_decode128_kernel<4>), grid, dim3(256), lds128, st, a, 0, a.Mpad);
     else if (mtc == 3) PSM_LAUNCH((psm_decode128_kernel<3>), grid, dim3(256), lds128, st, a, 0, a.Mpad);
