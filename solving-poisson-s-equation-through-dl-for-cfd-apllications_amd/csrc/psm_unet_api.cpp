@@ -172,11 +172,14 @@ void choose_config(Conv& c, int H, int W, int n_cases, bool can_split, int chunk
   }
   c.n_chunks = (c.cin + chunk_ch - 1) / chunk_ch;
   // split the input channels over workgroups until the chip is filled (partial-sum slabs, see psm_unet.h); only
-  // layers whose output feeds another convolution can be split, at most 8 ways, at least 2 chunks per split
+  // layers whose output feeds another convolution can be split, at most 8 ways
   const int th = psm_conv_tile_rows(c.arrangement);
   const long wgs = (long)((W + 15) / 16) * ((H + th - 1) / th) * c.groups * n_cases;
   c.ksplit = 1;
-  while (can_split && wgs * c.ksplit < fill && c.ksplit < ks_max && c.n_chunks / (c.ksplit * 2) >= 2) c.ksplit *= 2;
+  // chunks per split, at least (1: measured at batch 1, 174 -> 166 us in float32 and 107 -> 105 us in bf16 against 2 --
+  // the 16^2 layer with 4 chunks runs as 128 workgroups instead of 64; no change at 8 cases per step)
+  const int min_chunks = getenv("PSM_UNET_SPLIT_MIN_CHUNKS") ? atoi(getenv("PSM_UNET_SPLIT_MIN_CHUNKS")) : 1;
+  while (can_split && wgs * c.ksplit < fill && c.ksplit < ks_max && c.n_chunks / (c.ksplit * 2) >= min_chunks) c.ksplit *= 2;
 }
 
 int upload_conv(psm_unet* u, Conv& c) {
@@ -387,6 +390,16 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
     // a 3x3 layer none of whose inputs arrives as split-K slabs (those loaders sum float32 slabs) and whose concatenation
     // seam lies on a chunk boundary; a consumer with one float32 input takes all its inputs in float32.
     const size_t n = u->convs.size();
+    // level pairs come first: two convolutions that the pair kernels could take (shape and tile count) are not split over K
+    // -- a pair has no slabs, and a level large enough for a pair fills the chip without them
+    const long pair_min = getenv("PSM_UNET_PAIR_MIN") ? atol(getenv("PSM_UNET_PAIR_MIN")) : 96;
+    for (size_t i = 0; u->bf16 && getenv("PSM_UNET_NO_PAIR") == nullptr && i + 1 < n; ++i) {
+      Conv& A = u->convs[i]; Conv& B = u->convs[i + 1];
+      if (A.k != 3 || B.k != 3 || B.src != 1 || A.level != B.level || B.cin != A.cout || B.cout != A.cout || (A.cout != 16 && A.cout != 32)) continue;
+      const int H = ny >> A.level, W = nx >> A.level;
+      if ((long)((W + PSM_PAIR_TX - 1) / PSM_PAIR_TX) * ((H + PSM_PAIR_TY - 1) / PSM_PAIR_TY) * max_cases < pair_min) continue;
+      A.ksplit = 1; B.ksplit = 1;
+    }
     std::vector<char> obf(n, 0);
     for (size_t i = 0; i < n; ++i) obf[i] = (u->bf16 && u->convs[i].k == 3 && u->convs[i].ksplit == 1 && getenv("PSM_UNET_F32_ACT") == nullptr) ? 1 : 0;
     for (bool changed = true; changed;) {
@@ -407,7 +420,6 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
     for (size_t i = 0; i < n; ++i) u->convs[i].out_bf = obf[i] != 0;
     // fused level pairs (psm_unet_pair.hip): both 3x3 convolutions of a level in one launch, where the level is wide
     // enough to fill the chip with 30 x 14 tiles and the shapes are ones the pair kernels are written for
-    const long pair_min = getenv("PSM_UNET_PAIR_MIN") ? atol(getenv("PSM_UNET_PAIR_MIN")) : 96;
     for (size_t i = 0; i + 1 < n; ++i) { u->convs[i].pair = 0; u->convs[i + 1].pair = 0; }
     for (size_t i = 0; u->bf16 && getenv("PSM_UNET_NO_PAIR") == nullptr && i + 1 < n; ++i) {
       Conv& A = u->convs[i]; Conv& B = u->convs[i + 1];

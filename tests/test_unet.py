@@ -133,14 +133,18 @@ def test_gpu_unet_bf16_fused_level_pairs(ny, nx, n, keep, monkeypatch):
         out = net.forward(grids)
         for k in range(n):
             ref, acts = uo.unet_forward(grids[k], W, return_all=True, precision="bf16")
+            on_chip = []
             for i in range(len(specs) - 1):
-                if not keep and i in (0, 2, 14, 16, 17):           # enc0a, enc1a, dec1a, dec0a and dec0b (head fused) stay on chip
-                    with pytest.raises(_lib.PsmError):
-                        net.activation(i, n)
+                try:
+                    a = net.activation(i, n)[k]
+                except _lib.PsmError:                              # kept on chip by a fused pair (never with keep_activations)
+                    assert not keep
+                    on_chip.append(i)
                     continue
-                a = net.activation(i, n)[k]
                 err = np.linalg.norm(a - acts[i]) / max(np.linalg.norm(acts[i]), 1e-12)
                 assert err <= 1e-2, (specs[i].name, err)
+            if not keep:                                           # the level-0 pairs at least: enc0a, dec0a and dec0b (head fused); the
+                assert {0, 16, 17} <= set(on_chip) <= {0, 2, 14, 16, 17}, on_chip     # 128^2 pairs depend on what the planner splits
             assert np.linalg.norm(out[k] - ref) / np.linalg.norm(ref) <= 1e-2
     monkeypatch.setenv("PSM_UNET_NO_PAIR", "1")                    # and the unfused path gives the same field to bf16 rounding flips
     with UNetSurrogate(W, ny, nx, max_cases=n, precision="bf16") as net:
