@@ -176,9 +176,11 @@ void choose_config(Conv& c, int H, int W, int n_cases, bool can_split, int chunk
   const int th = psm_conv_tile_rows(c.arrangement);
   const long wgs = (long)((W + 15) / 16) * ((H + th - 1) / th) * c.groups * n_cases;
   c.ksplit = 1;
-  // chunks per split, at least (1: measured at batch 1, 174 -> 166 us in float32 and 107 -> 105 us in bf16 against 2 --
-  // the 16^2 layer with 4 chunks runs as 128 workgroups instead of 64; no change at 8 cases per step)
-  const int min_chunks = getenv("PSM_UNET_SPLIT_MIN_CHUNKS") ? atoi(getenv("PSM_UNET_SPLIT_MIN_CHUNKS")) : 1;
+  // chunks per split, at least: one for layers of four or more chunks, two below.  Measured at batch 1 against "two
+  // everywhere": float32 174 -> 167 us, bf16 107 -> 98 us (the 16^2 layer with 4 chunks runs as 128 workgroups instead of
+  // 64); one everywhere also splits the 2-chunk layers, whose consumers then read float32 slabs: bf16 105 us.  No change at
+  // 8 cases per step.
+  const int min_chunks = getenv("PSM_UNET_SPLIT_MIN_CHUNKS") ? atoi(getenv("PSM_UNET_SPLIT_MIN_CHUNKS")) : (c.n_chunks >= 4 ? 1 : 2);
   while (can_split && wgs * c.ksplit < fill && c.ksplit < ks_max && c.n_chunks / (c.ksplit * 2) >= min_chunks) c.ksplit *= 2;
 }
 
