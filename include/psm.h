@@ -53,6 +53,7 @@ extern "C" {
 #define PSM_ERR_NO_DEVICE   -4 /* no usable gfx950 device */
 #define PSM_ERR_UNSUPPORTED -5 /* shape the reference itself cannot process */
 #define PSM_ERR_NOMEM       -6
+#define PSM_ERR_GEOMETRY    -7 /* a device-pointer solve ran on a grid whose flow-cell pattern is not the bound one */
 
 /* intermediate results readable with psm_read_stage (parity tests) */
 #define PSM_STAGE_X_INPUT    0 /* [rows, p_in]   scaled network input (PM:351)      */
@@ -136,7 +137,15 @@ int psm_grid_shape(const psm_handle* h, int32_t* shape);
  * is stale while bound).  Same results as the unbound path up to float32 summation order.
  * CONTRACT: until psm_unbind_geometry / a new bind / a model or plan change, the SDF channel of every solved grid
  * must have the flow-cell pattern of the bound one; the other channels are free.  Case counts other than the bound
- * one keep the general path.  bf16 handles: the decode rounds the network output to bf16, so their
+ * one keep the general path.
+ * The contract is CHECKED ON THE DEVICE at every bound solve: spare waves of the launch that computes the strip dots
+ * compare the pattern of the grid being solved (one ballot per 64 pixels) with the bound one.  On a mismatch the
+ * solve's field is NaN everywhere -- never a plausible field of the wrong geometry -- and a flag in mapped pinned
+ * memory is raised.  The host-buffer entries (psm_solve_grid, psm_wait_grid, psm_ring_wait) see the flag when the
+ * solve has finished, drop the binding, solve the same grid again on the general path and return the correct
+ * field with PSM_OK (psm_last_error tells, psm_guard_trips counts); after psm_solve_grid_device the NaN field is
+ * what the caller gets and the next psm_synchronize returns PSM_ERR_GEOMETRY (binding dropped).  The riders use
+ * CUs the head layer leaves idle; PSM_NO_GUARD=1 in the environment removes them (diagnostic).  bf16 handles: the decode rounds the network output to bf16, so their
  * strip dots are taken from the rounded output in a small launch of their own (7 launches; same rounding points as
  * the general bf16 path).  Grids of more than 64 blocks (the reference's shipped 400 x 3000 case has 104) take a
  * two-launch form of the end: one chain launch, then decode + paste in row chunks (7 launches instead of 9).
@@ -152,6 +161,8 @@ int psm_geometry_bound(const psm_handle* h);   /* 1 while a geometry is bound */
 /* The flow-cell pattern that was bound: mask [bound cases][ny*nx] (1 = SDF channel != 0), for callers that want to check
  * the contract above on their side (cap = bytes available).  PSM_ERR_STATE when nothing is bound. */
 int psm_bound_mask(const psm_handle* h, uint8_t* mask, size_t cap);
+/* Number of solves so far whose grid was not the bound geometry (each dropped the binding). */
+int64_t psm_guard_trips(const psm_handle* h);
 
 /* ---- per-step solve: grid-native counterpart of py_func (PM:249-517) and of
  *      Evaluation.timeStep from block extraction to assemble_prediction

@@ -22,7 +22,7 @@ PRECISIONS = {"f32": 0, "bf16": 1}
 STAGES = {"x_input": 0, "res": 1, "block_pred": 2, "offsets": 3, "shift": 4}
 KERNELS = ("encode", "reduce", "mlp", "decode", "strips", "chain", "paste")
 ERRORS = {0: "PSM_OK", -1: "PSM_ERR_ARG", -2: "PSM_ERR_STATE", -3: "PSM_ERR_HIP", -4: "PSM_ERR_NO_DEVICE",
-          -5: "PSM_ERR_UNSUPPORTED", -6: "PSM_ERR_NOMEM"}
+          -5: "PSM_ERR_UNSUPPORTED", -6: "PSM_ERR_NOMEM", -7: "PSM_ERR_GEOMETRY"}
 
 
 class PsmLibraryError(RuntimeError):
@@ -59,6 +59,7 @@ SIGNATURES = {
     "psm_unbind_geometry": (C.c_int, [_hp]),
     "psm_geometry_bound": (C.c_int, [_hp]),
     "psm_bound_mask": (C.c_int, [_hp, C.POINTER(C.c_uint8), C.c_size_t]),
+    "psm_guard_trips": (C.c_int64, [_hp]),
     "psm_solve_grid": (C.c_int, [_hp, _f32p, C.c_int32, _f32p, _f32p]),
     "psm_grid_shape": (C.c_int, [_hp, _i32p]),
     "psm_ring_acquire": (C.c_int, [_hp, C.POINTER(C.c_int64), C.POINTER(_f32p), C.POINTER(_f32p)]),

@@ -57,6 +57,8 @@ struct Workspace {
   float2* d_colpart = nullptr;
   float *d_offs = nullptr, *d_shift = nullptr;
   float* d_dots = nullptr;            // strip dots of the geometry-bound path (allocated by the bind)
+  float* d_gflags = nullptr;          // guard flags of the bound-geometry contract (psm_kernels.h PsmGuardArgs; allocated by the bind)
+  int gidx = 0;                       // this workspace's word in the handle's mapped guard page (0 = ws0, 1 + i = ring slot i)
 };
 }  // namespace
 
@@ -109,6 +111,9 @@ struct psm_handle {
     float *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr, *h_rs = nullptr;
     float *m_in = nullptr, *m_out = nullptr, *m_rs = nullptr;   // device-side addresses of the pinned buffers (mapped)
     Workspace ws;
+    const float* last_src = nullptr;   // what the ticket in flight was launched with (re-run on the general path when
+    float* last_dst = nullptr;         // the guard of the bound-geometry contract trips)
+    std::vector<float> last_scale;
     hipStream_t st = nullptr;
     hipEvent_t ev_out = nullptr;
     hipGraphExec_t g_full = nullptr, g_kern = nullptr;   // H2D + kernels + D2H on the slot's own buffers / the kernels alone
@@ -156,6 +161,13 @@ struct psm_handle {
   std::vector<uint8_t> bound_mask;      // [bound_cases][Ny*Nx] flow-cell pattern that was bound (psm_bound_mask)
   int32_t* d_row_of = nullptr;
   uint32_t* d_ownbits = nullptr;
+  // guard of the bound-geometry contract (psm_kernels.h PsmGuardArgs)
+  unsigned long long* d_maskbits = nullptr;   // bound flow-cell pattern, one 64-pixel ballot per word
+  int guard_ballots = 0, guard_waves = 0;
+  bool guard_on = true;                 // PSM_NO_GUARD=1 switches the riders off (diagnostic)
+  int *h_guard = nullptr, *m_guard = nullptr;   // mapped pinned page: one word per workspace, raised by a guard wave on mismatch
+  float* d_gzero = nullptr;             // one zero: the flags of solves without a guard
+  int64_t guard_trips = 0;
   int debug_skip = 0;                   // PSM_DEBUG_SKIP bit mask of kernel groups NOT launched (timing experiments only)
   bool fuse_reduce_dense1 = true;       // PSM_NO_FUSED_REDUCE=1 disables
   int last_cases = 0;
@@ -282,6 +294,16 @@ void destroy_graphs(psm_handle* h) {
 void ws_free(Workspace& w) {
   dev_free(w.d_part); dev_free(w.d_xin); dev_free(w.d_act[0]); dev_free(w.d_act[1]); dev_free(w.d_res); dev_free(w.d_pred);
   dev_free(w.d_row_scale); dev_free(w.d_spart); dev_free(w.d_colpart); dev_free(w.d_offs); dev_free(w.d_shift); dev_free(w.d_dots);
+  dev_free(w.d_gflags);
+}
+
+// flags of one solve's guard waves: zero until a wave finds a mismatch (every wave rewrites its flag on every solve)
+int ws_alloc_guard(psm_handle* h, Workspace& w) {
+  if (!h->guard_waves) return PSM_OK;
+  int rc = dev_alloc(h, &w.d_gflags, (size_t)h->guard_waves);
+  if (rc) return rc;
+  HIPCHK(h, hipMemset(w.d_gflags, 0, (size_t)h->guard_waves * sizeof(float)));
+  return PSM_OK;
 }
 
 int ws_alloc(psm_handle* h, Workspace& w) {
@@ -303,6 +325,7 @@ int ws_alloc(psm_handle* h, Workspace& w) {
   HIPCHK(h, hipMemset(w.d_act[0], 0, (size_t)h->Mpad_cap * h->max_width * sizeof(float)));
   HIPCHK(h, hipMemset(w.d_act[1], 0, (size_t)h->Mpad_cap * h->max_width * sizeof(float)));
   if (h->bound && h->bound_dots) { if ((rc = dev_alloc(h, &w.d_dots, h->bound_dots))) return rc; }
+  if (h->bound && (rc = ws_alloc_guard(h, w))) return rc;
   return PSM_OK;
 }
 
@@ -326,7 +349,9 @@ void free_plan(psm_handle* h) {
     if (s.d_out) (void)hipFree(s.d_out);
     if (s.ev_out) (void)hipEventDestroy(s.ev_out);
     ws_free(s.ws);
+    const int gidx = s.ws.gidx;
     s = psm_handle::Slot{};
+    s.ws.gidx = gidx;
   }
   h->ring_ready = false;
   destroy_graphs(h);
@@ -496,6 +521,17 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
     tm.after(PSM_K_ENCODE);
   }
 
+  // bound-geometry contract: guard riders in the launch that computes the strip dots (not for psm_solve, whose grid is
+  // built from the bound sdfunct itself)
+  PsmGuardArgs ga{};
+  const bool guard = use_bound && h->guard_on && h->bound_scope == 2 && h->d_maskbits && w.d_gflags;
+  if (guard) {
+    ga.sdf = d_grid + h->cfg.sdf_channel; ga.bits = h->d_maskbits; ga.flags = w.d_gflags;
+    ga.host_flag = h->m_guard ? h->m_guard + w.gidx : nullptr;
+    ga.npix = (long long)n_cases * h->Ny * h->Nx; ga.c_in = h->cfg.c_in; ga.n_ballots = h->guard_ballots; ga.n_waves = h->guard_waves;
+  }
+  const float* gflags = guard ? w.d_gflags : h->d_gzero;
+  const int n_gwaves = guard ? h->guard_waves : 1;
   PsmReduceArgs ra{w.d_part, w.d_xin, h->d_ia, h->d_ib, h->n_slices, Mpad, h->ld_in};
   const int nl = (int)h->dense.size();
   auto dense_args = [&](int l, const float* cur, int ld_cur) {
@@ -536,7 +572,7 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
     for (int l = l_first; l < nl; ++l) {
       PsmDenseArgs da = dense_args(l, cur, ld_cur);
       if (use_bound && !bf16 && l == nl - 1) { // head layer + strip dots of the bound geometry in one launch
-        PsmDotsArgs dd{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, w.d_dots, h->bound_rows * n_cases, h->dense[nl - 1].Kpad};
+        PsmDotsArgs dd{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, w.d_dots, h->bound_rows * n_cases, h->dense[nl - 1].Kpad, ga};
         HIPCHK(h, psm_launch_dense_dots(da, dd, st));
       } else {
         HIPCHK(h, psm_launch_dense(da, st));
@@ -555,12 +591,13 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
     ba.blk_y0x0 = h->d_blk; ba.shiftW = h->d_shiftW;
     for (int f = 0; f < 2; ++f) ba.shiftL[f] = (int)h->plan.shiftA[f].size();
     ba.fields = d_fields; ba.offs = w.d_offs; ba.shift = w.d_shift; ba.Nx = h->Nx; ba.n_strips = h->n_strips; ba.B = h->B;
+    ba.gflags = gflags; ba.n_gwaves = n_gwaves;
     if (h->bound_zero_fill)                    // cells no block covers stay 0 like the reference's np.zeros field
       HIPCHK(h, hipMemsetAsync(d_fields, 0, (size_t)n_cases * h->Ny * h->Nx * h->cfg.c_out * sizeof(float), st));
     if (n_cases == 1 && h->B <= 64) {
       tm.before(PSM_K_DECODE);
       if (bf16) {                               // strip dots from the bf16-rounded res (own small launch)
-        PsmDotsArgs dd{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, w.d_dots, h->bound_rows, h->ld_out};
+        PsmDotsArgs dd{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, w.d_dots, h->bound_rows, h->ld_out, ga};
         HIPCHK(h, psm_launch_res_dots(dd, w.d_res, h->ld_out, st));
       }
       PSM_REPEAT(h, PSM_K_DECODE) HIPCHK(h, psm_launch_decode_paste(de, ba, h->cfg.c_out, st, bf16 ? 1 : 0));
@@ -577,11 +614,12 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
     for (int f = 0; f < 2; ++f) bb.shiftL[f] = (int)h->plan.shiftA[f].size();
     bb.fields = d_fields; bb.offs = w.d_offs; bb.shift = w.d_shift; bb.Nx = h->Nx; bb.npix = h->Ny * h->Nx;
     bb.n_strips = h->n_strips; bb.B = h->B; bb.rows_pc = h->bound_rows; bb.n_cases = n_cases;
+    bb.gflags = gflags; bb.n_gwaves = n_gwaves;
     tm.before(PSM_K_DECODE); tm.after(PSM_K_DECODE);
     tm.before(PSM_K_STRIPS); tm.after(PSM_K_STRIPS);
     tm.before(PSM_K_CHAIN);
     if (bf16) {                                 // strip dots from the bf16-rounded res (own small launch)
-      PsmDotsArgs dd{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, w.d_dots, h->bound_rows * n_cases, h->ld_out};
+      PsmDotsArgs dd{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, w.d_dots, h->bound_rows * n_cases, h->ld_out, ga};
       HIPCHK(h, psm_launch_res_dots(dd, w.d_res, h->ld_out, st));
     }
     HIPCHK(h, psm_launch_chain_dots(bb, h->cfg.c_out, st));
@@ -680,6 +718,25 @@ int solve_device(psm_handle* h, const float* d_grid, int n_cases, const float* o
   return PSM_OK;
 }
 
+// ---- guard of the bound-geometry contract, host side -------------------------------------------------------------
+// true once per trip: a guard wave of a solve on workspace `w` found a grid whose flow-cell pattern is not the bound one
+bool guard_take(psm_handle* h, Workspace& w) {
+  if (!h->h_guard) return false;
+  volatile int* f = h->h_guard + w.gidx;
+  if (!*f) return false;
+  *f = 0;
+  return true;
+}
+// drop the binding: the following solves (and the re-run of the one that tripped) take the general path
+int guard_drop(psm_handle* h, const char* where) {
+  ++h->guard_trips;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  destroy_graphs(h);
+  h->bound = false;
+  h->err = std::string(where) + ": the grid's flow-cell pattern (SDF channel != 0) is not the one bound with psm_bind_geometry; the binding was dropped";
+  return PSM_OK;
+}
+
 }  // namespace
 
 // ============================================================================
@@ -739,6 +796,22 @@ int psm_create(const psm_config* cfg, psm_handle** out) {
     return fail(nullptr, PSM_ERR_HIP, "cannot create a stream on the device");
   }
   for (int i = 0; i < psm_handle::RING; ++i) (void)hipEventCreateWithFlags(&h->scale_ev[i], hipEventDisableTiming);
+  // guard of the bound-geometry contract: one word per workspace in mapped pinned memory (host-side detection; without a
+  // mapped view the device-side NaN poisoning still works) and the zero the unguarded solves read as their flag
+  {
+    const char* ng = getenv("PSM_NO_GUARD");
+    h->guard_on = !(ng && ng[0] == '1');
+    if (hipHostMalloc((void**)&h->h_guard, 64 * sizeof(int), hipHostMallocMapped) == hipSuccess) {
+      memset(h->h_guard, 0, 64 * sizeof(int));
+      if (hipHostGetDevicePointer((void**)&h->m_guard, h->h_guard, 0) != hipSuccess) { (void)hipGetLastError(); h->m_guard = nullptr; }
+    } else { (void)hipGetLastError(); h->h_guard = nullptr; }
+    h->ws0.gidx = 0;
+    for (int i = 0; i < psm_handle::SLOTS; ++i) h->slot[i].ws.gidx = 1 + i;
+    if (hipMalloc((void**)&h->d_gzero, sizeof(float)) != hipSuccess || hipMemset(h->d_gzero, 0, sizeof(float)) != hipSuccess) {
+      psm_destroy(h);
+      return fail(nullptr, PSM_ERR_NOMEM, "hipMalloc failed");
+    }
+  }
   *out = h;
   return PSM_OK;
 }
@@ -756,6 +829,8 @@ void psm_destroy(psm_handle* h) {
   if (h->scr_pin) (void)hipHostFree(h->scr_pin);
   dev_free(h->d_comp_nat); dev_free(h->d_g2); dev_free(h->d_c2); dev_free(h->d_cnt); dev_free(h->d_row_of); dev_free(h->d_ownbits);
   dev_free(h->d_ia); dev_free(h->d_ib); dev_free(h->d_sa); dev_free(h->d_sb);
+  dev_free(h->d_maskbits); dev_free(h->d_gzero);
+  if (h->h_guard) (void)hipHostFree(h->h_guard);
   for (int i = 0; i < psm_handle::RING; ++i) {
     if (h->h_scale[i]) (void)hipHostFree(h->h_scale[i]);
     if (h->scale_ev[i]) (void)hipEventDestroy(h->scale_ev[i]);
@@ -1037,13 +1112,23 @@ static int bind_geometry_device(psm_handle* h, const float* d_grid, int n_cases 
     HIPCHK(h, hipMemcpy(g.data(), d_grid, g.size() * sizeof(float), hipMemcpyDeviceToHost));
     h->bound_mask.resize((size_t)n_cases * npix);
     for (size_t q = 0; q < (size_t)n_cases * npix; ++q) h->bound_mask[q] = g[q * cin + h->cfg.sdf_channel] != 0.f ? 1 : 0;
+    // the same pattern as the guard waves see it: one 64-pixel ballot per word (pixels beyond the end clamp to the last)
+    const size_t T = (size_t)n_cases * npix;
+    h->guard_ballots = (int)((T + 63) / 64);
+    h->guard_waves = (h->guard_ballots + PSM_GUARD_BALLOTS - 1) / PSM_GUARD_BALLOTS;
+    std::vector<unsigned long long> bits((size_t)h->guard_ballots, 0ull);
+    for (size_t w = 0; w < bits.size(); ++w)
+      for (int l = 0; l < 64; ++l)
+        if (h->bound_mask[std::min(w * 64 + l, T - 1)]) bits[w] |= 1ull << l;
+    if ((rc = dev_upload(h, &h->d_maskbits, bits))) return rc;
+    if ((rc = ws_alloc_guard(h, h->ws0))) return rc;
   }
   h->bound_rows = rows;
   h->bound_cases = n_cases;
   h->bound_dots = all;
   h->bound = true;
   if (h->ring_ready)
-    for (auto& s : h->slot) { if ((rc = dev_alloc(h, &s.ws.d_dots, all))) { h->bound = false; return rc; } }
+    for (auto& s : h->slot) { if ((rc = dev_alloc(h, &s.ws.d_dots, all)) || (rc = ws_alloc_guard(h, s.ws))) { h->bound = false; return rc; } }
   return PSM_OK;
 }
 
@@ -1112,6 +1197,14 @@ int psm_solve_grid(psm_handle* h, const float* grid, int32_t n_cases, const floa
   if (rc) return rc;
   HIPCHK(h, hipMemcpyAsync(reg_out ? fields : h->h_fields, h->d_fields_stage, gout, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, wait_stream(h->stream));
+  if (guard_take(h, h->ws0)) {                 // not the bound geometry: the field is NaN -- drop the binding, solve again on the general path
+    if ((rc = guard_drop(h, "psm_solve_grid"))) return rc;
+    const std::string note = h->err;
+    if ((rc = solve_device(h, h->d_grid_stage, n_cases, out_scale, h->d_fields_stage, h->stream, nullptr))) return rc;
+    HIPCHK(h, hipMemcpyAsync(reg_out ? fields : h->h_fields, h->d_fields_stage, gout, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, wait_stream(h->stream));
+    h->err = note + " (solved on the general path)";
+  }
   if (!reg_out) memcpy(fields, h->h_fields, gout);
   return PSM_OK;
 }
@@ -1220,6 +1313,9 @@ static int ring_launch(psm_handle* h, psm_handle::Slot& s, int n_cases, const fl
   const size_t gin = (size_t)n_cases * npix * h->cfg.c_in * sizeof(float), gout = (size_t)n_cases * npix * h->cfg.c_out * sizeof(float);
   const bool scale = out_scale != nullptr;
   const bool own = (src == s.h_in && dst == s.h_out);
+  if (h->h_guard) h->h_guard[s.ws.gidx] = 0;            // the slot is free: nothing of an earlier ticket can still raise it
+  s.last_src = src; s.last_dst = dst;
+  if (scale) { if (out_scale != s.last_scale.data()) s.last_scale.assign(out_scale, out_scale + n_cases); } else s.last_scale.clear();
   const float* src_dev = nullptr;
   float* dst_dev = nullptr;
   if (!h->ring_dma) {                                    // pull form needs device-side views of both host buffers
@@ -1268,6 +1364,20 @@ static int ring_check(psm_handle* h, int32_t n_cases) {
   return PSM_OK;
 }
 
+// A ticket whose grid was not the bound geometry (its field is NaN): drop the binding and run the ticket again on the
+// general path, from the same source into the same destination.
+static int ring_guard_rerun(psm_handle* h, psm_handle::Slot& s, const char* where) {
+  if (!guard_take(h, s.ws)) return PSM_OK;
+  int rc = guard_drop(h, where);
+  if (rc) return rc;
+  const std::string note = h->err;
+  std::vector<float> sc = s.last_scale;
+  if ((rc = ring_launch(h, s, s.n_cases, sc.empty() ? nullptr : sc.data(), s.last_src, s.last_dst))) return rc;
+  HIPCHK(h, wait_event(s.ev_out));
+  h->err = note + " (ticket solved again on the general path)";
+  return PSM_OK;
+}
+
 int psm_ring_acquire(psm_handle* h, int64_t* ticket, float** grid_in, float** fields_out) {
   if (!h) return PSM_ERR_ARG;
   if (!h->planned) return fail(h, PSM_ERR_STATE, "psm_plan_grid has not been called");
@@ -1312,6 +1422,7 @@ int psm_ring_wait(psm_handle* h, int64_t ticket) {
   if (rc) return rc;
   HIPCHK(h, hipSetDevice(h->cfg.device));
   HIPCHK(h, wait_event(s->ev_out));
+  if ((rc = ring_guard_rerun(h, *s, "psm_ring_wait"))) return rc;
   s->state = 0;
   return PSM_OK;
 }
@@ -1352,6 +1463,7 @@ int psm_wait_grid(psm_handle* h, int64_t ticket, float* fields) {
   if (s->direct_out && fields != s->user_out) return fail(h, PSM_ERR_ARG, "this ticket's field was DMA'd into the buffer given at submission");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   HIPCHK(h, wait_event(s->ev_out));
+  if ((rc = ring_guard_rerun(h, *s, "psm_wait_grid"))) return rc;
   if (!s->direct_out) memcpy(fields, s->h_out, (size_t)s->n_cases * h->Ny * h->Nx * h->cfg.c_out * sizeof(float));
   s->state = 0;
   return PSM_OK;
@@ -1830,8 +1942,14 @@ int psm_synchronize(psm_handle* h) {
   HIPCHK(h, hipSetDevice(h->cfg.device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipDeviceSynchronize());
+  if (guard_take(h, h->ws0)) {                 // a psm_solve_grid_device call on another geometry: its field is NaN
+    int rc = guard_drop(h, "psm_solve_grid_device");
+    return rc ? rc : PSM_ERR_GEOMETRY;
+  }
   return PSM_OK;
 }
+
+int64_t psm_guard_trips(const psm_handle* h) { return h ? h->guard_trips : -1; }
 
 int psm_read_stage(psm_handle* h, int32_t stage, float* dst, size_t dst_floats) {
   if (!h || !dst) return PSM_ERR_ARG;

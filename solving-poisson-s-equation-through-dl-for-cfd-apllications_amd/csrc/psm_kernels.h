@@ -126,9 +126,26 @@ struct PsmBindArgs {                   // table build, once per geometry
   int nst, B, S, c_in, c_out, sdf_ch, Ny, Nx, ld_out;
   int row_base;                        // case * B: row_of holds global block rows (case batches)
 };
+// Guard of the bound-geometry contract (psm.h: "the SDF channel of every solved grid must have the bound flow-cell
+// pattern"): extra waves of the launch that computes the strip dots re-derive the pattern of the grid BEING SOLVED --
+// one ballot per 64 consecutive pixels, 8 ballots per wave -- and compare it with the bound one.  A wave writes
+// flags[wave] = 0 (match) or NaN (mismatch) on every solve (no reset needed); the launch that writes the field adds the
+// sum of the flags to the global shift, so a solve on another geometry returns NaN everywhere instead of a plausible
+// wrong field, and *host_flag (mapped pinned memory) is raised for the host-side entries, which then fall back to the
+// general path.  The riders run on CUs the head layer leaves idle: no launch, nothing on the critical path.
+struct PsmGuardArgs {
+  const float* sdf;                    // grid + sdf_channel (pixel stride c_in floats); null: no guard waves
+  const unsigned long long* bits;      // [n_ballots] bound pattern, bit l of word g = pixel min(64 g + l, npix - 1) is a flow cell
+  float* flags;                        // [n_waves]
+  int* host_flag;                      // device-side address of the workspace's word in mapped pinned memory (may be null)
+  long long npix;                      // cases * Ny * Nx
+  int c_in, n_ballots, n_waves;
+};
+constexpr int PSM_GUARD_BALLOTS = 8;   // per guard wave: 512 pixels
 struct PsmDotsArgs {                   // rows: [c_out][nst] strip means, then [c_out][B] shift partial sums
   const float* g2; const float* c2; const float* cnt; const int32_t* row_of; const float* row_scale;
   float* out; int n_rows, Kh;
+  PsmGuardArgs guard;
 };
 struct PsmBoundArgs {
   PsmChainParams cp; const PsmBlock* blocks;
@@ -136,6 +153,7 @@ struct PsmBoundArgs {
   int shiftL[2];
   float* fields; float* offs; float* shift;
   int Nx, n_strips, B;
+  const float* gflags; int n_gwaves;   // guard flags of this solve (0 / NaN), summed into the shift; never null (>= 1 entry)
 };
 struct PsmBoundBatchArgs {             // case batches: chain in its own small launch, then decode + paste
   PsmChainParams cp; const PsmBlock* blocks;
@@ -145,6 +163,7 @@ struct PsmBoundBatchArgs {             // case batches: chain in its own small l
   int shiftL[2];
   float* fields; float* offs; float* shift;    // offs [cases][c_out][B], shift [cases][c_out]
   int Nx, npix, n_strips, B, rows_pc, n_cases;
+  const float* gflags; int n_gwaves;           // as in PsmBoundArgs
 };
 hipError_t psm_launch_bind(const PsmBindArgs& a, hipStream_t s);
 hipError_t psm_launch_chain_dots(const PsmBoundBatchArgs& p, int c_out, hipStream_t s);

@@ -495,6 +495,35 @@ hipError_t psm_launch_reduce_dense1(const PsmReduceArgs& r, const PsmDenseArgs& 
 // is bound by what ONE CU can pull per round trip) or 32 (weights read once per 32 rows).
 __device__ __forceinline__ float wave_sum(float v);
 
+// One guard wave (PsmGuardArgs): 8 ballots of 64 consecutive pixels each against the bound pattern.
+__device__ __forceinline__ void psm_guard_wave(const PsmGuardArgs& g, int gw, int lane) {
+  constexpr int NB = PSM_GUARD_BALLOTS;
+  float v[NB];
+  unsigned long long want[NB];
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {                       // all loads up front, clamped
+    const long long pix = min((long long)(gw * NB + u) * 64 + lane, g.npix - 1);
+    v[u] = g.sdf[pix * g.c_in];
+    want[u] = g.bits[min(gw * NB + u, g.n_ballots - 1)];
+  }
+  bool bad = false;
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {
+    const unsigned long long got = __ballot(v[u] != 0.f);           // NaN != 0 is true, like NumPy's `!= 0`
+    bad |= (gw * NB + u < g.n_ballots) && got != want[u];
+  }
+  if (lane == 0) {
+    g.flags[gw] = bad ? __int_as_float(0x7fc00000) : 0.f;
+    if (bad && g.host_flag) __hip_atomic_store(g.host_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+// sum of the guard flags of a solve (0, or NaN after a mismatch): one wave, every lane gets the total
+__device__ __forceinline__ float psm_guard_sum(const float* flags, int n, int lane, float f0, float f1) {
+  float gs = (lane < n ? f0 : 0.f) + (lane + 64 < n ? f1 : 0.f);
+  for (int k = lane + 128; k < n; k += 64) gs += flags[k];
+  return wave_sum(gs);
+}
+
 // DOTS (head layer of the geometry-bound path): workgroups with blockIdx.z > 0 do not compute the layer but the
 // strip dot products of psm_kernels.h (PsmDotsArgs) from the same input activation: one wave per two table rows,
 // every load issued up front (clamped), out[row] = scale * (act . g2[row] + c2[row]) / cnt[row]  (0/0 = NaN for an
@@ -505,6 +534,12 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a, PsmDotsA
     constexpr int RPW = 2, NQ = 4;                     // rows per wave; float4 per lane and row (Kh <= 1024)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wg = ((int)(blockIdx.z - 1) * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
+    const int n_dot_wgs = (d.n_rows + 8 * RPW - 1) / (8 * RPW);
+    if (wg >= n_dot_wgs) {                               // guard riders behind the dots workgroups (uniform per workgroup)
+      const int gw = (wg - n_dot_wgs) * 8 + wave;
+      if (gw < d.guard.n_waves) psm_guard_wave(d.guard, gw, lane);
+      return;
+    }
     const int nq = d.Kh / 4;
     f32x4 g[RPW][NQ], x[RPW][NQ];
     float c2[RPW], cn[RPW], rs[RPW];
@@ -627,8 +662,9 @@ hipError_t psm_launch_dense_dots(const PsmDenseArgs& a, const PsmDotsArgs& d, hi
   if (d.Kh < 4 || d.Kh % 4 != 0 || d.Kh > 1024 || d.Kh > a.ld_in || d.n_rows < 1) return hipErrorInvalidValue;
   const bool r16 = a.Mpad <= 128;                   // same tile choice as psm_launch_dense
   const int gx = a.ld_w / 16, gy = a.Mpad / (r16 ? 16 : 32);
-  const int per_plane = gx * gy * 8 * 2;            // rows per z plane: 8 waves x 2 rows per workgroup
-  const dim3 grid(gx, gy, 1 + (d.n_rows + per_plane - 1) / per_plane), blk(512);
+  // z planes > 0: ceil(n_rows / 16) dots workgroups (8 waves x 2 rows), then ceil(guard waves / 8) guard workgroups
+  const int extra = (d.n_rows + 15) / 16 + (d.guard.sdf ? (d.guard.n_waves + 7) / 8 : 0);
+  const dim3 grid(gx, gy, 1 + (extra + gx * gy - 1) / (gx * gy)), blk(512);
 #define DD(N)                                                                                          \
   do {                                                                                                 \
     if (r16) PSM_LAUNCH((psm_dense_kernel<N, false, 16, true>), grid, blk, 0, st, a, d);       \
@@ -1552,6 +1588,7 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
   const int cf = min(max(wave - 4, 0), C - 1);         // chain waves: their field
   const float w_shift = p.shiftW[cf * B + min(lane, B - 1)];
   const float s_raw = p.dots[C * nst + cf * B + min(lane, B - 1)];
+  const float gf0 = p.gflags[min(lane, p.n_gwaves - 1)], gf1 = p.gflags[min(lane + 64, p.n_gwaves - 1)];   // guard flags (0 / NaN)
   v4f x[NA];
 #pragma unroll
   for (int u = 0; u < NA; ++u) {                       // (the two chain waves load a clamped duplicate: 384 threads, 256 slots)
@@ -1625,7 +1662,8 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
     const float t = (lane < B && w_shift != 0.f) ? w_shift * offs[f * B + lane] : 0.f;   // same-wave LDS writes are visible
     const float t_shift = wave_sum(t);
     const float raw = wave_sum(lane < B ? s_raw : 0.f);
-    if (lane == 0) wred[f] = raw / (float)p.shiftL[f] / 3.f - t_shift;
+    const float guard = psm_guard_sum(p.gflags, p.n_gwaves, lane, gf0, gf1);   // NaN when the grid is not the bound geometry
+    if (lane == 0) wred[f] = raw / (float)p.shiftL[f] / 3.f - t_shift + guard;
     if (blockIdx.x == 0 && f == 0 && lane == 0) {
 #ifdef PSM_STAMPS
       g_psm_stamps[39] = __builtin_amdgcn_s_memrealtime();
@@ -1727,7 +1765,8 @@ __global__ __launch_bounds__(256) void psm_chain_dots_kernel(PsmBoundBatchArgs p
       p.offs[((int64_t)cs * C + wave) * B + b] = offs[wave * B + b];
     }
     const float t_shift = wave_sum(t), raw_all = wave_sum(raw);
-    if (lane == 0) p.shift[cs * C + wave] = raw_all / (float)p.shiftL[wave] / 3.f - t_shift;
+    const float guard = psm_guard_sum(p.gflags, p.n_gwaves, lane, p.gflags[min(lane, p.n_gwaves - 1)], p.gflags[min(lane + 64, p.n_gwaves - 1)]);
+    if (lane == 0) p.shift[cs * C + wave] = raw_all / (float)p.shiftL[wave] / 3.f - t_shift + guard;
   }
 }
 
@@ -1908,6 +1947,12 @@ hipError_t psm_launch_decode_paste_batch(const PsmDecodeArgs& a, const PsmBoundB
 // own (one wave per table row):  out[row] = scale * (bf16(res[b]) . G[row] + M[row]) / cnt[row]
 __global__ __launch_bounds__(256) void psm_res_dots_kernel(PsmDotsArgs d, const float* res, int ld_res) {
   const int lane = threadIdx.x & 63, row = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int n_dot_wgs = (d.n_rows + 3) / 4;
+  if ((int)blockIdx.x >= n_dot_wgs) {                    // guard riders (PsmGuardArgs)
+    const int gw = ((int)blockIdx.x - n_dot_wgs) * 4 + (int)(threadIdx.x >> 6);
+    if (gw < d.guard.n_waves) psm_guard_wave(d.guard, gw, lane);
+    return;
+  }
   const int rc = min(row, d.n_rows - 1);
   const int blk = d.row_of[rc];
   float acc = 0.f;
@@ -1924,7 +1969,8 @@ __global__ __launch_bounds__(256) void psm_res_dots_kernel(PsmDotsArgs d, const 
 
 hipError_t psm_launch_res_dots(const PsmDotsArgs& d, const float* res, int ld_res, hipStream_t st) {
   if (ld_res > 128 || ld_res < 1 || d.n_rows < 1) return hipErrorInvalidValue;
-  PSM_LAUNCH(psm_res_dots_kernel, dim3((d.n_rows + 3) / 4), dim3(256), 0, st, d, res, ld_res);
+  const int nwg = (d.n_rows + 3) / 4 + (d.guard.sdf ? (d.guard.n_waves + 3) / 4 : 0);
+  PSM_LAUNCH(psm_res_dots_kernel, dim3(nwg), dim3(256), 0, st, d, res, ld_res);
   return hipGetLastError();
 }
 

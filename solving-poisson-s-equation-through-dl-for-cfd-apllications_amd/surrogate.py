@@ -231,6 +231,11 @@ class GridSurrogate:
     def geometry_bound(self) -> bool:
         return bool(self.lib.psm_geometry_bound(self.h))
 
+    @property
+    def guard_trips(self) -> int:
+        """Solves so far whose grid was not the bound geometry (detected on the device; each dropped the binding)."""
+        return int(self.lib.psm_guard_trips(self.h))
+
     def solve_device(self, d_grid: int, n_cases: int, d_fields: int, stream: int = 0,
                      out_scale: Optional[Sequence[float]] = None):
         """Asynchronous solve on raw device pointers (e.g. ``torch.Tensor.data_ptr()``)."""

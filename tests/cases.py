@@ -32,6 +32,16 @@ GOLDEN_CASES = {
 }
 
 
+# Grids whose last block row duplicates the previous one (p_i == 0): the reference does not define an answer there.
+# U_to_gradP takes the mean of an empty slice (Eval_dual_Dense_onlycil.py:340) and the NaN offset reaches every cell
+# through the global shift (:359); deltaU_to_deltaP raises a broadcast error (SM_call.py:335).  BASELINE configs[1]
+# (256 rows, gradP) and configs[4] (512 rows, deltas) are such grids; `strict_degenerate=1` must reproduce exactly this.
+DEGENERATE_CASES = {
+    "gradp_degenerate_256x256":  dict(variant="gradp", Ny=256, Nx=256, seed=71, p=16),
+    "deltas_degenerate_512x512": dict(variant="deltas", Ny=512, Nx=512, seed=72, p=16, scaler="std"),
+}
+
+
 def real_chapter5_weights():
     d = np.load(os.path.join(GOLDEN_DIR, "chapter5_weights.npz"))
     n = len([k for k in d.files if k.startswith("W")])
@@ -49,7 +59,7 @@ def real_chapter4_weights(which: str):
 
 def build(name: str):
     """-> (grid[Ny,Nx,C] float64, SurrogateModel) for a GOLDEN_CASES entry."""
-    sp = GOLDEN_CASES[name]
+    sp = GOLDEN_CASES[name] if name in GOLDEN_CASES else DEGENERATE_CASES[name]
     v, Ny, Nx = sp["variant"], sp["Ny"], sp["Nx"]
     if sp.get("chapter4"):
         which = sp["chapter4"]

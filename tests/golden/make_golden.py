@@ -158,7 +158,7 @@ def run_gradp(grid6, model, keep_labels=False):
     return out
 
 
-def run_deltas(grid5, model, U_max_norm=1.0, max_abs_p=1.0):
+def run_deltas(grid5, model, U_max_norm=1.0, max_abs_p=1.0, _keep=None):
     """SMD.timeStep, from the block extraction to ``assemble_prediction``."""
     tree = _tree(SMD)
     glb = {"np": np, "ndimage": None}
@@ -191,6 +191,8 @@ def run_deltas(grid5, model, U_max_norm=1.0, max_abs_p=1.0):
                 _run(stmts, glb, loc, SMD)
         finally:
             os.chdir(cwd)
+            if _keep is not None:                        # what was computed before an exception of the reassembly
+                _keep.update({k: loc[k] for k in ("x_input", "N") if k in loc})
     return dict(x_input=np.asarray(loc["x_input"], np.float64), fields=np.asarray(loc["deltap_res"])[..., None],
                 n_blocks=np.int64(loc["N"]))
 
@@ -528,6 +530,25 @@ def main():
     out = run_poisson_features(cases.build_poisson_case())
     np.savez_compressed(os.path.join(HERE, "poisson_features_160x200.npz"), **out)
     print("poisson_features: |grid|max per channel", np.abs(out["grid"]).max(axis=(0, 1)))
+
+    # ---- p_i == 0 grids (BASELINE configs[1] / configs[4] shapes): what the reference's statements do there
+    for name, sp in cases.DEGENERATE_CASES.items():
+        grid, model = cases.build(name)
+        if sp["variant"] == "gradp":
+            out = run_gradp(grid, model)
+            f = out["fields"]
+            out["raised"] = np.int64(0)
+            print(f"{name}: B={int(out['n_blocks'])} NaN cells {int(np.isnan(f).sum())} of {f.size}")
+        else:
+            keep = {}
+            try:
+                run_deltas(grid, model, _keep=keep)
+                raised = 0
+            except ValueError as e:                      # 'could not broadcast input array ...' (SM_call.py:335)
+                raised = 1
+                print(f"{name}: the reference raises {type(e).__name__}")
+            out = dict(raised=np.int64(raised), x_input=np.asarray(keep["x_input"], np.float64), n_blocks=np.int64(keep["N"]))
+        np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
 
     for name in cases.GOLDEN_CASES:
         grid, model = cases.build(name)

@@ -35,6 +35,18 @@ def test_c_port_matches_numpy_oracle_on_baseline_shapes(variant, ny, nx):
     assert np.abs(f4 - f1).max() <= 1e-9 * np.abs(f1).max()                         # only the split-K summation order differs
 
 
+def test_c_port_strict_mode_on_the_degenerate_golden():
+    grid, model = cases.build("gradp_degenerate_256x256")
+    ref = cases.load_golden("gradp_degenerate_256x256")["fields"]
+    f = psm_cpu.solve_grid(grid, psm_cpu.CpuModel(oracle_model(model), strict=True))
+    np.testing.assert_array_equal(np.isnan(f), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    np.testing.assert_allclose(f[ok], ref[ok], rtol=1e-6, atol=2e-6 * np.abs(ref[ok]).max())
+    grid, model = cases.build("deltas_degenerate_512x512")
+    with pytest.raises(ValueError):
+        psm_cpu.solve_grid(grid, psm_cpu.CpuModel(oracle_model(model), strict=True))
+
+
 def test_c_port_refuses_what_the_reference_cannot_process():
     model = synthetic.make_model("deltas", p_in=8, p_out=8)
     g = synthetic.channel_grid(512, 512, seed=1)                                    # p_i == 0: broadcast error at SMD:335

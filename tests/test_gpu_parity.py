@@ -67,6 +67,45 @@ def test_golden_cases(name):
     assert rel_l2(fields, ref) <= 5e-5
 
 
+@pytest.mark.parametrize("bind", [False, True])
+def test_strict_degenerate_is_the_reference_on_p_i_zero_grids(bind):
+    """strict_degenerate=1 on the GPU: on the 256-row U_to_gradP grid (BASELINE configs[1] shape) the reference's own run
+    gives dp_dx = NaN everywhere (UGP:340 -> UGP:359) and dp_dy = NaN on the last block row's paste, finite elsewhere
+    (tests/golden/gradp_degenerate_256x256.npz); on a 512-row deltaU_to_deltaP grid (configs[4] shape) it raises
+    (SMD:335) -> PSM_ERR_UNSUPPORTED.  General and geometry-bound paths."""
+    name = "gradp_degenerate_256x256"
+    grid, model = cases.build(name)
+    ref = cases.load_golden(name)["fields"]
+    g32 = grid[..., :3].astype(np.float32)
+    with GridSurrogate(model, 256, 256, strict_degenerate=True) as sur:
+        assert sur.B == 30
+        if bind:
+            assert sur.bind_geometry(g32)
+        fields = sur.solve(g32)[0]
+        assert sur.geometry_bound == bind
+    np.testing.assert_array_equal(np.isnan(fields), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    assert ok.sum() == 224 * 256
+    assert np.abs(fields[ok] - ref[ok]).max() <= 2e-4 * np.abs(ref[ok]).max()
+    # the same grid in the build-defined default mode: finite everywhere
+    with GridSurrogate(model, 256, 256) as sur:
+        if bind:
+            assert sur.bind_geometry(g32)
+        assert np.isfinite(sur.solve(g32)[0]).all()
+    grid, model = cases.build("deltas_degenerate_512x512")
+    with pytest.raises(_lib.PsmError) as e:
+        GridSurrogate(model, 512, 512, strict_degenerate=True)
+    assert e.value.code == -5                           # PSM_ERR_UNSUPPORTED: the reference raises here
+    with GridSurrogate(model, 512, 512) as sur:
+        g32 = grid[..., :3].astype(np.float32)
+        if bind:
+            assert sur.bind_geometry(g32)
+        f = sur.solve(g32, out_scale=[model.out_scale])[0]
+        x = sur.stage("x_input")
+    assert np.isfinite(f).all()
+    assert rel_l2(x, cases.load_golden("deltas_degenerate_512x512")["x_input"]) <= 5e-6
+
+
 def test_config1_gradp_256_p128():
     """BASELINE config 1: 256x256 U_to_gradP, batch 1, fp32, P_i = P_o = 128, MLP_small."""
     model = synthetic.make_model("gradp")

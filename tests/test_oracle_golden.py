@@ -30,6 +30,33 @@ def test_oracle_matches_reference_run(name):
         assert a.covered.all()
 
 
+def test_oracle_strict_mode_is_the_reference_on_degenerate_grids():
+    """p_i == 0 (BASELINE configs[1] / configs[4] shapes): the reference's own statements give dp_dx = NaN everywhere
+    (UGP:340 -> UGP:359), dp_dy = NaN on the rows the last block row pastes and finite elsewhere, and raise a
+    broadcast error for deltaU_to_deltaP (SMD:335).  degenerate='strict' must reproduce exactly that."""
+    name = "gradp_degenerate_256x256"
+    grid, model = cases.build(name)
+    gold = cases.load_golden(name)
+    with np.errstate(all="ignore"):
+        sol = orc.solve_grid(grid, oracle_model(model), degenerate="strict")
+    ref = gold["fields"]
+    assert np.isnan(ref[..., 0]).all() and np.isnan(ref[224:, :, 1]).all() and not np.isnan(ref[:224, :, 1]).any()
+    np.testing.assert_array_equal(np.isnan(sol.fields), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    np.testing.assert_allclose(sol.fields[ok], ref[ok], rtol=1e-6, atol=1e-6 * np.abs(ref[ok]).max())
+    np.testing.assert_allclose(sol.x_input, gold["x_input"], rtol=1e-9, atol=1e-11)
+    name = "deltas_degenerate_512x512"
+    grid, model = cases.build(name)
+    gold = cases.load_golden(name)
+    assert int(gold["raised"]) == 1 and int(gold["n_blocks"]) == 30
+    with pytest.raises(ValueError):
+        orc.solve_grid(grid, oracle_model(model), degenerate="strict")
+    # the build-defined default still encodes the reference's block list: same coefficients
+    sol = orc.solve_grid(grid, oracle_model(model))
+    np.testing.assert_allclose(sol.x_input, gold["x_input"], rtol=1e-9, atol=1e-11)
+    assert np.isfinite(sol.fields).all()
+
+
 def test_labels_through_gradp_reassembly():
     """UGP:509-511,546-547: the labels, de-meaned per block, pushed through the
     same reassembly (the reference's own self-check)."""
