@@ -153,6 +153,87 @@ def test_gpu_unet_bf16_fused_level_pairs(ny, nx, n, keep, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pairs", ["planner", "forced", "off"])
+def test_gpu_unet_bf16_512x512_layer_by_layer(pairs, monkeypatch):
+    """BASELINE configs[4] as BASELINE.json words it -- 512x512, bf16 MFMA conv path, batch 1: every layer against the
+    bf16-rounding oracle, with the pair kernels as the planner places them, forced for every eligible level, and off."""
+    from psm_amd import UNetSurrogate
+    if pairs == "forced":
+        monkeypatch.setenv("PSM_UNET_PAIR_MIN", "1")
+    elif pairs == "off":
+        monkeypatch.setenv("PSM_UNET_NO_PAIR", "1")
+    specs = uo.unet_specs()
+    W = uo.he_weights(specs, seed=11)
+    g = synthetic.channel_grid(512, 512, seed=4, noise=0.05).astype(np.float32)
+    ref, acts = uo.unet_forward(g, W, return_all=True, precision="bf16")
+    with UNetSurrogate(W, 512, 512, precision="bf16", keep_activations=True) as net:
+        out = net.forward(g)[0]
+        for i in range(len(specs) - 1):
+            a = net.activation(i, 1)[0]
+            assert a.shape == acts[i].shape, specs[i].name
+            err = np.linalg.norm(a - acts[i]) / max(np.linalg.norm(acts[i]), 1e-12)
+            assert err <= 1e-2, (specs[i].name, err)
+    assert np.isfinite(out).all()
+    assert np.linalg.norm(out - ref) / np.linalg.norm(ref) <= 1e-2
+    with UNetSurrogate(W, 512, 512, precision="bf16") as net:       # the timed configuration: inner activations on chip
+        out2 = net.forward(g)[0]
+    assert np.linalg.norm(out2 - ref) / np.linalg.norm(ref) <= 1e-2
+
+
+@pytest.mark.gpu
+def test_gpu_unet_bf16_pairs_512x512_eight_cases():
+    """Pair kernels at 512x512 x 8 cases per step (the largest launch the bench times: 2312 tiles per level-0 pair): first,
+    middle and last case against the bf16 oracle end to end, the last one layer by layer as well."""
+    from psm_amd import UNetSurrogate
+    specs = uo.unet_specs()
+    W = uo.he_weights(specs, seed=11)
+    grids = np.stack([synthetic.channel_grid(512, 512, seed=60 + k, noise=0.05, cx=0.25 + 0.06 * k).astype(np.float32) for k in range(8)])
+    with UNetSurrogate(W, 512, 512, max_cases=8, precision="bf16", keep_activations=True) as net:
+        out = net.forward(grids)
+        ref, acts = uo.unet_forward(grids[7], W, return_all=True, precision="bf16")
+        for i in range(len(specs) - 1):
+            a = net.activation(i, 8)[7]
+            err = np.linalg.norm(a - acts[i]) / max(np.linalg.norm(acts[i]), 1e-12)
+            assert err <= 1e-2, (specs[i].name, err)
+        assert np.linalg.norm(out[7] - ref) / np.linalg.norm(ref) <= 1e-2
+    with UNetSurrogate(W, 512, 512, max_cases=8, precision="bf16") as net:
+        out2 = net.forward(grids)
+    assert np.isfinite(out2).all()
+    for k in (0, 4, 7):
+        ref = uo.unet_forward(grids[k], W, precision="bf16")
+        assert np.linalg.norm(out2[k] - ref) / np.linalg.norm(ref) <= 1e-2, k
+    assert np.linalg.norm(out2 - out) / np.linalg.norm(out) <= 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ny,nx", [(144, 208), (176, 144)])
+def test_gpu_unet_bf16_pairs_tiles_straddle_the_image_edge_on_both_axes(ny, nx, monkeypatch):
+    """The pair kernels own 30 x 14 output tiles: image sizes that leave a partial tile at the bottom AND at the right at
+    both fused levels (144 = 4*30 + 24, 208 = 14*14 + 12; 72 = 2*30 + 12, 104 = 7*14 + 6; 176 x 144 likewise), three cases,
+    every layer."""
+    from psm_amd import UNetSurrogate
+    monkeypatch.setenv("PSM_UNET_PAIR_MIN", "1")
+    for lv in (0, 1):
+        assert (ny >> lv) % 30 != 0 and (nx >> lv) % 14 != 0
+    specs = uo.unet_specs()
+    W = uo.he_weights(specs, seed=17)
+    grids = np.stack([synthetic.channel_grid(ny, nx, seed=70 + k, cx=0.9, cy=0.85).astype(np.float32) for k in range(3)])   # obstacle at the corner
+    with UNetSurrogate(W, ny, nx, max_cases=3, precision="bf16", keep_activations=True) as net:
+        out = net.forward(grids)
+        for k in range(3):
+            ref, acts = uo.unet_forward(grids[k], W, return_all=True, precision="bf16")
+            for i in range(len(specs) - 1):
+                a = net.activation(i, 3)[k]
+                err = np.linalg.norm(a - acts[i]) / max(np.linalg.norm(acts[i]), 1e-12)
+                assert err <= 1e-2, (specs[i].name, err)
+                # the partial tiles themselves: last rows / columns of the layer
+                edge = np.concatenate([(a - acts[i])[-6:].ravel(), (a - acts[i])[:, -6:].ravel()])
+                scale = np.abs(acts[i]).max()
+                assert np.abs(edge).max() <= 4e-2 * max(scale, 1e-6), (specs[i].name, np.abs(edge).max(), scale)
+            assert np.linalg.norm(out[k] - ref) / np.linalg.norm(ref) <= 1e-2
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("c_in,widths,c_out", [(4, (16, 32), 1), (3, (16, 32, 64), 2), (4, (16, 32, 48), 1)])
 def test_gpu_unet_bf16_pairs_other_shapes(c_in, widths, c_out, monkeypatch):
     """Fused level pairs on other networks: the 4-channel stem (pressureSM_Poisson's image), two head outputs, a 48-channel
