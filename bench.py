@@ -4,16 +4,19 @@
     python bench.py --gpus N --steps K --warmup W
 
 ``--gpus N`` with no torchrun environment starts the N ranks itself (fresh child processes, one per GPU, before this
-process touches the GPU); under ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`` the
-environment's ranks are used.  The world size reported by the process group must equal ``--gpus``.
+process touches the GPU; every child is supervised: the first rank that fails ends the job within seconds, each rank's
+stderr is kept in bench_rank<r>.err); under ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`` the
+environment's ranks are used.  The world size reported by the process group must equal ``--gpus`` and every rank must
+sit on its own GPU (PCI bus ids on the line).
 
 Workload of ``value`` at every N (weak scaling: the per-GPU work is fixed): BASELINE.json configs[1] -- 256x256
 channel-with-obstacle U_to_gradP inference, batch 1, fp32, P_i = P_o = 128, MLP 3x512 (SURVEY.md §8 d config 1;
 synthetic seeded input, seeded random-init weights of that architecture).  One step = one solve
-(grid[256,256,3] -> fields[256,256,2]) through the C-ABI with the input already resident in HBM; steps are issued
-back to back on one stream, K steps are timed between barrier + synchronize on both sides, MAX over ranks.  Each rank
-drives its own GPU with its own independent case stream (no data-path collective); RCCL carries the model broadcast
-(outside the timed region), the barrier and the max-reduction of the time.
+(grid[256,256,3] -> fields[256,256,2]) through the C-ABI with the input already resident in HBM (the bench contract:
+the PCIe-inclusive rate is never ``value``; it is ``value_end_to_end`` on the same line); steps are issued back to back
+on one stream, K steps are timed between barrier + synchronize on both sides, MAX over ranks.  Each rank drives its own
+GPU with its own independent case stream (no data-path collective); RCCL carries the model broadcast (outside the timed
+region), the barrier and the max-reduction of the time.
 
 Extra objects on the JSON line:
   value_end_to_end / end_to_end   SURVEY §8(d)'s solve INCLUDING the H2D copy of the grid and the D2H copy of the field
@@ -22,14 +25,18 @@ Extra objects on the JSON line:
                the ring on pageable memory and the zero-copy slot form.
   case_batch   BASELINE configs[3]: random-obstacle 256x256 deltaU_to_deltaP cases, 8 per GPU per step (64 over 8 GPUs),
                one geometry per case slot, aggregate solves/s over all ranks + one all-gather of the result shards
-               (outside the timed region).
+               (outside the timed region); roofline of its dominant kernel against the f32 matrix peak.
+  legs         (N = 1) every other BASELINE config and the convolutional path with the same protocol at a smaller K:
+               configs[2], configs[4] (PCA-MLP, bf16 operands, 512x512), unet (UNet-S f32 batch 1), unet8_bf16,
+               unet512_bf16 (configs[4] as BASELINE.json words it) -- each with ms_per_step, l2_vs_oracle, roofline and,
+               for the conv legs, the NumPy U-Net as cpu_baseline.
   roofline     the kernel with the largest measured time in this run: every dispatch of K instrumented solves carries
                its own begin / end stamps (hipExtLaunchKernelGGL events, psm_time_kernels); achieved = that kernel's
                algorithmic bytes per launch / its average duration.  "traffic" = HBM-side bytes per launch from the
-               committed PMC run of the same kernel (profiles/r02_pmc.json; null when the kernel source has changed
+               committed PMC run of the same kernel (profiles/r03_pmc.json; null when the kernel source has changed
                since that run).
-  cpu_baseline the NumPy oracle ("port" of the reference's algorithm, float64 PCA + float32 MLP like the reference)
-               timed on the host cores, rank 0, N=1.
+  cpu_baseline the C / OpenMP port of the reference's algorithm (float64 PCA + float32 MLP like the reference) timed on
+               the host cores, rank 0, N=1; the NumPy oracle beside it.
 """
 import argparse
 import hashlib
@@ -42,15 +49,41 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# The host-buffer ring keeps several tickets in flight on their own streams: give the HIP runtime enough hardware queues
-# for them (read when the runtime initialises, i.e. before torch touches the GPU; libpsm_hip.so asks for the same when it
-# is loaded first).  Measured: 50 us per end-to-end solve with 8 queues against 35 with 16.
+# The host-buffer ring keeps several tickets in flight on their own streams: this PROGRAM asks the HIP runtime for enough
+# hardware queues for them (read when the runtime initialises, i.e. before torch touches the GPU).  Measured: 50 us per
+# end-to-end solve with 8 queues against 35 with 16.  The library itself never changes the
+# environment; end_to_end.hw_queues reports what this process asked for and whether that was before HIP came up.
+
+
+def _cpu_share():
+    """CPUs this process may use: min(affinity, cgroup quota) -- the GPU boxes show 256 CPUs with a quota of 16."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+# BLAS / OpenMP pools of the CPU-baseline legs sized to that share BEFORE NumPy loads its BLAS: a pool of 256 spinning
+# threads inside a 16-CPU quota gets the whole process throttled, launch thread included (measured: the f32 U-Net leg,
+# 18 launches per step, at 364 us per step instead of 168 after an oracle call with the default pool).
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, str(_cpu_share()))
+_HWQ_PRESET = os.environ.get("GPU_MAX_HW_QUEUES")
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 P = 128
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 matrix peak (256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz)
 MFMA_BF16_PEAK_TFLOPS = 2516.6   # dense bf16 matrix peak (16x the f32 rate)
+PMC_FILE = "profiles/r03_pmc.json"
 
 # BASELINE.json configs as (variant, Ny, Nx, cases per step per GPU, precision, description)
 WORKLOADS = {
@@ -60,49 +93,106 @@ WORKLOADS = {
                 "B=9 blocks, P=128, MLP 3x512"),
     "config3": ("deltas", 256, 256, 8, "f32", "BASELINE configs[3]: random-obstacle 256x256 cases, 8 per GPU per step, "
                 "B=9 blocks per case, P=128, MLP 3x512"),
-    "config4": ("deltas", 512, 512, 1, "bf16", "BASELINE configs[4]: 512x512 high-Re cylinder, bf16 operands / f32 accumulate, "
+    "config4": ("deltas", 512, 512, 1, "bf16", "BASELINE configs[4] (PCA-MLP form): 512x512 high-Re cylinder, bf16 operands / f32 accumulate, "
                 "B=30 blocks, P=128, MLP 3x512"),
 }
 UNET_WORKLOADS = {           # the convolutional path (SURVEY.md section 8 row a-conv, parity unpinned) -- not the headline
     "unet": (256, 256, 1, "UNet-S (build-defined: 3x3 convs x2 per level, widths 16-32-64-128-256, max-pool, nearest "
              "upsample + skip concat, 1x1 head), 256x256x3 -> 256x256x1, batch 1, fp32, 7.0 GFLOP per solve"),
     "unet8": (256, 256, 8, "UNet-S, 256x256x3 -> 256x256x1, 8 cases per step per GPU, fp32"),
+    "unet_bf16": (256, 256, 1, "UNet-S, 256x256x3 -> 256x256x1, batch 1, bf16 operands / f32 accumulate"),
     "unet8_bf16": (256, 256, 8, "UNet-S, 256x256x3 -> 256x256x1, 8 cases per step per GPU, bf16 operands / f32 accumulate"),
-    "unet512_bf16": (512, 512, 1, "UNet-S, 512x512x3 -> 512x512x1 (BASELINE configs[4] shape), batch 1, bf16 operands / f32 accumulate"),
+    "unet512_bf16": (512, 512, 1, "UNet-S, 512x512x3 -> 512x512x1 (BASELINE configs[4] as worded: bf16 MFMA conv path), batch 1, "
+                     "bf16 operands / f32 accumulate"),
 }
+DEFAULT_LEGS = ("config2", "config4", "unet", "unet8_bf16", "unet512_bf16")
 
 
 # ----------------------------------------------------------------------------------------------------------------
 # launcher: --gpus N without a torchrun environment
 # ----------------------------------------------------------------------------------------------------------------
+def _tail(path, n=1500):
+    try:
+        with open(path, "rb") as f:
+            f.seek(0, 2)
+            f.seek(max(0, f.tell() - n))
+            return f.read().decode(errors="replace")
+    except OSError:
+        return ""
+
+
 def spawn_ranks(n: int) -> int:
-    """Start n fresh rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) and relay rank 0's
-    JSON line.  Called before anything in this process has touched the GPU (nothing is ever re-exec'd)."""
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0 = procs[0].communicate()[0]
-    rcs = [procs[0].returncode]
-    for p in procs[1:]:
-        try:
-            rcs.append(p.wait(timeout=120))
-        except subprocess.TimeoutExpired:
-            p.kill()                                  # exactly the child this launcher started
-            rcs.append(p.wait())
-    sys.stdout.write(out0)
-    sys.stdout.flush()
-    bad = [rc for rc in rcs if rc != 0]
-    return bad[0] if bad else 0
+    """Start n fresh rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), supervise ALL of them
+    and relay rank 0's JSON line.  The first rank that exits non-zero ends the job: the other children (exactly the ones
+    started here) are terminated and its exit code is returned within seconds, with the tail of its stderr; every rank's
+    stderr stays in bench_rank<r>.err (PSM_BENCH_LOGDIR, default: the working directory).  PSM_BENCH_TIMEOUT (seconds,
+    default 1500) bounds the whole job.  Called before anything in this process has touched the GPU; nothing is ever
+    re-exec'd."""
+    deadline = time.time() + float(os.environ.get("PSM_BENCH_TIMEOUT", "1500"))
+    logdir = os.environ.get("PSM_BENCH_LOGDIR", os.getcwd())
+    os.makedirs(logdir, exist_ok=True)
+    out0 = os.path.join(logdir, "bench_rank0.out")
+    for attempt in range(3):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()                                     # rank 0 binds it next; a lost race shows as EADDRINUSE -> retried below
+        procs, files = [], []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            ferr = open(os.path.join(logdir, f"bench_rank{r}.err"), "wb")
+            fout = open(out0, "wb") if r == 0 else subprocess.DEVNULL
+            files += [ferr] + ([fout] if r == 0 else [])
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=fout, stderr=ferr))
+
+        def stop_all():
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()                     # exactly the children this launcher started
+            t_end = time.time() + 5.0
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+
+        rc_job, failed = 0, None
+        while True:
+            rcs = [p.poll() for p in procs]
+            bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+            if bad:
+                failed, rc_job = bad[0]
+                stop_all()
+                break
+            if all(rc == 0 for rc in rcs):
+                break
+            if time.time() > deadline:
+                stop_all()
+                failed, rc_job = -1, 124
+                break
+            time.sleep(0.05)
+        for f in files:
+            f.close()
+        if rc_job == 0:
+            with open(out0) as f:
+                sys.stdout.write(f.read())
+            sys.stdout.flush()
+            return 0
+        err = _tail(os.path.join(logdir, f"bench_rank{max(failed, 0)}.err"))
+        if failed == 0 and attempt < 2 and ("EADDRINUSE" in err or "ddress already in use" in err):
+            continue                                  # another process took the rendezvous port: new port, new ranks
+        what = "deadline PSM_BENCH_TIMEOUT passed" if failed < 0 else f"rank {failed} exited with {rc_job}"
+        sys.stderr.write(f"bench.py --gpus {n}: {what}; the other ranks were stopped.  Its stderr ({logdir}/bench_rank{max(failed, 0)}.err) ends:\n{err}\n")
+        return rc_job if rc_job > 0 else 1
+    return 1
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# algorithmic work (SURVEY.md section 8(d))
+# ----------------------------------------------------------------------------------------------------------------
 def algorithmic_bytes(model, ny, nx, wbytes=4):
     """SURVEY.md §8(d) BYTES formula, split per kernel group (float32 = 4 B)."""
     S2 = model.S ** 2
@@ -112,19 +202,27 @@ def algorithmic_bytes(model, ny, nx, wbytes=4):
     return {"encode": enc, "decode": dec, "mlp": sum(layers), "layers": layers, "total": enc + dec + sum(layers)}
 
 
-def kernel_algorithmic_bytes(name, ab, launches_per_solve):
-    """Algorithmic bytes one launch of kernel `name` must move (None for kernels whose traffic is an artefact of the
-    launch structure: slab sums, strip sums, chain)."""
-    nl = len(ab["layers"])
+def algorithmic_flops(model, M):
+    """SURVEY.md §8(d) FLOP formula for M block rows, split per kernel group."""
+    S2 = model.S ** 2
+    layers = [2 * M * W.shape[0] * W.shape[1] for W, _ in model.weights]
+    enc, dec = 2 * M * S2 * model.c_in * model.p_in, 2 * M * model.p_out * S2 * model.c_out
+    return {"encode": enc, "decode": dec, "layers": layers, "total": enc + dec + sum(layers)}
+
+
+def kernel_algorithmic(name, table, launches_per_solve):
+    """Algorithmic bytes (or flops) one launch of kernel `name` accounts for (None for kernels whose traffic is an
+    artefact of the launch structure: slab sums, strip sums, chain)."""
+    nl = len(table["layers"])
     if "encode" in name:
-        return ab["encode"]
+        return table["encode"]
     if "decode" in name:
-        return ab["decode"]
+        return table["decode"]
     if "reduce_dense1" in name:
-        return ab["layers"][0]
+        return table["layers"][0]
     if "dense" in name:
-        # the remaining layers share this kernel: average bytes of the layers it ran
-        rest = ab["layers"][1:] if launches_per_solve < nl else ab["layers"]
+        # the remaining layers share this kernel: average over the layers it ran
+        rest = table["layers"][1:] if launches_per_solve < nl else table["layers"]
         return sum(rest) / max(len(rest), 1)
     return None
 
@@ -141,15 +239,22 @@ def kernel_source_hash():
 def committed_traffic(kernel, workload):
     """HBM-side bytes per launch of `kernel` from the committed PMC passes (tools/pmc_summary.py), only while the
     kernel sources are the ones that were profiled."""
-    f = os.path.join(ROOT, "profiles", "r02_pmc.json")
+    f = os.path.join(ROOT, PMC_FILE)
     try:
         d = json.load(open(f))
     except Exception:
         return None, None
     if d.get("workload") != workload or d.get("kernel_source_hash") != kernel_source_hash():
-        return None, "profiles/r02_pmc.json is from other kernel sources: not used"
+        return None, PMC_FILE + " is from other kernel sources: not used"
     v = d.get("kernels", {}).get(kernel)
-    return (v, "profiles/r02_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2*FETCH + WRITE KiB, gfx950 correction)") if v else (None, None)
+    return (v, PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2*FETCH + WRITE KiB, gfx950 correction)") if v else (None, None)
+
+
+def oracle_model(model):
+    from oracle import psm_oracle as orc
+    sc = orc.Scaler(model.scaler_kind, model.in_a, model.in_b, model.out_a, model.out_b)
+    return orc.Model(model.variant, model.c_in, model.c_out, model.comp_in, model.mean_in, model.comp_out,
+                     model.mean_out, model.weights, sc, model.out_scale, model.S, model.ov, model.sdf_ch)
 
 
 def cpu_baseline(model, grid, precision="f32", budget_s=12.0, max_solves=4000):
@@ -161,9 +266,7 @@ def cpu_baseline(model, grid, precision="f32", budget_s=12.0, max_solves=4000):
     from psm_amd import hostinfo
     cores = hostinfo.available_cpus()            # CPU share of this process (affinity / cgroup quota)
     _limit = hostinfo.limit_blas_threads(cores)  # BLAS pool = the threads actually used
-    sc = orc.Scaler(model.scaler_kind, model.in_a, model.in_b, model.out_a, model.out_b)
-    om = orc.Model(model.variant, model.c_in, model.c_out, model.comp_in, model.mean_in, model.comp_out,
-                   model.mean_out, model.weights, sc, model.out_scale, model.S, model.ov, model.sdf_ch)
+    om = oracle_model(model)
     g = grid.astype(np.float64)
     orc.solve_grid(g, om, precision=precision)  # warm-up (BLAS threads, page faults)
     n, t0 = 0, time.perf_counter()
@@ -200,10 +303,12 @@ def degenerate_note(variant, ny, nx, S=128):
     stride = 32 if variant == "gradp" else (96 if variant == "deltas" else None)
     if stride is None or (ny - S) % stride != 0:
         return None
-    where = "UGP:340 -> UGP:359 (mean of an empty slice, NaN field)" if variant == "gradp" else "SMD:335 (broadcast error)"
+    where = ("UGP:340 -> UGP:359 (mean of an empty slice: NaN dp/dx field, NaN rows in dp/dy; tests/golden/gradp_degenerate_256x256.npz)" if variant == "gradp"
+             else "SMD:335 (broadcast error; tests/golden/deltas_degenerate_512x512.npz)")
     return ("build-defined skip: p_i == 0 on this grid, where the reference itself is undefined (" + where + "); the duplicate "
             "last block row is encoded / decoded but left out of the reassembly, and l2_vs_oracle compares with the "
-            "oracle's same skip mode (the golden vectors use non-degenerate grids)")
+            "oracle's same skip mode (strict_degenerate=1 reproduces the reference's NaN / error; the golden vectors of "
+            "the parity claim use non-degenerate grids)")
 
 
 def finish(pdist_mod=None):
@@ -220,6 +325,9 @@ def main_dry(args):
     from psm_amd import dist as pdist
     import torch.distributed as dist
     rank, world, _ = pdist.env_world()
+    if os.environ.get("PSM_BENCH_FAIL_RANK") == str(rank):          # supervision test: this rank dies before the rendezvous
+        sys.stderr.write(f"rank {rank}: PSM_BENCH_FAIL_RANK set, exiting with 3\n")
+        sys.exit(3)
     pdist.init(os.environ.get("PSM_BENCH_BACKEND", "gloo"))
     if world != args.gpus:
         raise SystemExit(f"world size {world} != --gpus {args.gpus}")
@@ -233,61 +341,25 @@ def main_dry(args):
     finish()
 
 
-def main_unet(args):
-    """Same protocol for the convolutional path: K forward passes back to back, input resident in HBM."""
-    import numpy as np
-    import torch
-    from psm_amd import UNetSurrogate, dist as pdist, synthetic
-    rank, world, local_rank = pdist.env_world()
-    backend = os.environ.get("PSM_BENCH_BACKEND", "nccl")
-    local_rank = int(os.environ.get("PSM_BENCH_DEVICE", local_rank))
-    torch.cuda.set_device(local_rank)
-    pdist.init(backend, torch.device("cuda", local_rank))
-    NY, NX, NC, desc = UNET_WORKLOADS[args.workload]
-    W = synthetic.unet_he_weights(seed=7)
-    prec = "bf16" if args.workload.endswith("bf16") else "f32"
-    peak = MFMA_BF16_PEAK_TFLOPS if prec == "bf16" else MFMA_F32_PEAK_TFLOPS
-    net = UNetSurrogate(W, NY, NX, max_cases=NC, device=local_rank, precision=prec)
-    grids = [np.stack([synthetic.channel_grid(NY, NX, seed=1 + 1000 * rank + 10 * i + k).astype(np.float32) for k in range(NC)])
-             for i in range(args.inputs)]
-    d_in = [torch.from_numpy(g).cuda() for g in grids]
-    d_out = [torch.empty((NC, NY, NX, 1), dtype=torch.float32, device="cuda") for _ in grids]
-    stream = torch.cuda.current_stream().cuda_stream
+# ----------------------------------------------------------------------------------------------------------------
+# GPU helpers
+# ----------------------------------------------------------------------------------------------------------------
+def device_identity(torch, local_rank):
+    pr = torch.cuda.get_device_properties(local_rank)
+    if all(hasattr(pr, a) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+        return f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+    return str(getattr(pr, "uuid", f"ordinal{local_rank}"))
 
-    def step(i):
-        k = i % len(d_in)
-        net.forward_device(d_in[k].data_ptr(), NC, d_out[k].data_ptr(), stream)
-    dt_max = pdist.timed_region(step, args.steps, args.warmup, torch.cuda.synchronize, "cuda" if backend == "nccl" else "cpu")
-    flops = net.flops * NC
-    achieved = flops * args.steps / dt_max / 1e12
-    ms, _ = net.profile(d_in[0].data_ptr(), NC, d_out[0].data_ptr())
-    out = {"metric": "pressure-solves/sec (256x256 U->p inference)", "value": pdist.aggregate_throughput(NC, args.steps, world, dt_max),
-           "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": prec, "data": "synthetic",
-           "config": {"workload": desc, "grid": [NY, NX], "cases_per_step_per_gpu": NC,
-                      "parallelism": f"case-sharded x{world} (no data-path collective)", "parity": "unpinned (no reference network)"},
-           "roofline": {"kernel": "psm_conv3x3_kernel (all 18 layers + head, whole forward pass)", "bound": "mfma", "achieved": achieved,
-                        "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
-                        "algorithmic_flops": flops, "per_layer_ms": [float(v) for v in ms]}}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import unet_oracle as uo           # cpu_baseline leg only
-        from psm_amd import hostinfo
-        cores = hostinfo.available_cpus()
-        hostinfo.limit_blas_threads(cores)
-        g0 = grids[0][0]
-        ref = uo.unet_forward(g0, W, precision=prec)
-        n, t0 = 0, time.perf_counter()
-        while n < 200 and time.perf_counter() - t0 < 12.0:
-            uo.unet_forward(g0, W, precision=prec); n += 1
-        dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": n / dt, "unit": "solves/s", "cores": int(cores), "kind": "port",
-                               "sample": f"{n} UNet-S forward passes of the NumPy oracle (float64 accumulation) in {dt:.1f} s"}
-        got = d_out[0][0].cpu().numpy()
-        out["l2_vs_oracle"] = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
-    if rank == 0:
-        print(json.dumps(out))
-    net.close()
-    finish()
+
+def gather_devices(torch, local_rank, world):
+    """PCI bus id of every rank's GPU; under RCCL the ranks must sit on distinct cards."""
+    import torch.distributed as dist
+    me = device_identity(torch, local_rank)
+    if not (dist.is_available() and dist.is_initialized()) or world == 1:
+        return [me]
+    got = [None] * world
+    dist.all_gather_object(got, me)
+    return got
 
 
 def host_rates(sur, grids, n_cases, steps, warmup, modes):
@@ -322,6 +394,179 @@ def time_kernels(sur, d_grid, n_cases, d_fields, steps):
     return out
 
 
+def pca_roofline(sur, model, ny, nx, n_cases, precision, d_grid, d_fields, steps, dt_step, workload, bound_path):
+    """Roofline of the kernel with the largest measured time: every dispatch of an instrumented pass over `steps` solves
+    carries its own begin / end stamps.  Both ceilings are priced -- algorithmic bytes against the HBM peak, algorithmic
+    flops against the f32 / bf16 matrix peak -- and the kernel is bound by the one it sits closer to."""
+    wb = 2 if precision == "bf16" else 4
+    ab = algorithmic_bytes(model, ny, nx, wb)
+    ab_batch = dict(ab, encode=ab["encode"] + (n_cases - 1) * 4 * ny * nx * model.c_in,
+                    decode=ab["decode"] + (n_cases - 1) * 4 * ny * nx * model.c_out)       # bases read once, fields per case
+    af = algorithmic_flops(model, n_cases * sur.B)
+    peak_f = MFMA_BF16_PEAK_TFLOPS if precision == "bf16" else MFMA_F32_PEAK_TFLOPS
+    kt = time_kernels(sur, d_grid, n_cases, d_fields, steps)
+    per_solve = {nm: n / steps for nm, _, n in kt}
+    kernels = []
+    for nm, us, n in kt:
+        b, f = kernel_algorithmic(nm, ab_batch, per_solve[nm]), kernel_algorithmic(nm, af, per_solve[nm])
+        kernels.append({"name": nm, "avg_us": us, "launches_per_solve": per_solve[nm], "algorithmic_bytes": b, "algorithmic_flops": f,
+                        "achieved_GBs": (b / (us * 1e-6) / 1e9) if b else None,
+                        "achieved_TFLOPs": (f / (us * 1e-6) / 1e12) if f else None})
+    dom = max(kernels, key=lambda k: k["avg_us"] * k["launches_per_solve"])
+    gbs, tfl = dom["achieved_GBs"] or 0.0, dom["achieved_TFLOPs"] or 0.0
+    f_hbm, f_mfma = gbs / HBM_PEAK_GBS, tfl / peak_f
+    traffic, traffic_src = committed_traffic(dom["name"], workload) if bound_path else (None, None)
+    tot_b = ab_batch["total"]
+    roof = {"kernel": dom["name"], "bound": "mfma" if f_mfma > f_hbm else "hbm"}
+    if roof["bound"] == "hbm":
+        roof.update(achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=f_hbm)
+    else:
+        roof.update(achieved=tfl, peak=peak_f, unit="TFLOP/s", frac=f_mfma)
+    roof.update(traffic=traffic, traffic_source=traffic_src, algorithmic_bytes=dom["algorithmic_bytes"], algorithmic_flops=dom["algorithmic_flops"],
+                avg_launch_us=dom["avg_us"], launches=int(dom["launches_per_solve"] * steps), frac_hbm=f_hbm, frac_mfma=f_mfma,
+                selection="largest measured time per solve among all kernels of the instrumented pass; bound = the ceiling it sits closer to",
+                whole_solve={"algorithmic_bytes": tot_b, "algorithmic_flops": af["total"],
+                             "achieved_GBs": tot_b / dt_step / 1e9, "frac_hbm": tot_b / dt_step / 1e9 / HBM_PEAK_GBS,
+                             "achieved_TFLOPs": af["total"] / dt_step / 1e12, "frac_mfma": af["total"] / dt_step / 1e12 / peak_f},
+                kernels=kernels)
+    return roof
+
+
+def unet_leg(name, args, torch, pdist, rank, world, local_rank, backend, steps, warmup, with_cpu, cpu_budget_s=4.0):
+    """The convolutional path with the bench protocol: K forward passes back to back, input resident in HBM."""
+    import numpy as np
+    from psm_amd import UNetSurrogate, synthetic
+    NY, NX, NC, desc = UNET_WORKLOADS[name]
+    W = synthetic.unet_he_weights(seed=7)
+    prec = "bf16" if name.endswith("bf16") else "f32"
+    peak = MFMA_BF16_PEAK_TFLOPS if prec == "bf16" else MFMA_F32_PEAK_TFLOPS
+    net = UNetSurrogate(W, NY, NX, max_cases=NC, device=local_rank, precision=prec)
+    n_in = min(args.inputs, 2 if NY > 256 else args.inputs)
+    grids = [np.stack([synthetic.channel_grid(NY, NX, seed=1 + 1000 * rank + 10 * i + k, noise=0.05 if NY > 256 else 0.02).astype(np.float32)
+                       for k in range(NC)]) for i in range(n_in)]
+    d_in = [torch.from_numpy(g).cuda() for g in grids]
+    d_out = [torch.empty((NC, NY, NX, 1), dtype=torch.float32, device="cuda") for _ in grids]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(i):
+        k = i % len(d_in)
+        net.forward_device(d_in[k].data_ptr(), NC, d_out[k].data_ptr(), stream)
+    dt_max = pdist.timed_region(step, steps, warmup, torch.cuda.synchronize, "cuda" if backend == "nccl" else "cpu")
+    torch.cuda.synchronize()
+    got = d_out[0][0].cpu().numpy()
+    flops = net.flops * NC
+    achieved = flops * steps / dt_max / 1e12
+    # every launch of the forward pass with its own dispatch stamps: flops and activation / weight bytes of the convolutions it covers
+    ab, wbts = (2, 2) if prec == "bf16" else (4, 4)
+    launches = []
+    for first, convs, kname, us in net.time_kernels(d_in[0].data_ptr(), NC, d_out[0].data_ptr(), steps=max(5, min(20, steps))):
+        fl = sum(net.conv_flops(c) for c in convs) * NC
+        # a fused launch (level pair, fused 1x1 head) reads the first convolution's input and writes the last one's output
+        by = (net.conv_bytes(convs[0], ab, wbts)[0] + net.conv_bytes(convs[-1], ab, wbts)[1]) * NC + sum(net.conv_bytes(c, ab, wbts)[2] for c in convs)
+        launches.append({"convs": convs, "kernel": kname, "avg_us": us, "flops": fl, "algorithmic_bytes": by,
+                         "achieved_TFLOPs": fl / (us * 1e-6) / 1e12, "achieved_GBs": by / (us * 1e-6) / 1e9})
+    dom = max(launches, key=lambda l: l["avg_us"])
+    f_mfma, f_hbm = dom["achieved_TFLOPs"] / peak, dom["achieved_GBs"] / HBM_PEAK_GBS
+    roof = {"kernel": f"{dom['kernel']} (convolutions {dom['convs']})", "bound": "mfma" if f_mfma > f_hbm else "hbm"}
+    if roof["bound"] == "mfma":
+        roof.update(achieved=dom["achieved_TFLOPs"], peak=peak, unit="TFLOP/s", frac=f_mfma)
+    else:
+        roof.update(achieved=dom["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=f_hbm)
+    roof.update(traffic=None, avg_launch_us=dom["avg_us"], algorithmic_flops=dom["flops"], algorithmic_bytes=dom["algorithmic_bytes"],
+                frac_mfma=f_mfma, frac_hbm=f_hbm, selection="the launch of the forward pass with the largest dispatch-stamped duration",
+                whole_pass={"algorithmic_flops": flops, "achieved_TFLOPs": achieved, "frac_mfma": achieved / peak,
+                            "sum_of_launches_us": sum(l["avg_us"] for l in launches), "n_launches": len(launches)},
+                launches=launches)
+    leg = {"workload": desc, "value": pdist.aggregate_throughput(NC, steps, world, dt_max), "unit": "solves/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": dt_max / steps * 1e3, "dtype": prec, "cases_per_step_per_gpu": NC, "grid": [NY, NX],
+           "parity": "unpinned (no reference network): l2_vs_oracle is against the build-defined NumPy U-Net with the same rounding points",
+           "roofline": roof}
+    if with_cpu:
+        from oracle import unet_oracle as uo           # checker + cpu_baseline leg only
+        from psm_amd import hostinfo
+        cores = hostinfo.available_cpus()
+        hostinfo.limit_blas_threads(cores)
+        g0 = grids[0][0]
+        n, t0 = 0, time.perf_counter()
+        while n < 50 and (n == 0 or time.perf_counter() - t0 < cpu_budget_s):
+            ref = uo.unet_forward(g0, W, precision=prec)
+            n += 1
+        dt = time.perf_counter() - t0
+        leg["cpu_baseline"] = {"value": n / dt, "unit": "solves/s", "cores": int(cores), "kind": "port",
+                               "sample": f"{n} UNet-S {NY}x{NX} forward pass(es) of the NumPy oracle (float64 accumulation, BLAS on {int(cores)} threads) in {dt:.1f} s"}
+        leg["l2_vs_oracle"] = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+    net.close()
+    return leg
+
+
+def main_unet(args):
+    import torch
+    from psm_amd import dist as pdist
+    rank, world, local_rank = pdist.env_world()
+    backend = os.environ.get("PSM_BENCH_BACKEND", "nccl")
+    local_rank = int(os.environ.get("PSM_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(local_rank)
+    pdist.init(backend, torch.device("cuda", local_rank))
+    leg = unet_leg(args.workload, args, torch, pdist, rank, world, local_rank, backend, args.steps, args.warmup,
+                   rank == 0 and world == 1 and not args.no_cpu_baseline, cpu_budget_s=12.0)
+    out = {"metric": "pressure-solves/sec (256x256 U->p inference)", "value": leg["value"], "unit": "solves/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": leg["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": leg["dtype"], "data": "synthetic",
+           "config": {"workload": leg["workload"], "grid": leg["grid"], "cases_per_step_per_gpu": leg["cases_per_step_per_gpu"],
+                      "parallelism": f"case-sharded x{world} (no data-path collective)", "parity": leg["parity"]},
+           "roofline": leg["roofline"]}
+    for k in ("cpu_baseline", "l2_vs_oracle"):
+        if k in leg:
+            out[k] = leg[k]
+    if rank == 0:
+        print(json.dumps(out))
+    finish()
+
+
+def pca_leg(name, model, args, torch, pdist, psm_amd, synthetic, rank, world, local_rank, red_dev, steps, warmup, with_oracle):
+    """One BASELINE config of the PCA-MLP path with the bench protocol (device-resident steps, geometry bound once)."""
+    import numpy as np
+    variant, NY, NX, NC, precision, desc = WORKLOADS[name]
+    sur = psm_amd.GridSurrogate(model, NY, NX, max_cases=NC, device=local_rank, precision=precision)
+    if name == "config2":        # sequential delta-U fields of one simulation: phase-shifted frames on one geometry
+        base = synthetic.channel_grid(NY, NX, seed=1 + 1000 * rank).astype(np.float32)
+        grids = []
+        for i in range(args.inputs):
+            g = synthetic.delta_grid(NY, NX, seed=2 + 1000 * rank, step=i).astype(np.float32)
+            g[..., model.sdf_ch] = base[..., model.sdf_ch]
+            g[..., :model.sdf_ch] *= (base[..., model.sdf_ch:model.sdf_ch + 1] != 0)
+            grids.append(g[None])
+    else:
+        grids = [synthetic.channel_grid(NY, NX, seed=4 + 1000 * rank + i, noise=0.05 if NY > 256 else 0.02).astype(np.float32)[None]
+                 for i in range(args.inputs)]
+    d_in = [torch.from_numpy(g).cuda() for g in grids]
+    d_out = [torch.empty((NC, NY, NX, model.c_out), dtype=torch.float32, device="cuda") for _ in grids]
+    stream = torch.cuda.current_stream().cuda_stream
+    masks = [g[..., model.sdf_ch] != 0 for g in grids]
+    bound = (not args.no_bind) and all(np.array_equal(masks[0], m) for m in masks[1:]) and sur.bind_geometry(d_in[0].data_ptr(), on_device=True, n_cases=NC)
+
+    def step(i):
+        k = i % len(d_in)
+        sur.solve_device(d_in[k].data_ptr(), NC, d_out[k].data_ptr(), stream)
+    dt = pdist.timed_region(step, steps, warmup, torch.cuda.synchronize, red_dev)
+    torch.cuda.synchronize()
+    got = d_out[0].cpu().numpy()[0]
+    leg = {"workload": desc, "value": pdist.aggregate_throughput(NC, steps, world, dt), "unit": "solves/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": dt / steps * 1e3, "dtype": precision, "grid": [NY, NX], "blocks": sur.B,
+           "geometry": "bound once per case stream" if bound else "general path", "guard_trips": sur.guard_trips,
+           "degenerate": degenerate_note(variant, NY, NX),
+           "roofline": pca_roofline(sur, model, NY, NX, NC, precision, d_in[0].data_ptr(), d_out[0].data_ptr(), steps, dt / steps, name, bound)}
+    if with_oracle:
+        from oracle import psm_oracle as orc
+        t0 = time.perf_counter()
+        ref = orc.solve_grid(grids[0][0].astype(np.float64), oracle_model(model), precision=precision).fields
+        leg["l2_vs_oracle"] = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+        leg["oracle"] = ("NumPy oracle with the same bf16 rounding points (the reference has no bf16 path)" if precision == "bf16"
+                         else "NumPy oracle (float64 PCA / reassembly, float32 MLP)") + f", one solve in {time.perf_counter() - t0:.2f} s"
+    sur.close()
+    return leg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -330,10 +575,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inputs", type=int, default=4, help="distinct input grids rotated through (all resident in HBM)")
     ap.add_argument("--no-bind", action="store_true", help="do not bind the geometry: general 8-launch path")
-    ap.add_argument("--no-extras", action="store_true", help="skip the end-to-end and case-batch legs")
+    ap.add_argument("--no-extras", action="store_true", help="skip the end-to-end, case-batch and other legs")
+    ap.add_argument("--legs", default=",".join(DEFAULT_LEGS), help="comma-separated extra legs at N = 1 (BASELINE configs and conv path); 'none' skips them")
     ap.add_argument("--dry-run", action="store_true", help="launcher / process-group plumbing only (no GPU work)")
     ap.add_argument("--workload", default="config1", choices=sorted(WORKLOADS) + sorted(UNET_WORKLOADS),
-                    help="BASELINE.json config to run (default: configs[1], the one the metric is quoted on)")
+                    help="BASELINE.json config to run as the headline (default: configs[1], the one the metric is quoted on)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -347,6 +593,7 @@ def main():
 
     import numpy as np
     import torch
+    hip_up_before = torch.cuda.is_initialized()
     import psm_amd
     from psm_amd import dist as pdist, synthetic
     rank, world, local_rank = pdist.env_world()
@@ -355,7 +602,10 @@ def main():
     # Rehearsal switches (not used by the driver): several ranks on ONE card need the gloo backend and a
     # forced device index, e.g. PSM_BENCH_BACKEND=gloo PSM_BENCH_DEVICE=0 python bench.py --gpus 2
     backend = os.environ.get("PSM_BENCH_BACKEND", "nccl")
+    shared_card = "PSM_BENCH_DEVICE" in os.environ
     local_rank = int(os.environ.get("PSM_BENCH_DEVICE", local_rank))
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     pdist.init(backend, torch.device("cuda", local_rank))
     red_dev = "cuda" if backend == "nccl" else "cpu"
@@ -363,6 +613,9 @@ def main():
     world_reported = dist.get_world_size() if dist.is_initialized() else 1
     if world_reported != args.gpus:
         raise SystemExit(f"process group reports {world_reported} ranks, --gpus {args.gpus}")
+    devices = gather_devices(torch, local_rank, world)
+    if world > 1 and not shared_card and len(set(devices)) != world:
+        raise SystemExit(f"ranks share a GPU: {devices}")
 
     variant, NY, NX, NC, precision, wl_desc = WORKLOADS[args.workload]
     # rank 0 builds the artefacts, every other rank receives them over RCCL (one byte broadcast, outside the timed region)
@@ -390,7 +643,8 @@ def main():
 
     # One case stream per GPU = one simulation: its geometry (the flow-cell pattern of the SDF channel) is bound once,
     # outside the timed region, like the reference's computeOnlyOnce / init_func; the rotated inputs differ in the
-    # velocity channels only (checked).  --no-bind times the general path, which takes any geometry per call.
+    # velocity channels only (checked here, and on the device at every solve: guard_trips stays 0).  --no-bind times the
+    # general path, which takes any geometry per call.
     bound = False
     if not args.no_bind:
         masks = [g[..., model.sdf_ch] != 0 for g in grids]
@@ -404,34 +658,15 @@ def main():
     dt_max = pdist.timed_region(step, args.steps, args.warmup, torch.cuda.synchronize, red_dev)
     torch.cuda.synchronize()
     got_dev = d_out[0].cpu().numpy()
-
-    # ---- roofline of the kernel with the largest measured time: every dispatch of an instrumented pass over the same
-    # K steps carries its own begin / end stamps
-    ab = algorithmic_bytes(model, NY, NX, 2 if precision == "bf16" else 4)
-    kt = time_kernels(sur, d_in[0].data_ptr(), NC, d_out[0].data_ptr(), args.steps)
-    per_solve = {nm: n / args.steps for nm, _, n in kt}
-    # time per solve of each kernel (a kernel launched several times per solve counts with all its launches)
-    dom_name, dom_us, dom_n = max(kt, key=lambda r: r[1] * per_solve[r[0]])
-    kernels = []
-    for nm, us, n in kt:
-        b = kernel_algorithmic_bytes(nm, ab, per_solve[nm])
-        kernels.append({"name": nm, "avg_us": us, "launches_per_solve": per_solve[nm], "algorithmic_bytes": b,
-                        "achieved_GBs": (b / (us * 1e-6) / 1e9) if b else None})
-    dom_bytes = kernel_algorithmic_bytes(dom_name, ab, per_solve[dom_name])
-    achieved = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_bytes else 0.0
-    traffic, traffic_src = committed_traffic(dom_name, args.workload) if bound else (None, None)
-    roofline = {"kernel": dom_name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes": dom_bytes, "avg_launch_us": dom_us, "launches": dom_n,
-                "selection": "largest measured time per solve among all kernels of the instrumented pass",
-                "whole_solve": {"algorithmic_bytes": ab["total"], "achieved_GBs": ab["total"] * NC / (dt_max / args.steps) / 1e9,
-                                "frac": ab["total"] * NC / (dt_max / args.steps) / 1e9 / HBM_PEAK_GBS},
-                "kernels": kernels}
+    value = pdist.aggregate_throughput(NC, args.steps, world, dt_max)
+    roofline = pca_roofline(sur, model, NY, NX, NC, precision, d_in[0].data_ptr(), d_out[0].data_ptr(), args.steps, dt_max / args.steps,
+                            args.workload, bound)
 
     out = {
         "metric": "pressure-solves/sec (256x256 U->p inference)",
-        "value": pdist.aggregate_throughput(NC, args.steps, world, dt_max),
-        "unit": "solves/s", "n_gpus": world, "world_size_reported": world_reported, "steps": args.steps, "warmup": args.warmup,
+        "value": value, "value_device_resident": value,
+        "unit": "solves/s", "n_gpus": world, "world_size_reported": world_reported, "devices": devices,
+        "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": precision, "data": "synthetic",
         "config": {"workload": wl_desc,
@@ -439,11 +674,14 @@ def main():
                    "parallelism": f"case-sharded x{world} (no data-path collective; model broadcast from rank 0 over "
                                   f"{'RCCL' if backend == 'nccl' else backend} before the timed region: {broadcast_s * 1e3:.0f} ms)",
                    "value_is": "device-resident rate: the input grid is already in HBM when the timed region starts and the "
-                               "field stays in HBM (the bench contract); the H2D/D2H-inclusive solve of SURVEY section 8(d) is "
-                               "value_end_to_end",
+                               "field stays in HBM (the bench contract: the PCIe-inclusive rate is never `value`); the solve of "
+                               "SURVEY section 8(d) / BASELINE.md:4 -- host grid in, host field out, H2D and D2H included -- is "
+                               "value_end_to_end on this line",
                    "degenerate": degenerate_note(variant, NY, NX),
                    "geometry": ("bound once per case stream (psm_bind_geometry = the reference's computeOnlyOnce / init_func split): "
-                                "6 launches per solve, 7 for case batches") if bound else "general path (any geometry per call): 8 launches per solve (9 for case batches)"},
+                                "6 launches per solve, 7 for case batches; the contract is checked on the device at every solve") if bound
+                               else "general path (any geometry per call): 8 launches per solve (9 for case batches)",
+                   "guard_trips": sur.guard_trips},
         "roofline": roofline,
     }
 
@@ -463,11 +701,13 @@ def main():
                     "C++ loop inside the library through the public C-ABI (psm_bench_host); ring slots with their own "
                     "stream and scratch: DMA copy in, one hipGraph replay of the kernels, DMA copy out per ticket",
             "value_is": key + " (psm_submit_grid_io / psm_wait_grid on caller-registered memory, 4 tickets in flight)",
-            "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+            "hw_queues": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "set_by": "the caller's environment" if _HWQ_PRESET else "bench.py (the library never sets it)",
+                          "hip_initialised_before_it_was_set": bool(hip_up_before)},
             "steps": n_e2e, "solves_per_s_per_rank": {k: v[0] for k, v in rates.items()},
             "matches_device_resident_result": bool(np.array_equal(rates[key][1], d_out[last_in].cpu().numpy()))}
 
     # ---- BASELINE configs[3]: the case batch, 8 random-obstacle cases per GPU per step
+    m3 = None
     if not args.no_extras and args.workload == "config1":
         v3, ny3, nx3, nc3, prec3, desc3 = WORKLOADS["config3"]
         m3 = synthetic.make_model(v3, p_in=P, p_out=P) if rank == 0 else None
@@ -489,12 +729,41 @@ def main():
             sur3.solve_device(g3[k].data_ptr(), count, o3[k].data_ptr(), stream)
         k3 = max(100, args.steps // 4)
         dt3 = pdist.timed_region(step3, k3, max(10, args.warmup // 4), torch.cuda.synchronize, red_dev)
+        torch.cuda.synchronize()
         whole = pdist.gather_cases(o3[0] if red_dev == "cuda" else o3[0].cpu(), total_cases)     # one all-gather, untimed
         out["case_batch"] = {"workload": desc3, "value": total_cases * k3 / dt3, "unit": "solves/s", "steps": k3,
-                             "ms_per_step": dt3 / k3 * 1e3, "cases_per_step_per_gpu": count, "total_cases": total_cases,
+                             "ms_per_step": dt3 / k3 * 1e3, "dtype": prec3, "cases_per_step_per_gpu": count, "total_cases": total_cases,
                              "geometry": "one bound geometry per case slot (7 launches per step)" if b3 else "general path (9 launches per step)",
-                             "gathered_shape": list(whole.shape)}
+                             "guard_trips": sur3.guard_trips, "gathered_shape": list(whole.shape),
+                             "roofline": pca_roofline(sur3, m3, ny3, nx3, count, prec3, g3[0].data_ptr(), o3[0].data_ptr(), k3, dt3 / k3, "config3", bool(b3))}
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            from oracle import psm_oracle as orc
+            c = count - 1
+            ref = orc.solve_grid(allc[c].astype(np.float64), oracle_model(m3)).fields
+            gotc = o3[0][c].cpu().numpy()
+            out["case_batch"]["l2_vs_oracle"] = float(np.linalg.norm(gotc - ref) / np.linalg.norm(ref))
         sur3.close()
+
+    # ---- the other BASELINE configs and the convolutional path (N = 1): same protocol, smaller K
+    legs = [] if (args.no_extras or world > 1 or args.workload != "config1" or args.legs in ("", "none")) else [l for l in args.legs.split(",") if l]
+    if legs:
+        out["legs"] = {}
+        k_leg, w_leg = max(100, args.steps // 4), max(10, args.warmup // 4)
+        with_oracle = rank == 0 and not args.no_cpu_baseline
+        for name in legs:
+            t0 = time.perf_counter()
+            if name in WORKLOADS:
+                if m3 is None:
+                    m3 = synthetic.make_model("deltas", p_in=P, p_out=P)
+                mdl = m3 if WORKLOADS[name][0] == "deltas" else model
+                leg = pca_leg(name, mdl, args, torch, pdist, psm_amd, synthetic, rank, world, local_rank, red_dev, k_leg, w_leg, with_oracle)
+            elif name in UNET_WORKLOADS:
+                ku = max(20, min(k_leg, 200 if UNET_WORKLOADS[name][0] <= 256 else 100))
+                leg = unet_leg(name, args, torch, pdist, rank, world, local_rank, backend, ku, max(5, w_leg // 2), with_oracle)
+            else:
+                raise SystemExit(f"unknown leg {name!r}")
+            leg["leg_wall_s"] = time.perf_counter() - t0
+            out["legs"][name] = leg
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb, sol = cpu_baseline(model, grids[0][0], precision)

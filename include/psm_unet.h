@@ -58,6 +58,13 @@ int psm_unet_read_activation(psm_unet* u, int32_t idx, float* dst, int64_t dst_f
 /* One forward pass with a HIP event between the layers: ms [num_convs] (each includes ~3 us of event overhead),
  * wgs [num_convs] workgroups launched per layer (may be NULL).  Introspection for tuning. */
 int psm_unet_profile(psm_unet* u, const float* d_grid, int32_t n_cases, float* d_field, float* ms, int32_t* wgs);
+/* Dispatch-level time of every launch of the forward pass: `steps` passes on the handle's stream, each dispatch stamped with
+ * its own begin / end by hipExtLaunchKernelGGL (the timestamps rocprofv3 --kernel-trace reads; no marker packets between
+ * the layers).  us [num_convs]: average duration in microseconds of the launch that STARTS at convolution i -- a fused pair
+ * or a fused head is one launch, the convolutions it also computes report 0; launches [num_convs] (may be NULL): launches
+ * per pass (0 or 1); names [num_convs][64] (may be NULL): the kernel instantiation that ran. */
+int psm_unet_time_kernels(psm_unet* u, const float* d_grid, int32_t n_cases, float* d_field, int32_t steps, double* us,
+                          int32_t* launches, char* names);
 /* Diagnostic builds (-DPSM_STAMPS) only: runs the network up to and including convolution `idx` on the staged input of
  * the last psm_unet_forward and returns workgroup-0 time stamps of that last layer, stamps_us[64] in microseconds
  * after the first (-1: not reached; all -1 in the shipped library). */

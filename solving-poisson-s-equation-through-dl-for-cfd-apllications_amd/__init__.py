@@ -3,12 +3,8 @@
 The directory name carries hyphens (it is fixed by the project layout), so the
 package is imported through the root-level alias module ``psm_amd``.
 """
-import os as _os
-
-# enough HIP hardware queues for the tickets of the host-buffer ring (see csrc/psm_api.cpp psm_default_hw_queues): only
-# effective when this import precedes the first GPU call of the process
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-
+# (The host-buffer ring wants GPU_MAX_HW_QUEUES=16 in the environment of the HOST PROGRAM before its first GPU call -- see
+# INTEGRATION.md; neither this package nor the library sets it.)
 from . import _lib, dist, formats, geometry, hostinfo, surrogate, synthetic, unet  # noqa: F401
 from .unet import UNetSurrogate  # noqa: F401
 from .surrogate import Evaluation, EvaluationGradP, EvaluationPoisson, GridSurrogate, SolverModule, call_SM_main  # noqa: F401

@@ -28,10 +28,8 @@ thread_local std::string g_create_error;
 // The ring keeps PSM_RING_SLOTS tickets in flight on their own streams, each stream with copy and kernel work; with the HIP
 // runtime's default number of hardware queues streams share queues and neighbouring tickets end up behind each other
 // (measured with 8 slots: 50 us per solve with 8 queues, 40 with 4, 34-35 with 12 / 16 / 32).  The runtime reads
-// GPU_MAX_HW_QUEUES when it initialises, so the library asks for 16 when it is loaded (before the fat-binary
-// registration of this library touches the runtime) -- unless the process has already chosen a value.  No effect when
-// HIP was initialised before the load.
-__attribute__((constructor(101))) void psm_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// GPU_MAX_HW_QUEUES once, when it initialises: that is the HOST PROGRAM's choice (bench.py and INTEGRATION.md set 16) --
+// the library never touches the environment of the process it is loaded into.
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 

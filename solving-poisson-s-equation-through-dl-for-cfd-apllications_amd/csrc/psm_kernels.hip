@@ -518,9 +518,19 @@ __device__ __forceinline__ void psm_guard_wave(const PsmGuardArgs& g, int gw, in
   }
 }
 // sum of the guard flags of a solve (0, or NaN after a mismatch): one wave, every lane gets the total
+__device__ __forceinline__ float psm_guard_part(const float* flags, int n, int lane, int first) {   // this lane's share from `first` on
+  float gs = 0.f;
+  for (int k0 = first + lane; k0 < n; k0 += 64 * 8) {  // 8 independent loads per round
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = flags[min(k0 + 64 * u, n - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) gs += (k0 + 64 * u < n) ? v[u] : 0.f;
+  }
+  return gs;
+}
 __device__ __forceinline__ float psm_guard_sum(const float* flags, int n, int lane, float f0, float f1) {
-  float gs = (lane < n ? f0 : 0.f) + (lane + 64 < n ? f1 : 0.f);
-  for (int k = lane + 128; k < n; k += 64) gs += flags[k];
+  const float gs = (lane < n ? f0 : 0.f) + (lane + 64 < n ? f1 : 0.f) + psm_guard_part(flags, n, lane, 128);
   return wave_sum(gs);
 }
 
@@ -1743,6 +1753,7 @@ __global__ __launch_bounds__(256) void psm_chain_dots_kernel(PsmBoundBatchArgs p
   const float* dots = p.dots + (int64_t)cs * p.rows_pc;
   const float* cnt = p.scnt + (int64_t)cs * p.rows_pc;
   const int n_stage = C * nst + nst;
+  const float gpart = psm_guard_part(p.gflags, p.n_gwaves, lane, 0);   // guard flags of this solve (0 / NaN): in flight with the staging loads
   for (int base = 0; base < n_stage; base += 256 * 8) {            // 8 loads in flight per thread and round
     float sv[8];
 #pragma unroll
@@ -1765,7 +1776,7 @@ __global__ __launch_bounds__(256) void psm_chain_dots_kernel(PsmBoundBatchArgs p
       p.offs[((int64_t)cs * C + wave) * B + b] = offs[wave * B + b];
     }
     const float t_shift = wave_sum(t), raw_all = wave_sum(raw);
-    const float guard = psm_guard_sum(p.gflags, p.n_gwaves, lane, p.gflags[min(lane, p.n_gwaves - 1)], p.gflags[min(lane + 64, p.n_gwaves - 1)]);
+    const float guard = wave_sum(gpart);                              // NaN when a grid of this batch is not its bound geometry
     if (lane == 0) p.shift[cs * C + wave] = raw_all / (float)p.shiftL[wave] / 3.f - t_shift + guard;
   }
 }

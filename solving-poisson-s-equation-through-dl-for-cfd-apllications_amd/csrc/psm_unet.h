@@ -4,6 +4,8 @@
 
 #include <cstdint>
 
+#include "psm_launch.h"
+
 enum { PSM_SRC_SAME = 0, PSM_SRC_UPSAMPLE = 1, PSM_SRC_MAXPOOL = 2 };
 
 struct PsmConvArgs {

@@ -636,15 +636,15 @@ static void launch_variant(const PsmConvArgs& a, dim3 grid, int groups, hipStrea
   do {                                                                                                                   \
     if constexpr (K == 1 && S >= 0 && S != 3) {                                                                          \
       if (a.bf16 && a.in_bf) {                                                                                           \
-        if (one) hipLaunchKernelGGL((psm_conv3x3_kernel<TH, WM, NCT, WN, S, 1, true, 1, true>), grid, dim3(256), 0, st, a, groups);     \
-        else hipLaunchKernelGGL((psm_conv3x3_kernel<TH, WM, NCT, WN, S, 1, true, 2, true>), grid, dim3(256), 0, st, a, groups);         \
+        if (one) PSM_LAUNCH((psm_conv3x3_kernel<TH, WM, NCT, WN, S, 1, true, 1, true>), grid, dim3(256), 0, st, a, groups);     \
+        else PSM_LAUNCH((psm_conv3x3_kernel<TH, WM, NCT, WN, S, 1, true, 2, true>), grid, dim3(256), 0, st, a, groups);         \
         break;                                                                                                           \
       }                                                                                                                  \
     }                                                                                                                    \
-    if (a.bf16) { if (one && K == 1) hipLaunchKernelGGL((psm_conv3x3_kernel<TH, WM, NCT, WN, S, 1, true, 1>), grid, dim3(256), 0, st, a, groups);    \
-                  else hipLaunchKernelGGL((psm_conv3x3_kernel<TH, WM, NCT, WN, S, K, true, 2>), grid, dim3(256), 0, st, a, groups); }            \
-    else { if (one && K == 1) hipLaunchKernelGGL((psm_conv3x3_kernel<TH, WM, NCT, WN, S, 1, false, 1>), grid, dim3(256), 0, st, a, groups);          \
-           else hipLaunchKernelGGL((psm_conv3x3_kernel<TH, WM, NCT, WN, S, K, false, 2>), grid, dim3(256), 0, st, a, groups); }                  \
+    if (a.bf16) { if (one && K == 1) PSM_LAUNCH((psm_conv3x3_kernel<TH, WM, NCT, WN, S, 1, true, 1>), grid, dim3(256), 0, st, a, groups);    \
+                  else PSM_LAUNCH((psm_conv3x3_kernel<TH, WM, NCT, WN, S, K, true, 2>), grid, dim3(256), 0, st, a, groups); }            \
+    else { if (one && K == 1) PSM_LAUNCH((psm_conv3x3_kernel<TH, WM, NCT, WN, S, 1, false, 1>), grid, dim3(256), 0, st, a, groups);          \
+           else PSM_LAUNCH((psm_conv3x3_kernel<TH, WM, NCT, WN, S, K, false, 2>), grid, dim3(256), 0, st, a, groups); }                  \
   } while (0)
   if (stem) { GO(-1, 1); return; }
   if (a.mode0 == PSM_SRC_SAME) { if (slabs) GO(PSM_SRC_SAME, 8); else GO(PSM_SRC_SAME, 1); }
@@ -681,16 +681,16 @@ hipError_t psm_launch_conv_stem(const PsmConvArgs& a, int n_cases, hipStream_t s
   const int kg = (9 * a.c0 + 15) / 16;
   if (a.c0 < 1 || kg > 4 || a.cout > 16 || a.mode0 != PSM_SRC_SAME || a.c1 != 0 || a.ks0 != 1 || a.ksplit != 1) return hipErrorInvalidValue;
   const dim3 grid((a.W + TW - 1) / TW, (a.H + 7) / 8, n_cases);
-  if (a.c0 == 3) hipLaunchKernelGGL((psm_conv_stem_kernel<2, 3>), grid, dim3(256), 0, st, a);          // (Ux, Uy, SDF)
-  else if (a.c0 == 4) hipLaunchKernelGGL((psm_conv_stem_kernel<3, 4>), grid, dim3(256), 0, st, a);     // pressureSM_Poisson's 4 channels
-  else if (kg == 1) hipLaunchKernelGGL((psm_conv_stem_kernel<1, 0>), grid, dim3(256), 0, st, a);
-  else if (kg == 2) hipLaunchKernelGGL((psm_conv_stem_kernel<2, 0>), grid, dim3(256), 0, st, a);
-  else if (kg == 3) hipLaunchKernelGGL((psm_conv_stem_kernel<3, 0>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((psm_conv_stem_kernel<4, 0>), grid, dim3(256), 0, st, a);
+  if (a.c0 == 3) PSM_LAUNCH((psm_conv_stem_kernel<2, 3>), grid, dim3(256), 0, st, a);          // (Ux, Uy, SDF)
+  else if (a.c0 == 4) PSM_LAUNCH((psm_conv_stem_kernel<3, 4>), grid, dim3(256), 0, st, a);     // pressureSM_Poisson's 4 channels
+  else if (kg == 1) PSM_LAUNCH((psm_conv_stem_kernel<1, 0>), grid, dim3(256), 0, st, a);
+  else if (kg == 2) PSM_LAUNCH((psm_conv_stem_kernel<2, 0>), grid, dim3(256), 0, st, a);
+  else if (kg == 3) PSM_LAUNCH((psm_conv_stem_kernel<3, 0>), grid, dim3(256), 0, st, a);
+  else PSM_LAUNCH((psm_conv_stem_kernel<4, 0>), grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
 hipError_t psm_launch_head1x1(const PsmHeadArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(psm_head1x1_kernel, dim3((unsigned)((a.n_pix + 255) / 256)), dim3(256), 0, st, a);
+  PSM_LAUNCH(psm_head1x1_kernel, dim3((unsigned)((a.n_pix + 255) / 256)), dim3(256), 0, st, a);
   return hipGetLastError();
 }

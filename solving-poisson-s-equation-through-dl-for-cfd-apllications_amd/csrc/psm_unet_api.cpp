@@ -225,6 +225,7 @@ int forward(psm_unet* u, const float* d_grid, int n, float* d_field, hipStream_t
   const size_t n_run = n_layers < 0 ? u->convs.size() : (size_t)n_layers;
   for (size_t i = 0; i < n_run; ++i) {
     if (ev) UCHK(u, hipEventRecord(ev[i], st));
+    if (psm_launch_probe) psm_launch_probe->tag = (int)i;
     Conv& c = u->convs[i];
     const int H = u->ny >> c.level, W = u->nx >> c.level;
     float* out = (i + 1 == u->convs.size()) ? d_field : c.d_out;
@@ -579,6 +580,54 @@ int psm_unet_profile(psm_unet* u, const float* d_grid, int32_t n_cases, float* d
   }
   for (auto& e : ev) (void)hipEventDestroy(e);
   return rc;
+}
+
+int psm_unet_time_kernels(psm_unet* u, const float* d_grid, int32_t n_cases, float* d_field, int32_t steps, double* us, int32_t* launches,
+                          char* names) {
+  if (!u || !us || steps < 1) return PSM_ERR_ARG;
+  if (!u->planned) return fail(u, PSM_ERR_STATE, "psm_unet_plan has not been called");
+  if (!d_grid || !d_field || n_cases < 1 || n_cases > u->max_cases) return fail(u, PSM_ERR_ARG, "bad arguments");
+  UCHK(u, hipSetDevice(u->device));
+  UCHK(u, hipStreamSynchronize(u->stream));
+  const size_t nc = u->convs.size();
+  std::vector<double> tot(nc, 0.0);
+  std::vector<int64_t> cnt(nc, 0);
+  if (names) std::memset(names, 0, nc * 64);
+  PsmLaunchProbe probe;
+  auto drain = [&]() -> int {
+    UCHK(u, hipStreamSynchronize(u->stream));
+    for (auto& r : probe.recs) {
+      float t = 0.f;
+      if (r.tag >= 0 && r.tag < (int)nc && hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) {
+        tot[r.tag] += t; cnt[r.tag] += 1;
+        if (names && !names[(size_t)r.tag * 64]) {
+          std::string nm(r.name);
+          while (!nm.empty() && (nm[0] == '(' || nm[0] == ' ')) nm.erase(0, 1);
+          while (!nm.empty() && (nm.back() == ')' || nm.back() == ' ')) nm.pop_back();
+          std::snprintf(names + (size_t)r.tag * 64, 64, "%s", nm.c_str());
+        }
+      }
+      probe.pool.push_back(r.e0); probe.pool.push_back(r.e1);
+    }
+    probe.recs.clear();
+    return PSM_OK;
+  };
+  int rc = PSM_OK;
+  psm_launch_probe = &probe;
+  for (int i = 0; i < steps && rc == PSM_OK; ++i) {
+    rc = forward(u, d_grid, n_cases, d_field, u->stream);
+    if (rc == PSM_OK && (i % 16) == 15) rc = drain();
+  }
+  psm_launch_probe = nullptr;
+  if (rc == PSM_OK) rc = drain(); else (void)hipStreamSynchronize(u->stream);
+  for (auto& r : probe.recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  for (auto e : probe.pool) (void)hipEventDestroy(e);
+  if (rc) return rc;
+  for (size_t i = 0; i < nc; ++i) {
+    us[i] = cnt[i] ? tot[i] / (double)cnt[i] * 1e3 : 0.0;
+    if (launches) launches[i] = (int32_t)(cnt[i] / steps);
+  }
+  return PSM_OK;
 }
 
 int psm_unet_debug_run_layer(psm_unet* u, int32_t idx, float* stamps_us) {

@@ -787,12 +787,12 @@ hipError_t psm_launch_conv_pair(const PsmPairArgs& a, int kind, int cm, int n_ca
   const bool keep = a.mid_out != nullptr, head = a.head_w != nullptr;
   if (!head && !a.out) return hipErrorInvalidValue;
   if (keep && !a.out) return hipErrorInvalidValue;
-#define PAIR_GO(K, ...) do { if (keep) hipLaunchKernelGGL((K<__VA_ARGS__, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((K<__VA_ARGS__, false>), grid, dim3(256), 0, st, a); } while (0)
+#define PAIR_GO(K, ...) do { if (keep) PSM_LAUNCH((K<__VA_ARGS__, true>), grid, dim3(256), 0, st, a); else PSM_LAUNCH((K<__VA_ARGS__, false>), grid, dim3(256), 0, st, a); } while (0)
   if (kind == PSM_PAIR_STEM && cm == 16 && a.c0 == 3 && !head) PAIR_GO(psm_pair_stem16_kernel, 3);
   else if (kind == PSM_PAIR_STEM && cm == 16 && a.c0 == 4 && !head) PAIR_GO(psm_pair_stem16_kernel, 4);
   else if (kind == PSM_PAIR_UPCAT && cm == 16 && a.c0 == 32 && a.c1 == 16) {
-    if (keep) { if (head) hipLaunchKernelGGL((psm_pair_up16_kernel<true, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((psm_pair_up16_kernel<true, false>), grid, dim3(256), 0, st, a); }
-    else { if (head) hipLaunchKernelGGL((psm_pair_up16_kernel<false, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((psm_pair_up16_kernel<false, false>), grid, dim3(256), 0, st, a); }
+    if (keep) { if (head) PSM_LAUNCH((psm_pair_up16_kernel<true, true>), grid, dim3(256), 0, st, a); else PSM_LAUNCH((psm_pair_up16_kernel<true, false>), grid, dim3(256), 0, st, a); }
+    else { if (head) PSM_LAUNCH((psm_pair_up16_kernel<false, true>), grid, dim3(256), 0, st, a); else PSM_LAUNCH((psm_pair_up16_kernel<false, false>), grid, dim3(256), 0, st, a); }
   }
   else if (kind == PSM_PAIR_POOL && cm == 32 && a.c0 % 16 == 0 && a.c0 >= 16 && !head) PAIR_GO(psm_pair32_kernel, 2);
   else if (kind == PSM_PAIR_UPCAT && cm == 32 && a.c0 % 32 == 0 && a.c0 >= 32 && a.c1 % 16 == 0 && a.c1 >= 16 && !head) PAIR_GO(psm_pair32_kernel, 1);

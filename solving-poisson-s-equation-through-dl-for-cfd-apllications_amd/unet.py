@@ -130,6 +130,43 @@ class UNetSurrogate:
         self._chk(self.lib.psm_unet_profile(self.h, d_grid, n_cases, d_field, _p(ms), _p(wg, C.c_int32)))
         return ms, wg
 
+    def time_kernels(self, d_grid: int, n_cases: int, d_field: int, steps: int = 20):
+        """Dispatch-level timing (psm_unet_time_kernels) -> [(first conv index, convs covered, kernel name, avg us)] per launch."""
+        n = len(self.shapes)
+        us = (C.c_double * n)()
+        cnt = (C.c_int32 * n)()
+        names = C.create_string_buffer(n * 64)
+        self._chk(self.lib.psm_unet_time_kernels(self.h, d_grid, n_cases, d_field, steps, us, cnt, names))
+        starts = [i for i in range(n) if cnt[i] > 0]
+        out = []
+        for j, i in enumerate(starts):
+            end = starts[j + 1] if j + 1 < len(starts) else n
+            out.append((i, list(range(i, end)), names.raw[i * 64:(i + 1) * 64].split(b"\0", 1)[0].decode(), float(us[i])))
+        return out
+
+    def conv_flops(self, idx: int) -> int:
+        k, ci, co = self.shapes[idx]
+        lv = self._level(idx)
+        return 2 * (self.ny >> lv) * (self.nx >> lv) * k * k * ci * co
+
+    def conv_bytes(self, idx: int, act_bytes: int = 4, w_bytes: int = 4):
+        """Algorithmic bytes of convolution idx for one case: (input activations, output activation, weights)."""
+        k, ci, co = self.shapes[idx]
+        lv = self._level(idx)
+        L = (len(self.shapes) + 1) // 4
+        hw = (self.ny >> lv) * (self.nx >> lv)
+        last = idx == len(self.shapes) - 1
+        if idx == 0:
+            a_in = hw * ci * 4                                   # the float32 image
+        elif idx < 2 * L and idx % 2 == 0:
+            a_in = 4 * hw * ci * act_bytes                       # max-pool source at twice the resolution
+        elif 2 * L <= idx < len(self.shapes) - 1 and (idx - 2 * L) % 2 == 0:
+            up = self.shapes[idx - 1][2]
+            a_in = (hw // 4) * up * act_bytes + hw * (ci - up) * act_bytes   # upsample source + skip
+        else:
+            a_in = hw * ci * act_bytes
+        return a_in, hw * co * (4 if last else act_bytes), k * k * ci * co * (4 if last else w_bytes)
+
     @property
     def flops(self) -> int:
         return int(self.lib.psm_unet_flops(self.h))
