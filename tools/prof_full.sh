@@ -13,7 +13,7 @@ timeout -k 10 400 python bench.py > $O/bench.log 2>&1; tail -1 $O/bench.log | cu
 
 # convolutional path: kernel stats + bench lines
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/unet_stats -- python3 $R/bench.py --workload unet8 --steps 100 --warmup 10 --no-cpu-baseline > $O/unet_stats.log 2>&1; echo "unet stats rc=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/unet_stats -- python3 $R/bench.py --workload unet8_bf16 --steps 100 --warmup 10 --no-cpu-baseline > $O/unet_stats.log 2>&1; echo "unet stats rc=$?"
 cd $R
 timeout -k 10 300 python bench.py --workload unet > $O/bench_unet.log 2>&1; tail -1 $O/bench_unet.log | cut -c1-160
 timeout -k 10 300 python bench.py --workload unet8 --no-cpu-baseline > $O/bench_unet8.log 2>&1; tail -1 $O/bench_unet8.log | cut -c1-160
