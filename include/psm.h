@@ -110,6 +110,15 @@ int psm_set_pca(psm_handle* h, const double* comp_in, const double* mean_in,
 /* Keras Dense kernel [n_in, n_out] row-major and bias [n_out]; layer in [0, n_dense). */
 int psm_set_dense(psm_handle* h, int32_t layer, int32_t n_in, int32_t n_out,
                   const float* kernel, const float* bias);
+/* conv1D_PCA head (NNs.py:75-124; architecture 'conv1D' of utils.py:452-454: 7 layers of 128-64-32-16-32-64-128 filters):
+ * n_layers Conv1D layers (kernel_size taps, 'same' padding, ReLU) over the p_in scaled PCA coefficients seen as a sequence
+ * [p_in, 1], then Flatten ([p_in, filters] row-major: index p * filters + c) and the Dense layers of psm_set_dense (the
+ * reference has exactly one, Dense(PC_p)), the first of which takes p_in * filters inputs.  kernel [kernel_size, c_in,
+ * c_out] float32 (Keras Conv1D layout; cross-correlation, (kernel_size - 1) / 2 zeros in front), bias [c_out]; layer in
+ * [0, n_layers), c_in of layer 0 is 1.  Call for every layer BEFORE psm_set_dense(layer 0) and psm_plan_grid.  float32
+ * handles only; such a model keeps the general (unbound) solve path unless it has a hidden Dense layer. */
+int psm_set_conv1d(psm_handle* h, int32_t layer, int32_t n_layers, int32_t kernel_size, int32_t c_in, int32_t c_out,
+                   const float* kernel, const float* bias);
 /* max_abs: in_a[0] = max_abs_input_PCA, out_a[0] = max_abs_output_PCA (others ignored);
  * std: in_a = mean_in, in_b = std_in, out_a = mean_out, out_b = std_out  ([p_in]/[p_out]);
  * min_max: in_a = min_in, in_b = max_in, out_a = min_out, out_b = max_out. */

@@ -199,6 +199,7 @@ class Model:
     S: int = 128
     ov: int | None = None
     sdf_ch: int = 2
+    conv1d: Sequence[Tuple[np.ndarray, np.ndarray]] = ()   # conv1D_PCA head (NNS:75-124): [(K[k, c_in, c_out] f32, b[c_out] f32)]
 
     def overlap(self) -> int:
         return default_overlap(self.variant, self.S) if self.ov is None else self.ov
@@ -211,10 +212,29 @@ def pca_encode(x_blocks: np.ndarray, comp_in: np.ndarray, mean_in: np.ndarray) -
     return np.dot(flat - mean_in, comp_in.T)
 
 
-def mlp_forward(x: np.ndarray, weights) -> np.ndarray:
+def conv1d_forward(x: np.ndarray, convs) -> np.ndarray:
+    """The Conv1D part of ``conv1D_PCA`` (NNS:81-114): Input(shape=(PC_input, 1)), then per layer
+    ``Conv1D(filters, kernel_size, activation='relu', padding='same')`` -- a cross-correlation over the coefficient index
+    with (k - 1) // 2 zeros in front (TensorFlow's 'same' rule) -- and ``Flatten`` ([p, c] row-major).  float32."""
+    h = np.asarray(x, np.float32)[:, :, None]
+    B, Pn = h.shape[:2]
+    for K, b in convs:
+        K = np.asarray(K, np.float32)
+        k, cin, cout = K.shape
+        front = (k - 1) // 2
+        hp = np.pad(h, ((0, 0), (front, k - 1 - front), (0, 0)))
+        cols = np.concatenate([hp[:, t:t + Pn, :] for t in range(k)], axis=2)          # [B, P, (t, ci)]
+        h = np.maximum(cols.reshape(B * Pn, k * cin) @ K.reshape(k * cin, cout) + np.asarray(b, np.float32), np.float32(0)).reshape(B, Pn, cout)
+    return h.reshape(B, -1)
+
+
+def mlp_forward(x: np.ndarray, weights, conv1d=()) -> np.ndarray:
     """Keras ``Dense`` stack (PM:121-134, NNS:8-38): relu(x@W+b) for every layer
-    but the last, which is linear.  float32 like Keras (floatx)."""
+    but the last, which is linear.  float32 like Keras (floatx).  ``conv1d``: the Conv1D layers of the conv1D_PCA head
+    in front of it (NNS:75-124)."""
     h = np.asarray(x, dtype=np.float32)
+    if len(conv1d):
+        h = conv1d_forward(h, conv1d)
     n = len(weights)
     for li, (W, b) in enumerate(weights):
         h = h @ np.asarray(W, np.float32) + np.asarray(b, np.float32)
@@ -512,6 +532,8 @@ def solve_grid(grid: np.ndarray, model: Model, degenerate: str = "skip", precisi
     Ny, Nx = grid.shape[:2]
     lay = block_layout(model.variant, Ny, Nx, model.S, model.overlap())
     xb = extract_blocks(np.asarray(grid, np.float64), lay, model.c_in)
+    if precision == "bf16" and len(model.conv1d):
+        raise ValueError("the conv1D_PCA head has no bf16 path")
     if precision == "bf16":
         flat = xb.reshape(lay.B, -1).astype(np.float32) - model.mean_in.astype(np.float32)
         coeff = bf16_round(flat).astype(np.float64) @ bf16_round(model.comp_in).astype(np.float64).T
@@ -528,7 +550,7 @@ def solve_grid(grid: np.ndarray, model: Model, degenerate: str = "skip", precisi
     elif precision == "f32":
         coeff = pca_encode(xb, model.comp_in, model.mean_in)
         x_in = model.scaler.fwd(coeff)
-        res = mlp_forward(x_in, model.weights)
+        res = mlp_forward(x_in, model.weights, model.conv1d)
         dec_in = model.scaler.inv(res.astype(np.float64))
         bp = pca_decode(dec_in, model.comp_out, model.mean_out, model.S, model.c_out) * model.out_scale
     else:

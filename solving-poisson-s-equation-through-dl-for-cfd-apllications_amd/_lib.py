@@ -51,6 +51,7 @@ SIGNATURES = {
     "psm_last_error": (C.c_char_p, [_hp]),
     "psm_set_pca": (C.c_int, [_hp, _f64p, _f64p, _f64p, _f64p]),
     "psm_set_dense": (C.c_int, [_hp, C.c_int32, C.c_int32, C.c_int32, _f32p, _f32p]),
+    "psm_set_conv1d": (C.c_int, [_hp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f32p, _f32p]),
     "psm_set_scaler": (C.c_int, [_hp, _f64p, _f64p, _f64p, _f64p]),
     "psm_plan_grid": (C.c_int, [_hp, C.c_int32, C.c_int32]),
     "psm_num_blocks": (C.c_int, [_hp]),

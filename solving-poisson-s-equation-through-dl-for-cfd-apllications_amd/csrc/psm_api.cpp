@@ -41,6 +41,12 @@ struct DenseLayer {
   bool set = false;
 };
 
+struct Conv1dLayer {            // conv1D_PCA head (NNs.py:75-124)
+  int k = 0, cin = 0, cout = 0;
+  float *W = nullptr, *b = nullptr;
+  bool set = false;
+};
+
 struct GraphKey {
   int n; const void* g; void* f;
   bool operator<(const GraphKey& o) const { return std::tie(n, g, f) < std::tie(o.n, o.g, o.f); }
@@ -55,6 +61,7 @@ struct Workspace {
   float2* d_colpart = nullptr;
   float *d_offs = nullptr, *d_shift = nullptr;
   float* d_dots = nullptr;            // strip dots of the geometry-bound path (allocated by the bind)
+  float* d_c1[2] = {nullptr, nullptr}; // Conv1D activations of the conv1D_PCA head (ping-pong), [Mpad][c1_stride]
   float* d_gflags = nullptr;          // guard flags of the bound-geometry contract (psm_kernels.h PsmGuardArgs; allocated by the bind)
   int gidx = 0;                       // this workspace's word in the handle's mapped guard page (0 = ws0, 1 + i = ring slot i)
 };
@@ -66,6 +73,8 @@ struct psm_handle {
   int S = 0, ov = 0, K_in = 0, K_out = 0, ld_in = 0, ld_out = 0, NT = 0, n_slices = 0, Gd = 0, n_coltiles = 0;
   bool have_pca = false, have_scaler = false;
   std::vector<DenseLayer> dense;
+  std::vector<Conv1dLayer> conv1d;      // in front of the dense layers when the model is the reference's conv1D_PCA
+  int64_t c1_stride = 0;                // floats per block row of the Conv1D activation buffers
   float *d_mean_in = nullptr, *d_mean_out = nullptr;
   float4 *d_bpack_in = nullptr, *d_bpack_out = nullptr;
   float *d_ia = nullptr, *d_ib = nullptr, *d_sa = nullptr, *d_sb = nullptr;
@@ -292,7 +301,7 @@ void destroy_graphs(psm_handle* h) {
 void ws_free(Workspace& w) {
   dev_free(w.d_part); dev_free(w.d_xin); dev_free(w.d_act[0]); dev_free(w.d_act[1]); dev_free(w.d_res); dev_free(w.d_pred);
   dev_free(w.d_row_scale); dev_free(w.d_spart); dev_free(w.d_colpart); dev_free(w.d_offs); dev_free(w.d_shift); dev_free(w.d_dots);
-  dev_free(w.d_gflags);
+  dev_free(w.d_gflags); dev_free(w.d_c1[0]); dev_free(w.d_c1[1]);
 }
 
 // flags of one solve's guard waves: zero until a wave finds a mismatch (every wave rewrites its flag on every solve)
@@ -324,6 +333,10 @@ int ws_alloc(psm_handle* h, Workspace& w) {
   HIPCHK(h, hipMemset(w.d_act[1], 0, (size_t)h->Mpad_cap * h->max_width * sizeof(float)));
   if (h->bound && h->bound_dots) { if ((rc = dev_alloc(h, &w.d_dots, h->bound_dots))) return rc; }
   if (h->bound && (rc = ws_alloc_guard(h, w))) return rc;
+  for (int q = 0; q < 2 && h->c1_stride; ++q) {             // padding columns of the last layer's rows are read by the dense kernel
+    if ((rc = dev_alloc(h, &w.d_c1[q], (size_t)h->Mpad_cap * h->c1_stride))) return rc;
+    HIPCHK(h, hipMemset(w.d_c1[q], 0, (size_t)h->Mpad_cap * h->c1_stride * sizeof(float)));
+  }
   return PSM_OK;
 }
 
@@ -464,6 +477,7 @@ std::vector<uint16_t> pack_comp_out_bf16(const double* comp, int P, int K_out, i
 bool model_complete(const psm_handle* h) {
   if (!h->have_pca || !h->have_scaler) return false;
   for (auto& d : h->dense) if (!d.set) return false;
+  for (auto& c : h->conv1d) if (!c.set) return false;
   return true;
 }
 
@@ -545,8 +559,9 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
     return da;
   };
   // few block rows: slab reduce + first dense layer in one launch (one workgroup per row)
+  const bool c1 = !h->conv1d.empty();
   const bool fuse1 = h->fuse_reduce_dense1 && Mpad <= 128 && h->ld_in <= 512 && h->dense[0].ldw <= 1024 &&
-                     h->timed_kernel != PSM_K_REDUCE;
+                     h->timed_kernel != PSM_K_REDUCE && !c1;
   int l_first = 0;
   if (fuse1) {
     tm.before(PSM_K_REDUCE);
@@ -561,6 +576,20 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
   PSM_REPEAT(h, PSM_K_MLP) {
     const float* cur = w.d_xin; int ld_cur = h->ld_in;
     l_first = 0;
+    if (c1) {                                  // conv1D_PCA head: Conv1D layers over the scaled coefficients, then Flatten
+      int64_t stride = h->ld_in;
+      const int nc = (int)h->conv1d.size();
+      for (int q = 0; q < nc; ++q) {
+        const Conv1dLayer& c = h->conv1d[q];
+        PsmConv1dArgs ca{};
+        ca.in = cur; ca.in_stride = stride; ca.W = c.W; ca.bias = c.b; ca.out = w.d_c1[q & 1];
+        ca.out_stride = q == nc - 1 ? (int64_t)round_up(h->cfg.p_in * c.cout, 32) : (int64_t)h->cfg.p_in * c.cout;
+        ca.M = M; ca.P = h->cfg.p_in; ca.k = c.k; ca.c_in = c.cin; ca.c_out = c.cout; ca.relu = 1;
+        HIPCHK(h, psm_launch_conv1d(ca, st));
+        cur = ca.out; stride = ca.out_stride;
+      }
+      ld_cur = (int)stride;
+    }
     if (fuse1) {
       PsmDenseArgs d0 = dense_args(0, cur, ld_cur);
       HIPCHK(h, psm_launch_reduce_dense1(ra, d0, st));
@@ -828,6 +857,7 @@ void psm_destroy(psm_handle* h) {
   dev_free(h->d_comp_nat); dev_free(h->d_g2); dev_free(h->d_c2); dev_free(h->d_cnt); dev_free(h->d_row_of); dev_free(h->d_ownbits);
   dev_free(h->d_ia); dev_free(h->d_ib); dev_free(h->d_sa); dev_free(h->d_sb);
   dev_free(h->d_maskbits); dev_free(h->d_gzero);
+  for (auto& c : h->conv1d) { dev_free(c.W); dev_free(c.b); }
   if (h->h_guard) (void)hipHostFree(h->h_guard);
   for (int i = 0; i < psm_handle::RING; ++i) {
     if (h->h_scale[i]) (void)hipHostFree(h->h_scale[i]);
@@ -887,8 +917,11 @@ int psm_set_pca(psm_handle* h, const double* comp_in, const double* mean_in, con
 int psm_set_dense(psm_handle* h, int32_t layer, int32_t n_in, int32_t n_out, const float* kernel, const float* bias) {
   if (!h) return PSM_ERR_ARG;
   if (layer < 0 || layer >= (int)h->dense.size()) return fail(h, PSM_ERR_ARG, "layer index out of range");
-  if (!kernel || !bias || n_in < 1 || n_out < 1 || n_in > 4096 || n_out > 4096) return fail(h, PSM_ERR_ARG, "bad dense layer");
-  if (layer == 0 && n_in != h->cfg.p_in) return fail(h, PSM_ERR_ARG, "first layer input width must equal p_in");
+  const int in_cap = h->conv1d.empty() ? 4096 : (1 << 18);
+  if (!kernel || !bias || n_in < 1 || n_out < 1 || n_in > (layer == 0 ? in_cap : 4096) || n_out > 4096) return fail(h, PSM_ERR_ARG, "bad dense layer");
+  const int first_in = h->conv1d.empty() ? h->cfg.p_in : h->cfg.p_in * h->conv1d.back().cout;     // Flatten of [p_in, filters]
+  if (layer == 0 && n_in != first_in)
+    return fail(h, PSM_ERR_ARG, h->conv1d.empty() ? "first layer input width must equal p_in" : "first Dense layer after the Conv1D stack must take p_in * filters inputs (Flatten)");
   if (layer == (int)h->dense.size() - 1 && n_out != h->cfg.p_out) return fail(h, PSM_ERR_ARG, "head width must equal p_out");
   if (layer > 0 && h->dense[layer - 1].set && h->dense[layer - 1].n_out != n_in) return fail(h, PSM_ERR_ARG, "dense layers do not chain");
   HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -931,6 +964,34 @@ int psm_set_dense(psm_handle* h, int32_t layer, int32_t n_in, int32_t n_out, con
   }
   if ((rc = dev_upload(h, &d.b, b))) return rc;
   d.set = true;
+  return PSM_OK;
+}
+
+int psm_set_conv1d(psm_handle* h, int32_t layer, int32_t n_layers, int32_t kernel_size, int32_t c_in, int32_t c_out, const float* kernel,
+                   const float* bias) {
+  if (!h) return PSM_ERR_ARG;
+  if (n_layers < 1 || n_layers > 32 || layer < 0 || layer >= n_layers) return fail(h, PSM_ERR_ARG, "Conv1D layer index out of range");
+  if (!kernel || !bias || kernel_size < 1 || kernel_size > 15 || c_in < 1 || c_out < 1 || c_in > 2048 || c_out > 2048)
+    return fail(h, PSM_ERR_ARG, "bad Conv1D layer");
+  if (h->cfg.precision != PSM_PRECISION_F32) return fail(h, PSM_ERR_UNSUPPORTED, "the conv1D_PCA head is float32 only");
+  if ((int64_t)h->cfg.p_in * c_out > (1 << 18)) return fail(h, PSM_ERR_UNSUPPORTED, "Conv1D activation wider than 2^18 per block");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  destroy_graphs(h);
+  h->bound = false;
+  if ((int)h->conv1d.size() != n_layers) {
+    for (auto& c : h->conv1d) { dev_free(c.W); dev_free(c.b); }
+    h->conv1d.assign(n_layers, Conv1dLayer{});
+    if (h->planned) free_plan(h);                        // the workspaces depend on the stack
+  }
+  if (layer == 0 && c_in != 1) return fail(h, PSM_ERR_ARG, "the first Conv1D layer sees the coefficients as [p_in, 1]: c_in must be 1");
+  if (layer > 0 && h->conv1d[layer - 1].set && h->conv1d[layer - 1].cout != c_in) return fail(h, PSM_ERR_ARG, "Conv1D layers do not chain");
+  Conv1dLayer& c = h->conv1d[layer];
+  c.k = kernel_size; c.cin = c_in; c.cout = c_out;
+  std::vector<float> W(kernel, kernel + (size_t)kernel_size * c_in * c_out), b(bias, bias + c_out);
+  int rc;
+  if ((rc = dev_upload(h, &c.W, W)) || (rc = dev_upload(h, &c.b, b))) return rc;
+  c.set = true;
   return PSM_OK;
 }
 
@@ -983,6 +1044,13 @@ int psm_plan_grid(psm_handle* h, int32_t ny, int32_t nx) {
   h->n_strips = (int)h->plan.strips.size();
   h->max_width = h->ld_in;
   for (auto& d : h->dense) h->max_width = std::max(h->max_width, d.ldw);
+  h->c1_stride = 0;
+  for (size_t q = 0; q < h->conv1d.size(); ++q) {
+    if (q > 0 && h->conv1d[q - 1].cout != h->conv1d[q].cin) return fail(h, PSM_ERR_ARG, "Conv1D layers do not chain");
+    h->c1_stride = std::max<int64_t>(h->c1_stride, round_up(h->cfg.p_in * h->conv1d[q].cout, 32));
+  }
+  if (!h->conv1d.empty() && h->dense[0].n_in != h->cfg.p_in * h->conv1d.back().cout)
+    return fail(h, PSM_ERR_ARG, "first Dense layer after the Conv1D stack must take p_in * filters inputs (call psm_set_conv1d before psm_set_dense)");
   const size_t npix = (size_t)ny * nx;
   h->n_bands = h->S / PSM_STRIP_BAND;
   if ((rc = ws_alloc(h, h->ws0))) return rc;

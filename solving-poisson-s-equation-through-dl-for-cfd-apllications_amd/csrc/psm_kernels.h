@@ -44,6 +44,16 @@ struct PsmDenseArgs {
   int layer;                           // layer index (diagnostic stamps only)
 };
 
+// Conv1D layer of the reference's conv1D_PCA head (NNs.py:75-124): 'same' padding, cross-correlation like Keras,
+// out[m][p][co] = act(bias[co] + sum_{t, ci} in[m][p + t - (k-1)/2][ci] * W[t][ci][co])  over the p_in scaled PCA coefficients
+struct PsmConv1dArgs {
+  const float* in; int64_t in_stride;   // row m at in + m * in_stride, element (p, ci) at p * c_in + ci
+  const float* W; const float* bias;    // Keras Conv1D kernel [k][c_in][c_out], bias [c_out]
+  float* out; int64_t out_stride;       // element (p, co) at p * c_out + co
+  int M, P, k, c_in, c_out, relu;
+};
+hipError_t psm_launch_conv1d(const PsmConv1dArgs& a, hipStream_t s);
+
 struct PsmDecodeArgs {
   const float* res; int ld_res;        // [Mpad][ld_res] inverse-scaled network output
   const float4* bpack;                 // [ncoltiles][Gd][64] float4

@@ -474,6 +474,51 @@ hipError_t psm_launch_reduce_dense1(const PsmReduceArgs& r, const PsmDenseArgs& 
 }
 
 // ---------------------------------------------------------------------------
+// Conv1D over the PCA coefficients (conv1D_PCA head, NNs.py:75-124; the reference's 'conv1D' architecture has 7 layers of
+// 128-64-32-16-32-64-128 filters, kernel 3, utils.py:452-454).  A rarely used head on <= a few hundred block rows of
+// <= 128 positions: plain float32 FMAs, a thread owns 4 consecutive positions of one output channel (one weight load
+// feeds 4 FMAs; lanes run over the output channels, so weight loads are coalesced and activation loads broadcast).
+__global__ __launch_bounds__(256) void psm_conv1d_kernel(PsmConv1dArgs a) {
+  const int m = blockIdx.y;
+  const int items = ((a.P + 3) / 4) * a.c_out;
+  const int item = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (item >= items) return;
+  const int pt = item / a.c_out, co = item - pt * a.c_out;
+  const int p0 = 4 * pt - (a.k - 1) / 2;                    // Keras 'same': (k - 1) / 2 zeros in front
+  const float* in = a.in + (int64_t)m * a.in_stride;
+  const float bv = a.bias[co];
+  float acc[4] = {bv, bv, bv, bv};
+  for (int t = 0; t < a.k; ++t) {
+    const float* w = a.W + (int64_t)t * a.c_in * a.c_out + co;
+    int pos[4]; float keep[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int p = p0 + t + j;
+      keep[j] = (p >= 0 && p < a.P) ? 1.f : 0.f;
+      pos[j] = min(max(p, 0), a.P - 1) * a.c_in;
+    }
+    for (int ci = 0; ci < a.c_in; ++ci) {
+      const float wv = w[(int64_t)ci * a.c_out];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = fmaf(in[pos[j] + ci] * keep[j], wv, acc[j]);
+    }
+  }
+  float* out = a.out + (int64_t)m * a.out_stride;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int p = 4 * pt + j;
+    if (p < a.P) out[(int64_t)p * a.c_out + co] = a.relu ? fmaxf(acc[j], 0.f) : acc[j];
+  }
+}
+
+hipError_t psm_launch_conv1d(const PsmConv1dArgs& a, hipStream_t st) {
+  if (a.M < 1 || a.P < 1 || a.k < 1 || a.k > 15 || a.c_in < 1 || a.c_out < 1) return hipErrorInvalidValue;
+  const int items = ((a.P + 3) / 4) * a.c_out;
+  PSM_LAUNCH(psm_conv1d_kernel, dim3((items + 255) / 256, a.M), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // dense layer: v_mfma_f32_16x16x4_f32, one 16-column tile x 32 rows per workgroup,
 // K split over 8 waves, operands prefetched to registers in one round trip.
 //   A: lane l holds A[i = l&15][k = l>>4];  B: lane l holds B[k = l>>4][j = l&15]

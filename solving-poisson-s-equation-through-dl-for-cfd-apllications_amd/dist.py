@@ -139,6 +139,10 @@ def broadcast_model(model, src: int = 0, device="cpu"):
                 for i, (W, b) in enumerate(v):
                     payload[f"W{i}"], payload[f"b{i}"] = np.asarray(W), np.asarray(b)
                 scal["n_layers"] = len(v)
+            elif f.name == "conv1d":
+                for i, (K, b) in enumerate(v):
+                    payload[f"cK{i}"], payload[f"cb{i}"] = np.asarray(K), np.asarray(b)
+                scal["n_conv1d"] = len(v)
             elif isinstance(v, np.ndarray):
                 payload["f:" + f.name] = v
             else:
@@ -148,9 +152,11 @@ def broadcast_model(model, src: int = 0, device="cpu"):
     arrs = broadcast_arrays(payload, src, device)
     scal = dict(meta[0])
     n_layers = scal.pop("n_layers")
+    n_conv1d = scal.pop("n_conv1d", 0)
     kw = dict(scal)
     kw.update({k[2:]: v for k, v in arrs.items() if k.startswith("f:")})
     kw["weights"] = [(arrs[f"W{i}"], arrs[f"b{i}"]) for i in range(n_layers)]
+    kw["conv1d"] = [(arrs[f"cK{i}"], arrs[f"cb{i}"]) for i in range(n_conv1d)]
     return SurrogateModel(**kw)
 
 

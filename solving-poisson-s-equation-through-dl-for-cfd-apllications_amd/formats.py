@@ -236,6 +236,39 @@ def read_keras_dense_weights(path: str) -> List[Tuple[np.ndarray, np.ndarray]]:
     return out
 
 
+def read_keras_conv1d_head(path: str):
+    """A Keras HDF5 file of the reference's NN zoo (NNs.py) -> (conv1d layers, dense layers): the Conv1D layers
+    ``conv1d``, ``conv1d_1``, ... of ``conv1D_PCA`` (kernel [k, c_in, c_out]) in creation order -- an empty list for the
+    Dense stacks of ``densePCA`` -- and the Dense layers behind them.  The first Dense layer of a conv1D_PCA file takes the
+    flattened [p_in, filters] activation."""
+    ds = read_h5_datasets(path)
+    layers: Dict[str, Dict[str, np.ndarray]] = {}
+    for p, a in ds.items():
+        parts = [q for q in p.split("/") if q]
+        if parts[-1] not in ("kernel:0", "bias:0"):
+            continue
+        lname = next((q for q in parts if re.fullmatch(r"conv1d(?:_\d+)?", q)), None)
+        if lname is not None:
+            layers.setdefault(lname, {})[parts[-1]] = a
+    convs = []
+    for n in sorted(layers, key=lambda s: int(s.split("_")[1]) if "_" in s else 0):
+        if "kernel:0" not in layers[n] or "bias:0" not in layers[n]:
+            raise H5FormatError(f"layer {n} lacks kernel or bias")
+        K = np.ascontiguousarray(layers[n]["kernel:0"], np.float32)
+        b = np.ascontiguousarray(layers[n]["bias:0"], np.float32)
+        if K.ndim != 3 or b.shape != (K.shape[2],):
+            raise H5FormatError(f"layer {n}: unexpected shapes {K.shape} {b.shape}")
+        if convs and convs[-1][0].shape[2] != K.shape[1]:
+            raise H5FormatError("conv1d layers do not chain")
+        convs.append((K, b))
+    if convs and convs[0][0].shape[1] != 1:
+        raise H5FormatError("the first Conv1D layer of conv1D_PCA has one input channel")
+    dense = read_keras_dense_weights(path)
+    if convs and dense[0][0].shape[0] % convs[-1][0].shape[2] != 0:
+        raise H5FormatError("the Dense layer behind the Conv1D stack does not take a flattened [p_in, filters] input")
+    return convs, dense
+
+
 def read_keras_conv_weights(path: str) -> List[Tuple[np.ndarray, np.ndarray]]:
     """Ordered [(kernel[kh,kw,c_in,c_out] f32, bias[c_out] f32)] of the Conv2D layers of a Keras HDF5 file
     (``model.save_weights`` / ``model.save``): layers are the groups named ``conv2d``, ``conv2d_1``, ... and are ordered

@@ -66,6 +66,12 @@ class GridSurrogate:
             if ci.shape != (model.p_in, model.S ** 2 * model.c_in) or co.shape != (model.p_out, model.S ** 2 * model.c_out):
                 raise ValueError("PCA component matrices have the wrong shape")
             self._chk(self.lib.psm_set_pca(h, _p(ci, C.c_double), _p(mi, C.c_double), _p(co, C.c_double), _p(mo, C.c_double)))
+            convs = list(getattr(model, "conv1d", None) or [])
+            for l, (K, b) in enumerate(convs):                  # conv1D_PCA head: before the Dense layers
+                K, b = _f32(K), _f32(b)
+                if K.ndim != 3 or b.shape != (K.shape[2],):
+                    raise ValueError("Conv1D kernels must be [kernel_size, c_in, c_out] with bias [c_out]")
+                self._chk(self.lib.psm_set_conv1d(h, l, len(convs), K.shape[0], K.shape[1], K.shape[2], _p(K, C.c_float), _p(b, C.c_float)))
             for l, (W, b) in enumerate(model.weights):
                 W, b = _f32(W), _f32(b)
                 self._chk(self.lib.psm_set_dense(h, l, W.shape[0], W.shape[1], _p(W, C.c_float), _p(b, C.c_float)))
@@ -400,7 +406,7 @@ def load_artifacts(variant, model_path, directory, var_p, var_in, max_num_PC, st
     -> (SurrogateModel, maxs)."""
     from . import formats
     maxs = formats.read_maxs(os.path.join(directory, "maxs"))
-    weights = formats.read_keras_dense_weights(model_path)
+    convs, weights = formats.read_keras_conv1d_head(model_path)     # Dense stack, or the conv1D_PCA head (NNs.py:75-124)
     pin = formats.load_pca(formats.find_pca(directory, "ipca_input"))
     pout = formats.load_pca(formats.find_pca(directory, "ipca_p"))
     pc_p = formats.select_num_pc(pout.explained_variance_ratio_, var_p, max_num_PC)
@@ -408,11 +414,13 @@ def load_artifacts(variant, model_path, directory, var_p, var_in, max_num_PC, st
     c_out = 2 if variant == "gradp" else 1
     if pin.components_.shape[1] != shape * shape * c_in or pout.components_.shape[1] != shape * shape * c_out:
         raise ValueError("PCA artefacts do not match the block shape / channel count")
-    if weights[0][0].shape[0] != pc_in or weights[-1][0].shape[1] != pc_p:
-        raise ValueError(f"network is {weights[0][0].shape[0]} -> {weights[-1][0].shape[1]} but the PCA rule gives "
+    first_in = weights[0][0].shape[0] // (convs[-1][0].shape[2] if convs else 1)
+    if first_in != pc_in or weights[-1][0].shape[1] != pc_p:
+        raise ValueError(f"network is {first_in} -> {weights[-1][0].shape[1]} but the PCA rule gives "
                          f"{pc_in} -> {pc_p} components")
     m = SurrogateModel(variant, c_in, c_out, pin.components_[:pc_in], pin.mean_, pout.components_[:pc_p], pout.mean_,
                        list(weights), scaler_kind=standardization_method, S=shape)
+    m.conv1d = list(convs)
     m.ov = int(overlap) if overlap else None                 # deltas: overlap in cells; gradp: `avance`
     m.sdf_ch = sdf_ch
     if standardization_method == "max_abs":
@@ -424,6 +432,30 @@ def load_artifacts(variant, model_path, directory, var_p, var_in, max_num_PC, st
         m.in_a, m.in_b, m.out_a, m.out_b = (np.asarray(a, np.float64)[:pc_in], np.asarray(b, np.float64)[:pc_in],
                                             np.asarray(c, np.float64)[:pc_p], np.asarray(d, np.float64)[:pc_p])
     return m, maxs
+
+
+def error_metrics(pred, truth, no_flow_bool) -> dict:
+    """The error summary every evaluator of the reference prints per frame (SM_call.py:696-724;
+    pressureSM_Poisson/SM_call.py:962-994; Eval_dual_Dense_onlycil.py:667-687): over the flow cells, with
+    norm = max - min of the truth there and NaN differences left out,
+    BIAS = mean(pred - true) / norm, RMSE = sqrt(mean((pred - true)^2)) / norm, STDE = sqrt(RMSE^2 - BIAS^2), in percent;
+    ``mean_err`` / ``mean_sq_err`` are the two values the reference appends to ``pred_minus_true`` / ``pred_minus_true_squared``."""
+    true_masked, pred_masked = np.asarray(truth)[~no_flow_bool], np.asarray(pred)[~no_flow_bool]
+    norm = np.max(true_masked) - np.min(true_masked)
+    diff = pred_masked - true_masked
+    diff = diff[~np.isnan(diff)]
+    bias = np.mean(diff) / norm * 100
+    rmse = np.sqrt(np.mean(diff ** 2)) / norm * 100
+    with np.errstate(invalid="ignore"):
+        stde = np.sqrt(rmse ** 2 - bias ** 2)
+    return {"normVal": float(norm), "biasNorm": float(bias), "stdeNorm": float(stde), "rmseNorm": float(rmse),
+            "mean_err": float(np.mean(diff) / norm), "mean_sq_err": float(np.mean(diff ** 2) / norm ** 2)}
+
+
+def _summary(b, s) -> dict:
+    """BIAS / RMSE / STDE [%] of a list of frames as the reference's mains print them (SM_call.py:887-895)."""
+    bias, rmse = np.mean(b) * 100, np.sqrt(np.mean(s)) * 100
+    return {"BIAS": float(bias), "RMSE": float(rmse), "STDE": float(np.sqrt(max(rmse ** 2 - bias ** 2, 0.0)))}
 
 
 class Evaluation:
@@ -546,18 +578,30 @@ class Evaluation:
         self._record_errors(res, self.cfd_results, self.no_flow_bool)
         return res
 
-    def _record_errors(self, field, truth, no_flow_bool):
-        """SM_call.py:696-724: normalised bias / squared error of the assembled field over the flow cells,
-        appended to ``pred_minus_true`` / ``pred_minus_true_squared`` (what ``call_SM_main`` averages)."""
-        true_masked, pred_masked = truth[~no_flow_bool], field[~no_flow_bool]
-        norm = np.max(true_masked) - np.min(true_masked)
-        diff = pred_masked - true_masked
-        diff = diff[~np.isnan(diff)]
-        for name in ("pred_minus_true", "pred_minus_true_squared"):
+    print_metrics = False           # True: print the per-frame error block like the reference's timeStep does
+
+    def _record_errors(self, field, truth, no_flow_bool, suffix: str = "", title: str = None):
+        """SM_call.py:696-724: normalised bias / squared error of the assembled field over the flow cells, appended to
+        ``pred_minus_true<suffix>`` / ``pred_minus_true_squared<suffix>`` (what the mains average); the frame's
+        normVal / biasNorm / stdeNorm / rmseNorm are kept in ``self.last_metrics[suffix or 'delta_p']``."""
+        m = error_metrics(field, truth, no_flow_bool)
+        for name in ("pred_minus_true" + suffix, "pred_minus_true_squared" + suffix):
             if not hasattr(self, name):
                 setattr(self, name, [])
-        self.pred_minus_true.append(np.mean(diff) / norm)
-        self.pred_minus_true_squared.append(np.mean(diff ** 2) / norm ** 2)
+        getattr(self, "pred_minus_true" + suffix).append(m["mean_err"])
+        getattr(self, "pred_minus_true_squared" + suffix).append(m["mean_sq_err"])
+        if not isinstance(getattr(self, "last_metrics", None), dict):
+            self.last_metrics = {}
+        self.last_metrics[suffix.lstrip("_") or "delta_p"] = m
+        if self.print_metrics:
+            print(f"""
+		{'** ' + title + ' **' if title else ''}
+		normVal  = {m['normVal']} Pa
+		biasNorm = {m['biasNorm']:.3f}%
+		stdeNorm = {m['stdeNorm']:.3f}%
+		rmseNorm = {m['rmseNorm']:.3f}%
+		""", flush=True)
+        return m
 
     def timeStep_grid(self, grid: np.ndarray, U_max_norm: float = 1.0, max_abs_p: float = 1.0) -> np.ndarray:
         """Grid-native body of ``timeStep`` (SM_call.py:452-575): -> deltap_res [Ny,Nx]."""
@@ -613,9 +657,7 @@ def call_SM_main(delta, model_name, shape, overlap_ratio, var_p, var_in, max_num
                     device=device, artifact_dir=artifact_dir)
     ev.pred_minus_true, ev.pred_minus_true_squared = [], []
 
-    def summary(b, s):
-        bias, rmse = np.mean(b) * 100, np.sqrt(np.mean(s)) * 100
-        return {"BIAS": float(bias), "RMSE": float(rmse), "STDE": float(np.sqrt(max(rmse ** 2 - bias ** 2, 0.0)))}
+    summary = _summary
     out = {"sims": []}
     for sim in range(n_sims):
         n0 = len(ev.pred_minus_true)
@@ -628,6 +670,70 @@ def call_SM_main(delta, model_name, shape, overlap_ratio, var_p, var_in, max_num
             out["sims"].append(None)                       # every frame of this simulation was irrelevant
     if ev.pred_minus_true:
         out["overall"] = summary(ev.pred_minus_true, ev.pred_minus_true_squared)
+    return out
+
+
+def call_SM_main_Poisson(delta, model_name, shape, overlap_ratio, var_p, var_in, max_num_PC, dataset_path,
+                         plot_intermediate_fields, standardization_method, k, save_plots, show_plots, apply_filter, create_GIF,
+                         n_sims, n_ts, phis_fn, device: int = 0, artifact_dir: str = None, sim_offset: int = 1, time_offset: int = 16):
+    """``pressureSM_Poisson.SM_call.call_SM_main`` (pressureSM_Poisson/SM_call.py:1069-1170), same argument list: evaluates
+    frames ``time_offset .. time_offset + n_ts`` of simulations ``sim_offset .. sim_offset + n_sims`` (the reference's
+    ``sim += 1`` / ``time += 16``, :1095, :1104) with ``phi = phi_list[sim]`` from ``phis_fn`` and returns the three error
+    summaries it prints -- delta-p with the deltaU-change weighting, delta-p without it, and p -- per simulation (last
+    ``n_ts`` frames, :1110-1116) and overall.  Plots and GIFs are not produced."""
+    overlap = int(overlap_ratio * shape)
+    ev = EvaluationPoisson(delta, shape, overlap, var_p, var_in, dataset_path, model_name, max_num_PC, standardization_method,
+                           k, phis_fn, device=device, artifact_dir=artifact_dir)
+    for sfx in ("", "_deltap_crude", "_p"):
+        setattr(ev, "pred_minus_true" + sfx, [])
+        setattr(ev, "pred_minus_true_squared" + sfx, [])
+    phi_list = np.atleast_1d(np.loadtxt(phis_fn, dtype=float))
+    out = {"sims": []}
+    for sim in range(n_sims):
+        sim += sim_offset
+        ev.computeOnlyOnce(sim)
+        phi = phi_list[sim]
+        n0 = len(ev.pred_minus_true)
+        for time in range(n_ts):
+            ev.timeStep(sim, time + time_offset, plot_intermediate_fields, save_plots, show_plots, apply_filter, phi)
+        if len(ev.pred_minus_true) > n0:
+            out["sims"].append({"sim": sim, "phi": float(phi),
+                                "delta_p": _summary(ev.pred_minus_true[-n_ts:], ev.pred_minus_true_squared[-n_ts:]),
+                                "delta_p_no_weighting": _summary(ev.pred_minus_true_deltap_crude[-n_ts:], ev.pred_minus_true_squared_deltap_crude[-n_ts:])})
+        else:
+            out["sims"].append(None)
+    if ev.pred_minus_true:
+        out["overall"] = {"delta_p": _summary(ev.pred_minus_true, ev.pred_minus_true_squared),
+                          "delta_p_no_weighting": _summary(ev.pred_minus_true_deltap_crude, ev.pred_minus_true_squared_deltap_crude),
+                          "p": _summary(ev.pred_minus_true_p, ev.pred_minus_true_squared_p)}
+    return out
+
+
+def main_gradP(delta=5e-3, model_directory="model_1.h5", shape=128, avance=None, var_p=0.95, var_in=0.95, max_number_PC=512,
+               hdf5_path="dataset_gradP_cil.hdf5", plot_intermediate_fields=True, save_plots=True, show_plots=False,
+               apply_filter=False, sims=(0,), n_ts=5, device: int = 0, artifact_dir: str = None):
+    """``main`` of the U_to_gradP evaluator (Eval_dual_Dense_onlycil.py:692-744) with its hard-coded inputs as defaults
+    (``avance = int(0.75 * shape)``, simulations ``[0]``, five time steps): computeOnlyOnce + timeStep per frame, then
+    BIAS / RMSE / STDE [%] "for the sim" from the accumulated per-frame values (:735-742) -- printed like the reference and
+    returned.  Plots are not produced."""
+    if avance is None:
+        avance = int(0.75 * shape)
+    ev = EvaluationGradP(delta, shape, avance, var_p, var_in, hdf5_path, model_directory, max_number_PC, device=device,
+                         artifact_dir=artifact_dir)
+    ev.pred_minus_true, ev.pred_minus_true_squared = [], []
+    out = {"sims": [], "frames": []}
+    for sim in sims:
+        ev.computeOnlyOnce(sim)
+        for time in range(n_ts):
+            ev.timeStep(sim, time, plot_intermediate_fields, save_plots, show_plots, apply_filter)
+            out["frames"].append(dict(sim=sim, time=time, **{k: dict(v) for k, v in ev.last_metrics.items()}))
+        # like the reference: over everything accumulated so far, not only this simulation (:735-737)
+        s = _summary(ev.pred_minus_true, ev.pred_minus_true_squared)
+        print("Metrics for the whole simulation:")
+        print("BIAS for the sim: " + str(s["BIAS"]))
+        print("RMSE for the sim: " + str(s["RMSE"]))
+        print("STDE for the sim: " + str(s["STDE"]))
+        out["sims"].append(s)
     return out
 
 
@@ -676,9 +782,20 @@ class EvaluationPoisson(Evaluation):
         g = self._mesh_to_grid(cols)                                                                 # :577-600, NaNs kept
         U = float(U_max_norm)
         self.U_max_norm = U
-        return self.timeStep_grid(g[..., 0], g[..., 1], g[..., 2], g[..., 3], self.sdfunct[..., 0], phi, U,
-                                  deltaU_change_grid=g[..., 6], deltaP_prev_grid=g[..., 7], apply_filter=apply_filter,
-                                  apply_deltaU_change_wgt=True)                                       # :831
+        field_deltap = self.timeStep_grid(g[..., 0], g[..., 1], g[..., 2], g[..., 3], self.sdfunct[..., 0], phi, U,
+                                          deltaU_change_grid=g[..., 6], deltaP_prev_grid=g[..., 7], apply_filter=apply_filter,
+                                          apply_deltaU_change_wgt=True)                               # :831
+        # ---- the three error blocks of :962-1043: delta-p (weighted), delta-p without the weighting, and p
+        delta_p_grid = np.nan_to_num(g[..., 4] / pow(U, 2.0), nan=0.0) / self.max_abs_delta_p         # :687-711 (channel 4)
+        p_grid = np.nan_to_num(g[..., 5], nan=0.0)                                                    # :692-702 (channel 5)
+        self.cfd_results = delta_p_grid * self.max_abs_delta_p * pow(U, 2.0)                          # :849
+        sd = np.nan_to_num(self.sdfunct[..., 0], nan=0.0) / self.max_abs_dist
+        self.no_flow_bool = sd == 0                                                                   # :850
+        self.p_pred = (p_grid - self.cfd_results) + field_deltap                                      # :907-908
+        self._record_errors(field_deltap, self.cfd_results, self.no_flow_bool, "", "Error in delta_p")
+        self._record_errors(self.deltap_res, self.cfd_results, self.no_flow_bool, "_deltap_crude", "Error in delta_p - no weighting")
+        self._record_errors(self.p_pred, p_grid, self.no_flow_bool, "_p", "Error in p")
+        return field_deltap
 
     def build_features(self, ux_grid, uy_grid, delta_ux_grid, delta_uy_grid, sdfunct, phi, U_max_norm) -> np.ndarray:
         """SM_call.py:588-711 (after the interpolation to the grid): -> grid [Ny,Nx,4] float32."""
@@ -698,6 +815,7 @@ class EvaluationPoisson(Evaluation):
         res = sur.solve(grid, out_scale=[self.max_abs_delta_p * U_max_norm ** 2])[0, :, :, 0]     # :816
         wgt = apply_deltaU_change_wgt and deltaU_change_grid is not None and deltaP_prev_grid is not None
         res, change = self._post_steps(sur, res, apply_filter, deltaU_change_grid, deltaP_prev_grid, wgt)
+        self.deltap_res = res                                    # the assembled delta-p before the weighting (:833)
         return np.asarray(deltaP_prev_grid, np.float32) + change if wgt else res
 
 
@@ -777,7 +895,17 @@ class EvaluationGradP(Evaluation):
         center_p_y = 200
         sur.set_integration(self.sdfunct[..., 0], center_p_y, center_p_x, float(np.diff(xl)[0]), float(np.diff(yl)[0]))
         self.center_p_x, self.center_p_y = center_p_x, center_p_y
-        return sur.integrate_gradp(gradP)                                                 # :597-628
+        field = sur.integrate_gradp(gradP)                                                # :597-628
+        # ---- error block of :667-687.  The reference takes its "true" values from grid channel 3 -- the normalised dP/dx
+        # label, not the pressure of channel 5 that its plot shows (:644-650) -- and that is what it accumulates in
+        # pred_minus_true / pred_minus_true_squared; reproduced as written, with the comparison against the pressure label
+        # kept beside it (last_metrics['p']).
+        no_flow = grid[..., 2] == 0
+        self.no_flow_bool = no_flow
+        self._record_errors(field, grid[..., 3], no_flow, "", "reference metric (grid channel 3)")
+        self.last_metrics["reference"] = self.last_metrics.pop("delta_p")
+        self.last_metrics["p"] = error_metrics(field, grid[..., 5], no_flow)
+        return field
 
     def timeStep_grid(self, grid: np.ndarray) -> np.ndarray:
         """Eval_dual_Dense_onlycil.py:470-547: -> [Ny,Nx,2] = (res_dPdx, res_dPdy)."""

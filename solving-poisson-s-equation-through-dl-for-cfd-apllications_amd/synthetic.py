@@ -45,6 +45,8 @@ class SurrogateModel:
     S: int = 128
     ov: int | None = None
     sdf_ch: int = 2
+    # conv1D_PCA head (NNs.py:75-124): Conv1D layers [(kernel[k, c_in, c_out] f32, bias[c_out] f32)] in front of `weights`
+    conv1d: List[Tuple[np.ndarray, np.ndarray]] = field(default_factory=list)
 
     @property
     def p_in(self):
@@ -73,6 +75,22 @@ def he_dense_stack(p_in: int, widths: Sequence[int], p_out: int, seed: int):
         bias = (rng.standard_normal(b) * 0.01).astype(np.float32)
         out.append((W, bias))
     return out
+
+
+CONV1D_WIDTHS = [128, 64, 32, 16, 32, 64, 128]        # utils.define_model_arch('conv1D'), utils.py:452-454
+
+
+def he_conv1d_head(p_in: int, filters: Sequence[int], p_out: int, seed: int, kernel_size: int = 3):
+    """Seeded random-init weights of the reference's conv1D_PCA network -> (conv1d layers, dense layers)."""
+    rng = np.random.default_rng(seed)
+    convs, cin = [], 1
+    for f in filters:
+        K = (rng.standard_normal((kernel_size, cin, f)) * np.sqrt(2.0 / (kernel_size * cin))).astype(np.float32)
+        convs.append((K, (rng.standard_normal(f) * 0.01).astype(np.float32)))
+        cin = f
+    n = p_in * cin
+    W = (rng.standard_normal((n, p_out)) * np.sqrt(1.0 / n)).astype(np.float32)
+    return convs, [(W, (rng.standard_normal(p_out) * 0.01).astype(np.float32))]
 
 
 def make_model(variant: str, p_in: int = 128, p_out: int = 128, arch: str = "MLP_small",

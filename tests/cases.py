@@ -29,6 +29,9 @@ GOLDEN_CASES = {
     "chapter4_Mu_128x128": dict(variant="chapter5", Ny=128, Nx=128, chapter4="M_u"),                 # cavity-like vortex, 4 blocks
     "chapter4_Mu_232x312": dict(variant="chapter5", Ny=232, Nx=312, seed=61, chapter4="M_u"),        # channel + cylinder, 35 blocks
     "chapter4_MfU_200x280": dict(variant="chapter5", Ny=200, Nx=280, seed=62, chapter4="M_fU"),      # f(U), SDF -> p: 2 input channels
+    # the reference's conv1D_PCA network (NNs.py:75-124, architecture 'conv1D' of utils.py:452-454) as the evaluator's model:
+    # built by the reference's own function (tests/golden/make_golden.py), weights stored as data in the fixture
+    "deltas_conv1d_256x256": dict(variant="deltas", Ny=256, Nx=256, seed=81, p=32, scaler="std", conv1d=True),
 }
 
 
@@ -40,6 +43,9 @@ DEGENERATE_CASES = {
     "gradp_degenerate_256x256":  dict(variant="gradp", Ny=256, Nx=256, seed=71, p=16),
     "deltas_degenerate_512x512": dict(variant="deltas", Ny=512, Nx=512, seed=72, p=16, scaler="std"),
 }
+
+
+DENSE_GOLDEN_CASES = [k for k, v in GOLDEN_CASES.items() if not v.get("conv1d")]     # Dense-stack networks (C port, bound path)
 
 
 def real_chapter5_weights():
@@ -96,6 +102,13 @@ def build(name: str):
         grid[y0:y1, x0:x1, :] = 0.0
     model = synthetic.make_model(v, p_in=sp["p"], p_out=sp["p"], scaler_kind=sp.get("scaler"),
                                  seed_pca=1000 + sp["seed"], seed_w=sp["seed"])
+    if sp.get("conv1d"):          # weights drawn by the reference-built network in make_golden.py, kept in the fixture
+        f = os.path.join(GOLDEN_DIR, f"{name}.npz")
+        if os.path.exists(f):
+            d = np.load(f)
+            nc = len([k for k in d.files if k.startswith("convK")])
+            model.conv1d = [(d[f"convK{i}"], d[f"convb{i}"]) for i in range(nc)]
+            model.weights = [(d["denseW"], d["denseb"])]
     if v == "deltas":
         model.out_scale = sp.get("max_abs_p", 1.0) * sp.get("U_max_norm", 1.0) ** 2
     return grid, model

@@ -122,6 +122,104 @@ def dense_callable(weights):
     return model
 
 
+class _KerasStub:
+    """Stand-ins for the Keras symbols the reference's ``conv1D_PCA`` (NNs.py:75-124) touches, so that the FUNCTION
+    ITSELF can be executed: it decides which layers exist, in which order, with which kernel size, padding and activation,
+    where the Flatten sits and what the head is.  The arithmetic of the layers is restated in NumPy float32 (TensorFlow is
+    not installable here): Conv1D as an explicit sum over taps of cross-correlations with TensorFlow's 'same' padding,
+    Dense as x @ W + b.  Weights are drawn in layer-creation order from one seeded generator."""
+
+    def __init__(self, seed):
+        self.rng = np.random.default_rng(seed)
+        self.layers = []
+        stub = self
+
+        class Sym:
+            def __init__(self, fn, shape=None):
+                self.fn, self.shape = fn, shape
+
+        def Input(shape=None, **kw):
+            shape = tuple(shape) if isinstance(shape, (tuple, list)) else (int(shape),)
+
+            def feed(x):
+                x = np.asarray(x, np.float32)
+                return x[..., None] if x.ndim == len(shape) else x      # functional models expand a missing last axis of 1
+            return Sym(feed, shape)
+
+        class Layer:
+            def __call__(self, x):
+                return Sym(lambda v: self.apply(x.fn(v)))
+
+        class Conv1D(Layer):
+            def __init__(self, filters, kernel_size, activation=None, padding="valid", kernel_regularizer=None, **kw):
+                self.filters, self.k, self.activation, self.padding = int(filters), int(kernel_size), activation, padding
+                self.K = self.b = None
+                stub.layers.append(self)
+
+            def apply(self, h):
+                if self.K is None:
+                    cin = h.shape[2]
+                    self.K = (stub.rng.standard_normal((self.k, cin, self.filters)) * np.sqrt(2.0 / (self.k * cin))).astype(np.float32)
+                    self.b = (stub.rng.standard_normal(self.filters) * 0.05).astype(np.float32)
+                assert self.padding == "same"
+                n = h.shape[1]
+                front = (self.k - 1) // 2
+                hp = np.pad(h, ((0, 0), (front, self.k - 1 - front), (0, 0)))
+                out = np.zeros((h.shape[0], n, self.filters), np.float32) + self.b
+                for t in range(self.k):
+                    out = out + hp[:, t:t + n, :] @ self.K[t]
+                return np.maximum(out, np.float32(0)) if self.activation == "relu" else out
+
+        class Dense(Layer):
+            def __init__(self, units, activation=None, kernel_regularizer=None, **kw):
+                self.units, self.activation, self.W = int(units), activation, None
+                stub.layers.append(self)
+
+            def apply(self, h):
+                if self.W is None:
+                    self.W = (stub.rng.standard_normal((h.shape[1], self.units)) * np.sqrt(1.0 / h.shape[1])).astype(np.float32)
+                    self.b = (stub.rng.standard_normal(self.units) * 0.05).astype(np.float32)
+                out = h @ self.W + self.b
+                return np.maximum(out, np.float32(0)) if self.activation == "relu" else out
+
+        class Dropout(Layer):
+            def __init__(self, rate, **kw):
+                pass
+
+            def apply(self, h):                       # inference: identity
+                return h
+
+        class Flatten(Layer):
+            def apply(self, h):
+                return h.reshape(h.shape[0], -1)
+
+        class Model:
+            def __init__(self, inputs, outputs, name=None):
+                self.outputs, self.name = outputs, name
+
+            def __call__(self, x):
+                return self.outputs.fn(x)
+
+            def summary(self):
+                return ""
+
+        layers = types.SimpleNamespace(Conv1D=Conv1D, Dense=Dense, Dropout=Dropout, Flatten=Flatten)
+        self.tf = types.SimpleNamespace(keras=types.SimpleNamespace(layers=layers))
+        self.glb = {"tf": self.tf, "Input": Input, "Model": Model, "regularizers": types.SimpleNamespace(l2=lambda v: None), "print": lambda *a, **k: None}
+
+
+def build_reference_conv1d_model(p_in, p_out, seed):
+    """``utils.define_model_arch('conv1D')`` (utils.py:435-461) and ``NNs.conv1D_PCA`` (NNs.py:75-124) executed as written."""
+    UTL = f"{REF}/Improved_SM/deltaU_to_deltaP/source/pressureSM_deltas/utils.py"
+    NNS = f"{REF}/Improved_SM/deltaU_to_deltaP/source/pressureSM_deltas/NNs.py"
+    arch = _method(_tree(UTL), None, "define_model_arch", {}, UTL)
+    n_layers, width = arch("conv1D")
+    stub = _KerasStub(seed)
+    fn = _method(_tree(NNS), None, "conv1D_PCA", stub.glb, NNS)
+    model = fn(n_layers, width, p_in, p_out, 0.1, 1e-4)       # train.py:568 argument order (dropout, L2: inert at inference)
+    return model, stub
+
+
 def solid_band(grid, y0, y1, x0, x1):
     """Zero a rectangle of every channel (a big solid body): forces the
     'no flow cell in the strip' NaN branches of the reassembly."""
@@ -158,7 +256,7 @@ def run_gradp(grid6, model, keep_labels=False):
     return out
 
 
-def run_deltas(grid5, model, U_max_norm=1.0, max_abs_p=1.0, _keep=None):
+def run_deltas(grid5, model, U_max_norm=1.0, max_abs_p=1.0, _keep=None, keras_model=None):
     """SMD.timeStep, from the block extraction to ``assemble_prediction``."""
     tree = _tree(SMD)
     glb = {"np": np, "ndimage": None}
@@ -171,7 +269,7 @@ def run_deltas(grid5, model, U_max_norm=1.0, max_abs_p=1.0, _keep=None):
     self.standardization_method = model.scaler_kind
     self.max_abs_input_PCA, self.max_abs_output_PCA = model.in_a, model.out_a
     self.max_abs_p = max_abs_p
-    self.model = dense_callable(model.weights)
+    self.model = keras_model if keras_model is not None else dense_callable(model.weights)
     body = _find_fn(tree, "timeStep", "Evaluation").body
     stmts = _slice(body, lambda s: s.startswith("x_list = []"),
                    lambda s: s.startswith("(deltap_res, change_in_deltap) =") or s.startswith("deltap_res, change_in_deltap ="))
@@ -556,6 +654,16 @@ def main():
             out = run_chapter4(grid, model, cases.GOLDEN_CASES[name]["chapter4"])
         elif model.variant == "gradp":
             out = run_gradp(grid, model, keep_labels=(name == "gradp_272x288"))
+        elif cases.GOLDEN_CASES[name].get("conv1d"):
+            km, stub = build_reference_conv1d_model(model.p_in, model.p_out, seed=cases.GOLDEN_CASES[name]["seed"])
+            out = run_deltas(grid, model, keras_model=km)
+            convs = [l for l in stub.layers if hasattr(l, "K")]
+            dense = [l for l in stub.layers if hasattr(l, "W")]
+            assert len(dense) == 1 and stub.layers.index(dense[0]) == len(stub.layers) - 1
+            for i, l in enumerate(convs):
+                out[f"convK{i}"], out[f"convb{i}"] = l.K, l.b
+            out["denseW"], out["denseb"] = dense[0].W, dense[0].b
+            print(f"{name}: reference-built conv1D_PCA: filters {[l.filters for l in convs]}, kernel {convs[0].k}, head {dense[0].W.shape}")
         elif model.variant == "deltas":
             out = run_deltas(grid, model, U_max_norm=cases.GOLDEN_CASES[name].get("U_max_norm", 1.0),
                              max_abs_p=cases.GOLDEN_CASES[name].get("max_abs_p", 1.0))

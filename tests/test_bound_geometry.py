@@ -24,7 +24,7 @@ def same(a, b, tol=2e-5):
     assert np.nanmax(np.abs(a - b), initial=0.0) <= tol * scale, (np.nanmax(np.abs(a - b)), scale)
 
 
-@pytest.mark.parametrize("name", list(cases.GOLDEN_CASES))
+@pytest.mark.parametrize("name", cases.DENSE_GOLDEN_CASES)
 def test_bound_equals_general_path_and_golden(name):
     grid, model = cases.build(name)
     gold = cases.load_golden(name)

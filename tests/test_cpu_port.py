@@ -10,7 +10,7 @@ from psm_amd import synthetic
 from test_oracle_golden import oracle_model
 
 
-@pytest.mark.parametrize("name", list(cases.GOLDEN_CASES))
+@pytest.mark.parametrize("name", cases.DENSE_GOLDEN_CASES)
 def test_c_port_matches_reference_run(name):
     grid, model = cases.build(name)
     gold = cases.load_golden(name)

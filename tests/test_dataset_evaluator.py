@@ -216,3 +216,91 @@ def test_poisson_evaluation_from_files_end_to_end(tmp_path):
     ok = ~np.isnan(want)
     assert ok.mean() > 0.1 and np.array_equal(np.isnan(got), ~ok)
     assert np.abs(got[ok] - want[ok]).max() <= 2e-4 * max(np.abs(want[ok]).max(), np.abs(sol.fields).max())
+
+
+# ---------------------------------------------------------------------------------------------
+# error summaries and mains (Eval_dual_Dense_onlycil.py:667-744; pressureSM_Poisson/SM_call.py:962-1170)
+# ---------------------------------------------------------------------------------------------
+def _ref_metrics(pred, truth, no_flow):
+    """The reference's statements (Eval_dual_Dense_onlycil.py:667-676) on plain arrays."""
+    true_mask, pred_mask = truth[~no_flow], pred[~no_flow]
+    norm = np.max(true_mask) - np.min(true_mask)
+    mask_nan = ~np.isnan(pred_mask - true_mask)
+    BIAS_norm = np.mean((pred_mask - true_mask)[mask_nan]) / norm * 100
+    RMSE_norm = np.sqrt(np.mean((pred_mask - true_mask)[mask_nan] ** 2)) / norm * 100
+    return norm, BIAS_norm, np.sqrt(RMSE_norm ** 2 - BIAS_norm ** 2), RMSE_norm, \
+        np.mean((pred_mask - true_mask)[mask_nan]) / norm, np.mean((pred_mask - true_mask)[mask_nan] ** 2) / norm ** 2
+
+
+def test_error_metrics_are_the_reference_statements():
+    from psm_amd import error_metrics
+    rng = np.random.default_rng(4)
+    truth, pred = rng.standard_normal((40, 60)), rng.standard_normal((40, 60))
+    pred[3, 4] = np.nan
+    no_flow = rng.random((40, 60)) < 0.2
+    m = error_metrics(pred, truth, no_flow)
+    norm, b, s, r, e1, e2 = _ref_metrics(pred, truth, no_flow)
+    assert (m["normVal"], m["biasNorm"], m["stdeNorm"], m["rmseNorm"], m["mean_err"], m["mean_sq_err"]) == pytest.approx((norm, b, s, r, e1, e2), rel=1e-13)
+
+
+@pytest.mark.gpu
+def test_gradp_main_and_metrics(gds, capsys):
+    """main() of the U_to_gradP evaluator with its own argument names: per-frame metrics as the reference computes them
+    (against grid channel 3, as written at :667) and the per-simulation BIAS / RMSE / STDE it prints."""
+    from psm_amd import EvaluationGradP, main_gradP
+    d, c = gds
+    out = main_gradP(delta=5e-3, model_directory=c["model_path"], shape=128, var_p=0.95, var_in=0.95, max_number_PC=128,
+                     hdf5_path=c["dataset_path"], plot_intermediate_fields=False, save_plots=False, n_ts=2, artifact_dir=d)
+    printed = capsys.readouterr().out
+    assert "Metrics for the whole simulation:" in printed and "BIAS for the sim: " in printed
+    ev = EvaluationGradP(5e-3, 128, 96, 0.95, 0.95, c["dataset_path"], c["model_path"], 128, artifact_dir=d)
+    ev.computeOnlyOnce(0)
+    e1, e2 = [], []
+    for t in range(2):
+        field = ev.timeStep(0, t, False, False, False, False)
+        norm, b, s, r, m1, m2 = _ref_metrics(field, ev.grid[..., 3], ev.grid[..., 2] == 0)
+        fr = out["frames"][t]["reference"]
+        assert (fr["normVal"], fr["biasNorm"], fr["rmseNorm"]) == pytest.approx((norm, b, r), rel=1e-6)
+        assert ev.last_metrics["p"]["rmseNorm"] == pytest.approx(_ref_metrics(field, ev.grid[..., 5], ev.grid[..., 2] == 0)[3], rel=1e-6)
+        e1.append(m1); e2.append(m2)
+    BIAS_value = np.mean(e1) * 100
+    RMSE_value = np.sqrt(np.mean(e2)) * 100
+    assert out["sims"][0]["BIAS"] == pytest.approx(BIAS_value, rel=1e-6) and out["sims"][0]["RMSE"] == pytest.approx(RMSE_value, rel=1e-6)
+    assert out["sims"][0]["STDE"] == pytest.approx(np.sqrt(RMSE_value ** 2 - BIAS_value ** 2), rel=1e-5)
+    assert ev.pred_minus_true == pytest.approx(e1, rel=1e-6)
+
+
+@pytest.mark.gpu
+def test_poisson_main_and_metrics(tmp_path):
+    """call_SM_main of pressureSM_Poisson with its argument list: the three error blocks per frame (delta-p with the
+    weighting, delta-p without, p) and the summaries."""
+    from psm_amd import EvaluationPoisson, call_SM_main_Poisson
+    d = str(tmp_path)
+    c = cases.build_dataset_case(d, poisson=True)
+    phis = os.path.join(d, "phis.txt")
+    np.savetxt(phis, np.array([0.16, 0.2]))
+    out = call_SM_main_Poisson(5e-3, c["model_path"], 128, 0.25, 0.95, 0.95, 128, c["dataset_path"], False, "std", 0.5, False, False,
+                               False, False, 1, 2, phis, artifact_dir=d, sim_offset=0, time_offset=1)
+    ev = EvaluationPoisson(5e-3, 128, 32, 0.95, 0.95, c["dataset_path"], c["model_path"], 128, "std", 0.5, phis, artifact_dir=d)
+    ev.computeOnlyOnce(0)
+    acc = {k: ([], []) for k in ("", "_deltap_crude", "_p")}
+    for t in (1, 2):
+        field = ev.timeStep(0, t, False, False, False, False, 0.16)
+        U = ev.U_max_norm
+        cells = c["sim"][0, t, :c["N"]]
+        tb = _tables(c)
+        g = np.zeros((tb.ny, tb.nx)); g[tuple(tb.indices.T)] = orc.interpolate_fill(np.asarray(cells[:, 7], np.float64), tb.vtx_m2g, tb.wts_m2g)
+        cfd = np.nan_to_num(g / U ** 2) / cases.POISSON_MAXS[4] * cases.POISSON_MAXS[4] * U ** 2
+        assert np.abs(ev.cfd_results - cfd).max() <= 1e-12 * np.abs(cfd).max()
+        pg = np.zeros((tb.ny, tb.nx)); pg[tuple(tb.indices.T)] = orc.interpolate_fill(np.asarray(cells[:, 2], np.float64), tb.vtx_m2g, tb.wts_m2g)
+        pg = np.nan_to_num(pg)
+        no_flow = np.nan_to_num(tb.sdfunct) == 0
+        for sfx, pred, truth in (("", field, cfd), ("_deltap_crude", ev.deltap_res, cfd), ("_p", (pg - cfd) + field, pg)):
+            norm, b, s, r, m1, m2 = _ref_metrics(pred, truth, no_flow)
+            lm = ev.last_metrics[sfx.lstrip("_") or "delta_p"]
+            assert (lm["normVal"], lm["biasNorm"], lm["rmseNorm"]) == pytest.approx((norm, b, r), rel=1e-6, abs=1e-9), sfx
+            acc[sfx][0].append(m1); acc[sfx][1].append(m2)
+    for key, sfx in (("delta_p", ""), ("delta_p_no_weighting", "_deltap_crude"), ("p", "_p")):
+        BIAS, RMSE = np.mean(acc[sfx][0]) * 100, np.sqrt(np.mean(acc[sfx][1])) * 100
+        assert out["overall"][key]["BIAS"] == pytest.approx(BIAS, rel=1e-5, abs=1e-9) and out["overall"][key]["RMSE"] == pytest.approx(RMSE, rel=1e-5)
+    assert out["sims"][0]["sim"] == 0 and out["sims"][0]["phi"] == 0.16
