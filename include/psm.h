@@ -205,6 +205,10 @@ int psm_solve_grid(psm_handle* h, const float* grid, int32_t n_cases,
 int psm_ring_acquire(psm_handle* h, int64_t* ticket, float** grid_in, float** fields_out);
 int psm_ring_submit(psm_handle* h, int64_t ticket, int32_t n_cases, const float* out_scale);
 int psm_ring_wait(psm_handle* h, int64_t ticket);
+/* Give an acquired ticket back without submitting it (the caller decided not to solve after all): its slot is free
+ * again and is handed out when its turn comes round (slots rotate in ticket order).  PSM_ERR_ARG for a ticket that was
+ * not acquired or was already submitted. */
+int psm_ring_release(psm_handle* h, int64_t ticket);
 int psm_host_register(psm_handle* h, void* ptr, size_t bytes);
 int psm_host_unregister(psm_handle* h, void* ptr);
 /* fields may be NULL (destination given to psm_wait_grid instead). */

@@ -15,6 +15,9 @@
  *
  * Build: gcc -O3 -mavx2 -mfma -fopenmp -shared -fPIC oracle/psm_cpu.c -o oracle/_build/libpsm_cpu.so  (oracle/Makefile)
  */
+#ifndef _POSIX_C_SOURCE
+#define _POSIX_C_SOURCE 200809L   /* clock_gettime under -std=c99 */
+#endif
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -23,6 +26,11 @@
 #include <time.h>
 #ifdef _OPENMP
 #include <omp.h>
+#else  /* a host compiler without OpenMP: one thread */
+static void omp_set_num_threads(int n) { (void)n; }
+static int omp_get_max_threads(void) { return 1; }
+static int omp_get_thread_num(void) { return 0; }
+static int omp_get_num_threads(void) { return 1; }
 #endif
 
 static double now_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }

@@ -66,6 +66,7 @@ SIGNATURES = {
     "psm_ring_acquire": (C.c_int, [_hp, C.POINTER(C.c_int64), C.POINTER(_f32p), C.POINTER(_f32p)]),
     "psm_ring_submit": (C.c_int, [_hp, C.c_int64, C.c_int32, _f32p]),
     "psm_ring_wait": (C.c_int, [_hp, C.c_int64]),
+    "psm_ring_release": (C.c_int, [_hp, C.c_int64]),
     "psm_host_register": (C.c_int, [_hp, C.c_void_p, C.c_size_t]),
     "psm_host_unregister": (C.c_int, [_hp, C.c_void_p]),
     "psm_submit_grid_io": (C.c_int, [_hp, _f32p, C.c_int32, _f32p, _f32p, C.POINTER(C.c_int64)]),

@@ -1460,6 +1460,17 @@ int psm_ring_acquire(psm_handle* h, int64_t* ticket, float** grid_in, float** fi
   return PSM_OK;
 }
 
+static int slot_of(psm_handle* h, int64_t ticket, int state, psm_handle::Slot** out);
+int psm_ring_release(psm_handle* h, int64_t ticket) {
+  if (!h) return PSM_ERR_ARG;
+  psm_handle::Slot* s = nullptr;
+  int rc = slot_of(h, ticket, 1, &s);                  // acquired, not submitted
+  if (rc) return rc;
+  s->state = 0;
+  // the slot comes round again PSM_RING_SLOTS tickets later; the ticket counter does not go back (tickets stay unique)
+  return PSM_OK;
+}
+
 static int slot_of(psm_handle* h, int64_t ticket, int state, psm_handle::Slot** out) {
   if (ticket < 0 || !h->ring_ready) return fail(h, PSM_ERR_ARG, "unknown ticket");
   psm_handle::Slot& s = h->slot[ticket % h->ring_slots];

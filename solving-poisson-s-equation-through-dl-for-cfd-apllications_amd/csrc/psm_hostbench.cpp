@@ -25,7 +25,7 @@ extern "C" int psm_bench_host(psm_handle* h, const float* grids, int32_t n_input
   }
   // mode 3 packs each slot during the warm-up: at least one full turn of the ring
   const int wu = (mode == 3 && warmup < PSM_RING_SLOTS) ? PSM_RING_SLOTS : warmup;
-  std::vector<int64_t> ticket((size_t)steps + wu);
+  std::vector<int64_t> ticket((size_t)steps + wu, -1);
   std::vector<float*> slot_out(PSM_RING_SLOTS, nullptr);
   const float* last = nullptr;
   // PSM_BENCH_VERBOSE=1: where the calling thread spends its time (submission calls / waits), to stderr
@@ -78,6 +78,16 @@ extern "C" int psm_bench_host(psm_handle* h, const float* grids, int32_t n_input
     if (verbose && mode != 0)
       std::fprintf(stderr, "psm_bench_host mode %d depth %d: %.1f us per solve = %.1f us in submission calls + %.1f us waiting\n",
                    mode, depth, *seconds * 1e6 / steps, t_submit / steps, t_wait / steps);
+  }
+  if (rc != PSM_OK && mode != 0) {
+    // a failed run must not leave slots taken: wait for every ticket that is still in flight (newest PSM_RING_SLOTS at most)
+    // and give back one that was acquired but not submitted; the first error stays the result
+    const int issued = (int)ticket.size();
+    for (int i = issued > PSM_RING_SLOTS ? issued - PSM_RING_SLOTS : 0; i < issued; ++i) {
+      if (ticket[i] < 0) continue;
+      if (mode == 3) { if (psm_ring_wait(h, ticket[i]) != PSM_OK) (void)psm_ring_release(h, ticket[i]); }
+      else (void)psm_wait_grid(h, ticket[i], mode == 1 ? outs + (size_t)(i % PSM_RING_SLOTS) * gout : nullptr);
+    }
   }
   if (rc == PSM_OK && last_fields && last) std::memcpy(last_fields, last, gout * sizeof(float));
   if (mode == 2) { psm_host_unregister(h, (void*)grids); psm_host_unregister(h, outs); }

@@ -73,4 +73,5 @@ struct PsmPairArgs {
   int64_t in0_case, in1_case, out_case;   // per-case strides (elements)
 };
 hipError_t psm_unet_pair_read_stamps(unsigned long long* out);   // [64]: 3 workgroups x 16 stamps; zeros unless built with -DPSM_STAMPS
+bool psm_pair_kernel_available(int kind, int cm, int c0, int c1, bool head);   // shared by the planner and the launcher
 hipError_t psm_launch_conv_pair(const PsmPairArgs& a, int kind, int cm, int n_cases, hipStream_t st);

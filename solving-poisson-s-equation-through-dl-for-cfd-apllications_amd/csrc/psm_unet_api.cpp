@@ -429,18 +429,16 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
       if (A.k != 3 || B.k != 3 || B.src != 1 || A.level != B.level || A.pair || B.pair) continue;
       const int cm = A.cout, H = ny >> A.level, W = nx >> A.level;
       if (B.cin != cm || B.cout != cm || (cm != 16 && cm != 32) || A.ksplit != 1 || B.ksplit != 1) continue;
-      if (!(B.out_bf || B.fuse_head) || (B.fuse_head && cm != 16)) continue;
+      if (!(B.out_bf || B.fuse_head)) continue;
       const long wgs = (long)((W + PSM_PAIR_TX - 1) / PSM_PAIR_TX) * ((H + PSM_PAIR_TY - 1) / PSM_PAIR_TY) * max_cases;
       if (wgs < pair_min) continue;
-      int kind = -1;
-      if (A.src == 0 && cm == 16 && (A.cin == 3 || A.cin == 4)) kind = PSM_PAIR_STEM;
-      else if (A.src == 2 && A.in_bf && cm == 32 && A.cin % 16 == 0) kind = PSM_PAIR_POOL;
-      else if (A.src == 3 && A.in_bf) {
-        const int c0 = u->convs[i - 1].cout, c1 = u->convs[A.skip].cout;
-        if (cm == 16 && c0 == 32 && c1 == 16) kind = PSM_PAIR_UPCAT;
-        if (cm == 32 && c0 % 32 == 0 && c1 % 16 == 0) kind = PSM_PAIR_UPCAT;
-      }
-      if (kind < 0) continue;
+      // the source transform names the kind; whether a kernel exists for these channel counts (and a fused head) is the
+      // launcher's own predicate
+      int kind = -1, c0 = A.cin, c1 = 0;
+      if (A.src == 0) kind = PSM_PAIR_STEM;
+      else if (A.src == 2 && A.in_bf) kind = PSM_PAIR_POOL;
+      else if (A.src == 3 && A.in_bf) { kind = PSM_PAIR_UPCAT; c0 = u->convs[i - 1].cout; c1 = u->convs[A.skip].cout; }
+      if (kind < 0 || !psm_pair_kernel_available(kind, cm, c0, c1, B.fuse_head)) continue;
       if (cm == 32 && getenv("PSM_UNET_PAIR32") && atoi(getenv("PSM_UNET_PAIR32")) == 0) continue;     // diagnostic: 16-channel pairs only
       A.pair = 1; A.pair_kind = kind; B.pair = 2;
     }
@@ -537,7 +535,7 @@ int psm_unet_read_activation(psm_unet* u, int32_t idx, float* dst, int64_t dst_f
   if (dst_floats < n) return fail(u, PSM_ERR_ARG, "destination too small");
   UCHK(u, hipSetDevice(u->device));
   UCHK(u, hipStreamSynchronize(u->stream));
-  if (c.out_bf) {                 // stored as bf16: widen
+  if (c.out_bf || c.pair != 0) {  // stored as bf16 (finished activations in bf16 mode; a pair kernel always writes bf16): widen
     std::vector<uint16_t> hb((size_t)n);
     UCHK(u, hipMemcpy(hb.data(), c.d_out, (size_t)n * sizeof(uint16_t), hipMemcpyDeviceToHost));
     for (int64_t q = 0; q < n; ++q) { const uint32_t w = (uint32_t)hb[q] << 16; std::memcpy(&dst[q], &w, 4); }

@@ -776,6 +776,18 @@ __global__ __launch_bounds__(256, 2) void psm_pair32_kernel(PsmPairArgs a) {
 }  // namespace
 
 // grid: persistent workgroups, two per CU, a multiple of 8 (one share per XCD) when the tile count allows
+// Which (kind, channel counts, fused head) combinations the pair kernels below are instantiated for: the ONE predicate the
+// planner (psm_unet_api.cpp) and the launcher share.
+bool psm_pair_kernel_available(int kind, int cm, int c0, int c1, bool head) {
+  if (kind == PSM_PAIR_STEM) return cm == 16 && (c0 == 3 || c0 == 4) && !head;
+  if (kind == PSM_PAIR_POOL) return cm == 32 && c0 % 16 == 0 && c0 >= 16 && !head;
+  if (kind == PSM_PAIR_UPCAT) {
+    if (cm == 16) return c0 == 32 && c1 == 16;                                   // with or without the fused 1x1 head
+    if (cm == 32) return c0 % 32 == 0 && c0 >= 32 && c1 % 16 == 0 && c1 >= 16 && !head;
+  }
+  return false;
+}
+
 hipError_t psm_launch_conv_pair(const PsmPairArgs& a, int kind, int cm, int n_cases, hipStream_t st) {
   if (a.tiles_x != (a.W + TX - 1) / TX || a.tiles_y != (a.H + TY - 1) / TY || n_cases < 1 || a.n_cases != n_cases) return hipErrorInvalidValue;
   if (a.head_w && (a.head_cout < 1 || a.head_cout > 16)) return hipErrorInvalidValue;
@@ -785,6 +797,7 @@ hipError_t psm_launch_conv_pair(const PsmPairArgs& a, int kind, int cm, int n_ca
   if ((total & 7) == 0 && g >= 8) g &= ~7;
   const dim3 grid((unsigned)g);
   const bool keep = a.mid_out != nullptr, head = a.head_w != nullptr;
+  if (!psm_pair_kernel_available(kind, cm, a.c0, a.c1, head)) return hipErrorInvalidValue;
   if (!head && !a.out) return hipErrorInvalidValue;
   if (keep && !a.out) return hipErrorInvalidValue;
 #define PAIR_GO(K, ...) do { if (keep) PSM_LAUNCH((K<__VA_ARGS__, true>), grid, dim3(256), 0, st, a); else PSM_LAUNCH((K<__VA_ARGS__, false>), grid, dim3(256), 0, st, a); } while (0)

@@ -180,6 +180,10 @@ class GridSurrogate:
     def ring_wait(self, ticket: int):
         self._chk(self.lib.psm_ring_wait(self.h, ticket))
 
+    def ring_release(self, ticket: int):
+        """Give an acquired, not yet submitted ticket back (psm_ring_release)."""
+        self._chk(self.lib.psm_ring_release(self.h, ticket))
+
     def host_register(self, arr: np.ndarray):
         """Register a caller-owned contiguous array for direct DMA (psm_host_register); keep it alive until
         :meth:`host_unregister` / close."""

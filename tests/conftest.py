@@ -32,15 +32,24 @@ def _install_abort_trace():
     import ctypes
     import shutil
     import subprocess
-    import tempfile
+    import stat
     gcc = shutil.which("gcc")
     if not gcc:
         return
-    so = os.path.join(tempfile.gettempdir(), "psm_abort_trace_%d.so" % os.getuid())
+    # built inside the repository (git-ignored tests/_build, mode 0700), never in the world-writable temp directory; an
+    # existing file is only loaded when this user owns it and nobody else can write it
+    bdir = os.path.join(ROOT, "tests", "_build")
+    so = os.path.join(bdir, "psm_abort_trace.so")
     src = os.path.join(ROOT, "tests", "abort_trace.c")
     try:
-        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        os.makedirs(bdir, mode=0o700, exist_ok=True)
+        st = os.stat(so) if os.path.exists(so) else None
+        trusted = st is not None and st.st_uid == os.getuid() and not (st.st_mode & (stat.S_IWGRP | stat.S_IWOTH))
+        if not trusted or st.st_mtime < os.path.getmtime(src):
+            if st is not None:
+                os.unlink(so)
             subprocess.run([gcc, "-O1", "-g", "-shared", "-fPIC", src, "-o", so], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            os.chmod(so, 0o700)
         ctypes.CDLL(so).abort_trace_install()
     except Exception:
         pass

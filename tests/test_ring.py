@@ -128,6 +128,21 @@ def test_ring_state_errors():
             sur.ring_wait(t)
         with pytest.raises(_lib.PsmError):
             sur.ring_wait(ts[0])                        # already waited for
+        # psm_ring_release: an acquired ticket the caller decides not to submit gives its slot back
+        t, gi, fo = sur.ring_acquire()
+        sur.ring_release(t)
+        for bad in (sur.ring_release, sur.ring_wait):
+            with pytest.raises(_lib.PsmError):
+                bad(t)                                  # released: neither acquired nor in flight any more
+        with pytest.raises(_lib.PsmError):
+            sur.ring_release(ts[0])                     # long gone
+        ref = sur.solve(g)[0]
+        for _ in range(9):                              # a full turn of the ring passes over the released slot
+            t, gi, fo = sur.ring_acquire()
+            gi[0] = g
+            sur.ring_submit(t, 1)
+            sur.ring_wait(t)
+            np.testing.assert_array_equal(fo[0], ref)
         with pytest.raises(_lib.PsmError):
             sur.host_unregister(g)                      # never registered
         sur.host_register(g)
