@@ -61,6 +61,7 @@ struct Workspace {
   float2* d_colpart = nullptr;
   float *d_offs = nullptr, *d_shift = nullptr;
   float* d_dots = nullptr;            // strip dots of the geometry-bound path (allocated by the bind)
+  float* d_dots2 = nullptr;           // pair dots of the closed-form chain (allocated by the bind)
   float* d_c1[2] = {nullptr, nullptr}; // Conv1D activations of the conv1D_PCA head (ping-pong), [Mpad][c1_stride]
   float* d_gflags = nullptr;          // guard flags of the bound-geometry contract (psm_kernels.h PsmGuardArgs; allocated by the bind)
   int gidx = 0;                       // this workspace's word in the handle's mapped guard page (0 = ws0, 1 + i = ring slot i)
@@ -168,6 +169,13 @@ struct psm_handle {
   std::vector<uint8_t> bound_mask;      // [bound_cases][Ny*Nx] flow-cell pattern that was bound (psm_bound_mask)
   int32_t* d_row_of = nullptr;
   uint32_t* d_ownbits = nullptr;
+  // closed form of the offset chain for case batches (psm_kernels.h PsmBoundBatchArgs): pair tables
+  bool bound_cf = false;
+  size_t cf_rows_all = 0;               // cases * c_out * B * B
+  float *d_g2p = nullptr, *d_c2p = nullptr, *d_cntp = nullptr, *d_cfa0 = nullptr;
+  int32_t* d_row_of_p = nullptr;
+  std::vector<float> h_shiftW;          // host copy of d_shiftW [c_out][B]
+  const float* last_row_scale = nullptr;   // row scale of the last solve on ws0 (introspection)
   // guard of the bound-geometry contract (psm_kernels.h PsmGuardArgs)
   unsigned long long* d_maskbits = nullptr;   // bound flow-cell pattern, one 64-pixel ballot per word
   int guard_ballots = 0, guard_waves = 0;
@@ -301,7 +309,7 @@ void destroy_graphs(psm_handle* h) {
 void ws_free(Workspace& w) {
   dev_free(w.d_part); dev_free(w.d_xin); dev_free(w.d_act[0]); dev_free(w.d_act[1]); dev_free(w.d_res); dev_free(w.d_pred);
   dev_free(w.d_row_scale); dev_free(w.d_spart); dev_free(w.d_colpart); dev_free(w.d_offs); dev_free(w.d_shift); dev_free(w.d_dots);
-  dev_free(w.d_gflags); dev_free(w.d_c1[0]); dev_free(w.d_c1[1]);
+  dev_free(w.d_gflags); dev_free(w.d_c1[0]); dev_free(w.d_c1[1]); dev_free(w.d_dots2);
 }
 
 // flags of one solve's guard waves: zero until a wave finds a mismatch (every wave rewrites its flag on every solve)
@@ -333,6 +341,7 @@ int ws_alloc(psm_handle* h, Workspace& w) {
   HIPCHK(h, hipMemset(w.d_act[1], 0, (size_t)h->Mpad_cap * h->max_width * sizeof(float)));
   if (h->bound && h->bound_dots) { if ((rc = dev_alloc(h, &w.d_dots, h->bound_dots))) return rc; }
   if (h->bound && (rc = ws_alloc_guard(h, w))) return rc;
+  if (h->bound && h->bound_cf) { if ((rc = dev_alloc(h, &w.d_dots2, h->cf_rows_all))) return rc; }
   for (int q = 0; q < 2 && h->c1_stride; ++q) {             // padding columns of the last layer's rows are read by the dense kernel
     if ((rc = dev_alloc(h, &w.d_c1[q], (size_t)h->Mpad_cap * h->c1_stride))) return rc;
     HIPCHK(h, hipMemset(w.d_c1[q], 0, (size_t)h->Mpad_cap * h->c1_stride * sizeof(float)));
@@ -520,6 +529,11 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
   for (auto& b : h->plan.blocks) if ((b.x0 * h->cfg.c_in) % 4 != 0) aligned = false;
   ea.aligned = aligned ? 1 : 0;
   { static const bool chunked = getenv("PSM_ENCODE_CHUNKED") != nullptr; ea.whole = chunked ? 0 : 1; }
+  // arithmetic of the encode contraction: exact-float32 MFMA for a single row tile (one case: the launch is bound by the basis
+  // stream, the matrix phase is short), the x6 form (six bf16 MFMA terms of exactly split operands, float32 accuracy,
+  // psm_encode_x6_kernel) from two row tiles up, where the matrix phase is the longest serial phase of the launch
+  // (8 cases: 17.6 -> 15.5 us, 64 cases: 75 -> 60 us).  PSM_X6=0 / 1 forces float32 / x6 everywhere.
+  { static const int x6 = getenv("PSM_X6") ? atoi(getenv("PSM_X6")) : -1; ea.x6 = x6 < 0 ? (Mpad > 32 ? 1 : 0) : ((x6 & 1) ? 1 : 0); }
 
   if (h->timed_kernel == PSM_K_ENCODE && !prof) {
     // dominant kernel: dispatch-level begin / end stamps (no marker packets around the launch)
@@ -544,6 +558,9 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
   }
   const float* gflags = guard ? w.d_gflags : h->d_gzero;
   const int n_gwaves = guard ? h->guard_waves : 1;
+  // case batches (and single cases of more than 64 blocks) on a bound geometry: closed form of the chain where it was built
+  const bool use_cf = use_bound && h->bound_cf && w.d_dots2 && !(n_cases == 1 && h->B <= 64);
+  if (&w == &h->ws0) h->last_row_scale = d_row_scale;
   PsmReduceArgs ra{w.d_part, w.d_xin, h->d_ia, h->d_ib, h->n_slices, Mpad, h->ld_in};
   const int nl = (int)h->dense.size();
   auto dense_args = [&](int l, const float* cur, int ld_cur) {
@@ -599,7 +616,8 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
     for (int l = l_first; l < nl; ++l) {
       PsmDenseArgs da = dense_args(l, cur, ld_cur);
       if (use_bound && !bf16 && l == nl - 1) { // head layer + strip dots of the bound geometry in one launch
-        PsmDotsArgs dd{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, w.d_dots, h->bound_rows * n_cases, h->dense[nl - 1].Kpad, ga};
+        PsmDotsArgs dd = use_cf ? PsmDotsArgs{h->d_g2p, h->d_c2p, h->d_cntp, h->d_row_of_p, d_row_scale, w.d_dots2, (int)h->cf_rows_all, h->dense[nl - 1].Kpad, ga}
+                                : PsmDotsArgs{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, w.d_dots, h->bound_rows * n_cases, h->dense[nl - 1].Kpad, ga};
         HIPCHK(h, psm_launch_dense_dots(da, dd, st));
       } else {
         HIPCHK(h, psm_launch_dense(da, st));
@@ -642,14 +660,16 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
     bb.fields = d_fields; bb.offs = w.d_offs; bb.shift = w.d_shift; bb.Nx = h->Nx; bb.npix = h->Ny * h->Nx;
     bb.n_strips = h->n_strips; bb.B = h->B; bb.rows_pc = h->bound_rows; bb.n_cases = n_cases;
     bb.gflags = gflags; bb.n_gwaves = n_gwaves;
+    bb.cf = use_cf ? 1 : 0; bb.cf_dots = w.d_dots2; bb.cf_a0 = h->d_cfa0;
     tm.before(PSM_K_DECODE); tm.after(PSM_K_DECODE);
     tm.before(PSM_K_STRIPS); tm.after(PSM_K_STRIPS);
     tm.before(PSM_K_CHAIN);
-    if (bf16) {                                 // strip dots from the bf16-rounded res (own small launch)
-      PsmDotsArgs dd{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, w.d_dots, h->bound_rows * n_cases, h->ld_out, ga};
+    if (bf16) {                                 // dots from the bf16-rounded res (own small launch): pair rows, or the strip rows of the chain
+      PsmDotsArgs dd = use_cf ? PsmDotsArgs{h->d_g2p, h->d_c2p, h->d_cntp, h->d_row_of_p, d_row_scale, w.d_dots2, (int)h->cf_rows_all, h->ld_out, ga}
+                              : PsmDotsArgs{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, w.d_dots, h->bound_rows * n_cases, h->ld_out, ga};
       HIPCHK(h, psm_launch_res_dots(dd, w.d_res, h->ld_out, st));
     }
-    HIPCHK(h, psm_launch_chain_dots(bb, h->cfg.c_out, st));
+    if (!use_cf) HIPCHK(h, psm_launch_chain_dots(bb, h->cfg.c_out, st));     // closed form: no chain launch
     tm.after(PSM_K_CHAIN);
     tm.before(PSM_K_PASTE);
     HIPCHK(h, psm_launch_decode_paste_batch(de, bb, h->cfg.c_out, st, bf16 ? 1 : 0));
@@ -857,6 +877,7 @@ void psm_destroy(psm_handle* h) {
   dev_free(h->d_comp_nat); dev_free(h->d_g2); dev_free(h->d_c2); dev_free(h->d_cnt); dev_free(h->d_row_of); dev_free(h->d_ownbits);
   dev_free(h->d_ia); dev_free(h->d_ib); dev_free(h->d_sa); dev_free(h->d_sb);
   dev_free(h->d_maskbits); dev_free(h->d_gzero);
+  dev_free(h->d_g2p); dev_free(h->d_c2p); dev_free(h->d_cntp); dev_free(h->d_cfa0); dev_free(h->d_row_of_p);
   for (auto& c : h->conv1d) { dev_free(c.W); dev_free(c.b); }
   if (h->h_guard) (void)hipHostFree(h->h_guard);
   for (int i = 0; i < psm_handle::RING; ++i) {
@@ -1108,6 +1129,7 @@ int psm_plan_grid(psm_handle* h, int32_t ny, int32_t nx) {
     if ((rc = dev_upload(h, &h->d_shiftOwnA, oA))) return rc;
     if ((rc = dev_upload(h, &h->d_shiftOwnB, oB))) return rc;
     if ((rc = dev_upload(h, &h->d_shiftW, w))) return rc;
+    h->h_shiftW = w;
   }
   HIPCHK(h, hipDeviceSynchronize());
   {
@@ -1123,6 +1145,100 @@ int psm_plan_grid(psm_handle* h, int32_t ny, int32_t nx) {
     h->fused_assemble = (h->B <= 64 && h->plan.cp.n_x < 64) && !(nf && nf[0] == '1');
   }
   h->planned = true;
+  return PSM_OK;
+}
+
+// Closed form of the offset chain for a bound case batch.  On a bound geometry every branch of the chain (np.isnan tests,
+// the 0.9 coverage test, the first non-empty column) is decided by the strip COUNTS, so the correction of block b plus the
+// global shift is a fixed linear map of the strip means: read off the host replay of the chain (psm_chain, double) by
+// probing it with unit vectors, checked against a random probe, and folded into one table row per (field, block, source
+// block) -- a linear combination of the strip / shift rows the bind kernels have just built.  Leaves bound_cf false (the
+// chain launch stays) if the probe disagrees.
+static int build_closed_form(psm_handle* h, int n_cases, int rows, int Kh) {
+  const int C = h->cfg.c_out, B = h->B, nst = h->n_strips, NS = h->plan.cp.NS;
+  std::vector<float> hcnt((size_t)rows * n_cases);
+  HIPCHK(h, hipMemcpy(hcnt.data(), h->d_cnt, hcnt.size() * sizeof(float), hipMemcpyDeviceToHost));
+  const double qnan = std::nan("");
+  std::vector<int32_t> ptr(1, 0), src, row_of_p;
+  std::vector<float> coef, a0((size_t)n_cases * C * B);
+  std::vector<std::vector<int>> strips_of(B);
+  for (int s = 0; s < nst; ++s) strips_of[h->plan.strips[s].data].push_back(s);
+  std::vector<double> mean(nst), cnt(nst), up(PSM_MAX_COLS), offs0(B), offs1(B), L((size_t)B * nst), A((size_t)B * nst);
+  uint64_t rng = 0x9E3779B97F4A7C15ull;
+  auto rnd = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (double)(rng >> 11) / (double)(1ull << 53) - 0.5; };
+  for (int cs = 0; cs < n_cases; ++cs)
+    for (int f = 0; f < C; ++f) {
+      for (int s = 0; s < nst; ++s) cnt[s] = hcnt[(size_t)cs * rows + (size_t)f * nst + s];
+      auto run = [&](std::vector<double>& out) {
+        std::fill(up.begin(), up.end(), 0.0);
+        PsmArrayChainCtx<double> cx{h->plan.blocks.data(), mean.data(), cnt.data(), NS, h->plan.cp.col_base, h->S, up.data(), out.data()};
+        psm_chain<double>(h->plan.cp, cx, f);
+      };
+      for (int s = 0; s < nst; ++s) mean[s] = cnt[s] > 0 ? 0.0 : qnan;
+      run(offs0);
+      std::fill(L.begin(), L.end(), 0.0);
+      for (int s = 0; s < nst; ++s) {
+        if (!(cnt[s] > 0)) continue;
+        mean[s] = 1.0;
+        run(offs1);
+        mean[s] = 0.0;
+        for (int b = 0; b < B; ++b) { const double v = offs1[b] - offs0[b]; L[(size_t)b * nst + s] = (v == v) ? v : 0.0; }
+      }
+      // sub[b] = offs[b] + shift, shift = (sum of the shift partials) / (3 L_f) - sum_{w != 0} w[b'] offs[b']
+      const float* w = h->h_shiftW.data() + (size_t)f * B;
+      double base_shift = 0.0;
+      std::vector<double> sh(nst, 0.0);
+      for (int b2 = 0; b2 < B; ++b2) {
+        if (w[b2] == 0.f) continue;
+        base_shift += (double)w[b2] * offs0[b2];
+        for (int s = 0; s < nst; ++s) sh[s] += (double)w[b2] * L[(size_t)b2 * nst + s];
+      }
+      for (int b = 0; b < B; ++b) {
+        a0[((size_t)cs * C + f) * B + b] = (float)(offs0[b] - base_shift);       // NaN for skipped blocks / a poisoned shift, like the chain
+        for (int s = 0; s < nst; ++s) A[(size_t)b * nst + s] = L[(size_t)b * nst + s] - sh[s];
+      }
+      // random probe: the chain itself against base + A . means
+      for (int s = 0; s < nst; ++s) mean[s] = cnt[s] > 0 ? rnd() : qnan;
+      run(offs1);
+      double tsh = 0.0;
+      for (int b2 = 0; b2 < B; ++b2) if (w[b2] != 0.f) tsh += (double)w[b2] * offs1[b2];
+      for (int b = 0; b < B; ++b) {
+        double want = offs1[b] - tsh, got = (double)a0[((size_t)cs * C + f) * B + b];
+        for (int s = 0; s < nst; ++s) if (A[(size_t)b * nst + s] != 0.0) got += A[(size_t)b * nst + s] * mean[s];
+        const bool wn = want != want, gn = got != got;
+        if (wn != gn || (!wn && std::fabs(want - got) > 1e-5 * (1.0 + std::fabs(want)))) return PSM_OK;   // not linear: keep the chain launch
+      }
+      const double inv3L = h->plan.shiftA[f].empty() ? 0.0 : 1.0 / (3.0 * (double)h->plan.shiftA[f].size());
+      for (int b = 0; b < B; ++b)
+        for (int blk = 0; blk < B; ++blk) {
+          for (int s : strips_of[blk]) {
+            const double a = A[(size_t)b * nst + s];
+            if (a != 0.0 && cnt[s] > 0) { src.push_back(f * nst + s); coef.push_back((float)(a / cnt[s])); }
+          }
+          src.push_back(C * nst + f * B + blk); coef.push_back((float)inv3L);          // the block's share of the shift's gathered part
+          ptr.push_back((int32_t)src.size());
+          row_of_p.push_back(cs * B + blk);
+        }
+    }
+  const size_t pairs_pc = (size_t)C * B * B, pairs = pairs_pc * n_cases;
+  int rc;
+  int32_t *d_ptr = nullptr, *d_src = nullptr;
+  float* d_coef = nullptr;
+  if ((rc = dev_upload(h, &d_ptr, ptr)) || (rc = dev_upload(h, &d_src, src)) || (rc = dev_upload(h, &d_coef, coef))) return rc;
+  std::vector<float> ones(pairs, 1.f);
+  if ((rc = dev_alloc(h, &h->d_g2p, pairs * Kh)) || (rc = dev_alloc(h, &h->d_c2p, pairs)) || (rc = dev_upload(h, &h->d_cntp, ones)) ||
+      (rc = dev_upload(h, &h->d_cfa0, a0)) || (rc = dev_upload(h, &h->d_row_of_p, row_of_p))) { dev_free(d_ptr); dev_free(d_src); dev_free(d_coef); return rc; }
+  hipError_t e = hipSuccess;
+  for (int cs = 0; cs < n_cases && e == hipSuccess; ++cs) {
+    PsmPairFoldArgs pa{d_ptr + (size_t)cs * pairs_pc, d_src, d_coef, h->d_g2 + (size_t)cs * rows * Kh, h->d_c2 + (size_t)cs * rows,
+                       h->d_g2p + (size_t)cs * pairs_pc * Kh, h->d_c2p + (size_t)cs * pairs_pc, (int)pairs_pc, Kh};
+    e = psm_launch_pair_fold(pa, h->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  dev_free(d_ptr); dev_free(d_src); dev_free(d_coef);
+  if (e != hipSuccess) return fail(h, PSM_ERR_HIP, std::string("psm_launch_pair_fold: ") + hipGetErrorString(e));
+  h->cf_rows_all = pairs;
+  h->bound_cf = true;
   return PSM_OK;
 }
 
@@ -1192,9 +1308,17 @@ static int bind_geometry_device(psm_handle* h, const float* d_grid, int n_cases 
   h->bound_rows = rows;
   h->bound_cases = n_cases;
   h->bound_dots = all;
+  h->bound_cf = false;
+  if (!(n_cases == 1 && small) && h->B <= 64 && getenv("PSM_NO_CLOSED_FORM") == nullptr) {
+    if ((rc = build_closed_form(h, n_cases, rows, Kh))) return rc;
+    if (h->bound_cf && (rc = dev_alloc(h, &h->ws0.d_dots2, h->cf_rows_all))) return rc;
+  }
   h->bound = true;
   if (h->ring_ready)
-    for (auto& s : h->slot) { if ((rc = dev_alloc(h, &s.ws.d_dots, all)) || (rc = ws_alloc_guard(h, s.ws))) { h->bound = false; return rc; } }
+    for (auto& s : h->slot) {
+      if ((rc = dev_alloc(h, &s.ws.d_dots, all)) || (rc = ws_alloc_guard(h, s.ws)) ||
+          (h->bound_cf && (rc = dev_alloc(h, &s.ws.d_dots2, h->cf_rows_all)))) { h->bound = false; return rc; }
+    }
   return PSM_OK;
 }
 
@@ -2043,16 +2167,37 @@ int psm_read_stage(psm_handle* h, int32_t stage, float* dst, size_t dst_floats) 
     case PSM_STAGE_X_INPUT: return rows(h->ws0.d_xin, h->ld_in, h->cfg.p_in);
     case PSM_STAGE_RES: return rows(h->ws0.d_res, h->ld_out, h->cfg.p_out);
     case PSM_STAGE_BLOCK_PRED: return rows(h->ws0.d_pred, h->K_out, h->K_out);
-    case PSM_STAGE_OFFSETS: {
+    case PSM_STAGE_OFFSETS:
+    case PSM_STAGE_SHIFT:
+      if (h->bound && h->bound_cf && (h->bound_scope == 2) && h->last_cases == h->bound_cases && !(h->last_cases == 1 && h->B <= 64)) {
+        // the last solve took the closed form: run the chain itself once, from the strip means of the same activations
+        const int nl = (int)h->dense.size();
+        const bool bf = h->cfg.precision == PSM_PRECISION_BF16;
+        const float* act = bf ? h->ws0.d_res : h->ws0.d_act[(nl - 2) & 1];
+        const int ld_act = bf ? h->ld_out : h->dense[nl - 2].ldw;
+        PsmDotsArgs dd{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, h->last_row_scale ? h->last_row_scale : h->d_ones, h->ws0.d_dots,
+                       h->bound_rows * h->last_cases, bf ? h->ld_out : h->dense[nl - 1].Kpad, PsmGuardArgs{}};
+        HIPCHK(h, psm_launch_act_dots(dd, act, ld_act, bf ? 1 : 0, h->stream));
+        PsmBoundBatchArgs bb{};
+        bb.cp = h->plan.cp; bb.blocks = h->d_blocks; bb.dots = h->ws0.d_dots; bb.scnt = h->d_cnt; bb.ownbits = h->d_ownbits;
+        bb.blk_y0x0 = h->d_blk; bb.shiftW = h->d_shiftW;
+        for (int f = 0; f < 2; ++f) bb.shiftL[f] = (int)h->plan.shiftA[f].size();
+        bb.offs = h->ws0.d_offs; bb.shift = h->ws0.d_shift; bb.Nx = h->Nx; bb.npix = h->Ny * h->Nx;
+        bb.n_strips = h->n_strips; bb.B = h->B; bb.rows_pc = h->bound_rows; bb.n_cases = h->last_cases;
+        bb.gflags = h->d_gzero; bb.n_gwaves = 1;
+        HIPCHK(h, psm_launch_chain_dots(bb, h->cfg.c_out, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+      }
+      if (stage == PSM_STAGE_SHIFT) {
+        const size_t n = (size_t)h->last_cases * h->cfg.c_out;
+        if (dst_floats < n) return fail(h, PSM_ERR_ARG, "destination too small");
+        HIPCHK(h, hipMemcpy(dst, h->ws0.d_shift, n * sizeof(float), hipMemcpyDeviceToHost));
+        return PSM_OK;
+      }
+      {
       const size_t n = (size_t)h->last_cases * h->cfg.c_out * h->B;
       if (dst_floats < n) return fail(h, PSM_ERR_ARG, "destination too small");
       HIPCHK(h, hipMemcpy(dst, h->ws0.d_offs, n * sizeof(float), hipMemcpyDeviceToHost));
-      return PSM_OK;
-    }
-    case PSM_STAGE_SHIFT: {
-      const size_t n = (size_t)h->last_cases * h->cfg.c_out;
-      if (dst_floats < n) return fail(h, PSM_ERR_ARG, "destination too small");
-      HIPCHK(h, hipMemcpy(dst, h->ws0.d_shift, n * sizeof(float), hipMemcpyDeviceToHost));
       return PSM_OK;
     }
     case 6: {   // diagnostic builds only: raw stamps of workgroup 0, microseconds after the earliest one

@@ -23,6 +23,7 @@ struct PsmEncodeArgs {
   int64_t row_stride;      // Nx*C_in floats
   int M, Mpad, NT, ldp, S, c_in, aligned;
   int whole;               // 33..128 rows: stage all rows at once (PSM_ENCODE_CHUNKED=1 keeps the double-buffered chunks)
+  int x6;                  // float32 contraction as six bf16 MFMA terms of exactly split operands (psm_encode_x6_kernel)
 };
 
 struct PsmReduceArgs {
@@ -155,7 +156,22 @@ struct PsmBoundBatchArgs {             // case batches: chain in its own small l
   float* fields; float* offs; float* shift;    // offs [cases][c_out][B], shift [cases][c_out]
   int Nx, npix, n_strips, B, rows_pc, n_cases;
   const float* gflags; int n_gwaves;           // as in PsmBoundArgs
+  // Closed form of the offset chain (psm_bind_geometry_cases, B <= 64): on a bound geometry every branch of the chain is
+  // decided by the strip counts, so offset + shift of block b is a fixed linear map of the strip means, which are
+  // themselves dot products with the activation row of their source block: folded at bind time into one table row per
+  // (field, block, source block).  The head launch leaves cf_dots [cases][C][B][B]; the value subtracted from block b is
+  // cf_a0[case][f][b] + sum over source blocks -- no chain launch between the head and this one.
+  const float* cf_dots; const float* cf_a0; int cf;
 };
+struct PsmPairFoldArgs {               // bind time: pair rows as linear combinations of the strip / shift rows
+  const int32_t* ptr; const int32_t* src; const float* coef;    // CSR over the pair rows
+  const float* g2; const float* c2;    // [rows][Kh], [rows] of one case
+  float* g2p; float* c2p;              // [pairs][Kh], [pairs]
+  int n_pairs, Kh;
+};
+hipError_t psm_launch_pair_fold(const PsmPairFoldArgs& a, hipStream_t s);
+// strip dots from an arbitrary activation (introspection under the closed form; the bf16 handles' own dots launch)
+hipError_t psm_launch_act_dots(const PsmDotsArgs& d, const float* act, int ld_act, int round_bf16, hipStream_t s);
 hipError_t psm_launch_bind(const PsmBindArgs& a, hipStream_t s);
 hipError_t psm_launch_chain_dots(const PsmBoundBatchArgs& p, int c_out, hipStream_t s);
 hipError_t psm_launch_decode_paste_batch(const PsmDecodeArgs& a, const PsmBoundBatchArgs& p, int c_out, hipStream_t s, int bf16 = 0);

@@ -280,10 +280,208 @@ __global__ __launch_bounds__(256) void psm_encode_kernel(PsmEncodeArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// encode, "x6" arithmetic: the same contraction on the bf16 matrix pipe at float32 accuracy.
+// Every float32 operand is split EXACTLY into three bf16 terms, x = hi + mid + lo (8 + 8 + 8 significant bits: the two
+// remainders x - hi and (x - hi) - mid are exact in float32), and a product a * w is taken as the six terms whose
+// weight is >= 2^-16 of it -- hh, hm, mh, hl, lh, mm -- by v_mfma_f32_32x32x16_bf16 (products of bf16 pairs are exact in
+// float32; accumulation in float32).  The three dropped terms are <= 2^-23 of the product, the size of one float32
+// rounding.  Six MFMAs of 32 cycles cover 16 k where the float32 instruction (v_mfma_f32_32x32x2_f32, 64 cycles) needs
+// eight: 192 vs 512 cycles, and the matrix phase is the longest serial phase of this kernel for case batches.
+// The basis stays float32 in memory (same packing, same bytes): a wave splits its slice in registers while the rest of
+// the stream is in flight; the activation rows are split once, on their way into LDS (three bf16 planes).
+// k order inside a 16-step: lane half h holds k = 16 s + 4 h + (0..3) and 16 s + 8 + 4 h + (0..3) in both operands.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 x6_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 x6_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void psm_split3(f32x4 x, x6_bf16x4& h, x6_bf16x4& m, x6_bf16x4& l) {
+  h = __builtin_convertvector(x, x6_bf16x4);                       // round to nearest even
+  const f32x4 r1 = x - __builtin_convertvector(h, f32x4);          // exact
+  m = __builtin_convertvector(r1, x6_bf16x4);
+  const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);         // exact, <= 8 significant bits
+  l = __builtin_convertvector(r2, x6_bf16x4);
+}
+__device__ __forceinline__ x6_bf16x8 psm_cat4(x6_bf16x4 a, x6_bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+#define MFMA_X6(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+template <int C_IN, bool ALIGNED>
+__global__ __launch_bounds__(256) void psm_encode_x6_kernel(PsmEncodeArgs a) {
+  constexpr int KS = PSM_PIX_PER_SLICE * C_IN;  // K elements per workgroup
+  constexpr int G = KS / 8;                     // float4 groups of the packed basis per lane
+  constexpr int NS = KS / 16;                   // MFMA steps
+  constexpr int LDB = KS + 4;                   // plane row stride in bf16: KS / 2 + 2 dwords = 2 * odd -> ds_read_b64 of 32 rows conflict-free
+  constexpr int Q = KS / 4;
+  extern __shared__ __attribute__((aligned(16))) __bf16 ldsx[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s = blockIdx.x;
+  const int runs = a.S / PSM_PIX_PER_SLICE;
+  const int r = s / runs, c0 = (s - r * runs) * PSM_PIX_PER_SLICE;
+  const int64_t src_off = (int64_t)r * a.row_stride + (int64_t)c0 * C_IN;
+  const int NT = a.NT;
+  const int i = lane & 31, h = lane >> 5;
+  const int ql = lane < Q ? lane : Q - 1;
+  const int R = a.Mpad <= 32 ? 32 : 32 * PSM_MT_CHUNK;       // rows per plane (as the launcher sized the LDS)
+  const int PL = R * LDB;                                    // plane stride
+  const float4 mu = *reinterpret_cast<const float4*>(a.mean + (int64_t)s * KS + 4 * ql);
+
+  auto load_rows = [&](float4 (&x)[8], int m0, int row0) {
+    int64_t rb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) rb[u] = a.row_base[min(m0 + row0 + wave + 4 * u, a.M - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float* src = a.grid + rb[u] + src_off + 4 * ql;
+      if (ALIGNED) x[u] = *reinterpret_cast<const float4*>(src);
+      else x[u] = make_float4(src[0], src[1], src[2], src[3]);
+    }
+  };
+  auto write_rows = [&](const float4 (&x)[8], int m0, int row0, int buf_row0) {   // rows row0 + wave + 4u of chunk m0 -> LDS rows buf_row0 + ...
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int row = wave + 4 * u;
+      const float keep = (m0 + row0 + row) < a.M ? 1.f : 0.f;
+      const f32x4 v = {(x[u].x - mu.x) * keep, (x[u].y - mu.y) * keep, (x[u].z - mu.z) * keep, (x[u].w - mu.w) * keep};
+      x6_bf16x4 vh, vm, vl;
+      psm_split3(v, vh, vm, vl);
+      if (lane < Q) {
+        __bf16* dst = &ldsx[(buf_row0 + row) * LDB + 4 * lane];
+        *reinterpret_cast<x6_bf16x4*>(dst) = vh;
+        *reinterpret_cast<x6_bf16x4*>(dst + PL) = vm;
+        *reinterpret_cast<x6_bf16x4*>(dst + 2 * PL) = vl;
+      }
+    }
+  };
+  x6_bf16x8 Bh[NS], Bm[NS], Bl[NS];
+  // one 32-row tile against this wave's 32 components.  SPLIT: the basis registers b[] are split on the way (first tile:
+  // each step waits only for the two groups it needs, the rest of the stream stays in flight)
+  auto gemm_tile = [&](const float4 (&b)[G], bool split, int lds_row0, int out_row0, int t, bool store) {
+    f32x16 acc = {0};
+    const __bf16* arow = &ldsx[(lds_row0 + i) * LDB + 4 * h];
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      if (split) {
+        x6_bf16x4 h0, m0, l0, h1, m1, l1;
+        psm_split3((f32x4){b[2 * st].x, b[2 * st].y, b[2 * st].z, b[2 * st].w}, h0, m0, l0);
+        psm_split3((f32x4){b[2 * st + 1].x, b[2 * st + 1].y, b[2 * st + 1].z, b[2 * st + 1].w}, h1, m1, l1);
+        Bh[st] = psm_cat4(h0, h1); Bm[st] = psm_cat4(m0, m1); Bl[st] = psm_cat4(l0, l1);
+      }
+      const x6_bf16x8 ah = psm_cat4(*reinterpret_cast<const x6_bf16x4*>(arow + 16 * st), *reinterpret_cast<const x6_bf16x4*>(arow + 16 * st + 8));
+      const x6_bf16x8 am = psm_cat4(*reinterpret_cast<const x6_bf16x4*>(arow + PL + 16 * st), *reinterpret_cast<const x6_bf16x4*>(arow + PL + 16 * st + 8));
+      const x6_bf16x8 al = psm_cat4(*reinterpret_cast<const x6_bf16x4*>(arow + 2 * PL + 16 * st), *reinterpret_cast<const x6_bf16x4*>(arow + 2 * PL + 16 * st + 8));
+      acc = MFMA_X6(am, Bm[st], acc);            // small terms first
+      acc = MFMA_X6(al, Bh[st], acc);
+      acc = MFMA_X6(ah, Bl[st], acc);
+      acc = MFMA_X6(am, Bh[st], acc);
+      acc = MFMA_X6(ah, Bm[st], acc);
+      acc = MFMA_X6(ah, Bh[st], acc);
+    }
+    if (store) {
+      float* out = a.part + ((int64_t)s * a.Mpad + out_row0) * a.ldp + t * 32 + i;
+#pragma unroll
+      for (int rg = 0; rg < 16; ++rg) out[(int64_t)acc_row(rg, h) * a.ldp] = acc[rg];
+    }
+  };
+  auto load_basis = [&](float4 (&b)[G], int t) {
+    const float4* p = a.bpack + (((int64_t)s * NT + t) * G) * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < G; ++g) b[g] = stream_load(p + g * 64);
+  };
+
+  if (a.Mpad <= 32 * PSM_MT_CHUNK) {
+    // up to 128 block rows: every row staged once; the first tile's rows and the basis slice are requested first, the
+    // other tiles' rows land under the first tile's matrix work
+    const int t = min(wave, NT - 1);
+    const int tiles = a.Mpad / 32;
+    float4 x0[8];
+    load_rows(x0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    float4 b[G];
+    load_basis(b, t);
+    __builtin_amdgcn_sched_barrier(0);
+    write_rows(x0, 0, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    float4 x1[8], x2[8], x3[8];
+    if (tiles > 1) load_rows(x1, 0, 32);
+    if (tiles > 2) load_rows(x2, 0, 64);
+    if (tiles > 3) load_rows(x3, 0, 96);
+    __builtin_amdgcn_sched_barrier(0);
+    gemm_tile(b, true, 0, 0, t, wave < NT);
+    if (tiles > 1) {
+      __builtin_amdgcn_sched_barrier(0);
+      write_rows(x1, 0, 32, 32);
+      if (tiles > 2) write_rows(x2, 0, 64, 64);
+      if (tiles > 3) write_rows(x3, 0, 96, 96);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      for (int mt = 1; mt < tiles; ++mt) gemm_tile(b, false, mt * 32, mt * 32, t, wave < NT);
+    }
+    return;
+  }
+
+  // many block rows: 64-row chunks double-buffered in LDS (rows of chunk c + 1 requested before the matrix work of chunk
+  // c, written to the other buffer after it); with one or two component tiles the waves split the chunk's two row tiles
+  constexpr int CH = 64;
+  int t, mt_first, mt_step;
+  bool store;
+  if (NT == 2) { t = wave & 1; mt_first = wave >> 1; mt_step = 2; store = true; }
+  else if (NT == 1) { t = 0; mt_first = wave & 1; mt_step = 2; store = wave < 2; }
+  else { t = min(wave, NT - 1); mt_first = 0; mt_step = 1; store = wave < NT; }
+  float4 xa[8], xb[8];
+  load_rows(xa, 0, 0);
+  load_rows(xb, 0, 32);
+  __builtin_amdgcn_sched_barrier(0);
+  float4 b[G];
+  load_basis(b, t);
+  __builtin_amdgcn_sched_barrier(0);
+  write_rows(xa, 0, 0, 0);
+  write_rows(xb, 0, 32, 32);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  int buf = 0;
+  bool first = true;
+  for (int m0 = 0; m0 < a.Mpad; m0 += CH) {
+    const bool more = m0 + CH < a.Mpad;
+    if (more) { load_rows(xa, m0 + CH, 0); load_rows(xb, m0 + CH, 32); }
+    const int tiles = min(2, (a.Mpad - m0) / 32);
+    for (int mt = mt_first; mt < tiles; mt += mt_step) {
+      if (first) gemm_tile(b, true, buf * CH + mt * 32, m0 + mt * 32, t, store);
+      else gemm_tile(b, false, buf * CH + mt * 32, m0 + mt * 32, t, store);
+      first = false;
+    }
+    if (more) {
+      write_rows(xa, m0 + CH, 0, (buf ^ 1) * CH);
+      write_rows(xb, m0 + CH, 32, (buf ^ 1) * CH + 32);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    buf ^= 1;
+  }
+}
+
+// x6 covers <= 128 components (NT <= 4) and an LDS footprint of three bf16 planes
+static bool psm_encode_x6_fits(const PsmEncodeArgs& a, size_t* lds) {
+  const int rows = a.Mpad <= 32 ? 32 : 32 * PSM_MT_CHUNK;
+  *lds = (size_t)3 * rows * (PSM_PIX_PER_SLICE * a.c_in + 4) * 2;
+  return a.NT <= 4 && *lds <= 156 * 1024 && a.Mpad % 32 == 0;
+}
+
 hipError_t psm_launch_encode(const PsmEncodeArgs& a, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
   const int n_slices = a.S * a.S / PSM_PIX_PER_SLICE;
   const int rows = a.Mpad <= 32 ? 32 : 32 * PSM_MT_CHUNK;        // one tile, or 2 x 64-row buffers / a 128-row chunk
-  const size_t lds = (size_t)rows * (PSM_PIX_PER_SLICE * a.c_in + 4) * sizeof(float);
+  size_t lds = (size_t)rows * (PSM_PIX_PER_SLICE * a.c_in + 4) * sizeof(float);
+  size_t lds_x6 = 0;
+  if (a.x6 && psm_encode_x6_fits(a, &lds_x6)) {
+    lds = lds_x6;
+#define ENCX2(C, AL)                                                                                          \
+  if (ev_start) hipExtLaunchKernelGGL((psm_encode_x6_kernel<C, AL>), dim3(n_slices), dim3(256), (std::uint32_t)lds, st, ev_start, ev_stop, 0, a); \
+  else PSM_LAUNCH((psm_encode_x6_kernel<C, AL>), dim3(n_slices), dim3(256), lds, st, a)
+#define ENCX(C) case C: if (a.aligned) { ENCX2(C, true); } else { ENCX2(C, false); } break;
+    switch (a.c_in) {
+      ENCX(1) ENCX(2) ENCX(3) ENCX(4)
+      default: return hipErrorInvalidValue;
+    }
+#undef ENCX
+#undef ENCX2
+    return hipGetLastError();
+  }
   // With events: hipExtLaunchKernelGGL stamps them with the dispatch's own begin / end times
   // (the source rocprofv3 reads), not with separate marker packets around the launch.
 #define ENC2(C, AL)                                                                                          \
@@ -346,7 +544,6 @@ hipError_t psm_launch_reduce(const PsmReduceArgs& a, hipStream_t st) {
 // VALU -- the contraction is only p_in (<= 512) long.  Saves a launch (~5 us) over
 // psm_reduce_kernel + psm_dense_kernel; slab summation order is that of psm_reduce_kernel.
 // ---------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <bool BF16>
 __global__ __launch_bounds__(1024) void psm_reduce_dense1_kernel(PsmReduceArgs r, PsmDenseArgs d) {
   __shared__ float red[16][512];
@@ -1865,9 +2062,28 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
     o.cs = m / B; o.b = m - o.cs * B;
     o.rs = a.row_scale[m];
 #pragma unroll
-    for (int f = 0; f < C; ++f) o.sub[f] = p.offs[((int64_t)o.cs * C + f) * B + o.b] + p.shift[o.cs * C + f];
-#pragma unroll
     for (int w = 0; w < WPB; ++w) o.own[w] = p.ownbits[((int64_t)o.cs * B + o.b) * wps + (int)blockIdx.x * WPB + w];
+  };
+  // offset + shift of the row's block: requested AFTER the basis stream has been issued (first chunk), so that the sums'
+  // wait does not sit in front of it
+  auto load_sub = [&](RowOps& o) {
+#pragma unroll
+    for (int f = 0; f < C; ++f) {
+      if (p.cf) {                                      // closed form: a0 + the B pair dots of this (case, field, block)
+        const float* d2 = p.cf_dots + (((int64_t)o.cs * C + f) * B + o.b) * B;
+        float sa = p.cf_a0[((int64_t)o.cs * C + f) * B + o.b];
+        for (int q0 = 0; q0 < B; q0 += 16) {           // 16 independent loads per round trip (B = 9 ... 64)
+          float v[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) v[u] = d2[min(q0 + u, B - 1)];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) sa += (q0 + u < B) ? v[u] : 0.f;
+        }
+        o.sub[f] = sa;
+      } else {
+        o.sub[f] = p.offs[((int64_t)o.cs * C + f) * B + o.b] + p.shift[o.cs * C + f];
+      }
+    }
   };
   v4f x[NA];
   RowOps ro;
@@ -1881,7 +2097,25 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
   const int col = ct * 32 + i;
   const float mu = a.mean[col];
   __builtin_amdgcn_sched_barrier(0);
+  load_sub(ro);
+  // guard flags of this solve (0, or NaN after a geometry mismatch): with the closed form there is no chain launch to fold
+  // them into the shift, so every workgroup sums them itself (a few loads per thread, in flight with everything else)
+  float gpart = 0.f;
+  if (p.cf) {
+    for (int k0 = tid; k0 < p.n_gwaves; k0 += 256 * 4) {
+      float gv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) gv[u] = p.gflags[min(k0 + 256 * u, p.n_gwaves - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) gpart += (k0 + 256 * u < p.n_gwaves) ? gv[u] : 0.f;
+    }
+  }
   for (int t = tid; t < 2 * B; t += 256) yx[t] = p.blk_y0x0[t];      // B may exceed 128 here (single cases with many blocks)
+  float* lg = reinterpret_cast<float*>(yx + 2 * B);                  // [4] guard partial per wave
+  {
+    const float gw = wave_sum(gpart);
+    if (lane == 0) lg[wave] = gw;
+  }
   const int px = col / C, f = col - px * C;
   const int pxl = px - (int)blockIdx.x * (128 / C);
   const int r = px / S, c = px - r * S;
@@ -1890,6 +2124,7 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
       __syncthreads();                                 // every wave is done with the previous chunk
       load_tile(x, m_base);
       load_rows(ro, m_base);
+      load_sub(ro);
     }
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
@@ -1937,6 +2172,7 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
       }
     }
     if (live) {
+      const float gsum = (lg[0] + lg[1]) + (lg[2] + lg[3]);            // written before the barrier above
 #pragma unroll
       for (int mt = 0; mt < MTC; ++mt) {
 #pragma unroll
@@ -1946,7 +2182,7 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
           if (mine) {
             const int cs = lcb[2 * rr], bb = lcb[2 * rr + 1];
             const int y = yx[2 * bb] + r, xx = yx[2 * bb + 1] + c;
-            p.fields[((int64_t)cs * p.npix + (int64_t)y * p.Nx + xx) * C + f] = (acc[mt][rg] + mu) * lrs[rr] - lsub[rr * C + f];
+            p.fields[((int64_t)cs * p.npix + (int64_t)y * p.Nx + xx) * C + f] = (acc[mt][rg] + mu) * lrs[rr] - lsub[rr * C + f] - gsum;
           }
         }
       }
@@ -1979,7 +2215,7 @@ hipError_t psm_launch_decode_paste_batch(const PsmDecodeArgs& a, const PsmBoundB
     groups = std::min((tiles + mtc - 1) / mtc, cap);
   }
   const int R = mtc * 32;
-  const size_t lds = ((size_t)R * (a.ld_res + 4) + R + (size_t)R * c_out + (size_t)R * wpb + 2 * (size_t)R + 2 * (size_t)p.B) * sizeof(float);
+  const size_t lds = ((size_t)R * (a.ld_res + 4) + R + (size_t)R * c_out + (size_t)R * wpb + 2 * (size_t)R + 2 * (size_t)p.B + 4) * sizeof(float);
   const dim3 grid(nwg, groups);
 #define DP(M_, C_, L_)                                                                                                          \
   do {                                                                                                                          \
@@ -2001,6 +2237,48 @@ hipError_t psm_launch_decode_paste_batch(const PsmDecodeArgs& a, const PsmBoundB
 // ---- bf16 handles on a bound geometry: the decode rounds `res` to bf16, which is not linear, so the strip dots
 // cannot be folded through the head layer; they are taken from the rounded `res` itself in a small launch of their
 // own (one wave per table row):  out[row] = scale * (bf16(res[b]) . G[row] + M[row]) / cnt[row]
+// pair rows of the closed form (bind time): g2p[pair] = sum_e coef_e g2[src_e], c2p likewise
+__global__ __launch_bounds__(256) void psm_pair_fold_kernel(PsmPairFoldArgs a) {
+  const int pr = blockIdx.x;
+  const int e0 = a.ptr[pr], e1 = a.ptr[pr + 1];
+  for (int k = threadIdx.x; k < a.Kh; k += 256) {
+    double acc = 0.0;
+    for (int e = e0; e < e1; ++e) acc += (double)a.coef[e] * (double)a.g2[(int64_t)a.src[e] * a.Kh + k];
+    a.g2p[(int64_t)pr * a.Kh + k] = (float)acc;
+  }
+  if (threadIdx.x == 0) {
+    double acc = 0.0;
+    for (int e = e0; e < e1; ++e) acc += (double)a.coef[e] * (double)a.c2[a.src[e]];
+    a.c2p[pr] = (float)acc;
+  }
+}
+hipError_t psm_launch_pair_fold(const PsmPairFoldArgs& a, hipStream_t st) {
+  if (a.n_pairs < 1 || a.Kh < 1) return hipErrorInvalidValue;
+  PSM_LAUNCH(psm_pair_fold_kernel, dim3(a.n_pairs), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+// table dots from any activation [rows][ld_act] (one wave per table row; d.Kh <= ld_act): introspection under the closed
+// form (the strip means the chain would have consumed)
+__global__ __launch_bounds__(256) void psm_act_dots_kernel(PsmDotsArgs d, const float* act, int ld_act, int round_bf16) {
+  const int lane = threadIdx.x & 63, row = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int rc = min(row, d.n_rows - 1);
+  const int blk = d.row_of[rc];
+  float acc = 0.f;
+  for (int k = lane; k < d.Kh; k += 64) {
+    float x = act[(int64_t)blk * ld_act + k];
+    if (round_bf16) x = (float)(__bf16)x;
+    acc += x * d.g2[(int64_t)rc * d.Kh + k];
+  }
+  const float tot = wave_sum(acc);
+  if (lane == 0 && row < d.n_rows) d.out[row] = d.row_scale[blk] * (tot + d.c2[rc]) / d.cnt[rc];
+}
+hipError_t psm_launch_act_dots(const PsmDotsArgs& d, const float* act, int ld_act, int round_bf16, hipStream_t st) {
+  if (d.n_rows < 1 || d.Kh < 1 || d.Kh > ld_act) return hipErrorInvalidValue;
+  PSM_LAUNCH(psm_act_dots_kernel, dim3((d.n_rows + 3) / 4), dim3(256), 0, st, d, act, ld_act, round_bf16);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void psm_res_dots_kernel(PsmDotsArgs d, const float* res, int ld_res) {
   const int lane = threadIdx.x & 63, row = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int n_dot_wgs = (d.n_rows + 3) / 4;

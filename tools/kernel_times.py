@@ -10,6 +10,8 @@ from hipmem import DeviceArray
 wl = sys.argv[1] if len(sys.argv) > 1 else "config1"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 variant, NY, NX, NC, prec, _ = bench.WORKLOADS[wl]
+import os
+NC = int(os.environ.get("PSM_KT_CASES", NC))          # e.g. 64 cases per step on the config3 model
 model = synthetic.make_model(variant)
 g = synthetic.channel_grid(NY, NX, seed=1).astype(np.float32)[None] if NC == 1 else synthetic.random_obstacle_cases(NC, NY, NX, seed=3).astype(np.float32)
 with psm_amd.GridSurrogate(model, NY, NX, max_cases=NC, precision=prec) as sur:
