@@ -170,12 +170,14 @@ struct psm_handle {
   int32_t* d_row_of = nullptr;
   uint32_t* d_ownbits = nullptr;
   // closed form of the offset chain for case batches (psm_kernels.h PsmBoundBatchArgs): pair tables
+  int x6_mode = -1;                     // PSM_X6 at psm_create: -1 default (see launch_all), bit 0 encode, bit 1 bound decode
   bool bound_cf = false;
   size_t cf_rows_all = 0;               // cases * c_out * B * B
   float *d_g2p = nullptr, *d_c2p = nullptr, *d_cntp = nullptr, *d_cfa0 = nullptr;
   int32_t* d_row_of_p = nullptr;
   std::vector<float> h_shiftW;          // host copy of d_shiftW [c_out][B]
   const float* last_row_scale = nullptr;   // row scale of the last solve on ws0 (introspection)
+  bool last_used_cf = false;            // the last solve on ws0 took the closed form: offsets / shift are computed on demand
   // guard of the bound-geometry contract (psm_kernels.h PsmGuardArgs)
   unsigned long long* d_maskbits = nullptr;   // bound flow-cell pattern, one 64-pixel ballot per word
   int guard_ballots = 0, guard_waves = 0;
@@ -533,7 +535,7 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
   // stream, the matrix phase is short), the x6 form (six bf16 MFMA terms of exactly split operands, float32 accuracy,
   // psm_encode_x6_kernel) from two row tiles up, where the matrix phase is the longest serial phase of the launch
   // (8 cases: 17.6 -> 15.5 us, 64 cases: 75 -> 60 us).  PSM_X6=0 / 1 forces float32 / x6 everywhere.
-  { static const int x6 = getenv("PSM_X6") ? atoi(getenv("PSM_X6")) : -1; ea.x6 = x6 < 0 ? (Mpad > 32 ? 1 : 0) : ((x6 & 1) ? 1 : 0); }
+  ea.x6 = h->x6_mode < 0 ? (Mpad > 32 ? 1 : 0) : ((h->x6_mode & 1) ? 1 : 0);
 
   if (h->timed_kernel == PSM_K_ENCODE && !prof) {
     // dominant kernel: dispatch-level begin / end stamps (no marker packets around the launch)
@@ -559,8 +561,9 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
   const float* gflags = guard ? w.d_gflags : h->d_gzero;
   const int n_gwaves = guard ? h->guard_waves : 1;
   // case batches (and single cases of more than 64 blocks) on a bound geometry: closed form of the chain where it was built
-  const bool use_cf = use_bound && h->bound_cf && w.d_dots2 && !(n_cases == 1 && h->B <= 64);
-  if (&w == &h->ws0) h->last_row_scale = d_row_scale;
+  const bool use_cf = use_bound && h->bound_cf && w.d_dots2;
+  const int CB = h->cfg.c_out * h->B;
+  if (&w == &h->ws0) { h->last_row_scale = d_row_scale; h->last_used_cf = use_cf; }
   PsmReduceArgs ra{w.d_part, w.d_xin, h->d_ia, h->d_ib, h->n_slices, Mpad, h->ld_in};
   const int nl = (int)h->dense.size();
   auto dense_args = [&](int l, const float* cur, int ld_cur) {
@@ -616,7 +619,7 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
     for (int l = l_first; l < nl; ++l) {
       PsmDenseArgs da = dense_args(l, cur, ld_cur);
       if (use_bound && !bf16 && l == nl - 1) { // head layer + strip dots of the bound geometry in one launch
-        PsmDotsArgs dd = use_cf ? PsmDotsArgs{h->d_g2p, h->d_c2p, h->d_cntp, h->d_row_of_p, d_row_scale, w.d_dots2, (int)h->cf_rows_all, h->dense[nl - 1].Kpad, ga}
+        PsmDotsArgs dd = use_cf ? PsmDotsArgs{h->d_g2p, h->d_c2p, h->d_cntp, h->d_row_of_p, d_row_scale, w.d_dots2, n_cases * CB, h->dense[nl - 1].Kpad, ga, h->B, CB}
                                 : PsmDotsArgs{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, w.d_dots, h->bound_rows * n_cases, h->dense[nl - 1].Kpad, ga};
         HIPCHK(h, psm_launch_dense_dots(da, dd, st));
       } else {
@@ -631,18 +634,23 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
     de.res = w.d_res; de.ld_res = h->ld_out; de.bpack = h->d_bpack_out; de.mean = h->d_mean_out;
     de.row_scale = d_row_scale; de.pred = nullptr; de.M = M; de.Mpad = Mpad; de.Gd = h->Gd;
     de.n_coltiles = h->n_coltiles; de.K_out = h->K_out;
+    // decode + paste on a bound geometry: x6 arithmetic by default (single case 8.44 -> 8.16 us, 8 cases 10.2 -> 8.8 us; same
+    // accuracy as the float32 MFMA, tools/x6_check.py); PSM_X6 bit 1 = 0 keeps v_mfma_f32_32x32x2_f32
+    de.x6 = h->x6_mode < 0 ? 1 : ((h->x6_mode & 2) ? 1 : 0);
     PsmBoundArgs ba{};
     ba.cp = h->plan.cp; ba.blocks = h->d_blocks; ba.dots = w.d_dots; ba.scnt = h->d_cnt; ba.ownbits = h->d_ownbits;
     ba.blk_y0x0 = h->d_blk; ba.shiftW = h->d_shiftW;
     for (int f = 0; f < 2; ++f) ba.shiftL[f] = (int)h->plan.shiftA[f].size();
     ba.fields = d_fields; ba.offs = w.d_offs; ba.shift = w.d_shift; ba.Nx = h->Nx; ba.n_strips = h->n_strips; ba.B = h->B;
     ba.gflags = gflags; ba.n_gwaves = n_gwaves;
+    ba.cf = use_cf ? 1 : 0; ba.cf_dots = w.d_dots2; ba.cf_a0 = h->d_cfa0;
     if (h->bound_zero_fill)                    // cells no block covers stay 0 like the reference's np.zeros field
       HIPCHK(h, hipMemsetAsync(d_fields, 0, (size_t)n_cases * h->Ny * h->Nx * h->cfg.c_out * sizeof(float), st));
     if (n_cases == 1 && h->B <= 64) {
       tm.before(PSM_K_DECODE);
-      if (bf16) {                               // strip dots from the bf16-rounded res (own small launch)
-        PsmDotsArgs dd{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, w.d_dots, h->bound_rows, h->ld_out, ga};
+      if (bf16) {                               // dots from the bf16-rounded res (own small launch)
+        PsmDotsArgs dd = use_cf ? PsmDotsArgs{h->d_g2p, h->d_c2p, h->d_cntp, h->d_row_of_p, d_row_scale, w.d_dots2, CB, h->ld_out, ga, h->B, CB}
+                                : PsmDotsArgs{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, w.d_dots, h->bound_rows, h->ld_out, ga};
         HIPCHK(h, psm_launch_res_dots(dd, w.d_res, h->ld_out, st));
       }
       PSM_REPEAT(h, PSM_K_DECODE) HIPCHK(h, psm_launch_decode_paste(de, ba, h->cfg.c_out, st, bf16 ? 1 : 0));
@@ -665,7 +673,7 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
     tm.before(PSM_K_STRIPS); tm.after(PSM_K_STRIPS);
     tm.before(PSM_K_CHAIN);
     if (bf16) {                                 // dots from the bf16-rounded res (own small launch): pair rows, or the strip rows of the chain
-      PsmDotsArgs dd = use_cf ? PsmDotsArgs{h->d_g2p, h->d_c2p, h->d_cntp, h->d_row_of_p, d_row_scale, w.d_dots2, (int)h->cf_rows_all, h->ld_out, ga}
+      PsmDotsArgs dd = use_cf ? PsmDotsArgs{h->d_g2p, h->d_c2p, h->d_cntp, h->d_row_of_p, d_row_scale, w.d_dots2, n_cases * CB, h->ld_out, ga, h->B, CB}
                               : PsmDotsArgs{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, w.d_dots, h->bound_rows * n_cases, h->ld_out, ga};
       HIPCHK(h, psm_launch_res_dots(dd, w.d_res, h->ld_out, st));
     }
@@ -848,6 +856,7 @@ int psm_create(const psm_config* cfg, psm_handle** out) {
   {
     const char* ng = getenv("PSM_NO_GUARD");
     h->guard_on = !(ng && ng[0] == '1');
+    h->x6_mode = getenv("PSM_X6") ? atoi(getenv("PSM_X6")) : -1;
     if (hipHostMalloc((void**)&h->h_guard, 64 * sizeof(int), hipHostMallocMapped) == hipSuccess) {
       memset(h->h_guard, 0, 64 * sizeof(int));
       if (hipHostGetDevicePointer((void**)&h->m_guard, h->h_guard, 0) != hipSuccess) { (void)hipGetLastError(); h->m_guard = nullptr; }
@@ -1309,7 +1318,7 @@ static int bind_geometry_device(psm_handle* h, const float* d_grid, int n_cases 
   h->bound_cases = n_cases;
   h->bound_dots = all;
   h->bound_cf = false;
-  if (!(n_cases == 1 && small) && h->B <= 64 && getenv("PSM_NO_CLOSED_FORM") == nullptr) {
+  if (h->B <= 64 && getenv("PSM_NO_CLOSED_FORM") == nullptr) {
     if ((rc = build_closed_form(h, n_cases, rows, Kh))) return rc;
     if (h->bound_cf && (rc = dev_alloc(h, &h->ws0.d_dots2, h->cf_rows_all))) return rc;
   }
@@ -2169,7 +2178,7 @@ int psm_read_stage(psm_handle* h, int32_t stage, float* dst, size_t dst_floats) 
     case PSM_STAGE_BLOCK_PRED: return rows(h->ws0.d_pred, h->K_out, h->K_out);
     case PSM_STAGE_OFFSETS:
     case PSM_STAGE_SHIFT:
-      if (h->bound && h->bound_cf && (h->bound_scope == 2) && h->last_cases == h->bound_cases && !(h->last_cases == 1 && h->B <= 64)) {
+      if (h->bound && h->bound_cf && h->last_used_cf && h->last_cases == h->bound_cases) {
         // the last solve took the closed form: run the chain itself once, from the strip means of the same activations
         const int nl = (int)h->dense.size();
         const bool bf = h->cfg.precision == PSM_PRECISION_BF16;

@@ -62,6 +62,7 @@ struct PsmDecodeArgs {
   const float* row_scale;              // [Mpad] out_scale per block row
   float* pred;                         // [M][K_out]
   int M, Mpad, Gd, n_coltiles, K_out;
+  int x6;                              // batch decode: six bf16 MFMA terms of exactly split operands (float32 accuracy)
 };
 
 struct PsmStripArgs {
@@ -138,6 +139,9 @@ struct PsmDotsArgs {                   // rows: [c_out][nst] strip means, then [
   const float* g2; const float* c2; const float* cnt; const int32_t* row_of; const float* row_scale;
   float* out; int n_rows, Kh;
   PsmGuardArgs guard;
+  // closed form of the chain (n_src > 1): a row is the concatenation of n_src table rows, one per source block of the
+  // row's case -- out[r] = scale * (sum_blk act[case * n_src + blk] . g2[r * n_src + blk] + c2[r]); rows_per_case rows per case
+  int n_src, rows_per_case;
 };
 struct PsmBoundArgs {
   PsmChainParams cp; const PsmBlock* blocks;
@@ -146,6 +150,7 @@ struct PsmBoundArgs {
   float* fields; float* offs; float* shift;
   int Nx, n_strips, B;
   const float* gflags; int n_gwaves;   // guard flags of this solve (0 / NaN), summed into the shift; never null (>= 1 entry)
+  const float* cf_dots; const float* cf_a0; int cf;   // closed form of the chain (see PsmBoundBatchArgs): [C][B] each
 };
 struct PsmBoundBatchArgs {             // case batches: chain in its own small launch, then decode + paste
   PsmChainParams cp; const PsmBlock* blocks;
@@ -159,8 +164,9 @@ struct PsmBoundBatchArgs {             // case batches: chain in its own small l
   // Closed form of the offset chain (psm_bind_geometry_cases, B <= 64): on a bound geometry every branch of the chain is
   // decided by the strip counts, so offset + shift of block b is a fixed linear map of the strip means, which are
   // themselves dot products with the activation row of their source block: folded at bind time into one table row per
-  // (field, block, source block).  The head launch leaves cf_dots [cases][C][B][B]; the value subtracted from block b is
-  // cf_a0[case][f][b] + sum over source blocks -- no chain launch between the head and this one.
+  // (field, block, source block), which the head launch contracts with the activation rows of the case's blocks in one
+  // long dot per (field, block): cf_dots [cases][C][B].  The value subtracted from block b is cf_a0[case][f][b] + cf_dots
+  // -- no chain launch between the head and this one, no chain waves in the single-case kernel.
   const float* cf_dots; const float* cf_a0; int cf;
 };
 struct PsmPairFoldArgs {               // bind time: pair rows as linear combinations of the strip / shift rows

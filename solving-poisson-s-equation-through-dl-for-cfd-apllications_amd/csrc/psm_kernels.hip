@@ -786,13 +786,59 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a, PsmDotsA
     constexpr int RPW = 2, NQ = 4;                     // rows per wave; float4 per lane and row (Kh <= 1024)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wg = ((int)(blockIdx.z - 1) * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
-    const int n_dot_wgs = (d.n_rows + 8 * RPW - 1) / (8 * RPW);
+    const int n_dot_wgs = d.n_src > 1 ? d.n_rows : (d.n_rows + 8 * RPW - 1) / (8 * RPW);
     if (wg >= n_dot_wgs) {                               // guard riders behind the dots workgroups (uniform per workgroup)
       const int gw = (wg - n_dot_wgs) * 8 + wave;
       if (gw < d.guard.n_waves) psm_guard_wave(d.guard, gw, lane);
       return;
     }
     const int nq = d.Kh / 4;
+    if (d.n_src > 1) {
+      // closed form: one WORKGROUP per row -- wave w takes the source blocks w, w + 8, ... (four per batch, all loads of a
+      // batch up front), the eight partial sums meet in LDS
+      __shared__ float lsum[8];
+      const int row = wg, rc = min(row, d.n_rows - 1);
+      const int cs = rc / d.rows_per_case;
+      const f32x4* gp = reinterpret_cast<const f32x4*>(d.g2) + (int64_t)rc * d.n_src * nq;
+      const float* ap = a.in + (int64_t)cs * d.n_src * a.ld_in;
+      const float rsv = d.row_scale[cs * d.n_src];
+      float acc = 0.f;
+      for (int b0 = wave; b0 < d.n_src; b0 += 32) {
+        f32x4 gg[4][NQ], xx[4][NQ];
+        float cc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int blk = min(b0 + 8 * t, d.n_src - 1);
+          cc[t] = d.c2[(int64_t)rc * d.n_src + blk];
+#pragma unroll
+          for (int u = 0; u < NQ; ++u) {
+            const int q = min(lane + 64 * u, nq - 1);
+            gg[t][u] = gp[(int64_t)blk * nq + q];
+            xx[t][u] = reinterpret_cast<const f32x4*>(ap + (int64_t)blk * a.ld_in)[q];
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const bool on = b0 + 8 * t < d.n_src;
+#pragma unroll
+          for (int u = 0; u < NQ; ++u) {
+            const float s4 = (gg[t][u].x * xx[t][u].x + gg[t][u].y * xx[t][u].y) + (gg[t][u].z * xx[t][u].z + gg[t][u].w * xx[t][u].w);
+            acc += (on && lane + 64 * u < nq) ? s4 : 0.f;
+          }
+          acc += (on && lane == 0) ? cc[t] : 0.f;
+        }
+      }
+      const float tot = wave_sum(acc);
+      if (lane == 0) lsum[wave] = tot;
+      __syncthreads();
+      if (threadIdx.x == 0 && row < d.n_rows) {
+        float t8 = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) t8 += lsum[w8];
+        d.out[row] = rsv * t8;
+      }
+      return;
+    }
     f32x4 g[RPW][NQ], x[RPW][NQ];
     float c2[RPW], cn[RPW], rs[RPW];
     int row[RPW];
@@ -915,7 +961,7 @@ hipError_t psm_launch_dense_dots(const PsmDenseArgs& a, const PsmDotsArgs& d, hi
   const bool r16 = a.Mpad <= 128;                   // same tile choice as psm_launch_dense
   const int gx = a.ld_w / 16, gy = a.Mpad / (r16 ? 16 : 32);
   // z planes > 0: ceil(n_rows / 16) dots workgroups (8 waves x 2 rows), then ceil(guard waves / 8) guard workgroups
-  const int extra = (d.n_rows + 15) / 16 + (d.guard.sdf ? (d.guard.n_waves + 7) / 8 : 0);
+  const int extra = (d.n_src > 1 ? d.n_rows : (d.n_rows + 15) / 16) + (d.guard.sdf ? (d.guard.n_waves + 7) / 8 : 0);
   const dim3 grid(gx, gy, 1 + (extra + gx * gy - 1) / (gx * gy)), blk(512);
 #define DD(N)                                                                                          \
   do {                                                                                                 \
@@ -1800,9 +1846,11 @@ typedef __bf16 pk_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 pk_bf16x4 __attribute__((ext_vector_type(4)));
 // BF (bf16 handles): the tile is rounded to bf16 on its way into LDS and multiplied with the bf16 basis by
 // v_mfma_f32_32x32x16_bf16, exactly like psm_decode_bf16_kernel (psm_bf16.hip) -- same rounding points.
-template <int MTC, int C, int LDR, bool BF>      // LDR = ld_res: output components padded to 32, 64, 96 or 128
+template <int MTC, int C, int LDR, int MODE>     // LDR = ld_res: output components padded to 32, 64, 96 or 128; MODE 0 f32, 1 bf16 handle, 2 x6
 __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, PsmBoundArgs p) {
-  constexpr int LDA = BF ? (LDR + 8) / 2 : LDR + 4;    // tile row stride in floats (bf16: LDR + 8 halves)
+  constexpr bool BF = MODE == 1, X6 = MODE == 2;
+  constexpr int LDX = LDR + 4;                         // x6: plane row stride in bf16
+  constexpr int LDA = X6 ? 3 * LDX / 2 : (BF ? (LDR + 8) / 2 : LDR + 4);    // tile floats per row (bf16: LDR + 8 halves; x6: three planes)
   constexpr int Q = LDR / 4, GD = BF ? LDR / 16 : LDR / 8, NA = MTC * 32 * Q / 256;
   constexpr int WPB = (128 / C) / 32;                  // ownership words per block for this workgroup's 128 columns
   constexpr int NST = 8;                               // staging rounds of 384 floats (C*nst + nst <= 3072)
@@ -1823,14 +1871,17 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
   const bool live = dec && ((int)blockIdx.x * 4 + wave) < a.n_coltiles;
   PSM_STAMP(0, 20);
   // ---- every load of the prologue, clamped and unconditional
-  const int n_stage = C * nst + nst;
+  const int n_stage = p.cf ? 1 : C * nst + nst;
   float sv[NST];
 #pragma unroll
   for (int u = 0; u < NST; ++u) {
     const int idx = min(tid + 384 * u, n_stage - 1);
-    const float* src = idx < C * nst ? p.dots + idx : p.scnt + (idx - C * nst);
+    const float* src = p.cf ? p.cf_dots : (idx < C * nst ? p.dots + idx : p.scnt + (idx - C * nst));
     sv[u] = *src;
   }
+  // closed form of the chain: offset + shift of block b = a0 + the long dot the head launch left (one thread per value)
+  const int cfi = min(tid, C * B - 1);
+  const float cfv = p.cf ? p.cf_a0[cfi] + p.cf_dots[cfi] : 0.f;
   const int rb = min(tid, B - 1);                      // threads < B: the record of block row tid
   uint32_t ow[WPB];
 #pragma unroll
@@ -1839,7 +1890,7 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
   const float rs = a.row_scale[min(rb, a.Mpad - 1)];
   const int cf = min(max(wave - 4, 0), C - 1);         // chain waves: their field
   const float w_shift = p.shiftW[cf * B + min(lane, B - 1)];
-  const float s_raw = p.dots[C * nst + cf * B + min(lane, B - 1)];
+  const float s_raw = p.cf ? 0.f : p.dots[C * nst + cf * B + min(lane, B - 1)];
   const float gf0 = p.gflags[min(lane, p.n_gwaves - 1)], gf1 = p.gflags[min(lane + 64, p.n_gwaves - 1)];   // guard flags (0 / NaN)
   v4f x[NA];
 #pragma unroll
@@ -1858,7 +1909,8 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
   // ---- LDS staging; the barrier drains LDS traffic only, so the basis loads above stay in flight behind it
 #pragma unroll
   for (int u = 0; u < NST; ++u)
-    if (tid + 384 * u < n_stage) smean[tid + 384 * u] = sv[u];       // smean and scnt are contiguous
+    if (!p.cf && tid + 384 * u < n_stage) smean[tid + 384 * u] = sv[u];       // smean and scnt are contiguous
+  if (p.cf && tid < C * B) offs[tid] = cfv;
   if (tid < B) {
     float* rr = rec + tid * 8;
     rr[0] = __int_as_float(y0v); rr[1] = __int_as_float(x0v); rr[2] = rs; rr[3] = 0.f;
@@ -1869,7 +1921,14 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
       const int idx = tid + 256 * u, row = idx / Q, q = idx - row * Q;
-      if constexpr (BF) {
+      if constexpr (X6) {
+        x6_bf16x4 vh, vm, vl;
+        psm_split3(x[u], vh, vm, vl);
+        __bf16* dst = reinterpret_cast<__bf16*>(lds) + row * LDX + 4 * q;
+        *reinterpret_cast<x6_bf16x4*>(dst) = vh;
+        *reinterpret_cast<x6_bf16x4*>(dst + R * LDX) = vm;
+        *reinterpret_cast<x6_bf16x4*>(dst + 2 * R * LDX) = vl;
+      } else if constexpr (BF) {
         pk_bf16x4 v;
         v[0] = (__bf16)x[u][0]; v[1] = (__bf16)x[u][1]; v[2] = (__bf16)x[u][2]; v[3] = (__bf16)x[u][3];
         *reinterpret_cast<pk_bf16x4*>(reinterpret_cast<__bf16*>(&lds[row * LDA]) + 4 * q) = v;
@@ -1881,11 +1940,32 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
   PSM_LDS_BARRIER();
   PSM_STAMP(0, 21);
   f32x16 acc[MTC];
+  x6_bf16x8 Bh[X6 ? LDR / 16 : 1], Bm[X6 ? LDR / 16 : 1], Bl[X6 ? LDR / 16 : 1];
   if (dec) {
 #pragma unroll
     for (int mt = 0; mt < MTC; ++mt) {
       acc[mt] = (f32x16){0};
-      if constexpr (BF) {
+      if constexpr (X6) {
+        const __bf16* arow = reinterpret_cast<const __bf16*>(lds) + (mt * 32 + i) * LDX + 4 * h;
+#pragma unroll
+        for (int st = 0; st < LDR / 16; ++st) {
+          if (mt == 0) {                               // the basis slice is split on the way: each step waits for its two groups only
+            x6_bf16x4 h0, m0, l0, h1, m1, l1;
+            psm_split3((f32x4){b[2 * st].x, b[2 * st].y, b[2 * st].z, b[2 * st].w}, h0, m0, l0);
+            psm_split3((f32x4){b[2 * st + 1].x, b[2 * st + 1].y, b[2 * st + 1].z, b[2 * st + 1].w}, h1, m1, l1);
+            Bh[st] = psm_cat4(h0, h1); Bm[st] = psm_cat4(m0, m1); Bl[st] = psm_cat4(l0, l1);
+          }
+          const x6_bf16x8 ah = psm_cat4(*reinterpret_cast<const x6_bf16x4*>(arow + 16 * st), *reinterpret_cast<const x6_bf16x4*>(arow + 16 * st + 8));
+          const x6_bf16x8 am = psm_cat4(*reinterpret_cast<const x6_bf16x4*>(arow + R * LDX + 16 * st), *reinterpret_cast<const x6_bf16x4*>(arow + R * LDX + 16 * st + 8));
+          const x6_bf16x8 al = psm_cat4(*reinterpret_cast<const x6_bf16x4*>(arow + 2 * R * LDX + 16 * st), *reinterpret_cast<const x6_bf16x4*>(arow + 2 * R * LDX + 16 * st + 8));
+          acc[mt] = MFMA_X6(am, Bm[st], acc[mt]);
+          acc[mt] = MFMA_X6(al, Bh[st], acc[mt]);
+          acc[mt] = MFMA_X6(ah, Bl[st], acc[mt]);
+          acc[mt] = MFMA_X6(am, Bh[st], acc[mt]);
+          acc[mt] = MFMA_X6(ah, Bm[st], acc[mt]);
+          acc[mt] = MFMA_X6(ah, Bh[st], acc[mt]);
+        }
+      } else if constexpr (BF) {
         const __bf16* arow = reinterpret_cast<const __bf16*>(&lds[(mt * 32 + i) * LDA]) + 8 * h;
 #pragma unroll
         for (int g = 0; g < GD; ++g) {
@@ -1908,14 +1988,18 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
     }
   } else if (wave - 4 < C) {
     const int f = wave - 4;
-    // (the chain shares its SIMD with an MFMA wave and in effect runs after that wave's 2 us of MFMAs -- 3.7 us to the
-    // chain's end instead of 1.6 alone; s_setprio(3) here changes nothing: the vector ALU itself is taken)
-    psm_chain_wave(p.cp, smean + f * nst, scnt, p.blocks, f, lane, offs + f * B);
-    const float t = (lane < B && w_shift != 0.f) ? w_shift * offs[f * B + lane] : 0.f;   // same-wave LDS writes are visible
-    const float t_shift = wave_sum(t);
-    const float raw = wave_sum(lane < B ? s_raw : 0.f);
     const float guard = psm_guard_sum(p.gflags, p.n_gwaves, lane, gf0, gf1);   // NaN when the grid is not the bound geometry
-    if (lane == 0) wred[f] = raw / (float)p.shiftL[f] / 3.f - t_shift + guard;
+    if (p.cf) {                                // closed form: the staged values already hold offset + shift
+      if (lane == 0) wred[f] = guard;
+    } else {
+      // (the chain shares its SIMD with an MFMA wave and in effect runs after that wave's 2 us of MFMAs -- 3.7 us to the
+      // chain's end instead of 1.6 alone; s_setprio(3) here changes nothing: the vector ALU itself is taken)
+      psm_chain_wave(p.cp, smean + f * nst, scnt, p.blocks, f, lane, offs + f * B);
+      const float t = (lane < B && w_shift != 0.f) ? w_shift * offs[f * B + lane] : 0.f;   // same-wave LDS writes are visible
+      const float t_shift = wave_sum(t);
+      const float raw = wave_sum(lane < B ? s_raw : 0.f);
+      if (lane == 0) wred[f] = raw / (float)p.shiftL[f] / 3.f - t_shift + guard;
+    }
     if (blockIdx.x == 0 && f == 0 && lane == 0) {
 #ifdef PSM_STAMPS
       g_psm_stamps[39] = __builtin_amdgcn_s_memrealtime();
@@ -1924,7 +2008,7 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
   }
   PSM_STAMP(0, 22);
   PSM_LDS_BARRIER();
-  if (blockIdx.x == 0) {       // introspection copies (psm_read_stage)
+  if (blockIdx.x == 0 && !p.cf) {       // introspection copies (psm_read_stage; under the closed form it runs the chain itself)
     for (int idx = tid; idx < C * B; idx += 384) p.offs[idx] = offs[idx];
     if (tid < C) p.shift[tid] = wred[tid];
   }
@@ -1965,11 +2049,14 @@ hipError_t psm_launch_decode_paste(const PsmDecodeArgs& a, const PsmBoundArgs& p
   if ((c_out != 1 && c_out != 2) || c_out * p.n_strips + p.n_strips > 8 * 384) return hipErrorInvalidValue;
   const int nwg = (a.n_coltiles + 3) / 4, mtc = a.Mpad / 32, wpb = (128 / c_out) / 32;
   (void)wpb;
-  const size_t lds = ((size_t)mtc * 32 * (a.ld_res + 4) + (size_t)mtc * 32 * 8 + (size_t)c_out * p.n_strips + p.n_strips + (size_t)c_out * p.B + 4) * sizeof(float);
+  const bool x6 = a.x6 && !bf16;
+  const size_t tile_floats = x6 ? (size_t)mtc * 32 * (a.ld_res + 4) * 3 / 2 : (size_t)mtc * 32 * (a.ld_res + 4);
+  const size_t lds = (tile_floats + (size_t)mtc * 32 * 8 + (size_t)c_out * p.n_strips + p.n_strips + (size_t)c_out * p.B + 4) * sizeof(float);
 #define DP(M_, C_, L_)                                                                                              \
   do {                                                                                                              \
-    if (bf16) PSM_LAUNCH((psm_decode_paste_kernel<M_, C_, L_, true>), dim3(nwg), dim3(384), lds, st, a, p);    \
-    else PSM_LAUNCH((psm_decode_paste_kernel<M_, C_, L_, false>), dim3(nwg), dim3(384), lds, st, a, p);        \
+    if (bf16) PSM_LAUNCH((psm_decode_paste_kernel<M_, C_, L_, 1>), dim3(nwg), dim3(384), lds, st, a, p);    \
+    else if (x6) PSM_LAUNCH((psm_decode_paste_kernel<M_, C_, L_, 2>), dim3(nwg), dim3(384), lds, st, a, p); \
+    else PSM_LAUNCH((psm_decode_paste_kernel<M_, C_, L_, 0>), dim3(nwg), dim3(384), lds, st, a, p);         \
   } while (0)
 #define DPL(L_)                                                        \
   do {                                                                 \
@@ -2031,9 +2118,11 @@ hipError_t psm_launch_chain_dots(const PsmBoundBatchArgs& p, int c_out, hipStrea
   return hipGetLastError();
 }
 
-template <int MTC, int C, int LDR, bool BF>
+template <int MTC, int C, int LDR, int MODE>           // MODE 0: exact-f32 MFMA, 1: bf16 handle (operands rounded), 2: x6 (float32 accuracy on the bf16 pipe)
 __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeArgs a, PsmBoundBatchArgs p, int m_end) {
-  constexpr int LDA = BF ? (LDR + 8) / 2 : LDR + 4;    // tile row stride in floats (bf16: LDR + 8 halves)
+  constexpr bool BF = MODE == 1, X6 = MODE == 2;
+  constexpr int LDX = LDR + 4;                         // x6: plane row stride in bf16 (LDR / 2 + 2 dwords = 2 * odd: ds_read_b64 conflict-free)
+  constexpr int LDA = X6 ? 3 * LDX / 2 : (BF ? (LDR + 8) / 2 : LDR + 4);    // tile floats per row (bf16: LDR + 8 halves; x6: three planes)
   constexpr int Q = LDR / 4, GD = BF ? LDR / 16 : LDR / 8, NA = MTC * 32 * Q / 256;
   constexpr int WPB = (128 / C) / 32, R = MTC * 32;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -2070,16 +2159,7 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
 #pragma unroll
     for (int f = 0; f < C; ++f) {
       if (p.cf) {                                      // closed form: a0 + the B pair dots of this (case, field, block)
-        const float* d2 = p.cf_dots + (((int64_t)o.cs * C + f) * B + o.b) * B;
-        float sa = p.cf_a0[((int64_t)o.cs * C + f) * B + o.b];
-        for (int q0 = 0; q0 < B; q0 += 16) {           // 16 independent loads per round trip (B = 9 ... 64)
-          float v[16];
-#pragma unroll
-          for (int u = 0; u < 16; ++u) v[u] = d2[min(q0 + u, B - 1)];
-#pragma unroll
-          for (int u = 0; u < 16; ++u) sa += (q0 + u < B) ? v[u] : 0.f;
-        }
-        o.sub[f] = sa;
+        o.sub[f] = p.cf_a0[((int64_t)o.cs * C + f) * B + o.b] + p.cf_dots[((int64_t)o.cs * C + f) * B + o.b];
       } else {
         o.sub[f] = p.offs[((int64_t)o.cs * C + f) * B + o.b] + p.shift[o.cs * C + f];
       }
@@ -2116,6 +2196,17 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
     const float gw = wave_sum(gpart);
     if (lane == 0) lg[wave] = gw;
   }
+  // x6: this wave's basis slice split once into three bf16 planes (registers); reused by every row chunk
+  x6_bf16x8 Bh[X6 ? LDR / 16 : 1], Bm[X6 ? LDR / 16 : 1], Bl[X6 ? LDR / 16 : 1];
+  if constexpr (X6) {
+#pragma unroll
+    for (int st = 0; st < LDR / 16; ++st) {
+      x6_bf16x4 h0, m0, l0, h1, m1, l1;
+      psm_split3((f32x4){b[2 * st].x, b[2 * st].y, b[2 * st].z, b[2 * st].w}, h0, m0, l0);
+      psm_split3((f32x4){b[2 * st + 1].x, b[2 * st + 1].y, b[2 * st + 1].z, b[2 * st + 1].w}, h1, m1, l1);
+      Bh[st] = psm_cat4(h0, h1); Bm[st] = psm_cat4(m0, m1); Bl[st] = psm_cat4(l0, l1);
+    }
+  }
   const int px = col / C, f = col - px * C;
   const int pxl = px - (int)blockIdx.x * (128 / C);
   const int r = px / S, c = px - r * S;
@@ -2129,7 +2220,14 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
       const int idx = tid + 256 * u, row = idx / Q, q = idx - row * Q;
-      if constexpr (BF) {
+      if constexpr (X6) {                            // exact three-way split, one bf16 plane each
+        x6_bf16x4 vh, vm, vl;
+        psm_split3(x[u], vh, vm, vl);
+        __bf16* dst = reinterpret_cast<__bf16*>(lds) + row * LDX + 4 * q;
+        *reinterpret_cast<x6_bf16x4*>(dst) = vh;
+        *reinterpret_cast<x6_bf16x4*>(dst + R * LDX) = vm;
+        *reinterpret_cast<x6_bf16x4*>(dst + 2 * R * LDX) = vl;
+      } else if constexpr (BF) {
         pk_bf16x4 v;
         v[0] = (__bf16)x[u][0]; v[1] = (__bf16)x[u][1]; v[2] = (__bf16)x[u][2]; v[3] = (__bf16)x[u][3];
         *reinterpret_cast<pk_bf16x4*>(reinterpret_cast<__bf16*>(&lds[row * LDA]) + 4 * q) = v;
@@ -2150,7 +2248,21 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
 #pragma unroll
     for (int mt = 0; mt < MTC; ++mt) {
       acc[mt] = (f32x16){0};
-      if constexpr (BF) {
+      if constexpr (X6) {
+        const __bf16* arow = reinterpret_cast<const __bf16*>(lds) + (mt * 32 + i) * LDX + 4 * h;
+#pragma unroll
+        for (int st = 0; st < LDR / 16; ++st) {
+          const x6_bf16x8 ah = psm_cat4(*reinterpret_cast<const x6_bf16x4*>(arow + 16 * st), *reinterpret_cast<const x6_bf16x4*>(arow + 16 * st + 8));
+          const x6_bf16x8 am = psm_cat4(*reinterpret_cast<const x6_bf16x4*>(arow + R * LDX + 16 * st), *reinterpret_cast<const x6_bf16x4*>(arow + R * LDX + 16 * st + 8));
+          const x6_bf16x8 al = psm_cat4(*reinterpret_cast<const x6_bf16x4*>(arow + 2 * R * LDX + 16 * st), *reinterpret_cast<const x6_bf16x4*>(arow + 2 * R * LDX + 16 * st + 8));
+          acc[mt] = MFMA_X6(am, Bm[st], acc[mt]);
+          acc[mt] = MFMA_X6(al, Bh[st], acc[mt]);
+          acc[mt] = MFMA_X6(ah, Bl[st], acc[mt]);
+          acc[mt] = MFMA_X6(am, Bh[st], acc[mt]);
+          acc[mt] = MFMA_X6(ah, Bm[st], acc[mt]);
+          acc[mt] = MFMA_X6(ah, Bh[st], acc[mt]);
+        }
+      } else if constexpr (BF) {
         const __bf16* arow = reinterpret_cast<const __bf16*>(&lds[(mt * 32 + i) * LDA]) + 8 * h;
 #pragma unroll
         for (int g = 0; g < GD; ++g) {
@@ -2215,12 +2327,15 @@ hipError_t psm_launch_decode_paste_batch(const PsmDecodeArgs& a, const PsmBoundB
     groups = std::min((tiles + mtc - 1) / mtc, cap);
   }
   const int R = mtc * 32;
-  const size_t lds = ((size_t)R * (a.ld_res + 4) + R + (size_t)R * c_out + (size_t)R * wpb + 2 * (size_t)R + 2 * (size_t)p.B + 4) * sizeof(float);
+  const bool x6 = a.x6 && !bf16;
+  const size_t tile_floats = x6 ? (size_t)R * (a.ld_res + 4) * 3 / 2 : (size_t)R * (a.ld_res + 4);
+  const size_t lds = (tile_floats + R + (size_t)R * c_out + (size_t)R * wpb + 2 * (size_t)R + 2 * (size_t)p.B + 4) * sizeof(float);
   const dim3 grid(nwg, groups);
 #define DP(M_, C_, L_)                                                                                                          \
   do {                                                                                                                          \
-    if (bf16) PSM_LAUNCH((psm_decode_paste_batch_kernel<M_, C_, L_, true>), grid, dim3(256), lds, st, a, p, a.Mpad);      \
-    else PSM_LAUNCH((psm_decode_paste_batch_kernel<M_, C_, L_, false>), grid, dim3(256), lds, st, a, p, a.Mpad);          \
+    if (bf16) PSM_LAUNCH((psm_decode_paste_batch_kernel<M_, C_, L_, 1>), grid, dim3(256), lds, st, a, p, a.Mpad);      \
+    else if (x6) PSM_LAUNCH((psm_decode_paste_batch_kernel<M_, C_, L_, 2>), grid, dim3(256), lds, st, a, p, a.Mpad);   \
+    else PSM_LAUNCH((psm_decode_paste_batch_kernel<M_, C_, L_, 0>), grid, dim3(256), lds, st, a, p, a.Mpad);           \
   } while (0)
 #define DPM(C_, L_)                                                                 \
   do {                                                                              \
@@ -2281,13 +2396,46 @@ hipError_t psm_launch_act_dots(const PsmDotsArgs& d, const float* act, int ld_ac
 
 __global__ __launch_bounds__(256) void psm_res_dots_kernel(PsmDotsArgs d, const float* res, int ld_res) {
   const int lane = threadIdx.x & 63, row = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int n_dot_wgs = (d.n_rows + 3) / 4;
+  const int n_dot_wgs = d.n_src > 1 ? d.n_rows : (d.n_rows + 3) / 4;
   if ((int)blockIdx.x >= n_dot_wgs) {                    // guard riders (PsmGuardArgs)
     const int gw = ((int)blockIdx.x - n_dot_wgs) * 4 + (int)(threadIdx.x >> 6);
     if (gw < d.guard.n_waves) psm_guard_wave(d.guard, gw, lane);
     return;
   }
   const int rc = min(row, d.n_rows - 1);
+  if (d.n_src > 1) {                                     // closed form: one workgroup per row, wave w takes the source blocks w, w + 4, ...
+    __shared__ float lsum[4];
+    const int wave = threadIdx.x >> 6;
+    const int rowl = (int)blockIdx.x, rl = min(rowl, d.n_rows - 1);
+    const int cs = rl / d.rows_per_case;
+    float acc = 0.f;
+    for (int b0 = wave; b0 < d.n_src; b0 += 16) {
+      float xv[4][2], gv[4][2], cc[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int blk = min(b0 + 4 * t, d.n_src - 1);
+        cc[t] = d.c2[(int64_t)rl * d.n_src + blk];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int k = min(lane + 64 * u, ld_res - 1);
+          xv[t][u] = res[((int64_t)cs * d.n_src + blk) * ld_res + k];
+          gv[t][u] = d.g2[((int64_t)rl * d.n_src + blk) * ld_res + k];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bool on = b0 + 4 * t < d.n_src;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc += (on && lane + 64 * u < ld_res) ? (float)(__bf16)xv[t][u] * gv[t][u] : 0.f;
+        acc += (on && lane == 0) ? cc[t] : 0.f;
+      }
+    }
+    const float tot = wave_sum(acc);
+    if (lane == 0) lsum[wave] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0 && rowl < d.n_rows) d.out[rowl] = d.row_scale[cs * d.n_src] * ((lsum[0] + lsum[1]) + (lsum[2] + lsum[3]));
+    return;
+  }
   const int blk = d.row_of[rc];
   float acc = 0.f;
 #pragma unroll
@@ -2303,7 +2451,7 @@ __global__ __launch_bounds__(256) void psm_res_dots_kernel(PsmDotsArgs d, const 
 
 hipError_t psm_launch_res_dots(const PsmDotsArgs& d, const float* res, int ld_res, hipStream_t st) {
   if (ld_res > 128 || ld_res < 1 || d.n_rows < 1) return hipErrorInvalidValue;
-  const int nwg = (d.n_rows + 3) / 4 + (d.guard.sdf ? (d.guard.n_waves + 3) / 4 : 0);
+  const int nwg = (d.n_src > 1 ? d.n_rows : (d.n_rows + 3) / 4) + (d.guard.sdf ? (d.guard.n_waves + 3) / 4 : 0);
   PSM_LAUNCH(psm_res_dots_kernel, dim3(nwg), dim3(256), 0, st, d, res, ld_res);
   return hipGetLastError();
 }

@@ -342,3 +342,32 @@ def test_bf16_bound_batches_and_many_blocks(variant, ny, nx, n):
         bound = sur.solve(grids)
     for k in range(n):
         same(bound[k], general[k], tol=5e-5)
+
+
+@pytest.mark.parametrize("mode", ["0", "3"])
+def test_x6_arithmetic_against_the_oracle(mode, monkeypatch):
+    """The PCA contractions on the bf16 matrix pipe at float32 accuracy (x6: every float32 operand split exactly into three
+    bf16 terms, six MFMA terms kept; default for the encode from two row tiles up and for the bound decode) against the
+    exact-float32 MFMA (PSM_X6=0) and the float64 oracle: same tolerances, batch of 8 cases and single case, both forced
+    everywhere (PSM_X6=3) and switched off."""
+    monkeypatch.setenv("PSM_X6", mode)
+    from test_gpu_parity import check_against_oracle
+    model = synthetic.make_model("deltas")
+    grids = synthetic.random_obstacle_cases(8, 256, 256, seed=3).astype(np.float32)
+    with GridSurrogate(model, 256, 256, max_cases=8) as sur:
+        general = sur.solve(grids)
+        sol = orc.solve_grid(grids[5].astype(np.float64), oracle_model(model))
+        check_against_oracle(sur, grids[5], model, sol, n_cases=8, case=5)            # coefficients <= 2e-6, decoded blocks <= 1e-5
+        assert sur.bind_geometry(grids)
+        bound = sur.solve(grids)
+        assert np.abs(bound[5] - sol.fields).max() <= 1e-4 * np.abs(sol.fields).max()
+        same(bound, general)
+    m1 = synthetic.make_model("gradp")
+    g1 = synthetic.channel_grid(256, 256, seed=1).astype(np.float32)
+    with GridSurrogate(m1, 256, 256) as sur:
+        f = sur.solve(g1)[0]
+        s1 = orc.solve_grid(g1.astype(np.float64), oracle_model(m1))
+        check_against_oracle(sur, g1, m1, s1)
+        assert sur.bind_geometry(g1)
+        fb = sur.solve(g1)[0]
+    assert rel_l2(fb, s1.fields) <= 2e-6 and rel_l2(f, s1.fields) <= 2e-6
