@@ -311,6 +311,30 @@ def degenerate_note(variant, ny, nx, S=128):
             "the parity claim use non-degenerate grids)")
 
 
+_REAL_STDOUT = None
+
+
+def own_stdout():
+    """The driver reads ONE JSON line from stdout, but gloo and RCCL print banners there ("[Gloo] Rank 0 is connected ...",
+    "RCCL version : ...").  From here on file descriptor 1 of this process points to stderr; the JSON line goes to the
+    original stdout through emit()."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = json.dumps(obj) + "\n"
+    if _REAL_STDOUT is not None:
+        _REAL_STDOUT.write(line)
+        _REAL_STDOUT.flush()
+    else:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+
+
 def finish(pdist_mod=None):
     try:
         import torch.distributed as dist
@@ -334,10 +358,10 @@ def main_dry(args):
     dt = pdist.timed_region(lambda i: time.sleep(1e-4), args.steps, args.warmup)
     reported = dist.get_world_size() if dist.is_initialized() else 1
     if rank == 0:
-        print(json.dumps({"metric": "pressure-solves/sec (256x256 U->p inference)", "value": None, "unit": "solves/s",
+        emit({"metric": "pressure-solves/sec (256x256 U->p inference)", "value": None, "unit": "solves/s",
                           "n_gpus": world, "world_size_reported": reported, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / args.steps * 1e3, "dry_run": True, "data": "none (dry run: launcher and "
-                          "process-group plumbing only)"}))
+                          "process-group plumbing only)"})
     finish()
 
 
@@ -519,7 +543,7 @@ def main_unet(args):
         if k in leg:
             out[k] = leg[k]
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
     finish()
 
 
@@ -586,6 +610,7 @@ def main():
     # N ranks asked for and no launcher environment: start them ourselves, before this process touches the GPU
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
+    own_stdout()
     if args.dry_run:
         return main_dry(args)
     if args.workload in UNET_WORKLOADS:
@@ -772,7 +797,7 @@ def main():
         out["l2_vs_oracle"] = float(np.linalg.norm(got_dev[0] - ref) / np.linalg.norm(ref))
         out["gpu_over_cpu"] = out["value"] / cb["value"]
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
     sur.close()
     finish()
 
