@@ -1318,7 +1318,12 @@ static int bind_geometry_device(psm_handle* h, const float* d_grid, int n_cases 
   h->bound_cases = n_cases;
   h->bound_dots = all;
   h->bound_cf = false;
-  if (h->B <= 64 && getenv("PSM_NO_CLOSED_FORM") == nullptr) {
+  // The closed form trades the chain for a longer dots table: C B^2 rows per case against C (strips + B).  It is used where
+  // that table stays small next to what the head launch streams anyway (deltas / chapter5 batches: fewer rows than the
+  // strips; a single U_to_gradP case: 3.7 MB); a batch of U_to_gradP cases (1800 rows per case against 728) keeps the
+  // chain launch.
+  const double cf_bytes = (double)n_cases * C * h->B * h->B * Kh * 4.0, strip_bytes = (double)all * Kh * 4.0;
+  if (h->B <= 64 && getenv("PSM_NO_CLOSED_FORM") == nullptr && cf_bytes <= std::max(8.0e6, 1.5 * strip_bytes)) {
     if ((rc = build_closed_form(h, n_cases, rows, Kh))) return rc;
     if (h->bound_cf && (rc = dev_alloc(h, &h->ws0.d_dots2, h->cf_rows_all))) return rc;
   }
