@@ -464,7 +464,7 @@ def unet_leg(name, args, torch, pdist, rank, world, local_rank, backend, steps, 
     W = synthetic.unet_he_weights(seed=7)
     prec = "bf16" if name.endswith("bf16") else "f32"
     peak = MFMA_BF16_PEAK_TFLOPS if prec == "bf16" else MFMA_F32_PEAK_TFLOPS
-    net = UNetSurrogate(W, NY, NX, max_cases=NC, device=local_rank, precision=prec)
+    net = UNetSurrogate(W, NY, NX, max_cases=NC, device=local_rank, precision=prec, autotune=True)   # plan-time, outside the timed region
     n_in = min(args.inputs, 2 if NY > 256 else args.inputs)
     grids = [np.stack([synthetic.channel_grid(NY, NX, seed=1 + 1000 * rank + 10 * i + k, noise=0.05 if NY > 256 else 0.02).astype(np.float32)
                        for k in range(NC)]) for i in range(n_in)]
@@ -504,6 +504,7 @@ def unet_leg(name, args, torch, pdist, rank, world, local_rank, backend, steps, 
     leg = {"workload": desc, "value": pdist.aggregate_throughput(NC, steps, world, dt_max), "unit": "solves/s", "steps": steps, "warmup": warmup,
            "ms_per_step": dt_max / steps * 1e3, "dtype": prec, "cases_per_step_per_gpu": NC, "grid": [NY, NX],
            "parity": "unpinned (no reference network): l2_vs_oracle is against the build-defined NumPy U-Net with the same rounding points",
+           "planner": {"autotuned_split_k": net.autotuned},
            "roofline": roof}
     if with_cpu:
         from oracle import unet_oracle as uo           # checker + cpu_baseline leg only
@@ -537,7 +538,7 @@ def main_unet(args):
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": leg["ms_per_step"], "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": leg["dtype"], "data": "synthetic",
            "config": {"workload": leg["workload"], "grid": leg["grid"], "cases_per_step_per_gpu": leg["cases_per_step_per_gpu"],
-                      "parallelism": f"case-sharded x{world} (no data-path collective)", "parity": leg["parity"]},
+                      "parallelism": f"case-sharded x{world} (no data-path collective)", "parity": leg["parity"], "planner": leg["planner"]},
            "roofline": leg["roofline"]}
     for k in ("cpu_baseline", "l2_vs_oracle"):
         if k in leg:

@@ -58,6 +58,14 @@ int psm_unet_read_activation(psm_unet* u, int32_t idx, float* dst, int64_t dst_f
 /* One forward pass with a HIP event between the layers: ms [num_convs] (each includes ~3 us of event overhead),
  * wgs [num_convs] workgroups launched per layer (may be NULL).  Introspection for tuning. */
 int psm_unet_profile(psm_unet* u, const float* d_grid, int32_t n_cases, float* d_field, float* ms, int32_t* wgs);
+/* Plan-time autotune of the split-K depth per layer (call after psm_unet_plan, before the forward passes that matter): the
+ * planner splits the input channels of layers that cannot fill the chip, which shortens them but makes their consumers sum
+ * float32 partial-sum slabs; this measures, layer by layer, whether a shallower split makes the WHOLE forward pass of
+ * n_cases cases faster and re-plans accordingly (a few hundred forward passes on zero images, the handle's buffers are
+ * re-allocated).  us_before / us_after (may be NULL): microseconds per forward pass.  Results are unchanged by the choice
+ * up to float32 summation order.  psm_unet_ksplit: the split of convolution idx in the current plan. */
+int psm_unet_autotune(psm_unet* u, int32_t n_cases, int32_t iters, float* us_before, float* us_after);
+int psm_unet_ksplit(const psm_unet* u, int32_t idx);
 /* Dispatch-level time of every launch of the forward pass: `steps` passes on the handle's stream, each dispatch stamped with
  * its own begin / end by hipExtLaunchKernelGGL (the timestamps rocprofv3 --kernel-trace reads; no marker packets between
  * the layers).  us [num_convs]: average duration in microseconds of the launch that STARTS at convolution i -- a fused pair

@@ -1,5 +1,6 @@
 // psm_unet_api.cpp -- handle, layer schedule, weight packing and C-ABI of the convolutional path
 // (include/psm_unet.h; kernels in psm_unet.hip).
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -45,6 +46,7 @@ struct psm_unet {
   std::vector<Conv> convs;
   int ny = 0, nx = 0, max_cases = 0, last_cases = 0, bf16 = 0;
   bool planned = false;
+  std::vector<int> ksplit_cap;  // per convolution: deepest split-K the planner may choose (psm_unet_autotune lowers it where a split does not pay)
   bool keep_act = false;        // fused pairs also store what they would keep on chip (introspection for the parity tests)
   float *d_in = nullptr, *d_field = nullptr, *h_in = nullptr, *h_out = nullptr;
   hipStream_t stream = nullptr;
@@ -154,7 +156,7 @@ std::vector<uint16_t> pack_pair(const Conv& c, bool flat, int c0, int c1) {
 }
 
 // workgroup count first (fill 256 CUs), then the most reuse per workgroup
-void choose_config(Conv& c, int H, int W, int n_cases, bool can_split, int chunk_ch) {
+void choose_config(Conv& c, int H, int W, int n_cases, bool can_split, int chunk_ch, int ks_cap = 8) {
   const int ctiles = (c.cout + 15) / 16;
   struct Cand { int arr, nct, th; };
   const Cand cands[3] = {{0, 2, 8}, {0, 1, 8}, {1, 4, 2}};     // arrangements 2 and 3 (psm_unet.h) only by override / autotune
@@ -181,7 +183,11 @@ void choose_config(Conv& c, int H, int W, int n_cases, bool can_split, int chunk
   // 64); one everywhere also splits the 2-chunk layers, whose consumers then read float32 slabs: bf16 105 us.  No change at
   // 8 cases per step.
   const int min_chunks = getenv("PSM_UNET_SPLIT_MIN_CHUNKS") ? atoi(getenv("PSM_UNET_SPLIT_MIN_CHUNKS")) : (c.n_chunks >= 4 ? 1 : 2);
-  while (can_split && wgs * c.ksplit < fill && c.ksplit < ks_max && c.n_chunks / (c.ksplit * 2) >= min_chunks) c.ksplit *= 2;
+  // Whether a split pays is not decidable from the workgroup count alone: 512 x 512 batch 1 bf16, enc4b split in two runs in
+  // 9.4 us against 9.2 us whole while its consumer dec3a then reads float32 partial-sum slabs through the summing loader
+  // instead of finished bf16 activations (25.6 against 13.4 us); 256 x 256 batch 1, dec2a split in two: 9.0 against 14.3 us.
+  // psm_unet_autotune measures it per layer (ksplit_cap); this is the starting point.
+  while (can_split && wgs * c.ksplit < fill && c.ksplit < std::min(ks_max, ks_cap) && c.n_chunks / (c.ksplit * 2) >= min_chunks) c.ksplit *= 2;
 }
 
 int upload_conv(psm_unet* u, Conv& c) {
@@ -455,7 +461,8 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
       UCHK(u, hipMalloc((void**)&c.d_out, (size_t)c.ksplit * c.slab * sizeof(float) + 64));
       continue;
     }
-    if (c.k == 3) choose_config(c, H, W, max_cases, feeds_conv3 && getenv("PSM_UNET_NO_SPLIT") == nullptr, u->bf16 ? 32 : 16);
+    if (c.k == 3) choose_config(c, H, W, max_cases, feeds_conv3 && getenv("PSM_UNET_NO_SPLIT") == nullptr, u->bf16 ? 32 : 16,
+                                ci < u->ksplit_cap.size() ? u->ksplit_cap[ci] : 8);
     // diagnostic override: PSM_UNET_FORCE="layer:arrangement:nct:ksplit,..." (tools/unet_bench.py experiments)
     if (const char* f = getenv("PSM_UNET_FORCE")) {
       for (const char* q = f; q && *q; q = std::strchr(q, ',') ? std::strchr(q, ',') + 1 : nullptr) {
@@ -626,6 +633,65 @@ int psm_unet_time_kernels(psm_unet* u, const float* d_grid, int32_t n_cases, flo
     if (launches) launches[i] = (int32_t)(cnt[i] / steps);
   }
   return PSM_OK;
+}
+
+// Plan-time autotune of the split-K depth: the planner splits the input channels of a layer that cannot fill the chip over up
+// to 8 workgroups, which shortens that layer but makes its consumer sum float32 partial-sum slabs; whether the pair comes
+// out ahead depends on both layers' shapes.  Measured, not guessed: for every split layer, in network order, halve the cap
+// while the whole forward pass (median of `iters` passes of n_cases zero images) gets faster by more than 1 %.
+int psm_unet_autotune(psm_unet* u, int32_t n_cases, int32_t iters, float* us_before, float* us_after) {
+  if (!u) return PSM_ERR_ARG;
+  if (!u->planned) return fail(u, PSM_ERR_STATE, "psm_unet_plan has not been called");
+  if (n_cases < 1 || n_cases > u->max_cases || iters < 1) return fail(u, PSM_ERR_ARG, "bad arguments");
+  UCHK(u, hipSetDevice(u->device));
+  const int ny = u->ny, nx = u->nx, mc = u->max_cases;
+  auto measure = [&](double* out) -> int {
+    UCHK(u, hipMemsetAsync(u->d_in, 0, (size_t)ny * nx * n_cases * u->c_in * sizeof(float), u->stream));
+    hipEvent_t e0, e1;
+    UCHK(u, hipEventCreate(&e0)); UCHK(u, hipEventCreate(&e1));
+    int rc = PSM_OK;
+    std::vector<float> t;
+    for (int rep = 0; rep < 5 && rc == PSM_OK; ++rep) {           // 5 batches of `iters` passes, median batch
+      for (int w = 0; w < 2 && rc == PSM_OK; ++w) rc = forward(u, u->d_in, n_cases, u->d_field, u->stream);
+      (void)hipEventRecord(e0, u->stream);
+      for (int i = 0; i < iters && rc == PSM_OK; ++i) rc = forward(u, u->d_in, n_cases, u->d_field, u->stream);
+      (void)hipEventRecord(e1, u->stream);
+      if (hipEventSynchronize(e1) != hipSuccess) rc = fail(u, PSM_ERR_HIP, "autotune: synchronize failed");
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      t.push_back(ms * 1e3f / iters);
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    std::sort(t.begin(), t.end());
+    *out = t[t.size() / 2];
+    return PSM_OK;
+  };
+  if (u->ksplit_cap.size() != u->convs.size()) u->ksplit_cap.assign(u->convs.size(), 8);
+  double best = 0.0;
+  int rc = measure(&best);
+  if (rc) return rc;
+  if (us_before) *us_before = (float)best;
+  for (size_t i = 0; i < u->convs.size(); ++i) {
+    while (u->convs[i].ksplit > 1) {
+      const int old_cap = u->ksplit_cap[i], cand = u->convs[i].ksplit / 2;
+      u->ksplit_cap[i] = cand;
+      if ((rc = psm_unet_plan(u, ny, nx, mc))) return rc;
+      double t = 0.0;
+      if ((rc = measure(&t))) return rc;
+      if (t < best * 0.99) { best = t; continue; }                // keep the shallower split, try one more halving
+      u->ksplit_cap[i] = old_cap;                                  // no gain: back to what it was
+      if ((rc = psm_unet_plan(u, ny, nx, mc))) return rc;
+      break;
+    }
+  }
+  if (us_after) *us_after = (float)best;
+  return PSM_OK;
+}
+
+int psm_unet_ksplit(const psm_unet* u, int32_t idx) {
+  if (!u || !u->planned || idx < 0 || idx >= (int)u->convs.size()) return PSM_ERR_ARG;
+  return u->convs[idx].ksplit;
 }
 
 int psm_unet_debug_run_layer(psm_unet* u, int32_t idx, float* stamps_us) {

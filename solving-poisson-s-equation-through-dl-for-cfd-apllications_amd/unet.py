@@ -27,7 +27,8 @@ class UNetSurrogate:
     """weights: [(kernel[k,k,c_in,c_out] f32, bias[c_out] f32)] in the order enc0a, enc0b, ..., dec0a, dec0b, head."""
 
     def __init__(self, weights, ny: int, nx: int, c_in: int = 3, c_out: int = 1, widths: Sequence[int] = WIDTHS_S,
-                 max_cases: int = 1, device: int = 0, precision: str = "f32", keep_activations: bool = False):
+                 max_cases: int = 1, device: int = 0, precision: str = "f32", keep_activations: bool = False,
+                 autotune: bool = False):
         self.lib = _lib.load()
         self.ny, self.nx, self.c_in, self.c_out, self.max_cases = int(ny), int(nx), int(c_in), int(c_out), int(max_cases)
         w = np.ascontiguousarray(widths, np.int32)
@@ -53,6 +54,12 @@ class UNetSurrogate:
             # bf16 mode keeps the inner activation of a fused level pair on chip; True stores it too (activation(i) of every layer)
             self._chk(self.lib.psm_unet_keep_activations(self.h, 1 if keep_activations else 0))
             self._chk(self.lib.psm_unet_plan(self.h, self.ny, self.nx, self.max_cases))
+            self.autotuned = None
+            if autotune:                       # split-K depth per layer, measured on this GPU for max_cases cases (psm_unet_autotune)
+                b, a = C.c_float(), C.c_float()
+                self._chk(self.lib.psm_unet_autotune(self.h, self.max_cases, 20, C.byref(b), C.byref(a)))
+                self.autotuned = {"us_before": float(b.value), "us_after": float(a.value),
+                                  "ksplit": [int(self.lib.psm_unet_ksplit(self.h, i)) for i in range(n)]}
         except Exception:
             self.close()
             raise

@@ -318,3 +318,25 @@ def test_gpu_unet_from_keras_h5(tmp_path):
         out = net.forward(g)[0]
     ref = uo.unet_forward(g, W, widths)
     assert np.abs(out - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,ny,nx,n", [("bf16", 512, 512, 1), ("f32", 256, 256, 1), ("bf16", 96, 160, 2)])
+def test_gpu_unet_autotuned_plan_keeps_the_result(precision, ny, nx, n):
+    """psm_unet_autotune re-plans the split-K depth layer by layer from measurements: whatever it chooses, the field is the
+    un-tuned plan's up to float32 summation order (bf16: rounding flips) and matches the oracle."""
+    from psm_amd import UNetSurrogate
+    W = uo.he_weights(uo.unet_specs(), seed=11)
+    grids = np.stack([synthetic.channel_grid(ny, nx, seed=90 + k, noise=0.05).astype(np.float32) for k in range(n)])
+    with UNetSurrogate(W, ny, nx, max_cases=n, precision=precision) as net:
+        plain = net.forward(grids)
+        before = [int(net.lib.psm_unet_ksplit(net.h, i)) for i in range(len(net.shapes))]
+    with UNetSurrogate(W, ny, nx, max_cases=n, precision=precision, autotune=True) as net:
+        tuned = net.forward(grids)
+        t = net.autotuned
+    assert t["us_after"] <= t["us_before"] * 1.01 and len(t["ksplit"]) == 19
+    assert all(a <= b for a, b in zip(t["ksplit"], before))          # the tuner only makes splits shallower
+    tol = 1e-2 if precision == "bf16" else 1e-5
+    assert np.linalg.norm(tuned - plain) / np.linalg.norm(plain) <= tol
+    ref = uo.unet_forward(grids[0], W, precision=precision)
+    assert np.linalg.norm(tuned[0] - ref) / np.linalg.norm(ref) <= (1e-2 if precision == "bf16" else 1e-5)
