@@ -58,14 +58,19 @@ int psm_unet_read_activation(psm_unet* u, int32_t idx, float* dst, int64_t dst_f
 /* One forward pass with a HIP event between the layers: ms [num_convs] (each includes ~3 us of event overhead),
  * wgs [num_convs] workgroups launched per layer (may be NULL).  Introspection for tuning. */
 int psm_unet_profile(psm_unet* u, const float* d_grid, int32_t n_cases, float* d_field, float* ms, int32_t* wgs);
-/* Plan-time autotune of the split-K depth per layer (call after psm_unet_plan, before the forward passes that matter): the
- * planner splits the input channels of layers that cannot fill the chip, which shortens them but makes their consumers sum
- * float32 partial-sum slabs; this measures, layer by layer, whether a shallower split makes the WHOLE forward pass of
- * n_cases cases faster and re-plans accordingly (a few hundred forward passes on zero images, the handle's buffers are
- * re-allocated).  us_before / us_after (may be NULL): microseconds per forward pass.  Results are unchanged by the choice
- * up to float32 summation order.  psm_unet_ksplit: the split of convolution idx in the current plan. */
+/* Plan-time autotune (call after psm_unet_plan, before the forward passes that matter).  The planner decides by rules --
+ * fuse a level's two convolutions when it has enough tiles, pick the tile shape that fills the chip, split the input channels
+ * of layers that cannot fill it -- whose pay-off depends on the shapes of BOTH a layer and its consumer (a split shortens a
+ * layer but makes its consumer sum float32 partial-sum slabs).  This measures instead: per level the other pair choice, per
+ * unfused layer the two other tile shapes, per split layer a shallower split, each kept when the WHOLE forward pass of
+ * n_cases cases gets more than 1 % faster (a few thousand forward passes on zero images in all; the handle's buffers are
+ * re-allocated).  us_before / us_after (may be NULL): microseconds per forward pass.  Results are unchanged by the choices
+ * up to float32 summation order (bf16: rounding flips).
+ * psm_unet_ksplit: the split of convolution idx in the current plan; psm_unet_plan_info: info[4] = {tile rows, channel tiles
+ * per workgroup, split, pair role (0 none, 1 leader, 2 computed by the leader's launch)}. */
 int psm_unet_autotune(psm_unet* u, int32_t n_cases, int32_t iters, float* us_before, float* us_after);
 int psm_unet_ksplit(const psm_unet* u, int32_t idx);
+int psm_unet_plan_info(const psm_unet* u, int32_t idx, int32_t* info);
 /* Dispatch-level time of every launch of the forward pass: `steps` passes on the handle's stream, each dispatch stamped with
  * its own begin / end by hipExtLaunchKernelGGL (the timestamps rocprofv3 --kernel-trace reads; no marker packets between
  * the layers).  us [num_convs]: average duration in microseconds of the launch that STARTS at convolution i -- a fused pair

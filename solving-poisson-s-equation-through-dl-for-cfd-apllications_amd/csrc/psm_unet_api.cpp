@@ -46,6 +46,8 @@ struct psm_unet {
   std::vector<Conv> convs;
   int ny = 0, nx = 0, max_cases = 0, last_cases = 0, bf16 = 0;
   bool planned = false;
+  std::vector<int> tile_choice; // per convolution: -1 planner's tile, else 0 (8 rows x 2 channel tiles), 1 (8 x 1), 2 (2 rows x 4) -- psm_unet_autotune
+  std::vector<int> pair_choice; // per convolution (pair leaders): -1 planner's rule (tile count), 0 never pair, 1 pair whenever a kernel exists
   std::vector<int> ksplit_cap;  // per convolution: deepest split-K the planner may choose (psm_unet_autotune lowers it where a split does not pay)
   bool keep_act = false;        // fused pairs also store what they would keep on chip (introspection for the parity tests)
   float *d_in = nullptr, *d_field = nullptr, *h_in = nullptr, *h_out = nullptr;
@@ -406,7 +408,8 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
       Conv& A = u->convs[i]; Conv& B = u->convs[i + 1];
       if (A.k != 3 || B.k != 3 || B.src != 1 || A.level != B.level || B.cin != A.cout || B.cout != A.cout || (A.cout != 16 && A.cout != 32)) continue;
       const int H = ny >> A.level, W = nx >> A.level;
-      if ((long)((W + PSM_PAIR_TX - 1) / PSM_PAIR_TX) * ((H + PSM_PAIR_TY - 1) / PSM_PAIR_TY) * max_cases < pair_min) continue;
+      const int pc = i < u->pair_choice.size() ? u->pair_choice[i] : -1;
+      if (pc == 0 || (pc < 0 && (long)((W + PSM_PAIR_TX - 1) / PSM_PAIR_TX) * ((H + PSM_PAIR_TY - 1) / PSM_PAIR_TY) * max_cases < pair_min)) continue;
       A.ksplit = 1; B.ksplit = 1;
     }
     std::vector<char> obf(n, 0);
@@ -437,7 +440,8 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
       if (B.cin != cm || B.cout != cm || (cm != 16 && cm != 32) || A.ksplit != 1 || B.ksplit != 1) continue;
       if (!(B.out_bf || B.fuse_head)) continue;
       const long wgs = (long)((W + PSM_PAIR_TX - 1) / PSM_PAIR_TX) * ((H + PSM_PAIR_TY - 1) / PSM_PAIR_TY) * max_cases;
-      if (wgs < pair_min) continue;
+      const int pc = i < u->pair_choice.size() ? u->pair_choice[i] : -1;
+      if (pc == 0 || (pc < 0 && wgs < pair_min)) continue;
       // the source transform names the kind; whether a kernel exists for these channel counts (and a fused head) is the
       // launcher's own predicate
       int kind = -1, c0 = A.cin, c1 = 0;
@@ -463,6 +467,15 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
     }
     if (c.k == 3) choose_config(c, H, W, max_cases, feeds_conv3 && getenv("PSM_UNET_NO_SPLIT") == nullptr, u->bf16 ? 32 : 16,
                                 ci < u->ksplit_cap.size() ? u->ksplit_cap[ci] : 8);
+    if (c.k == 3 && ci < u->tile_choice.size() && u->tile_choice[ci] >= 0) {           // measured choice of psm_unet_autotune
+      static const int ARR[3] = {0, 0, 1}, NCT[3] = {2, 1, 4};
+      const int arr = ARR[u->tile_choice[ci]], nct = NCT[u->tile_choice[ci]];
+      if (nct <= (c.cout + 15) / 16) {
+        const int ks_keep = c.ksplit;
+        c.arrangement = arr; c.nct = nct; c.groups = ((c.cout + 15) / 16 + nct - 1) / nct;
+        c.ksplit = ks_keep;
+      }
+    }
     // diagnostic override: PSM_UNET_FORCE="layer:arrangement:nct:ksplit,..." (tools/unet_bench.py experiments)
     if (const char* f = getenv("PSM_UNET_FORCE")) {
       for (const char* q = f; q && *q; q = std::strchr(q, ',') ? std::strchr(q, ',') + 1 : nullptr) {
@@ -667,11 +680,43 @@ int psm_unet_autotune(psm_unet* u, int32_t n_cases, int32_t iters, float* us_bef
     *out = t[t.size() / 2];
     return PSM_OK;
   };
-  if (u->ksplit_cap.size() != u->convs.size()) u->ksplit_cap.assign(u->convs.size(), 8);
+  const size_t nc = u->convs.size();
+  if (u->ksplit_cap.size() != nc) u->ksplit_cap.assign(nc, 8);
+  if (u->tile_choice.size() != nc) u->tile_choice.assign(nc, -1);
+  if (u->pair_choice.size() != nc) u->pair_choice.assign(nc, -1);
   double best = 0.0;
   int rc = measure(&best);
   if (rc) return rc;
   if (us_before) *us_before = (float)best;
+  auto try_set = [&](std::vector<int>& vec, size_t i, int value) -> int {       // keep `value` if the whole pass gets > 1 % faster
+    const int old = vec[i];
+    vec[i] = value;
+    int r = psm_unet_plan(u, ny, nx, mc);
+    double t = 0.0;
+    if (!r) r = measure(&t);
+    if (r) return r;
+    if (t < best * 0.99) { best = t; return PSM_OK; }
+    vec[i] = old;
+    return psm_unet_plan(u, ny, nx, mc);
+  };
+  // 1. fused level pairs (bf16 mode): the other choice than the tile-count rule made, per level that has a pair kernel
+  for (size_t i = 0; u->bf16 && i + 1 < nc; ++i) {
+    const Conv& A = u->convs[i]; const Conv& B = u->convs[i + 1];
+    if (A.k != 3 || B.k != 3 || B.src != 1 || A.level != B.level || B.cout != A.cout || (A.cout != 16 && A.cout != 32)) continue;
+    if ((rc = try_set(u->pair_choice, i, A.pair == 1 ? 0 : 1))) return rc;
+  }
+  // 2. tile shape of the unfused 3x3 layers: the two candidates the planner did not pick
+  for (size_t i = 0; i < nc; ++i) {
+    const Conv& c = u->convs[i];
+    if (c.k != 3 || c.stem || c.pair != 0 || c.fuse_head) continue;
+    const int cur = c.arrangement == 1 ? 2 : (c.nct == 2 ? 0 : 1);
+    for (int cand = 0; cand < 3; ++cand) {
+      static const int NCT[3] = {2, 1, 4};
+      if (cand == cur || NCT[cand] > (c.cout + 15) / 16) continue;
+      if ((rc = try_set(u->tile_choice, i, cand))) return rc;
+    }
+  }
+  // 3. split-K depth
   for (size_t i = 0; i < u->convs.size(); ++i) {
     while (u->convs[i].ksplit > 1) {
       const int old_cap = u->ksplit_cap[i], cand = u->convs[i].ksplit / 2;
@@ -692,6 +737,13 @@ int psm_unet_autotune(psm_unet* u, int32_t n_cases, int32_t iters, float* us_bef
 int psm_unet_ksplit(const psm_unet* u, int32_t idx) {
   if (!u || !u->planned || idx < 0 || idx >= (int)u->convs.size()) return PSM_ERR_ARG;
   return u->convs[idx].ksplit;
+}
+
+int psm_unet_plan_info(const psm_unet* u, int32_t idx, int32_t* info) {
+  if (!u || !info || !u->planned || idx < 0 || idx >= (int)u->convs.size()) return PSM_ERR_ARG;
+  const Conv& c = u->convs[idx];
+  info[0] = psm_conv_tile_rows(c.arrangement); info[1] = c.nct; info[2] = c.ksplit; info[3] = c.pair;
+  return PSM_OK;
 }
 
 int psm_unet_debug_run_layer(psm_unet* u, int32_t idx, float* stamps_us) {

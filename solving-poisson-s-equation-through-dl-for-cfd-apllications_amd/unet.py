@@ -59,7 +59,8 @@ class UNetSurrogate:
                 b, a = C.c_float(), C.c_float()
                 self._chk(self.lib.psm_unet_autotune(self.h, self.max_cases, 20, C.byref(b), C.byref(a)))
                 self.autotuned = {"us_before": float(b.value), "us_after": float(a.value),
-                                  "ksplit": [int(self.lib.psm_unet_ksplit(self.h, i)) for i in range(n)]}
+                                  "ksplit": [int(self.lib.psm_unet_ksplit(self.h, i)) for i in range(n)],
+                                  "plan": [self.plan_info(i) for i in range(n)]}
         except Exception:
             self.close()
             raise
@@ -136,6 +137,12 @@ class UNetSurrogate:
         wg = np.zeros(len(self.shapes), np.int32)
         self._chk(self.lib.psm_unet_profile(self.h, d_grid, n_cases, d_field, _p(ms), _p(wg, C.c_int32)))
         return ms, wg
+
+    def plan_info(self, idx: int):
+        """(tile rows, channel tiles per workgroup, split-K, pair role) of convolution idx in the current plan."""
+        info = (C.c_int32 * 4)()
+        self._chk(self.lib.psm_unet_plan_info(self.h, idx, info))
+        return [int(v) for v in info]
 
     def time_kernels(self, d_grid: int, n_cases: int, d_field: int, steps: int = 20):
         """Dispatch-level timing (psm_unet_time_kernels) -> [(first conv index, convs covered, kernel name, avg us)] per launch."""
