@@ -220,6 +220,8 @@ def kernel_algorithmic(name, table, launches_per_solve):
         return table["decode"]
     if "reduce_dense1" in name:
         return table["layers"][0]
+    if "#layer" in name:                       # psm_time_kernels lists every Dense layer by itself
+        return table["layers"][int(name.rsplit("#layer", 1)[1])]
     if "dense" in name:
         # the remaining layers share this kernel: average over the layers it ran
         rest = table["layers"][1:] if launches_per_solve < nl else table["layers"]
@@ -246,7 +248,7 @@ def committed_traffic(kernel, workload):
         return None, None
     if d.get("workload") != workload or d.get("kernel_source_hash") != kernel_source_hash():
         return None, PMC_FILE + " is from other kernel sources: not used"
-    v = d.get("kernels", {}).get(kernel)
+    v = d.get("kernels", {}).get(kernel.split("#layer")[0])          # rocprofv3 names the symbol, not the layer
     return (v, PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2*FETCH + WRITE KiB, gfx950 correction)") if v else (None, None)
 
 
@@ -448,7 +450,9 @@ def pca_roofline(sur, model, ny, nx, n_cases, precision, d_grid, d_fields, steps
         roof.update(achieved=tfl, peak=peak_f, unit="TFLOP/s", frac=f_mfma)
     roof.update(traffic=traffic, traffic_source=traffic_src, algorithmic_bytes=dom["algorithmic_bytes"], algorithmic_flops=dom["algorithmic_flops"],
                 avg_launch_us=dom["avg_us"], launches=int(dom["launches_per_solve"] * steps), frac_hbm=f_hbm, frac_mfma=f_mfma,
-                selection="largest measured time per solve among all kernels of the instrumented pass; bound = the ceiling it sits closer to",
+                selection="largest measured time per solve among all launches of the instrumented pass (every Dense layer is its own "
+                          "entry: the two hidden layers run the same template instantiation, which rocprofv3 lists as one kernel "
+                          "with two calls per solve); bound = the ceiling it sits closer to",
                 whole_solve={"algorithmic_bytes": tot_b, "algorithmic_flops": af["total"],
                              "achieved_GBs": tot_b / dt_step / 1e9, "frac_hbm": tot_b / dt_step / 1e9 / HBM_PEAK_GBS,
                              "achieved_TFLOPs": af["total"] / dt_step / 1e12, "frac_mfma": af["total"] / dt_step / 1e12 / peak_f},

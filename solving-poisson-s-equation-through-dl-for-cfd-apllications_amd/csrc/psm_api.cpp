@@ -2303,6 +2303,11 @@ int psm_time_kernels(psm_handle* h, const float* d_grid, int32_t n_cases, float*
       std::string nm(r.name);                       // "(psm_x_kernel<A, B>)" -> "psm_x_kernel<A, B>": the launcher's template
       while (!nm.empty() && (nm[0] == '(' || nm[0] == ' ')) nm.erase(0, 1);     // expression, distinct per instantiation family
       while (!nm.empty() && (nm.back() == ')' || nm.back() == ' ')) nm.pop_back();
+      if (r.tag >= 0) {                             // the same instantiation serves several Dense layers: one entry per layer
+        const std::string sfx = "#layer" + std::to_string(r.tag);
+        if (nm.size() + sfx.size() > 63) nm.resize(63 - sfx.size());
+        nm += sfx;
+      }
       if (nm.size() > 63) nm.resize(63);
       if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) {
         size_t k = 0;

@@ -949,7 +949,9 @@ hipError_t psm_launch_dense(const PsmDenseArgs& a, hipStream_t st) {
       else PSM_LAUNCH((psm_dense_kernel<N, false, 32, false>), grid, blk, 0, st, a, PsmDotsArgs{});       \
     }                                                                                       \
   } while (0)
+  if (psm_launch_probe) psm_launch_probe->tag = a.layer;          // every Dense layer is its own entry of psm_time_kernels
   if (ng == 1) DENSE(1); else if (ng == 2) DENSE(2); else DENSE(4);
+  if (psm_launch_probe) psm_launch_probe->tag = -1;
 #undef DENSE
   return hipGetLastError();
 }
@@ -968,7 +970,9 @@ hipError_t psm_launch_dense_dots(const PsmDenseArgs& a, const PsmDotsArgs& d, hi
     if (r16) PSM_LAUNCH((psm_dense_kernel<N, false, 16, true>), grid, blk, 0, st, a, d);       \
     else PSM_LAUNCH((psm_dense_kernel<N, false, 32, true>), grid, blk, 0, st, a, d);           \
   } while (0)
+  if (psm_launch_probe) psm_launch_probe->tag = a.layer;
   if (ng == 1) DD(1); else if (ng == 2) DD(2); else DD(4);
+  if (psm_launch_probe) psm_launch_probe->tag = -1;
 #undef DD
   return hipGetLastError();
 }

@@ -84,7 +84,8 @@ def test_default_bench_line():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     # the roofline kernel is the one with the largest measured time of the instrumented pass
     top = max(r["kernels"], key=lambda k: k["avg_us"] * k["launches_per_solve"])
-    assert r["kernel"] == top["name"] and len(r["kernels"]) >= 4
+    assert r["kernel"] == top["name"] and len(r["kernels"]) >= 6 and all(k["launches_per_solve"] == 1 for k in r["kernels"])
+    assert sum("#layer" in k["name"] for k in r["kernels"]) == 3          # dense 2, dense 3, head (layer 1 is fused with the slab reduction)
     # the H2D / D2H-inclusive solve, and BASELINE configs[3]
     e = d["end_to_end"]
     assert d["value_end_to_end"] > 1000 and e["matches_device_resident_result"] is True

@@ -34,5 +34,5 @@ for variant, ny, nx, nc in (("gradp", 256, 256, 1), ("deltas", 256, 256, 8), ("d
         dt = (time.perf_counter() - t0) / n
         fb = d_out.cpu().numpy()
     sol = orc.solve_grid(grids[0].astype(np.float64), oracle_model(model))      # after the timing: no BLAS threads spinning under it
-    print(f"PSM_X6={os.environ.get('PSM_X6', '0')} {variant} x{nc}: x_input rel-L2 {rel(x, sol.x_input):.2e}  fields rel-L2 {rel(f[0], sol.fields):.2e} "
+    print(f"PSM_X6={os.environ.get('PSM_X6', 'default')} {variant} x{nc}: x_input rel-L2 {rel(x, sol.x_input):.2e}  fields rel-L2 {rel(f[0], sol.fields):.2e} "
           f"(bound {rel(fb[0], sol.fields):.2e})  {dt * 1e6:.1f} us per step = {nc / dt:.0f} solves/s")
