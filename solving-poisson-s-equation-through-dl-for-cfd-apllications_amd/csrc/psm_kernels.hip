@@ -2316,20 +2316,14 @@ hipError_t psm_launch_decode_paste_batch(const PsmDecodeArgs& a, const PsmBoundB
   // 512 / nwg groups, one chunk each where possible -- 8 cases x 9 blocks of a one-field model ran as 128 workgroups of 3
   // tiles (14.7 us), as 384 workgroups of one tile they take 10.6 us.  PSM_DECODE_MTC forces mtc (diagnostic).
   const int tiles = a.Mpad / 32, wpb = (128 / c_out) / 32;
+  // One 32-row tile per chunk, the row tiles spread over up to `target / nwg` row groups (grid.y): measured against two and
+  // three tiles per chunk (fewer passes over the basis slice, but 2-3x the LDS and registers per workgroup) at 8 ... 64
+  // cases and both field counts -- 16 cases: 12.5 against 20.0 us, 64 cases: 30.2 against 48.8 us, U_to_gradP 8 cases: 24.1
+  // against 36.8 us, 8 deltas cases: equal (tools/decode_mtc_sweep.py).  PSM_DECODE_MTC / PSM_DECODE_WGS: diagnostic.
   static const int mtc_force = getenv("PSM_DECODE_MTC") ? atoi(getenv("PSM_DECODE_MTC")) : 0;
-  int mtc, groups;
-  if (nwg >= 256 || mtc_force) {
-    const int it3 = (tiles + 2) / 3;
-    mtc = mtc_force ? std::min(std::max(mtc_force, 1), 3) : (tiles + it3 - 1) / it3;
-    const int iters = (tiles + mtc - 1) / mtc;
-    groups = 1;
-    while (nwg * groups < 256 && groups * 2 <= iters) groups *= 2;
-    if (mtc_force) groups = std::min(iters, std::max(1, 512 / nwg));
-  } else {
-    const int cap = std::max(1, 512 / nwg);
-    mtc = std::min(3, std::max(1, (tiles + cap - 1) / cap));
-    groups = std::min((tiles + mtc - 1) / mtc, cap);
-  }
+  static const int wg_target = getenv("PSM_DECODE_WGS") ? atoi(getenv("PSM_DECODE_WGS")) : 512;
+  const int mtc = mtc_force ? std::min(std::max(mtc_force, 1), 3) : 1;
+  const int groups = std::min((tiles + mtc - 1) / mtc, std::max(1, wg_target / nwg));
   const int R = mtc * 32;
   const bool x6 = a.x6 && !bf16;
   const size_t tile_floats = x6 ? (size_t)R * (a.ld_res + 4) * 3 / 2 : (size_t)R * (a.ld_res + 4);
