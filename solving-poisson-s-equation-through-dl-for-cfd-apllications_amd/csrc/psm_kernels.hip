@@ -321,8 +321,11 @@ __global__ __launch_bounds__(256) void psm_encode_x6_kernel(PsmEncodeArgs a) {
   const int NT = a.NT;
   const int i = lane & 31, h = lane >> 5;
   const int ql = lane < Q ? lane : Q - 1;
-  const int R = a.Mpad <= 32 ? 32 : 32 * PSM_MT_CHUNK;       // rows per plane (as the launcher sized the LDS)
+  // rows per plane (as the launcher sized the LDS).  33 ... 128 block rows run as TWO workgroups per slice (gridDim.y == 2),
+  // 64 rows each: half the LDS, so two workgroups share a CU and one's matrix phase covers the other's load latency
+  const int R = a.Mpad <= 32 ? 32 : (gridDim.y == 2 ? 64 : 32 * PSM_MT_CHUNK);
   const int PL = R * LDB;                                    // plane stride
+  const int mrow0 = gridDim.y == 2 ? 64 * (int)blockIdx.y : 0;   // first block row of this workgroup
   const float4 mu = *reinterpret_cast<const float4*>(a.mean + (int64_t)s * KS + 4 * ql);
 
   auto load_rows = [&](float4 (&x)[8], int m0, int row0) {
@@ -392,28 +395,28 @@ __global__ __launch_bounds__(256) void psm_encode_x6_kernel(PsmEncodeArgs a) {
     // up to 128 block rows: every row staged once; the first tile's rows and the basis slice are requested first, the
     // other tiles' rows land under the first tile's matrix work
     const int t = min(wave, NT - 1);
-    const int tiles = a.Mpad / 32;
+    const int tiles = min(a.Mpad - mrow0, R) / 32;           // row tiles of this workgroup (>= 1)
     float4 x0[8];
-    load_rows(x0, 0, 0);
+    load_rows(x0, mrow0, 0);
     __builtin_amdgcn_sched_barrier(0);
     float4 b[G];
     load_basis(b, t);
     __builtin_amdgcn_sched_barrier(0);
-    write_rows(x0, 0, 0, 0);
+    write_rows(x0, mrow0, 0, 0);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     float4 x1[8], x2[8], x3[8];
-    if (tiles > 1) load_rows(x1, 0, 32);
-    if (tiles > 2) load_rows(x2, 0, 64);
-    if (tiles > 3) load_rows(x3, 0, 96);
+    if (tiles > 1) load_rows(x1, mrow0, 32);
+    if (tiles > 2) load_rows(x2, mrow0, 64);
+    if (tiles > 3) load_rows(x3, mrow0, 96);
     __builtin_amdgcn_sched_barrier(0);
-    gemm_tile(b, true, 0, 0, t, wave < NT);
+    gemm_tile(b, true, 0, mrow0, t, wave < NT);
     if (tiles > 1) {
       __builtin_amdgcn_sched_barrier(0);
-      write_rows(x1, 0, 32, 32);
-      if (tiles > 2) write_rows(x2, 0, 64, 64);
-      if (tiles > 3) write_rows(x3, 0, 96, 96);
+      write_rows(x1, mrow0, 32, 32);
+      if (tiles > 2) write_rows(x2, mrow0, 64, 64);
+      if (tiles > 3) write_rows(x3, mrow0, 96, 96);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      for (int mt = 1; mt < tiles; ++mt) gemm_tile(b, false, mt * 32, mt * 32, t, wave < NT);
+      for (int mt = 1; mt < tiles; ++mt) gemm_tile(b, false, mt * 32, mrow0 + mt * 32, t, wave < NT);
     }
     return;
   }
@@ -457,8 +460,13 @@ __global__ __launch_bounds__(256) void psm_encode_x6_kernel(PsmEncodeArgs a) {
 }
 
 // x6 covers <= 128 components (NT <= 4) and an LDS footprint of three bf16 planes
-static bool psm_encode_x6_fits(const PsmEncodeArgs& a, size_t* lds) {
-  const int rows = a.Mpad <= 32 ? 32 : 32 * PSM_MT_CHUNK;
+static bool psm_encode_x6_fits(const PsmEncodeArgs& a, size_t* lds, int* row_wgs) {
+  // Negative result, kept as a knob: two workgroups per slice (64 rows each, half the LDS, two per CU so that one's matrix
+  // phase covers the other's load latency) -- 17.7 against 15.0 us at 8 cases, 21.8 against 17.6 us at 12: the launch is bound
+  // by its streams, and the split reads the basis slice twice.  PSM_ENCODE_ROWSPLIT=1 selects it.
+  static const bool row_split = getenv("PSM_ENCODE_ROWSPLIT") != nullptr;
+  *row_wgs = (a.Mpad > 64 && a.Mpad <= 32 * PSM_MT_CHUNK && row_split) ? 2 : 1;
+  const int rows = a.Mpad <= 32 ? 32 : (*row_wgs == 2 ? 64 : 32 * PSM_MT_CHUNK);
   *lds = (size_t)3 * rows * (PSM_PIX_PER_SLICE * a.c_in + 4) * 2;
   return a.NT <= 4 && *lds <= 156 * 1024 && a.Mpad % 32 == 0;
 }
@@ -468,11 +476,12 @@ hipError_t psm_launch_encode(const PsmEncodeArgs& a, hipStream_t st, hipEvent_t 
   const int rows = a.Mpad <= 32 ? 32 : 32 * PSM_MT_CHUNK;        // one tile, or 2 x 64-row buffers / a 128-row chunk
   size_t lds = (size_t)rows * (PSM_PIX_PER_SLICE * a.c_in + 4) * sizeof(float);
   size_t lds_x6 = 0;
-  if (a.x6 && psm_encode_x6_fits(a, &lds_x6)) {
+  int row_wgs = 1;
+  if (a.x6 && psm_encode_x6_fits(a, &lds_x6, &row_wgs)) {
     lds = lds_x6;
 #define ENCX2(C, AL)                                                                                          \
-  if (ev_start) hipExtLaunchKernelGGL((psm_encode_x6_kernel<C, AL>), dim3(n_slices), dim3(256), (std::uint32_t)lds, st, ev_start, ev_stop, 0, a); \
-  else PSM_LAUNCH((psm_encode_x6_kernel<C, AL>), dim3(n_slices), dim3(256), lds, st, a)
+  if (ev_start) hipExtLaunchKernelGGL((psm_encode_x6_kernel<C, AL>), dim3(n_slices, row_wgs), dim3(256), (std::uint32_t)lds, st, ev_start, ev_stop, 0, a); \
+  else PSM_LAUNCH((psm_encode_x6_kernel<C, AL>), dim3(n_slices, row_wgs), dim3(256), lds, st, a)
 #define ENCX(C) case C: if (a.aligned) { ENCX2(C, true); } else { ENCX2(C, false); } break;
     switch (a.c_in) {
       ENCX(1) ENCX(2) ENCX(3) ENCX(4)
