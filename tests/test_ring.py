@@ -186,6 +186,8 @@ def test_bench_host_and_kernel_timing_entries():
             base[b] = base.get(b, 0) + n
         assert {"psm_encode_kernel", "psm_reduce_dense1_kernel", "psm_dense_kernel", "psm_decode_paste_kernel"} <= set(base), got
         assert base["psm_encode_kernel"] == 70 and base["psm_dense_kernel"] == 3 * 70 and base["psm_decode_paste_kernel"] == 70
-        assert len([nm for nm in got if nm.startswith("psm_dense_kernel")]) == 2        # plain layers / head + strip dots
+        dense = sorted(nm for nm in got if nm.startswith("psm_dense_kernel"))
+        assert [nm.split("#")[1] for nm in dense] == ["layer1", "layer2", "layer3"]    # one entry per Dense launch; the last is head + strip dots
+        assert all(got[nm][1] == 70 for nm in dense)
         assert all(0 < t / n < 1.0 for t, n in got.values())            # every dispatch took between 0 and 1 ms
         np.testing.assert_array_equal(d_out.numpy()[None], ref[0])
