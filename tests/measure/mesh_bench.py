@@ -1,8 +1,9 @@
 """Rate of the solver boundary psm_solve (cells[N,5] float64 -> p[N] float64; PythonComm.H contract): host buffers in,
 host buffers out, synchronous like py_func -- next to the NumPy oracle's py_func on the same case."""
-import sys, time
+import os, sys, time
 import numpy as np
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import cases
 from oracle import psm_oracle as orc
 from psm_amd import SolverModule

@@ -4,7 +4,7 @@
 pressureSM_Poisson feature image (SM_call.py:588-711) and the mesh -> grid interpolation of the evaluators."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import cases
 from oracle import psm_oracle as orc

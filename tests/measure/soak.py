@@ -1,0 +1,93 @@
+"""Randomised soak of the surrogate path against the NumPy oracle (run by hand on a GPU box; tests/ holds the fixed-seed
+subset of this).  Every trial draws a variant, a grid shape, component counts, an obstacle plus solid bands, an output scale
+and a case count, and compares -- NaN pattern and values -- the general path, the geometry-bound path (closed-form chain, x6
+arithmetic, device guard) and, for several cases, the batched launch with the oracle's solve of each case.
+
+    python tests/measure/soak.py [trials] [seed]
+"""
+import os, sys, time
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+    os.environ.setdefault(_v, "16")
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import psm_amd
+from psm_amd import GridSurrogate, synthetic, _lib
+from oracle import psm_oracle as orc
+from bench import oracle_model
+
+trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2026
+rng = np.random.default_rng(seed)
+variants = ("deltas", "gradp", "chapter5")
+TOL = 1e-4
+n_run = n_bound = n_batch = n_skip = n_nan = 0
+worst = 0.0
+t0 = time.time()
+
+
+def compare(tag, got, want, info):
+    global worst, n_nan
+    got = np.asarray(got, np.float64)
+    if not np.array_equal(np.isnan(got), np.isnan(want)):
+        raise SystemExit(f"NaN pattern differs: {tag} {info}: got {int(np.isnan(got).sum())} NaN, oracle {int(np.isnan(want).sum())}")
+    ok = ~np.isnan(want)
+    n_nan += int((~ok).any())
+    if ok.any():
+        err = float(np.abs(got[ok] - want[ok]).max() / max(1e-3, np.abs(want[ok]).max()))
+        worst = max(worst, err)
+        if err > TOL:
+            raise SystemExit(f"mismatch {err:.2e} > {TOL}: {tag} {info}")
+
+
+for trial in range(trials):
+    variant = variants[int(rng.integers(3))]
+    ny, nx = int(rng.integers(128, 560)), int(rng.integers(256, 1000))
+    if rng.random() < 0.3:
+        ny, nx = 256, 256                                             # the BASELINE shape (p_i == 0: skip mode)
+    p_in, p_out = int(rng.integers(1, 140)), int(rng.integers(1, 140))
+    n_cases = int(rng.integers(1, 7)) if rng.random() < 0.35 else 1
+    model = synthetic.make_model(variant, p_in=p_in, p_out=p_out, seed_pca=int(rng.integers(1 << 20)), seed_w=int(rng.integers(1 << 20)))
+    grids = []
+    for k in range(n_cases):
+        g = synthetic.channel_grid(ny, nx, seed=int(rng.integers(1 << 30)), obstacle=("circle", "rectangle", "plate", "none")[int(rng.integers(4))],
+                                   cx=float(rng.uniform(0.15, 0.85)), cy=float(rng.uniform(0.15, 0.85)), r=float(rng.uniform(0.04, 0.2))).astype(np.float32)
+        big = rng.random() < 0.4                                       # wide solid bands empty whole overlap strips: the NaN branches
+        for _ in range(int(rng.integers(0, 3))):
+            h, w = (int(rng.integers(30, 160)), int(rng.integers(130, max(131, nx)))) if big else (int(rng.integers(4, 60)), int(rng.integers(20, 200)))
+            h, w = min(h, ny), min(w, nx)
+            y0, x0 = int(rng.integers(0, max(1, ny - h))), int(rng.integers(0, max(1, nx - w)))
+            g[y0:y0 + h, x0:x0 + w, :] = 0.0
+        grids.append(g)
+    grids = np.stack(grids)
+    sc = [float(rng.uniform(0.3, 2.0)) for _ in range(n_cases)]
+    info = dict(trial=trial, variant=variant, ny=ny, nx=nx, p_in=p_in, p_out=p_out, n_cases=n_cases)
+    try:
+        sur = GridSurrogate(model, ny, nx, max_cases=n_cases)
+    except _lib.PsmError:
+        n_skip += 1                                                    # shapes the reference itself cannot process
+        continue
+    om = oracle_model(model)
+    with sur:
+        want = [orc.solve_grid(grids[k].astype(np.float64), om).fields * sc[k] for k in range(n_cases)]
+        general = sur.solve(grids if n_cases > 1 else grids[0], out_scale=sc)
+        for k in range(n_cases):
+            compare("general", general[k], want[k], info)
+        if sur.bind_geometry(grids if n_cases > 1 else grids[0]):
+            n_bound += 1
+            bound = sur.solve(grids if n_cases > 1 else grids[0], out_scale=sc)
+            for k in range(n_cases):
+                compare("bound", bound[k], want[k], info)
+            g2 = grids.copy()                                          # the next time step: velocities change, geometry stays
+            g2[..., :model.sdf_ch] *= np.float32(0.7)
+            b2 = sur.solve(g2 if n_cases > 1 else g2[0], out_scale=sc)
+            for k in range(n_cases):
+                compare("bound, next step", b2[k], orc.solve_grid(g2[k].astype(np.float64), om).fields * sc[k], info)
+            if sur.guard_trips != 0:
+                raise SystemExit(f"guard tripped on its own geometry: {info}")
+        n_batch += n_cases > 1
+    n_run += 1
+    if trial % 20 == 19:
+        print(f"trial {trial + 1}/{trials}: {n_run} run, {n_bound} bound, {n_batch} batched, {n_skip} unsupported shapes, "
+              f"{n_nan} comparisons with NaN regions, worst rel err {worst:.2e}, {time.time() - t0:.0f} s", flush=True)
+print(f"SOAK OK: {n_run} configurations ({n_bound} bound, {n_batch} batched, {n_skip} skipped), worst rel err {worst:.2e} (tolerance {TOL}), seed {seed}")

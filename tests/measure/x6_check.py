@@ -5,7 +5,7 @@ import os, sys, time
 for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS"):        # 16-CPU quota on a 256-CPU box: keep the BLAS pool small
     os.environ.setdefault(_v, "16")
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import psm_amd
 from psm_amd import synthetic
