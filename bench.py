@@ -27,8 +27,8 @@ Extra objects on the JSON line:
                one geometry per case slot, aggregate solves/s over all ranks + one all-gather of the result shards
                (outside the timed region); roofline of its dominant kernel against the f32 matrix peak.
   legs         (N = 1) every other BASELINE config and the convolutional path with the same protocol at a smaller K:
-               configs[2], configs[4] (PCA-MLP, bf16 operands, 512x512), unet (UNet-S f32 batch 1), unet8_bf16,
-               unet512_bf16 (configs[4] as BASELINE.json words it) -- each with ms_per_step, l2_vs_oracle, roofline and,
+               configs[2], configs[4] (PCA-MLP, bf16 operands, 512x512), unet (UNet-S f32 batch 1), unet8 (f32, 8 cases per
+               step: the x6 arithmetic's regime), unet8_bf16, unet512_bf16 (configs[4] as BASELINE.json words it) -- each with ms_per_step, l2_vs_oracle, roofline and,
                for the conv legs, the NumPy U-Net as cpu_baseline.
   roofline     the kernel with the largest measured time in this run: every dispatch of K instrumented solves carries
                its own begin / end stamps (hipExtLaunchKernelGGL events, psm_time_kernels); achieved = that kernel's
@@ -99,13 +99,13 @@ WORKLOADS = {
 UNET_WORKLOADS = {           # the convolutional path (SURVEY.md section 8 row a-conv, parity unpinned) -- not the headline
     "unet": (256, 256, 1, "UNet-S (build-defined: 3x3 convs x2 per level, widths 16-32-64-128-256, max-pool, nearest "
              "upsample + skip concat, 1x1 head), 256x256x3 -> 256x256x1, batch 1, fp32, 7.0 GFLOP per solve"),
-    "unet8": (256, 256, 8, "UNet-S, 256x256x3 -> 256x256x1, 8 cases per step per GPU, fp32"),
+    "unet8": (256, 256, 8, "UNet-S, 256x256x3 -> 256x256x1, 8 cases per step per GPU, fp32 (wide layers: float32 products as six bf16 MFMA terms of exactly split operands)"),
     "unet_bf16": (256, 256, 1, "UNet-S, 256x256x3 -> 256x256x1, batch 1, bf16 operands / f32 accumulate"),
     "unet8_bf16": (256, 256, 8, "UNet-S, 256x256x3 -> 256x256x1, 8 cases per step per GPU, bf16 operands / f32 accumulate"),
     "unet512_bf16": (512, 512, 1, "UNet-S, 512x512x3 -> 512x512x1 (BASELINE configs[4] as worded: bf16 MFMA conv path), batch 1, "
                      "bf16 operands / f32 accumulate"),
 }
-DEFAULT_LEGS = ("config2", "config4", "unet", "unet8_bf16", "unet512_bf16")
+DEFAULT_LEGS = ("config2", "config4", "unet", "unet8", "unet8_bf16", "unet512_bf16")
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -491,18 +491,24 @@ def unet_leg(name, args, torch, pdist, rank, world, local_rank, backend, steps, 
         fl = sum(net.conv_flops(c) for c in convs) * NC
         # a fused launch (level pair, fused 1x1 head) reads the first convolution's input and writes the last one's output
         by = (net.conv_bytes(convs[0], ab, wbts)[0] + net.conv_bytes(convs[-1], ab, wbts)[1]) * NC + sum(net.conv_bytes(c, ab, wbts)[2] for c in convs)
+        # float32 mode: a layer planned with the x6 arithmetic issues SIX bf16 MFMA flops per algorithmic flop, so its ceiling is
+        # the bf16 matrix peak / 6 (419 TFLOP/s of float32-accurate products), not the f32 MFMA peak
+        x6 = prec == "f32" and bool(net.plan_info(first)[3] & 4)
+        pk = MFMA_BF16_PEAK_TFLOPS / 6.0 if x6 else peak
         launches.append({"convs": convs, "kernel": kname, "avg_us": us, "flops": fl, "algorithmic_bytes": by,
-                         "achieved_TFLOPs": fl / (us * 1e-6) / 1e12, "achieved_GBs": by / (us * 1e-6) / 1e9})
+                         "arithmetic": "x6 (3 bf16 planes per operand, 6 MFMA terms)" if x6 else ("bf16 MFMA" if prec == "bf16" else "f32 MFMA"),
+                         "peak_TFLOPs": pk, "achieved_TFLOPs": fl / (us * 1e-6) / 1e12, "achieved_GBs": by / (us * 1e-6) / 1e9})
     dom = max(launches, key=lambda l: l["avg_us"])
-    f_mfma, f_hbm = dom["achieved_TFLOPs"] / peak, dom["achieved_GBs"] / HBM_PEAK_GBS
+    f_mfma, f_hbm = dom["achieved_TFLOPs"] / dom["peak_TFLOPs"], dom["achieved_GBs"] / HBM_PEAK_GBS
     roof = {"kernel": f"{dom['kernel']} (convolutions {dom['convs']})", "bound": "mfma" if f_mfma > f_hbm else "hbm"}
     if roof["bound"] == "mfma":
-        roof.update(achieved=dom["achieved_TFLOPs"], peak=peak, unit="TFLOP/s", frac=f_mfma)
+        roof.update(achieved=dom["achieved_TFLOPs"], peak=dom["peak_TFLOPs"], unit="TFLOP/s", frac=f_mfma, arithmetic=dom["arithmetic"])
     else:
         roof.update(achieved=dom["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=f_hbm)
     roof.update(traffic=None, avg_launch_us=dom["avg_us"], algorithmic_flops=dom["flops"], algorithmic_bytes=dom["algorithmic_bytes"],
                 frac_mfma=f_mfma, frac_hbm=f_hbm, selection="the launch of the forward pass with the largest dispatch-stamped duration",
                 whole_pass={"algorithmic_flops": flops, "achieved_TFLOPs": achieved, "frac_mfma": achieved / peak,
+                            "frac_mfma_priced_against": f"{peak:.1f} TFLOP/s ({'bf16' if prec == 'bf16' else 'f32'} MFMA peak; x6 layers run on the bf16 pipe)",
                             "sum_of_launches_us": sum(l["avg_us"] for l in launches), "n_launches": len(launches)},
                 launches=launches)
     leg = {"workload": desc, "value": pdist.aggregate_throughput(NC, steps, world, dt_max), "unit": "solves/s", "steps": steps, "warmup": warmup,

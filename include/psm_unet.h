@@ -67,7 +67,13 @@ int psm_unet_profile(psm_unet* u, const float* d_grid, int32_t n_cases, float* d
  * re-allocated).  us_before / us_after (may be NULL): microseconds per forward pass.  Results are unchanged by the choices
  * up to float32 summation order (bf16: rounding flips).
  * psm_unet_ksplit: the split of convolution idx in the current plan; psm_unet_plan_info: info[4] = {tile rows, channel tiles
- * per workgroup, split, pair role (0 none, 1 leader, 2 computed by the leader's launch)}. */
+ * per workgroup, split, role}: role & 3 = pair role (0 none, 1 leader, 2 computed by the leader's launch), role & 4 = the layer
+ * runs the x6 form.
+ * x6 (float32 mode, default on; PSM_UNET_X6=0 switches it off): layers with at least 64 input channels and an 8-row tile run
+ * their float32 contractions on the bf16 matrix pipe -- activations and weights split EXACTLY into three bf16 planes
+ * (x = hi + mid + lo), six MFMA terms per product (hh, hm, mh, hl, lh, mm; the dropped terms are below 2^-24 of the
+ * product), float32 accumulation: float32 accuracy (same parity tests and tolerances as the float32 MFMA form) at 6 x 16
+ * cycles per 32 channels instead of 8 x 32.  psm_unet_autotune also measures the other choice per layer. */
 int psm_unet_autotune(psm_unet* u, int32_t n_cases, int32_t iters, float* us_before, float* us_after);
 int psm_unet_ksplit(const psm_unet* u, int32_t idx);
 int psm_unet_plan_info(const psm_unet* u, int32_t idx, int32_t* info);

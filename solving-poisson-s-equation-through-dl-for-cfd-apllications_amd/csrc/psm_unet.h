@@ -24,6 +24,8 @@ struct PsmConvArgs {
   // writes head_out[pixel][o] = sum_co act[co] * head_w[co][o] + head_b[o]
   const float* head_w; const float* head_b; float* head_out; int head_cout; int64_t head_case;
   int bf16;                    // operands rounded to bf16, chunks of 32 channels, wpack holds bf16x8 pieces
+  int x6;                      // float32 mode on the bf16 matrix pipe: operands split exactly into three bf16 planes, six MFMA terms per product;
+                               // chunks of 32 channels, wpack [co_group][chunk][plane 3][tap 9][ct][lane] bf16x8 (arrangement 0 only)
   // bf16 mode only: finished activations may live in HBM as bf16 (half the bytes of the bandwidth-bound shallow layers;
   // the consumer would round them to bf16 anyway, and rounding commutes with max-pool / upsample / concat).
   // in_bf: in0 and in1 are bf16 [..][c] (only with ks0 == ks1 == 1); out_bf: this layer stores bf16 (only with ksplit == 1)

@@ -273,15 +273,23 @@ __device__ __forceinline__ void store_act(float* out, int64_t elem, float v, boo
 //     the workgroups per CU to cover each other's load latency), else 2.
 //   ABF (bf16 mode, finished inputs only): the inputs are bf16 in HBM; a fetch is 8 channels = 16 bytes that go to LDS as
 //     they are (max-pool: element-wise max of the four source pixels first) -- half the fetches, no conversion.
-template <int TH, int WM, int NCT, int WN, int SRC, int KSM, bool BF, int NB, bool ABF = false>     // SRC: PSM_SRC_*, -1 = unaligned stem, 3 = upsample + skip with the seam inside a chunk
+//   X6 (float32 mode, round 3): float32 arithmetic on the bf16 matrix pipe.  Activations (on their way into LDS) and
+//     weights (on the host) are split EXACTLY into three bf16 planes x = hi + mid + lo (8 + 8 + 8 significant bits); a
+//     product runs as the six MFMA terms hh, hm, mh, hl, lh, mm (what is dropped is below 2^-24 of the product), small
+//     terms first, float32 accumulation: 6 x 16 cycles per 32 channels against 8 x 32 for v_mfma_f32_16x16x4_f32.  Chunks
+//     of 32 channels, three LDS planes per operand; the weights (27 KiB x NCT per chunk) are single-buffered.
+template <int TH, int WM, int NCT, int WN, int SRC, int KSM, bool BF, int NB, bool ABF = false, bool X6 = false>     // SRC: PSM_SRC_*, -1 = unaligned stem, 3 = upsample + skip with the seam inside a chunk
 __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_groups) {
   static_assert(!ABF || (BF && KSM == 1 && SRC >= 0 && SRC != 3), "bf16 activations: finished same / upsample / max-pool sources only");
+  static_assert(!X6 || (BF && !ABF && NB == 2 && SRC >= 0), "x6: float32 inputs, bf16 MFMA, double-buffered input planes");
+  constexpr int PL = X6 ? 3 : 1;                                    // operand planes
+  constexpr int NBW = X6 ? 1 : NB;                                  // weight buffers
   constexpr int CB = BF ? 32 : 16;                                  // input channels per chunk
   constexpr int FG = ABF ? 8 : 4;                                   // channels per fetch (16 bytes: 4 float32 or 8 bf16)
   constexpr int G4 = CB / FG;                                       // fetch groups per pixel
   constexpr int NPIX = (TH + 2) * (TW + 2);
   constexpr int NF = (NPIX * G4 + 255) / 256;                       // 4-channel input fetches per thread and chunk
-  constexpr int WQ = 9 * NCT * 64;                                  // 16-byte pieces per weight chunk
+  constexpr int WQ = PL * 9 * NCT * 64;                             // 16-byte pieces per weight chunk (x6: [plane][tap][ct][lane])
   constexpr int NWF = (WQ + 255) / 256;
   // both LDS buffers are rounded up to whole fetch rounds: every thread stores every round (the surplus lands in the
   // pad), so no store sits behind a branch -- a skipped store leaves its load "pending" for the compiler, which then
@@ -292,8 +300,8 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
   constexpr int NQ = SRCP == PSM_SRC_MAXPOOL ? 4 : 1;               // source pixels per fetch
   constexpr bool DEFER = ABF || (SRC >= 0 && SRC != 3 && NF * NQ * KSM <= 24);   // raw loads held across the MFMAs (<= 96 VGPRs)
   constexpr int NRAW = DEFER ? NQ * KSM : 1;
-  __shared__ __attribute__((aligned(16))) float in_tile[NB * TILE];
-  __shared__ __attribute__((aligned(16))) f32x4 w_tile[NB * WQP];
+  __shared__ __attribute__((aligned(16))) float in_tile[NB * PL * TILE];
+  __shared__ __attribute__((aligned(16))) f32x4 w_tile[NBW * WQP];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int zz = blockIdx.z / a.ksplit, split = blockIdx.z - zz * a.ksplit;
@@ -416,7 +424,17 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0.f;
       }
-      if constexpr (BF) {
+      if constexpr (X6) {
+        const bf16x4 h = __builtin_convertvector(v, bf16x4);                  // round to nearest even
+        const f32x4 r1 = v - __builtin_convertvector(h, f32x4);               // exact
+        const bf16x4 md = __builtin_convertvector(r1, bf16x4);
+        const f32x4 r2 = r1 - __builtin_convertvector(md, f32x4);             // exact, <= 8 significant bits
+        const bf16x4 lo = __builtin_convertvector(r2, bf16x4);
+        __bf16* dst = reinterpret_cast<__bf16*>(&in_tile[buf * PL * TILE + lds_slot(pos, c4 >> 1)]) + 4 * (c4 & 1);
+        *reinterpret_cast<bf16x4*>(dst) = h;
+        *reinterpret_cast<bf16x4*>(dst + 2 * TILE) = md;                      // plane stride TILE floats = 2 * TILE bf16
+        *reinterpret_cast<bf16x4*>(dst + 4 * TILE) = lo;
+      } else if constexpr (BF) {
         bf16x4 h;
         h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
         *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(&in_tile[buf * TILE + lds_slot(pos, c4 >> 1)]) + 4 * (c4 & 1)) = h;
@@ -442,16 +460,20 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
   auto run_chunk = [&](int g, auto more_tag) {
     constexpr bool more = decltype(more_tag)::value;
     USTAMP(2 + 4 * (g - g_beg));
-    const float* tile = &in_tile[buf * TILE];
-    const f32x4* wt = &w_tile[buf * WQP + ct_w * 64 + lane];
-    f32x4 av[2][WM], bv[2][WN];
+    const float* tile = &in_tile[buf * PL * TILE];
+    const f32x4* wt = &w_tile[(NBW == 2 ? buf : 0) * WQP + ct_w * 64 + lane];
+    f32x4 av[2][WM][PL], bv[2][WN][PL];
     auto lds_read = [&](int tap, int s) {
       const int ky = tap / 3, kx = tap - 3 * ky;
 #pragma unroll
       for (int m = 0; m < WM; ++m)
-        av[s][m] = *reinterpret_cast<const f32x4*>(&tile[lds_slot((row_w + m + ky) * (TW + 2) + px + kx, kq)]);
 #pragma unroll
-      for (int n = 0; n < WN; ++n) bv[s][n] = wt[(tap * NCT + n) * 64];
+        for (int p = 0; p < PL; ++p)
+          av[s][m][p] = *reinterpret_cast<const f32x4*>(&tile[p * TILE + lds_slot((row_w + m + ky) * (TW + 2) + px + kx, kq)]);
+#pragma unroll
+      for (int n = 0; n < WN; ++n)
+#pragma unroll
+        for (int p = 0; p < PL; ++p) bv[s][n][p] = wt[((p * 9 + tap) * NCT + n) * 64];
     };
     lds_read(0, 0);
 #pragma unroll
@@ -467,12 +489,23 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
 #endif
       __builtin_amdgcn_sched_barrier(0);
 #if !defined(PSM_EXP) || PSM_EXP < 3
-      if constexpr (BF) {
+      if constexpr (X6) {
+        // (activation plane, weight plane) pairs, small terms first: mm, lh, hl, mh, hm, hh
+        constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+        for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+          for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int n = 0; n < WN; ++n)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[s][m][PA[t6]]),
+                                                                  __builtin_bit_cast(bf16x8, bv[s][n][PB[t6]]), acc[m][n], 0, 0, 0);
+      } else if constexpr (BF) {
 #pragma unroll
         for (int m = 0; m < WM; ++m)
 #pragma unroll
           for (int n = 0; n < WN; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[s][m]), __builtin_bit_cast(bf16x8, bv[s][n]),
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[s][m][0]), __builtin_bit_cast(bf16x8, bv[s][n][0]),
                                                                 acc[m][n], 0, 0, 0);
       } else {
         // consecutive MFMAs go to different accumulators (dependent-accumulator latency 40 > issue 32 cycles)
@@ -481,7 +514,7 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
 #pragma unroll
           for (int m = 0; m < WM; ++m)
 #pragma unroll
-            for (int n = 0; n < WN; ++n) acc[m][n] = MFMA16(av[s][m][j], bv[s][n][j], acc[m][n]);
+            for (int n = 0; n < WN; ++n) acc[m][n] = MFMA16(av[s][m][0][j], bv[s][n][0][j], acc[m][n]);
       }
 #endif
       // nothing may move across: above all not the combines / LDS stores below, which wait for the loads issued above
@@ -489,7 +522,14 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
     }
     USTAMP(3 + 4 * (g - g_beg));
 #if !defined(PSM_EXP) || PSM_EXP == 3
-    if constexpr (more) { finish_x(g + 1, buf ^ 1); store_w(buf ^ 1); }
+    if constexpr (more) {
+      finish_x(g + 1, buf ^ 1);
+      if constexpr (NBW == 2) store_w(buf ^ 1);
+      else {                           // single weight buffer: every wave has read chunk g's fragments before they are replaced
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        store_w(0);
+      }
+    }
 #endif
     USTAMP(4 + 4 * (g - g_beg));
 #if !defined(PSM_EXP) || PSM_EXP != 2
@@ -641,6 +681,9 @@ static void launch_variant(const PsmConvArgs& a, dim3 grid, int groups, hipStrea
         break;                                                                                                           \
       }                                                                                                                  \
     }                                                                                                                    \
+    if constexpr (S >= 0 && NCT <= 2) {                                                                                  \
+      if (a.x6) { PSM_LAUNCH((psm_conv3x3_kernel<TH, WM, NCT, WN, S, K, true, 2, false, true>), grid, dim3(256), 0, st, a, groups); break; } \
+    }                                                                                                                    \
     if (a.bf16) { if (one && K == 1) PSM_LAUNCH((psm_conv3x3_kernel<TH, WM, NCT, WN, S, 1, true, 1>), grid, dim3(256), 0, st, a, groups);    \
                   else PSM_LAUNCH((psm_conv3x3_kernel<TH, WM, NCT, WN, S, K, true, 2>), grid, dim3(256), 0, st, a, groups); }            \
     else { if (one && K == 1) PSM_LAUNCH((psm_conv3x3_kernel<TH, WM, NCT, WN, S, 1, false, 1>), grid, dim3(256), 0, st, a, groups);          \
@@ -649,7 +692,7 @@ static void launch_variant(const PsmConvArgs& a, dim3 grid, int groups, hipStrea
   if (stem) { GO(-1, 1); return; }
   if (a.mode0 == PSM_SRC_SAME) { if (slabs) GO(PSM_SRC_SAME, 8); else GO(PSM_SRC_SAME, 1); }
   else if (a.mode0 == PSM_SRC_UPSAMPLE) {
-    const bool seam_inside = a.c1 > 0 && (a.c0 % (a.bf16 ? 32 : 16)) != 0;
+    const bool seam_inside = a.c1 > 0 && (a.c0 % ((a.bf16 || a.x6) ? 32 : 16)) != 0;
     if (seam_inside) { if (slabs) GO(3, 8); else GO(3, 1); }
     else { if (slabs) GO(PSM_SRC_UPSAMPLE, 8); else GO(PSM_SRC_UPSAMPLE, 1); }
   }

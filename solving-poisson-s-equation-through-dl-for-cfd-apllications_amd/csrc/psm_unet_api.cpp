@@ -25,6 +25,7 @@ struct Conv {
   bool stem = false;            // K = 9*c_in flattened (first layer on the raw image)
   bool fuse_head = false;       // this layer's epilogue also computes the 1x1 head
   bool in_bf = false, out_bf = false;   // bf16 mode: inputs read / output stored as bf16 (finished activations only)
+  bool x6 = false;              // float32 mode: this layer runs the x6 form (three bf16 planes per operand, chunks of 32 channels; 8-row tiles only)
   // fused level pair (psm_unet_pair.hip): 1 = first convolution of a pair (its launch computes both), 2 = second (no launch)
   int pair = 0, pair_kind = 0;
   uint4* d_wpa = nullptr;       // pair leader: conv A's fragments
@@ -48,8 +49,10 @@ struct psm_unet {
   bool planned = false;
   std::vector<int> tile_choice; // per convolution: -1 planner's tile, else 0 (8 rows x 2 channel tiles), 1 (8 x 1), 2 (2 rows x 4) -- psm_unet_autotune
   std::vector<int> pair_choice; // per convolution (pair leaders): -1 planner's rule (tile count), 0 never pair, 1 pair whenever a kernel exists
+  std::vector<int> x6_choice;   // per convolution (float32 mode): -1 planner's rule (c_in >= 64), 0 float32 MFMA, 1 x6 wherever the kernel exists
   std::vector<int> ksplit_cap;  // per convolution: deepest split-K the planner may choose (psm_unet_autotune lowers it where a split does not pay)
   bool keep_act = false;        // fused pairs also store what they would keep on chip (introspection for the parity tests)
+  bool x6 = true;               // float32 mode: 8-row-tile layers run on the bf16 matrix pipe with exactly split operands (PSM_UNET_X6=0: float32 MFMA)
   float *d_in = nullptr, *d_field = nullptr, *h_in = nullptr, *h_out = nullptr;
   hipStream_t stream = nullptr;
   std::string err;
@@ -101,6 +104,32 @@ std::vector<uint16_t> pack_conv3x3_bf16(const Conv& c) {
               if (ci < c.cin && co < c.cout)
                 p[(((((size_t)cog * chunks + g) * 9 + tap) * nct + ct) * 64 + lane) * 8 + j] =
                     f2bf(c.W[((size_t)tap * c.cin + ci) * c.cout + co]);
+            }
+  return p;
+}
+
+// x6 (float32 mode on the bf16 matrix pipe): every weight split exactly into hi + mid + lo bf16 planes;
+// wpack[cog][chunk g of 32][plane][tap][ct][lane][j < 8] = plane(W[tap][32g + 8*(lane>>4) + j][16*(cog*nct + ct) + (lane&15)])
+float bf2f(uint16_t h) { const uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; }
+std::vector<uint16_t> pack_conv3x3_x6(const Conv& c) {
+  const int chunks = c.n_chunks, nct = c.nct, groups = c.groups;
+  std::vector<uint16_t> p((size_t)groups * chunks * 3 * 9 * nct * 64 * 8, 0);
+  for (int cog = 0; cog < groups; ++cog)
+    for (int g = 0; g < chunks; ++g)
+      for (int tap = 0; tap < 9; ++tap)
+        for (int ct = 0; ct < nct; ++ct)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+              const int ci = 32 * g + 8 * (lane >> 4) + j, co = 16 * (cog * nct + ct) + (lane & 15);
+              if (ci >= c.cin || co >= c.cout) continue;
+              const float w = c.W[((size_t)tap * c.cin + ci) * c.cout + co];
+              const uint16_t h = f2bf(w);
+              const float r1 = w - bf2f(h);                     // exact
+              const uint16_t m = f2bf(r1);
+              const float r2 = r1 - bf2f(m);                    // exact
+              const uint16_t pl[3] = {h, m, f2bf(r2)};
+              for (int q = 0; q < 3; ++q)
+                p[((((((size_t)cog * chunks + g) * 3 + q) * 9 + tap) * nct + ct) * 64 + lane) * 8 + j] = pl[q];
             }
   return p;
 }
@@ -158,7 +187,7 @@ std::vector<uint16_t> pack_pair(const Conv& c, bool flat, int c0, int c1) {
 }
 
 // workgroup count first (fill 256 CUs), then the most reuse per workgroup
-void choose_config(Conv& c, int H, int W, int n_cases, bool can_split, int chunk_ch, int ks_cap = 8) {
+void choose_config(Conv& c, int H, int W, int n_cases, bool can_split, int chunk_ch, int ks_cap = 8, bool x6_ok = false) {
   const int ctiles = (c.cout + 15) / 16;
   struct Cand { int arr, nct, th; };
   const Cand cands[3] = {{0, 2, 8}, {0, 1, 8}, {1, 4, 2}};     // arrangements 2 and 3 (psm_unet.h) only by override / autotune
@@ -174,6 +203,8 @@ void choose_config(Conv& c, int H, int W, int n_cases, bool can_split, int chunk
     const long score = wgs >= fill ? 1000000 + reuse * 1000 + (k.arr ? 1 : 0) : wgs * 10 + (k.arr ? 1 : 0);
     if (score > best_score) { best_score = score; c.arrangement = k.arr; c.nct = k.nct; c.groups = groups; }
   }
+  c.x6 = x6_ok && c.arrangement == 0;                 // the x6 form exists for the 8-row tiles (psm_unet.hip)
+  if (c.x6) chunk_ch = 32;
   c.n_chunks = (c.cin + chunk_ch - 1) / chunk_ch;
   // split the input channels over workgroups until the chip is filled (partial-sum slabs, see psm_unet.h); only
   // layers whose output feeds another convolution can be split, at most 8 ways
@@ -203,6 +234,10 @@ int upload_conv(psm_unet* u, Conv& c) {
     const std::vector<float> p = pack_stem(c, u->bf16 != 0);
     UCHK(u, hipMalloc((void**)&c.d_w, p.size() * sizeof(float)));
     UCHK(u, hipMemcpy(c.d_w, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
+  } else if (c.k == 3 && c.x6) {
+    const std::vector<uint16_t> p = pack_conv3x3_x6(c);
+    UCHK(u, hipMalloc((void**)&c.d_w, p.size() * sizeof(uint16_t)));
+    UCHK(u, hipMemcpy(c.d_w, p.data(), p.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   } else if (c.k == 3 && u->bf16) {
     const std::vector<uint16_t> p = pack_conv3x3_bf16(c);
     UCHK(u, hipMalloc((void**)&c.d_w, p.size() * sizeof(uint16_t)));
@@ -270,7 +305,7 @@ int forward(psm_unet* u, const float* d_grid, int n, float* d_field, hipStream_t
     a.wpack = c.d_w; a.bias = c.d_b; a.out = out; a.n_chunks = c.n_chunks; a.H = H; a.W = W; a.cout = c.cout; a.relu = c.relu;
     a.out_case = (int64_t)H * W * c.cout;
     a.ksplit = c.ksplit; a.out_slab = c.slab; a.ks0 = 1; a.ks1 = 1; a.bf16 = u->bf16;
-    a.in_bf = c.in_bf ? 1 : 0; a.out_bf = c.out_bf ? 1 : 0;
+    a.in_bf = c.in_bf ? 1 : 0; a.out_bf = c.out_bf ? 1 : 0; a.x6 = c.x6 ? 1 : 0;
     if (c.src == 0) { a.in0 = d_grid; a.c0 = c.cin; a.mode0 = PSM_SRC_SAME; a.H0 = H; a.W0 = W; }
     else {
       const Conv& pv = u->convs[i - 1];
@@ -395,6 +430,7 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
   UCHK(u, hipSetDevice(u->device));
   UCHK(u, hipStreamSynchronize(u->stream));
   u->ny = ny; u->nx = nx; u->max_cases = max_cases;
+  u->x6 = !(getenv("PSM_UNET_X6") && atoi(getenv("PSM_UNET_X6")) == 0);
   for (int pass = 0; pass < 2; ++pass) {
   if (pass == 1) {
     // bf16 activation storage (bf16 mode): a finished activation is stored as bf16 when every consumer reads bf16, i.e. is
@@ -465,15 +501,22 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
       UCHK(u, hipMalloc((void**)&c.d_out, (size_t)c.ksplit * c.slab * sizeof(float) + 64));
       continue;
     }
+    const bool stem_layer = c.k == 3 && c.src == 0 && 9 * c.cin <= 64 && c.cout <= 16 && getenv("PSM_UNET_NO_STEM") == nullptr;
+    // x6 pays where the matrix work dominates: measured at 8 cases per step it halves the wide layers (dec3a 66 -> 43 us,
+    // enc4b 31 -> 20 us) and loses on the 16-channel 256^2 layers (enc0b 30 -> 67 us: half of every 32-channel chunk is
+    // padding and the three-plane tiles leave one workgroup per CU) -- rule: c_in >= 64; psm_unet_autotune measures the rest
+    const int x6c = ci < u->x6_choice.size() ? u->x6_choice[ci] : -1;
+    const bool x6_ok = !u->bf16 && u->x6 && c.k == 3 && !stem_layer && c.src != 0 && (x6c == 1 || (x6c < 0 && c.cin >= 64));
     if (c.k == 3) choose_config(c, H, W, max_cases, feeds_conv3 && getenv("PSM_UNET_NO_SPLIT") == nullptr, u->bf16 ? 32 : 16,
-                                ci < u->ksplit_cap.size() ? u->ksplit_cap[ci] : 8);
+                                ci < u->ksplit_cap.size() ? u->ksplit_cap[ci] : 8, x6_ok);
     if (c.k == 3 && ci < u->tile_choice.size() && u->tile_choice[ci] >= 0) {           // measured choice of psm_unet_autotune
       static const int ARR[3] = {0, 0, 1}, NCT[3] = {2, 1, 4};
       const int arr = ARR[u->tile_choice[ci]], nct = NCT[u->tile_choice[ci]];
       if (nct <= (c.cout + 15) / 16) {
-        const int ks_keep = c.ksplit;
         c.arrangement = arr; c.nct = nct; c.groups = ((c.cout + 15) / 16 + nct - 1) / nct;
-        c.ksplit = ks_keep;
+        c.x6 = x6_ok && arr == 0;
+        c.n_chunks = (c.cin + (c.x6 || u->bf16 ? 32 : 16) - 1) / (c.x6 || u->bf16 ? 32 : 16);
+        while (c.ksplit > 1 && c.ksplit > c.n_chunks) c.ksplit /= 2;
       }
     }
     // diagnostic override: PSM_UNET_FORCE="layer:arrangement:nct:ksplit,..." (tools/unet_bench.py experiments)
@@ -482,15 +525,18 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
         int li, arr, nct, ks;
         if (std::sscanf(q, "%d:%d:%d:%d", &li, &arr, &nct, &ks) == 4 && li == (int)ci && c.k == 3 && psm_conv_tile_rows(arr) &&
             nct == psm_conv_tile_nct(arr, nct) && nct <= (c.cout + 15) / 16 && ks >= 1 && ks <= 8 && (ks == 1 || feeds_conv3) && ks <= c.n_chunks) {
-          c.arrangement = arr; c.nct = nct; c.groups = ((c.cout + 15) / 16 + nct - 1) / nct; c.ksplit = ks;
+          c.arrangement = arr; c.nct = nct; c.groups = ((c.cout + 15) / 16 + nct - 1) / nct;
+          c.x6 = x6_ok && arr == 0;
+          c.n_chunks = (c.cin + (c.x6 || u->bf16 ? 32 : 16) - 1) / (c.x6 || u->bf16 ? 32 : 16);
+          c.ksplit = std::min(ks, c.n_chunks);
         }
       }
     }
     c.stem = c.k == 3 && c.src == 0 && 9 * c.cin <= 64 && c.cout <= 16 && getenv("PSM_UNET_NO_STEM") == nullptr;
-    if (c.stem) { c.ksplit = 1; c.nct = 1; c.groups = 1; c.arrangement = 0; }
+    if (c.stem) { c.ksplit = 1; c.nct = 1; c.groups = 1; c.arrangement = 0; c.x6 = false; }
     c.fuse_head = c.k == 3 && ci + 1 < u->convs.size() && u->convs[ci + 1].k == 1 && c.cout == 16 && !c.stem &&
                   getenv("PSM_UNET_NO_HEAD_FUSION") == nullptr;
-    if (c.fuse_head) { c.arrangement = 0; c.nct = 1; c.groups = 1; c.ksplit = 1; }
+    if (c.fuse_head) { c.arrangement = 0; c.nct = 1; c.groups = 1; c.ksplit = 1; c.x6 = x6_ok; c.n_chunks = (c.cin + (c.x6 || u->bf16 ? 32 : 16) - 1) / (c.x6 || u->bf16 ? 32 : 16); }
   }
   }
   free_dev(u->d_in); free_dev(u->d_field);
@@ -684,6 +730,7 @@ int psm_unet_autotune(psm_unet* u, int32_t n_cases, int32_t iters, float* us_bef
   if (u->ksplit_cap.size() != nc) u->ksplit_cap.assign(nc, 8);
   if (u->tile_choice.size() != nc) u->tile_choice.assign(nc, -1);
   if (u->pair_choice.size() != nc) u->pair_choice.assign(nc, -1);
+  if (u->x6_choice.size() != nc) u->x6_choice.assign(nc, -1);
   double best = 0.0;
   int rc = measure(&best);
   if (rc) return rc;
@@ -716,6 +763,12 @@ int psm_unet_autotune(psm_unet* u, int32_t n_cases, int32_t iters, float* us_bef
       if ((rc = try_set(u->tile_choice, i, cand))) return rc;
     }
   }
+  // 2b. float32 mode: the other arithmetic (x6 on the bf16 matrix pipe / float32 MFMA) for every layer with an 8-row tile
+  for (size_t i = 0; !u->bf16 && u->x6 && i < nc; ++i) {
+    const Conv& c = u->convs[i];
+    if (c.k != 3 || c.stem || c.src == 0 || c.arrangement != 0) continue;
+    if ((rc = try_set(u->x6_choice, i, c.x6 ? 0 : 1))) return rc;
+  }
   // 3. split-K depth
   for (size_t i = 0; i < u->convs.size(); ++i) {
     while (u->convs[i].ksplit > 1) {
@@ -742,7 +795,7 @@ int psm_unet_ksplit(const psm_unet* u, int32_t idx) {
 int psm_unet_plan_info(const psm_unet* u, int32_t idx, int32_t* info) {
   if (!u || !info || !u->planned || idx < 0 || idx >= (int)u->convs.size()) return PSM_ERR_ARG;
   const Conv& c = u->convs[idx];
-  info[0] = psm_conv_tile_rows(c.arrangement); info[1] = c.nct; info[2] = c.ksplit; info[3] = c.pair;
+  info[0] = psm_conv_tile_rows(c.arrangement); info[1] = c.nct; info[2] = c.ksplit; info[3] = c.pair | (c.x6 ? 4 : 0);
   return PSM_OK;
 }
 

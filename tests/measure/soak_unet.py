@@ -19,7 +19,7 @@ trials = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 11
 rng = np.random.default_rng(seed)
 worst = {"f32": 0.0, "bf16": 0.0}
-n_pairs = n_split = 0
+n_pairs = n_split = n_x6 = 0
 t0 = time.time()
 for trial in range(trials):
     levels = int(rng.integers(2, 6))
@@ -43,7 +43,8 @@ for trial in range(trials):
     with UNetSurrogate(W, ny, nx, c_in=c_in, c_out=c_out, widths=widths, max_cases=n, precision=prec, autotune=tune) as net:
         out = net.forward(grids)
         plan = [net.plan_info(i) for i in range(len(specs))]
-    n_pairs += any(p[3] for p in plan)
+    n_pairs += any(p[3] & 3 for p in plan)
+    n_x6 += any(p[3] & 4 for p in plan)
     n_split += any(p[2] > 1 for p in plan)
     for k in range(n):
         ref = uo.unet_forward(grids[k], W, widths, precision=prec) if prec == "bf16" else uo.unet_forward(grids[k], W, widths)
@@ -59,6 +60,6 @@ for trial in range(trials):
             raise SystemExit(f"mismatch {err:.2e} > {tol}: {info} case {k} plan {plan}")
     if trial % 10 == 9:
         print(f"trial {trial + 1}/{trials}: worst f32 max-abs/max {worst['f32']:.2e}, worst bf16 rel-L2 {worst['bf16']:.2e}, "
-              f"{n_pairs} with fused pairs, {n_split} with split-K, {time.time() - t0:.0f} s", flush=True)
+              f"{n_pairs} with fused pairs, {n_split} with split-K, {n_x6} with x6 layers, {time.time() - t0:.0f} s", flush=True)
 print(f"SOAK OK: {trials} networks, worst f32 {worst['f32']:.2e} (tol 1e-4), worst bf16 rel-L2 {worst['bf16']:.2e} (tol 2e-2), "
-      f"{n_pairs} with fused pairs, {n_split} with split-K, seed {seed}")
+      f"{n_pairs} with fused pairs, {n_split} with split-K, {n_x6} with x6 layers, seed {seed}")

@@ -97,7 +97,7 @@ def test_default_bench_line():
     assert d["value_device_resident"] == d["value"] and len(d["devices"]) == 1 and d["config"]["guard_trips"] == 0
     assert e["hw_queues"]["hip_initialised_before_it_was_set"] is False
     legs = d["legs"]
-    assert set(legs) == {"config2", "config4", "unet", "unet8_bf16", "unet512_bf16"}
+    assert set(legs) == {"config2", "config4", "unet", "unet8", "unet8_bf16", "unet512_bf16"}
     for name, leg in legs.items():
         assert leg["ms_per_step"] > 0 and leg["value"] > 100 and leg["l2_vs_oracle"] < (2e-2 if leg["dtype"] == "bf16" else 1e-5), name
         assert ROOF <= set(leg["roofline"]) and 0 < leg["roofline"]["frac"] < 1, name

@@ -340,3 +340,31 @@ def test_gpu_unet_autotuned_plan_keeps_the_result(precision, ny, nx, n):
     assert np.linalg.norm(tuned - plain) / np.linalg.norm(plain) <= tol
     ref = uo.unet_forward(grids[0], W, precision=precision)
     assert np.linalg.norm(tuned[0] - ref) / np.linalg.norm(ref) <= (1e-2 if precision == "bf16" else 1e-5)
+
+
+@pytest.mark.gpu
+def test_gpu_unet_x6_layers_keep_float32_accuracy(monkeypatch):
+    """float32 mode: layers with at least 64 input channels and an 8-row tile run their contractions on the bf16 matrix pipe
+    with operands split exactly into three bf16 planes (six MFMA terms per product).  Same oracle, same float32 tolerances,
+    layer by layer; PSM_UNET_X6=0 plans no such layer and gives the same field up to float32 summation order."""
+    from psm_amd import UNetSurrogate
+    specs = uo.unet_specs()
+    W = uo.he_weights(specs, seed=13)
+    ny, nx, n = 256, 256, 4                     # enough workgroups for 8-row tiles on the 64^2 level and the wide decoder layers
+    grids = np.stack([synthetic.channel_grid(ny, nx, seed=40 + k, noise=0.05).astype(np.float32) for k in range(n)])
+    with UNetSurrogate(W, ny, nx, max_cases=n) as net:
+        roles = [net.plan_info(i)[3] for i in range(len(specs))]
+        x6 = [i for i, r in enumerate(roles) if r & 4]
+        assert len(x6) >= 4 and all(specs[i].c_in >= 64 and net.plan_info(i)[0] == 8 for i in x6), roles
+        out = net.forward(grids)
+        for k in (0, n - 1):
+            ref, acts = uo.unet_forward(grids[k], W, return_all=True)
+            for i in range(len(specs) - 1):
+                a = net.activation(i, n)[k]
+                assert np.abs(a - acts[i]).max() <= 2e-5 * max(np.abs(acts[i]).max(), 1e-6), (specs[i].name, i in x6)
+            assert np.abs(out[k] - ref).max() <= 1e-4 * np.abs(ref).max()
+    monkeypatch.setenv("PSM_UNET_X6", "0")
+    with UNetSurrogate(W, ny, nx, max_cases=n) as net:
+        assert not any(net.plan_info(i)[3] & 4 for i in range(len(specs)))
+        plain = net.forward(grids)
+    assert np.linalg.norm(out - plain) / np.linalg.norm(plain) <= 1e-5

@@ -1,0 +1,8 @@
+#!/bin/bash
+# usage: tools/conv_f32.sh -- the float32 conv workloads of bench.py (autotuned plan), one line each
+for wl in unet unet8; do
+  python bench.py --workload $wl --steps 300 --warmup 30 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('$wl', round(d['ms_per_step']*1e3,1), 'us', 'l2', d.get('l2_vs_oracle'), d['config'].get('planner') or '', [round(l['avg_us'],1) for l in d['roofline']['launches']])"
+done
