@@ -73,7 +73,9 @@ int psm_unet_profile(psm_unet* u, const float* d_grid, int32_t n_cases, float* d
  * their float32 contractions on the bf16 matrix pipe -- activations and weights split EXACTLY into three bf16 planes
  * (x = hi + mid + lo), six MFMA terms per product (hh, hm, mh, hl, lh, mm; the dropped terms are below 2^-24 of the
  * product), float32 accumulation: float32 accuracy (same parity tests and tolerances as the float32 MFMA form) at 6 x 16
- * cycles per 32 channels instead of 8 x 32.  psm_unet_autotune also measures the other choice per layer. */
+ * cycles per 32 channels instead of 8 x 32.  psm_unet_autotune also measures the other choice per layer.  Finite values only:
+ * an infinite activation or weight splits into (inf, NaN, NaN), so where the float32 MFMA would return +-inf an x6 layer
+ * returns NaN (NaN stays NaN); magnitudes below 2^-110 lose the low planes to underflow. */
 int psm_unet_autotune(psm_unet* u, int32_t n_cases, int32_t iters, float* us_before, float* us_after);
 int psm_unet_ksplit(const psm_unet* u, int32_t idx);
 int psm_unet_plan_info(const psm_unet* u, int32_t idx, int32_t* info);
