@@ -19,6 +19,9 @@
 #include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef PSM_CONV_PD
+#define PSM_CONV_PD 1
+#endif
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 // activation stores: -DPSM_NT_ACT streams them past the L2 (the consumer is the next launch, on any XCD)
 #ifdef PSM_NT_ACT
@@ -462,7 +465,11 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
     USTAMP(2 + 4 * (g - g_beg));
     const float* tile = &in_tile[buf * PL * TILE];
     const f32x4* wt = &w_tile[(NBW == 2 ? buf : 0) * WQP + ct_w * 64 + lane];
-    f32x4 av[2][WM][PL], bv[2][WN][PL];
+    // operand prefetch depth in taps (-DPSM_CONV_PD=n, bf16 form).  Measured with 3 instead of 1: nothing (8 cases bf16 158.4 vs
+    // 157.5 us, dec3a 14.6 vs 14.5): a bf16 chunk's matrix phase (0.57 us for 36 MFMAs = 0.24 us of issue) is bound by the
+    // THROUGHPUT of its 36 ds_read_b128 per wave (four waves: 0.48 us), not by their latency
+    constexpr int PD = (BF && !X6) ? PSM_CONV_PD : 1, NS = PD + 1;
+    f32x4 av[NS][WM][PL], bv[NS][WN][PL];
     auto lds_read = [&](int tap, int s) {
       const int ky = tap / 3, kx = tap - 3 * ky;
 #pragma unroll
@@ -475,11 +482,12 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
 #pragma unroll
         for (int p = 0; p < PL; ++p) bv[s][n][p] = wt[((p * 9 + tap) * NCT + n) * 64];
     };
-    lds_read(0, 0);
+#pragma unroll
+    for (int t0 = 0; t0 < PD; ++t0) lds_read(t0, t0);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int s = tap & 1;
-      if (tap < 8) lds_read(tap + 1, s ^ 1);           // next tap's operands are on their way during this tap's MFMAs
+      const int s = tap % NS;
+      if (tap + PD < 9) lds_read(tap + PD, (tap + PD) % NS);      // operands of the tap PD ahead are on their way during this tap's MFMAs
 #if !defined(PSM_EXP) || PSM_EXP == 3
       if constexpr (more) {                            // this tap's share of the next chunk's requests
 #pragma unroll
