@@ -392,6 +392,14 @@ int psm_debug_reassemble_host(int32_t variant, int32_t ny, int32_t nx, int32_t b
                               int32_t strict_degenerate, int32_t c_in, int32_t c_out, int32_t sdf_channel,
                               const float* grid, const float* pred, float* fields, float* offsets,
                               float* shifts);
+/* Diagnostic: with PSM_GUARD_PAGES=1 in the environment (read once, at the first allocation) every device buffer of the
+ * library is placed at the end of its own mapping with an unmapped granule behind it, so that a kernel running past the end
+ * of a buffer takes a GPU page fault instead of touching a neighbour (the GPU address sanitizer's stand-in for that class;
+ * csrc/psm_alloc.cpp).  psm_debug_guard_pages: 1 when the mode is on; psm_debug_malloc / psm_debug_free: the same allocator
+ * for a caller's own test buffers (hipError_t values). */
+int psm_debug_guard_pages(void);
+int psm_debug_malloc(void** ptr, size_t bytes);
+int psm_debug_free(void* ptr);
 int psm_abi_version(void);
 
 #ifdef __cplusplus

@@ -106,6 +106,9 @@ SIGNATURES = {
     "psm_layout": (C.c_int, [C.c_int32] * 5 + [_i32p, C.c_int32, _i32p, _i32p]),
     "psm_owner_map": (C.c_int, [C.c_int32] * 6 + [_i32p]),
     "psm_debug_reassemble_host": (C.c_int, [C.c_int32] * 9 + [_f32p, _f32p, _f32p, _f32p, _f32p]),
+    "psm_debug_guard_pages": (C.c_int, []),
+    "psm_debug_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "psm_debug_free": (C.c_int, [C.c_void_p]),
     "psm_abi_version": (C.c_int, []),
 }
 

@@ -1,0 +1,89 @@
+// psm_alloc.cpp -- see psm_alloc.h
+#include "psm_alloc.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <unordered_map>
+
+namespace {
+struct Guarded { void* va; size_t reserved, mapped; hipMemGenericAllocationHandle_t handle; };
+std::mutex g_mu;
+std::unordered_map<void*, Guarded> g_live;
+
+bool guard_mode() {
+  static const bool on = [] { const char* e = getenv("PSM_GUARD_PAGES"); return e && e[0] == '1'; }();
+  return on;
+}
+}  // namespace
+
+hipError_t psm_dev_malloc(void** p, size_t bytes) {
+  if (!guard_mode()) return hipMalloc(p, bytes);
+  *p = nullptr;
+  if (bytes == 0) bytes = 1;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = dev;
+  size_t gran = 0;
+  if ((e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum)) != hipSuccess) return e;
+  if (gran == 0) return hipErrorInvalidValue;
+  Guarded g{};
+  g.mapped = (bytes + gran - 1) / gran * gran;
+  g.reserved = g.mapped + gran;                                   // one granule of reserved, never mapped, address space behind it
+  if ((e = hipMemAddressReserve(&g.va, g.reserved, gran, nullptr, 0)) != hipSuccess) return e;
+  if ((e = hipMemCreate(&g.handle, g.mapped, &prop, 0)) != hipSuccess) { (void)hipMemAddressFree(g.va, g.reserved); return e; }
+  if ((e = hipMemMap(g.va, g.mapped, 0, g.handle, 0)) != hipSuccess) {
+    (void)hipMemRelease(g.handle); (void)hipMemAddressFree(g.va, g.reserved); return e;
+  }
+  hipMemAccessDesc acc = {};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  if ((e = hipMemSetAccess(g.va, g.mapped, &acc, 1)) != hipSuccess) {
+    (void)hipMemUnmap(g.va, g.mapped); (void)hipMemRelease(g.handle); (void)hipMemAddressFree(g.va, g.reserved); return e;
+  }
+  // PSM_GUARD_FILL=<byte>: fill the whole mapping (memory from hipMemCreate is not cleared) -- 0 mimics the fresh pages hipMalloc
+  // usually hands out, 255 poisons: floats read as NaN, indices as -1, so a kernel that depends on what it never wrote shows
+  if (const char* f = getenv("PSM_GUARD_FILL")) {
+    if ((e = hipMemset(g.va, atoi(f) & 255, g.mapped)) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) {
+      (void)hipMemUnmap(g.va, g.mapped); (void)hipMemRelease(g.handle); (void)hipMemAddressFree(g.va, g.reserved); return e;
+    }
+  }
+  const size_t used = (bytes + 15) / 16 * 16;
+  *p = (char*)g.va + (g.mapped - used);                           // the buffer ends where the mapping ends
+  if (getenv("PSM_GUARD_LOG")) fprintf(stderr, "psm_alloc: + %p %zu B (va %p, mapped %zu)\n", *p, bytes, g.va, g.mapped);
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_live[*p] = g;
+  return hipSuccess;
+}
+
+hipError_t psm_dev_free(void* p) {
+  if (!p) return hipSuccess;
+  if (!guard_mode()) return hipFree(p);
+  Guarded g;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_live.find(p);
+    if (it == g_live.end()) {                                     // not a live buffer of this allocator: a double free or a foreign pointer
+      fprintf(stderr, "psm_alloc: free of %p, which is not a live guarded buffer (double free?)\n", p);
+      return hipErrorInvalidValue;
+    }
+    g = it->second;
+    g_live.erase(it);
+  }
+  if (getenv("PSM_GUARD_LOG")) fprintf(stderr, "psm_alloc: - %p (va %p, mapped %zu)\n", p, g.va, g.mapped);
+  hipError_t e = hipDeviceSynchronize();                          // hipFree's implicit synchronisation
+  (void)hipMemUnmap(g.va, g.mapped);
+  (void)hipMemRelease(g.handle);
+  // The address range stays reserved for the life of the process: (i) a use after free then faults as well, (ii) on ROCm 7.2 a
+  // range handed out again right after hipMemAddressFree was seen to alias the physical pages of a LATER allocation (the
+  // bound-pattern table read back another buffer's contents) -- address space is plentiful, a diagnostic run is short.
+  return e;
+}
+
+extern "C" int psm_debug_guard_pages(void) { return guard_mode() ? 1 : 0; }
+extern "C" int psm_debug_malloc(void** p, size_t bytes) { return p ? (int)psm_dev_malloc(p, bytes) : (int)hipErrorInvalidValue; }
+extern "C" int psm_debug_free(void* p) { return (int)psm_dev_free(p); }

@@ -4,6 +4,8 @@
 // usable device psm_create fails with PSM_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include "psm_alloc.h"
+
 #include <sched.h>
 
 #include <algorithm>
@@ -265,9 +267,9 @@ int fail(psm_handle* h, int code, const std::string& msg) {
 
 template <typename T>
 int dev_alloc(psm_handle* h, T** p, size_t n) {
-  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (*p) { (void)psm_dev_free(*p); *p = nullptr; }
   if (n == 0) n = 1;
-  hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+  hipError_t e = psm_dev_malloc((void**)p, n * sizeof(T));
   if (e != hipSuccess) return fail(h, PSM_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
   return PSM_OK;
 }
@@ -281,14 +283,14 @@ int dev_upload(psm_handle* h, T** p, const std::vector<T>& v) {
 }
 
 template <typename T>
-void dev_free(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
+void dev_free(T*& p) { if (p) { (void)psm_dev_free(p); p = nullptr; } }
 
 int scratch_reserve(psm_handle* h, size_t dev_bytes, size_t pin_bytes) {
   if (dev_bytes > h->scr_dev_cap) {
-    if (h->scr_dev) { (void)hipStreamSynchronize(h->stream); (void)hipFree(h->scr_dev); h->scr_dev = nullptr; h->scr_dev_cap = 0; }
+    if (h->scr_dev) { (void)hipStreamSynchronize(h->stream); (void)psm_dev_free(h->scr_dev); h->scr_dev = nullptr; h->scr_dev_cap = 0; }
     const size_t cap = dev_bytes + dev_bytes / 2;
-    hipError_t e = hipMalloc(&h->scr_dev, cap);
-    if (e != hipSuccess) return fail(h, PSM_ERR_NOMEM, std::string("hipMalloc(scratch): ") + hipGetErrorString(e));
+    hipError_t e = psm_dev_malloc(&h->scr_dev, cap);
+    if (e != hipSuccess) return fail(h, PSM_ERR_NOMEM, std::string("psm_dev_malloc(scratch): ") + hipGetErrorString(e));
     h->scr_dev_cap = cap;
   }
   if (pin_bytes > h->scr_pin_cap) {
@@ -367,8 +369,8 @@ void free_plan(psm_handle* h) {
     if (s.h_in) (void)hipHostFree(s.h_in);
     if (s.h_out) (void)hipHostFree(s.h_out);
     if (s.h_rs) (void)hipHostFree(s.h_rs);
-    if (s.d_in) (void)hipFree(s.d_in);
-    if (s.d_out) (void)hipFree(s.d_out);
+    if (s.d_in) (void)psm_dev_free(s.d_in);
+    if (s.d_out) (void)psm_dev_free(s.d_out);
     if (s.ev_out) (void)hipEventDestroy(s.ev_out);
     ws_free(s.ws);
     const int gidx = s.ws.gidx;
@@ -863,7 +865,7 @@ int psm_create(const psm_config* cfg, psm_handle** out) {
     } else { (void)hipGetLastError(); h->h_guard = nullptr; }
     h->ws0.gidx = 0;
     for (int i = 0; i < psm_handle::SLOTS; ++i) h->slot[i].ws.gidx = 1 + i;
-    if (hipMalloc((void**)&h->d_gzero, sizeof(float)) != hipSuccess || hipMemset(h->d_gzero, 0, sizeof(float)) != hipSuccess) {
+    if (psm_dev_malloc((void**)&h->d_gzero, sizeof(float)) != hipSuccess || hipMemset(h->d_gzero, 0, sizeof(float)) != hipSuccess) {
       psm_destroy(h);
       return fail(nullptr, PSM_ERR_NOMEM, "hipMalloc failed");
     }
@@ -879,9 +881,9 @@ void psm_destroy(psm_handle* h) {
   (void)hipDeviceSynchronize();
   free_plan(h);
   free_geometry(h);
-  for (auto& d : h->dense) { dev_free(d.W); dev_free(d.b); if (d.Wp) { (void)hipFree(d.Wp); d.Wp = nullptr; } }
+  for (auto& d : h->dense) { dev_free(d.W); dev_free(d.b); if (d.Wp) { (void)psm_dev_free(d.Wp); d.Wp = nullptr; } }
   dev_free(h->d_mean_in); dev_free(h->d_mean_out); dev_free(h->d_bpack_in); dev_free(h->d_bpack_out);
-  if (h->scr_dev) (void)hipFree(h->scr_dev);
+  if (h->scr_dev) (void)psm_dev_free(h->scr_dev);
   if (h->scr_pin) (void)hipHostFree(h->scr_pin);
   dev_free(h->d_comp_nat); dev_free(h->d_g2); dev_free(h->d_c2); dev_free(h->d_cnt); dev_free(h->d_row_of); dev_free(h->d_ownbits);
   dev_free(h->d_ia); dev_free(h->d_ib); dev_free(h->d_sa); dev_free(h->d_sb);
@@ -975,7 +977,7 @@ int psm_set_dense(psm_handle* h, int32_t layer, int32_t n_in, int32_t n_out, con
           const int k = 16 * kg + 4 * (lane >> 4) + j, n = 16 * nt + (lane & 15);
           if (k < n_in && n < n_out) Wp[(((size_t)nt * groups + kg) * 64 + lane) * 4 + j] = kernel[(size_t)k * n_out + n];
         }
-  if (d.Wp) { (void)hipFree(d.Wp); d.Wp = nullptr; }
+  if (d.Wp) { (void)psm_dev_free(d.Wp); d.Wp = nullptr; }
   if (h->cfg.precision == PSM_PRECISION_BF16) {
     std::vector<uint16_t> Wb(W.size()), Wpb(Wp.size());
     for (size_t q = 0; q < W.size(); ++q) Wb[q] = f2bf(W[q]);

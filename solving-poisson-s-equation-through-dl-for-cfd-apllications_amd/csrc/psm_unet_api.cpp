@@ -10,6 +10,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "psm_alloc.h"
+
 #include "../../include/psm.h"
 #include "../../include/psm_unet.h"
 #include "psm_unet.h"
@@ -63,7 +65,7 @@ int fail(psm_unet* u, int code, const std::string& m) { if (u) u->err = m; else 
 #define UCHK(u, expr)                                                                                   \
   do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail((u), PSM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 
-void free_dev(void* p) { if (p) (void)hipFree(p); }
+void free_dev(void* p) { if (p) (void)psm_dev_free(p); }
 
 // MFMA operand order: wpack[cog][chunk g][tap][ct][lane][j] = W[tap][16g + 4*(lane>>4) + j][16*(cog*nct + ct) + (lane&15)]
 std::vector<float> pack_conv3x3(const Conv& c) {
@@ -228,26 +230,26 @@ int upload_conv(psm_unet* u, Conv& c) {
   free_dev(c.d_wpa); c.d_wpa = nullptr; free_dev(c.d_wpb); c.d_wpb = nullptr;
   std::vector<float> bias((size_t)((c.cout + 15) / 16 + 4) * 16, 0.f);
   std::memcpy(bias.data(), c.b.data(), c.cout * sizeof(float));
-  UCHK(u, hipMalloc((void**)&c.d_b, bias.size() * sizeof(float)));
+  UCHK(u, psm_dev_malloc((void**)&c.d_b, bias.size() * sizeof(float)));
   UCHK(u, hipMemcpy(c.d_b, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
   if (c.k == 3 && c.stem) {
     const std::vector<float> p = pack_stem(c, u->bf16 != 0);
-    UCHK(u, hipMalloc((void**)&c.d_w, p.size() * sizeof(float)));
+    UCHK(u, psm_dev_malloc((void**)&c.d_w, p.size() * sizeof(float)));
     UCHK(u, hipMemcpy(c.d_w, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
   } else if (c.k == 3 && c.x6) {
     const std::vector<uint16_t> p = pack_conv3x3_x6(c);
-    UCHK(u, hipMalloc((void**)&c.d_w, p.size() * sizeof(uint16_t)));
+    UCHK(u, psm_dev_malloc((void**)&c.d_w, p.size() * sizeof(uint16_t)));
     UCHK(u, hipMemcpy(c.d_w, p.data(), p.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   } else if (c.k == 3 && u->bf16) {
     const std::vector<uint16_t> p = pack_conv3x3_bf16(c);
-    UCHK(u, hipMalloc((void**)&c.d_w, p.size() * sizeof(uint16_t)));
+    UCHK(u, psm_dev_malloc((void**)&c.d_w, p.size() * sizeof(uint16_t)));
     UCHK(u, hipMemcpy(c.d_w, p.data(), p.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   } else if (c.k == 3) {
     const std::vector<float> p = pack_conv3x3(c);
-    UCHK(u, hipMalloc((void**)&c.d_w, p.size() * sizeof(float)));
+    UCHK(u, psm_dev_malloc((void**)&c.d_w, p.size() * sizeof(float)));
     UCHK(u, hipMemcpy(c.d_w, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
   } else {
-    UCHK(u, hipMalloc((void**)&c.d_w1, c.W.size() * sizeof(float)));
+    UCHK(u, psm_dev_malloc((void**)&c.d_w1, c.W.size() * sizeof(float)));
     UCHK(u, hipMemcpy(c.d_w1, c.W.data(), c.W.size() * sizeof(float), hipMemcpyHostToDevice));
   }
   if (c.pair == 1) {
@@ -256,9 +258,9 @@ int upload_conv(psm_unet* u, Conv& c) {
     int c0 = c.cin, c1 = 0;
     if (c.pair_kind == PSM_PAIR_UPCAT) { c0 = u->convs[ci - 1].cout; c1 = u->convs[c.skip].cout; }
     const std::vector<uint16_t> pa = pack_pair(c, c.pair_kind == PSM_PAIR_STEM, c0, c1), pb = pack_pair(B, false, B.cin, 0);
-    UCHK(u, hipMalloc((void**)&c.d_wpa, pa.size() * sizeof(uint16_t)));
+    UCHK(u, psm_dev_malloc((void**)&c.d_wpa, pa.size() * sizeof(uint16_t)));
     UCHK(u, hipMemcpy(c.d_wpa, pa.data(), pa.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    UCHK(u, hipMalloc((void**)&c.d_wpb, pb.size() * sizeof(uint16_t)));
+    UCHK(u, psm_dev_malloc((void**)&c.d_wpb, pb.size() * sizeof(uint16_t)));
     UCHK(u, hipMemcpy(c.d_wpb, pb.data(), pb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   }
   return PSM_OK;
@@ -498,7 +500,7 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
       if (rc) return rc;
       free_dev(c.d_out); c.d_out = nullptr;
       c.slab = (int64_t)max_cases * H * W * c.cout;
-      UCHK(u, hipMalloc((void**)&c.d_out, (size_t)c.ksplit * c.slab * sizeof(float) + 64));
+      UCHK(u, psm_dev_malloc((void**)&c.d_out, (size_t)c.ksplit * c.slab * sizeof(float) + 64));
       continue;
     }
     const bool stem_layer = c.k == 3 && c.src == 0 && 9 * c.cin <= 64 && c.cout <= 16 && getenv("PSM_UNET_NO_STEM") == nullptr;
@@ -543,8 +545,8 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
   if (u->h_in) { (void)hipHostFree(u->h_in); u->h_in = nullptr; }
   if (u->h_out) { (void)hipHostFree(u->h_out); u->h_out = nullptr; }
   const size_t npix = (size_t)ny * nx * max_cases;
-  UCHK(u, hipMalloc((void**)&u->d_in, npix * u->c_in * sizeof(float)));
-  UCHK(u, hipMalloc((void**)&u->d_field, npix * u->c_out * sizeof(float)));
+  UCHK(u, psm_dev_malloc((void**)&u->d_in, npix * u->c_in * sizeof(float)));
+  UCHK(u, psm_dev_malloc((void**)&u->d_field, npix * u->c_out * sizeof(float)));
   UCHK(u, hipHostMalloc((void**)&u->h_in, npix * u->c_in * sizeof(float), hipHostMallocDefault));
   UCHK(u, hipHostMalloc((void**)&u->h_out, npix * u->c_out * sizeof(float), hipHostMallocDefault));
   u->planned = true;

@@ -1,6 +1,9 @@
 """Minimal HIP runtime access through ctypes for the GPU tests (device buffers without importing
-torch, whose first import on a fresh box can take minutes)."""
+torch, whose first import on a fresh box can take minutes).  With PSM_GUARD_PAGES=1 in the environment the buffers come
+from the library's guard-page allocator (csrc/psm_alloc.cpp): a kernel that runs past the end of a test's input or
+output buffer faults instead of touching a neighbour."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -26,7 +29,14 @@ class DeviceArray:
         self.shape, self.dtype = tuple(shape), np.dtype(dtype)
         self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
         p = C.c_void_p()
-        assert hip().hipMalloc(C.byref(p), self.nbytes) == 0
+        self._guarded = os.environ.get("PSM_GUARD_PAGES") == "1"
+        if self._guarded:
+            from psm_amd import _lib
+            lib = _lib.load()
+            assert lib.psm_debug_guard_pages() == 1 and lib.psm_debug_malloc(C.byref(p), self.nbytes) == 0
+            self._lib = lib
+        else:
+            assert hip().hipMalloc(C.byref(p), self.nbytes) == 0
         self.ptr = p.value
         if host is not None:
             assert hip().hipMemcpy(self.ptr, host.ctypes.data, self.nbytes, 1) == 0      # H2D
@@ -39,7 +49,10 @@ class DeviceArray:
 
     def free(self):
         if self.ptr:
-            hip().hipFree(self.ptr)
+            if self._guarded:
+                self._lib.psm_debug_free(self.ptr)
+            else:
+                hip().hipFree(self.ptr)
             self.ptr = None
 
     def __del__(self):

@@ -2,6 +2,7 @@
 handle for another grid size, destroying a handle with tickets still in flight, and two handles interleaved on the
 same device (what a host that owns several independent cases does)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -23,6 +24,7 @@ def _free_bytes():
     return free.value
 
 
+@pytest.mark.skipif(os.environ.get("PSM_GUARD_PAGES") == "1", reason="guard-page allocator: freed ranges stay reserved and every buffer takes whole granules")
 def test_no_device_memory_leak_over_handle_cycles():
     model = synthetic.make_model("deltas", p_in=16, p_out=16)
     grid = synthetic.channel_grid(256, 256, seed=1).astype(np.float32)
@@ -85,3 +87,43 @@ def test_calls_in_the_wrong_order_are_reported():
         assert lib.psm_bind_geometry(None, g.ctypes.data_as(C.c_void_p), 0) == -1
     finally:
         lib.psm_destroy(h)
+
+
+@pytest.mark.gpu
+def test_guard_page_allocator_places_buffers_at_the_end_of_their_mapping():
+    """PSM_GUARD_PAGES=1 (diagnostic, csrc/psm_alloc.cpp): every buffer ends where its mapping ends (16-byte granularity) with
+    an unmapped granule behind it, data round-trips through it, and a whole bound solve runs on guarded buffers.  Run in a
+    child process: the mode is read once per process."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import ctypes as C, sys, os
+        import numpy as np
+        sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+        from psm_amd import _lib, GridSurrogate, synthetic
+        from hipmem import DeviceArray, hip
+        lib = _lib.load()
+        assert lib.psm_debug_guard_pages() == 1
+        for n in (1, 100, 4096, (1 << 20) + 4):
+            p = C.c_void_p()
+            assert lib.psm_debug_malloc(C.byref(p), n) == 0
+            assert (p.value + (n + 15) // 16 * 16) % 4096 == 0, (n, hex(p.value))
+            src = (np.arange(n) % 251).astype(np.uint8); dst = np.zeros(n, np.uint8)
+            assert hip().hipMemcpy(p.value, src.ctypes.data, n, 1) == 0 and hip().hipMemcpy(dst.ctypes.data, p.value, n, 2) == 0
+            assert np.array_equal(src, dst)
+            assert lib.psm_debug_free(p.value) == 0
+        model = synthetic.make_model("gradp", p_in=16, p_out=16)
+        g = synthetic.channel_grid(256, 256, seed=2).astype(np.float32)
+        with GridSurrogate(model, 256, 256) as sur:
+            a = sur.solve(g)
+            assert sur.bind_geometry(g)
+            b = sur.solve(g)
+            d_in, d_out = DeviceArray(g), DeviceArray(shape=(256, 256, 2))
+            sur.solve_device(d_in.ptr, 1, d_out.ptr)
+            c = d_out.numpy()
+        assert np.abs(a - b).max() <= 5e-5 * np.abs(a).max() and np.array_equal(c[None], b)
+        print("GUARDED OK")
+    ''')
+    env = dict(os.environ, PSM_GUARD_PAGES="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and "GUARDED OK" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
