@@ -11,10 +11,11 @@ struct Guarded { void* va; size_t reserved, mapped; hipMemGenericAllocationHandl
 std::mutex g_mu;
 std::unordered_map<void*, Guarded> g_live;
 
-bool guard_mode() {
-  static const bool on = [] { const char* e = getenv("PSM_GUARD_PAGES"); return e && e[0] == '1'; }();
-  return on;
+int guard_kind() {                                                 // 0 off, 1 unmapped granule BEHIND the buffer, 2 in FRONT of it
+  static const int k = [] { const char* e = getenv("PSM_GUARD_PAGES"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }();
+  return k;
 }
+bool guard_mode() { return guard_kind() != 0; }
 }  // namespace
 
 hipError_t psm_dev_malloc(void** p, size_t bytes) {
@@ -34,26 +35,28 @@ hipError_t psm_dev_malloc(void** p, size_t bytes) {
   Guarded g{};
   g.mapped = (bytes + gran - 1) / gran * gran;
   g.reserved = g.mapped + gran;                                   // one granule of reserved, never mapped, address space behind it
-  if ((e = hipMemAddressReserve(&g.va, g.reserved, gran, nullptr, 0)) != hipSuccess) return e;
-  if ((e = hipMemCreate(&g.handle, g.mapped, &prop, 0)) != hipSuccess) { (void)hipMemAddressFree(g.va, g.reserved); return e; }
+  void* base = nullptr;
+  if ((e = hipMemAddressReserve(&base, g.reserved, gran, nullptr, 0)) != hipSuccess) return e;
+  g.va = guard_kind() == 2 ? (char*)base + gran : base;          // kind 2: the unmapped granule comes first
+  if ((e = hipMemCreate(&g.handle, g.mapped, &prop, 0)) != hipSuccess) { (void)hipMemAddressFree(base, g.reserved); return e; }
   if ((e = hipMemMap(g.va, g.mapped, 0, g.handle, 0)) != hipSuccess) {
-    (void)hipMemRelease(g.handle); (void)hipMemAddressFree(g.va, g.reserved); return e;
+    (void)hipMemRelease(g.handle); (void)hipMemAddressFree(base, g.reserved); return e;
   }
   hipMemAccessDesc acc = {};
   acc.location = prop.location;
   acc.flags = hipMemAccessFlagsProtReadWrite;
   if ((e = hipMemSetAccess(g.va, g.mapped, &acc, 1)) != hipSuccess) {
-    (void)hipMemUnmap(g.va, g.mapped); (void)hipMemRelease(g.handle); (void)hipMemAddressFree(g.va, g.reserved); return e;
+    (void)hipMemUnmap(g.va, g.mapped); (void)hipMemRelease(g.handle); (void)hipMemAddressFree(base, g.reserved); return e;
   }
   // PSM_GUARD_FILL=<byte>: fill the whole mapping (memory from hipMemCreate is not cleared) -- 0 mimics the fresh pages hipMalloc
   // usually hands out, 255 poisons: floats read as NaN, indices as -1, so a kernel that depends on what it never wrote shows
   if (const char* f = getenv("PSM_GUARD_FILL")) {
     if ((e = hipMemset(g.va, atoi(f) & 255, g.mapped)) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) {
-      (void)hipMemUnmap(g.va, g.mapped); (void)hipMemRelease(g.handle); (void)hipMemAddressFree(g.va, g.reserved); return e;
+      (void)hipMemUnmap(g.va, g.mapped); (void)hipMemRelease(g.handle); (void)hipMemAddressFree(base, g.reserved); return e;
     }
   }
   const size_t used = (bytes + 15) / 16 * 16;
-  *p = (char*)g.va + (g.mapped - used);                           // the buffer ends where the mapping ends
+  *p = guard_kind() == 2 ? g.va : (char*)g.va + (g.mapped - used);   // kind 1: the buffer ends where the mapping ends; kind 2: it starts where it starts
   if (getenv("PSM_GUARD_LOG")) fprintf(stderr, "psm_alloc: + %p %zu B (va %p, mapped %zu)\n", *p, bytes, g.va, g.mapped);
   std::lock_guard<std::mutex> lk(g_mu);
   g_live[*p] = g;

@@ -1,4 +1,5 @@
-// psm_alloc.h -- device allocations of the library.  Normally hipMalloc / hipFree.  With PSM_GUARD_PAGES=1 in the
+// psm_alloc.h -- device allocations of the library.  Normally hipMalloc / hipFree.  With PSM_GUARD_PAGES=1 (=2: the mirror
+// image, unmapped granule in FRONT of a buffer that starts with its mapping -- accesses before the start) in the
 // environment (diagnostic; read once) every allocation gets its own virtual-address reservation with an UNMAPPED granule
 // behind it and the buffer is placed at the END of the mapped part (16-byte granularity), so a kernel that reads or writes
 // past the end of any library buffer takes a GPU page fault at that instruction instead of silently touching a neighbour;

@@ -29,7 +29,7 @@ class DeviceArray:
         self.shape, self.dtype = tuple(shape), np.dtype(dtype)
         self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
         p = C.c_void_p()
-        self._guarded = os.environ.get("PSM_GUARD_PAGES") == "1"
+        self._guarded = os.environ.get("PSM_GUARD_PAGES") in ("1", "2")
         if self._guarded:
             from psm_amd import _lib
             lib = _lib.load()

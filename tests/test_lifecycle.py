@@ -24,7 +24,7 @@ def _free_bytes():
     return free.value
 
 
-@pytest.mark.skipif(os.environ.get("PSM_GUARD_PAGES") == "1", reason="guard-page allocator: freed ranges stay reserved and every buffer takes whole granules")
+@pytest.mark.skipif(os.environ.get("PSM_GUARD_PAGES") in ("1", "2"), reason="guard-page allocator: freed ranges stay reserved and every buffer takes whole granules")
 def test_no_device_memory_leak_over_handle_cycles():
     model = synthetic.make_model("deltas", p_in=16, p_out=16)
     grid = synthetic.channel_grid(256, 256, seed=1).astype(np.float32)
