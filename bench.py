@@ -193,6 +193,19 @@ def spawn_ranks(n: int) -> int:
 # ----------------------------------------------------------------------------------------------------------------
 # algorithmic work
 # ----------------------------------------------------------------------------------------------------------------
+def to_device(torch, arr):
+    """NumPy -> device through a PINNED host tensor: hipMemcpy from ordinary memory makes the runtime pin the caller's pages on
+    the fly; the library never does that (csrc/psm_alloc.h) and the bench does not either."""
+    return torch.from_numpy(arr).pin_memory().cuda()
+
+
+def to_host(torch, t):
+    """device tensor -> NumPy through a pinned host tensor (see to_device)."""
+    h = torch.empty(tuple(t.shape), dtype=t.dtype, pin_memory=True)
+    h.copy_(t)
+    return h.numpy().copy()
+
+
 def algorithmic_bytes(model, ny, nx, wbytes=4):
     """SURVEY.md §8(d) BYTES formula, split per kernel group (float32 = 4 B)."""
     S2 = model.S ** 2
@@ -472,7 +485,7 @@ def unet_leg(name, args, torch, pdist, rank, world, local_rank, backend, steps, 
     n_in = min(args.inputs, 2 if NY > 256 else args.inputs)
     grids = [np.stack([synthetic.channel_grid(NY, NX, seed=1 + 1000 * rank + 10 * i + k, noise=0.05 if NY > 256 else 0.02).astype(np.float32)
                        for k in range(NC)]) for i in range(n_in)]
-    d_in = [torch.from_numpy(g).cuda() for g in grids]
+    d_in = [to_device(torch, g) for g in grids]
     d_out = [torch.empty((NC, NY, NX, 1), dtype=torch.float32, device="cuda") for _ in grids]
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -481,7 +494,7 @@ def unet_leg(name, args, torch, pdist, rank, world, local_rank, backend, steps, 
         net.forward_device(d_in[k].data_ptr(), NC, d_out[k].data_ptr(), stream)
     dt_max = pdist.timed_region(step, steps, warmup, torch.cuda.synchronize, "cuda" if backend == "nccl" else "cpu")
     torch.cuda.synchronize()
-    got = d_out[0][0].cpu().numpy()
+    got = to_host(torch, d_out[0][0])
     flops = net.flops * NC
     achieved = flops * steps / dt_max / 1e12
     # every launch of the forward pass with its own dispatch stamps: flops and activation / weight bytes of the convolutions it covers
@@ -574,7 +587,7 @@ def pca_leg(name, model, args, torch, pdist, psm_amd, synthetic, rank, world, lo
     else:
         grids = [synthetic.channel_grid(NY, NX, seed=4 + 1000 * rank + i, noise=0.05 if NY > 256 else 0.02).astype(np.float32)[None]
                  for i in range(args.inputs)]
-    d_in = [torch.from_numpy(g).cuda() for g in grids]
+    d_in = [to_device(torch, g) for g in grids]
     d_out = [torch.empty((NC, NY, NX, model.c_out), dtype=torch.float32, device="cuda") for _ in grids]
     stream = torch.cuda.current_stream().cuda_stream
     masks = [g[..., model.sdf_ch] != 0 for g in grids]
@@ -585,7 +598,7 @@ def pca_leg(name, model, args, torch, pdist, psm_amd, synthetic, rank, world, lo
         sur.solve_device(d_in[k].data_ptr(), NC, d_out[k].data_ptr(), stream)
     dt = pdist.timed_region(step, steps, warmup, torch.cuda.synchronize, red_dev)
     torch.cuda.synchronize()
-    got = d_out[0].cpu().numpy()[0]
+    got = to_host(torch, d_out[0])[0]
     leg = {"workload": desc, "value": pdist.aggregate_throughput(NC, steps, world, dt), "unit": "solves/s", "steps": steps, "warmup": warmup,
            "ms_per_step": dt / steps * 1e3, "dtype": precision, "grid": [NY, NX], "blocks": sur.B,
            "geometry": "bound once per case stream" if bound else "general path", "guard_trips": sur.guard_trips,
@@ -673,7 +686,7 @@ def main():
             g = base.copy()
             g[..., :model.sdf_ch] *= np.float32(1.0 + 0.05 * i)
             grids.append(g)
-    d_in = [torch.from_numpy(g).cuda() for g in grids]
+    d_in = [to_device(torch, g) for g in grids]
     d_out = [torch.empty((NC, NY, NX, model.c_out), dtype=torch.float32, device="cuda") for _ in grids]
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -693,7 +706,7 @@ def main():
 
     dt_max = pdist.timed_region(step, args.steps, args.warmup, torch.cuda.synchronize, red_dev)
     torch.cuda.synchronize()
-    got_dev = d_out[0].cpu().numpy()
+    got_dev = to_host(torch, d_out[0])
     value = pdist.aggregate_throughput(NC, args.steps, world, dt_max)
     roofline = pca_roofline(sur, model, NY, NX, NC, precision, d_in[0].data_ptr(), d_out[0].data_ptr(), args.steps, dt_max / args.steps,
                             args.workload, bound)
@@ -740,7 +753,7 @@ def main():
             "hw_queues": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "set_by": "the caller's environment" if _HWQ_PRESET else "bench.py (the library never sets it)",
                           "hip_initialised_before_it_was_set": bool(hip_up_before)},
             "steps": n_e2e, "solves_per_s_per_rank": {k: v[0] for k, v in rates.items()},
-            "matches_device_resident_result": bool(np.array_equal(rates[key][1], d_out[last_in].cpu().numpy()))}
+            "matches_device_resident_result": bool(np.array_equal(rates[key][1], to_host(torch, d_out[last_in])))}
 
     # ---- BASELINE configs[3]: the case batch, 8 random-obstacle cases per GPU per step
     m3 = None
@@ -756,7 +769,7 @@ def main():
         for i in range(args.inputs):
             g = allc.copy()
             g[..., :m3.sdf_ch] *= np.float32(1.0 + 0.05 * i)
-            g3.append(torch.from_numpy(g).cuda())
+            g3.append(to_device(torch, g))
         o3 = [torch.empty((count, ny3, nx3, m3.c_out), dtype=torch.float32, device="cuda") for _ in g3]
         b3 = sur3.bind_geometry(g3[0].data_ptr(), on_device=True, n_cases=count) if not args.no_bind else False
 
@@ -766,7 +779,7 @@ def main():
         k3 = max(100, args.steps // 4)
         dt3 = pdist.timed_region(step3, k3, max(10, args.warmup // 4), torch.cuda.synchronize, red_dev)
         torch.cuda.synchronize()
-        whole = pdist.gather_cases(o3[0] if red_dev == "cuda" else o3[0].cpu(), total_cases)     # one all-gather, untimed
+        whole = pdist.gather_cases(o3[0] if red_dev == "cuda" else torch.from_numpy(to_host(torch, o3[0])), total_cases)     # one all-gather, untimed
         out["case_batch"] = {"workload": desc3, "value": total_cases * k3 / dt3, "unit": "solves/s", "steps": k3,
                              "ms_per_step": dt3 / k3 * 1e3, "dtype": prec3, "cases_per_step_per_gpu": count, "total_cases": total_cases,
                              "geometry": "one bound geometry per case slot (7 launches per step)" if b3 else "general path (9 launches per step)",
@@ -776,7 +789,7 @@ def main():
             from oracle import psm_oracle as orc
             c = count - 1
             ref = orc.solve_grid(allc[c].astype(np.float64), oracle_model(m3)).fields
-            gotc = o3[0][c].cpu().numpy()
+            gotc = to_host(torch, o3[0][c])
             out["case_batch"]["l2_vs_oracle"] = float(np.linalg.norm(gotc - ref) / np.linalg.norm(ref))
         sur3.close()
 

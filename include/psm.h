@@ -400,6 +400,11 @@ int psm_debug_reassemble_host(int32_t variant, int32_t ny, int32_t nx, int32_t b
 int psm_debug_guard_pages(void);
 int psm_debug_malloc(void** ptr, size_t bytes);
 int psm_debug_free(void* ptr);
+/* Synchronous copies between device memory and ordinary (pageable) host memory through the library's pinned bounce buffer --
+ * what every entry of this library that takes host pointers does internally (the GPU never touches caller memory that was
+ * not registered explicitly; csrc/psm_alloc.h says why).  For a caller's own test buffers; hipError_t values. */
+int psm_debug_copy_to_device(void* dst_device, const void* src_host, size_t bytes);
+int psm_debug_copy_to_host(void* dst_host, const void* src_device, size_t bytes);
 int psm_abi_version(void);
 
 #ifdef __cplusplus

@@ -109,6 +109,8 @@ SIGNATURES = {
     "psm_debug_guard_pages": (C.c_int, []),
     "psm_debug_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "psm_debug_free": (C.c_int, [C.c_void_p]),
+    "psm_debug_copy_to_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "psm_debug_copy_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "psm_abi_version": (C.c_int, []),
 }
 

@@ -3,6 +3,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <unordered_map>
 
@@ -87,6 +88,57 @@ hipError_t psm_dev_free(void* p) {
   return e;
 }
 
+// ---- bounce-buffer copies ---------------------------------------------------------------------------------------------
+namespace {
+constexpr size_t BOUNCE_BYTES = (size_t)4 << 20;
+std::mutex g_bounce_mu;
+void* g_bounce = nullptr;
+hipError_t bounce_ready() {
+  if (g_bounce) return hipSuccess;
+  return hipHostMalloc(&g_bounce, BOUNCE_BYTES, hipHostMallocPortable);      // one per process, lives until exit
+}
+}  // namespace
+
+hipError_t psm_copy_h2d(void* dst_dev, const void* src_host, size_t bytes) {
+  if (bytes == 0) return hipSuccess;
+  std::lock_guard<std::mutex> lk(g_bounce_mu);
+  hipError_t e = bounce_ready();
+  for (size_t off = 0; e == hipSuccess && off < bytes; off += BOUNCE_BYTES) {
+    const size_t n = bytes - off < BOUNCE_BYTES ? bytes - off : BOUNCE_BYTES;
+    std::memcpy(g_bounce, (const char*)src_host + off, n);
+    e = hipMemcpy((char*)dst_dev + off, g_bounce, n, hipMemcpyHostToDevice);
+  }
+  return e;
+}
+
+hipError_t psm_copy_d2h(void* dst_host, const void* src_dev, size_t bytes) {
+  if (bytes == 0) return hipSuccess;
+  std::lock_guard<std::mutex> lk(g_bounce_mu);
+  hipError_t e = bounce_ready();
+  for (size_t off = 0; e == hipSuccess && off < bytes; off += BOUNCE_BYTES) {
+    const size_t n = bytes - off < BOUNCE_BYTES ? bytes - off : BOUNCE_BYTES;
+    e = hipMemcpy(g_bounce, (const char*)src_dev + off, n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) std::memcpy((char*)dst_host + off, g_bounce, n);
+  }
+  return e;
+}
+
+hipError_t psm_copy_d2h_2d(void* dst_host, size_t dpitch, const void* src_dev, size_t spitch, size_t width, size_t height) {
+  if (width == 0 || height == 0) return hipSuccess;
+  if (width > BOUNCE_BYTES) return hipErrorInvalidValue;
+  std::lock_guard<std::mutex> lk(g_bounce_mu);
+  hipError_t e = bounce_ready();
+  const size_t rows_per = BOUNCE_BYTES / width;
+  for (size_t r0 = 0; e == hipSuccess && r0 < height; r0 += rows_per) {
+    const size_t nr = height - r0 < rows_per ? height - r0 : rows_per;
+    e = hipMemcpy2D(g_bounce, width, (const char*)src_dev + r0 * spitch, spitch, width, nr, hipMemcpyDeviceToHost);
+    for (size_t r = 0; e == hipSuccess && r < nr; ++r) std::memcpy((char*)dst_host + (r0 + r) * dpitch, (const char*)g_bounce + r * width, width);
+  }
+  return e;
+}
+
+extern "C" int psm_debug_copy_to_device(void* dst_dev, const void* src_host, size_t bytes) { return (int)psm_copy_h2d(dst_dev, src_host, bytes); }
+extern "C" int psm_debug_copy_to_host(void* dst_host, const void* src_dev, size_t bytes) { return (int)psm_copy_d2h(dst_host, src_dev, bytes); }
 extern "C" int psm_debug_guard_pages(void) { return guard_mode() ? 1 : 0; }
 extern "C" int psm_debug_malloc(void** p, size_t bytes) { return p ? (int)psm_dev_malloc(p, bytes) : (int)hipErrorInvalidValue; }
 extern "C" int psm_debug_free(void* p) { return (int)psm_dev_free(p); }

@@ -10,7 +10,19 @@
 #include <cstddef>
 
 hipError_t psm_dev_malloc(void** p, size_t bytes);
+// Synchronous copies between device memory and ORDINARY (pageable) host memory, through a pinned bounce buffer owned by the
+// library.  hipMemcpy on pageable memory lets the runtime pin the caller's pages for the DMA engine on the fly (copies of
+// 1 MiB and more) and cache those mappings by address; in a long-lived process whose heap addresses get reused that path
+// produced "Memory access fault ... Write access to a read-only page" on a HOST address during a device-to-host copy
+// (seen twice in ten runs of the GPU test suite, never with these).  With the bounce buffer the GPU only ever touches memory
+// this library allocated with hipHostMalloc or that the caller registered explicitly.  Both return when the copy is done;
+// like hipMemcpy they do not order themselves against the library's non-blocking streams.
+hipError_t psm_copy_h2d(void* dst_dev, const void* src_host, size_t bytes);
+hipError_t psm_copy_d2h(void* dst_host, const void* src_dev, size_t bytes);
+hipError_t psm_copy_d2h_2d(void* dst_host, size_t dpitch, const void* src_dev, size_t spitch, size_t width, size_t height);
 hipError_t psm_dev_free(void* p);
 extern "C" int psm_debug_guard_pages(void);                       // 1 when PSM_GUARD_PAGES=1 took effect
 extern "C" int psm_debug_malloc(void** p, size_t bytes);          // the same allocator for test buffers (tests/hipmem.py)
 extern "C" int psm_debug_free(void* p);
+extern "C" int psm_debug_copy_to_device(void* dst_dev, const void* src_host, size_t bytes);   // psm_copy_h2d / _d2h for test buffers
+extern "C" int psm_debug_copy_to_host(void* dst_host, const void* src_dev, size_t bytes);

@@ -278,7 +278,7 @@ template <typename T>
 int dev_upload(psm_handle* h, T** p, const std::vector<T>& v) {
   int rc = dev_alloc(h, p, v.size());
   if (rc) return rc;
-  if (!v.empty()) HIPCHK(h, hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  if (!v.empty()) HIPCHK(h, psm_copy_h2d(*p, v.data(), v.size() * sizeof(T)));
   return PSM_OK;
 }
 
@@ -1168,7 +1168,7 @@ int psm_plan_grid(psm_handle* h, int32_t ny, int32_t nx) {
 static int build_closed_form(psm_handle* h, int n_cases, int rows, int Kh) {
   const int C = h->cfg.c_out, B = h->B, nst = h->n_strips, NS = h->plan.cp.NS;
   std::vector<float> hcnt((size_t)rows * n_cases);
-  HIPCHK(h, hipMemcpy(hcnt.data(), h->d_cnt, hcnt.size() * sizeof(float), hipMemcpyDeviceToHost));
+  HIPCHK(h, psm_copy_d2h(hcnt.data(), h->d_cnt, hcnt.size() * sizeof(float)));
   const double qnan = std::nan("");
   std::vector<int32_t> ptr(1, 0), src, row_of_p;
   std::vector<float> coef, a0((size_t)n_cases * C * B);
@@ -1302,7 +1302,7 @@ static int bind_geometry_device(psm_handle* h, const float* d_grid, int n_cases 
   {                                                           // host copy of the bound flow-cell pattern (contract checks)
     const size_t npix = (size_t)h->Ny * h->Nx, cin = h->cfg.c_in;
     std::vector<float> g((size_t)n_cases * npix * cin);
-    HIPCHK(h, hipMemcpy(g.data(), d_grid, g.size() * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(h, psm_copy_d2h(g.data(), d_grid, g.size() * sizeof(float)));
     h->bound_mask.resize((size_t)n_cases * npix);
     for (size_t q = 0; q < (size_t)n_cases * npix; ++q) h->bound_mask[q] = g[q * cin + h->cfg.sdf_channel] != 0.f ? 1 : 0;
     // the same pattern as the guard waves see it: one 64-pixel ballot per word (pixels beyond the end clamp to the last)
@@ -1348,7 +1348,7 @@ int psm_bind_geometry_cases(psm_handle* h, const float* grids, int32_t n_cases, 
   h->bound_scope = 2;
   if (on_device) return bind_geometry_device(h, grids, n_cases);
   const size_t gin = (size_t)n_cases * h->Ny * h->Nx * h->cfg.c_in * sizeof(float);
-  HIPCHK(h, hipMemcpy(h->d_grid_stage, grids, gin, hipMemcpyHostToDevice));
+  HIPCHK(h, psm_copy_h2d(h->d_grid_stage, grids, gin));
   return bind_geometry_device(h, h->d_grid_stage, n_cases);
 }
 
@@ -1719,8 +1719,9 @@ int psm_reassemble(psm_handle* h, const float* grid, const float* block_pred, fl
   HIPCHK(h, hipSetDevice(h->cfg.device));
   hipStream_t st = h->stream;
   const size_t npix = (size_t)h->Ny * h->Nx;
-  HIPCHK(h, hipMemcpyAsync(h->d_grid_stage, grid, npix * h->cfg.c_in * sizeof(float), hipMemcpyHostToDevice, st));
-  HIPCHK(h, hipMemcpyAsync(h->ws0.d_pred, block_pred, (size_t)h->B * h->K_out * sizeof(float), hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipStreamSynchronize(st));                    // the staging buffers are free; caller memory goes through the bounce buffer
+  HIPCHK(h, psm_copy_h2d(h->d_grid_stage, grid, npix * h->cfg.c_in * sizeof(float)));
+  HIPCHK(h, psm_copy_h2d(h->ws0.d_pred, block_pred, (size_t)h->B * h->K_out * sizeof(float)));
   PsmStripArgs sa{};
   sa.pred = h->ws0.d_pred; sa.grid = h->d_grid_stage; sa.strips = h->d_strips; sa.blk_y0x0 = h->d_blk; sa.spart = h->ws0.d_spart; sa.colpart = h->ws0.d_colpart; sa.NS = h->plan.cp.NS; sa.n_bands = h->n_bands;
   sa.B = h->B; sa.S = h->S; sa.c_in = h->cfg.c_in; sa.c_out = h->cfg.c_out;
@@ -1734,8 +1735,8 @@ int psm_reassemble(psm_handle* h, const float* grid, const float* block_pred, fl
   HIPCHK(h, psm_launch_chain(ca, 1, st));
   PsmPasteArgs pa{h->ws0.d_pred, h->d_owner, h->ws0.d_offs, h->ws0.d_shift, h->d_fields_stage, h->B, h->S, h->cfg.c_out, h->Ny * h->Nx};
   HIPCHK(h, psm_launch_paste(pa, 1, st));
-  HIPCHK(h, hipMemcpyAsync(fields, h->d_fields_stage, npix * h->cfg.c_out * sizeof(float), hipMemcpyDeviceToHost, st));
   HIPCHK(h, wait_stream(st));
+  HIPCHK(h, psm_copy_d2h(fields, h->d_fields_stage, npix * h->cfg.c_out * sizeof(float)));
   h->last_cases = 1;
   return PSM_OK;
 }
@@ -1832,7 +1833,7 @@ int psm_set_geometry(psm_handle* h, int64_t n_cells, int32_t ny, int32_t nx, con
       const double sdv = sdfunct[t] * sc;                    // the SDF channel exactly as psm_to_grid_kernel writes it
       g[(size_t)t * 3 + 2] = (sdv != sdv) ? 0.f : (float)sdv;
     }
-    HIPCHK(h, hipMemcpy(h->d_grid_stage, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(h, psm_copy_h2d(h->d_grid_stage, g.data(), g.size() * sizeof(float)));
     rc = bind_geometry_device(h, h->d_grid_stage);
     if (rc == PSM_OK) h->bound_scope = 1;
     else if (rc == PSM_ERR_UNSUPPORTED) h->err.clear();      // configuration outside the fused path: general path
@@ -2176,7 +2177,7 @@ int psm_read_stage(psm_handle* h, int32_t stage, float* dst, size_t dst_floats) 
   const int M = h->last_cases * h->B;
   auto rows = [&](const float* src, int ld, int width) -> int {
     if (dst_floats < (size_t)M * width) return fail(h, PSM_ERR_ARG, "destination too small");
-    HIPCHK(h, hipMemcpy2D(dst, (size_t)width * sizeof(float), src, (size_t)ld * sizeof(float), (size_t)width * sizeof(float), M, hipMemcpyDeviceToHost));
+    HIPCHK(h, psm_copy_d2h_2d(dst, (size_t)width * sizeof(float), src, (size_t)ld * sizeof(float), (size_t)width * sizeof(float), M));
     return PSM_OK;
   };
   switch (stage) {
@@ -2207,13 +2208,13 @@ int psm_read_stage(psm_handle* h, int32_t stage, float* dst, size_t dst_floats) 
       if (stage == PSM_STAGE_SHIFT) {
         const size_t n = (size_t)h->last_cases * h->cfg.c_out;
         if (dst_floats < n) return fail(h, PSM_ERR_ARG, "destination too small");
-        HIPCHK(h, hipMemcpy(dst, h->ws0.d_shift, n * sizeof(float), hipMemcpyDeviceToHost));
+        HIPCHK(h, psm_copy_d2h(dst, h->ws0.d_shift, n * sizeof(float)));
         return PSM_OK;
       }
       {
       const size_t n = (size_t)h->last_cases * h->cfg.c_out * h->B;
       if (dst_floats < n) return fail(h, PSM_ERR_ARG, "destination too small");
-      HIPCHK(h, hipMemcpy(dst, h->ws0.d_offs, n * sizeof(float), hipMemcpyDeviceToHost));
+      HIPCHK(h, psm_copy_d2h(dst, h->ws0.d_offs, n * sizeof(float)));
       return PSM_OK;
     }
     case 6: {   // diagnostic builds only: raw stamps of workgroup 0, microseconds after the earliest one

@@ -231,26 +231,26 @@ int upload_conv(psm_unet* u, Conv& c) {
   std::vector<float> bias((size_t)((c.cout + 15) / 16 + 4) * 16, 0.f);
   std::memcpy(bias.data(), c.b.data(), c.cout * sizeof(float));
   UCHK(u, psm_dev_malloc((void**)&c.d_b, bias.size() * sizeof(float)));
-  UCHK(u, hipMemcpy(c.d_b, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+  UCHK(u, psm_copy_h2d(c.d_b, bias.data(), bias.size() * sizeof(float)));
   if (c.k == 3 && c.stem) {
     const std::vector<float> p = pack_stem(c, u->bf16 != 0);
     UCHK(u, psm_dev_malloc((void**)&c.d_w, p.size() * sizeof(float)));
-    UCHK(u, hipMemcpy(c.d_w, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
+    UCHK(u, psm_copy_h2d(c.d_w, p.data(), p.size() * sizeof(float)));
   } else if (c.k == 3 && c.x6) {
     const std::vector<uint16_t> p = pack_conv3x3_x6(c);
     UCHK(u, psm_dev_malloc((void**)&c.d_w, p.size() * sizeof(uint16_t)));
-    UCHK(u, hipMemcpy(c.d_w, p.data(), p.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    UCHK(u, psm_copy_h2d(c.d_w, p.data(), p.size() * sizeof(uint16_t)));
   } else if (c.k == 3 && u->bf16) {
     const std::vector<uint16_t> p = pack_conv3x3_bf16(c);
     UCHK(u, psm_dev_malloc((void**)&c.d_w, p.size() * sizeof(uint16_t)));
-    UCHK(u, hipMemcpy(c.d_w, p.data(), p.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    UCHK(u, psm_copy_h2d(c.d_w, p.data(), p.size() * sizeof(uint16_t)));
   } else if (c.k == 3) {
     const std::vector<float> p = pack_conv3x3(c);
     UCHK(u, psm_dev_malloc((void**)&c.d_w, p.size() * sizeof(float)));
-    UCHK(u, hipMemcpy(c.d_w, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
+    UCHK(u, psm_copy_h2d(c.d_w, p.data(), p.size() * sizeof(float)));
   } else {
     UCHK(u, psm_dev_malloc((void**)&c.d_w1, c.W.size() * sizeof(float)));
-    UCHK(u, hipMemcpy(c.d_w1, c.W.data(), c.W.size() * sizeof(float), hipMemcpyHostToDevice));
+    UCHK(u, psm_copy_h2d(c.d_w1, c.W.data(), c.W.size() * sizeof(float)));
   }
   if (c.pair == 1) {
     const size_t ci = &c - u->convs.data();
@@ -259,9 +259,9 @@ int upload_conv(psm_unet* u, Conv& c) {
     if (c.pair_kind == PSM_PAIR_UPCAT) { c0 = u->convs[ci - 1].cout; c1 = u->convs[c.skip].cout; }
     const std::vector<uint16_t> pa = pack_pair(c, c.pair_kind == PSM_PAIR_STEM, c0, c1), pb = pack_pair(B, false, B.cin, 0);
     UCHK(u, psm_dev_malloc((void**)&c.d_wpa, pa.size() * sizeof(uint16_t)));
-    UCHK(u, hipMemcpy(c.d_wpa, pa.data(), pa.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    UCHK(u, psm_copy_h2d(c.d_wpa, pa.data(), pa.size() * sizeof(uint16_t)));
     UCHK(u, psm_dev_malloc((void**)&c.d_wpb, pb.size() * sizeof(uint16_t)));
-    UCHK(u, hipMemcpy(c.d_wpb, pb.data(), pb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    UCHK(u, psm_copy_h2d(c.d_wpb, pb.data(), pb.size() * sizeof(uint16_t)));
   }
   return PSM_OK;
 }
@@ -605,15 +605,15 @@ int psm_unet_read_activation(psm_unet* u, int32_t idx, float* dst, int64_t dst_f
   UCHK(u, hipStreamSynchronize(u->stream));
   if (c.out_bf || c.pair != 0) {  // stored as bf16 (finished activations in bf16 mode; a pair kernel always writes bf16): widen
     std::vector<uint16_t> hb((size_t)n);
-    UCHK(u, hipMemcpy(hb.data(), c.d_out, (size_t)n * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    UCHK(u, psm_copy_d2h(hb.data(), c.d_out, (size_t)n * sizeof(uint16_t)));
     for (int64_t q = 0; q < n; ++q) { const uint32_t w = (uint32_t)hb[q] << 16; std::memcpy(&dst[q], &w, 4); }
     return PSM_OK;
   }
-  UCHK(u, hipMemcpy(dst, c.d_out, n * sizeof(float), hipMemcpyDeviceToHost));
+  UCHK(u, psm_copy_d2h(dst, c.d_out, n * sizeof(float)));
   if (c.ksplit > 1) {            // partial-sum slabs: finish like the consumer's loader (slab order, bias, ReLU)
     std::vector<float> tmp(n);
     for (int s = 1; s < c.ksplit; ++s) {
-      UCHK(u, hipMemcpy(tmp.data(), c.d_out + (int64_t)s * c.slab, n * sizeof(float), hipMemcpyDeviceToHost));
+      UCHK(u, psm_copy_d2h(tmp.data(), c.d_out + (int64_t)s * c.slab, n * sizeof(float)));
       for (int64_t q = 0; q < n; ++q) dst[q] += tmp[q];
     }
     for (int64_t q = 0; q < n; ++q) { const float v = dst[q] + c.b[q % c.cout]; dst[q] = v > 0.f ? v : 0.f; }

@@ -111,9 +111,15 @@ def broadcast_arrays(arrays, src: int = 0, device="cpu"):
     buf = torch.empty(max(total, 1), dtype=torch.uint8, device=device)
     if rank == src and total:
         flat = np.concatenate([v.reshape(-1).view(np.uint8) for v in arrays.values()])
-        buf[:total].copy_(torch.from_numpy(flat))
+        staged = torch.from_numpy(flat)
+        buf[:total].copy_(staged.pin_memory() if buf.is_cuda else staged)      # device copies from / to pinned host tensors only
     dist.broadcast(buf, src=src)
-    raw = buf.cpu().numpy()
+    if buf.is_cuda:
+        host = torch.empty(buf.shape, dtype=torch.uint8, pin_memory=True)
+        host.copy_(buf)
+        raw = host.numpy()
+    else:
+        raw = buf.numpy()
     out, off = {}, 0
     for k, sh, dt in manifest[0]:
         n = int(np.prod(sh, dtype=np.int64)) * np.dtype(dt).itemsize

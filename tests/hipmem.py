@@ -1,7 +1,10 @@
 """Minimal HIP runtime access through ctypes for the GPU tests (device buffers without importing
-torch, whose first import on a fresh box can take minutes).  With PSM_GUARD_PAGES=1 in the environment the buffers come
-from the library's guard-page allocator (csrc/psm_alloc.cpp): a kernel that runs past the end of a test's input or
-output buffer faults instead of touching a neighbour."""
+torch, whose first import on a fresh box can take minutes).  Host <-> device copies go through the library's pinned bounce
+buffer (psm_debug_copy_to_device / _to_host): hipMemcpy on ordinary NumPy memory lets the HIP runtime pin the caller's pages on
+the fly, a path that produced "Write access to a read-only page" faults on host addresses in this long-lived test process.
+With PSM_GUARD_PAGES=1 / 2 in the environment the buffers come from the library's guard-page allocator
+(csrc/psm_alloc.cpp): a kernel that runs past the end (before the start) of a test's buffer faults instead of touching a
+neighbour."""
 import ctypes as C
 import os
 
@@ -21,6 +24,11 @@ def hip():
     return _hip
 
 
+def _psm():
+    from psm_amd import _lib
+    return _lib.load()
+
+
 class DeviceArray:
     def __init__(self, host: np.ndarray = None, shape=None, dtype=np.float32):
         if host is not None:
@@ -31,20 +39,19 @@ class DeviceArray:
         p = C.c_void_p()
         self._guarded = os.environ.get("PSM_GUARD_PAGES") in ("1", "2")
         if self._guarded:
-            from psm_amd import _lib
-            lib = _lib.load()
+            lib = _psm()
             assert lib.psm_debug_guard_pages() == 1 and lib.psm_debug_malloc(C.byref(p), self.nbytes) == 0
             self._lib = lib
         else:
             assert hip().hipMalloc(C.byref(p), self.nbytes) == 0
         self.ptr = p.value
         if host is not None:
-            assert hip().hipMemcpy(self.ptr, host.ctypes.data, self.nbytes, 1) == 0      # H2D
+            assert _psm().psm_debug_copy_to_device(self.ptr, host.ctypes.data, self.nbytes) == 0
 
     def numpy(self) -> np.ndarray:
         assert hip().hipDeviceSynchronize() == 0
         out = np.empty(self.shape, self.dtype)
-        assert hip().hipMemcpy(out.ctypes.data, self.ptr, self.nbytes, 2) == 0           # D2H
+        assert _psm().psm_debug_copy_to_host(out.ctypes.data, self.ptr, self.nbytes) == 0
         return out
 
     def free(self):

@@ -108,7 +108,7 @@ def test_guard_page_allocator_places_buffers_at_the_end_of_their_mapping():
             assert lib.psm_debug_malloc(C.byref(p), n) == 0
             assert (p.value + (n + 15) // 16 * 16) % 4096 == 0, (n, hex(p.value))
             src = (np.arange(n) % 251).astype(np.uint8); dst = np.zeros(n, np.uint8)
-            assert hip().hipMemcpy(p.value, src.ctypes.data, n, 1) == 0 and hip().hipMemcpy(dst.ctypes.data, p.value, n, 2) == 0
+            assert lib.psm_debug_copy_to_device(p.value, src.ctypes.data, n) == 0 and lib.psm_debug_copy_to_host(dst.ctypes.data, p.value, n) == 0
             assert np.array_equal(src, dst)
             assert lib.psm_debug_free(p.value) == 0
         model = synthetic.make_model("gradp", p_in=16, p_out=16)
