@@ -21,7 +21,7 @@ for variant, ny, nx, nc in (("gradp", 256, 256, 1), ("deltas", 256, 256, 8), ("d
     with psm_amd.GridSurrogate(model, ny, nx, max_cases=nc) as sur:
         f = sur.solve(grids)
         x = sur.stage("x_input", nc)[:sur.B]
-        d_in, d_out = torch.from_numpy(grids).cuda(), torch.empty((nc, ny, nx, model.c_out), device="cuda")
+        d_in, d_out = torch.from_numpy(grids).pin_memory().cuda(), torch.empty((nc, ny, nx, model.c_out), device="cuda")
         sur.bind_geometry(d_in.data_ptr(), on_device=True, n_cases=nc)
         for _ in range(50):
             sur.solve_device(d_in.data_ptr(), nc, d_out.data_ptr(), 0)
@@ -32,7 +32,7 @@ for variant, ny, nx, nc in (("gradp", 256, 256, 1), ("deltas", 256, 256, 8), ("d
             sur.solve_device(d_in.data_ptr(), nc, d_out.data_ptr(), 0)
         sur.synchronize()
         dt = (time.perf_counter() - t0) / n
-        fb = d_out.cpu().numpy()
+        fb = torch.empty(d_out.shape, dtype=d_out.dtype, pin_memory=True).copy_(d_out).numpy()
     sol = orc.solve_grid(grids[0].astype(np.float64), oracle_model(model))      # after the timing: no BLAS threads spinning under it
     print(f"PSM_X6={os.environ.get('PSM_X6', 'default')} {variant} x{nc}: x_input rel-L2 {rel(x, sol.x_input):.2e}  fields rel-L2 {rel(f[0], sol.fields):.2e} "
           f"(bound {rel(fb[0], sol.fields):.2e})  {dt * 1e6:.1f} us per step = {nc / dt:.0f} solves/s")

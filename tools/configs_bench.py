@@ -9,7 +9,7 @@ from psm_amd import synthetic
 def run(name, model, ny, nx, n_cases, steps=1500, warm=150, precision="f32", bind=False):
     grids = synthetic.random_obstacle_cases(n_cases, ny, nx, seed=3).astype(np.float32)
     with psm_amd.GridSurrogate(model, ny, nx, max_cases=n_cases, precision=precision) as sur:
-        d_in = torch.from_numpy(grids).cuda()
+        d_in = torch.from_numpy(grids).pin_memory().cuda()
         if bind:
             assert sur.bind_geometry(d_in.data_ptr(), on_device=True, n_cases=n_cases)
             name += " [bound]"

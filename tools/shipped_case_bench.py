@@ -13,7 +13,7 @@ model.in_a, model.out_a = float(maxs_pca[0]), float(maxs_pca[1])
 grid = synthetic.channel_grid(400, 3000, seed=1).astype(np.float32)
 for bind in (False, True):
     with psm_amd.GridSurrogate(model, 400, 3000) as sur:
-        d_in = torch.from_numpy(grid[None]).cuda(); d_out = torch.empty((1, 400, 3000, 1), dtype=torch.float32, device="cuda")
+        d_in = torch.from_numpy(grid[None]).pin_memory().cuda(); d_out = torch.empty((1, 400, 3000, 1), dtype=torch.float32, device="cuda")
         st = torch.cuda.current_stream().cuda_stream
         if bind: assert sur.bind_geometry(d_in.data_ptr(), on_device=True)
         for i in range(200): sur.solve_device(d_in.data_ptr(), 1, d_out.data_ptr(), st)

@@ -10,7 +10,7 @@ BIND = len(sys.argv) > 1 and sys.argv[1] == "bind"     # one geometry per stream
 for S in (1, 2, 3, 4, 6, 8):
     surs = [psm_amd.GridSurrogate(model, 256, 256) for _ in range(S)]
     streams = [torch.cuda.Stream() for _ in range(S)]
-    d_in = [torch.from_numpy(synthetic.channel_grid(256, 256, seed=1 + i).astype(np.float32)).cuda() for i in range(S)]
+    d_in = [torch.from_numpy(synthetic.channel_grid(256, 256, seed=1 + i).astype(np.float32)).pin_memory().cuda() for i in range(S)]
     d_out = [torch.empty((256, 256, 2), dtype=torch.float32, device="cuda") for _ in range(S)]
     if BIND:
         for k in range(S): assert surs[k].bind_geometry(d_in[k].data_ptr(), on_device=True)
