@@ -698,13 +698,18 @@ static void launch_variant(const PsmConvArgs& a, dim3 grid, int groups, hipStrea
            else PSM_LAUNCH((psm_conv3x3_kernel<TH, WM, NCT, WN, S, K, false, 2>), grid, dim3(256), 0, st, a, groups); }                  \
   } while (0)
   if (stem) { GO(-1, 1); return; }
-  if (a.mode0 == PSM_SRC_SAME) { if (slabs) GO(PSM_SRC_SAME, 8); else GO(PSM_SRC_SAME, 1); }
+  // slab count of the deepest-split input, as a compile-time loop bound of the summing loader: 2, 4 or 8 (a loader built for 8
+  // slabs issues 8 clamped loads per fetch whatever the producer's split)
+  const int km = a.ks0 > a.ks1 ? a.ks0 : a.ks1;
+#define GOK(S) do { if (!slabs) GO(S, 1); else if (km <= 2) GO(S, 2); else if (km <= 4) GO(S, 4); else GO(S, 8); } while (0)
+  if (a.mode0 == PSM_SRC_SAME) GOK(PSM_SRC_SAME);
   else if (a.mode0 == PSM_SRC_UPSAMPLE) {
     const bool seam_inside = a.c1 > 0 && (a.c0 % ((a.bf16 || a.x6) ? 32 : 16)) != 0;
-    if (seam_inside) { if (slabs) GO(3, 8); else GO(3, 1); }
-    else { if (slabs) GO(PSM_SRC_UPSAMPLE, 8); else GO(PSM_SRC_UPSAMPLE, 1); }
+    if (seam_inside) GOK(3);
+    else GOK(PSM_SRC_UPSAMPLE);
   }
-  else { if (slabs) GO(PSM_SRC_MAXPOOL, 8); else GO(PSM_SRC_MAXPOOL, 1); }
+  else GOK(PSM_SRC_MAXPOOL);
+#undef GOK
 #undef GO
 }
 
