@@ -84,7 +84,8 @@ hipError_t psm_dev_free(void* p) {
   (void)hipMemRelease(g.handle);
   // The address range stays reserved for the life of the process: (i) a use after free then faults as well, (ii) on ROCm 7.2 a
   // range handed out again right after hipMemAddressFree was seen to alias the physical pages of a LATER allocation (the
-  // bound-pattern table read back another buffer's contents) -- address space is plentiful, a diagnostic run is short.
+  // bound-pattern table read back another buffer's contents) -- a diagnostic run is short: the GPU test suite and a soak of
+  // 250 autotuned networks fit, a longer one ends with hipErrorOutOfMemory from the reservations.
   return e;
 }
 
