@@ -12,13 +12,108 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
 ROOF = {"bound", "achieved", "peak", "unit", "frac", "traffic"}
 
 
-def run_bench(*extra):
+LINE_LIMIT = 4096       # the driver keeps ~8 KB of stdout (round 3: a 42 KB line was cut and the record had parsed = null)
+
+
+def run_bench(*extra, logdir=None):
+    """-> (compact line as the driver sees it, full record from bench_detail.json)."""
+    logdir = logdir or os.path.join(ROOT, "gpurun_out", "bench_test")
+    env = dict(os.environ, PSM_BENCH_LOGDIR=str(logdir))
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "10", *extra],
-                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
+    assert len(out.stdout) < LINE_LIMIT and len(out.stderr) < LINE_LIMIT, (len(out.stdout), len(out.stderr))
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-1000:]
-    return json.loads(lines[0])
+    return json.loads(lines[0]), json.load(open(os.path.join(logdir, "bench_detail.json")))
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("psm_bench_script", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "GPU_MAX_HW_QUEUES")}
+    try:
+        spec.loader.exec_module(m)
+    finally:
+        for k, v in saved.items():                   # bench.py sizes thread pools through the environment: not in this process
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return m
+
+
+def test_line_built_from_a_recorded_run_fits_the_driver():
+    """The full record of a real run (round 3's 42 KB line, kept as a fixture) -> the line bench.py prints now: every
+    contract key, roofline and cpu_baseline present, shorter than 4096 characters, strings bounded."""
+    b = _bench_module()
+    detail = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_detail_r03.json")))
+    assert len(json.dumps(detail)) > 30000
+    line = b.compact_line(detail)
+    assert len(line) < LINE_LIMIT and "\n" not in line
+    d = json.loads(line)
+    assert KEYS <= set(d) and ROOF <= set(d["roofline"]) and {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"])
+    assert d["value"] == detail["value"] and d["ms_per_step"] == detail["ms_per_step"] and d["steps"] == detail["steps"]
+    assert "configs[1]" in d["config"]["workload"] and d["dtype"] == "f32" and d["detail"] == "bench_detail.json"
+    assert all(len(v) <= 160 for v in d["config"].values() if isinstance(v, str)) and len(d["cpu_baseline"]["sample"]) <= 120
+    assert set(d["roofline"]) == {"kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "avg_launch_us"}
+    assert set(d["legs"]) == set(detail["legs"])
+    for leg in list(d["legs"].values()) + [d["case_batch"]]:
+        assert {"value", "ms_per_step", "dtype", "l2_vs_oracle", "bound", "frac", "cpu"} <= set(leg)
+    # a pathological record (hundreds of legs, kilobyte strings) still yields a line the driver can keep
+    fat = dict(detail, legs={f"leg{i}": detail["legs"]["unet"] for i in range(300)})
+    fat["config"] = dict(detail["config"], workload="x" * 5000, geometry="y" * 5000)
+    fat["devices"] = ["0000:0d:00.0"] * 64
+    line = b.compact_line(fat)
+    assert len(line) < LINE_LIMIT and KEYS <= set(json.loads(line))
+
+
+def test_eight_ranks_dry_run(tmp_path):
+    """First contact of the N = 8 launch, rehearsed on the CPU: `bench.py --gpus 8 --dry-run` starts eight gloo ranks itself,
+    the process group reports 8, configs[3]'s 64 cases are sharded 8 per rank (rank 3 owns cases 24..31) and the N > 1 line
+    obeys the same length bound."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PSM_BENCH_BACKEND="gloo", PSM_BENCH_LOGDIR=str(tmp_path), OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "5", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert len(out.stdout) < LINE_LIMIT
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["world_size_reported"] == 8 and d["dry_run"] is True and len(d["devices"]) == 8
+    cb = d["case_batch"]
+    assert cb["total_cases"] == 64 and cb["cases_per_step_per_gpu"] == 8 and cb["shards"][3] == [24, 8]
+    assert [s[0] for s in cb["shards"]] == list(range(0, 64, 8)) and sum(s[1] for s in cb["shards"]) == 64
+    assert (tmp_path / "bench_detail.json").exists() and all((tmp_path / f"bench_rank{r}.err").exists() for r in range(8))
+
+
+def test_launcher_stops_its_ranks_when_it_is_terminated(tmp_path):
+    """SIGTERM to the launcher (an outer `timeout`): its ranks are stopped with it, none is left parked in a barrier."""
+    import signal
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PSM_BENCH_BACKEND="gloo", PSM_BENCH_LOGDIR=str(tmp_path), PSM_BENCH_DRY_SLEEP="60")
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "5", "--warmup", "1"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env)
+    pidfile = tmp_path / "rank_pids"
+    t_end = time.time() + 60
+    while time.time() < t_end and not (pidfile.exists() and len(pidfile.read_text().split()) == 2):
+        time.sleep(0.1)
+    pids = [int(x) for x in pidfile.read_text().split()]
+    assert len(pids) == 2
+    p.send_signal(signal.SIGTERM)
+    _, err = p.communicate(timeout=30)
+    assert p.returncode == 128 + signal.SIGTERM and "the ranks were stopped" in err
+    time.sleep(0.5)
+    for pid in pids:
+        try:
+            os.kill(pid, 0)
+            alive = open(f"/proc/{pid}/stat").read().split()[2] != "Z"
+        except (ProcessLookupError, FileNotFoundError):
+            alive = False
+        assert not alive, pid
 
 
 def test_gpus_n_starts_n_ranks_without_a_launcher():
@@ -72,7 +167,8 @@ def test_world_size_must_match_gpus():
 
 @pytest.mark.gpu
 def test_default_bench_line():
-    d = run_bench()
+    d, full = run_bench()
+    # ---- the line the driver parses
     assert KEYS <= set(d) and ROOF <= set(d["roofline"])
     assert d["metric"].startswith("pressure-solves/sec") and d["unit"] == "solves/s" and d["n_gpus"] == 1
     assert d["steps"] == 60 and d["warmup"] == 10 and d["higher_is_better"] is True and d["scaling"] == "weak"
@@ -80,36 +176,47 @@ def test_default_bench_line():
     assert d["value"] > 1000 and abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     assert "configs[1]" in d["config"]["workload"] and d["config"]["geometry"].startswith("bound once")
     assert "device-resident" in d["config"]["value_is"] and d["config"]["degenerate"].startswith("build-defined skip")
+    assert "x6" in d["config"]["arithmetic"] and d["config"]["guard_trips"] == 0
+    assert all(len(v) <= 160 for v in d["config"].values() if isinstance(v, str))
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    # the roofline kernel is the one with the largest measured time of the instrumented pass
-    top = max(r["kernels"], key=lambda k: k["avg_us"] * k["launches_per_solve"])
-    assert r["kernel"] == top["name"] and len(r["kernels"]) >= 6 and all(k["launches_per_solve"] == 1 for k in r["kernels"])
-    assert sum("#layer" in k["name"] for k in r["kernels"]) == 3          # dense 2, dense 3, head (layer 1 is fused with the slab reduction)
-    # the H2D / D2H-inclusive solve, and BASELINE configs[3]
-    e = d["end_to_end"]
-    assert d["value_end_to_end"] > 1000 and e["matches_device_resident_result"] is True
-    assert {"sync_pageable", "ring_pageable_depth4", "ring_registered_depth4", "ring_zero_copy_depth4"} <= set(e["solves_per_s_per_rank"])
-    cbat = d["case_batch"]
-    assert "configs[3]" in cbat["workload"] and cbat["cases_per_step_per_gpu"] == 8 and cbat["value"] > 1000
-    assert cbat["gathered_shape"] == [8, 256, 256, 1] and cbat["total_cases"] == 8 and cbat["guard_trips"] == 0
-    assert cbat["roofline"]["bound"] in ("mfma", "hbm") and cbat["roofline"]["frac"] > 0 and cbat["l2_vs_oracle"] < 1e-5
-    assert d["value_device_resident"] == d["value"] and len(d["devices"]) == 1 and d["config"]["guard_trips"] == 0
-    assert e["hw_queues"]["hip_initialised_before_it_was_set"] is False
-    legs = d["legs"]
-    assert set(legs) == {"config2", "config4", "unet", "unet8", "unet8_bf16", "unet512_bf16"}
-    for name, leg in legs.items():
-        assert leg["ms_per_step"] > 0 and leg["value"] > 100 and leg["l2_vs_oracle"] < (2e-2 if leg["dtype"] == "bf16" else 1e-5), name
-        assert ROOF <= set(leg["roofline"]) and 0 < leg["roofline"]["frac"] < 1, name
-    assert legs["unet512_bf16"]["grid"] == [512, 512] and legs["unet512_bf16"]["cpu_baseline"]["value"] > 0
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5
+    assert r["avg_launch_us"] > 0 and abs(r["algorithmic_bytes"] / (r["avg_launch_us"] * 1e-6) / 1e9 - r["achieved"]) < 1e-3 * r["achieved"]
     cb = d["cpu_baseline"]
-    assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] == "port" and cb["value"] > 0
-    assert d["l2_vs_oracle"] < 1e-5
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] == "port" and cb["value"] > 0 and len(cb["sample"]) <= 120
+    assert d["l2_vs_oracle"] < 1e-5 and d["value_end_to_end"] > 1000 and len(d["devices"]) == 1
+    cbat = d["case_batch"]
+    assert cbat["cases_per_step_per_gpu"] == 8 and cbat["value"] > 1000 and cbat["total_cases"] == 8 and cbat["guard_trips"] == 0
+    assert cbat["bound"] in ("mfma", "hbm") and 0 < cbat["frac"] < 1 and cbat["l2_vs_oracle"] < 1e-5
+    assert set(d["legs"]) == {"config2", "config4", "unet", "unet8", "unet8_bf16", "unet512_bf16"}
+    for name, leg in d["legs"].items():
+        assert leg["ms_per_step"] > 0 and leg["value"] > 100 and leg["l2_vs_oracle"] < (2e-2 if leg["dtype"] == "bf16" else 1e-5), name
+        assert leg["bound"] in ("mfma", "hbm") and 0 < leg["frac"] < 1 and 0 < leg["frac_pass"] < 1, name
+        assert (leg["cpu"] is not None and leg["cpu"] > 0) or name.startswith("config"), name
+    # ---- the full record (bench_detail.json)
+    assert full["value"] == d["value"] and full["ms_per_step"] == d["ms_per_step"]
+    fr = full["roofline"]
+    top = max(fr["kernels"], key=lambda k: k["avg_us"] * k["launches_per_solve"])
+    assert fr["kernel"] == top["name"] == r["kernel"] and len(fr["kernels"]) >= 5 and all(k["launches_per_solve"] == 1 for k in fr["kernels"])
+    assert all(k["peak_TFLOPs"] in (157.3, 2516.6 / 6) for k in fr["kernels"])            # every launch priced against its own pipe
+    assert all(k["achieved_TFLOPs"] is None or k["achieved_TFLOPs"] < k["peak_TFLOPs"] for k in fr["kernels"])
+    e = full["end_to_end"]
+    assert e["matches_device_resident_result"] is True and e["hw_queues"]["hip_initialised_before_it_was_set"] is False
+    assert {"sync_pageable", "ring_pageable_depth4", "ring_registered_depth4", "ring_zero_copy_depth4"} <= set(e["solves_per_s_per_rank"])
+    fc = full["case_batch"]
+    assert "configs[3]" in fc["workload"] and fc["gathered_shape"] == [8, 256, 256, 1]
+    assert "x6" in fc["roofline"]["kernel"] and abs(fc["roofline"]["peak"] - 2516.6 / 6) < 1e-6     # x6 launch: bf16 peak / 6
+    for name, leg in full["legs"].items():
+        assert ROOF <= set(leg["roofline"]), name
+        if name.startswith("unet"):
+            wp = leg["roofline"]["whole_pass"]
+            assert 0 < wp["frac"] < 1 and all(l["achieved_TFLOPs"] < l["peak_TFLOPs"] for l in leg["roofline"]["launches"]), name
+    assert full["legs"]["unet512_bf16"]["grid"] == [512, 512] and full["legs"]["unet512_bf16"]["cpu_baseline"]["value"] > 0
 
 
 @pytest.mark.gpu
 def test_general_path_and_conv_bench_lines():
-    d = run_bench("--no-bind", "--no-cpu-baseline")
+    d, _ = run_bench("--no-bind", "--no-cpu-baseline")
     assert d["config"]["geometry"].startswith("general path") and "cpu_baseline" not in d
-    u = run_bench("--workload", "unet", "--no-cpu-baseline")
-    assert KEYS <= set(u) and u["roofline"]["bound"] in ("mfma", "hbm") and u["roofline"]["whole_pass"]["achieved_TFLOPs"] > 1 and u["value"] > 100
+    u, full = run_bench("--workload", "unet", "--no-cpu-baseline")
+    assert KEYS <= set(u) and u["roofline"]["bound"] in ("mfma", "hbm") and u["value"] > 100 and "arithmetic" in u["config"]
+    assert full["roofline"]["whole_pass"]["achieved_TFLOPs"] > 1

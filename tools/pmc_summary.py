@@ -39,7 +39,7 @@ def _short(k):
     return k
 json.dump({"workload": "config1", "kernel_source_hash": _bench.kernel_source_hash(), "profile_tag": tag,
            "unit": "HBM-side bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024; separate --pmc passes with --kernel-trace only",
-           "kernels": {_short(r[0]): r[3] for r in rows}}, open("profiles/r03_pmc.json", "w"), indent=1)
+           "kernels": {_short(r[0]): r[3] for r in rows}}, open(_bench.PMC_FILE, "w"), indent=1)
 enc = [r for r in rows if "psm_encode_kernel" in r[0]][0]
 json.dump({"kernel": enc[0], "FETCH_SIZE_KB": enc[1], "WRITE_SIZE_KB": enc[2],
            "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B for 16-B/lane coalesced streams -> doubled (MI355X_MICROARCH.md HBM section); WRITE_SIZE exact",
@@ -48,7 +48,9 @@ json.dump({"kernel": enc[0], "FETCH_SIZE_KB": enc[1], "WRITE_SIZE_KB": enc[2],
            "profile_tag": tag, "all_kernels": allk}, open("profiles/pmc_encode.json", "w"), indent=1)
 st = sorted(glob.glob(f"{O}/stats/*/*kernel_stats.csv"))[-1]
 shutil.copy(st, f"profiles/{tag}_kernel_stats.csv")
-open(f"profiles/{tag}_bench.json.log", "w").write(open(f"{O}/bench.log").read().strip().splitlines()[-1] + "\n")
+open(f"profiles/{tag}_bench.json.log", "w").write([l for l in open(f"{O}/bench.log").read().strip().splitlines() if l.startswith("{")][-1] + "\n")
+if os.path.exists(f"{O}/detail_bench/bench_detail.json"):
+    shutil.copy(f"{O}/detail_bench/bench_detail.json", f"profiles/{tag}_bench_detail.json")
 for r in list(csv.DictReader(open(st)))[:10]:
     print(f"{r['Name'][:60]:60s} calls={int(r['Calls']):6d} avg_us={float(r['AverageNs'])/1e3:8.2f}")
 
@@ -60,6 +62,9 @@ if us:
 for name in ("bench_unet", "bench_unet8", "bench_unet8_bf16"):
     p = f"{O}/{name}.log"
     if os.path.exists(p):
-        lines = open(p).read().strip().splitlines()
+        lines = [l for l in open(p).read().strip().splitlines() if l.startswith("{")]
         if lines:
             open(f"profiles/{tag}_{name}.json.log", "w").write(lines[-1] + "\n")
+        dd = f"{O}/detail_{name[6:]}/bench_detail.json"
+        if os.path.exists(dd):
+            shutil.copy(dd, f"profiles/{tag}_{name}_detail.json")
