@@ -77,6 +77,14 @@ int psm_unet_profile(psm_unet* u, const float* d_grid, int32_t n_cases, float* d
  * an infinite activation or weight splits into (inf, NaN, NaN), so where the float32 MFMA would return +-inf an x6 layer
  * returns NaN (NaN stays NaN); magnitudes below 2^-110 lose the low planes to underflow. */
 int psm_unet_autotune(psm_unet* u, int32_t n_cases, int32_t iters, float* us_before, float* us_after);
+/* The planner's per-layer choices as psm_unet_autotune left them, so that a later process can REPLAY the plan instead of
+ * measuring again (the 1 % keep rule on measured medians makes the chosen plan run-dependent, and with it the float32
+ * summation order): choices [4 * num_convs] = per convolution {split-K cap 1..8, tile shape -1 (rule) / 0..2, pair -1 (rule)
+ * / 0 / 1, x6 -1 (rule) / 0 / 1}.  get: returns num_convs (n = capacity of choices, >= 4 * num_convs); set: n must be
+ * 4 * num_convs, re-plans at the planned size.  Two handles with the same weights, size and choices produce bit-identical
+ * fields. */
+int psm_unet_get_choices(const psm_unet* u, int32_t* choices, int32_t n);
+int psm_unet_set_choices(psm_unet* u, const int32_t* choices, int32_t n);
 int psm_unet_ksplit(const psm_unet* u, int32_t idx);
 int psm_unet_plan_info(const psm_unet* u, int32_t idx, int32_t* info);
 /* Dispatch-level time of every launch of the forward pass: `steps` passes on the handle's stream, each dispatch stamped with

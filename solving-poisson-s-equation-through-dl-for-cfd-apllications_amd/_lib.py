@@ -133,6 +133,8 @@ SIGNATURES_UNET = {
     "psm_unet_read_activation": (C.c_int, [_up, C.c_int32, _f32p, C.c_int64]),
     "psm_unet_profile": (C.c_int, [_up, C.c_void_p, C.c_int32, C.c_void_p, _f32p, _i32ptr]),
     "psm_unet_autotune": (C.c_int, [_up, C.c_int32, C.c_int32, _f32p, _f32p]),
+    "psm_unet_get_choices": (C.c_int, [_up, _i32ptr, C.c_int32]),
+    "psm_unet_set_choices": (C.c_int, [_up, _i32ptr, C.c_int32]),
     "psm_unet_ksplit": (C.c_int, [_up, C.c_int32]),
     "psm_unet_plan_info": (C.c_int, [_up, C.c_int32, _i32ptr]),
     "psm_unet_time_kernels": (C.c_int, [_up, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_double), _i32ptr, C.c_char_p]),

@@ -90,36 +90,55 @@ hipError_t psm_dev_free(void* p) {
 }
 
 // ---- bounce-buffer copies ---------------------------------------------------------------------------------------------
+// One pinned bounce buffer and one mutex PER DEVICE (handles on different GPUs upload and read back concurrently; threads on
+// the same GPU take turns).  The copies themselves stay legacy-stream hipMemcpy on purpose: like hipMemcpy they are ordered
+// after the caller's null-stream work -- psm_bind_geometry(on_device) reads a grid the caller may just have uploaded on
+// that stream -- and they return when the data has arrived.
 namespace {
 constexpr size_t BOUNCE_BYTES = (size_t)4 << 20;
-std::mutex g_bounce_mu;
-void* g_bounce = nullptr;
-hipError_t bounce_ready() {
-  if (g_bounce) return hipSuccess;
-  return hipHostMalloc(&g_bounce, BOUNCE_BYTES, hipHostMallocPortable);      // one per process, lives until exit
+constexpr int MAX_DEV = 64;
+struct Bounce { std::mutex mu; void* buf = nullptr; };
+Bounce g_bounce[MAX_DEV];
+hipError_t bounce_for_current_device(Bounce** out) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= MAX_DEV) return hipErrorInvalidDevice;
+  *out = &g_bounce[dev];
+  return hipSuccess;
+}
+hipError_t bounce_ready(Bounce& b) {                                           // called with b.mu held
+  if (b.buf) return hipSuccess;
+  return hipHostMalloc(&b.buf, BOUNCE_BYTES, hipHostMallocPortable);           // one per device, lives until exit
 }
 }  // namespace
 
 hipError_t psm_copy_h2d(void* dst_dev, const void* src_host, size_t bytes) {
   if (bytes == 0) return hipSuccess;
-  std::lock_guard<std::mutex> lk(g_bounce_mu);
-  hipError_t e = bounce_ready();
+  Bounce* b = nullptr;
+  hipError_t e = bounce_for_current_device(&b);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lk(b->mu);
+  e = bounce_ready(*b);
   for (size_t off = 0; e == hipSuccess && off < bytes; off += BOUNCE_BYTES) {
     const size_t n = bytes - off < BOUNCE_BYTES ? bytes - off : BOUNCE_BYTES;
-    std::memcpy(g_bounce, (const char*)src_host + off, n);
-    e = hipMemcpy((char*)dst_dev + off, g_bounce, n, hipMemcpyHostToDevice);
+    std::memcpy(b->buf, (const char*)src_host + off, n);
+    e = hipMemcpy((char*)dst_dev + off, b->buf, n, hipMemcpyHostToDevice);
   }
   return e;
 }
 
 hipError_t psm_copy_d2h(void* dst_host, const void* src_dev, size_t bytes) {
   if (bytes == 0) return hipSuccess;
-  std::lock_guard<std::mutex> lk(g_bounce_mu);
-  hipError_t e = bounce_ready();
+  Bounce* b = nullptr;
+  hipError_t e = bounce_for_current_device(&b);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lk(b->mu);
+  e = bounce_ready(*b);
   for (size_t off = 0; e == hipSuccess && off < bytes; off += BOUNCE_BYTES) {
     const size_t n = bytes - off < BOUNCE_BYTES ? bytes - off : BOUNCE_BYTES;
-    e = hipMemcpy(g_bounce, (const char*)src_dev + off, n, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) std::memcpy((char*)dst_host + off, g_bounce, n);
+    e = hipMemcpy(b->buf, (const char*)src_dev + off, n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) std::memcpy((char*)dst_host + off, b->buf, n);
   }
   return e;
 }
@@ -127,13 +146,16 @@ hipError_t psm_copy_d2h(void* dst_host, const void* src_dev, size_t bytes) {
 hipError_t psm_copy_d2h_2d(void* dst_host, size_t dpitch, const void* src_dev, size_t spitch, size_t width, size_t height) {
   if (width == 0 || height == 0) return hipSuccess;
   if (width > BOUNCE_BYTES) return hipErrorInvalidValue;
-  std::lock_guard<std::mutex> lk(g_bounce_mu);
-  hipError_t e = bounce_ready();
+  Bounce* b = nullptr;
+  hipError_t e = bounce_for_current_device(&b);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lk(b->mu);
+  e = bounce_ready(*b);
   const size_t rows_per = BOUNCE_BYTES / width;
   for (size_t r0 = 0; e == hipSuccess && r0 < height; r0 += rows_per) {
     const size_t nr = height - r0 < rows_per ? height - r0 : rows_per;
-    e = hipMemcpy2D(g_bounce, width, (const char*)src_dev + r0 * spitch, spitch, width, nr, hipMemcpyDeviceToHost);
-    for (size_t r = 0; e == hipSuccess && r < nr; ++r) std::memcpy((char*)dst_host + (r0 + r) * dpitch, (const char*)g_bounce + r * width, width);
+    e = hipMemcpy2D(b->buf, width, (const char*)src_dev + r0 * spitch, spitch, width, nr, hipMemcpyDeviceToHost);
+    for (size_t r = 0; e == hipSuccess && r < nr; ++r) std::memcpy((char*)dst_host + (r0 + r) * dpitch, (const char*)b->buf + r * width, width);
   }
   return e;
 }

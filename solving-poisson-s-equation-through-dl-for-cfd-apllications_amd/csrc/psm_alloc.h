@@ -3,7 +3,8 @@
 // environment (diagnostic; read once) every allocation gets its own virtual-address reservation with an UNMAPPED granule
 // behind it and the buffer is placed at the END of the mapped part (16-byte granularity), so a kernel that reads or writes
 // past the end of any library buffer takes a GPU page fault at that instruction instead of silently touching a neighbour;
-// freed ranges are never handed out again, so a use after free faults too:
+// freed ranges are never handed out again, so a use after free faults too.  NOTE: in guard mode (kind 1) a buffer is only
+// 16-byte aligned (it ends where the mapping ends), not 256-byte like hipMalloc's: kernels must not assume more than that.
 // the GPU address sanitizer is not available on this pool, this is its stand-in for the out-of-bounds-past-the-end class.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -11,7 +12,7 @@
 
 hipError_t psm_dev_malloc(void** p, size_t bytes);
 // Synchronous copies between device memory and ORDINARY (pageable) host memory, through a pinned bounce buffer owned by the
-// library.  hipMemcpy on pageable memory lets the runtime pin the caller's pages for the DMA engine on the fly (copies of
+// library (one per device, with its own mutex: handles on different GPUs do not serialise each other).  hipMemcpy on pageable memory lets the runtime pin the caller's pages for the DMA engine on the fly (copies of
 // 1 MiB and more) and cache those mappings by address; in a long-lived process whose heap addresses get reused that path
 // produced "Memory access fault ... Write access to a read-only page" on a HOST address during a device-to-host copy
 // (seen twice in ten runs of the GPU test suite, never with these).  With the bounce buffer the GPU only ever touches memory

@@ -1007,17 +1007,21 @@ int psm_set_conv1d(psm_handle* h, int32_t layer, int32_t n_layers, int32_t kerne
     return fail(h, PSM_ERR_ARG, "bad Conv1D layer");
   if (h->cfg.precision != PSM_PRECISION_F32) return fail(h, PSM_ERR_UNSUPPORTED, "the conv1D_PCA head is float32 only");
   if ((int64_t)h->cfg.p_in * c_out > (1 << 18)) return fail(h, PSM_ERR_UNSUPPORTED, "Conv1D activation wider than 2^18 per block");
+  // every argument check comes BEFORE the handle is touched: a rejected call leaves graphs, binding, stack and plan as they were
+  if (layer == 0 && c_in != 1) return fail(h, PSM_ERR_ARG, "the first Conv1D layer sees the coefficients as [p_in, 1]: c_in must be 1");
+  const bool same_stack = (int)h->conv1d.size() == n_layers;
+  if (same_stack && layer > 0 && h->conv1d[layer - 1].set && h->conv1d[layer - 1].cout != c_in) return fail(h, PSM_ERR_ARG, "Conv1D layers do not chain");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   destroy_graphs(h);
   h->bound = false;
-  if ((int)h->conv1d.size() != n_layers) {
+  if (!same_stack) {
     for (auto& c : h->conv1d) { dev_free(c.W); dev_free(c.b); }
     h->conv1d.assign(n_layers, Conv1dLayer{});
-    if (h->planned) free_plan(h);                        // the workspaces depend on the stack
   }
-  if (layer == 0 && c_in != 1) return fail(h, PSM_ERR_ARG, "the first Conv1D layer sees the coefficients as [p_in, 1]: c_in must be 1");
-  if (layer > 0 && h->conv1d[layer - 1].set && h->conv1d[layer - 1].cout != c_in) return fail(h, PSM_ERR_ARG, "Conv1D layers do not chain");
+  // the workspaces (c1_stride, d_c1[]) are sized from p_in * c_out of every layer: a new stack, or the same stack with another
+  // filter count, needs a new plan: the plan is dropped and the next solve fails with PSM_ERR_STATE until psm_plan_grid is called again
+  if (h->planned && (!same_stack || !h->conv1d[layer].set || h->conv1d[layer].cout != c_out)) free_plan(h);
   Conv1dLayer& c = h->conv1d[layer];
   c.k = kernel_size; c.cin = c_in; c.cout = c_out;
   std::vector<float> W(kernel, kernel + (size_t)kernel_size * c_in * c_out), b(bias, bias + c_out);

@@ -774,9 +774,14 @@ int psm_unet_autotune(psm_unet* u, int32_t n_cases, int32_t iters, float* us_bef
   // 3. split-K depth
   for (size_t i = 0; i < u->convs.size(); ++i) {
     while (u->convs[i].ksplit > 1) {
-      const int old_cap = u->ksplit_cap[i], cand = u->convs[i].ksplit / 2;
+      const int old_cap = u->ksplit_cap[i], old_split = u->convs[i].ksplit, cand = old_split / 2;
       u->ksplit_cap[i] = cand;
       if ((rc = psm_unet_plan(u, ny, nx, mc))) return rc;
+      if (u->convs[i].ksplit >= old_split) {                      // the cap did not bind (a layer pinned by PSM_UNET_FORCE): the plan is the
+        u->ksplit_cap[i] = old_cap;                               // one just measured -- re-measuring it would only chase timing noise
+        if ((rc = psm_unet_plan(u, ny, nx, mc))) return rc;
+        break;
+      }
       double t = 0.0;
       if ((rc = measure(&t))) return rc;
       if (t < best * 0.99) { best = t; continue; }                // keep the shallower split, try one more halving
@@ -787,6 +792,39 @@ int psm_unet_autotune(psm_unet* u, int32_t n_cases, int32_t iters, float* us_bef
   }
   if (us_after) *us_after = (float)best;
   return PSM_OK;
+}
+
+int psm_unet_get_choices(const psm_unet* u, int32_t* choices, int32_t n) {
+  if (!u || !choices) return PSM_ERR_ARG;
+  if (!u->planned) return PSM_ERR_STATE;
+  const size_t nc = u->convs.size();
+  if (n < (int32_t)(4 * nc)) return PSM_ERR_ARG;
+  for (size_t i = 0; i < nc; ++i) {
+    choices[4 * i + 0] = u->ksplit_cap.size() == nc ? u->ksplit_cap[i] : 8;
+    choices[4 * i + 1] = u->tile_choice.size() == nc ? u->tile_choice[i] : -1;
+    choices[4 * i + 2] = u->pair_choice.size() == nc ? u->pair_choice[i] : -1;
+    choices[4 * i + 3] = u->x6_choice.size() == nc ? u->x6_choice[i] : -1;
+  }
+  return (int)nc;
+}
+
+int psm_unet_set_choices(psm_unet* u, const int32_t* choices, int32_t n) {
+  if (!u || !choices) return PSM_ERR_ARG;
+  if (!u->planned) return fail(u, PSM_ERR_STATE, "psm_unet_plan has not been called");
+  const size_t nc = u->convs.size();
+  if (n != (int32_t)(4 * nc)) return fail(u, PSM_ERR_ARG, "choices must hold 4 values per convolution");
+  for (size_t i = 0; i < nc; ++i) {
+    const int32_t* c = choices + 4 * i;
+    if (c[0] < 1 || c[0] > 8 || c[1] < -1 || c[1] > 2 || c[2] < -1 || c[2] > 1 || c[3] < -1 || c[3] > 1)
+      return fail(u, PSM_ERR_ARG, "choice out of range (split cap 1..8, tile -1..2, pair -1..1, x6 -1..1)");
+  }
+  u->ksplit_cap.assign(nc, 8); u->tile_choice.assign(nc, -1); u->pair_choice.assign(nc, -1); u->x6_choice.assign(nc, -1);
+  for (size_t i = 0; i < nc; ++i) {
+    u->ksplit_cap[i] = choices[4 * i]; u->tile_choice[i] = choices[4 * i + 1];
+    u->pair_choice[i] = choices[4 * i + 2]; u->x6_choice[i] = choices[4 * i + 3];
+  }
+  UCHK(u, hipSetDevice(u->device));
+  return psm_unet_plan(u, u->ny, u->nx, u->max_cases);
 }
 
 int psm_unet_ksplit(const psm_unet* u, int32_t idx) {

@@ -28,7 +28,7 @@ class UNetSurrogate:
 
     def __init__(self, weights, ny: int, nx: int, c_in: int = 3, c_out: int = 1, widths: Sequence[int] = WIDTHS_S,
                  max_cases: int = 1, device: int = 0, precision: str = "f32", keep_activations: bool = False,
-                 autotune: bool = False):
+                 autotune: bool = False, choices=None):
         self.lib = _lib.load()
         self.ny, self.nx, self.c_in, self.c_out, self.max_cases = int(ny), int(nx), int(c_in), int(c_out), int(max_cases)
         w = np.ascontiguousarray(widths, np.int32)
@@ -61,6 +61,8 @@ class UNetSurrogate:
                 self.autotuned = {"us_before": float(b.value), "us_after": float(a.value),
                                   "ksplit": [int(self.lib.psm_unet_ksplit(self.h, i)) for i in range(n)],
                                   "plan": [self.plan_info(i) for i in range(n)]}
+            if choices is not None:            # replay of a plan an earlier (autotuned) handle reported: bit-identical fields
+                self.set_choices(choices)
         except Exception:
             self.close()
             raise
@@ -137,6 +139,21 @@ class UNetSurrogate:
         wg = np.zeros(len(self.shapes), np.int32)
         self._chk(self.lib.psm_unet_profile(self.h, d_grid, n_cases, d_field, _p(ms), _p(wg, C.c_int32)))
         return ms, wg
+
+    def get_choices(self):
+        """The planner's per-layer choices (psm_unet_get_choices): [[split-K cap, tile, pair, x6]] per convolution -- what
+        psm_unet_autotune decided; feed it to ``UNetSurrogate(..., choices=...)`` / ``set_choices`` to replay the plan."""
+        n = len(self.shapes)
+        buf = (C.c_int32 * (4 * n))()
+        rc = self.lib.psm_unet_get_choices(self.h, buf, 4 * n)
+        if rc != n:
+            self._chk(rc if rc < 0 else -1)
+        return [[int(buf[4 * i + j]) for j in range(4)] for i in range(n)]
+
+    def set_choices(self, choices):
+        flat = [int(v) for row in choices for v in row]
+        buf = (C.c_int32 * len(flat))(*flat)
+        self._chk(self.lib.psm_unet_set_choices(self.h, buf, len(flat)))
 
     def plan_info(self, idx: int):
         """(tile rows, channel tiles per workgroup, split-K, role) of convolution idx in the current plan; role & 3 = pair role

@@ -343,6 +343,33 @@ def test_gpu_unet_autotuned_plan_keeps_the_result(precision, ny, nx, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_gpu_unet_autotuned_plan_can_be_replayed_bit_identically(precision):
+    """The autotuner's choices are run-dependent (a 1 % rule on measured medians); psm_unet_get_choices / set_choices let a
+    second handle replay them without measuring: same plan, bit-identical field.  Bad choices are rejected and leave the
+    plan as it was."""
+    from psm_amd import UNetSurrogate
+    W = uo.he_weights(uo.unet_specs(), seed=17)
+    ny, nx = 256, 256
+    grid = synthetic.channel_grid(ny, nx, seed=5, noise=0.05).astype(np.float32)[None]
+    with UNetSurrogate(W, ny, nx, precision=precision, autotune=True) as net:
+        tuned = net.forward(grid)
+        choices = net.get_choices()
+        plan = [net.plan_info(i) for i in range(len(net.shapes))]
+    assert len(choices) == 19 and all(len(c) == 4 and 1 <= c[0] <= 8 for c in choices)
+    with UNetSurrogate(W, ny, nx, precision=precision, choices=choices) as net:
+        assert [net.plan_info(i) for i in range(len(net.shapes))] == plan and net.get_choices() == choices
+        replay = net.forward(grid)
+        with pytest.raises(Exception):
+            net.set_choices([[9, -1, -1, -1]] * 19)
+        with pytest.raises(Exception):
+            net.set_choices(choices[:-1])
+        assert [net.plan_info(i) for i in range(len(net.shapes))] == plan
+        assert np.array_equal(net.forward(grid), replay)
+    assert np.array_equal(replay, tuned)
+
+
+@pytest.mark.gpu
 def test_gpu_unet_x6_layers_keep_float32_accuracy(monkeypatch):
     """float32 mode: layers with at least 64 input channels and an 8-row tile run their contractions on the bf16 matrix pipe
     with operands split exactly into three bf16 planes (six MFMA terms per product).  Same oracle, same float32 tolerances,
