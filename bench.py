@@ -319,7 +319,7 @@ def oracle_model(model):
     from oracle import psm_oracle as orc
     sc = orc.Scaler(model.scaler_kind, model.in_a, model.in_b, model.out_a, model.out_b)
     return orc.Model(model.variant, model.c_in, model.c_out, model.comp_in, model.mean_in, model.comp_out,
-                     model.mean_out, model.weights, sc, model.out_scale, model.S, model.ov, model.sdf_ch, getattr(model, "conv1d", ()))
+                     model.mean_out, model.weights, sc, model.out_scale, model.S, model.ov, model.sdf_ch, getattr(model, "conv1d", ()), getattr(model, "attention", None))
 
 
 def cpu_baseline(model, grid, precision="f32", budget_s=12.0, max_solves=4000):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PSM_ABI_VERSION 3
+#define PSM_ABI_VERSION 4
 
 /* block layout + reassembly variant */
 #define PSM_VARIANT_CHAPTER5 0 /* PM:303-332, 373-472 */
@@ -110,6 +110,26 @@ int psm_set_pca(psm_handle* h, const double* comp_in, const double* mean_in,
 /* Keras Dense kernel [n_in, n_out] row-major and bias [n_out]; layer in [0, n_dense). */
 int psm_set_dense(psm_handle* h, int32_t layer, int32_t n_in, int32_t n_out,
                   const float* kernel, const float* bias);
+/* densePCA_attention ('MLP_attention' of utils.py:455-457; Improved_SM/deltaU_to_deltaP/source/pressureSM_deltas/NNs.py:40-72):
+ *   x0 = relu(Dense(depth[0])(inputs));  a = LayerNormalization()(MultiHeadAttention(8, 64)(x0[:, None], x0[:, None]))[:, 0]
+ *   for i in 1 .. n_layers-1:  x = relu(Dense(depth[i])(a));  a = LayerNormalization()(x + a)
+ *   outputs = Dense(PC_p)(a)
+ * maps onto n_dense = n_layers + 2 layers of this handle: layer 0 = the first Dense, layer 1 = the attention block
+ * (psm_set_attention), layers 2 .. n_layers = the further Dense layers, the last layer = the head; psm_set_layernorm on layers
+ * 1 .. n_layers (residual = 0 on layer 1, 1 behind the others).
+ * psm_set_attention: the attention runs over a sequence of length 1 (NNs.py:54), so its softmax is exactly 1 and the query / key
+ * projections do not enter the result: out = (x . Wv + bv) . Wo + bo.  Wv [d_model, n_heads, value_dim], bv [n_heads, value_dim]
+ * (Keras `value` EinsumDense), Wo [n_heads, value_dim, d_model], bo [d_model] (`attention_output`), float32 row-major.  Folded
+ * on the host (float64) into one affine layer without activation in Dense slot `layer` (0 < layer < n_dense - 1).
+ * psm_set_layernorm: Keras LayerNormalization over the last axis behind hidden layer `layer` (call after that layer was set):
+ *   act = (v - mean(v)) * rsqrt(var(v) + epsilon) * gamma + beta,   v = layer output (after its activation) [+ the layer's own
+ *   input when residual != 0 -- NNs.py:64 `x + attn_output`; the layer must then be square], biased variance, float32;
+ *   n = the layer's n_out, gamma / beta [n], epsilon > 0 (Keras default 1e-3).
+ * Both: float32 and bf16 handles (the normalisation itself is float32 in both); the geometry-bound path is kept. */
+int psm_set_attention(psm_handle* h, int32_t layer, int32_t d_model, int32_t n_heads, int32_t value_dim,
+                      const float* Wv, const float* bv, const float* Wo, const float* bo);
+int psm_set_layernorm(psm_handle* h, int32_t layer, int32_t n, const float* gamma, const float* beta, float epsilon,
+                      int32_t residual);
 /* conv1D_PCA head (NNs.py:75-124; architecture 'conv1D' of utils.py:452-454: 7 layers of 128-64-32-16-32-64-128 filters):
  * n_layers Conv1D layers (kernel_size taps, 'same' padding, ReLU) over the p_in scaled PCA coefficients seen as a sequence
  * [p_in, 1], then Flatten ([p_in, filters] row-major: index p * filters + c) and the Dense layers of psm_set_dense (the
@@ -234,6 +254,17 @@ int psm_reassemble(psm_handle* h, const float* grid, const float* block_pred, fl
  * reference's self-check of the assembly ("it should be almost perfect in that case", SMD:577-580; live form
  * UGP:546-547 test_dPdx / test_dPdy).  Host buffers, synchronous. */
 int psm_label_blocks(psm_handle* h, const float* grid, const float* labels, float* blocks_out);
+/* compute_in_block_error (Improved_SM/deltaU_to_deltaP/source/pressureSM_deltas/utils.py:210-243, called at SM_call.py:555-557):
+ * the error of the DECODED BLOCKS of the last solve (case 0; on a bound geometry the blocks are decoded again from the stored
+ * network output) against the label blocks, before any reassembly.  grid [ny, nx, c_in] = the grid that was solved (flow
+ * cells: SDF channel != 0), labels [ny, nx, c_out] in the network's normalised output units; the label blocks are taken and
+ * de-meaned like psm_label_blocks and multiplied by the solve's out_scale (SM_call.py:555: y_array * max_abs_p * U_max_norm^2).
+ * Over the flow cells of all blocks, NaN differences left out, norm = max(true) - min(true):
+ *   out[0] = mean(pred - true) / norm            (what the reference appends to pred_minus_true_block)
+ *   out[1] = mean((pred - true)^2) / norm^2      (pred_minus_true_squared_block)
+ *   out[2] = norm (norm_true), out[3] = max(pred) - min(pred) (norm_pred), out[4] = number of differences.
+ * float64 accumulation; evaluation only (host buffers, synchronous). */
+int psm_block_error(psm_handle* h, const float* grid, const float* labels, double* out);
 /* ---- mesh-side entry: the contract of PythonComm_init.H / PythonComm.H ------------
  * psm_set_geometry installs the one-time tables that init_func builds (PM:195-243):
  *   vtx_m2g/wts_m2g [ny*nx,3]  simplices + barycentric weights, mesh -> grid (interp_weights, PM:210)

@@ -46,6 +46,8 @@ class CpuModel:
     def __init__(self, om, strict: bool = False):
         if len(getattr(om, "conv1d", ())):
             raise ValueError("psm_cpu.c restates the Dense stacks only (the conv1D_PCA head is covered by the NumPy oracle)")
+        if getattr(om, "attention", None):
+            raise ValueError("psm_cpu.c restates the Dense stacks only (densePCA_attention is covered by the NumPy oracle)")
         f64 = lambda a, n=None: np.ascontiguousarray(np.broadcast_to(np.asarray(a, np.float64), (n,)) if n else a, np.float64)
         self.keep = [f64(om.comp_in), f64(om.mean_in), f64(om.comp_out), f64(om.mean_out),
                      f64(om.scaler.in_a, om.comp_in.shape[0]), f64(om.scaler.in_b, om.comp_in.shape[0]),

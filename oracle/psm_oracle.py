@@ -200,6 +200,7 @@ class Model:
     ov: int | None = None
     sdf_ch: int = 2
     conv1d: Sequence[Tuple[np.ndarray, np.ndarray]] = ()   # conv1D_PCA head (NNS:75-124): [(K[k, c_in, c_out] f32, b[c_out] f32)]
+    attention: dict | None = None     # densePCA_attention (NNS:40-72): MultiHeadAttention + LayerNormalization parameters
 
     def overlap(self) -> int:
         return default_overlap(self.variant, self.S) if self.ov is None else self.ov
@@ -228,11 +229,64 @@ def conv1d_forward(x: np.ndarray, convs) -> np.ndarray:
     return h.reshape(B, -1)
 
 
-def mlp_forward(x: np.ndarray, weights, conv1d=()) -> np.ndarray:
+def multi_head_attention(q_in: np.ndarray, kv_in: np.ndarray, att: dict) -> np.ndarray:
+    """``tf.keras.layers.MultiHeadAttention(num_heads, key_dim)(query, value)`` as Keras defines it (third-party, un-vendored;
+    call site NNS:55 with query = value = x[:, None, :]): EinsumDense projections to [batch, seq, heads, dim] with bias,
+    scores = (q / sqrt(dim)) . k over dim, softmax over the KEY axis, context = scores . v, EinsumDense output projection
+    [heads, dim] -> d with bias.  float32.  q_in [B, T, d], kv_in [B, S, d] -> [B, T, d]."""
+    f = lambda a: np.asarray(a, np.float32)
+    q = np.einsum("btd,dhk->bthk", f(q_in), f(att["Wq"])) + f(att["bq"])
+    k = np.einsum("bsd,dhk->bshk", f(kv_in), f(att["Wk"])) + f(att["bk"])
+    v = np.einsum("bsd,dhk->bshk", f(kv_in), f(att["Wv"])) + f(att["bv"])
+    scores = np.einsum("bthk,bshk->bhts", q * np.float32(1.0 / np.sqrt(q.shape[-1])), k)
+    scores = np.exp(scores - scores.max(axis=-1, keepdims=True))
+    scores = (scores / scores.sum(axis=-1, keepdims=True)).astype(np.float32)
+    ctx = np.einsum("bhts,bshk->bthk", scores, v)
+    return (np.einsum("bthk,hkd->btd", ctx, f(att["Wo"])) + f(att["bo"])).astype(np.float32)
+
+
+def layer_normalization(x: np.ndarray, gamma, beta, eps: float = 1e-3) -> np.ndarray:
+    """``tf.keras.layers.LayerNormalization()`` (NNS:56, 64; Keras defaults: axis -1, epsilon 1e-3, center, scale): moments over
+    the last axis (biased variance), (x - mean) * rsqrt(var + eps) * gamma + beta, float32."""
+    x = np.asarray(x, np.float32)
+    mean = x.mean(axis=-1, keepdims=True, dtype=np.float32)
+    var = np.mean((x - mean) ** 2, axis=-1, keepdims=True, dtype=np.float32)
+    return ((x - mean) / np.sqrt(var + np.float32(eps)) * np.asarray(gamma, np.float32) + np.asarray(beta, np.float32)).astype(np.float32)
+
+
+def mlp_attention_forward(x: np.ndarray, weights, att: dict, rnd=None) -> np.ndarray:
+    """``densePCA_attention`` (NNS:40-72) at inference (Dropout = identity): ``weights`` = its n_layers Dense layers and the
+    head, ``att`` = the MultiHeadAttention and the LayerNormalizations.  ``rnd`` (None = the reference's float32 network):
+    rounding of the operands entering a contraction, for the emulation of the library's bf16 mode -- which runs the
+    attention block as ONE folded affine layer (its softmax over a single key is 1), so that is what is rounded."""
+    f = lambda a: np.asarray(a, np.float32)
+    if rnd is None:
+        dense = lambda h, W, b: h @ f(W) + f(b)
+    else:
+        dense = lambda h, W, b: (rnd(h).astype(np.float64) @ rnd(f(W)).astype(np.float64)).astype(np.float32) + f(b)
+    eps = att.get("eps", 1e-3)
+    h = np.maximum(dense(f(x), *weights[0]), np.float32(0))                     # NNS:49
+    if rnd is None:                                                               # the block as Keras runs it
+        a = multi_head_attention(h[:, None, :], h[:, None, :], att)[:, 0, :]      # NNS:54-55, 57
+    else:                                                                         # bf16 emulation: the folded affine layer
+        HV = int(np.prod(np.shape(att["Wv"])[1:]))
+        Wf = f(att["Wv"]).reshape(-1, HV).astype(np.float64) @ f(att["Wo"]).reshape(HV, -1).astype(np.float64)
+        bfold = f(att["bv"]).reshape(-1).astype(np.float64) @ f(att["Wo"]).reshape(HV, -1).astype(np.float64) + f(att["bo"])
+        a = dense(h, Wf.astype(np.float32), bfold.astype(np.float32))
+    a = layer_normalization(a, *att["ln"][0], eps)                               # NNS:56
+    for i in range(1, len(weights) - 1):                                          # NNS:60-64
+        xi = np.maximum(dense(a, *weights[i]), np.float32(0))
+        a = layer_normalization(xi + a, *att["ln"][i], eps)
+    return dense(a, *weights[-1])                                                 # NNS:66
+
+
+def mlp_forward(x: np.ndarray, weights, conv1d=(), attention=None) -> np.ndarray:
     """Keras ``Dense`` stack (PM:121-134, NNS:8-38): relu(x@W+b) for every layer
     but the last, which is linear.  float32 like Keras (floatx).  ``conv1d``: the Conv1D layers of the conv1D_PCA head
     in front of it (NNS:75-124)."""
     h = np.asarray(x, dtype=np.float32)
+    if attention:
+        return mlp_attention_forward(h, weights, attention)
     if len(conv1d):
         h = conv1d_forward(h, conv1d)
     n = len(weights)
@@ -241,6 +295,33 @@ def mlp_forward(x: np.ndarray, weights, conv1d=()) -> np.ndarray:
         if li != n - 1:
             h = np.maximum(h, np.float32(0))
     return h
+
+
+def label_blocks(grid: np.ndarray, labels: np.ndarray, lay: "Layout", c_in: int, sdf_ch: int = 2) -> np.ndarray:
+    """SMD:483-489 (UGP:509-511): the label image cut into the layout's blocks, each de-meaned over its flow cells
+    (``y -= mean(y[x[..., sdf] != 0])``; a block without flow cells keeps its values).  -> [B, S, S, c_out] float64."""
+    lab = np.asarray(labels, np.float64)
+    lab = lab[..., None] if lab.ndim == 2 else lab
+    xb = extract_blocks(np.asarray(grid, np.float64), lay, c_in)
+    yb = extract_blocks(lab, lay, lab.shape[-1]).copy()
+    for b in range(lay.B):
+        m = xb[b, :, :, sdf_ch] != 0
+        if m.any():
+            for ch in range(yb.shape[-1]):
+                yb[b, :, :, ch][m] -= np.mean(yb[b, :, :, ch][m])
+    return yb
+
+
+def compute_in_block_error(pred: np.ndarray, true: np.ndarray, flow_bool: np.ndarray):
+    """``utils.compute_in_block_error`` (pressureSM_deltas/utils.py:210-243; call site SMD:553-557): over the flow cells of all
+    blocks, norm = max(true) - min(true), NaN differences left out -> (mean(pred - true) / norm, mean((pred - true)^2) / norm^2),
+    the two values the evaluator appends to ``pred_minus_true_block`` / ``pred_minus_true_squared_block``."""
+    fb = np.broadcast_to(flow_bool, np.shape(true))
+    t, p = np.asarray(true)[fb], np.asarray(pred)[fb]
+    norm = np.max(t) - np.min(t)
+    d = p - t
+    d = d[~np.isnan(d)]
+    return float(np.mean(d) / norm), float(np.mean(d ** 2) / norm ** 2)
 
 
 def pca_decode(res: np.ndarray, comp_out: np.ndarray, mean_out: np.ndarray, S: int, c_out: int) -> np.ndarray:
@@ -539,10 +620,13 @@ def solve_grid(grid: np.ndarray, model: Model, degenerate: str = "skip", precisi
         coeff = bf16_round(flat).astype(np.float64) @ bf16_round(model.comp_in).astype(np.float64).T
         x_in = model.scaler.fwd(coeff)
         h = np.asarray(x_in, np.float32)
-        for li, (W, b) in enumerate(model.weights):
-            h = (bf16_round(h).astype(np.float64) @ bf16_round(W).astype(np.float64)).astype(np.float32) + np.asarray(b, np.float32)
-            if li != len(model.weights) - 1:
-                h = np.maximum(h, np.float32(0))
+        if model.attention:
+            h = mlp_attention_forward(h, model.weights, model.attention, rnd=bf16_round)
+        else:
+            for li, (W, b) in enumerate(model.weights):
+                h = (bf16_round(h).astype(np.float64) @ bf16_round(W).astype(np.float64)).astype(np.float32) + np.asarray(b, np.float32)
+                if li != len(model.weights) - 1:
+                    h = np.maximum(h, np.float32(0))
         res = h
         dec_in = model.scaler.inv(res.astype(np.float64))
         flat_out = bf16_round(dec_in).astype(np.float64) @ bf16_round(model.comp_out).astype(np.float64) + model.mean_out
@@ -550,7 +634,7 @@ def solve_grid(grid: np.ndarray, model: Model, degenerate: str = "skip", precisi
     elif precision == "f32":
         coeff = pca_encode(xb, model.comp_in, model.mean_in)
         x_in = model.scaler.fwd(coeff)
-        res = mlp_forward(x_in, model.weights, model.conv1d)
+        res = mlp_forward(x_in, model.weights, model.conv1d, model.attention)
         dec_in = model.scaler.inv(res.astype(np.float64))
         bp = pca_decode(dec_in, model.comp_out, model.mean_out, model.S, model.c_out) * model.out_scale
     else:

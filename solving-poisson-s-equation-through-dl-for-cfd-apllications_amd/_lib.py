@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("PSM_LIB") or os.path.join(HERE, "libpsm_hip.so")   # 
 HEADER = os.path.join(os.path.dirname(HERE), "include", "psm.h")
 HEADER_UNET = os.path.join(os.path.dirname(HERE), "include", "psm_unet.h")
 
-PSM_ABI_VERSION = 3
+PSM_ABI_VERSION = 4
 VARIANTS = {"chapter5": 0, "deltas": 1, "gradp": 2}
 SCALERS = {"max_abs": 0, "std": 1, "min_max": 2}
 PRECISIONS = {"f32": 0, "bf16": 1}
@@ -51,6 +51,8 @@ SIGNATURES = {
     "psm_last_error": (C.c_char_p, [_hp]),
     "psm_set_pca": (C.c_int, [_hp, _f64p, _f64p, _f64p, _f64p]),
     "psm_set_dense": (C.c_int, [_hp, C.c_int32, C.c_int32, C.c_int32, _f32p, _f32p]),
+    "psm_set_attention": (C.c_int, [_hp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f32p, _f32p, _f32p, _f32p]),
+    "psm_set_layernorm": (C.c_int, [_hp, C.c_int32, C.c_int32, _f32p, _f32p, C.c_float, C.c_int32]),
     "psm_set_conv1d": (C.c_int, [_hp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f32p, _f32p]),
     "psm_set_scaler": (C.c_int, [_hp, _f64p, _f64p, _f64p, _f64p]),
     "psm_plan_grid": (C.c_int, [_hp, C.c_int32, C.c_int32]),
@@ -75,6 +77,7 @@ SIGNATURES = {
     "psm_solve_grid_device": (C.c_int, [_hp, C.c_void_p, C.c_int32, _f32p, C.c_void_p, C.c_void_p]),
     "psm_reassemble": (C.c_int, [_hp, _f32p, _f32p, _f32p]),
     "psm_label_blocks": (C.c_int, [_hp, _f32p, _f32p, _f32p]),
+    "psm_block_error": (C.c_int, [_hp, _f32p, _f32p, C.POINTER(C.c_double)]),
     "psm_set_geometry": (C.c_int, [_hp, C.c_int64, C.c_int32, C.c_int32, _i32p, _f64p, _i32p, _f64p, _i32p, _f64p, _f64p,
                                    C.c_int32, C.c_int32, C.c_double]),
     "psm_set_case": (C.c_int, [_hp, _f64p, C.c_double, C.c_int32, C.c_double]),

@@ -41,6 +41,11 @@ struct DenseLayer {
   void* Wp = nullptr;      // MFMA-packed copy, see psm_dense_kernel
   float* b = nullptr;
   bool set = false;
+  bool linear = false;     // hidden layer without ReLU (the folded attention block of densePCA_attention)
+  // LayerNormalization behind this layer (densePCA_attention, NNs.py:56, 64): act = LN(act [+ this layer's input]) * gamma + beta
+  bool ln = false, ln_residual = false;
+  float *ln_gamma = nullptr, *ln_beta = nullptr;
+  float ln_eps = 1e-3f;
 };
 
 struct Conv1dLayer {            // conv1D_PCA head (NNs.py:75-124)
@@ -575,7 +580,7 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
     da.in = cur; da.ld_in = ld_cur; da.W = d.W; da.ld_w = d.ldw; da.bias = d.b; da.Wp = d.Wp; da.Kp = d.Kp;
     da.sa = h->d_sa; da.sb = h->d_sb;
     da.out = head ? w.d_res : w.d_act[l & 1]; da.ld_out = d.ldw;
-    da.Kpad = d.Kpad; da.Mpad = Mpad; da.relu = head ? 0 : 1; da.head = head ? 1 : 0;
+    da.Kpad = d.Kpad; da.Mpad = Mpad; da.relu = (head || d.linear) ? 0 : 1; da.head = head ? 1 : 0;
     da.bf16 = (h->cfg.precision == PSM_PRECISION_BF16) ? 1 : 0;
     da.layer = l;
     return da;
@@ -612,14 +617,31 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
       }
       ld_cur = (int)stride;
     }
+    // LayerNormalization (+ residual with the layer's own input) behind a hidden layer: densePCA_attention
+    auto layer_norm = [&](int l, float* act, const float* layer_in, int ld_layer_in) -> int {
+      const DenseLayer& d = h->dense[l];
+      if (!d.ln) return PSM_OK;
+      PsmLayerNormArgs la{act, d.ldw, d.ln_residual ? layer_in : nullptr, ld_layer_in, d.ln_gamma, d.ln_beta, Mpad, d.n_out, d.ln_eps};
+      HIPCHK(h, psm_launch_layernorm(la, st));
+      return PSM_OK;
+    };
     if (fuse1) {
       PsmDenseArgs d0 = dense_args(0, cur, ld_cur);
       HIPCHK(h, psm_launch_reduce_dense1(ra, d0, st));
+      int rc0 = layer_norm(0, d0.out, cur, ld_cur);
+      if (rc0) return rc0;
       cur = d0.out; ld_cur = h->dense[0].ldw;
       l_first = 1;
     }
     for (int l = l_first; l < nl; ++l) {
       PsmDenseArgs da = dense_args(l, cur, ld_cur);
+      if (h->dense[l].ln) {
+        HIPCHK(h, psm_launch_dense(da, st));
+        int rcl = layer_norm(l, da.out, cur, ld_cur);
+        if (rcl) return rcl;
+        cur = da.out; ld_cur = h->dense[l].ldw;
+        continue;
+      }
       if (use_bound && !bf16 && l == nl - 1) { // head layer + strip dots of the bound geometry in one launch
         PsmDotsArgs dd = use_cf ? PsmDotsArgs{h->d_g2p, h->d_c2p, h->d_cntp, h->d_row_of_p, d_row_scale, w.d_dots2, n_cases * CB, h->dense[nl - 1].Kpad, ga, h->B, CB}
                                 : PsmDotsArgs{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, w.d_dots, h->bound_rows * n_cases, h->dense[nl - 1].Kpad, ga};
@@ -890,6 +912,7 @@ void psm_destroy(psm_handle* h) {
   dev_free(h->d_maskbits); dev_free(h->d_gzero);
   dev_free(h->d_g2p); dev_free(h->d_c2p); dev_free(h->d_cntp); dev_free(h->d_cfa0); dev_free(h->d_row_of_p);
   for (auto& c : h->conv1d) { dev_free(c.W); dev_free(c.b); }
+  for (auto& d : h->dense) { dev_free(d.ln_gamma); dev_free(d.ln_beta); }
   if (h->h_guard) (void)hipHostFree(h->h_guard);
   for (int i = 0; i < psm_handle::RING; ++i) {
     if (h->h_scale[i]) (void)hipHostFree(h->h_scale[i]);
@@ -960,6 +983,8 @@ int psm_set_dense(psm_handle* h, int32_t layer, int32_t n_in, int32_t n_out, con
   destroy_graphs(h);
   h->bound = false;
   DenseLayer& d = h->dense[layer];
+  d.linear = false;                                     // psm_set_attention sets it again after this call
+  if (d.ln && d.n_out != n_out) { d.ln = false; dev_free(d.ln_gamma); dev_free(d.ln_beta); }   // a LayerNormalization of another width
   d.n_in = n_in; d.n_out = n_out; d.Kpad = round_up(n_in, 32); d.ldw = round_up(n_out, 32);
   std::vector<float> W((size_t)d.Kpad * d.ldw, 0.f), b(d.ldw, 0.f);
   for (int k = 0; k < n_in; ++k) memcpy(&W[(size_t)k * d.ldw], kernel + (size_t)k * n_out, n_out * sizeof(float));
@@ -996,6 +1021,53 @@ int psm_set_dense(psm_handle* h, int32_t layer, int32_t n_in, int32_t n_out, con
   }
   if ((rc = dev_upload(h, &d.b, b))) return rc;
   d.set = true;
+  return PSM_OK;
+}
+
+int psm_set_attention(psm_handle* h, int32_t layer, int32_t d_model, int32_t n_heads, int32_t value_dim, const float* Wv, const float* bv,
+                      const float* Wo, const float* bo) {
+  if (!h) return PSM_ERR_ARG;
+  if (layer < 1 || layer >= (int)h->dense.size() - 1) return fail(h, PSM_ERR_ARG, "the attention block must sit between the first Dense layer and the head");
+  if (!Wv || !bv || !Wo || !bo || d_model < 1 || d_model > 4096 || n_heads < 1 || value_dim < 1 || (int64_t)n_heads * value_dim > 65536)
+    return fail(h, PSM_ERR_ARG, "bad attention block");
+  // Sequence length 1 (NNs.py:54 tf.expand_dims(x, 1), NNs.py:55 attention of x with itself): the softmax over the single key
+  // is exactly 1 whatever the query and key projections give, so the block is value projection -> output projection:
+  //   out = (x . Wv + bv) . Wo + bo = x . (Wv Wo) + (bv Wo + bo)      -- folded here in float64, one Dense launch without ReLU
+  const int HV = n_heads * value_dim;
+  std::vector<double> W((size_t)d_model * d_model, 0.0), b(d_model, 0.0);
+  for (int i = 0; i < d_model; ++i)
+    for (int k = 0; k < HV; ++k) {
+      const double v = Wv[(size_t)i * HV + k];
+      const float* wo = Wo + (size_t)k * d_model;
+      double* wr = &W[(size_t)i * d_model];
+      for (int j = 0; j < d_model; ++j) wr[j] += v * (double)wo[j];
+    }
+  for (int j = 0; j < d_model; ++j) b[j] = bo[j];
+  for (int k = 0; k < HV; ++k)
+    for (int j = 0; j < d_model; ++j) b[j] += (double)bv[k] * (double)Wo[(size_t)k * d_model + j];
+  std::vector<float> Wf(W.begin(), W.end()), bf(b.begin(), b.end());
+  int rc = psm_set_dense(h, layer, d_model, d_model, Wf.data(), bf.data());
+  if (rc) return rc;
+  h->dense[layer].linear = true;
+  return PSM_OK;
+}
+
+int psm_set_layernorm(psm_handle* h, int32_t layer, int32_t n, const float* gamma, const float* beta, float epsilon, int32_t residual) {
+  if (!h) return PSM_ERR_ARG;
+  if (layer < 0 || layer >= (int)h->dense.size() - 1) return fail(h, PSM_ERR_ARG, "LayerNormalization follows a hidden layer (not the head)");
+  DenseLayer& d = h->dense[layer];
+  if (!d.set) return fail(h, PSM_ERR_STATE, "set the Dense layer (psm_set_dense / psm_set_attention) before its LayerNormalization");
+  if (!gamma || !beta || n != d.n_out) return fail(h, PSM_ERR_ARG, "LayerNormalization width must equal the layer's output width");
+  if (!(epsilon > 0.f)) return fail(h, PSM_ERR_ARG, "epsilon must be positive");
+  if (residual && d.n_in != d.n_out) return fail(h, PSM_ERR_ARG, "the residual x + input needs a square layer");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  destroy_graphs(h);
+  h->bound = false;
+  std::vector<float> g(gamma, gamma + n), b(beta, beta + n);
+  int rc;
+  if ((rc = dev_upload(h, &d.ln_gamma, g)) || (rc = dev_upload(h, &d.ln_beta, b))) return rc;
+  d.ln = true; d.ln_residual = residual != 0; d.ln_eps = epsilon;
   return PSM_OK;
 }
 
@@ -1766,6 +1838,51 @@ int psm_label_blocks(psm_handle* h, const float* grid, const float* labels, floa
   if (e == hipSuccess) e = wait_stream(st);
   if (e != hipSuccess) return fail(h, PSM_ERR_HIP, std::string("label blocks: ") + hipGetErrorString(e));
   memcpy(blocks_out, p_o, ob);
+  return PSM_OK;
+}
+
+int psm_block_error(psm_handle* h, const float* grid, const float* labels, double* out) {
+  if (!h) return PSM_ERR_ARG;
+  if (!h->planned || h->last_cases < 1) return fail(h, PSM_ERR_STATE, "no solve has run yet");
+  if (!grid || !labels || !out) return fail(h, PSM_ERR_ARG, "null buffer");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipDeviceSynchronize());                        // the solve may have run on the caller's stream
+  hipStream_t st = h->stream;
+  const size_t npix = (size_t)h->Ny * h->Nx;
+  const size_t gb = npix * h->cfg.c_in * sizeof(float), lb = npix * h->cfg.c_out * sizeof(float), ob = (size_t)h->B * h->K_out * sizeof(float);
+  const size_t pb = (size_t)h->B * 8 * sizeof(double);
+  int rc;
+  if ((rc = scratch_reserve(h, carve_size({gb, lb, ob, pb}), carve_size({gb, lb, pb})))) return rc;
+  Carver cd{(char*)h->scr_dev}, cp{(char*)h->scr_pin};
+  float* d_g = cd.take<float>(npix * h->cfg.c_in); float* d_l = cd.take<float>(npix * h->cfg.c_out); float* d_o = cd.take<float>((size_t)h->B * h->K_out);
+  double* d_p = cd.take<double>((size_t)h->B * 8);
+  float* p_g = cp.take<float>(npix * h->cfg.c_in); float* p_l = cp.take<float>(npix * h->cfg.c_out); double* p_p = cp.take<double>((size_t)h->B * 8);
+  memcpy(p_g, grid, gb); memcpy(p_l, labels, lb);
+  // the decoded blocks of the last solve (case 0): on the geometry-bound path they were never stored -- decode its network output again
+  const int M = h->B, Mpad = round_up(M, 32);
+  const float* scale = h->last_row_scale ? h->last_row_scale : h->d_ones;
+  PsmDecodeArgs de{};
+  de.res = h->ws0.d_res; de.ld_res = h->ld_out; de.bpack = h->d_bpack_out; de.mean = h->d_mean_out;
+  de.row_scale = scale; de.pred = h->ws0.d_pred; de.M = M; de.Mpad = Mpad; de.Gd = h->Gd; de.n_coltiles = h->n_coltiles; de.K_out = h->K_out;
+  const bool bf16 = h->cfg.precision == PSM_PRECISION_BF16;
+  hipError_t e = bf16 ? psm_launch_decode_bf16(de, st) : psm_launch_decode(de, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_g, p_g, gb, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_l, p_l, lb, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = psm_launch_label_blocks(d_g, d_l, h->d_blk, d_o, h->B, h->S, h->cfg.c_in, h->cfg.c_out, h->cfg.sdf_channel, h->Nx, st);
+  if (e == hipSuccess) e = psm_launch_block_error(d_g, h->ws0.d_pred, d_o, scale, h->d_blk, d_p, h->B, h->S, h->cfg.c_in, h->cfg.c_out, h->cfg.sdf_channel, h->Nx, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(p_p, d_p, pb, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = wait_stream(st);
+  if (e != hipSuccess) return fail(h, PSM_ERR_HIP, std::string("block error: ") + hipGetErrorString(e));
+  double n = 0, s1 = 0, s2 = 0, tmin = INFINITY, tmax = -INFINITY, pmin = INFINITY, pmax = -INFINITY, tnan = 0;
+  for (int b = 0; b < h->B; ++b) {
+    const double* q = p_p + (size_t)b * 8;
+    n += q[0]; s1 += q[1]; s2 += q[2]; tnan += q[7];
+    tmin = std::min(tmin, q[3]); tmax = std::max(tmax, q[4]); pmin = std::min(pmin, q[5]); pmax = std::max(pmax, q[6]);
+  }
+  const double norm = tnan > 0 ? NAN : tmax - tmin;        // np.max / np.min propagate a NaN label
+  out[0] = s1 / n / norm;                                   // pred_minus_true_block (utils.py:241)
+  out[1] = s2 / n / (norm * norm);                          // pred_minus_true_squared_block (utils.py:242)
+  out[2] = norm; out[3] = pmax - pmin; out[4] = n;
   return PSM_OK;
 }
 

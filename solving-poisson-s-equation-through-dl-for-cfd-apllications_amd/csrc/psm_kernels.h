@@ -45,6 +45,21 @@ struct PsmDenseArgs {
   int layer;                           // layer index (diagnostic stamps only)
 };
 
+// LayerNormalization of the reference's densePCA_attention (NNs.py:56, 64; Keras defaults: last axis, epsilon 1e-3, centre and
+// scale), in place on a finished activation, with the optional residual of NNs.py:64 (`x + attn_output`, where attn_output
+// is the INPUT of the Dense layer that produced x):  act[m][:] = LN(act[m][:] + res[m][:]) * gamma + beta over the first n
+// columns.  Its own launch: a Dense launch tiles the output columns over workgroups (16 per workgroup, so that 32+ CUs pull
+// the weights), no workgroup sees a whole row, and on this chip the kernel boundary is the cheapest grid-wide
+// synchronisation; one wave per row, three passes over a row that sits in L2.
+struct PsmLayerNormArgs {
+  float* act; int ld_act;               // [rows][ld_act], normalised in place
+  const float* res; int ld_res;         // [rows][ld_res] or null
+  const float* gamma; const float* beta;   // [n]
+  int rows, n;
+  float eps;
+};
+hipError_t psm_launch_layernorm(const PsmLayerNormArgs& a, hipStream_t s);
+
 // Conv1D layer of the reference's conv1D_PCA head (NNs.py:75-124): 'same' padding, cross-correlation like Keras,
 // out[m][p][co] = act(bias[co] + sum_{t, ci} in[m][p + t - (k-1)/2][ci] * W[t][ci][co])  over the p_in scaled PCA coefficients
 struct PsmConv1dArgs {

@@ -986,6 +986,29 @@ hipError_t psm_launch_dense_dots(const PsmDenseArgs& a, const PsmDotsArgs& d, hi
   return hipGetLastError();
 }
 
+// LayerNormalization (+ residual) of the densePCA_attention stack, see psm_kernels.h.  Two-pass moments like
+// tf.nn.moments (mean, then the mean of squared deviations; biased variance), float32.
+__global__ __launch_bounds__(256) void psm_layernorm_kernel(PsmLayerNormArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = (int)blockIdx.x * 4 + wave;
+  if (row >= a.rows) return;                          // wave-uniform
+  float* x = a.act + (int64_t)row * a.ld_act;
+  const float* r = a.res ? a.res + (int64_t)row * a.ld_res : nullptr;
+  float s = 0.f;
+  for (int k = lane; k < a.n; k += 64) s += x[k] + (r ? r[k] : 0.f);
+  const float mean = wave_sum(s) / (float)a.n;
+  float q = 0.f;
+  for (int k = lane; k < a.n; k += 64) { const float d = x[k] + (r ? r[k] : 0.f) - mean; q += d * d; }
+  const float inv = rsqrtf(wave_sum(q) / (float)a.n + a.eps);
+  for (int k = lane; k < a.n; k += 64) x[k] = (x[k] + (r ? r[k] : 0.f) - mean) * inv * a.gamma[k] + a.beta[k];
+}
+
+hipError_t psm_launch_layernorm(const PsmLayerNormArgs& a, hipStream_t st) {
+  if (!a.act || !a.gamma || !a.beta || a.rows < 1 || a.n < 1 || a.n > a.ld_act || (a.res && a.n > a.ld_res)) return hipErrorInvalidValue;
+  PSM_LAUNCH(psm_layernorm_kernel, dim3((a.rows + 3) / 4), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 // decode
 // ---------------------------------------------------------------------------

@@ -49,6 +49,9 @@ hipError_t psm_launch_gauss1d(const float* in, float* out, int ny, int nx, int a
 // label blocks [B][S*S*c_out] with the per-block flow-cell mean removed (SM_call.py:487-488, UGP:509-511)
 hipError_t psm_launch_label_blocks(const float* grid, const float* labels, const int32_t* blk_y0x0, float* out, int B, int S,
                                    int c_in, int c_out, int sdf_ch, int Nx, hipStream_t st);
+// compute_in_block_error (utils.py:210-243): per-block partial sums [B][8] doubles, see psm_mesh.hip
+hipError_t psm_launch_block_error(const float* grid, const float* pred, const float* label_blocks, const float* row_scale,
+                                  const int32_t* blk_y0x0, double* part, int B, int S, int c_in, int c_out, int sdf_ch, int Nx, hipStream_t st);
 
 // ---- U_to_gradP integration (UGP:371-416, 592-628)
 constexpr int PSM_INTEG_MAX_FIX = 4;   // distinct indices the "reset" quirk may touch per row

@@ -232,6 +232,50 @@ hipError_t psm_launch_label_blocks(const float* grid, const float* labels, const
   return hipGetLastError();
 }
 
+// compute_in_block_error (pressureSM_deltas/utils.py:210-243; called at SM_call.py:555-557 on the decoded blocks BEFORE the
+// reassembly): partial sums per workgroup over the flow cells of one block -- count and sum / sum of squares of the
+// non-NaN differences pred - true, extrema of true and pred, count of NaN truths (np.max then gives NaN) -- float64 like
+// the reference's arrays; `true` = label block * row_scale[b] (SM_call.py:555: y_array * max_abs_p * U_max_norm^2, the scale
+// the decoded blocks already carry).  Partials [B][8] doubles, summed on the host.
+__global__ __launch_bounds__(256) void psm_block_error_kernel(const float* grid, const float* pred, const float* label_blocks,
+                                                              const float* row_scale, const int32_t* blk_y0x0, double* part,
+                                                              int S, int c_in, int c_out, int sdf_ch, int Nx) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int y0 = blk_y0x0[2 * b], x0 = blk_y0x0[2 * b + 1];
+  const double sc = (double)row_scale[b];
+  double n = 0.0, s1 = 0.0, s2 = 0.0, tmin = INFINITY, tmax = -INFINITY, pmin = INFINITY, pmax = -INFINITY, tnan = 0.0;
+  for (int i = t; i < S * S; i += 256) {
+    const int64_t pix = (int64_t)(y0 + i / S) * Nx + x0 + i % S;
+    if (!(grid[pix * c_in + sdf_ch] != 0.f)) continue;
+    for (int c = 0; c < c_out; ++c) {
+      const int64_t e = ((int64_t)b * S * S + i) * c_out + c;
+      const double tr = (double)label_blocks[e] * sc, pr = (double)pred[e];
+      if (tr != tr) tnan += 1.0; else { tmin = fmin(tmin, tr); tmax = fmax(tmax, tr); }
+      if (pr == pr) { pmin = fmin(pmin, pr); pmax = fmax(pmax, pr); }
+      const double d = pr - tr;
+      if (d == d) { n += 1.0; s1 += d; s2 += d * d; }
+    }
+  }
+  __shared__ double sh[8][256];
+  sh[0][t] = n; sh[1][t] = s1; sh[2][t] = s2; sh[3][t] = tmin; sh[4][t] = tmax; sh[5][t] = pmin; sh[6][t] = pmax; sh[7][t] = tnan;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) {
+      sh[0][t] += sh[0][t + s]; sh[1][t] += sh[1][t + s]; sh[2][t] += sh[2][t + s]; sh[7][t] += sh[7][t + s];
+      sh[3][t] = fmin(sh[3][t], sh[3][t + s]); sh[4][t] = fmax(sh[4][t], sh[4][t + s]);
+      sh[5][t] = fmin(sh[5][t], sh[5][t + s]); sh[6][t] = fmax(sh[6][t], sh[6][t + s]);
+    }
+    __syncthreads();
+  }
+  if (t < 8) part[(int64_t)b * 8 + t] = sh[t][0];
+}
+
+hipError_t psm_launch_block_error(const float* grid, const float* pred, const float* label_blocks, const float* row_scale,
+                                  const int32_t* blk_y0x0, double* part, int B, int S, int c_in, int c_out, int sdf_ch, int Nx, hipStream_t st) {
+  hipLaunchKernelGGL(psm_block_error_kernel, dim3(B), dim3(256), 0, st, grid, pred, label_blocks, row_scale, blk_y0x0, part, S, c_in, c_out, sdf_ch, Nx);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 // U_to_gradP: integration of (dp/dx, dp/dy) into p over four quadrants
 // (integrate_field UGP:371-416, stitching UGP:597-628).  For a quadrant with reference corner

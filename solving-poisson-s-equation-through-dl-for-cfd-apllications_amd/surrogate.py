@@ -54,7 +54,8 @@ class GridSurrogate:
         cfg = _lib.psm_config(
             abi_version=_lib.PSM_ABI_VERSION, variant=_lib.VARIANTS[model.variant], block=model.S,
             overlap=0 if model.ov is None else int(model.ov), c_in=model.c_in, c_out=model.c_out,
-            p_in=model.p_in, p_out=model.p_out, n_dense=len(model.weights), scaler=_lib.SCALERS[model.scaler_kind],
+            p_in=model.p_in, p_out=model.p_out, n_dense=len(model.weights) + (1 if getattr(model, "attention", None) else 0),
+            scaler=_lib.SCALERS[model.scaler_kind],
             sdf_channel=model.sdf_ch, device=device, max_cases=max_cases, strict_degenerate=int(strict_degenerate),
             precision=_lib.PRECISIONS[precision])
         h = C.c_void_p()
@@ -72,9 +73,14 @@ class GridSurrogate:
                 if K.ndim != 3 or b.shape != (K.shape[2],):
                     raise ValueError("Conv1D kernels must be [kernel_size, c_in, c_out] with bias [c_out]")
                 self._chk(self.lib.psm_set_conv1d(h, l, len(convs), K.shape[0], K.shape[1], K.shape[2], _p(K, C.c_float), _p(b, C.c_float)))
+            att = getattr(model, "attention", None)
             for l, (W, b) in enumerate(model.weights):
                 W, b = _f32(W), _f32(b)
-                self._chk(self.lib.psm_set_dense(h, l, W.shape[0], W.shape[1], _p(W, C.c_float), _p(b, C.c_float)))
+                # densePCA_attention: the attention block takes Dense slot 1, the further layers move up by one
+                slot = l + 1 if (att and l > 0) else l
+                self._chk(self.lib.psm_set_dense(h, slot, W.shape[0], W.shape[1], _p(W, C.c_float), _p(b, C.c_float)))
+            if att:
+                self._set_attention(att, len(model.weights) - 1)
             ia = _f64(np.broadcast_to(model.in_a, (model.p_in,)))
             ib = _f64(np.broadcast_to(model.in_b, (model.p_in,)))
             oa = _f64(np.broadcast_to(model.out_a, (model.p_out,)))
@@ -85,6 +91,21 @@ class GridSurrogate:
         except Exception:
             self.close()
             raise
+
+    def _set_attention(self, att: dict, n_layers: int):
+        """The attention part of densePCA_attention (NNs.py:53-64) -> psm_set_attention (slot 1) + one psm_set_layernorm per
+        layer; the query / key projections are not passed on: over a sequence of length 1 they cannot change the result."""
+        Wv, bv, Wo, bo = _f32(att["Wv"]), _f32(att["bv"]), _f32(att["Wo"]), _f32(att["bo"])
+        d, heads, dim = Wv.shape
+        if bv.shape != (heads, dim) or Wo.shape != (heads, dim, d) or bo.shape != (d,):
+            raise ValueError("attention weights: Wv [d, heads, dim], bv [heads, dim], Wo [heads, dim, d], bo [d]")
+        if len(att["ln"]) != n_layers:
+            raise ValueError("densePCA_attention has one LayerNormalization per layer")
+        self._chk(self.lib.psm_set_attention(self.h, 1, d, heads, dim, _p(Wv, C.c_float), _p(bv, C.c_float), _p(Wo, C.c_float), _p(bo, C.c_float)))
+        for i, (g, b) in enumerate(att["ln"]):
+            g, b = _f32(g), _f32(b)
+            self._chk(self.lib.psm_set_layernorm(self.h, 1 + i, g.shape[0], _p(g, C.c_float), _p(b, C.c_float),
+                                                 float(att.get("eps", 1e-3)), 0 if i == 0 else 1))
 
     # -- plumbing
     def _chk(self, rc):
@@ -279,6 +300,23 @@ class GridSurrogate:
         out = np.empty((self.B, self.model.S, self.model.S, self.model.c_out), np.float32)
         self._chk(self.lib.psm_label_blocks(self.h, _p(g, C.c_float), _p(lab, C.c_float), _p(out, C.c_float)))
         return out
+
+    def block_error(self, grid: np.ndarray, labels: np.ndarray) -> dict:
+        """``utils.compute_in_block_error`` (pressureSM_deltas/utils.py:210-243) for the LAST solve: decoded blocks against the
+        de-meaned label blocks over the flow cells, before the reassembly.  ``labels`` [Ny,Nx,c_out] (or [Ny,Nx]) in the
+        network's normalised output units (scaled by the solve's out_scale like SM_call.py:555).  -> the two values the
+        reference appends (``mean_err``, ``mean_sq_err``) and the printed normVal / biasNorm / stdeNorm / rmseNorm."""
+        g = _f32(np.asarray(grid)[..., :self.model.c_in])
+        lab = _f32(np.asarray(labels).reshape(self.ny, self.nx, self.model.c_out))
+        if g.shape != (self.ny, self.nx, self.model.c_in):
+            raise ValueError("grid has the wrong shape")
+        out = (C.c_double * 5)()
+        self._chk(self.lib.psm_block_error(self.h, _p(g, C.c_float), _p(lab, C.c_float), out))
+        bias, rmse = out[0] * 100, np.sqrt(out[1]) * 100
+        with np.errstate(invalid="ignore"):
+            stde = np.sqrt(rmse ** 2 - bias ** 2)
+        return {"mean_err": float(out[0]), "mean_sq_err": float(out[1]), "normVal": float(out[2]), "norm_pred": float(out[3]),
+                "n": int(out[4]), "biasNorm": float(bias), "rmseNorm": float(rmse), "stdeNorm": float(stde)}
 
     def gaussian_filter(self, field: np.ndarray, sigma=(10.0, 10.0)) -> np.ndarray:
         """scipy.ndimage.gaussian_filter(field, sigma, order=0) on the GPU (SM_call.py:353-363)."""
@@ -574,6 +612,15 @@ class Evaluation:
         self.deltaU_change_grid, self.deltaP_prev_grid = g[..., 4], g[..., 5]            # :448-451 (NaNs kept)
         self.max_abs_p = max_abs_p
         res = self.timeStep_grid(grid[..., :3], U_max_norm, max_abs_p)                   # :452-572
+        # :553-557 the error of the decoded blocks against the de-meaned label blocks, before the assembly
+        mb = self._surrogate(*grid.shape[:2]).block_error(grid[..., :3], grid[..., 3])
+        for name, key in (("pred_minus_true_block", "mean_err"), ("pred_minus_true_squared_block", "mean_sq_err")):
+            if not hasattr(self, name):
+                setattr(self, name, [])
+            getattr(self, name).append(mb[key])
+        if not isinstance(getattr(self, "last_metrics", None), dict):
+            self.last_metrics = {}
+        self.last_metrics["blocks"] = mb
         if apply_filter:
             res = self._surrogate(*grid.shape[:2]).gaussian_filter(res, (10, 10))
         self.cfd_results = grid[..., 3] * max_abs_p * pow(U_max_norm, 2.0)               # :580 (float32 square, like the reference)
@@ -655,11 +702,13 @@ def call_SM_main(delta, model_name, shape, overlap_ratio, var_p, var_in, max_num
                  apply_filter=False, create_GIF=False, n_sims=1, n_ts=1, device: int = 0, artifact_dir: str = None):
     """``pressureSM_deltas.SM_call.call_SM_main`` (SM_call.py:778-900): evaluate ``n_ts`` frames of ``n_sims``
     simulations of the dataset and return the error summary the reference prints -- per simulation and overall
-    BIAS / STDE / RMSE [%] of delta-p over the flow cells (plots and GIFs are not produced)."""
+    BIAS / STDE / RMSE [%] of delta-p over the flow cells, and BIAS_block / RSME_block / STDE_block [%] of the decoded blocks
+    before the assembly (SM_call.py:824-826, from ``utils.compute_in_block_error``); plots and GIFs are not produced."""
     overlap = int(overlap_ratio * shape)
     ev = Evaluation(delta, shape, overlap, var_p, var_in, dataset_path, model_name, max_num_PC, standardization_method,
                     device=device, artifact_dir=artifact_dir)
     ev.pred_minus_true, ev.pred_minus_true_squared = [], []
+    ev.pred_minus_true_block, ev.pred_minus_true_squared_block = [], []
 
     summary = _summary
     out = {"sims": []}
@@ -669,11 +718,17 @@ def call_SM_main(delta, model_name, shape, overlap_ratio, var_p, var_in, max_num
         for time in range(n_ts):
             ev.timeStep(sim, time, plot_intermediate_fields, save_plots, show_plots, apply_filter)
         if len(ev.pred_minus_true) > n0:
-            out["sims"].append(summary(ev.pred_minus_true[n0:], ev.pred_minus_true_squared[n0:]))
+            s = summary(ev.pred_minus_true[n0:], ev.pred_minus_true_squared[n0:])
+            # SM_call.py:824-826 BIAS_block / RSME_block / STDE_block: the same summary over the per-frame block errors
+            blk = summary(ev.pred_minus_true_block[n0:], ev.pred_minus_true_squared_block[n0:])
+            s.update(BIAS_block=blk["BIAS"], RSME_block=blk["RMSE"], STDE_block=blk["STDE"])
+            out["sims"].append(s)
         else:
             out["sims"].append(None)                       # every frame of this simulation was irrelevant
     if ev.pred_minus_true:
         out["overall"] = summary(ev.pred_minus_true, ev.pred_minus_true_squared)
+        blk = summary(ev.pred_minus_true_block, ev.pred_minus_true_squared_block)
+        out["overall"].update(BIAS_block=blk["BIAS"], RSME_block=blk["RMSE"], STDE_block=blk["STDE"])
     return out
 
 

@@ -11,7 +11,7 @@ reference architectures (utils.py:435-461 ``define_model_arch``).
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import List, Sequence, Tuple
+from typing import Optional, List, Sequence, Tuple
 
 import numpy as np
 
@@ -21,6 +21,7 @@ ARCHS = {  # utils.py:435-461
     "MLP_huge": [256] + [512] * 10 + [256],
     "MLP_huger": [256] + [512] * 18 + [256],
     "MLP_small_unet": [512, 256, 128, 64, 32, 64, 128, 256, 512],
+    "MLP_attention": [512] * 3,       # densePCA_attention: the same three Dense layers + attention / LayerNormalization
 }
 
 
@@ -47,6 +48,10 @@ class SurrogateModel:
     sdf_ch: int = 2
     # conv1D_PCA head (NNs.py:75-124): Conv1D layers [(kernel[k, c_in, c_out] f32, bias[c_out] f32)] in front of `weights`
     conv1d: List[Tuple[np.ndarray, np.ndarray]] = field(default_factory=list)
+    # densePCA_attention (NNs.py:40-72, 'MLP_attention'): `weights` = the n_layers Dense layers + the head; this dict holds the
+    # MultiHeadAttention block behind the first of them -- Wq, bq, Wk, bk, Wv, bv [d, heads, dim] / [heads, dim], Wo [heads, dim, d],
+    # bo [d] (Keras EinsumDense layouts) -- and "ln": the n_layers LayerNormalizations [(gamma[d], beta[d])], "eps"
+    attention: Optional[dict] = None
 
     @property
     def p_in(self):
@@ -93,6 +98,25 @@ def he_conv1d_head(p_in: int, filters: Sequence[int], p_out: int, seed: int, ker
     return convs, [(W, (rng.standard_normal(p_out) * 0.01).astype(np.float32))]
 
 
+def he_attention_block(widths: Sequence[int], seed: int, n_heads: int = 8, key_dim: int = 64, eps: float = 1e-3) -> dict:
+    """Seeded random-init parameters of the attention part of the reference's densePCA_attention (NNs.py:53-64):
+    MultiHeadAttention(num_heads=8, key_dim=64) behind the first Dense layer and one LayerNormalization per layer.  gamma /
+    beta are drawn away from their (1, 0) initial values, as trained ones would be."""
+    rng = np.random.default_rng(seed)
+    d = int(widths[0])
+    if any(int(w) != d for w in widths):
+        raise ValueError("densePCA_attention adds the attention output to every further layer: equal widths only")
+    g = lambda *sh: (rng.standard_normal(sh) * np.sqrt(1.0 / sh[0])).astype(np.float32)
+    att = {"Wq": g(d, n_heads, key_dim), "bq": (rng.standard_normal((n_heads, key_dim)) * 0.05).astype(np.float32),
+           "Wk": g(d, n_heads, key_dim), "bk": (rng.standard_normal((n_heads, key_dim)) * 0.05).astype(np.float32),
+           "Wv": g(d, n_heads, key_dim), "bv": (rng.standard_normal((n_heads, key_dim)) * 0.05).astype(np.float32),
+           "Wo": (rng.standard_normal((n_heads, key_dim, d)) * np.sqrt(1.0 / (n_heads * key_dim))).astype(np.float32),
+           "bo": (rng.standard_normal(d) * 0.05).astype(np.float32), "eps": float(eps),
+           "ln": [((1.0 + 0.1 * rng.standard_normal(d)).astype(np.float32), (0.05 * rng.standard_normal(d)).astype(np.float32))
+                  for _ in widths]}
+    return att
+
+
 def make_model(variant: str, p_in: int = 128, p_out: int = 128, arch: str = "MLP_small",
                scaler_kind: str | None = None, weights=None, seed_pca: int = 1234,
                seed_w: int = 7, S: int = 128, c_in: int = 3, c_out: int | None = None,
@@ -111,6 +135,8 @@ def make_model(variant: str, p_in: int = 128, p_out: int = 128, arch: str = "MLP
         weights = he_dense_stack(p_in, ARCHS[arch], p_out, seed_w)
     m = SurrogateModel(variant, c_in, c_out, comp_in, mean_in, comp_out, mean_out, list(weights),
                        scaler_kind=scaler_kind, out_scale=out_scale, S=S)
+    if arch == "MLP_attention":
+        m.attention = he_attention_block(ARCHS[arch], seed_w + 100)
     if scaler_kind == "max_abs":
         # like the reference's maxs_PCA file (147.2, 26.7) but matched to the magnitude of the
         # synthetic PCA coefficients so that the network input is O(1)

@@ -32,6 +32,9 @@ GOLDEN_CASES = {
     # the reference's conv1D_PCA network (NNs.py:75-124, architecture 'conv1D' of utils.py:452-454) as the evaluator's model:
     # built by the reference's own function (tests/golden/make_golden.py), weights stored as data in the fixture
     "deltas_conv1d_256x256": dict(variant="deltas", Ny=256, Nx=256, seed=81, p=32, scaler="std", conv1d=True),
+    # the reference's densePCA_attention network (NNs.py:40-72, architecture 'MLP_attention' of utils.py:455-457), likewise built by
+    # the reference's own function: which layers exist, their order, the residuals and the attention call are the reference's
+    "deltas_attention_256x256": dict(variant="deltas", Ny=256, Nx=256, seed=82, p=32, scaler="std", attention=True),
 }
 
 
@@ -45,7 +48,10 @@ DEGENERATE_CASES = {
 }
 
 
-DENSE_GOLDEN_CASES = [k for k, v in GOLDEN_CASES.items() if not v.get("conv1d")]     # Dense-stack networks (C port, bound path)
+# compute_in_block_error (utils.py:210-243): golden values in tests/golden/block_error_deltas.npz, labels = channel 3 of the grids
+BLOCK_ERROR_CASES = ["deltas_256x256", "deltas_300x420", "deltas_nan_256x256"]
+
+DENSE_GOLDEN_CASES = [k for k, v in GOLDEN_CASES.items() if not v.get("conv1d") and not v.get("attention")]     # Dense-stack networks (C port, bound path)
 
 
 def real_chapter5_weights():
@@ -109,6 +115,21 @@ def build(name: str):
             nc = len([k for k in d.files if k.startswith("convK")])
             model.conv1d = [(d[f"convK{i}"], d[f"convb{i}"]) for i in range(nc)]
             model.weights = [(d["denseW"], d["denseb"])]
+    if sp.get("attention"):       # likewise: parameters drawn by the reference-built densePCA_attention network
+        f = os.path.join(GOLDEN_DIR, f"{name}.npz")
+        if os.path.exists(f):
+            d = np.load(f)
+            nd = len([k for k in d.files if k.startswith("denseW")])
+            model.weights = [(d[f"denseW{i}"], d[f"denseb{i}"]) for i in range(nd)]
+            nl = len([k for k in d.files if k.startswith("ln_gamma")])
+            att = {k: d["att_" + k] for k in ("Wv", "bv", "Wo", "bo")}
+            # the fixture does not carry the query / key projections: over the reference's sequence of length 1 the softmax is 1
+            # whatever they are (tests/test_attention.py proves it on the oracle) -- any values of the right shape do
+            rq = np.random.default_rng(4242)
+            for k in ("q", "k"):
+                att["W" + k] = (rq.standard_normal(att["Wv"].shape) * 0.05).astype(np.float32)
+                att["b" + k] = (rq.standard_normal(att["bv"].shape) * 0.05).astype(np.float32)
+            model.attention = dict(att, ln=[(d[f"ln_gamma{i}"], d[f"ln_beta{i}"]) for i in range(nl)], eps=float(d["ln_eps"]))
     if v == "deltas":
         model.out_scale = sp.get("max_abs_p", 1.0) * sp.get("U_max_norm", 1.0) ** 2
     return grid, model

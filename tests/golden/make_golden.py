@@ -138,6 +138,9 @@ class _KerasStub:
             def __init__(self, fn, shape=None):
                 self.fn, self.shape = fn, shape
 
+            def __add__(self, other):                 # `x + attn_output` (NNs.py:64): element-wise sum of two symbolic tensors
+                return Sym(lambda v: self.fn(v) + other.fn(v))
+
         def Input(shape=None, **kw):
             shape = tuple(shape) if isinstance(shape, (tuple, list)) else (int(shape),)
 
@@ -147,7 +150,9 @@ class _KerasStub:
             return Sym(feed, shape)
 
         class Layer:
-            def __call__(self, x):
+            def __call__(self, x, *more):
+                if more:                              # MultiHeadAttention(query, value)
+                    return Sym(lambda v: self.apply(x.fn(v), *[m.fn(v) for m in more]))
                 return Sym(lambda v: self.apply(x.fn(v)))
 
         class Conv1D(Layer):
@@ -182,6 +187,48 @@ class _KerasStub:
                 out = h @ self.W + self.b
                 return np.maximum(out, np.float32(0)) if self.activation == "relu" else out
 
+        class MultiHeadAttention(Layer):
+            """Keras' published definition restated in NumPy float32 (query / key / value EinsumDense projections with bias,
+            scaled dot product, softmax over the keys, EinsumDense output projection), for whatever sequence lengths the
+            reference's call produces."""
+            def __init__(self, num_heads, key_dim, **kw):
+                self.h, self.kd, self.P = int(num_heads), int(key_dim), None
+                stub.layers.append(self)
+
+            def apply(self, q_in, v_in):
+                d = q_in.shape[-1]
+                if self.P is None:
+                    g = lambda *sh: (stub.rng.standard_normal(sh) * np.sqrt(1.0 / sh[0])).astype(np.float32)
+                    bias = lambda *sh: (stub.rng.standard_normal(sh) * 0.05).astype(np.float32)
+                    self.P = dict(Wq=g(d, self.h, self.kd), bq=bias(self.h, self.kd), Wk=g(d, self.h, self.kd), bk=bias(self.h, self.kd),
+                                  Wv=g(d, self.h, self.kd), bv=bias(self.h, self.kd),
+                                  Wo=(stub.rng.standard_normal((self.h, self.kd, d)) * np.sqrt(1.0 / (self.h * self.kd))).astype(np.float32),
+                                  bo=bias(d))
+                P = self.P
+                q = np.einsum("btd,dhk->bthk", q_in, P["Wq"]) + P["bq"]
+                k = np.einsum("bsd,dhk->bshk", v_in, P["Wk"]) + P["bk"]
+                v = np.einsum("bsd,dhk->bshk", v_in, P["Wv"]) + P["bv"]
+                sc = np.einsum("bthk,bshk->bhts", q * np.float32(1.0 / np.sqrt(self.kd)), k)
+                sc = np.exp(sc - sc.max(axis=-1, keepdims=True))
+                sc = (sc / sc.sum(axis=-1, keepdims=True)).astype(np.float32)
+                ctx = np.einsum("bhts,bshk->bthk", sc, v)
+                return (np.einsum("bthk,hkd->btd", ctx, P["Wo"]) + P["bo"]).astype(np.float32)
+
+        class LayerNormalization(Layer):
+            """Keras defaults: axis -1, epsilon 1e-3, centre and scale; gamma / beta drawn away from (1, 0) as trained ones are."""
+            def __init__(self, axis=-1, epsilon=1e-3, **kw):
+                assert axis == -1
+                self.eps, self.gamma = float(epsilon), None
+                stub.layers.append(self)
+
+            def apply(self, h):
+                if self.gamma is None:
+                    self.gamma = (1.0 + 0.1 * stub.rng.standard_normal(h.shape[-1])).astype(np.float32)
+                    self.beta = (0.05 * stub.rng.standard_normal(h.shape[-1])).astype(np.float32)
+                mean = h.mean(axis=-1, keepdims=True, dtype=np.float32)
+                var = np.mean((h - mean) ** 2, axis=-1, keepdims=True, dtype=np.float32)
+                return ((h - mean) / np.sqrt(var + np.float32(self.eps)) * self.gamma + self.beta).astype(np.float32)
+
         class Dropout(Layer):
             def __init__(self, rate, **kw):
                 pass
@@ -203,8 +250,11 @@ class _KerasStub:
             def summary(self):
                 return ""
 
-        layers = types.SimpleNamespace(Conv1D=Conv1D, Dense=Dense, Dropout=Dropout, Flatten=Flatten)
-        self.tf = types.SimpleNamespace(keras=types.SimpleNamespace(layers=layers))
+        layers = types.SimpleNamespace(Conv1D=Conv1D, Dense=Dense, Dropout=Dropout, Flatten=Flatten, MultiHeadAttention=MultiHeadAttention,
+                                       LayerNormalization=LayerNormalization)
+        self.tf = types.SimpleNamespace(keras=types.SimpleNamespace(layers=layers),
+                                        expand_dims=lambda x, axis: Sym(lambda v: np.expand_dims(x.fn(v), axis)),
+                                        squeeze=lambda x, axis: Sym(lambda v: np.squeeze(x.fn(v), axis)))
         self.glb = {"tf": self.tf, "Input": Input, "Model": Model, "regularizers": types.SimpleNamespace(l2=lambda v: None), "print": lambda *a, **k: None}
 
 
@@ -217,6 +267,19 @@ def build_reference_conv1d_model(p_in, p_out, seed):
     stub = _KerasStub(seed)
     fn = _method(_tree(NNS), None, "conv1D_PCA", stub.glb, NNS)
     model = fn(n_layers, width, p_in, p_out, 0.1, 1e-4)       # train.py:568 argument order (dropout, L2: inert at inference)
+    return model, stub
+
+
+def build_reference_attention_model(p_in, p_out, seed):
+    """``utils.define_model_arch('MLP_attention')`` (utils.py:455-457) and ``NNs.densePCA_attention`` (NNs.py:40-72) executed as
+    written.  Its ``Input((int(PC_input),))`` is a plain vector: the stub's Input must not add an axis."""
+    UTL = f"{REF}/Improved_SM/deltaU_to_deltaP/source/pressureSM_deltas/utils.py"
+    NNS = f"{REF}/Improved_SM/deltaU_to_deltaP/source/pressureSM_deltas/NNs.py"
+    arch = _method(_tree(UTL), None, "define_model_arch", {}, UTL)
+    n_layers, width = arch("MLP_attention")
+    stub = _KerasStub(seed)
+    fn = _method(_tree(NNS), None, "densePCA_attention", stub.glb, NNS)
+    model = fn(n_layers, width, p_in, p_out, 0.1, 1e-4)       # train.py argument order (dropout, L2: inert at inference)
     return model, stub
 
 
@@ -256,7 +319,7 @@ def run_gradp(grid6, model, keep_labels=False):
     return out
 
 
-def run_deltas(grid5, model, U_max_norm=1.0, max_abs_p=1.0, _keep=None, keras_model=None):
+def run_deltas(grid5, model, U_max_norm=1.0, max_abs_p=1.0, _keep=None, keras_model=None, block_error=False):
     """SMD.timeStep, from the block extraction to ``assemble_prediction``."""
     tree = _tree(SMD)
     glb = {"np": np, "ndimage": None}
@@ -272,7 +335,9 @@ def run_deltas(grid5, model, U_max_norm=1.0, max_abs_p=1.0, _keep=None, keras_mo
     self.model = keras_model if keras_model is not None else dense_callable(model.weights)
     body = _find_fn(tree, "timeStep", "Evaluation").body
     stmts = _slice(body, lambda s: s.startswith("x_list = []"),
-                   lambda s: s.startswith("(deltap_res, change_in_deltap) =") or s.startswith("deltap_res, change_in_deltap ="))
+                   # block_error: stop BEFORE the assembly, which corrects the blocks of res_concat in place (a view is passed)
+                   (lambda s: s.startswith("res_concat = res_concat * self.max_abs_p")) if block_error else
+                   (lambda s: s.startswith("(deltap_res, change_in_deltap) =") or s.startswith("deltap_res, change_in_deltap =")))
     Ny, Nx = grid5.shape[:2]
     loc = {"self": self, "grid": grid5[None].astype(np.float64).copy(), "apply_filter": False,
            "U_max_norm": U_max_norm, "deltaU_change_grid": np.zeros((Ny, Nx)),
@@ -291,6 +356,15 @@ def run_deltas(grid5, model, U_max_norm=1.0, max_abs_p=1.0, _keep=None, keras_mo
             os.chdir(cwd)
             if _keep is not None:                        # what was computed before an exception of the reassembly
                 _keep.update({k: loc[k] for k in ("x_input", "N") if k in loc})
+    if block_error:
+        # utils.compute_in_block_error (utils.py:210-243) itself, called with the arguments of SM_call.py:554-555 (the statement
+        # is dropped from the slice above because it lives in another module): decoded, dimensional blocks against the de-meaned
+        # label blocks times the same scale, over the blocks' flow cells
+        UTL = f"{REF}/Improved_SM/deltaU_to_deltaP/source/pressureSM_deltas/utils.py"
+        fn = _method(_tree(UTL), None, "compute_in_block_error", {"np": np, "print": lambda *a, **k: None}, UTL)
+        flow_bool = self.x_array[..., 2:3] != 0
+        a, b = fn(loc["res_concat"], self.y_array * self.max_abs_p * pow(U_max_norm, 2.0), flow_bool)
+        return np.array([a, b], np.float64)
     return dict(x_input=np.asarray(loc["x_input"], np.float64), fields=np.asarray(loc["deltap_res"])[..., None],
                 n_blocks=np.int64(loc["N"]))
 
@@ -648,6 +722,16 @@ def main():
             out = dict(raised=np.int64(raised), x_input=np.asarray(keep["x_input"], np.float64), n_blocks=np.int64(keep["N"]))
         np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
 
+    # ---- compute_in_block_error (utils.py:210-243 at SM_call.py:555): the block-level error of three deltas cases, labels = the
+    #      grids' synthetic delta-p channel
+    be = {}
+    for name in cases.BLOCK_ERROR_CASES:
+        grid, model = cases.build(name)
+        be[name] = run_deltas(grid, model, U_max_norm=cases.GOLDEN_CASES[name].get("U_max_norm", 1.0),
+                              max_abs_p=cases.GOLDEN_CASES[name].get("max_abs_p", 1.0), block_error=True)
+        print(f"block_error {name}: pred_minus_true_block={be[name][0]:.6e} squared={be[name][1]:.6e}")
+    np.savez_compressed(os.path.join(HERE, "block_error_deltas.npz"), **be)
+
     for name in cases.GOLDEN_CASES:
         grid, model = cases.build(name)
         if cases.GOLDEN_CASES[name].get("chapter4"):
@@ -664,6 +748,23 @@ def main():
                 out[f"convK{i}"], out[f"convb{i}"] = l.K, l.b
             out["denseW"], out["denseb"] = dense[0].W, dense[0].b
             print(f"{name}: reference-built conv1D_PCA: filters {[l.filters for l in convs]}, kernel {convs[0].k}, head {dense[0].W.shape}")
+        elif cases.GOLDEN_CASES[name].get("attention"):
+            km, stub = build_reference_attention_model(model.p_in, model.p_out, seed=cases.GOLDEN_CASES[name]["seed"])
+            out = run_deltas(grid, model, keras_model=km)
+            kinds = [type(l).__name__ for l in stub.layers]
+            dense = [l for l in stub.layers if hasattr(l, "W")]
+            mha = [l for l in stub.layers if kinds[stub.layers.index(l)] == "MultiHeadAttention"]
+            lns = [l for l in stub.layers if hasattr(l, "gamma")]
+            assert len(mha) == 1 and len(lns) == len(dense) - 1 and kinds[0] == "Dense" and kinds[-1] == "Dense", kinds
+            for i, l in enumerate(dense):
+                out[f"denseW{i}"], out[f"denseb{i}"] = l.W, l.b
+            for k, v in mha[0].P.items():
+                if k[1] in "vo":      # the query / key projections cannot change the result (softmax over ONE key, tests/test_attention.py): not kept
+                    out["att_" + k] = v
+            for i, l in enumerate(lns):
+                out[f"ln_gamma{i}"], out[f"ln_beta{i}"] = l.gamma, l.beta
+            out["ln_eps"] = np.float64(lns[0].eps)
+            print(f"{name}: reference-built densePCA_attention: layers {kinds}, dense {[l.W.shape for l in dense]}, heads {mha[0].h} x {mha[0].kd}")
         elif model.variant == "deltas":
             out = run_deltas(grid, model, U_max_norm=cases.GOLDEN_CASES[name].get("U_max_norm", 1.0),
                              max_abs_p=cases.GOLDEN_CASES[name].get("max_abs_p", 1.0))

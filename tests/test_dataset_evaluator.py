@@ -112,7 +112,15 @@ def test_evaluation_from_files_end_to_end(ds):
     from psm_amd import call_SM_main
     rep = call_SM_main(5e-3, c["model_path"], 128, 0.25, 0.95, 0.95, 128, c["dataset_path"], False, "std", False, False, False,
                        False, 1, 3, artifact_dir=d)
-    assert len(rep["sims"]) == 1 and set(rep["overall"]) == {"BIAS", "RMSE", "STDE"}
+    assert len(rep["sims"]) == 1 and set(rep["overall"]) == {"BIAS", "RMSE", "STDE", "BIAS_block", "RSME_block", "STDE_block"}
+    # SM_call.py:553-557, 824-826: the block-level error of the last frame against the oracle's restatement of
+    # utils.compute_in_block_error on ITS decoded blocks and de-meaned label blocks
+    lay = orc.block_layout("deltas", grid.shape[0], grid.shape[1])
+    yb = orc.label_blocks(grid[..., :3], grid[..., 3], lay, 3)
+    scale = cases.DATASET_MAXS[3] * float(U) ** 2
+    a, b = orc.compute_in_block_error(sol.block_pred, yb * scale, sol.x_blocks[..., 2:3] != 0)
+    assert abs(ev.pred_minus_true_block[-1] - a) <= 2e-4 * np.sqrt(b) and abs(ev.pred_minus_true_squared_block[-1] - b) <= 2e-4 * b
+    assert rep["overall"]["RSME_block"] > 0 and len(ev.pred_minus_true_block) == len(ev.pred_minus_true)
     flow = ~ev.no_flow_bool
     diff = (res - ev.cfd_results)[flow]
     norm = ev.cfd_results[flow].max() - ev.cfd_results[flow].min()

@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 def oracle_model(m):
     sc = orc.Scaler(m.scaler_kind, m.in_a, m.in_b, m.out_a, m.out_b)
     return orc.Model(m.variant, m.c_in, m.c_out, m.comp_in, m.mean_in, m.comp_out, m.mean_out,
-                     m.weights, sc, m.out_scale, m.S, m.ov, m.sdf_ch, getattr(m, "conv1d", ()))
+                     m.weights, sc, m.out_scale, m.S, m.ov, m.sdf_ch, getattr(m, "conv1d", ()), getattr(m, "attention", None))
 
 
 def rel_l2(a, b):

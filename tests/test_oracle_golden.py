@@ -11,7 +11,7 @@ from oracle import psm_oracle as orc
 def oracle_model(m):
     sc = orc.Scaler(m.scaler_kind, m.in_a, m.in_b, m.out_a, m.out_b)
     return orc.Model(m.variant, m.c_in, m.c_out, m.comp_in, m.mean_in, m.comp_out, m.mean_out,
-                     m.weights, sc, m.out_scale, m.S, m.ov, m.sdf_ch, getattr(m, "conv1d", ()))
+                     m.weights, sc, m.out_scale, m.S, m.ov, m.sdf_ch, getattr(m, "conv1d", ()), getattr(m, "attention", None))
 
 
 @pytest.mark.parametrize("name", list(cases.GOLDEN_CASES))
