@@ -113,6 +113,8 @@ struct psm_handle {
   const double* pinned_cells = nullptr;   // caller buffers registered with psm_pin_buffers (DMA without staging copies)
   double* pinned_p = nullptr;
   double* pinned_p_dev = nullptr;       // device-side address of the registered output (the last kernel writes p straight into it)
+  const double* pinned_cells_dev = nullptr;   // device-side address of the registered input (psm_stage_cells_kernel reads it over PCIe)
+  hipGraphExec_t mesh_graph = nullptr;  // psm_solve on registered buffers: stage + to_grid + the solve + to_mesh as ONE graph replay
   double maxs[4] = {1, 1, 1, 1};
   int normalise_sdf = 0, fill_input = 0;
   double case_maxs[4] = {1, 1, 1, 1}, case_delta = 5e-3, case_wall = 0.05;   // psm_set_case (PM:106-109, 195, 494)
@@ -312,6 +314,7 @@ void ring_drop_graphs(psm_handle* h);
 void destroy_graphs(psm_handle* h) {
   for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
   h->graphs.clear();
+  if (h->mesh_graph) { (void)hipGraphExecDestroy(h->mesh_graph); h->mesh_graph = nullptr; }
   ring_drop_graphs(h);
 }
 
@@ -433,6 +436,8 @@ std::vector<float4> pack_comp_out(const double* comp, int P, int K_out, int Gd) 
 }
 
 void unpin_buffers(psm_handle* h) {
+  if (h->mesh_graph) { (void)hipGraphExecDestroy(h->mesh_graph); h->mesh_graph = nullptr; }      // it holds the registered addresses
+  h->pinned_cells_dev = nullptr;
   if (h->pinned_cells) { (void)hipHostUnregister((void*)h->pinned_cells); h->pinned_cells = nullptr; }
   if (h->pinned_p) { (void)hipHostUnregister((void*)h->pinned_p); h->pinned_p = nullptr; h->pinned_p_dev = nullptr; }
 }
@@ -797,6 +802,30 @@ int solve_device(psm_handle* h, const float* d_grid, int n_cases, const float* o
   return PSM_OK;
 }
 
+// psm_solve on registered, mapped caller buffers: every device-side step of the call, in stream order (captured once)
+int mesh_sequence(psm_handle* h, int64_t n, hipStream_t st) {
+  int n_partials = 0;
+  HIPCHK(h, psm_launch_stage_cells(h->pinned_cells_dev, h->d_cells, n, h->d_umax_part, &n_partials, st));
+  PsmToGridArgs ga{};
+  ga.cells = h->d_cells; ga.umax = nullptr; ga.umax_val = 0.0;
+  ga.umax_partials = h->d_umax_part; ga.n_partials = n_partials; ga.umax_out = h->d_umax;
+  ga.vtx = h->d_vtx_m2g; ga.wts = h->d_wts_m2g; ga.src_of_cell = h->d_src_of_cell;
+  ga.sdf = h->d_sdf; ga.grid = h->d_grid_stage; ga.n_grid = (int64_t)h->Ny * h->Nx;
+  ga.max_abs_ux = h->maxs[0]; ga.max_abs_uy = h->maxs[1]; ga.sdf_scale = h->normalise_sdf ? 1.0 / h->maxs[2] : 1.0;
+  ga.c_in = h->cfg.c_in; ga.fill = h->fill_input;
+  HIPCHK(h, psm_launch_to_grid(ga, st));
+  h->in_mesh_solve = true;
+  int rc = launch_all(h, h->ws0, h->d_grid_stage, 1, h->d_fields_stage, h->d_ones, st, nullptr);
+  h->in_mesh_solve = false;
+  if (rc) return rc;
+  PsmToMeshArgs ma{};
+  ma.cells = h->d_cells; ma.umax = h->d_umax; ma.umax_val = 0.0; ma.vtx = h->d_vtx_g2m; ma.wts = h->d_wts_g2m; ma.cell_of_point = h->d_cell_of_point;
+  ma.field = h->d_fields_stage; ma.near_wall = h->d_near_wall; ma.p_out = h->pinned_p_dev; ma.n_cells = n; ma.max_abs_p = h->maxs[3];
+  ma.c_out = h->cfg.c_out;
+  HIPCHK(h, psm_launch_to_mesh(ma, st));
+  return PSM_OK;
+}
+
 // ---- guard of the bound-geometry contract, host side -------------------------------------------------------------
 // true once per trip: a guard wave of a solve on workspace `w` found a grid whose flow-cell pattern is not the bound one
 bool guard_take(psm_handle* h, Workspace& w) {
@@ -1108,6 +1137,8 @@ int psm_set_scaler(psm_handle* h, const double* in_a, const double* in_b, const 
   if (!in_a || !out_a) return fail(h, PSM_ERR_ARG, "null scaler array");
   if (h->cfg.scaler != PSM_SCALER_MAX_ABS && (!in_b || !out_b)) return fail(h, PSM_ERR_ARG, "null scaler array");
   HIPCHK(h, hipSetDevice(h->cfg.device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  destroy_graphs(h);                          // captured launches hold the addresses of the arrays re-uploaded below
   h->bound = false;
   std::vector<float> ia(h->ld_in, 0.f), ib(h->ld_in, 0.f), sa(h->ld_out, 0.f), sb(h->ld_out, 0.f);
   // x_in = coeff*ia + ib ; res' = res*sa + sb  (affine forms of SMD:505-539, evaluated in f64 here)
@@ -2001,6 +2032,36 @@ int psm_solve_begin(psm_handle* h, const double* cells, int64_t n, int32_t rank,
   if (n != h->n_cells) return fail(h, PSM_ERR_ARG, "cell count differs from the geometry");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   hipStream_t st = h->stream;
+  // Both arrays registered (psm_pin_buffers) and mapped: the whole call is ONE hipGraph replay -- psm_stage_cells_kernel reads
+  // the cells over PCIe and takes the partial maxima of U_max on the way (no DMA-engine copy, no host pass, U_max never leaves
+  // the device: to_grid reduces the partials and hands the scalar to to_mesh through d_umax), to_grid, the kernels of the
+  // solve, to_mesh storing p straight into the caller's array.
+  // PSM_MESH_GRAPH: 0 = the separate submissions below (DMA copy, host U_max), 1 = one graph replay, 2 = the same sequence as
+  // plain launches (measured default)
+  static const int mesh_mode = getenv("PSM_MESH_GRAPH") ? atoi(getenv("PSM_MESH_GRAPH")) : 2;
+  if (mesh_mode != 0 && h->timed_kernel < 0 && n <= 131072 && cells == h->pinned_cells && h->pinned_cells_dev && p_out == h->pinned_p && h->pinned_p_dev) {
+    h->last_cases = 1;
+    if (mesh_mode == 2) {
+      int rc = mesh_sequence(h, n, st);
+      if (rc) return rc;
+    } else {
+      if (!h->mesh_graph) {
+        hipGraph_t graph = nullptr;
+        HIPCHK(h, hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+        int rc = mesh_sequence(h, n, st);
+        hipError_t e = hipStreamEndCapture(st, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); return fail(h, PSM_ERR_HIP, std::string("psm_solve capture: ") + hipGetErrorString(e)); }
+        e = hipGraphInstantiate(&h->mesh_graph, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { h->mesh_graph = nullptr; return fail(h, PSM_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+      }
+      HIPCHK(h, hipGraphLaunch(h->mesh_graph, st));
+    }
+    h->mesh_copy_out = nullptr;
+    h->mesh_inflight = true;
+    return PSM_OK;
+  }
   if (cells == h->pinned_cells) {            // registered by the caller: DMA straight from its buffer
     HIPCHK(h, hipMemcpyAsync(h->d_cells, cells, (size_t)n * 5 * sizeof(double), hipMemcpyHostToDevice, st));
   } else {
@@ -2086,6 +2147,9 @@ int psm_pin_buffers(psm_handle* h, const double* cells, double* p_out) {
     hipError_t e = hipHostRegister((void*)cells, (size_t)h->n_cells * 5 * sizeof(double), hipHostRegisterDefault);
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(h, PSM_ERR_HIP, std::string("hipHostRegister(cells): ") + hipGetErrorString(e)); }
     h->pinned_cells = cells;
+    void* dc = nullptr;                                   // mapped address: lets psm_stage_cells_kernel read the cells from the host array
+    if (hipHostGetDevicePointer(&dc, (void*)cells, 0) == hipSuccess && getenv("PSM_NO_DIRECT_IN") == nullptr) h->pinned_cells_dev = (const double*)dc;
+    else (void)hipGetLastError();
   }
   if (p_out) {
     hipError_t e = hipHostRegister((void*)p_out, (size_t)h->n_cells * sizeof(double), hipHostRegisterDefault);

@@ -39,6 +39,8 @@ struct PsmToMeshArgs {
 hipError_t psm_launch_umax(const double* cells, int64_t n, double* umax, hipStream_t st);
 // parallel form for large meshes: partials[0 .. *n_partials) (capacity 256), reduced by psm_to_grid_kernel
 hipError_t psm_launch_umax_partial(const double* cells, int64_t n, double* partials, int* n_partials, hipStream_t st);
+// registered caller buffers: host cells -> device copy + partial maxima (capacity 256) in one kernel, see psm_mesh.hip
+hipError_t psm_launch_stage_cells(const double* host_cells, double* cells, int64_t n, double* partials, int* n_partials, hipStream_t st);
 hipError_t psm_launch_to_grid(const PsmToGridArgs& a, hipStream_t st);
 hipError_t psm_launch_to_mesh(const PsmToMeshArgs& a, hipStream_t st);
 hipError_t psm_launch_interp_to_grid(const double* values, int k, const int32_t* vtx, const double* wts, const int32_t* src_of_cell,

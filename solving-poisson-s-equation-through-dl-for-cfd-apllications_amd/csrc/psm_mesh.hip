@@ -56,6 +56,78 @@ __global__ __launch_bounds__(1024) void psm_umax_partial_kernel(const double* ce
   }
 }
 
+// First kernel of the one-graph psm_solve (registered caller buffers): reads the solver's cells[N,5] array STRAIGHT from host
+// memory (the device-side address of the registered pages) -- every row requested at once over PCIe, no DMA-engine copy and no
+// copy -> kernel dependency in front of the first kernel --, stores it to the device copy the gathers read, and takes the
+// per-workgroup partial maxima of sqrt(Ux^2 + Uy^2) on the way (PM:270; reduced by every psm_to_grid workgroup).
+typedef double psm_d2 __attribute__((ext_vector_type(2)));
+// A workgroup owns 512 rows = 20480 bytes = 1280 16-byte pieces, five per thread, all five requested up front as fully
+// coalesced 16-byte loads (a wave reads 1 KB of consecutive host memory per instruction: whole PCIe read requests, each line
+// asked for once); the pieces go to the device copy from the registers and through LDS to the threads that own the rows'
+// (Ux, Uy) for the maximum.  ALIGNED = false (a host array that is not 16-byte aligned): 8-byte pieces, same structure.
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void psm_stage_cells_kernel(const double* host_cells, double* cells, int64_t n, double* partials) {
+  constexpr int ROWS = 512, NP = ROWS * 5 / 2 / 256;        // 5 pieces of 16 bytes per thread
+  __shared__ double row[ROWS * 5];
+  __shared__ double red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t d0 = (int64_t)blockIdx.x * ROWS * 5, dn = n * 5;          // in doubles
+  if (ALIGNED) {
+    psm_d2 v[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int64_t e = d0 + 2 * (int64_t)(j * 256 + tid);
+      v[j] = (e + 1 < dn) ? __builtin_nontemporal_load(reinterpret_cast<const psm_d2*>(host_cells + e))
+                          : (psm_d2){e < dn ? __builtin_nontemporal_load(host_cells + e) : 0.0, 0.0};
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int64_t e = d0 + 2 * (int64_t)(j * 256 + tid);
+      const int l = 2 * (j * 256 + tid);
+      row[l] = v[j].x; row[l + 1] = v[j].y;
+      if (e + 1 < dn) *reinterpret_cast<psm_d2*>(cells + e) = v[j];
+      else if (e < dn) cells[e] = v[j].x;
+    }
+  } else {
+    double v[2 * NP];
+#pragma unroll
+    for (int j = 0; j < 2 * NP; ++j) {
+      const int64_t e = d0 + (int64_t)(j * 256 + tid);
+      v[j] = e < dn ? __builtin_nontemporal_load(host_cells + e) : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 2 * NP; ++j) {
+      const int64_t e = d0 + (int64_t)(j * 256 + tid);
+      row[j * 256 + tid] = v[j];
+      if (e < dn) cells[e] = v[j];
+    }
+  }
+  __syncthreads();
+  double m = 0.0;
+#pragma unroll
+  for (int k = 0; k < ROWS / 256; ++k) {
+    const int r = k * 256 + tid;
+    if ((int64_t)blockIdx.x * ROWS + r < n) {
+      const double ux = row[r * 5], uy = row[r * 5 + 1];
+      m = nanmax2(m, sqrt(ux * ux + uy * uy));
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) m = nanmax2(m, __shfl_down(m, o, 64));
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  if (tid == 0) partials[blockIdx.x] = nanmax2(nanmax2(red[0], red[1]), nanmax2(red[2], red[3]));
+}
+
+hipError_t psm_launch_stage_cells(const double* host_cells, double* cells, int64_t n, double* partials, int* n_partials, hipStream_t st) {
+  const int64_t wgs = (n + 511) / 512;
+  if (wgs < 1 || wgs > 256) return hipErrorInvalidValue;          // the partials array holds 256 (131 072 cells)
+  *n_partials = (int)wgs;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(host_cells) | reinterpret_cast<uintptr_t>(cells)) & 15) == 0;
+  if (aligned) hipLaunchKernelGGL(psm_stage_cells_kernel<true>, dim3((unsigned)wgs), dim3(256), 0, st, host_cells, cells, n, partials);
+  else hipLaunchKernelGGL(psm_stage_cells_kernel<false>, dim3((unsigned)wgs), dim3(256), 0, st, host_cells, cells, n, partials);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void psm_to_grid_kernel(PsmToGridArgs a) {
   __shared__ double um_s[4];
   double umax_v = a.umax ? *a.umax : a.umax_val;
