@@ -47,6 +47,9 @@ struct PsmHeadArgs {           // 1x1 convolution on a thin activation (c_in <= 
 // arrangement (workgroup tile; 16 columns wide, 4 waves):
 //   0 = 8 rows x NCT (1 or 2) channel tiles of 16, each wave 2 rows x all channel tiles
 //   1 = 2 rows x 4 channel tiles, each wave both rows x one channel tile
+// (round 4: 8 rows x 4 channel tiles with one channel tile per wave and the activation rows kept across ky -- 13 LDS operand
+// reads per 24 MFMAs -- measured at 8 cases per step, bf16: slower on every deep layer, dec3a 21.7 against 15.3 us, with a split
+// in two 14.3 us and its consumer +2.2 us; profiles/r04_conv_experiments.txt; not kept)
 // (4 x 16 and 8 x 16 pixel tiles with 4 channel tiles per wave were measured too: within 1 us per layer at batch 1,
 // slower at 8 cases per step -- the staged bytes per MFMA are not what limits these layers; not kept)
 inline int psm_conv_tile_rows(int arrangement) { return arrangement == 0 ? 8 : arrangement == 1 ? 2 : 0; }

@@ -22,6 +22,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef PSM_CONV_PD
 #define PSM_CONV_PD 1
 #endif
+// bf16 form: activation rows kept across ky (round 4 experiment).  Measured A/B on one box, 8 cases per step: 157.3 / 157.2 us
+// with it, 154.4 / 155.1 us without (profiles/r04_conv_experiments.txt) -- a third of the LDS operand reads gone and the pass
+// 1.5 % SLOWER: the matrix phase is not what these layers wait for.  Off; -DPSM_CONV_KYREUSE=1 builds it.
+#ifndef PSM_CONV_KYREUSE
+#define PSM_CONV_KYREUSE 0
+#endif
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 // activation stores: -DPSM_NT_ACT streams them past the L2 (the consumer is the next launch, on any XCD)
 #ifdef PSM_NT_ACT
@@ -468,6 +474,50 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
     // operand prefetch depth in taps (-DPSM_CONV_PD=n, bf16 form).  Measured with 3 instead of 1: nothing (8 cases bf16 158.4 vs
     // 157.5 us, dec3a 14.6 vs 14.5): a bf16 chunk's matrix phase (0.57 us for 36 MFMAs = 0.24 us of issue) is bound by the
     // THROUGHPUT of its 36 ds_read_b128 per wave (four waves: 0.48 us), not by their latency
+    if constexpr (BF && !X6 && PSM_CONV_KYREUSE) {
+      // bf16 form: ACTIVATION ROWS KEPT ACROSS ky.  The matrix phase of a bf16 chunk was bound by the throughput of its LDS
+      // operand reads (one ds_read_b128 per 16-cycle MFMA: 36 per wave for 36 MFMAs).  For a tap column kx the WM rows of the
+      // three ky taps are WM + 2 distinct tile rows: they are read once and used by all three -- (WM + 2) + 3 WN reads per
+      // 3 WM WN MFMAs (WM = WN = 2: 10 per 12; WM = 8, WN = 1: 13 per 24).  The rows and weights of column kx + 1 are read
+      // while the MFMAs of column kx issue.  Accumulation order: (kx, ky) instead of (ky, kx).
+      f32x4 avr[2][WM + 2], bvr[2][3][WN];
+      auto lds_read_kx = [&](int kx, int s2) {
+#pragma unroll
+        for (int r = 0; r < WM + 2; ++r)
+          avr[s2][r] = *reinterpret_cast<const f32x4*>(&tile[lds_slot((row_w + r) * (TW + 2) + px + kx, kq)]);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int n = 0; n < WN; ++n) bvr[s2][ky][n] = wt[((ky * 3 + kx) * NCT + n) * 64];
+      };
+      lds_read_kx(0, 0);
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int s2 = kx & 1;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int step = kx * 3 + ky;
+          if (ky == 0 && kx + 1 < 3) lds_read_kx(kx + 1, s2 ^ 1);
+#if !defined(PSM_EXP) || PSM_EXP == 3
+          if constexpr (more) {                            // this step's share of the next chunk's requests
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+              if ((i * 9) / NI == step) issue_item(g + 1, i);
+          }
+#endif
+          __builtin_amdgcn_sched_barrier(0);
+#if !defined(PSM_EXP) || PSM_EXP < 3
+#pragma unroll
+          for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int n = 0; n < WN; ++n)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, avr[s2][m + ky]), __builtin_bit_cast(bf16x8, bvr[s2][ky][n]),
+                                                                  acc[m][n], 0, 0, 0);
+#endif
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
     constexpr int PD = (BF && !X6) ? PSM_CONV_PD : 1, NS = PD + 1;
     f32x4 av[NS][WM][PL], bv[NS][WN][PL];
     auto lds_read = [&](int tap, int s) {
@@ -527,6 +577,7 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
 #endif
       // nothing may move across: above all not the combines / LDS stores below, which wait for the loads issued above
       __builtin_amdgcn_sched_barrier(0);
+    }
     }
     USTAMP(3 + 4 * (g - g_beg));
 #if !defined(PSM_EXP) || PSM_EXP == 3

@@ -189,15 +189,23 @@ std::vector<uint16_t> pack_pair(const Conv& c, bool flat, int c0, int c1) {
 }
 
 // workgroup count first (fill 256 CUs), then the most reuse per workgroup
-void choose_config(Conv& c, int H, int W, int n_cases, bool can_split, int chunk_ch, int ks_cap = 8, bool x6_ok = false) {
+// forced: index into the candidate list (psm_unet_autotune's measured tile choice), -1 = by rule; the split rule below then
+// runs for the tile that was chosen, not for the rule's.
+void choose_config(Conv& c, int H, int W, int n_cases, bool can_split, int chunk_ch, int ks_cap = 8, bool x6_ok = false, int forced = -1) {
   const int ctiles = (c.cout + 15) / 16;
   struct Cand { int arr, nct, th; };
-  const Cand cands[3] = {{0, 2, 8}, {0, 1, 8}, {1, 4, 2}};     // arrangements 2 and 3 (psm_unet.h) only by override / autotune
+  const Cand cands[3] = {{0, 2, 8}, {0, 1, 8}, {1, 4, 2}};
   // diagnostic knobs (tools/unet_bench.py sweeps): workgroups wanted before reuse counts, deepest split
   const long fill = getenv("PSM_UNET_FILL") ? atol(getenv("PSM_UNET_FILL")) : 256;
   const int ks_max = getenv("PSM_UNET_KSPLIT_MAX") ? atoi(getenv("PSM_UNET_KSPLIT_MAX")) : 8;
   long best_score = -1;
-  for (const Cand& k : cands) {
+  const bool use_forced = forced >= 0 && forced < 3 && cands[forced].nct <= ctiles;
+  if (use_forced) {
+    const Cand& k = cands[forced];
+    c.arrangement = k.arr; c.nct = k.nct; c.groups = (ctiles + k.nct - 1) / k.nct;
+  }
+  for (int ki = 0; ki < 3 && !use_forced; ++ki) {
+    const Cand& k = cands[ki];
     if (k.nct > ctiles) continue;                       // never compute padded channel tiles
     const int groups = (ctiles + k.nct - 1) / k.nct;
     const long wgs = (long)((W + 15) / 16) * ((H + k.th - 1) / k.th) * groups * n_cases;
@@ -510,17 +518,8 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
     const int x6c = ci < u->x6_choice.size() ? u->x6_choice[ci] : -1;
     const bool x6_ok = !u->bf16 && u->x6 && c.k == 3 && !stem_layer && c.src != 0 && (x6c == 1 || (x6c < 0 && c.cin >= 64));
     if (c.k == 3) choose_config(c, H, W, max_cases, feeds_conv3 && getenv("PSM_UNET_NO_SPLIT") == nullptr, u->bf16 ? 32 : 16,
-                                ci < u->ksplit_cap.size() ? u->ksplit_cap[ci] : 8, x6_ok);
-    if (c.k == 3 && ci < u->tile_choice.size() && u->tile_choice[ci] >= 0) {           // measured choice of psm_unet_autotune
-      static const int ARR[3] = {0, 0, 1}, NCT[3] = {2, 1, 4};
-      const int arr = ARR[u->tile_choice[ci]], nct = NCT[u->tile_choice[ci]];
-      if (nct <= (c.cout + 15) / 16) {
-        c.arrangement = arr; c.nct = nct; c.groups = ((c.cout + 15) / 16 + nct - 1) / nct;
-        c.x6 = x6_ok && arr == 0;
-        c.n_chunks = (c.cin + (c.x6 || u->bf16 ? 32 : 16) - 1) / (c.x6 || u->bf16 ? 32 : 16);
-        while (c.ksplit > 1 && c.ksplit > c.n_chunks) c.ksplit /= 2;
-      }
-    }
+                                ci < u->ksplit_cap.size() ? u->ksplit_cap[ci] : 8, x6_ok,
+                                ci < u->tile_choice.size() ? u->tile_choice[ci] : -1);     // measured choice of psm_unet_autotune
     // diagnostic override: PSM_UNET_FORCE="layer:arrangement:nct:ksplit,..." (tools/unet_bench.py experiments)
     if (const char* f = getenv("PSM_UNET_FORCE")) {
       for (const char* q = f; q && *q; q = std::strchr(q, ',') ? std::strchr(q, ',') + 1 : nullptr) {

