@@ -610,6 +610,30 @@ def guard_trips_after(sur, what):
     return n
 
 
+def solver_boundary_leg(synthetic, device, steps):
+    """psm_solve as DLPoissonFoam calls it (PythonComm.H:1-37): the solver's persistent cells[N,5] / p[N] float64 arrays,
+    registered once (psm_pin_buffers), one synchronous call per time step -- mesh -> grid, the surrogate, grid -> mesh on the
+    GPU.  16 k-cell channel mesh, 138 x 300 grid, Chapter-5 layout (the shape of tests/measure/mesh_bench.py)."""
+    import numpy as np
+    from psm_amd import SolverModule
+    array, top, obst = synthetic.channel_mesh()
+    model = synthetic.make_model("chapter5", p_in=32, p_out=32, seed_pca=4321, seed_w=11)
+    sm = SolverModule(model, (1.0, 0.536133, 0.999023, 0.510742), device=device)
+    sm.init_func(array, top, obst)
+    cells, p = np.ascontiguousarray(array, np.float64).copy(), np.empty(array.shape[0], np.float64)
+    sm.pin(cells, p)
+    for _ in range(50):
+        sm.py_func(cells, out=p)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sm.py_func(cells, out=p)
+    dt = (time.perf_counter() - t0) / steps
+    sm.unpin()
+    return {"psm_solve_us": dt * 1e6, "solves_per_s": 1.0 / dt, "cells": int(array.shape[0]), "grid": [int(sm._sur.ny), int(sm._sur.nx)],
+            "steps": steps, "finite": bool(np.isfinite(p).all()),
+            "what": "psm_solve on registered buffers (psm_pin_buffers), synchronous, Python call overhead included"}
+
+
 def host_rates(sur, grids, n_cases, steps, warmup, modes):
     """psm_bench_host (C++ loop through the public C-ABI): {mode name: (solves/s per rank, last field)}."""
     import ctypes as C
@@ -979,6 +1003,13 @@ def main():
                           "hip_initialised_before_it_was_set": bool(hip_up_before)},
             "steps": n_e2e, "solves_per_s_per_rank": {k: v[0] for k, v in rates.items()},
             "matches_device_resident_result": bool(np.array_equal(rates[key][1], to_host(torch, d_out[last_in])))}
+
+    # ---- the solver boundary (psm_solve = py_func of PythonComm.H: cells[N,5] float64 in, p[N] float64 out), registered buffers
+    if not args.no_extras and world == 1 and args.workload == "config1" and "end_to_end" in out:
+        try:
+            out["end_to_end"]["psm_solve"] = solver_boundary_leg(synthetic, local_rank, max(200, min(args.steps, 2000)))
+        except Exception as e:                                # reported, not fatal for the headline
+            out["end_to_end"]["psm_solve"] = {"error": repr(e)[:200]}
 
     # ---- BASELINE configs[3]: the case batch, 8 random-obstacle cases per GPU per step
     m3 = None

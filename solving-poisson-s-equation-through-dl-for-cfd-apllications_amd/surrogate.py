@@ -997,10 +997,11 @@ class SolverModule:
     the ``maxs`` file (python_module.py:106-109)."""
 
     def __init__(self, model: SurrogateModel, maxs=(1.0, 1.0, 1.0, 1.0), device: int = 0, delta: float = 5e-3,
-                 geometry: str = "scipy"):
-        """``geometry``: who builds init_func's tables -- 'scipy' (this host, with the routines the reference calls:
-        qhull Delaunay in both directions) or 'native' (the library's C++ builder behind ``psm_init_geometry``, no SciPy;
-        differences listed at include/psm.h)."""
+                 geometry: str = "native"):
+        """``geometry``: who builds init_func's tables -- 'native' (default: the library's C++ builder behind
+        ``psm_init_geometry``, csrc/psm_geometry.cpp -- what a C++ solver gets, no SciPy and no Python helper code on the
+        path) or 'scipy' (this host, with the routines the reference calls: qhull Delaunay in both directions; the tables
+        the golden vectors were produced with).  Differences between the two are listed at include/psm.h."""
         if geometry not in ("scipy", "native"):
             raise ValueError("geometry must be 'scipy' or 'native'")
         self.model, self.maxs, self.device, self.delta = model, tuple(float(v) for v in maxs), device, delta

@@ -29,6 +29,6 @@ om = oracle_model(model)
 t0 = time.perf_counter(); n = 0
 while time.perf_counter() - t0 < 5: ref = orc.py_func_mesh(array, geo, om, maxs)[0]; n += 1
 dc = (time.perf_counter() - t0) / n
-print(f"cells {array.shape[0]}, grid {sm.tables.ny}x{sm.tables.nx}, blocks {sm._sur.B}: init_func {t_init:.2f} s (host, SciPy qhull)")
+print(f"cells {array.shape[0]}, grid {sm._sur.ny}x{sm._sur.nx}, blocks {sm._sur.B}: init_func {t_init:.2f} s (host, SciPy qhull)")
 print(f"psm_solve (py_func): {dt*1e6:7.1f} us per call = {1/dt:8.0f} solves/s ; NumPy oracle py_func {dc*1e3:6.2f} ms ({dt and dc/dt:.0f}x)")
 print("max |p - oracle| / max|p| =", np.abs(p - ref).max() / np.abs(ref).max())

@@ -202,6 +202,8 @@ def test_default_bench_line():
     e = full["end_to_end"]
     assert e["matches_device_resident_result"] is True and e["hw_queues"]["hip_initialised_before_it_was_set"] is False
     assert {"sync_pageable", "ring_pageable_depth4", "ring_registered_depth4", "ring_zero_copy_depth4"} <= set(e["solves_per_s_per_rank"])
+    ps = e["psm_solve"]                                   # the solver boundary (py_func of PythonComm.H) on registered buffers
+    assert ps.get("finite") is True and 10 < ps["psm_solve_us"] < 500 and ps["cells"] > 10000, ps
     fc = full["case_batch"]
     assert "configs[3]" in fc["workload"] and fc["gathered_shape"] == [8, 256, 256, 1]
     x6 = [k for k in fc["roofline"]["kernels"] if "x6" in k["name"]]

@@ -22,7 +22,7 @@ for mode in ("bound", "general"):
     for _ in range(200): sm.py_func(cells, out=out)
     dt = (time.perf_counter() - t0) / 200
     res[mode] = out.copy()
-    print(f"{mode:8s}: cells {array.shape[0]}, grid {sm.tables.ny}x{sm.tables.nx}, blocks {sm._sur.B}, bound={sm._sur.geometry_bound}, "
+    print(f"{mode:8s}: cells {array.shape[0]}, grid {sm._sur.ny}x{sm._sur.nx}, blocks {sm._sur.B}, bound={sm._sur.geometry_bound}, "
           f"init_func {t_init:.1f} s, psm_solve {dt*1e6:7.1f} us per call", flush=True)
     sm.unpin()
 d = np.abs(res["bound"] - res["general"]).max() / np.abs(res["general"]).max()
