@@ -12,10 +12,11 @@ cd $R
 export PSM_BENCH_LOGDIR=$O/detail_bench; timeout -k 10 400 python bench.py > $O/bench.log 2>$O/bench.err; tail -1 $O/bench.log | cut -c1-200
 
 # convolutional path: kernel stats + bench lines
+export PSM_BENCH_LOGDIR=$O/detail_prof
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/unet_stats -- python3 $R/bench.py --workload unet8_bf16 --steps 100 --warmup 10 --no-cpu-baseline > $O/unet_stats.log 2>&1; echo "unet stats rc=$?"
 cd $R
 export PSM_BENCH_LOGDIR=$O/detail_unet; timeout -k 10 300 python bench.py --workload unet > $O/bench_unet.log 2>&1; tail -1 $O/bench_unet.log | cut -c1-160
-export PSM_BENCH_LOGDIR=$O/detail_unet; export PSM_BENCH_LOGDIR=$O/detail_unet8; timeout -k 10 300 python bench.py --workload unet8 --no-cpu-baseline > $O/bench_unet8.log 2>&1; tail -1 $O/bench_unet8.log | cut -c1-160
-export PSM_BENCH_LOGDIR=$O/detail_unet; export PSM_BENCH_LOGDIR=$O/detail_unet8; export PSM_BENCH_LOGDIR=$O/detail_unet8_bf16; timeout -k 10 300 python bench.py --workload unet8_bf16 --no-cpu-baseline > $O/bench_unet8_bf16.log 2>&1; tail -1 $O/bench_unet8_bf16.log | cut -c1-160
+export PSM_BENCH_LOGDIR=$O/detail_unet8; timeout -k 10 300 python bench.py --workload unet8 --no-cpu-baseline > $O/bench_unet8.log 2>&1; tail -1 $O/bench_unet8.log | cut -c1-160
+export PSM_BENCH_LOGDIR=$O/detail_unet8_bf16; timeout -k 10 300 python bench.py --workload unet8_bf16 --no-cpu-baseline > $O/bench_unet8_bf16.log 2>&1; tail -1 $O/bench_unet8_bf16.log | cut -c1-160
 python tools/pmc_summary.py $TAG
