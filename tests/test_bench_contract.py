@@ -184,6 +184,8 @@ def test_default_bench_line():
     cb = d["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] == "port" and cb["value"] > 0 and len(cb["sample"]) <= 120
     assert d["l2_vs_oracle"] < 1e-5 and d["value_end_to_end"] > 1000 and len(d["devices"]) == 1
+    gp = d["l2_vs_reference_goldens"]                     # outputs of the reference's own statements, one golden per block layout
+    assert set(gp) == {"gradp_272x288", "deltas_256x256", "chapter5_300x400"} and all(0 < v < 5e-5 for v in gp.values()), gp
     cbat = d["case_batch"]
     assert cbat["cases_per_step_per_gpu"] == 8 and cbat["value"] > 1000 and cbat["total_cases"] == 8 and cbat["guard_trips"] == 0
     assert cbat["bound"] in ("mfma", "hbm") and 0 < cbat["frac"] < 1 and cbat["l2_vs_oracle"] < 1e-5
