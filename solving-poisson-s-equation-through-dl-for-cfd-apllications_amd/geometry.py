@@ -34,12 +34,16 @@ class GeometryTables:
     box: tuple = None        # (min_x, max_x, min_y, max_y) of the inside-domain test (evaluators)
 
 
+def _cell_centres(lo: float, hi: float, delta: float) -> np.ndarray:
+    """Centres of the ``int(round((hi - lo) / delta))`` cells of width ``delta`` that tile [lo, hi] (Python's round: half to even)."""
+    n_cells = int(round((hi - lo) / delta))
+    return np.linspace(lo + delta / 2, hi - delta / 2, n_cells)
+
+
 def create_uniform_grid(x_min, x_max, y_min, y_max, delta):
-    """python_module.py:42-48 / utils.py:111-125."""
-    X0 = np.linspace(x_min + delta / 2, x_max - delta / 2, num=int(round((x_max - x_min) / delta)))
-    Y0 = np.linspace(y_min + delta / 2, y_max - delta / 2, num=int(round((y_max - y_min) / delta)))
-    XX0, YY0 = np.meshgrid(X0, Y0)
-    return XX0.flatten(), YY0.flatten()
+    """The lattice of python_module.py:42-48 / utils.py:111-125: cell-centred, x fastest -> (X0, Y0), each [ny * nx]."""
+    xs, ys = _cell_centres(x_min, x_max, delta), _cell_centres(y_min, y_max, delta)
+    return np.tile(xs, ys.size), np.repeat(ys, xs.size)
 
 
 def interp_weights(xyz, uvw, idw_fallback: bool = False):
@@ -52,13 +56,13 @@ def interp_weights(xyz, uvw, idw_fallback: bool = False):
     (``1 / max(d**2, 1e-6)``, normalised) instead -- all positive, so ``interpolate_fill`` keeps them."""
     from scipy.spatial import Delaunay
     tri = Delaunay(xyz)
-    simplex = tri.find_simplex(uvw)
-    vertices = np.take(tri.simplices, simplex, axis=0)
-    temp = np.take(tri.transform, simplex, axis=0)
-    d = 2
-    delta = uvw - temp[:, d]
-    bary = np.einsum("njk,nk->nj", temp[:, :d, :], delta)
-    wts = np.hstack((bary, 1 - bary.sum(axis=1, keepdims=True)))
+    simplex = tri.find_simplex(uvw)                      # -1 outside the hull: indexes the LAST simplex below, like the reference
+    vertices = tri.simplices[simplex].copy()
+    # SciPy stores, per simplex, the inverse edge matrix (rows 0, 1) and the simplex's last vertex (row 2): the first two
+    # barycentric coordinates are Tinv . (target - r), the third closes the sum to one
+    T = tri.transform[simplex]
+    first_two = np.einsum("njk,nk->nj", T[:, :2, :], np.asarray(uvw) - T[:, 2, :])
+    wts = np.concatenate([first_two, 1.0 - first_two.sum(axis=1, keepdims=True)], axis=1)
     if idw_fallback:
         out = simplex == -1
         if out.any():

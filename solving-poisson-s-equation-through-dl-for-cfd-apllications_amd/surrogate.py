@@ -997,11 +997,14 @@ class SolverModule:
     the ``maxs`` file (python_module.py:106-109)."""
 
     def __init__(self, model: SurrogateModel, maxs=(1.0, 1.0, 1.0, 1.0), device: int = 0, delta: float = 5e-3,
-                 geometry: str = "native"):
-        """``geometry``: who builds init_func's tables -- 'native' (default: the library's C++ builder behind
-        ``psm_init_geometry``, csrc/psm_geometry.cpp -- what a C++ solver gets, no SciPy and no Python helper code on the
-        path) or 'scipy' (this host, with the routines the reference calls: qhull Delaunay in both directions; the tables
-        the golden vectors were produced with).  Differences between the two are listed at include/psm.h."""
+                 geometry: str = "scipy"):
+        """``geometry``: who builds init_func's tables -- 'scipy' (default in this Python mirror: the routines the reference
+        itself calls, qhull Delaunay in both directions, so that the tables -- including qhull's arbitrary choice of diagonal
+        in every cocircular lattice square of the grid -> mesh step -- are the reference's) or 'native' (the library's C++
+        builder behind ``psm_init_geometry``, csrc/psm_geometry.cpp: what a C++ solver gets; no SciPy).  The two differ only
+        where the reference's own result is an accident of qhull (include/psm.h): fixed lattice diagonals -- a second-order
+        difference on smooth fields, O(1) per cell on the white-noise fields of randomly initialised test networks
+        (tests/measure/mesh_native_vs_scipy.py) -- and the simplex used for lattice points outside the hull."""
         if geometry not in ("scipy", "native"):
             raise ValueError("geometry must be 'scipy' or 'native'")
         self.model, self.maxs, self.device, self.delta = model, tuple(float(v) for v in maxs), device, delta

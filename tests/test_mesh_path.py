@@ -56,7 +56,7 @@ def test_product_host_tables_equal_oracle(mesh_case):
 @pytest.mark.gpu
 def test_solver_module_init_func_py_func(mesh_case):
     array, top, obst, model, maxs, geo, gold = mesh_case
-    sm = SolverModule(model, maxs, geometry="scipy")
+    sm = SolverModule(model, maxs)
     assert sm.init_func(array, top, obst, 0) == 0
     p = sm.py_func(array, 0)
     assert p.dtype == np.float64 and p.shape == (len(array),)
@@ -79,14 +79,14 @@ def test_init_func_binds_the_geometry_for_py_func_only(mesh_case, monkeypatch):
     """psm_set_geometry binds the obstacle for the mesh entry (6-launch solves); the pressures equal those of the
     general path (PSM_NO_BIND=1) to float32 summation order, and grid-native solves on the same handle stay general."""
     array, top, obst, model, maxs, geo, gold = mesh_case
-    sm = SolverModule(model, maxs, geometry="scipy")
+    sm = SolverModule(model, maxs)
     sm.init_func(array, top, obst, 0)
     assert sm._sur.geometry_bound
     p_bound = sm.py_func(array, 0)
     g = cases.synthetic.channel_grid(sm.tables.ny, sm.tables.nx, seed=9).astype(np.float32)    # another geometry
     f_grid = sm._sur.solve(g)[0]
     monkeypatch.setenv("PSM_NO_BIND", "1")
-    sm2 = SolverModule(model, maxs, geometry="scipy")
+    sm2 = SolverModule(model, maxs)
     sm2.init_func(array, top, obst, 0)
     assert not sm2._sur.geometry_bound
     p_general = sm2.py_func(array, 0)
@@ -99,7 +99,7 @@ def test_pinned_solver_buffers_give_the_same_pressures(mesh_case):
     """psm_pin_buffers: the solver's persistent arrays registered for direct DMA -- bit-identical results, staging path
     still taken for any other pointer, unpin restores it."""
     array, top, obst, model, maxs, geo, gold = mesh_case
-    sm = SolverModule(model, maxs, geometry="scipy")
+    sm = SolverModule(model, maxs)
     sm.init_func(array, top, obst)
     ref = sm.py_func(array)
     cells, out = np.ascontiguousarray(array, np.float64).copy(), np.empty(array.shape[0], np.float64)
@@ -124,7 +124,7 @@ def test_ensemble_of_cases_advanced_from_one_thread(mesh_case):
     mods, arrays = [], []
     for k in range(3):
         a = cases.build_mesh_case(step=k)[0]
-        sm = SolverModule(model, maxs, geometry="scipy")
+        sm = SolverModule(model, maxs)
         sm.init_func(a, top, obst)
         mods.append(sm); arrays.append(a)
     ref = [sm.py_func(a) for sm, a in zip(mods, arrays)]
