@@ -269,6 +269,48 @@ def read_keras_conv1d_head(path: str):
     return convs, dense
 
 
+def read_keras_attention(path: str):
+    """The attention part of a ``densePCA_attention`` file (NNs.py:40-72), or None for a file without one: the
+    ``MultiHeadAttention`` layer's EinsumDense weights -- groups ``query`` / ``key`` / ``value`` (kernel [d, heads, dim], bias
+    [heads, dim]) and ``attention_output`` (kernel [heads, dim, d], bias [d]) below a group ``multi_head_attention`` -- and the
+    ``LayerNormalization`` layers ``layer_normalization``, ``layer_normalization_1``, ... (``gamma:0``, ``beta:0``) in creation
+    order.  -> the dict ``SurrogateModel.attention`` takes ({"Wq", "bq", "Wk", "bk", "Wv", "bv", "Wo", "bo", "ln", "eps"});
+    ``eps`` is Keras' default 1e-3 (weight files do not carry it)."""
+    ds = read_h5_datasets(path)
+    mha: Dict[str, Dict[str, np.ndarray]] = {}
+    lns: Dict[str, Dict[str, np.ndarray]] = {}
+    for p, a in ds.items():
+        parts = [q for q in p.split("/") if q]
+        leaf = parts[-1]
+        if any(re.fullmatch(r"multi_head_attention(?:_\d+)?", q) for q in parts) and leaf in ("kernel:0", "bias:0"):
+            sub = next((q for q in parts if q in ("query", "key", "value", "attention_output")), None)
+            if sub is not None:
+                mha.setdefault(sub, {})[leaf] = a
+        ln = next((q for q in parts if re.fullmatch(r"layer_normalization(?:_\d+)?", q)), None)
+        if ln is not None and leaf in ("gamma:0", "beta:0"):
+            lns.setdefault(ln, {})[leaf] = a
+    if not mha and not lns:
+        return None
+    for sub in ("query", "key", "value", "attention_output"):
+        if sub not in mha or "kernel:0" not in mha[sub] or "bias:0" not in mha[sub]:
+            raise H5FormatError(f"MultiHeadAttention: {sub} kernel / bias missing")
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    att = {"Wq": f(mha["query"]["kernel:0"]), "bq": f(mha["query"]["bias:0"]), "Wk": f(mha["key"]["kernel:0"]), "bk": f(mha["key"]["bias:0"]),
+           "Wv": f(mha["value"]["kernel:0"]), "bv": f(mha["value"]["bias:0"]),
+           "Wo": f(mha["attention_output"]["kernel:0"]), "bo": f(mha["attention_output"]["bias:0"]), "eps": 1e-3}
+    d, heads, dim = att["Wv"].shape if att["Wv"].ndim == 3 else (0, 0, 0)
+    if att["Wv"].ndim != 3 or att["bv"].shape != (heads, dim) or att["Wo"].shape != (heads, dim, d) or att["bo"].shape != (d,):
+        raise H5FormatError("MultiHeadAttention: value [d, heads, dim] / attention_output [heads, dim, d] expected")
+    att["ln"] = []
+    for n in sorted(lns, key=lambda s: int(s.rsplit("_", 1)[1]) if s[-1].isdigit() else 0):
+        if "gamma:0" not in lns[n] or "beta:0" not in lns[n] or lns[n]["gamma:0"].shape != lns[n]["beta:0"].shape:
+            raise H5FormatError(f"layer {n} lacks gamma or beta")
+        att["ln"].append((f(lns[n]["gamma:0"]), f(lns[n]["beta:0"])))
+    if not att["ln"]:
+        raise H5FormatError("densePCA_attention has one LayerNormalization per layer: none found")
+    return att
+
+
 def read_keras_conv_weights(path: str) -> List[Tuple[np.ndarray, np.ndarray]]:
     """Ordered [(kernel[kh,kw,c_in,c_out] f32, bias[c_out] f32)] of the Conv2D layers of a Keras HDF5 file
     (``model.save_weights`` / ``model.save``): layers are the groups named ``conv2d``, ``conv2d_1``, ... and are ordered

@@ -449,6 +449,7 @@ def load_artifacts(variant, model_path, directory, var_p, var_in, max_num_PC, st
     from . import formats
     maxs = formats.read_maxs(os.path.join(directory, "maxs"))
     convs, weights = formats.read_keras_conv1d_head(model_path)     # Dense stack, or the conv1D_PCA head (NNs.py:75-124)
+    attention = formats.read_keras_attention(model_path)            # densePCA_attention (NNs.py:40-72), else None
     pin = formats.load_pca(formats.find_pca(directory, "ipca_input"))
     pout = formats.load_pca(formats.find_pca(directory, "ipca_p"))
     pc_p = formats.select_num_pc(pout.explained_variance_ratio_, var_p, max_num_PC)
@@ -463,6 +464,7 @@ def load_artifacts(variant, model_path, directory, var_p, var_in, max_num_PC, st
     m = SurrogateModel(variant, c_in, c_out, pin.components_[:pc_in], pin.mean_, pout.components_[:pc_p], pout.mean_,
                        list(weights), scaler_kind=standardization_method, S=shape)
     m.conv1d = list(convs)
+    m.attention = attention
     m.ov = int(overlap) if overlap else None                 # deltas: overlap in cells; gradp: `avance`
     m.sdf_ch = sdf_ch
     if standardization_method == "max_abs":

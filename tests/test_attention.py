@@ -69,6 +69,43 @@ def test_length_one_attention_is_affine_and_ignores_query_and_key():
     assert np.abs(out - folded).max() <= 2e-6 * np.abs(folded).max()
 
 
+def test_keras_reader_finds_the_attention_block(tmp_path):
+    """A Keras-layout HDF5 file of densePCA_attention (Dense layers, one MultiHeadAttention with its four EinsumDense
+    sub-layers, LayerNormalization layers in creation order) -> the model dict the loader hands to the library; a plain Dense
+    file has no attention part."""
+    import h5write
+    from psm_amd import formats
+    dense = synthetic.he_dense_stack(12, [32, 32, 32], 6, seed=3)
+    att = synthetic.he_attention_block([32, 32, 32], seed=4, n_heads=2, key_dim=8)
+    tree = {}
+    for k, (W, b) in enumerate(dense):
+        n = "dense" if k == 0 else f"dense_{k}"
+        tree[n] = {n: {"kernel:0": W, "bias:0": b}}
+    m = "multi_head_attention"
+    tree[m] = {m: {"query": {"kernel:0": att["Wq"], "bias:0": att["bq"]}, "key": {"kernel:0": att["Wk"], "bias:0": att["bk"]},
+                   "value": {"kernel:0": att["Wv"], "bias:0": att["bv"]},
+                   "attention_output": {"kernel:0": att["Wo"], "bias:0": att["bo"]}}}
+    for k, (g, b) in reversed(list(enumerate(att["ln"]))):         # file order is not creation order
+        n = "layer_normalization" if k == 0 else f"layer_normalization_{k}"
+        tree[n] = {n: {"gamma:0": g, "beta:0": b}}
+    p = str(tmp_path / "attention.h5")
+    h5write.write_h5(p, {"model_weights": tree})
+    got = formats.read_keras_attention(p)
+    assert got["eps"] == 1e-3 and len(got["ln"]) == 3
+    for k in ("Wq", "bq", "Wk", "bk", "Wv", "bv", "Wo", "bo"):
+        np.testing.assert_array_equal(got[k], att[k])
+    for (g, b), (g0, b0) in zip(got["ln"], att["ln"]):
+        np.testing.assert_array_equal(g, g0); np.testing.assert_array_equal(b, b0)
+    d2 = formats.read_keras_dense_weights(p)
+    assert [W.shape for W, _ in d2] == [W.shape for W, _ in dense]
+    # the two network functions agree on what was read
+    x = np.random.default_rng(0).standard_normal((5, 12)).astype(np.float32)
+    np.testing.assert_array_equal(orc.mlp_attention_forward(x, d2, got), orc.mlp_attention_forward(x, dense, att))
+    p2 = str(tmp_path / "dense.h5")
+    h5write.write_keras_dense(p2, dense)
+    assert formats.read_keras_attention(p2) is None
+
+
 @pytest.mark.gpu
 def test_gpu_attention_golden_general_bound_and_batch():
     grid, model = cases.build(NAME)
@@ -139,3 +176,43 @@ def test_gpu_attention_errors():
         assert sur.lib.psm_set_layernorm(sur.h, 1, 512, p, p, 0.0, 0) != 0          # epsilon
         assert sur.lib.psm_set_layernorm(sur.h, 0, 512, p, p, 1e-3, 1) != 0         # residual on a 32 -> 512 layer
         assert sur.lib.psm_set_attention(sur.h, 0, 512, 8, 64, p, p, p, p) != 0     # not behind the first Dense layer
+
+
+@pytest.mark.gpu
+def test_gpu_evaluator_loads_an_attention_file(tmp_path):
+    """`Evaluation(..., model_path=<densePCA_attention .h5>)` -- the artefact directory of tests/cases.py with its network file
+    replaced by a Keras-layout attention file: load_artifacts picks up the MultiHeadAttention / LayerNormalization groups, the
+    frame solved from the files equals the oracle's network on the same grid, and call_SM_main reports the block-level error."""
+    import os
+    import h5write
+    from psm_amd import Evaluation, call_SM_main, formats
+    d = str(tmp_path)
+    c = cases.build_dataset_case(d)
+    pc = 24
+    dense = synthetic.he_dense_stack(pc, [64, 64, 64], pc, seed=9)
+    att = synthetic.he_attention_block([64, 64, 64], seed=10, n_heads=4, key_dim=8)
+    tree = {}
+    for k, (W, b) in enumerate(dense):
+        n = "dense" if k == 0 else f"dense_{k}"
+        tree[n] = {n: {"kernel:0": W, "bias:0": b}}
+    m = "multi_head_attention"
+    tree[m] = {m: {"query": {"kernel:0": att["Wq"], "bias:0": att["bq"]}, "key": {"kernel:0": att["Wk"], "bias:0": att["bk"]},
+                   "value": {"kernel:0": att["Wv"], "bias:0": att["bv"]}, "attention_output": {"kernel:0": att["Wo"], "bias:0": att["bo"]}}}
+    for k, (g, b) in enumerate(att["ln"]):
+        n = "layer_normalization" if k == 0 else f"layer_normalization_{k}"
+        tree[n] = {n: {"gamma:0": g, "beta:0": b}}
+    path = os.path.join(d, "attention.h5")
+    h5write.write_h5(path, {"model_weights": tree})
+    ev = Evaluation(5e-3, 128, 32, 0.95, 0.95, c["dataset_path"], path, 128, "std", artifact_dir=d)
+    assert ev.model.attention is not None and len(ev.model.attention["ln"]) == 3
+    ev.computeOnlyOnce(0)
+    res = ev.timeStep(0, 1, False, False, False, False)
+    model = c["model"]
+    import dataclasses
+    om_model = dataclasses.replace(model, weights=dense, attention=att)
+    om = oracle_model(om_model)
+    om.out_scale = cases.DATASET_MAXS[3] * ev.U_max_norm ** 2
+    sol = orc.solve_grid(ev.grid[..., :3], om)
+    assert np.abs(res - sol.fields[..., 0]).max() <= 1e-4 * np.abs(sol.fields).max()
+    rep = call_SM_main(5e-3, path, 128, 0.25, 0.95, 0.95, 128, c["dataset_path"], False, "std", False, False, False, False, 1, 2, artifact_dir=d)
+    assert rep["overall"]["RSME_block"] > 0 and np.isfinite(rep["overall"]["BIAS_block"])
