@@ -204,7 +204,7 @@ def test_gpu_evaluator_loads_an_attention_file(tmp_path):
     path = os.path.join(d, "attention.h5")
     h5write.write_h5(path, {"model_weights": tree})
     ev = Evaluation(5e-3, 128, 32, 0.95, 0.95, c["dataset_path"], path, 128, "std", artifact_dir=d)
-    assert ev.model.attention is not None and len(ev.model.attention["ln"]) == 3
+    assert ev.artifacts.attention is not None and len(ev.artifacts.attention["ln"]) == 3
     ev.computeOnlyOnce(0)
     res = ev.timeStep(0, 1, False, False, False, False)
     model = c["model"]
