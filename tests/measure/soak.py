@@ -48,6 +48,10 @@ for trial in range(trials):
     p_in, p_out = int(rng.integers(1, 140)), int(rng.integers(1, 140))
     n_cases = int(rng.integers(1, 7)) if rng.random() < 0.35 else 1
     model = synthetic.make_model(variant, p_in=p_in, p_out=p_out, seed_pca=int(rng.integers(1 << 20)), seed_w=int(rng.integers(1 << 20)))
+    if rng.random() < 0.15:                                           # densePCA_attention (round 4): other widths, depths, head shapes
+        width, depth = int(rng.integers(3, 40)) * 8, int(rng.integers(2, 5))
+        model.weights = synthetic.he_dense_stack(p_in, [width] * depth, p_out, seed=int(rng.integers(1 << 20)))
+        model.attention = synthetic.he_attention_block([width] * depth, seed=int(rng.integers(1 << 20)), n_heads=int(rng.integers(1, 9)), key_dim=int(rng.integers(4, 65)))
     grids = []
     for k in range(n_cases):
         g = synthetic.channel_grid(ny, nx, seed=int(rng.integers(1 << 30)), obstacle=("circle", "rectangle", "plate", "none")[int(rng.integers(4))],
@@ -61,7 +65,7 @@ for trial in range(trials):
         grids.append(g)
     grids = np.stack(grids)
     sc = [float(rng.uniform(0.3, 2.0)) for _ in range(n_cases)]
-    info = dict(trial=trial, variant=variant, ny=ny, nx=nx, p_in=p_in, p_out=p_out, n_cases=n_cases)
+    info = dict(trial=trial, variant=variant, ny=ny, nx=nx, p_in=p_in, p_out=p_out, n_cases=n_cases, attention=model.attention is not None)
     try:
         sur = GridSurrogate(model, ny, nx, max_cases=n_cases)
     except _lib.PsmError:
