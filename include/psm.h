@@ -125,7 +125,9 @@ int psm_set_dense(psm_handle* h, int32_t layer, int32_t n_in, int32_t n_out,
  *   act = (v - mean(v)) * rsqrt(var(v) + epsilon) * gamma + beta,   v = layer output (after its activation) [+ the layer's own
  *   input when residual != 0 -- NNs.py:64 `x + attn_output`; the layer must then be square], biased variance, float32;
  *   n = the layer's n_out, gamma / beta [n], epsilon > 0 (Keras default 1e-3).
- * Both: float32 and bf16 handles (the normalisation itself is float32 in both); the geometry-bound path is kept. */
+ * Both: float32 and bf16 handles (the normalisation itself is float32 in both); the geometry-bound path is kept.  A
+ * normalisation whose consumer is another hidden Dense layer costs no launch (that layer's launch applies it to its input rows);
+ * the last one runs as its own small launch. */
 int psm_set_attention(psm_handle* h, int32_t layer, int32_t d_model, int32_t n_heads, int32_t value_dim,
                       const float* Wv, const float* bv, const float* Wo, const float* bo);
 int psm_set_layernorm(psm_handle* h, int32_t layer, int32_t n, const float* gamma, const float* beta, float epsilon,

@@ -622,27 +622,44 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
       }
       ld_cur = (int)stride;
     }
-    // LayerNormalization (+ residual with the layer's own input) behind a hidden layer: densePCA_attention
-    auto layer_norm = [&](int l, float* act, const float* layer_in, int ld_layer_in) -> int {
+    // LayerNormalization (+ residual with the layer's own input) behind a hidden layer: densePCA_attention.  Where the consumer
+    // is another hidden Dense launch the normalisation is DEFERRED into it (psm_dense_kernel<..., LNIN>: moments of its own input
+    // rows in the prologue, the residual of NNs.py:64 in its epilogue) -- no launch; the last one, whose consumers are the head,
+    // the strip-dot riders and the introspection entries, finishes its activation with psm_layernorm_kernel.  PSM_LN_FUSE=0
+    // launches every normalisation on its own.
+    const char* ln_env = getenv("PSM_LN_FUSE");            // read per solve (diagnostic; the tests switch it in-process)
+    const bool ln_fuse = !(ln_env && atoi(ln_env) == 0);
+    bool pending = false;                               // `cur` is a raw output whose LayerNormalization the next launch applies
+    int pending_l = -1;
+    auto after_dense = [&](int l, float* act, const float* layer_in, int ld_layer_in, bool residual_done) -> int {
       const DenseLayer& d = h->dense[l];
+      pending = false;
       if (!d.ln) return PSM_OK;
-      PsmLayerNormArgs la{act, d.ldw, d.ln_residual ? layer_in : nullptr, ld_layer_in, d.ln_gamma, d.ln_beta, Mpad, d.n_out, d.ln_eps};
+      if (ln_fuse && l + 1 <= nl - 2) { pending = true; pending_l = l; return PSM_OK; }      // the next hidden layer applies it
+      PsmLayerNormArgs la{act, d.ldw, (d.ln_residual && !residual_done) ? layer_in : nullptr, ld_layer_in, d.ln_gamma, d.ln_beta, Mpad, d.n_out, d.ln_eps};
       HIPCHK(h, psm_launch_layernorm(la, st));
       return PSM_OK;
     };
     if (fuse1) {
       PsmDenseArgs d0 = dense_args(0, cur, ld_cur);
       HIPCHK(h, psm_launch_reduce_dense1(ra, d0, st));
-      int rc0 = layer_norm(0, d0.out, cur, ld_cur);
+      int rc0 = after_dense(0, d0.out, cur, ld_cur, false);
       if (rc0) return rc0;
       cur = d0.out; ld_cur = h->dense[0].ldw;
       l_first = 1;
     }
     for (int l = l_first; l < nl; ++l) {
       PsmDenseArgs da = dense_args(l, cur, ld_cur);
-      if (h->dense[l].ln) {
+      bool residual_done = false;
+      if (pending) {                                    // this launch normalises its input (and adds the residual of its own LN)
+        const DenseLayer& p = h->dense[pending_l];
+        da.ln_gamma = p.ln_gamma; da.ln_beta = p.ln_beta; da.ln_eps = p.ln_eps; da.ln_n = p.n_out;
+        da.ln_residual = (h->dense[l].ln && h->dense[l].ln_residual) ? 1 : 0;
+        residual_done = da.ln_residual != 0;
+      }
+      if (l < nl - 1) {
         HIPCHK(h, psm_launch_dense(da, st));
-        int rcl = layer_norm(l, da.out, cur, ld_cur);
+        int rcl = after_dense(l, da.out, cur, ld_cur, residual_done);
         if (rcl) return rcl;
         cur = da.out; ld_cur = h->dense[l].ldw;
         continue;
@@ -1093,7 +1110,10 @@ int psm_set_layernorm(psm_handle* h, int32_t layer, int32_t n, const float* gamm
   HIPCHK(h, hipStreamSynchronize(h->stream));
   destroy_graphs(h);
   h->bound = false;
-  std::vector<float> g(gamma, gamma + n), b(beta, beta + n);
+  // zero-padded to whole 16-byte pieces past the consumer's leading dimension: a Dense launch that applies this normalisation to
+  // its input (launch_all) reads gamma / beta with the clamped column index of its operand loads
+  std::vector<float> g(round_up(n, 32) + 32, 0.f), b(round_up(n, 32) + 32, 0.f);
+  std::copy(gamma, gamma + n, g.begin()); std::copy(beta, beta + n, b.begin());
   int rc;
   if ((rc = dev_upload(h, &d.ln_gamma, g)) || (rc = dev_upload(h, &d.ln_beta, b))) return rc;
   d.ln = true; d.ln_residual = residual != 0; d.ln_eps = epsilon;

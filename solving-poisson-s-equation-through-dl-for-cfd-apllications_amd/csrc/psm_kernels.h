@@ -43,6 +43,11 @@ struct PsmDenseArgs {
   int Kpad, Mpad, relu, head;
   int bf16;                            // W points to bf16 [Kpad][ld_w]; activations rounded to bf16 on load
   int layer;                           // layer index (diagnostic stamps only)
+  // LayerNormalization of the INPUT, fused into this launch (densePCA_attention, hidden layers): `in` holds the producer's raw
+  // output v; every workgroup takes the moments of its own input rows (two passes over the first ln_n columns) and contracts with
+  // (v - mean) * rsqrt(var + ln_eps) * ln_gamma + ln_beta.  ln_gamma / ln_beta: [>= ld_in], zero beyond ln_n; nullptr = plain input.
+  // ln_residual: the epilogue adds the NORMALISED input at the output column (NNs.py:64 `x + attn_output`; square layer).
+  const float* ln_gamma; const float* ln_beta; float ln_eps; int ln_n, ln_residual;
 };
 
 // LayerNormalization of the reference's densePCA_attention (NNs.py:56, 64; Keras defaults: last axis, epsilon 1e-3, centre and

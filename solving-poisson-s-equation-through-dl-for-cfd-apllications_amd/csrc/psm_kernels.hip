@@ -789,7 +789,9 @@ __device__ __forceinline__ float psm_guard_sum(const float* flags, int n, int la
 // strip dot products of psm_kernels.h (PsmDotsArgs) from the same input activation: one wave per two table rows,
 // every load issued up front (clamped), out[row] = scale * (act . g2[row] + c2[row]) / cnt[row]  (0/0 = NaN for an
 // empty strip, like np.mean([])).
-template <int NGC, bool BF16, int ROWS, bool DOTS>   // NGC: groups of 16 k per wave per pass
+// LNIN (hidden layers of densePCA_attention): the input carries a pending LayerNormalization (PsmDenseArgs::ln_*) -- moments of
+// the workgroup's own rows in a prologue, operands normalised on their way into the MFMAs, optional residual in the epilogue.
+template <int NGC, bool BF16, int ROWS, bool DOTS, bool LNIN = false>   // NGC: groups of 16 k per wave per pass
 __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a, PsmDotsArgs d) {
   if (DOTS && blockIdx.z > 0) {
     constexpr int RPW = 2, NQ = 4;                     // rows per wave; float4 per lane and row (Kh <= 1024)
@@ -895,14 +897,24 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a, PsmDotsA
   const int g_first = wave * ng;
   const int kmax = a.ld_in - 4;
   auto rnd = [](float v) { return BF16 ? (float)(__bf16)v : v; };
-  for (int g0 = 0; g0 < ng; g0 += NGC) {
-    f32x4 a0[NGC], a1[NGC], w[NGC];
+  // ---- operand loads, normalisation and matrix step of NGC groups (one pass of the contraction)
+  auto load_a = [&](int g0, f32x4 (&a0)[NGC], f32x4 (&a1)[NGC]) {
 #pragma unroll
     for (int g = 0; g < NGC; ++g) {
       const int kcol = min(16 * (g_first + g0 + g) + 4 * kq, kmax);
       a0[g] = *reinterpret_cast<const f32x4*>(arow0 + kcol);
       if (ROWS == 32) a1[g] = *reinterpret_cast<const f32x4*>(arow1 + kcol);
     }
+  };
+  auto load_gb = [&](int g0, f32x4 (&gm)[NGC], f32x4 (&bt)[NGC]) {       // columns beyond ln_n carry gamma = beta = 0 (and zero weight rows)
+#pragma unroll
+    for (int g = 0; g < NGC; ++g) {
+      const int kcol = min(16 * (g_first + g0 + g) + 4 * kq, kmax);
+      gm[g] = *reinterpret_cast<const f32x4*>(a.ln_gamma + kcol);
+      bt[g] = *reinterpret_cast<const f32x4*>(a.ln_beta + kcol);
+    }
+  };
+  auto load_w = [&](int g0, f32x4 (&w)[NGC]) {
 #pragma unroll
     for (int g = 0; g < NGC; ++g) {
       const int64_t widx = ((int64_t)nt * groups + g_first + g0 + g) * 64 + lane;
@@ -914,12 +926,107 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a, PsmDotsA
         w[g] = reinterpret_cast<const f32x4*>(a.Wp)[widx];
       }
     }
+  };
+  auto mma = [&](const f32x4 (&a0)[NGC], const f32x4 (&a1)[NGC], const f32x4 (&w)[NGC]) {
 #pragma unroll
     for (int g = 0; g < NGC; ++g) {
       acc0 = MFMA16(rnd(a0[g].x), w[g].x, acc0); if (ROWS == 32) acc1 = MFMA16(rnd(a1[g].x), w[g].x, acc1);
       acc0 = MFMA16(rnd(a0[g].y), w[g].y, acc0); if (ROWS == 32) acc1 = MFMA16(rnd(a1[g].y), w[g].y, acc1);
       acc0 = MFMA16(rnd(a0[g].z), w[g].z, acc0); if (ROWS == 32) acc1 = MFMA16(rnd(a1[g].z), w[g].z, acc1);
       acc0 = MFMA16(rnd(a0[g].w), w[g].w, acc0); if (ROWS == 32) acc1 = MFMA16(rnd(a1[g].w), w[g].w, acc1);
+    }
+  };
+  // ---- pending LayerNormalization of the input: moments of rows i (and i + 16) over the first ln_n columns, two passes like
+  // tf.nn.moments.  Lane (i, kq) of wave w owns columns 16 (g_first + g) + 4 kq + j; the four kq lanes of a row meet through
+  // two shuffles, the eight waves through LDS (the `red` buffer, free until the MFMA results are written).  A contraction of
+  // one pass (K <= 512: ng == NGC) takes the moments from its operand registers -- the row is loaded once, with the weights
+  // and gamma / beta already in flight; longer rows are read from L2 again for each pass.
+  __shared__ float ln_stat[2][32];
+  float mean0 = 0.f, rstd0 = 1.f, mean1 = 0.f, rstd1 = 1.f, res_raw = 0.f, res_g = 0.f, res_b = 0.f;
+  f32x4 p0[NGC], p1[NGC], pw[NGC], pg[NGC], pb[NGC];
+  const bool single = LNIN && ng == NGC;                 // uniform
+  if constexpr (LNIN) {
+    if (single) { load_a(0, p0, p1); load_gb(0, pg, pb); load_w(0, pw); }
+    if (a.ln_residual && tid < ROWS * 16) {              // the epilogue's residual operands: in flight from here
+      const int row = tid >> 4;
+      res_raw = a.in[(int64_t)(mt * ROWS + row) * a.ld_in + n_out];
+      res_g = a.ln_gamma[n_out]; res_b = a.ln_beta[n_out];
+    }
+    const float inv_n = 1.f / (float)a.ln_n;
+    auto meet = [&](float s0, float s1, float& o0, float& o1) {
+      s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);
+      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+      if (kq == 0) { red[wave][0][i] = s0; red[wave][1][i] = s1; }
+      __syncthreads();
+      float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) { t0 += red[w8][0][i]; t1 += red[w8][1][i]; }
+      __syncthreads();                                   // everyone has read the partials: `red` may be rewritten
+      o0 = t0 * inv_n; o1 = t1 * inv_n;
+    };
+    auto row_moment = [&](float m0, float m1, bool second, float& o0, float& o1) {
+      float s0 = 0.f, s1 = 0.f;
+      if (single) {
+#pragma unroll
+        for (int g = 0; g < NGC; ++g) {
+          const int k0 = 16 * (g_first + g) + 4 * kq;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool in = k0 + j < a.ln_n;
+            const float d0 = p0[g][j] - m0, d1 = (ROWS == 32 ? p1[g][j] : p0[g][j]) - m1;
+            s0 += in ? (second ? d0 * d0 : d0) : 0.f;
+            s1 += in ? (second ? d1 * d1 : d1) : 0.f;
+          }
+        }
+      } else {
+        for (int g = 0; g < ng; ++g) {
+          const int k0 = 16 * (g_first + g) + 4 * kq, kc = min(k0, kmax);
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(arow0 + kc);
+          f32x4 v1 = v0;
+          if (ROWS == 32) v1 = *reinterpret_cast<const f32x4*>(arow1 + kc);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool in = k0 + j < a.ln_n;
+            const float d0 = v0[j] - m0, d1 = v1[j] - m1;
+            s0 += in ? (second ? d0 * d0 : d0) : 0.f;
+            s1 += in ? (second ? d1 * d1 : d1) : 0.f;
+          }
+        }
+      }
+      meet(s0, s1, o0, o1);
+    };
+    float q0, q1;
+    row_moment(0.f, 0.f, false, mean0, mean1);
+    row_moment(mean0, mean1, true, q0, q1);
+    rstd0 = rsqrtf(q0 + a.ln_eps); rstd1 = rsqrtf(q1 + a.ln_eps);
+    if (wave == 0 && kq == 0) {
+      ln_stat[0][i] = mean0; ln_stat[1][i] = rstd0;
+      if (ROWS == 32) { ln_stat[0][16 + i] = mean1; ln_stat[1][16 + i] = rstd1; }
+    }
+  }
+  auto normalise = [&](f32x4 (&a0)[NGC], f32x4 (&a1)[NGC], const f32x4 (&gm)[NGC], const f32x4 (&bt)[NGC]) {
+#pragma unroll
+    for (int g = 0; g < NGC; ++g) {
+      a0[g] = (a0[g] - mean0) * rstd0 * gm[g] + bt[g];
+      if (ROWS == 32) a1[g] = (a1[g] - mean1) * rstd1 * gm[g] + bt[g];
+    }
+  };
+  if (single) {
+    normalise(p0, p1, pg, pb);
+    mma(p0, p1, pw);
+  } else {
+    for (int g0 = 0; g0 < ng; g0 += NGC) {
+      f32x4 a0[NGC], a1[NGC], w[NGC];
+      load_a(g0, a0, a1);
+      if constexpr (LNIN) {
+        f32x4 gm[NGC], bt[NGC];
+        load_gb(g0, gm, bt);
+        load_w(g0, w);
+        normalise(a0, a1, gm, bt);
+      } else {
+        load_w(g0, w);
+      }
+      mma(a0, a1, w);
     }
   }
   PSM_STAMP(0, 45 + 4 * (a.layer & 3));
@@ -937,6 +1044,9 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a, PsmDotsA
     for (int w8 = 0; w8 < 8; ++w8) v += red[w8][half][r16 * 17 + col];
     v += bias_v;
     if (a.relu) v = fmaxf(v, 0.f);
+    if constexpr (LNIN) {
+      if (a.ln_residual) v += (res_raw - ln_stat[0][row]) * ln_stat[1][row] * res_g + res_b;     // x + LN(input) (NNs.py:64)
+    }
     if (a.head) v = v * sa_v + sb_v;
     a.out[(int64_t)(mt * ROWS + row) * a.ld_out + n_out] = v;
   }
@@ -948,20 +1058,23 @@ hipError_t psm_launch_dense(const PsmDenseArgs& a, hipStream_t st) {
   if (!a.Wp || a.Kp % 128 != 0 || (ng > 2 && ng % 4 != 0) || a.ld_in < 4) return hipErrorInvalidValue;
   const bool r16 = a.Mpad <= 128;     // up to 128 block rows: 16-row tiles keep >= 64 workgroups pulling <= 64 KB each
   const dim3 grid(a.ld_w / 16, a.Mpad / (r16 ? 16 : 32)), blk(512);
-#define DENSE(N)                                                                            \
+#define DENSE2(N, L)                                                                        \
   do {                                                                                      \
     if (r16) {                                                                              \
-      if (a.bf16) PSM_LAUNCH((psm_dense_kernel<N, true, 16, false>), grid, blk, 0, st, a, PsmDotsArgs{}); \
-      else PSM_LAUNCH((psm_dense_kernel<N, false, 16, false>), grid, blk, 0, st, a, PsmDotsArgs{});       \
+      if (a.bf16) PSM_LAUNCH((psm_dense_kernel<N, true, 16, false, L>), grid, blk, 0, st, a, PsmDotsArgs{}); \
+      else PSM_LAUNCH((psm_dense_kernel<N, false, 16, false, L>), grid, blk, 0, st, a, PsmDotsArgs{});       \
     } else {                                                                                \
-      if (a.bf16) PSM_LAUNCH((psm_dense_kernel<N, true, 32, false>), grid, blk, 0, st, a, PsmDotsArgs{}); \
-      else PSM_LAUNCH((psm_dense_kernel<N, false, 32, false>), grid, blk, 0, st, a, PsmDotsArgs{});       \
+      if (a.bf16) PSM_LAUNCH((psm_dense_kernel<N, true, 32, false, L>), grid, blk, 0, st, a, PsmDotsArgs{}); \
+      else PSM_LAUNCH((psm_dense_kernel<N, false, 32, false, L>), grid, blk, 0, st, a, PsmDotsArgs{});       \
     }                                                                                       \
   } while (0)
+#define DENSE(N) do { if (a.ln_gamma) DENSE2(N, true); else DENSE2(N, false); } while (0)
   if (psm_launch_probe) psm_launch_probe->tag = a.layer;          // every Dense layer is its own entry of psm_time_kernels
+  if (a.ln_gamma && (!a.ln_beta || a.ln_n < 1 || a.ln_n > a.ld_in || (a.ln_residual && a.ln_n > a.ld_w))) return hipErrorInvalidValue;
   if (ng == 1) DENSE(1); else if (ng == 2) DENSE(2); else DENSE(4);
   if (psm_launch_probe) psm_launch_probe->tag = -1;
 #undef DENSE
+#undef DENSE2
   return hipGetLastError();
 }
 
@@ -988,24 +1101,51 @@ hipError_t psm_launch_dense_dots(const PsmDenseArgs& a, const PsmDotsArgs& d, hi
 
 // LayerNormalization (+ residual) of the densePCA_attention stack, see psm_kernels.h.  Two-pass moments like
 // tf.nn.moments (mean, then the mean of squared deviations; biased variance), float32.
+// NPL > 0: the row (n <= 64 * NPL) is read ONCE into NPL registers per lane, every load issued up front, and both moments come
+// from the registers (one memory round trip); NPL == 0: any n, three passes over a row that sits in L2.
+template <int NPL>
 __global__ __launch_bounds__(256) void psm_layernorm_kernel(PsmLayerNormArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = (int)blockIdx.x * 4 + wave;
   if (row >= a.rows) return;                          // wave-uniform
   float* x = a.act + (int64_t)row * a.ld_act;
   const float* r = a.res ? a.res + (int64_t)row * a.ld_res : nullptr;
+  const float inv_n = 1.f / (float)a.n;
+  if constexpr (NPL > 0) {
+    float v[NPL], rv[NPL], g[NPL], b[NPL];
+#pragma unroll
+    for (int u = 0; u < NPL; ++u) {
+      const int k = min(lane + 64 * u, a.n - 1);
+      v[u] = x[k]; rv[u] = r ? r[k] : 0.f; g[u] = a.gamma[k]; b[u] = a.beta[k];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < NPL; ++u) { v[u] += rv[u]; s += (lane + 64 * u < a.n) ? v[u] : 0.f; }
+    const float mean = wave_sum(s) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < NPL; ++u) { const float d = v[u] - mean; q += (lane + 64 * u < a.n) ? d * d : 0.f; }
+    const float inv = rsqrtf(wave_sum(q) * inv_n + a.eps);
+#pragma unroll
+    for (int u = 0; u < NPL; ++u)
+      if (lane + 64 * u < a.n) x[lane + 64 * u] = (v[u] - mean) * inv * g[u] + b[u];
+    return;
+  }
   float s = 0.f;
   for (int k = lane; k < a.n; k += 64) s += x[k] + (r ? r[k] : 0.f);
-  const float mean = wave_sum(s) / (float)a.n;
+  const float mean = wave_sum(s) * inv_n;
   float q = 0.f;
   for (int k = lane; k < a.n; k += 64) { const float d = x[k] + (r ? r[k] : 0.f) - mean; q += d * d; }
-  const float inv = rsqrtf(wave_sum(q) / (float)a.n + a.eps);
+  const float inv = rsqrtf(wave_sum(q) * inv_n + a.eps);
   for (int k = lane; k < a.n; k += 64) x[k] = (x[k] + (r ? r[k] : 0.f) - mean) * inv * a.gamma[k] + a.beta[k];
 }
 
 hipError_t psm_launch_layernorm(const PsmLayerNormArgs& a, hipStream_t st) {
   if (!a.act || !a.gamma || !a.beta || a.rows < 1 || a.n < 1 || a.n > a.ld_act || (a.res && a.n > a.ld_res)) return hipErrorInvalidValue;
-  PSM_LAUNCH(psm_layernorm_kernel, dim3((a.rows + 3) / 4), dim3(256), 0, st, a);
+  const dim3 grid((a.rows + 3) / 4), blk(256);
+  if (a.n <= 512) PSM_LAUNCH(psm_layernorm_kernel<8>, grid, blk, 0, st, a);
+  else if (a.n <= 1024) PSM_LAUNCH(psm_layernorm_kernel<16>, grid, blk, 0, st, a);
+  else PSM_LAUNCH(psm_layernorm_kernel<0>, grid, blk, 0, st, a);
   return hipGetLastError();
 }
 

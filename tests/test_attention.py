@@ -145,6 +145,40 @@ def test_gpu_attention_shapes(p, width, n_layers, variant):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_cases", [1, 5])
+def test_gpu_attention_fused_and_standalone_layernorm_agree(monkeypatch, n_cases):
+    """The LayerNormalizations that feed a hidden Dense layer run inside that layer's launch (moments of its own input rows in
+    the prologue, residual in the epilogue); PSM_LN_FUSE=0 launches each one on its own.  Same numbers up to float32 rounding
+    of the moments; 5 cases = 45 block rows take the 16-row tiles with other row groups, 160 rows the 32-row tiles."""
+    grid, model = cases.build(NAME)
+    g32 = np.stack([np.roll(grid.astype(np.float32), 7 * k, axis=1) for k in range(n_cases)])
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PSM_LN_FUSE", mode)
+        with GridSurrogate(model, 256, 256, max_cases=n_cases) as sur:
+            outs[mode] = sur.solve(g32, out_scale=[model.out_scale] * n_cases)
+            res = sur.stage("res", n_cases)
+            outs[mode + "res"] = res
+    assert rel_l2(outs["1res"], outs["0res"]) <= 2e-6 and np.abs(outs["1"] - outs["0"]).max() <= 2e-5 * np.abs(outs["0"]).max()
+    sol = orc.solve_grid(g32[n_cases - 1].astype(np.float64), oracle_model(model))
+    assert np.abs(outs["1"][n_cases - 1] - sol.fields).max() <= 2e-4 * np.abs(sol.fields).max()
+
+
+@pytest.mark.gpu
+def test_gpu_attention_32_row_tiles_and_wide_layers():
+    """More than 128 block rows (the 32-row tile of the Dense kernel: two row sets per lane in the moment prologue) and a hidden
+    width above 512 (two passes over the contraction: moments from L2 instead of the operand registers)."""
+    model = synthetic.make_model("deltas", p_in=40, p_out=24, seed_pca=77, weights=synthetic.he_dense_stack(40, [640] * 3, 24, seed=5))
+    model.attention = synthetic.he_attention_block([640] * 3, seed=6, n_heads=5, key_dim=16)
+    grids = synthetic.random_obstacle_cases(16, 256, 256, seed=12).astype(np.float32)        # 16 cases x 9 blocks = 144 rows
+    with GridSurrogate(model, 256, 256, max_cases=16) as sur:
+        out = sur.solve(grids)
+    for c in (0, 15):
+        sol = orc.solve_grid(grids[c].astype(np.float64), oracle_model(model))
+        assert np.abs(out[c] - sol.fields).max() <= 2e-4 * np.abs(sol.fields).max()
+
+
+@pytest.mark.gpu
 def test_gpu_attention_bf16_handle():
     """bf16 operands: the oracle rounds what enters each contraction, with the attention block as the ONE folded affine layer
     the library runs; the normalisations are float32 on both sides."""
