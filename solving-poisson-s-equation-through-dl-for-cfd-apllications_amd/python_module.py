@@ -11,6 +11,13 @@ Use: copy (or symlink) this file into the case directory as ``python_module.py``
 working directory, exactly like the reference (python_module.py:103-118,170):
 ``ipca_input_more.pkl``, ``ipca_p_more.pkl`` (or the ``.npz`` exports), ``maxs``, ``maxs_PCA``, ``weights.h5``.
 
+``PSM_PIN_SOLVER_BUFFERS=1`` (serial solver only, opt-in): the solver hands over the SAME array every step -- ``input_vals`` of
+PythonComm_init.H:53 is allocated once and never freed, PythonComm.H:17 wraps it without copying --, so it is registered with
+the GPU once (``psm_pin_buffers``) together with one persistent output array, and a step issues no copy at all (65 instead of
+95 us on a 16 k-cell mesh).  Opt-in because the module cannot see whether the caller's buffer outlives the registration: only a
+caller that keeps it allocated for the whole run (the reference solver does) may set it.  The returned array is then the same
+object every step (valid until the next call; PythonComm.H:31-36 copies it out at once -- and no longer leaks one array per step).
+
 MPI: with ``mpi4py`` importable and more than one rank the cell arrays are gathered to rank 0, solved
 there and scattered back (python_module.py:179-191, 258-264, 501-511); otherwise everything runs on the
 calling process (the serial module, singleCore/test_Case/python_module.py:139,199).
@@ -81,8 +88,28 @@ def init_func(array, top_boundary, obst_boundary, placeholder=0):
     lens = _gather(np.asarray(array).shape[0])
     if rank == 0:
         len_rankwise = lens
+        _pin_state.update(ptr=None, n=0, array=None, out=None)           # a new geometry = a new handle: nothing is registered on it yet
         _module.init_func(np.concatenate(array_global), np.concatenate(top_global), np.concatenate(obst_global))
     return 0
+
+
+_pin_state = {"ptr": None, "n": 0, "array": None, "out": None}
+_PIN = os.environ.get("PSM_PIN_SOLVER_BUFFERS", "0") not in ("", "0")
+
+
+def _solve_rank0(array):
+    """rank 0: one step.  With PSM_PIN_SOLVER_BUFFERS=1 on the serial solver the caller's (persistent) array and one output
+    array are registered on first use and re-registered if the caller ever comes with another buffer."""
+    if not (_PIN and (comm is None or nprocs == 1) and array.flags.c_contiguous):
+        return _module.py_func(array)
+    ptr, n = array.ctypes.data, array.shape[0]
+    if _pin_state["ptr"] != ptr or _pin_state["n"] != n:
+        if _pin_state["ptr"] is not None:
+            _module.unpin()
+        out = np.empty(n, np.float64)
+        _module.pin(array, out)
+        _pin_state.update(ptr=ptr, n=n, array=array, out=out)          # `array` kept: the registration must not outlive the view
+    return _module.py_func(array, out=_pin_state["out"])
 
 
 def py_func(array_in, placeholder=0):
@@ -92,9 +119,9 @@ def py_func(array_in, placeholder=0):
     array_global = _gather(array_in)
     p_rankwise = None
     if rank == 0:
-        array = np.concatenate(array_global)
+        array = array_global[0] if len(array_global) == 1 else np.concatenate(array_global)
         try:
-            p = _module.py_func(array)
+            p = _solve_rank0(array)
         except Exception:                                   # singleCore python_module.py:440-444 swallows and returns 0
             traceback.print_exc()
             p = array[:, 4].copy()

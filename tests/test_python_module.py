@@ -72,3 +72,31 @@ def test_module_py_func_equals_solver_module(case_dir):
     bad = array.copy(); bad = bad[:-5]                              # wrong cell count: reported, previous p returned
     pm.len_rankwise = [bad.shape[0]]
     np.testing.assert_array_equal(pm.py_func(bad, 0), bad[:, 4])
+
+
+@pytest.mark.gpu
+def test_module_pins_the_solvers_persistent_buffer_when_asked(case_dir, monkeypatch):
+    """PSM_PIN_SOLVER_BUFFERS=1 (serial solver): the array the solver hands over every step is registered once, later steps
+    with the same buffer take the copy-free path and return the same persistent output array; another buffer re-registers;
+    the pressures are those of the default path bit for bit."""
+    array, top, obst, model, maxs = case_dir
+    ref_mod = _import_module()
+    ref_mod.init_func(array, top, obst)
+    ref = [ref_mod.py_func(array * s).copy() for s in (1.0, 1.01)]
+    monkeypatch.setenv("PSM_PIN_SOLVER_BUFFERS", "1")
+    pm = _import_module()
+    assert pm._PIN and pm.init_func(array, top, obst) == 0
+    buf = np.ascontiguousarray(array, np.float64).copy()              # the solver's input_vals: one allocation for the whole run
+    p0 = pm.py_func(buf)
+    assert pm._pin_state["ptr"] == buf.ctypes.data and pm._module._pinned is not None
+    np.testing.assert_array_equal(p0, ref[0])
+    buf[:] = array * 1.01                                             # next time step, written in place
+    p1 = pm.py_func(buf)
+    assert np.shares_memory(p1, p0) and pm._pin_state["ptr"] == buf.ctypes.data       # the same registered output array
+    np.testing.assert_array_equal(p1, ref[1])
+    other = np.ascontiguousarray(array, np.float64).copy()            # a different buffer: registered in its place
+    np.testing.assert_array_equal(pm.py_func(other), ref[0])
+    assert pm._pin_state["ptr"] == other.ctypes.data
+    pm.init_func(array, top, obst)                                    # a new geometry forgets the registration
+    assert pm._pin_state["ptr"] is None
+    np.testing.assert_array_equal(pm.py_func(other), ref[0])
