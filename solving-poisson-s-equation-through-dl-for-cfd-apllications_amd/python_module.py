@@ -89,6 +89,7 @@ def init_func(array, top_boundary, obst_boundary, placeholder=0):
     if rank == 0:
         len_rankwise = lens
         _pin_state.update(ptr=None, n=0, array=None, out=None)           # a new geometry = a new handle: nothing is registered on it yet
+        _cat.update(buf=None, out=None)
         _module.init_func(np.concatenate(array_global), np.concatenate(top_global), np.concatenate(obst_global))
     return 0
 
@@ -112,6 +113,22 @@ def _solve_rank0(array):
     return _module.py_func(array, out=_pin_state["out"])
 
 
+_cat = {"buf": None, "out": None}
+
+
+def _gathered(parts):
+    """Parallel solver, rank 0: the ranks' arrays concatenated into ONE persistent buffer that this module owns and registers
+    with the GPU (safe by construction: it lives as long as the module) -- the concatenation is the only host copy of the step."""
+    n = sum(a.shape[0] for a in parts)
+    if _cat["buf"] is None or _cat["buf"].shape[0] != n:
+        if _cat["buf"] is not None:
+            _module.unpin()
+        _cat["buf"], _cat["out"] = np.empty((n, 5), np.float64), np.empty(n, np.float64)
+        _module.pin(_cat["buf"], _cat["out"])
+    np.concatenate(parts, out=_cat["buf"])
+    return _cat["buf"]
+
+
 def py_func(array_in, placeholder=0):
     """python_module.py:249-517: cells [N_local,5] -> p [N_local].  A failure on the GPU side never aborts the
     solver: it is reported and the previous pressure (column 4) is returned for this step."""
@@ -119,11 +136,16 @@ def py_func(array_in, placeholder=0):
     array_global = _gather(array_in)
     p_rankwise = None
     if rank == 0:
-        array = array_global[0] if len(array_global) == 1 else np.concatenate(array_global)
         try:
-            p = _solve_rank0(array)
+            if len(array_global) == 1:
+                array = array_global[0]
+                p = _solve_rank0(array)
+            else:
+                array = _gathered(array_global)
+                p = _module.py_func(array, out=_cat["out"])
         except Exception:                                   # singleCore python_module.py:440-444 swallows and returns 0
             traceback.print_exc()
+            array = array_global[0] if len(array_global) == 1 else np.concatenate(array_global)
             p = array[:, 4].copy()
         p_rankwise, init = [], 0
         for length in len_rankwise:                         # :501-507
