@@ -148,8 +148,10 @@ def py_func(array_in, placeholder=0):
             array = array_global[0] if len(array_global) == 1 else np.concatenate(array_global)
             p = array[:, 4].copy()
         p_rankwise, init = [], 0
+        own = len(array_global) > 1                         # slices of the module's persistent output buffer: handed out as copies
         for length in len_rankwise:                         # :501-507
-            p_rankwise.append(p[init:init + length, ...])
+            part = p[init:init + length, ...]
+            p_rankwise.append(part.copy() if own else part)
             init += length
     if comm is None or nprocs == 1:
         return p_rankwise[0]

@@ -115,9 +115,20 @@ class _StubSolver:
         self.init_args = (np.array(array), np.array(top), np.array(obst))
         return 0
 
-    def py_func(self, array):
+    def pin(self, array, out=None):                     # the module registers its persistent gather buffer (rank 0, parallel solver)
+        self.pinned = (array, out)
+
+    def unpin(self):
+        self.pinned = None
+
+    def py_func(self, array, out=None):
         self.calls += 1
-        return 2.0 * array[:, 0] - array[:, 3] + 0.5 * array[:, 4] + self.calls
+        p = 2.0 * array[:, 0] - array[:, 3] + 0.5 * array[:, 4] + self.calls
+        if out is None:
+            return p
+        assert self.pinned is not None and array is self.pinned[0] and out is self.pinned[1]     # the registered pair, every step
+        out[:] = p
+        return out
 
 
 def test_gather_slice_scatter_with_four_fake_ranks(case_dir, monkeypatch):  # noqa: F811
