@@ -408,6 +408,41 @@ def test_extreme_component_and_layer_counts(variant, p_in, p_out, arch_layers):
     assert np.abs(fields - sol.fields).max() <= 1e-4 * max(np.abs(sol.fields).max(), 1e-3)
 
 
+def test_cli_default_cap_of_512_components():
+    """`max_number_PC = 512` is the cap the reference's evaluator mains pass by default (Eval_dual_Dense_onlycil.py main,
+    entry_point.py --max_num_PC): 512 components on both sides -- 16 component tiles in the encode, the generic decode, a
+    first Dense layer of 512 inputs -- general and geometry-bound path."""
+    model = synthetic.make_model("deltas", p_in=512, p_out=512, seed_pca=512, seed_w=5)
+    grid = synthetic.channel_grid(256, 256, seed=31).astype(np.float32)
+    with GridSurrogate(model, 256, 256) as sur:
+        fields = sur.solve(grid)[0]
+        sol = orc.solve_grid(grid.astype(np.float64), oracle_model(model))
+        check_against_oracle(sur, grid, model, sol)
+        assert np.abs(fields - sol.fields).max() <= 1e-4 * np.abs(sol.fields).max()
+        if sur.bind_geometry(grid):                          # binding needs <= 128 output components: not for this model
+            assert np.abs(sur.solve(grid)[0] - sol.fields).max() <= 1e-4 * np.abs(sol.fields).max()
+    model = synthetic.make_model("gradp", p_in=512, p_out=96, seed_pca=513, seed_w=6)
+    with GridSurrogate(model, 256, 256) as sur:
+        assert sur.bind_geometry(grid)
+        bound = sur.solve(grid)[0]
+    sol = orc.solve_grid(grid.astype(np.float64), oracle_model(model))
+    assert np.abs(bound - sol.fields).max() <= 1e-4 * np.abs(sol.fields).max()
+
+
+def test_maximum_component_counts_of_the_abi():
+    """psm_create accepts up to 1024 components per side: 1024 in (32 component tiles, the separate slab-reduce launch, a first
+    Dense layer of 1024 inputs) and 640 out (generic decode, 20 groups of 32) on the Chapter-5 layout."""
+    model = synthetic.make_model("chapter5", p_in=1024, p_out=640, seed_pca=1024, seed_w=7)
+    grid = synthetic.channel_grid(256, 300, seed=32).astype(np.float32)
+    with GridSurrogate(model, 256, 300) as sur:
+        fields = sur.solve(grid)[0]
+        sol = orc.solve_grid(grid.astype(np.float64), oracle_model(model))
+        check_against_oracle(sur, grid, model, sol)
+    assert np.abs(fields - sol.fields).max() <= 1e-4 * np.abs(sol.fields).max()
+    with pytest.raises(_lib.PsmError):
+        GridSurrogate(synthetic.make_model("deltas", p_in=1025, p_out=8, seed_pca=3), 256, 256)
+
+
 def test_all_solid_and_all_flow_grids():
     """No flow cell at all: every masked strip is empty, the reference's np.mean([]) = NaN propagates through the
     offsets to the whole field (NumPy semantics, reproduced); no solid cell at all: nothing is masked."""
