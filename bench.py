@@ -163,7 +163,7 @@ def spawn_ranks(n: int) -> int:
         procs, files = [], []
         for r in range(n):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PSM_BENCH_SPAWNED="1")
             env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             ferr = open(os.path.join(logdir, f"bench_rank{r}.err"), "wb")
             fout = open(out0, "wb") if r == 0 else subprocess.DEVNULL
@@ -378,10 +378,10 @@ def degenerate_note(variant, ny, nx, S=128):
 
 
 def die_with_parent():
-    """A rank started by spawn_ranks (or by torchrun) asks the kernel for SIGTERM when its parent dies: a launcher killed
-    with SIGKILL cannot stop its ranks itself.  Linux prctl(PR_SET_PDEATHSIG); silently skipped elsewhere."""
-    if "RANK" not in os.environ:
-        return
+    """A rank started by spawn_ranks asks the kernel for SIGTERM when its parent dies: a launcher killed with SIGKILL cannot
+    stop its ranks itself.  Linux prctl(PR_SET_PDEATHSIG); silently skipped elsewhere."""
+    if os.environ.get("PSM_BENCH_SPAWNED") != "1":            # only ranks started by spawn_ranks (its main thread outlives them); the
+        return                                                # death signal follows the parent THREAD: not under other launchers
     try:
         import ctypes
         import signal
