@@ -89,6 +89,23 @@ def test_eight_ranks_dry_run(tmp_path):
     assert (tmp_path / "bench_detail.json").exists() and all((tmp_path / f"bench_rank{r}.err").exists() for r in range(8))
 
 
+def test_dry_run_under_torch_distributed_run(tmp_path):
+    """The driver's N > 1 form: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- the environment's ranks are used (no self-launch), rank 0 prints the one line."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PSM_BENCH_BACKEND="gloo", PSM_BENCH_LOGDIR=str(tmp_path), OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--dry-run"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < LINE_LIMIT, out.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size_reported"] == 2 and d["case_batch"]["shards"] == [[0, 8], [8, 8]]
+
+
 def test_launcher_stops_its_ranks_when_it_is_terminated(tmp_path):
     """SIGTERM to the launcher (an outer `timeout`): its ranks are stopped with it, none is left parked in a barrier."""
     import signal
