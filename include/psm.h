@@ -327,7 +327,7 @@ int psm_solve_end(psm_handle* h);
  * handle's pinned staging copies (saves two host memcpys per step).  cells [n_cells,5] and / or p_out [n_cells] (either
  * may be NULL); the caller guarantees they stay allocated, at the same address, until psm_unpin_buffers, a new
  * psm_set_geometry or psm_destroy.  psm_solve calls with other pointers keep using the staging path.
- * With BOTH arrays registered (and up to 131 072 cells) a step issues no copy at all: the first kernel of the call reads `cells`
+ * With BOTH arrays registered (and up to 50 000 cells; above that the DMA engine's large-copy rate wins) a step issues no copy at all: the first kernel of the call reads `cells`
  * from the registered pages over PCIe (fully coalesced, taking the U_max partial maxima on the way) and the last one stores p
  * into `p_out` -- 65 us per call against 74 us with the DMA copy on a 16 k-cell mesh.  The caller must not
  * write `cells` or read `p_out` between psm_solve_begin and psm_solve_end. */

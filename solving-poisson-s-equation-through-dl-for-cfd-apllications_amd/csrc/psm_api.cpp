@@ -819,6 +819,12 @@ int solve_device(psm_handle* h, const float* d_grid, int n_cases, const float* o
   return PSM_OK;
 }
 
+#ifndef PSM_MESH_STAGE_MAX_DEFAULT
+// cells up to which psm_solve reads registered input with the stage kernel; above, the DMA engine's higher large-copy rate (49 against
+// 40 GB/s over this PCIe link) wins: measured crossover between 44 k (stage 107 / DMA 110 us) and 69 k cells (147 / 142 us),
+// profiles/r04_psm_solve.txt
+#define PSM_MESH_STAGE_MAX_DEFAULT 50000
+#endif
 // psm_solve on registered, mapped caller buffers: every device-side step of the call, in stream order (captured once)
 int mesh_sequence(psm_handle* h, int64_t n, hipStream_t st) {
   int n_partials = 0;
@@ -2059,7 +2065,8 @@ int psm_solve_begin(psm_handle* h, const double* cells, int64_t n, int32_t rank,
   // PSM_MESH_GRAPH: 0 = the separate submissions below (DMA copy, host U_max), 1 = one graph replay, 2 = the same sequence as
   // plain launches (measured default)
   static const int mesh_mode = getenv("PSM_MESH_GRAPH") ? atoi(getenv("PSM_MESH_GRAPH")) : 2;
-  if (mesh_mode != 0 && h->timed_kernel < 0 && n <= 131072 && cells == h->pinned_cells && h->pinned_cells_dev && p_out == h->pinned_p && h->pinned_p_dev) {
+  static const int64_t stage_max = getenv("PSM_MESH_STAGE_MAX") ? atoll(getenv("PSM_MESH_STAGE_MAX")) : PSM_MESH_STAGE_MAX_DEFAULT;
+  if (mesh_mode != 0 && h->timed_kernel < 0 && n <= stage_max && cells == h->pinned_cells && h->pinned_cells_dev && p_out == h->pinned_p && h->pinned_p_dev) {
     h->last_cases = 1;
     if (mesh_mode == 2) {
       int rc = mesh_sequence(h, n, st);

@@ -71,46 +71,50 @@ __global__ __launch_bounds__(256) void psm_stage_cells_kernel(const double* host
   __shared__ double row[ROWS * 5];
   __shared__ double red[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t d0 = (int64_t)blockIdx.x * ROWS * 5, dn = n * 5;          // in doubles
-  if (ALIGNED) {
-    psm_d2 v[NP];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-      const int64_t e = d0 + 2 * (int64_t)(j * 256 + tid);
-      v[j] = (e + 1 < dn) ? __builtin_nontemporal_load(reinterpret_cast<const psm_d2*>(host_cells + e))
-                          : (psm_d2){e < dn ? __builtin_nontemporal_load(host_cells + e) : 0.0, 0.0};
-    }
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-      const int64_t e = d0 + 2 * (int64_t)(j * 256 + tid);
-      const int l = 2 * (j * 256 + tid);
-      row[l] = v[j].x; row[l + 1] = v[j].y;
-      if (e + 1 < dn) *reinterpret_cast<psm_d2*>(cells + e) = v[j];
-      else if (e < dn) cells[e] = v[j].x;
-    }
-  } else {
-    double v[2 * NP];
-#pragma unroll
-    for (int j = 0; j < 2 * NP; ++j) {
-      const int64_t e = d0 + (int64_t)(j * 256 + tid);
-      v[j] = e < dn ? __builtin_nontemporal_load(host_cells + e) : 0.0;
-    }
-#pragma unroll
-    for (int j = 0; j < 2 * NP; ++j) {
-      const int64_t e = d0 + (int64_t)(j * 256 + tid);
-      row[j * 256 + tid] = v[j];
-      if (e < dn) cells[e] = v[j];
-    }
-  }
-  __syncthreads();
+  const int64_t dn = n * 5, n_chunks = (n + ROWS - 1) / ROWS;              // in doubles; chunks of 512 rows
   double m = 0.0;
+  for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {  // more than 256 chunks (131 072 cells): a second round
+    const int64_t d0 = chunk * ROWS * 5;
+    if (ALIGNED) {
+      psm_d2 v[NP];
 #pragma unroll
-  for (int k = 0; k < ROWS / 256; ++k) {
-    const int r = k * 256 + tid;
-    if ((int64_t)blockIdx.x * ROWS + r < n) {
-      const double ux = row[r * 5], uy = row[r * 5 + 1];
-      m = nanmax2(m, sqrt(ux * ux + uy * uy));
+      for (int j = 0; j < NP; ++j) {
+        const int64_t e = d0 + 2 * (int64_t)(j * 256 + tid);
+        v[j] = (e + 1 < dn) ? __builtin_nontemporal_load(reinterpret_cast<const psm_d2*>(host_cells + e))
+                            : (psm_d2){e < dn ? __builtin_nontemporal_load(host_cells + e) : 0.0, 0.0};
+      }
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const int64_t e = d0 + 2 * (int64_t)(j * 256 + tid);
+        const int l = 2 * (j * 256 + tid);
+        row[l] = v[j].x; row[l + 1] = v[j].y;
+        if (e + 1 < dn) *reinterpret_cast<psm_d2*>(cells + e) = v[j];
+        else if (e < dn) cells[e] = v[j].x;
+      }
+    } else {
+      double v[2 * NP];
+#pragma unroll
+      for (int j = 0; j < 2 * NP; ++j) {
+        const int64_t e = d0 + (int64_t)(j * 256 + tid);
+        v[j] = e < dn ? __builtin_nontemporal_load(host_cells + e) : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < 2 * NP; ++j) {
+        const int64_t e = d0 + (int64_t)(j * 256 + tid);
+        row[j * 256 + tid] = v[j];
+        if (e < dn) cells[e] = v[j];
+      }
     }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ROWS / 256; ++k) {
+      const int r = k * 256 + tid;
+      if (chunk * ROWS + r < n) {
+        const double ux = row[r * 5], uy = row[r * 5 + 1];
+        m = nanmax2(m, sqrt(ux * ux + uy * uy));
+      }
+    }
+    __syncthreads();                                         // the rows are consumed: the next round may overwrite them
   }
   for (int o = 32; o > 0; o >>= 1) m = nanmax2(m, __shfl_down(m, o, 64));
   if (lane == 0) red[wave] = m;
@@ -119,8 +123,8 @@ __global__ __launch_bounds__(256) void psm_stage_cells_kernel(const double* host
 }
 
 hipError_t psm_launch_stage_cells(const double* host_cells, double* cells, int64_t n, double* partials, int* n_partials, hipStream_t st) {
-  const int64_t wgs = (n + 511) / 512;
-  if (wgs < 1 || wgs > 256) return hipErrorInvalidValue;          // the partials array holds 256 (131 072 cells)
+  if (n < 1) return hipErrorInvalidValue;
+  const int64_t wgs = std::min<int64_t>(256, (n + 511) / 512);   // the partials array holds 256: larger meshes take further rounds
   *n_partials = (int)wgs;
   const bool aligned = ((reinterpret_cast<uintptr_t>(host_cells) | reinterpret_cast<uintptr_t>(cells)) & 15) == 0;
   if (aligned) hipLaunchKernelGGL(psm_stage_cells_kernel<true>, dim3((unsigned)wgs), dim3(256), 0, st, host_cells, cells, n, partials);
