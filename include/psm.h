@@ -329,7 +329,8 @@ int psm_solve_end(psm_handle* h);
  * psm_set_geometry or psm_destroy.  psm_solve calls with other pointers keep using the staging path.
  * With BOTH arrays registered (and up to 50 000 cells; above that the DMA engine's large-copy rate wins) a step issues no copy at all: the first kernel of the call reads `cells`
  * from the registered pages over PCIe (fully coalesced, taking the U_max partial maxima on the way) and the last one stores p
- * into `p_out` -- 65 us per call against 74 us with the DMA copy on a 16 k-cell mesh.  The caller must not
+ * into `p_out` -- up to 9 us off the 74 us per call of the DMA-copy form on a 16 k-cell mesh, depending on the host's PCIe read
+ * rates.  The caller must not
  * write `cells` or read `p_out` between psm_solve_begin and psm_solve_end. */
 int psm_pin_buffers(psm_handle* h, const double* cells, double* p_out);
 int psm_unpin_buffers(psm_handle* h);

@@ -13,7 +13,7 @@ working directory, exactly like the reference (python_module.py:103-118,170):
 
 ``PSM_PIN_SOLVER_BUFFERS=1`` (serial solver only, opt-in): the solver hands over the SAME array every step -- ``input_vals`` of
 PythonComm_init.H:53 is allocated once and never freed, PythonComm.H:17 wraps it without copying --, so it is registered with
-the GPU once (``psm_pin_buffers``) together with one persistent output array, and a step issues no copy at all (65 instead of
+the GPU once (``psm_pin_buffers``) together with one persistent output array, and a step issues no copy at all (65-75 instead of
 95 us on a 16 k-cell mesh).  Opt-in because the module cannot see whether the caller's buffer outlives the registration: only a
 caller that keeps it allocated for the whole run (the reference solver does) may set it.  The returned array is then the same
 object every step (valid until the next call; PythonComm.H:31-36 copies it out at once -- and no longer leaks one array per step).
