@@ -58,7 +58,8 @@ constexpr int T16_BYTES = P16 * IH * 32;                 // 20160
 constexpr int M32_BYTES = P32 * MH * 64;                 // 40960
 constexpr int M16_BYTES = P16 * MH * 32;                 // 17920
 
-// diagnostic builds (-DPSM_PAIR_EXP=n, results wrong on purpose): 1 no MFMAs, 2 no tile staging, 3 neither
+// diagnostic builds (-DPSM_PAIR_EXP=n, results wrong on purpose): 1 no MFMAs, 2 no tile staging, 3 neither; 4 the staging requests from
+// trivially cheap addresses (upper bound of an address-arithmetic diet), 8 requests as shipped but no LDS writes
 #if defined(PSM_PAIR_EXP) && (PSM_PAIR_EXP & 1)
 #define MFMA_BF(w, x, c) (c)
 #else
@@ -123,6 +124,17 @@ struct Stage {
 #if defined(PSM_PAIR_EXP) && (PSM_PAIR_EXP & 2)
     return;
 #endif
+#if defined(PSM_PAIR_EXP) && (PSM_PAIR_EXP == 4)
+    {   // upper bound of an address-arithmetic diet: the same number of requests, from trivially cheap (wrong) addresses
+      const char* q = reinterpret_cast<const char*>(src) + tid * 16 + (ys0 & 1) * 64;
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < NQ; ++e) v[i][e] = *reinterpret_cast<const f32x4*>(q + 4096 * (i * NQ + e));
+      ok = ~0u;
+      return;
+    }
+#endif
     const int M = NQ == 4 ? 2 : 1;                           // source pixels per tile pixel and direction
     const int64_t row_bytes = (int64_t)M * Ws * cpx * 2;     // one source row
     unsigned xoff[KM];
@@ -170,6 +182,17 @@ struct Stage {
     constexpr int NV = JN * KM + (SIDE ? 1 : 0);
 #if defined(PSM_PAIR_EXP) && (PSM_PAIR_EXP & 2)
     return;
+#endif
+#if defined(PSM_PAIR_EXP) && (PSM_PAIR_EXP == 8)
+    {   // requests as shipped, but nothing written: one store of a value that depends on every request (so that none is dropped)
+      f32x4 t = v[0][0];
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < NQ; ++e) t += v[i][e];
+      if (t[0] == 12345.678f) *reinterpret_cast<f32x4*>(tile) = t;
+      return;
+    }
 #endif
     auto piece = [&](int i) {
       f32x4 t = v[i][0];
