@@ -21,7 +21,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2026
 rng = np.random.default_rng(seed)
 variants = ("deltas", "gradp", "chapter5")
 TOL = 1e-4
-n_run = n_bound = n_batch = n_skip = n_nan = 0
+n_run = n_bound = n_batch = n_skip = n_nan = n_undef = 0
 worst = 0.0
 t0 = time.time()
 
@@ -73,7 +73,19 @@ for trial in range(trials):
         continue
     om = oracle_model(model)
     with sur:
-        want = [orc.solve_grid(grids[k].astype(np.float64), om).fields * sc[k] for k in range(n_cases)]
+        try:
+            want = [orc.solve_grid(grids[k].astype(np.float64), om).fields * sc[k] for k in range(n_cases)]
+        except ValueError as e:
+            # a drawn solid band covers the whole first block of a gradp grid: the reference's search for the first column with a
+            # flow cell runs off the block (IndexError at UGP:294-300) -- no reference answer.  The library must neither fail nor
+            # return a plausible field: the whole dp/dx field is NaN (psm_plan.h, first_col_mean), dp/dy is unaffected.
+            if "first block has no flow cell" not in str(e):
+                raise
+            general = sur.solve(grids if n_cases > 1 else grids[0], out_scale=sc)
+            if not np.isnan(general[..., 0]).any():
+                raise SystemExit(f"reference-undefined geometry returned a finite dp/dx field: {info}")
+            n_undef += 1
+            continue
         general = sur.solve(grids if n_cases > 1 else grids[0], out_scale=sc)
         for k in range(n_cases):
             compare("general", general[k], want[k], info)
@@ -94,4 +106,4 @@ for trial in range(trials):
     if trial % 20 == 19:
         print(f"trial {trial + 1}/{trials}: {n_run} run, {n_bound} bound, {n_batch} batched, {n_skip} unsupported shapes, "
               f"{n_nan} comparisons with NaN regions, worst rel err {worst:.2e}, {time.time() - t0:.0f} s", flush=True)
-print(f"SOAK OK: {n_run} configurations ({n_bound} bound, {n_batch} batched, {n_skip} skipped), worst rel err {worst:.2e} (tolerance {TOL}), seed {seed}")
+print(f"SOAK OK: {n_run} configurations ({n_bound} bound, {n_batch} batched, {n_skip} skipped, {n_undef} reference-undefined), worst rel err {worst:.2e} (tolerance {TOL}), seed {seed}")

@@ -464,6 +464,32 @@ def test_all_solid_and_all_flow_grids():
         assert np.isnan(sur.solve(solid)[0]).any()
 
 
+def test_gradp_first_block_without_a_flow_cell_is_reference_undefined():
+    """A solid region covering the whole first block of a U_to_gradP grid: the reference's search for the first column holding
+    a flow cell runs off the block and fails its own assert (UGP:294-300, "At least the right-most column ... must belong to the
+    flow domain, or this won't work"); the oracle raises.  The library neither fails nor returns a plausible dp/dx: the
+    reference BC is NaN (psm_plan.h, first_col_mean), so every dp/dx value is NaN, while dp/dy -- anchored on row 1 of the
+    block (UGP:302-303), which np.mean([]) turns into NaN as well when the block is solid -- follows NumPy semantics.  Found by
+    tests/measure/soak.py (seed 9041)."""
+    model = synthetic.make_model("gradp", p_in=12, p_out=10)
+    om = oracle_model(model)
+    g = synthetic.channel_grid(272, 288, seed=5, obstacle="none").astype(np.float32)
+    g[:128, :128, :] = 0.0
+    with pytest.raises(ValueError, match="first block has no flow cell"):
+        orc.solve_grid(g.astype(np.float64), om)
+    flow = g[..., model.sdf_ch] != 0
+    with GridSurrogate(model, 272, 288) as sur:
+        general = sur.solve(g)[0]
+        assert np.isnan(general[..., 0][flow]).all()
+        assert sur.bind_geometry(g)
+        bound = sur.solve(g)[0]
+        np.testing.assert_array_equal(np.isnan(bound), np.isnan(general))
+        ok = ~np.isnan(general)
+        if ok.any():
+            assert np.abs(bound[ok] - general[ok]).max() <= 2e-5 * np.abs(general[ok]).max()
+        assert sur.guard_trips == 0
+
+
 def test_chapter4_channel_configuration():
     """The Chapter-4 M_fU evaluator's shape (Thesis_Work/Chapter4/MLP/M_fU/Evaluation/Eval.py:205-223): two input channels
     (f(U), SDF) with the flow mask in channel 1, Chapter-5 block layout, 116 -> 39 components like its model_first_.h5."""

@@ -82,3 +82,21 @@ def test_real_weights_fixture_is_the_reference_file():
     assert abs(float(W[0][0].min()) + 1.279) < 1e-3 and abs(float(W[0][0].max()) - 0.992) < 1e-3
     np.testing.assert_allclose(maxs, [1.0, 0.536133, 0.999023, 0.510742], rtol=1e-5)
     np.testing.assert_allclose(maxs_pca, [147.2389, 26.7201], rtol=1e-5)
+
+
+def test_oracle_refuses_a_gradp_grid_whose_first_block_is_solid():
+    """UGP:294-300: the inlet reference of dp/dx is taken on the first column of block 0 that holds a flow cell, and the
+    reference asserts that there is one ("At least the right-most column ... must belong to the flow domain, or this won't
+    work").  The oracle restates the failure as a ValueError instead of running off the block; the GPU library's answer for
+    such a grid (NaN dp/dx, never a plausible field) is pinned in tests/test_gpu_parity.py."""
+    import psm_amd
+    from psm_amd import synthetic
+    from bench import oracle_model
+    model = synthetic.make_model("gradp", p_in=6, p_out=5)
+    g = synthetic.channel_grid(272, 288, seed=5, obstacle="none").astype(np.float64)
+    g[:128, :128, :] = 0.0
+    with pytest.raises(ValueError, match="first block has no flow cell"):
+        orc.solve_grid(g, oracle_model(model))
+    g[5, 127, :] = 0.3                                       # one flow cell in the block's last column: defined again
+    with np.errstate(all="ignore"):
+        assert orc.solve_grid(g, oracle_model(model)).fields.shape == (272, 288, 2)
