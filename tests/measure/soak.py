@@ -47,7 +47,12 @@ for trial in range(trials):
         ny, nx = 256, 256                                             # the BASELINE shape (p_i == 0: skip mode)
     p_in, p_out = int(rng.integers(1, 140)), int(rng.integers(1, 140))
     n_cases = int(rng.integers(1, 7)) if rng.random() < 0.35 else 1
-    model = synthetic.make_model(variant, p_in=p_in, p_out=p_out, seed_pca=int(rng.integers(1 << 20)), seed_w=int(rng.integers(1 << 20)))
+    # scaler and architecture drawn too (second session of round 4): every standardization method of utils.py:290-329 with every
+    # block layout, and the deeper / narrower Dense stacks of utils.py:435-461 now and then
+    scaler = (None, "std", "max_abs", "min_max")[int(rng.integers(4))]
+    arch = "MLP_small" if rng.random() < 0.8 else ("MLP_big", "MLP_huge", "MLP_small_unet")[int(rng.integers(3))]
+    model = synthetic.make_model(variant, p_in=p_in, p_out=p_out, arch=arch, scaler_kind=scaler,
+                                 seed_pca=int(rng.integers(1 << 20)), seed_w=int(rng.integers(1 << 20)))
     if rng.random() < 0.15:                                           # densePCA_attention (round 4): other widths, depths, head shapes
         width, depth = int(rng.integers(3, 40)) * 8, int(rng.integers(2, 5))
         model.weights = synthetic.he_dense_stack(p_in, [width] * depth, p_out, seed=int(rng.integers(1 << 20)))
@@ -65,7 +70,7 @@ for trial in range(trials):
         grids.append(g)
     grids = np.stack(grids)
     sc = [float(rng.uniform(0.3, 2.0)) for _ in range(n_cases)]
-    info = dict(trial=trial, variant=variant, ny=ny, nx=nx, p_in=p_in, p_out=p_out, n_cases=n_cases, attention=model.attention is not None)
+    info = dict(trial=trial, variant=variant, ny=ny, nx=nx, p_in=p_in, p_out=p_out, n_cases=n_cases, attention=model.attention is not None, scaler=scaler, arch=arch)
     try:
         sur = GridSurrogate(model, ny, nx, max_cases=n_cases)
     except _lib.PsmError:
