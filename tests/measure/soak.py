@@ -57,6 +57,13 @@ for trial in range(trials):
         width, depth = int(rng.integers(3, 40)) * 8, int(rng.integers(2, 5))
         model.weights = synthetic.he_dense_stack(p_in, [width] * depth, p_out, seed=int(rng.integers(1 << 20)))
         model.attention = synthetic.he_attention_block([width] * depth, seed=int(rng.integers(1 << 20)), n_heads=int(rng.integers(1, 9)), key_dim=int(rng.integers(4, 65)))
+    elif rng.random() < 0.12:                                         # conv1D_PCA head (NNs.py:75-124): drawn filters, kernel sizes, an optional hidden Dense
+        filters = [int(rng.integers(1, 40)) for _ in range(int(rng.integers(1, 5)))]
+        model.conv1d, model.weights = synthetic.he_conv1d_head(p_in, filters, p_out, seed=int(rng.integers(1 << 20)), kernel_size=int(rng.integers(1, 6)))
+        if rng.random() < 0.4:
+            n0, hid = model.weights[0][0].shape[0], int(rng.integers(2, 20)) * 8
+            model.weights = [((rng.standard_normal((n0, hid)) / np.sqrt(n0)).astype(np.float32), (rng.standard_normal(hid) * 0.01).astype(np.float32)),
+                             ((rng.standard_normal((hid, p_out)) / np.sqrt(hid)).astype(np.float32), (rng.standard_normal(p_out) * 0.01).astype(np.float32))]
     grids = []
     for k in range(n_cases):
         g = synthetic.channel_grid(ny, nx, seed=int(rng.integers(1 << 30)), obstacle=("circle", "rectangle", "plate", "none")[int(rng.integers(4))],
@@ -70,7 +77,7 @@ for trial in range(trials):
         grids.append(g)
     grids = np.stack(grids)
     sc = [float(rng.uniform(0.3, 2.0)) for _ in range(n_cases)]
-    info = dict(trial=trial, variant=variant, ny=ny, nx=nx, p_in=p_in, p_out=p_out, n_cases=n_cases, attention=model.attention is not None, scaler=scaler, arch=arch)
+    info = dict(trial=trial, variant=variant, ny=ny, nx=nx, p_in=p_in, p_out=p_out, n_cases=n_cases, attention=model.attention is not None, scaler=scaler, arch=arch, conv1d=len(getattr(model, 'conv1d', ()) or ()))
     try:
         sur = GridSurrogate(model, ny, nx, max_cases=n_cases)
     except _lib.PsmError:
