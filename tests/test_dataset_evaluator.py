@@ -312,3 +312,43 @@ def test_poisson_main_and_metrics(tmp_path):
         BIAS, RMSE = np.mean(acc[sfx][0]) * 100, np.sqrt(np.mean(acc[sfx][1])) * 100
         assert out["overall"][key]["BIAS"] == pytest.approx(BIAS, rel=1e-5, abs=1e-9) and out["overall"][key]["RMSE"] == pytest.approx(RMSE, rel=1e-5)
     assert out["sims"][0]["sim"] == 0 and out["sims"][0]["phi"] == 0.16
+
+
+_REF = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(_REF), reason="the reference checkout is only present in the build container")
+def test_keras_reader_reads_every_h5_file_of_the_reference():
+    """Every Keras HDF5 file the reference ships (56: the Chapter-4 / Chapter-5 surrogates, full-model files with optimizer
+    state, the Chapter-3 PINNs) goes through formats.read_keras_dense_weights: a chain of Dense layers whose shapes fit each
+    other, finite float32 values.  Reads the files as DATA where they lie (nothing is copied); skipped where the checkout is
+    absent (the GPU box)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(_REF, "**", "*.h5"), recursive=True))
+    assert len(files) >= 40
+    shapes = set()
+    for f in files:
+        layers = formats.read_keras_dense_weights(f)
+        assert len(layers) >= 2, f
+        for (W, b), (W2, _) in zip(layers[:-1], layers[1:]):
+            assert W.shape[1] == b.shape[0] == W2.shape[0], f
+        assert all(W.dtype == np.float32 and np.isfinite(W).all() and np.isfinite(b).all() for W, b in layers), f
+        shapes.add((layers[0][0].shape[0], layers[-1][0].shape[1], len(layers)))
+    assert (45, 48, 4) in shapes and (116, 39, 4) in shapes and (2, 5, 8) in shapes     # test_case/weights.h5, M_fU/model_first_.h5, a PINN
+
+
+@pytest.mark.skipif(not os.path.isdir(_REF), reason="the reference checkout is only present in the build container")
+def test_maxs_reader_reads_every_maxs_file_of_the_reference():
+    """The reference's normalisation constants (`maxs`: one value per line; `maxs_PCA`: two) -- the values SURVEY.md section 8(c)
+    quotes for the shipped solver case and the Chapter-4 evaluator."""
+    import glob
+    files = sorted(glob.glob(os.path.join(_REF, "**", "maxs*"), recursive=True))
+    assert len(files) >= 6
+    for f in files:
+        v = formats.read_maxs(f)
+        assert v.ndim == 1 and np.isfinite(v).all() and (v > 0).all(), f
+        assert v.size in (2, 3, 4), f                 # (the Chapter-4 M_fU evaluator's maxs_PCA is a copy of its 3-value maxs)
+    np.testing.assert_allclose(formats.read_maxs(os.path.join(_REF, "Thesis_Work/Chapter5/parallelized/test_case/maxs")),
+                               [1.0, 0.536133, 0.999023, 0.510742], rtol=1e-5)
+    np.testing.assert_allclose(formats.read_maxs(os.path.join(_REF, "Thesis_Work/Chapter5/parallelized/test_case/maxs_PCA")),
+                               [147.2389, 26.7201], rtol=1e-5)
