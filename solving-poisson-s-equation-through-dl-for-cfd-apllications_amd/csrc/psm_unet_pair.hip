@@ -65,6 +65,13 @@ constexpr int M16_BYTES = P16 * MH * 32;                 // 17920
 #else
 #define MFMA_BF(w, x, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((w), (x), (c), 0, 0, 0)
 #endif
+// level-0 decoder pair: the next tile's ten requests spread over conv A's MFMA steps, two per step (1), or issued in one go
+// before them (0).  Measured A/B on one box (round 4, profiles/r04_conv_experiments.txt (5g)): 20.50 / 19.80 us spread against
+// 20.06 / 20.00 us in one go at 8 cases, 13.30 / 13.16 against 13.46 / 13.42 us at 512 x 512 x 1 -- the address path is not what
+// the tile waits for either.  Off; -DPSM_PAIR_SPREAD=1 builds it (parity tests green in both forms).
+#ifndef PSM_PAIR_SPREAD
+#define PSM_PAIR_SPREAD 0
+#endif
 
 // workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for the NEXT tile's
 // global requests, which are meant to stay in flight across the barriers
@@ -176,6 +183,39 @@ struct Stage {
       }
     }
   }
+  // ONE piece of issue() (whole tile: J0 = 0, JN = RW, with the side block; NQ == 1), so that a kernel can spread the requests
+  // of the next tile over the MFMA steps of the current one: a wave-wide 16-byte load holds the CU's address path for 16
+  // cycles, and ten of them issued in one go by eight waves in phase keep every wave -- and the MFMAs behind the loads in
+  // program order -- for up to 0.6 us per tile.  I < RW * KM: row iteration I / KM, column slot I % KM; I == RW * KM: side block.
+  // The first piece clears ok.
+  template <int I>
+  static __device__ __forceinline__ void issue_piece(f32x4 (&v)[NP][NQ], unsigned& ok, const unsigned short* src, int cpx, int cb,
+                                                     int Hs, int Ws, int ys0, int xs0, int wave, int lane, int tid) {
+    static_assert(NQ == 1 && I >= 0 && I < NP, "same-resolution pieces of a whole tile");
+    if (I == 0) ok = 0;
+#if defined(PSM_PAIR_EXP) && (PSM_PAIR_EXP & 2)
+    return;
+#endif
+    const int64_t row_bytes = (int64_t)Ws * cpx * 2;
+    if constexpr (I < RW * KM) {
+      constexpr int jj = I / KM, k = I % KM;
+      const int c = PPI * k + lane / G, g = lane % G, x = xs0 + c;
+      const bool xin = x >= 0 && x < Ws;
+      const unsigned xoff = (unsigned)((min(max(x, 0), Ws - 1) * cpx + cb + 8 * g) * 2);
+      const int r = min(wave + 4 * jj, NROW - 1), y = ys0 + r;          // uniform
+      const bool yok = y >= 0 && y < Hs;
+      const char* rowp = reinterpret_cast<const char*>(src) + (int64_t)min(max(y, 0), Hs - 1) * row_bytes;
+      v[I][0] = *reinterpret_cast<const f32x4*>(rowp + xoff);
+      ok |= (yok && xin) ? (1u << I) : 0u;
+    } else {
+      const int q = min(tid, NSIDE - 1), r = q / (SIDEW * G), rem = q - r * (SIDEW * G), c = MAINPX + rem / G, g = rem % G;
+      const int y = ys0 + r, x = xs0 + c;
+      ok |= (y >= 0 && y < Hs && x >= 0 && x < Ws) ? (1u << I) : 0u;
+      const char* qp = reinterpret_cast<const char*>(src) + (int64_t)min(max(y, 0), Hs - 1) * row_bytes +
+                       (min(max(x, 0), Ws - 1) * cpx + cb + 8 * g) * 2;
+      v[I][0] = *reinterpret_cast<const f32x4*>(qp);
+    }
+  }
   // interior (uniform): every staged pixel lies inside the image -- no selects
   template <int J0 = 0, int JN = RW, bool SIDE = (NSIDE > 0)>
   static __device__ __forceinline__ void write(char* tile, const f32x4 (&v)[JN * KM + (SIDE ? 1 : 0)][NQ], unsigned ok, bool interior, int wave, int lane, int tid) {
@@ -230,8 +270,11 @@ typedef Stage<64, 34, IH, P32, 4> StPool32;               // 32 channels through
 // NX input rows and the 3 NT weight fragments are read from LDS one step ahead of the MFMAs that use them (two register
 // stages; nothing moves across the sched_barriers, so the live set stays at two stages).
 //   xload(s, i): operand of step s, input-row slot i;   wload(s, ky, nt): weight fragment;   HALF: slot of row j is j >> 1
-template <int NT, int R, int NX, int S, bool HALF, bool DB, typename XLoad, typename WLoad>
-__device__ __forceinline__ void conv_steps(XLoad xload, WLoad wload, f32x4 (&acc)[R][NT]) {
+struct NoFill { __device__ __forceinline__ void operator()(int) const {} };
+//   fill(i): up to two slices of unrelated work per step (i = 2 s after the ky = 0 MFMAs, 2 s + 1 after the ky = 1 ones), pinned
+//   between the MFMA groups: what is issued there runs in the shadow of the MFMAs already in the pipe
+template <int NT, int R, int NX, int S, bool HALF, bool DB, typename XLoad, typename WLoad, typename Fill = NoFill>
+__device__ __forceinline__ void conv_steps(XLoad xload, WLoad wload, f32x4 (&acc)[R][NT], Fill fill = Fill()) {
   bf16x8 xb[DB ? 2 : 1][NX], wb[DB ? 2 : 1][3 * NT];
   auto load = [&](int s, int st) {
 #pragma unroll
@@ -246,12 +289,20 @@ __device__ __forceinline__ void conv_steps(XLoad xload, WLoad wload, f32x4 (&acc
     else load(s, 0);                     // one stage (register budget): the other wave of the SIMD covers the read latency
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+    for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int m = 0; m < R; ++m)
           acc[m][nt] = MFMA_BF(wb[DB ? (s & 1) : 0][ky * NT + nt], xb[DB ? (s & 1) : 0][HALF ? (m + ky) >> 1 : m + ky], acc[m][nt]);
+      if constexpr (!std::is_same<Fill, NoFill>::value) {
+        if (ky < 2) {
+          __builtin_amdgcn_sched_barrier(0);
+          fill(2 * s + ky);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -264,19 +315,19 @@ __device__ __forceinline__ void conv32(const char* tile, int r0, int xcol, int k
 }
 // the same on a HALF-resolution tile (2x nearest-neighbour upsample done by the addressing): pixel (r, c) of the input
 // tile is low-resolution pixel (r >> 1, c >> 1), pitch PL; r0 is even, so rows r0 + 2j and r0 + 2j + 1 share one read
-template <int NT, int R, typename WGet>
-__device__ __forceinline__ void conv32_up(const char* tile, int r0, int xcol, int kq, WGet wget, f32x4 (&acc)[R][NT]) {
+template <int NT, int R, typename WGet, typename Fill = NoFill>
+__device__ __forceinline__ void conv32_up(const char* tile, int r0, int xcol, int kq, WGet wget, f32x4 (&acc)[R][NT], Fill fill = Fill()) {
   static_assert((R & 1) == 0, "row pairs");
   conv_steps<NT, R, (R + 2) / 2, 3, true, NT == 1>(
       [&](int kx, int i) { return *reinterpret_cast<const bf16x8*>(tile + (r0 >> 1) * (PL * 64) + slot64((xcol + kx) >> 1, kq) + i * (PL * 64)); },
-      [&](int kx, int ky, int nt) { return wget((kx * 3 + ky) * NT + nt); }, acc);
+      [&](int kx, int ky, int nt) { return wget((kx * 3 + ky) * NT + nt); }, acc, fill);
 }
 // 16-channel chunk, 32-byte pixels, pitch P16: step = tap pair (kx = 2s, 2s + 1); fragments [s][ky][nt]
-template <int NT, int R, bool DB = (NT == 1), typename WGet>
-__device__ __forceinline__ void conv16(const char* tile, int r0, int xcol, int kq, WGet wget, f32x4 (&acc)[R][NT]) {
+template <int NT, int R, bool DB = (NT == 1), typename WGet, typename Fill = NoFill>
+__device__ __forceinline__ void conv16(const char* tile, int r0, int xcol, int kq, WGet wget, f32x4 (&acc)[R][NT], Fill fill = Fill()) {
   conv_steps<NT, R, R + 2, 2, false, DB>(
       [&](int s, int i) { return *reinterpret_cast<const bf16x8*>(tile + ((r0 + i) * P16 + xcol + 2 * s) * 32 + kq * 16); },
-      [&](int s, int ky, int nt) { return wget((s * 3 + ky) * NT + nt); }, acc);
+      [&](int s, int ky, int nt) { return wget((s * 3 + ky) * NT + nt); }, acc, fill);
 }
 
 // Persistent workgroups: workgroup w runs tiles it = 0, 1, ... of its own sequence.  Consecutive workgroup ids go to
@@ -588,16 +639,38 @@ __global__ __launch_bounds__(256, 2) void psm_pair_up16_kernel(PsmPairArgs a) {
     PSTAMP(2);
     const int next = tile_of(++it, total);
     const TilePos nxt = tile_pos(a, next >= 0 ? next : tile);          // past the end: the same tile again (no branch around the loads)
+#if PSM_PAIR_SPREAD
+    // the ten requests of the next tile, two per MFMA step of conv A (three steps on the upsample source, two on the skip input)
+    const unsigned short* nlo = reinterpret_cast<const unsigned short*>(a.in0) + (int64_t)nxt.cs * a.in0_case;
+    const unsigned short* n16 = reinterpret_cast<const unsigned short*>(a.in1) + (int64_t)nxt.cs * a.in1_case;
+    auto piece = [&](int p) {
+#define LO_PIECE(I) StLow::template issue_piece<I>(vlo, oklo, nlo, 32, 0, a.H / 2, a.W / 2, (nxt.y0 - 2) / 2, (nxt.x0 - 2) / 2, wave, lane, tid)
+#define SK_PIECE(I) St16::template issue_piece<I>(v16, ok16, n16, 16, 0, a.H, a.W, nxt.y0 - 2, nxt.x0 - 2, wave, lane, tid)
+      static_assert(StLow::NP == 4 && St16::NP == 6, "ten pieces over five steps");
+      if (p == 0) LO_PIECE(0); else if (p == 1) LO_PIECE(1); else if (p == 2) LO_PIECE(2); else if (p == 3) LO_PIECE(3);
+      else if (p == 4) SK_PIECE(0); else if (p == 5) SK_PIECE(1); else if (p == 6) SK_PIECE(2); else if (p == 7) SK_PIECE(3);
+      else if (p == 8) SK_PIECE(4); else if (p == 9) SK_PIECE(5);
+#undef LO_PIECE
+#undef SK_PIECE
+    };
+#else
     issue(nxt);
+#endif
     {
       constexpr int R = MH / 2;
       const int r0 = R * (wave >> 1);
       f32x4 acc[R][1];
 #pragma unroll
       for (int m = 0; m < R; ++m) acc[m][0] = bA;
+#if PSM_PAIR_SPREAD
+      conv32_up<1, R>(tlow, r0, 16 * xh + px, kq, [&](int i) { return wf[i * 64]; }, acc, [&](int i) { piece(i); });
+      PSTAMP(3);
+      conv16<1, R>(t16, r0, 16 * xh + px, kq, [&](int i) { return wf[(9 + i) * 64]; }, acc, [&](int i) { piece(6 + i); });
+#else
       conv32_up<1, R>(tlow, r0, 16 * xh + px, kq, [&](int i) { return wf[i * 64]; }, acc);
       PSTAMP(3);
       conv16<1, R>(t16, r0, 16 * xh + px, kq, [&](int i) { return wf[(9 + i) * 64]; }, acc);
+#endif
       PSTAMP(4);
       mid_epilogue<1, R, KEEP>(a, mid, cur.cs, cur.y0, cur.x0, r0, xh, lane, interior, acc);
     }
