@@ -59,7 +59,8 @@ constexpr int M32_BYTES = P32 * MH * 64;                 // 40960
 constexpr int M16_BYTES = P16 * MH * 32;                 // 17920
 
 // diagnostic builds (-DPSM_PAIR_EXP=n, results wrong on purpose): 1 no MFMAs, 2 no tile staging, 3 neither; 4 the staging requests from
-// trivially cheap addresses (upper bound of an address-arithmetic diet), 8 requests as shipped but no LDS writes
+// trivially cheap addresses (upper bound of an address-arithmetic diet), 8 requests as shipped but no LDS writes, 12 both, 16 the fused
+// head's stores dropped
 #if defined(PSM_PAIR_EXP) && (PSM_PAIR_EXP & 1)
 #define MFMA_BF(w, x, c) (c)
 #else
@@ -131,7 +132,7 @@ struct Stage {
 #if defined(PSM_PAIR_EXP) && (PSM_PAIR_EXP & 2)
     return;
 #endif
-#if defined(PSM_PAIR_EXP) && (PSM_PAIR_EXP == 4)
+#if defined(PSM_PAIR_EXP) && (PSM_PAIR_EXP == 4 || PSM_PAIR_EXP == 12)
     {   // upper bound of an address-arithmetic diet: the same number of requests, from trivially cheap (wrong) addresses
       const char* q = reinterpret_cast<const char*>(src) + tid * 16 + (ys0 & 1) * 64;
 #pragma unroll
@@ -223,7 +224,7 @@ struct Stage {
 #if defined(PSM_PAIR_EXP) && (PSM_PAIR_EXP & 2)
     return;
 #endif
-#if defined(PSM_PAIR_EXP) && (PSM_PAIR_EXP == 8)
+#if defined(PSM_PAIR_EXP) && (PSM_PAIR_EXP == 8 || PSM_PAIR_EXP == 12)
     {   // requests as shipped, but nothing written: one store of a value that depends on every request (so that none is dropped)
       f32x4 t = v[0][0];
 #pragma unroll
@@ -436,6 +437,9 @@ __device__ __forceinline__ void out_epilogue(const PsmPairArgs& a, int cs, int y
         const u32x2v t = __builtin_amdgcn_permlane16_swap(__float_as_uint(u01), __float_as_uint(u23), false, false);
         const float tot = __uint_as_float(t[0]) + __uint_as_float(t[1]) + hb;      // group g: row {0, 2, 1, 3}[g] of this group of four
         const int m = 4 * q + grp_row, y = y0 + r0 + m;
+#if defined(PSM_PAIR_EXP) && (PSM_PAIR_EXP == 16)
+        if (tot == 12345.678f)                     // diagnostic: the head's result computed, (almost) never stored
+#endif
         if (xok && m < R && y < a.H) a.head_out[(int64_t)cs * a.head_case + ((int64_t)y * a.W + x) * a.head_cout + o] = tot;
       }
     }
