@@ -197,6 +197,7 @@ struct psm_handle {
   int debug_skip = 0;                   // PSM_DEBUG_SKIP bit mask of kernel groups NOT launched (timing experiments only)
   bool fuse_reduce_dense1 = true;       // PSM_NO_FUSED_REDUCE=1 disables
   int last_cases = 0;
+  bool last_on_ws0 = false;             // the most recent solve ran on the handle's own workspace (not a ring slot's): what psm_block_error decodes
   // event timing of one kernel group
   int timed_kernel = -1;
   int timed_repeat = 1;
@@ -394,6 +395,11 @@ void free_plan(psm_handle* h) {
   if (h->h_grid) { (void)hipHostFree(h->h_grid); h->h_grid = nullptr; }
   if (h->h_fields) { (void)hipHostFree(h->h_fields); h->h_fields = nullptr; }
   h->planned = false;
+  // The mesh-side tables (psm_set_geometry) index THIS plan's grid and its staging buffers, which are gone now: a later
+  // psm_solve / psm_mesh_to_grid must fail with PSM_ERR_STATE until psm_set_geometry runs again, not launch on null buffers.
+  // (The registered host arrays stay registered; the graph that holds their addresses goes with the plan.)
+  h->have_geometry = false;
+  if (h->mesh_graph) { (void)hipGraphExecDestroy(h->mesh_graph); h->mesh_graph = nullptr; }
 }
 
 // ---- weight packing ----------------------------------------------------------
@@ -531,6 +537,7 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
                hipStream_t st, hipEvent_t* prof) {
   const int M = n_cases * h->B, Mpad = round_up(M, 32);
   Timer tm{h, st, 0, prof};
+  h->last_on_ws0 = (&w == &h->ws0);
   const bool bf16 = (h->cfg.precision == PSM_PRECISION_BF16);
   // geometry-bound fast path: one case, nothing but the encode group being timed / skipped
   const bool use_bound = h->bound && (h->bound_scope == 2 || h->in_mesh_solve) && n_cases == h->bound_cases && (h->timed_kernel < 0 || h->timed_kernel == PSM_K_ENCODE) && h->debug_skip == 0;
@@ -1036,7 +1043,9 @@ int psm_set_dense(psm_handle* h, int32_t layer, int32_t n_in, int32_t n_out, con
   h->bound = false;
   DenseLayer& d = h->dense[layer];
   d.linear = false;                                     // psm_set_attention sets it again after this call
-  if (d.ln && d.n_out != n_out) { d.ln = false; dev_free(d.ln_gamma); dev_free(d.ln_beta); }   // a LayerNormalization of another width
+  if (d.ln && (d.n_out != n_out || (d.ln_residual && n_in != n_out))) {      // a LayerNormalization of another width, or its residual x + input on a
+    d.ln = false; d.ln_residual = false; dev_free(d.ln_gamma); dev_free(d.ln_beta);   // layer that is no longer square: set it again after this call
+  }
   d.n_in = n_in; d.n_out = n_out; d.Kpad = round_up(n_in, 32); d.ldw = round_up(n_out, 32);
   std::vector<float> W((size_t)d.Kpad * d.ldw, 0.f), b(d.ldw, 0.f);
   for (int k = 0; k < n_in; ++k) memcpy(&W[(size_t)k * d.ldw], kernel + (size_t)k * n_out, n_out * sizeof(float));
@@ -1196,6 +1205,8 @@ int psm_plan_grid(psm_handle* h, int32_t ny, int32_t nx) {
   if (!model_complete(h)) return fail(h, PSM_ERR_STATE, "model incomplete: call psm_set_pca, psm_set_scaler and psm_set_dense for every layer first");
   for (size_t l = 1; l < h->dense.size(); ++l)
     if (h->dense[l - 1].n_out != h->dense[l].n_in) return fail(h, PSM_ERR_ARG, "dense layers do not chain");
+  for (const DenseLayer& d : h->dense)
+    if (d.ln && d.ln_residual && d.n_in != d.n_out) return fail(h, PSM_ERR_ARG, "a LayerNormalization with the residual x + input needs a square layer");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->bound = false;
@@ -1901,6 +1912,10 @@ int psm_label_blocks(psm_handle* h, const float* grid, const float* labels, floa
 int psm_block_error(psm_handle* h, const float* grid, const float* labels, double* out) {
   if (!h) return PSM_ERR_ARG;
   if (!h->planned || h->last_cases < 1) return fail(h, PSM_ERR_STATE, "no solve has run yet");
+  // The network output it decodes lives in the handle's own workspace.  A solve through the asynchronous ring
+  // (psm_submit_grid*, psm_ring_*, psm_bench_host) ran on a ring slot's workspace and left an OLDER solve here.
+  if (!h->last_on_ws0)
+    return fail(h, PSM_ERR_STATE, "psm_block_error follows a synchronous solve (psm_solve_grid / psm_solve_grid_device / psm_solve); the last solve ran on the ring");
   if (!grid || !labels || !out) return fail(h, PSM_ERR_ARG, "null buffer");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   HIPCHK(h, hipDeviceSynchronize());                        // the solve may have run on the caller's stream
@@ -2051,7 +2066,8 @@ int psm_solve_begin(psm_handle* h, const double* cells, int64_t n, int32_t rank,
   (void)rank;
   if (!h) return PSM_ERR_ARG;
   if (h->mesh_inflight) return fail(h, PSM_ERR_STATE, "a psm_solve_begin is already in flight on this handle: call psm_solve_end first");
-  if (!h->have_geometry) return fail(h, PSM_ERR_STATE, "psm_set_geometry has not been called");
+  if (!h->have_geometry || !h->planned)
+    return fail(h, PSM_ERR_STATE, "psm_set_geometry has not been called (or the plan it belonged to was dropped by a later psm_set_* / psm_plan_grid)");
   if (h->cfg.c_in != 3 || h->cfg.c_out != 1) return fail(h, PSM_ERR_UNSUPPORTED, "the mesh entry needs c_in == 3 and c_out == 1 (python_module.py:288-292)");
   if (!h->have_g2m) return fail(h, PSM_ERR_STATE, "psm_set_geometry was called without the grid->mesh tables");
   if (!cells || !p_out) return fail(h, PSM_ERR_ARG, "null buffer");

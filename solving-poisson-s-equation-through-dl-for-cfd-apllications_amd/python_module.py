@@ -104,7 +104,12 @@ def _solve_rank0(array):
     if not (_PIN and (comm is None or nprocs == 1) and array.flags.c_contiguous):
         return _module.py_func(array)
     ptr, n = array.ctypes.data, array.shape[0]
-    if _pin_state["ptr"] != ptr or _pin_state["n"] != n:
+    # Same address and length, but another owner (array.base) than the one registered: the old buffer may have been freed and
+    # this one allocated in its place -- register again.  (A solver that wraps ITS persistent C buffer in a fresh ndarray per
+    # call has base None both times and keeps the registration, which is the case this option exists for.)
+    prev = _pin_state["array"]
+    stale = prev is not None and prev is not array and (getattr(prev, "base", None) is not getattr(array, "base", None))
+    if _pin_state["ptr"] != ptr or _pin_state["n"] != n or stale:
         if _pin_state["ptr"] is not None:
             _module.unpin()
         out = np.empty(n, np.float64)
@@ -145,8 +150,8 @@ def py_func(array_in, placeholder=0):
                 p = _module.py_func(array, out=_cat["out"])
         except Exception:                                   # singleCore python_module.py:440-444 swallows and returns 0
             traceback.print_exc()
-            array = array_global[0] if len(array_global) == 1 else np.concatenate(array_global)
-            p = array[:, 4].copy()
+            array = np.asarray(array_global[0] if len(array_global) == 1 else np.concatenate(array_global), np.float64)
+            p = array[:, 4].copy() if array.ndim == 2 and array.shape[1] >= 5 else np.zeros(array.shape[0] if array.ndim else 0)
         p_rankwise, init = [], 0
         own = len(array_global) > 1                         # slices of the module's persistent output buffer: handed out as copies
         for length in len_rankwise:                         # :501-507

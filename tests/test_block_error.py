@@ -82,3 +82,21 @@ def test_gpu_block_error_needs_a_solve_and_skips_nan_differences():
         assert g32[100, 100, 2] != 0
         m1 = sur.block_error(g32[..., :3], lab)
         assert np.isnan(m1["mean_err"]) and np.isnan(m1["normVal"]) and m1["n"] < m0["n"]
+
+
+@pytest.mark.gpu
+def test_gpu_block_error_refuses_a_solve_that_ran_on_the_ring():
+    """the asynchronous ring solves on its slots' workspaces, so the handle's own workspace would hold an OLDER
+    network output -- PSM_ERR_STATE instead of metrics of stale data; a synchronous solve afterwards makes it valid again."""
+    grid, model = cases.build("deltas_256x256")
+    g32 = grid.astype(np.float32)
+    with GridSurrogate(model, 256, 256) as sur:
+        sur.solve(g32[..., :3], out_scale=[model.out_scale])
+        m0 = sur.block_error(g32[..., :3], g32[..., 3])
+        other = (g32[..., :3] * np.float32(0.5)).copy(); other[..., 2] = g32[..., 2]
+        sur.wait(sur.submit(other, out_scale=[model.out_scale]))
+        with pytest.raises(Exception, match="ring"):
+            sur.block_error(g32[..., :3], g32[..., 3])
+        sur.solve(g32[..., :3], out_scale=[model.out_scale])
+        m1 = sur.block_error(g32[..., :3], g32[..., 3])
+        assert m0["mean_sq_err"] == m1["mean_sq_err"]

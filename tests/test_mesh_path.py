@@ -213,3 +213,27 @@ def test_gpu_integration_of_gradp():
         p2 = sur.integrate_gradp(ic["gradP"])
         ref2 = orc.integrate_gradp(ic["gradP"], sd2, dx, dy, cy, cx)
         assert np.abs(p2 - ref2).max() <= 1e-4 * np.abs(ref2).max()
+
+
+@pytest.mark.gpu
+def test_solve_after_the_plan_was_dropped_is_a_state_error(mesh_case):
+    """psm_set_geometry's tables belong to one plan.  A later psm_plan_grid with another size (or a psm_set_*
+    call that drops the plan) must make psm_solve fail with PSM_ERR_STATE instead of launching on freed buffers; calling
+    init_func again restores the path."""
+    import ctypes as C
+    array, top, obst, model, maxs, geo, gold = mesh_case
+    sm = SolverModule(model, maxs)
+    sm.init_func(array, top, obst, 0)
+    ref = sm.py_func(array, 0)
+    sur = sm._sur
+    assert sur.lib.psm_plan_grid(sur.h, sm.tables.ny + 96, sm.tables.nx) == 0           # another grid: stale mesh tables
+    cells = np.ascontiguousarray(array, np.float64)
+    out = np.empty(len(array), np.float64)
+    rc = sur.lib.psm_solve(sur.h, cells.ctypes.data_as(C.POINTER(C.c_double)), len(array), 0, out.ctypes.data_as(C.POINTER(C.c_double)))
+    assert rc == -2
+    grid = np.empty((sm.tables.ny, sm.tables.nx), np.float64)
+    rc = sur.lib.psm_mesh_to_grid(sur.h, cells[:, 4].copy().ctypes.data_as(C.POINTER(C.c_double)), len(array), 1, 0, grid.ctypes.data_as(C.POINTER(C.c_double)))
+    assert rc == -2
+    sm2 = SolverModule(model, maxs)                     # a fresh handle is unaffected, and gives the same pressures
+    sm2.init_func(array, top, obst, 0)
+    np.testing.assert_array_equal(sm2.py_func(array, 0), ref)
