@@ -37,6 +37,10 @@ struct PsmConvArgs {
   int H0, W0;                  // resolution of in0
   int cout, relu;
   int64_t in0_case, in1_case, out_case;   // per-case strides (elements)
+  // row pitches in pixels (in0 at ITS resolution).  Finished bf16 activations live in zero-haloed tensors (psm_unet_api.cpp,
+  // act_layout): the pointers above address pixel (0, 0) of case 0, a row is P pixels apart, a case *_case elements.  Dense
+  // tensors (the raw image, float32 activations, split-K slabs): P = the tensor's width.
+  int P0, P1, PO;
 };
 
 struct PsmHeadArgs {           // 1x1 convolution on a thin activation (c_in <= 64), linear
@@ -76,6 +80,7 @@ struct PsmPairArgs {
   int H, W, c0, c1;
   int tiles_x, tiles_y, n_cases;
   int64_t in0_case, in1_case, out_case;   // per-case strides (elements)
+  int P0, P1, PO;              // row pitches in pixels of in0 (at its own resolution), in1, out / mid_out (see PsmConvArgs)
 };
 hipError_t psm_unet_pair_read_stamps(unsigned long long* out);   // [64]: 3 workgroups x 16 stamps; zeros unless built with -DPSM_STAMPS
 bool psm_pair_kernel_available(int kind, int cm, int c0, int c1, bool head);   // shared by the planner and the launcher

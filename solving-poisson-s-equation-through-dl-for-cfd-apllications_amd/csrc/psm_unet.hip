@@ -126,22 +126,22 @@ __device__ __forceinline__ f32x4 fetch4(const PsmConvArgs& a, const float* in0, 
   const int ch0 = min(ch, a.c0 - 4);
   f32x4 v;
   if (SRC == PSM_SRC_SAME) {
-    v = read4<KSM>(in0 + ((int64_t)yc * a.W0 + xc) * a.c0 + ch0, a.ks0, a.slab0, a.pbias0, ch0);
+    v = read4<KSM>(in0 + ((int64_t)yc * a.P0 + xc) * a.c0 + ch0, a.ks0, a.slab0, a.pbias0, ch0);
   } else if (SRC == PSM_SRC_UPSAMPLE) {
-    v = read4<KSM>(in0 + ((int64_t)(yc >> 1) * a.W0 + (xc >> 1)) * a.c0 + ch0, a.ks0, a.slab0, a.pbias0, ch0);
+    v = read4<KSM>(in0 + ((int64_t)(yc >> 1) * a.P0 + (xc >> 1)) * a.c0 + ch0, a.ks0, a.slab0, a.pbias0, ch0);
   } else {
-    const float* p = in0 + ((int64_t)(2 * yc) * a.W0 + 2 * xc) * a.c0 + ch0;
+    const float* p = in0 + ((int64_t)(2 * yc) * a.P0 + 2 * xc) * a.c0 + ch0;
     const f32x4 q0 = read4<KSM>(p, a.ks0, a.slab0, a.pbias0, ch0);
     const f32x4 q1 = read4<KSM>(p + a.c0, a.ks0, a.slab0, a.pbias0, ch0);
-    const f32x4 q2 = read4<KSM>(p + (int64_t)a.W0 * a.c0, a.ks0, a.slab0, a.pbias0, ch0);
-    const f32x4 q3 = read4<KSM>(p + (int64_t)a.W0 * a.c0 + a.c0, a.ks0, a.slab0, a.pbias0, ch0);
+    const f32x4 q2 = read4<KSM>(p + (int64_t)a.P0 * a.c0, a.ks0, a.slab0, a.pbias0, ch0);
+    const f32x4 q3 = read4<KSM>(p + (int64_t)a.P0 * a.c0 + a.c0, a.ks0, a.slab0, a.pbias0, ch0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaxf(q0[j], q1[j]), fmaxf(q2[j], q3[j]));
   }
   bool ok = inside && first;
   if (SRC == PSM_SRC_UPSAMPLE) {                      // the only source with a skip input concatenated behind it
     const int c = min(max(ch - a.c0, 0), a.c1 - 4);
-    const f32x4 s = read4<KSM>(in1 + ((int64_t)yc * a.W + xc) * a.c1 + c, a.ks1, a.slab1, a.pbias1, c);
+    const f32x4 s = read4<KSM>(in1 + ((int64_t)yc * a.P1 + xc) * a.c1 + c, a.ks1, a.slab1, a.pbias1, c);
     const bool second = !first && (ch - a.c0) < a.c1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = first ? v[j] : s[j];
@@ -156,7 +156,7 @@ __device__ __forceinline__ f32x4 fetch4(const PsmConvArgs& a, const float* in0, 
 __device__ __forceinline__ f32x4 fetch4_stem(const PsmConvArgs& a, const float* in0, int y, int x, int ch) {
   const bool inside = (y >= 0) && (y < a.H) && (x >= 0) && (x < a.W);
   const int yc = min(max(y, 0), a.H - 1), xc = min(max(x, 0), a.W - 1);
-  const float* p = in0 + ((int64_t)yc * a.W0 + xc) * a.c0;
+  const float* p = in0 + ((int64_t)yc * a.P0 + xc) * a.c0;
   f32x4 v;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -180,10 +180,10 @@ __device__ __forceinline__ PsmFetchPos prepare_fetch(const PsmConvArgs& a, int y
   PsmFetchPos f;
   f.ok = (y >= 0) && (y < a.H) && (x >= 0) && (x < a.W);
   const int yc = min(max(y, 0), a.H - 1), xc = min(max(x, 0), a.W - 1);
-  if (SRC == PSM_SRC_UPSAMPLE) f.off0 = ((yc >> 1) * a.W0 + (xc >> 1)) * a.c0;
-  else if (SRC == PSM_SRC_MAXPOOL) f.off0 = ((2 * yc) * a.W0 + 2 * xc) * a.c0;
-  else f.off0 = (yc * a.W0 + xc) * a.c0;
-  f.off1 = (yc * a.W + xc) * a.c1;
+  if (SRC == PSM_SRC_UPSAMPLE) f.off0 = ((yc >> 1) * a.P0 + (xc >> 1)) * a.c0;
+  else if (SRC == PSM_SRC_MAXPOOL) f.off0 = ((2 * yc) * a.P0 + 2 * xc) * a.c0;
+  else f.off0 = (yc * a.P0 + xc) * a.c0;
+  f.off1 = (yc * a.P1 + xc) * a.c1;
   return f;
 }
 
@@ -197,8 +197,8 @@ __device__ __forceinline__ f32x4 fetch4_prepared(const PsmConvArgs& a, const flo
     const float* p = in0 + f.off0 + ch;
     const f32x4 q0 = read4<KSM>(p, a.ks0, a.slab0, a.pbias0, ch);
     const f32x4 q1 = read4<KSM>(p + a.c0, a.ks0, a.slab0, a.pbias0, ch);
-    const f32x4 q2 = read4<KSM>(p + a.W0 * a.c0, a.ks0, a.slab0, a.pbias0, ch);
-    const f32x4 q3 = read4<KSM>(p + a.W0 * a.c0 + a.c0, a.ks0, a.slab0, a.pbias0, ch);
+    const f32x4 q2 = read4<KSM>(p + a.P0 * a.c0, a.ks0, a.slab0, a.pbias0, ch);
+    const f32x4 q3 = read4<KSM>(p + a.P0 * a.c0 + a.c0, a.ks0, a.slab0, a.pbias0, ch);
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaxf(q0[j], q1[j]), fmaxf(q2[j], q3[j]));
   } else if (SRC == PSM_SRC_UPSAMPLE) {
@@ -363,8 +363,8 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
           const unsigned short* p = h0 + fp[u].off0 + chc;
           xr[u][0] = *reinterpret_cast<const f32x4*>(p);
           xr[u][1] = *reinterpret_cast<const f32x4*>(p + a.c0);
-          xr[u][2] = *reinterpret_cast<const f32x4*>(p + a.W0 * a.c0);
-          xr[u][3] = *reinterpret_cast<const f32x4*>(p + a.W0 * a.c0 + a.c0);
+          xr[u][2] = *reinterpret_cast<const f32x4*>(p + a.P0 * a.c0);
+          xr[u][3] = *reinterpret_cast<const f32x4*>(p + a.P0 * a.c0 + a.c0);
         } else if constexpr (SRCP == PSM_SRC_UPSAMPLE) {
           const unsigned short* p = from0 ? h0 + fp[u].off0 + chc : h1 + fp[u].off1 + (chc - a.c0);
           xr[u][0] = *reinterpret_cast<const f32x4*>(p);
@@ -383,8 +383,8 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
         const float* p = in0 + fp[u].off0 + chc;
         issue4<KSM>(p, a.ks0, a.slab0, &xr[u][0]);
         issue4<KSM>(p + a.c0, a.ks0, a.slab0, &xr[u][KSM]);
-        issue4<KSM>(p + a.W0 * a.c0, a.ks0, a.slab0, &xr[u][2 * KSM]);
-        issue4<KSM>(p + a.W0 * a.c0 + a.c0, a.ks0, a.slab0, &xr[u][3 * KSM]);
+        issue4<KSM>(p + a.P0 * a.c0, a.ks0, a.slab0, &xr[u][2 * KSM]);
+        issue4<KSM>(p + a.P0 * a.c0 + a.c0, a.ks0, a.slab0, &xr[u][3 * KSM]);
         if (KSM > 1) xb[u] = *reinterpret_cast<const f32x4*>(a.pbias0 + chc);
       } else if constexpr (SRCP == PSM_SRC_UPSAMPLE) {
         const float* p = from0 ? in0 + fp[u].off0 + chc : in1 + fp[u].off1 + (chc - a.c0);
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
         const int x = x0 + 4 * kq + r;
         float v = acc[m][n][r] + b;
         if (fin && a.relu) v = fmaxf(v, 0.f);
-        store_act(out, ((int64_t)y * a.W + x) * a.cout + co, v, y < a.H && x < a.W && co < a.cout, a.out_bf != 0, co);
+        store_act(out, ((int64_t)y * a.PO + x) * a.cout + co, v, y < a.H && x < a.W && co < a.cout, a.out_bf != 0, co);
         acc[m][n][r] = v;
       }
     }
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256) void psm_conv_stem_kernel(PsmConvArgs a) {
     const int r = pos / (TW + 2), c = pos - r * (TW + 2);
     const int y = y0 - 1 + r, x = x0 - 1 + c;
     const bool ok = y >= 0 && y < a.H && x >= 0 && x < a.W;
-    const float t = in0[((int64_t)min(max(y, 0), a.H - 1) * a.W + min(max(x, 0), a.W - 1)) * c0 + ci];
+    const float t = in0[((int64_t)min(max(y, 0), a.H - 1) * a.P0 + min(max(x, 0), a.W - 1)) * c0 + ci];
     ev[u] = ok ? t : 0.f;
   }
   f32x4 bw[KG];
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(256) void psm_conv_stem_kernel(PsmConvArgs a) {
       const int x = x0 + 4 * kq + r;
       float v = acc[m][r] + bias;
       if (a.relu) v = fmaxf(v, 0.f);
-      store_act(out, ((int64_t)y * a.W + x) * a.cout + co, v, y < a.H && x < a.W && co < a.cout, a.out_bf != 0, co);
+      store_act(out, ((int64_t)y * a.PO + x) * a.cout + co, v, y < a.H && x < a.W && co < a.cout, a.out_bf != 0, co);
     }
   }
 }

@@ -39,6 +39,11 @@ struct Conv {
   float* d_w1 = nullptr;       // head: [cin][cout]
   float* d_out = nullptr;      // [ksplit][max_cases][H][W][cout] (ksplit > 1: partial-sum slabs, finished by the consumer's loader)
   int64_t slab = 0;
+  // layout of d_out (act_layout): finished bf16 activations are zero-haloed, everything else is dense
+  bool padded = false;
+  int P = 0;                   // row pitch (pixels)
+  int64_t case_elems = 0;      // elements per case
+  int64_t origin = 0;          // element offset of pixel (0, 0) of case 0 within d_out
 };
 thread_local std::string g_err;
 }  // namespace
@@ -66,6 +71,27 @@ int fail(psm_unet* u, int code, const std::string& m) { if (u) u->err = m; else 
   do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail((u), PSM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 
 void free_dev(void* p) { if (p) (void)psm_dev_free(p); }
+
+// Finished bf16 activations (bf16 mode) live in ZERO-HALOED tensors: [case][ACT_PADT + H + ACT_PADB][ACT_PADL + W + ACT_PADR][C],
+// the halo written once (memset at plan time) and never again -- every producer masks its stores to the image.  A consumer
+// that stages whole tiles (the fused level pairs, psm_unet_pair.hip) then reads its halo -- the 'same' padding, the overhang of
+// the last tile, a max-pool's doubled extent -- straight from memory: no clamps, no selects, and the tile can be moved by
+// LDS-DMA, which cannot write zeros of its own.  The margins cover: 2 pixels of halo left / top at the tensor's own resolution
+// and 4 when it is read through a 2x2 max-pool; right / bottom the last 30 x 14 tile's overhang + halo (32 / 16), doubled
+// through a max-pool (64 / 32).  288 GB of HBM: the 20-45 % of extra footprint are never traffic.
+constexpr int ACT_PADL = 4, ACT_PADT = 4, ACT_PADR = 64, ACT_PADB = 32;
+void act_layout(Conv& c, int H, int W, bool padded) {
+  c.padded = padded;
+  if (padded) {
+    c.P = ACT_PADL + W + ACT_PADR;
+    c.case_elems = (int64_t)(ACT_PADT + H + ACT_PADB) * c.P * c.cout;
+    c.origin = ((int64_t)ACT_PADT * c.P + ACT_PADL) * c.cout;
+  } else { c.P = W; c.case_elems = (int64_t)H * W * c.cout; c.origin = 0; }
+}
+// pixel (0, 0) of case 0 of a convolution's output, as the kernels' float pointer (bf16 tensors are addressed in 2-byte elements)
+float* act_ptr(const Conv& c) {
+  return c.padded ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(c.d_out) + c.origin) : c.d_out;
+}
 
 // MFMA operand order: wpack[cog][chunk g][tap][ct][lane][j] = W[tap][16g + 4*(lane>>4) + j][16*(cog*nct + ct) + (lane&15)]
 std::vector<float> pack_conv3x3(const Conv& c) {
@@ -281,22 +307,21 @@ int forward(psm_unet* u, const float* d_grid, int n, float* d_field, hipStream_t
     if (psm_launch_probe) psm_launch_probe->tag = (int)i;
     Conv& c = u->convs[i];
     const int H = u->ny >> c.level, W = u->nx >> c.level;
-    float* out = (i + 1 == u->convs.size()) ? d_field : c.d_out;
+    float* out = (i + 1 == u->convs.size()) ? d_field : act_ptr(c);
     if (c.pair == 2) continue;                                // computed by the pair's first convolution's launch
     if (c.pair == 1) {
       const Conv& B = u->convs[i + 1];
       PsmPairArgs p{};
       p.wA = c.d_wpa; p.wB = c.d_wpb; p.biasA = c.d_b; p.biasB = B.d_b;
       p.H = H; p.W = W; p.tiles_x = (W + PSM_PAIR_TX - 1) / PSM_PAIR_TX; p.tiles_y = (H + PSM_PAIR_TY - 1) / PSM_PAIR_TY; p.n_cases = n;
-      p.out_case = (int64_t)H * W * c.cout;
-      p.out = (B.fuse_head && !u->keep_act) ? nullptr : reinterpret_cast<unsigned short*>(B.d_out);
-      p.mid_out = u->keep_act ? reinterpret_cast<unsigned short*>(c.d_out) : nullptr;
-      if (c.pair_kind == PSM_PAIR_STEM) { p.in0 = d_grid; p.c0 = c.cin; p.in0_case = (int64_t)H * W * c.cin; }
+      p.out_case = B.case_elems; p.PO = B.P;                // conv A's kept activation (mid_out) has the same layout
+      p.out = (B.fuse_head && !u->keep_act) ? nullptr : reinterpret_cast<unsigned short*>(act_ptr(B));
+      p.mid_out = u->keep_act ? reinterpret_cast<unsigned short*>(act_ptr(c)) : nullptr;
+      if (c.pair_kind == PSM_PAIR_STEM) { p.in0 = d_grid; p.c0 = c.cin; p.in0_case = (int64_t)H * W * c.cin; p.P0 = W; }
       else {
         const Conv& pv = u->convs[i - 1];
-        p.in0 = pv.d_out; p.c0 = pv.cout;
-        if (c.pair_kind == PSM_PAIR_POOL) p.in0_case = (int64_t)4 * H * W * pv.cout;
-        else { p.in0_case = (int64_t)(H / 2) * (W / 2) * pv.cout; p.in1 = u->convs[c.skip].d_out; p.c1 = u->convs[c.skip].cout; p.in1_case = (int64_t)H * W * p.c1; }
+        p.in0 = act_ptr(pv); p.c0 = pv.cout; p.in0_case = pv.case_elems; p.P0 = pv.P;
+        if (c.pair_kind == PSM_PAIR_UPCAT) { const Conv& sk = u->convs[c.skip]; p.in1 = act_ptr(sk); p.c1 = sk.cout; p.in1_case = sk.case_elems; p.P1 = sk.P; }
       }
       if (B.fuse_head) {
         const Conv& hd = u->convs[i + 2];
@@ -307,26 +332,26 @@ int forward(psm_unet* u, const float* d_grid, int n, float* d_field, hipStream_t
     }
     if (c.k == 1) {
       if (u->convs[i - 1].fuse_head) continue;               // computed in the previous layer's epilogue
-      PsmHeadArgs ha{u->convs[i - 1].d_out, c.d_w1, c.d_b, out, (int64_t)n * H * W, c.cin, c.cout};
+      PsmHeadArgs ha{u->convs[i - 1].d_out, c.d_w1, c.d_b, out, (int64_t)n * H * W, c.cin, c.cout};     // its input is float32 (dense) by the planner's rule
       UCHK(u, psm_launch_head1x1(ha, st));
       continue;
     }
     PsmConvArgs a{};
     a.wpack = c.d_w; a.bias = c.d_b; a.out = out; a.n_chunks = c.n_chunks; a.H = H; a.W = W; a.cout = c.cout; a.relu = c.relu;
-    a.out_case = (int64_t)H * W * c.cout;
+    a.out_case = (i + 1 == u->convs.size()) ? (int64_t)H * W * c.cout : c.case_elems;
+    a.PO = (i + 1 == u->convs.size()) ? W : c.P;
     a.ksplit = c.ksplit; a.out_slab = c.slab; a.ks0 = 1; a.ks1 = 1; a.bf16 = u->bf16;
     a.in_bf = c.in_bf ? 1 : 0; a.out_bf = c.out_bf ? 1 : 0; a.x6 = c.x6 ? 1 : 0;
-    if (c.src == 0) { a.in0 = d_grid; a.c0 = c.cin; a.mode0 = PSM_SRC_SAME; a.H0 = H; a.W0 = W; }
+    if (c.src == 0) { a.in0 = d_grid; a.c0 = c.cin; a.mode0 = PSM_SRC_SAME; a.H0 = H; a.W0 = W; a.P0 = W; a.in0_case = (int64_t)H * W * c.cin; }
     else {
       const Conv& pv = u->convs[i - 1];
-      a.in0 = pv.d_out; a.c0 = pv.cout; a.ks0 = pv.ksplit; a.slab0 = pv.slab; a.pbias0 = pv.d_b;
+      a.in0 = act_ptr(pv); a.c0 = pv.cout; a.ks0 = pv.ksplit; a.slab0 = pv.slab; a.pbias0 = pv.d_b; a.P0 = pv.P; a.in0_case = pv.case_elems;
       if (c.src == 1) { a.mode0 = PSM_SRC_SAME; a.H0 = H; a.W0 = W; }
       else if (c.src == 2) { a.mode0 = PSM_SRC_MAXPOOL; a.H0 = 2 * H; a.W0 = 2 * W; }
-      else { a.mode0 = PSM_SRC_UPSAMPLE; a.H0 = H / 2; a.W0 = W / 2; a.in1 = u->convs[c.skip].d_out; a.c1 = u->convs[c.skip].cout;
-             a.ks1 = u->convs[c.skip].ksplit; a.slab1 = u->convs[c.skip].slab; a.pbias1 = u->convs[c.skip].d_b;
-             a.in1_case = (int64_t)H * W * a.c1; }
+      else { const Conv& sk = u->convs[c.skip];
+             a.mode0 = PSM_SRC_UPSAMPLE; a.H0 = H / 2; a.W0 = W / 2; a.in1 = act_ptr(sk); a.c1 = sk.cout;
+             a.ks1 = sk.ksplit; a.slab1 = sk.slab; a.pbias1 = sk.d_b; a.in1_case = sk.case_elems; a.P1 = sk.P; }
     }
-    a.in0_case = (int64_t)a.H0 * a.W0 * a.c0;
     if (c.fuse_head) {
       const Conv& hd = u->convs[i + 1];
       a.head_w = hd.d_w1; a.head_b = hd.d_b; a.head_out = d_field; a.head_cout = hd.cout; a.head_case = (int64_t)H * W * hd.cout;
@@ -508,7 +533,14 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
       if (rc) return rc;
       free_dev(c.d_out); c.d_out = nullptr;
       c.slab = (int64_t)max_cases * H * W * c.cout;
-      UCHK(u, psm_dev_malloc((void**)&c.d_out, (size_t)c.ksplit * c.slab * sizeof(float) + 64));
+      // bf16 tensors (finished activations of bf16 mode; a fused pair always writes bf16) get the zero halo
+      act_layout(c, H, W, u->bf16 && c.k == 3 && (c.out_bf || c.pair != 0));
+      if (c.padded) {
+        const size_t bytes = (size_t)max_cases * c.case_elems * sizeof(uint16_t) + 4096;      // + slack: a tile's last LDS-DMA piece may start past its last row
+        UCHK(u, psm_dev_malloc((void**)&c.d_out, bytes));
+        UCHK(u, hipMemsetAsync(c.d_out, 0, bytes, u->stream));
+        UCHK(u, hipStreamSynchronize(u->stream));
+      } else UCHK(u, psm_dev_malloc((void**)&c.d_out, (size_t)c.ksplit * c.slab * sizeof(float) + 64));
       continue;
     }
     const bool stem_layer = c.k == 3 && c.src == 0 && 9 * c.cin <= 64 && c.cout <= 16 && getenv("PSM_UNET_NO_STEM") == nullptr;
@@ -602,10 +634,16 @@ int psm_unet_read_activation(psm_unet* u, int32_t idx, float* dst, int64_t dst_f
   if (dst_floats < n) return fail(u, PSM_ERR_ARG, "destination too small");
   UCHK(u, hipSetDevice(u->device));
   UCHK(u, hipStreamSynchronize(u->stream));
-  if (c.out_bf || c.pair != 0) {  // stored as bf16 (finished activations in bf16 mode; a pair kernel always writes bf16): widen
-    std::vector<uint16_t> hb((size_t)n);
-    UCHK(u, psm_copy_d2h(hb.data(), c.d_out, (size_t)n * sizeof(uint16_t)));
-    for (int64_t q = 0; q < n; ++q) { const uint32_t w = (uint32_t)hb[q] << 16; std::memcpy(&dst[q], &w, 4); }
+  if (c.padded) {                 // stored as bf16 in a zero-haloed tensor (act_layout): take the image rows, widen
+    const int H = u->ny >> c.level, W = u->nx >> c.level;
+    std::vector<uint16_t> hb((size_t)u->last_cases * c.case_elems);
+    UCHK(u, psm_copy_d2h(hb.data(), c.d_out, hb.size() * sizeof(uint16_t)));
+    for (int cs = 0; cs < u->last_cases; ++cs)
+      for (int y = 0; y < H; ++y) {
+        const uint16_t* row = hb.data() + (size_t)cs * c.case_elems + c.origin + (size_t)y * c.P * c.cout;
+        float* d = dst + ((size_t)cs * H + y) * W * c.cout;
+        for (int q = 0; q < W * c.cout; ++q) { const uint32_t w = (uint32_t)row[q] << 16; std::memcpy(&d[q], &w, 4); }
+      }
     return PSM_OK;
   }
   UCHK(u, psm_copy_d2h(dst, c.d_out, n * sizeof(float)));

@@ -126,7 +126,7 @@ struct Stage {
   // J0, JN: the row iterations of this call (registers: a max-pool chunk is staged in two halves); SIDE: with the side block
   template <int J0 = 0, int JN = RW, bool SIDE = (NSIDE > 0)>
   static __device__ __forceinline__ void issue(f32x4 (&v)[JN * KM + (SIDE ? 1 : 0)][NQ], unsigned& ok, const unsigned short* src, int cpx, int cb,
-                                               int Hs, int Ws, int ys0, int xs0, int wave, int lane, int tid) {
+                                               int Hs, int Ws, int Ps, int ys0, int xs0, int wave, int lane, int tid) {
     constexpr int NV = JN * KM + (SIDE ? 1 : 0);
     ok = 0;
 #if defined(PSM_PAIR_EXP) && (PSM_PAIR_EXP & 2)
@@ -144,7 +144,7 @@ struct Stage {
     }
 #endif
     const int M = NQ == 4 ? 2 : 1;                           // source pixels per tile pixel and direction
-    const int64_t row_bytes = (int64_t)M * Ws * cpx * 2;     // one source row
+    const int64_t row_bytes = (int64_t)Ps * cpx * 2;         // one source row (Ps: the source tensor's pitch in ITS pixels)
     unsigned xoff[KM];
     unsigned xok = 0;
 #pragma unroll
@@ -191,13 +191,13 @@ struct Stage {
   // The first piece clears ok.
   template <int I>
   static __device__ __forceinline__ void issue_piece(f32x4 (&v)[NP][NQ], unsigned& ok, const unsigned short* src, int cpx, int cb,
-                                                     int Hs, int Ws, int ys0, int xs0, int wave, int lane, int tid) {
+                                                     int Hs, int Ws, int Ps, int ys0, int xs0, int wave, int lane, int tid) {
     static_assert(NQ == 1 && I >= 0 && I < NP, "same-resolution pieces of a whole tile");
     if (I == 0) ok = 0;
 #if defined(PSM_PAIR_EXP) && (PSM_PAIR_EXP & 2)
     return;
 #endif
-    const int64_t row_bytes = (int64_t)Ws * cpx * 2;
+    const int64_t row_bytes = (int64_t)Ps * cpx * 2;
     if constexpr (I < RW * KM) {
       constexpr int jj = I / KM, k = I % KM;
       const int c = PPI * k + lane / G, g = lane % G, x = xs0 + c;
@@ -385,7 +385,7 @@ __device__ __forceinline__ void mid_epilogue(const PsmPairArgs& a, char* mid, in
       if (!interior) { h[0] = ok ? h[0] : 0u; h[1] = ok ? h[1] : 0u; }
       *reinterpret_cast<u32x2*>(base[nt] + m * (NT == 1 ? P16 * 32 : P32 * 64)) = h;
       if (KEEP && ok && r0 + m >= 1 && r0 + m <= TY && col >= 1 && col <= TX)
-        *reinterpret_cast<u32x2*>(a.mid_out + (int64_t)cs * a.out_case + ((int64_t)y * a.W + x) * (16 * NT) + 16 * nt + 4 * kq) = h;
+        *reinterpret_cast<u32x2*>(a.mid_out + (int64_t)cs * a.out_case + ((int64_t)y * a.PO + x) * (16 * NT) + 16 * nt + 4 * kq) = h;
     }
   }
 }
@@ -402,14 +402,14 @@ __device__ __forceinline__ void out_epilogue(const PsmPairArgs& a, int cs, int y
   const int col = 16 * xh + px, x = x0 + col;
   const bool xok = col < TX && x < a.W;
   if constexpr (STORE) {
-    const unsigned loff = (unsigned)((((y0 + r0) * a.W + x) * (16 * NT) + 4 * kq) * 2);       // bytes within the case
+    const unsigned loff = (unsigned)((((y0 + r0) * a.PO + x) * (16 * NT) + 4 * kq) * 2);       // bytes within the case
     char* obase = reinterpret_cast<char*>(a.out + (int64_t)cs * a.out_case);
 #pragma unroll
     for (int m = 0; m < R; ++m) {
       const bool ok = xok && y0 + r0 + m < a.H;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
-        if (ok) *reinterpret_cast<u32x2*>(obase + loff + (unsigned)(m * a.W * (16 * NT) * 2) + nt * 32) = pack4_relu(acc[m][nt]);
+        if (ok) *reinterpret_cast<u32x2*>(obase + loff + (unsigned)(m * a.PO * (16 * NT) * 2) + nt * 32) = pack4_relu(acc[m][nt]);
     }
   }
   if constexpr (HEAD) {
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void psm_pair_stem16_kernel(PsmPairArgs a) 
     for (int j = 0; j < RW; ++j) {
       const int y = t.y0 - 2 + min(wave + 4 * j, IH - 1);
       const bool yok = y >= 0 && y < a.H;
-      const float* rowp = in0 + (int64_t)min(max(y, 0), a.H - 1) * a.W * C0;
+      const float* rowp = in0 + (int64_t)min(max(y, 0), a.H - 1) * a.P0 * C0;
 #pragma unroll
       for (int k = 0; k < KR; ++k) {
         ev[j][k] = rowp[xo[k]];                         // raw: the zero padding is applied when the tile is written, not here
@@ -621,9 +621,9 @@ __global__ __launch_bounds__(256, 2) void psm_pair_up16_kernel(PsmPairArgs a) {
   f32x4 vlo[StLow::NP][1], v16[St16::NP][1];
   unsigned oklo, ok16;
   auto issue = [&](const TilePos& t) {
-    StLow::issue(vlo, oklo, reinterpret_cast<const unsigned short*>(a.in0) + (int64_t)t.cs * a.in0_case, 32, 0, a.H / 2, a.W / 2,
+    StLow::issue(vlo, oklo, reinterpret_cast<const unsigned short*>(a.in0) + (int64_t)t.cs * a.in0_case, 32, 0, a.H / 2, a.W / 2, a.P0,
                  (t.y0 - 2) / 2, (t.x0 - 2) / 2, wave, lane, tid);                     // tile origins are even: exact, also for -2
-    St16::issue(v16, ok16, reinterpret_cast<const unsigned short*>(a.in1) + (int64_t)t.cs * a.in1_case, 16, 0, a.H, a.W,
+    St16::issue(v16, ok16, reinterpret_cast<const unsigned short*>(a.in1) + (int64_t)t.cs * a.in1_case, 16, 0, a.H, a.W, a.P1,
                 t.y0 - 2, t.x0 - 2, wave, lane, tid);
   };
   int it = 0, tile = tile_of(0, total);
@@ -648,8 +648,8 @@ __global__ __launch_bounds__(256, 2) void psm_pair_up16_kernel(PsmPairArgs a) {
     const unsigned short* nlo = reinterpret_cast<const unsigned short*>(a.in0) + (int64_t)nxt.cs * a.in0_case;
     const unsigned short* n16 = reinterpret_cast<const unsigned short*>(a.in1) + (int64_t)nxt.cs * a.in1_case;
     auto piece = [&](int p) {
-#define LO_PIECE(I) StLow::template issue_piece<I>(vlo, oklo, nlo, 32, 0, a.H / 2, a.W / 2, (nxt.y0 - 2) / 2, (nxt.x0 - 2) / 2, wave, lane, tid)
-#define SK_PIECE(I) St16::template issue_piece<I>(v16, ok16, n16, 16, 0, a.H, a.W, nxt.y0 - 2, nxt.x0 - 2, wave, lane, tid)
+#define LO_PIECE(I) StLow::template issue_piece<I>(vlo, oklo, nlo, 32, 0, a.H / 2, a.W / 2, a.P0, (nxt.y0 - 2) / 2, (nxt.x0 - 2) / 2, wave, lane, tid)
+#define SK_PIECE(I) St16::template issue_piece<I>(v16, ok16, n16, 16, 0, a.H, a.W, a.P1, nxt.y0 - 2, nxt.x0 - 2, wave, lane, tid)
       static_assert(StLow::NP == 4 && St16::NP == 6, "ten pieces over five steps");
       if (p == 0) LO_PIECE(0); else if (p == 1) LO_PIECE(1); else if (p == 2) LO_PIECE(2); else if (p == 3) LO_PIECE(3);
       else if (p == 4) SK_PIECE(0); else if (p == 5) SK_PIECE(1); else if (p == 6) SK_PIECE(2); else if (p == 7) SK_PIECE(3);
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(256, 2) void psm_pair32_kernel(PsmPairArgs a) {
       const Chunk first = chunk_at(0);
       issue_w(a.wA + frag_of(first) * 64, frags_in(first.form));
       if constexpr (KIND == 1)
-        if (first.form == CK_UP32) StLow::issue(pf, pok, in0, a.c0, first.cb, a.H / 2, a.W / 2, (y0 - 2) / 2, (x0 - 2) / 2, wave, lz, tz);
+        if (first.form == CK_UP32) StLow::issue(pf, pok, in0, a.c0, first.cb, a.H / 2, a.W / 2, a.P0, (y0 - 2) / 2, (x0 - 2) / 2, wave, lz, tz);
     }
     // one chunk: stage it (the upsample source: write what was prefetched), request the next chunk's prefetch, MFMAs.  The
     // form is a compile-time tag and every form runs in its own loop below: with one loop over a run-time form the
@@ -804,23 +804,23 @@ __global__ __launch_bounds__(256, 2) void psm_pair32_kernel(PsmPairArgs a) {
       if constexpr (FORM == CK_UP32) StLow::write(tile, pf, pok, interior, wave, lz, tz);
       else if constexpr (FORM == CK_SAME32) {
         f32x4 v[St32::NP][1]; unsigned ok;
-        St32::issue(v, ok, in1, a.c1, cb, a.H, a.W, y0 - 2, x0 - 2, wave, lz, tz);
+        St32::issue(v, ok, in1, a.c1, cb, a.H, a.W, a.P1, y0 - 2, x0 - 2, wave, lz, tz);
         St32::write(tile, v, ok, interior, wave, lz, tz);
       } else if constexpr (FORM == CK_SAME16) {
         f32x4 v[St16::NP][1]; unsigned ok;
-        St16::issue(v, ok, in1, a.c1, cb, a.H, a.W, y0 - 2, x0 - 2, wave, lz, tz);
+        St16::issue(v, ok, in1, a.c1, cb, a.H, a.W, a.P1, y0 - 2, x0 - 2, wave, lz, tz);
         St16::write(tile, v, ok, interior, wave, lz, tz);
       } else if constexpr (FORM == CK_POOL32) {              // four source pixels per piece: in two halves (registers)
         constexpr int JA = (StPool32::RW + 1) / 2, JB = StPool32::RW - JA;
         { f32x4 v[JA * StPool32::KM][4]; unsigned ok;
-          StPool32::template issue<0, JA, false>(v, ok, in0, a.c0, cb, a.H, a.W, y0 - 2, x0 - 2, wave, lz, tz);
+          StPool32::template issue<0, JA, false>(v, ok, in0, a.c0, cb, a.H, a.W, a.P0, y0 - 2, x0 - 2, wave, lz, tz);
           StPool32::template write<0, JA, false>(tile, v, ok, interior, wave, lz, tz); }
         { f32x4 v[JB * StPool32::KM + 1][4]; unsigned ok;
-          StPool32::template issue<JA, JB, true>(v, ok, in0, a.c0, cb, a.H, a.W, y0 - 2, x0 - 2, wave, lz, tz);
+          StPool32::template issue<JA, JB, true>(v, ok, in0, a.c0, cb, a.H, a.W, a.P0, y0 - 2, x0 - 2, wave, lz, tz);
           StPool32::template write<JA, JB, true>(tile, v, ok, interior, wave, lz, tz); }
       } else {
         f32x4 v[StPool16::NP][4]; unsigned ok;
-        StPool16::issue(v, ok, in0, a.c0, cb, a.H, a.W, y0 - 2, x0 - 2, wave, lz, tz);
+        StPool16::issue(v, ok, in0, a.c0, cb, a.H, a.W, a.P0, y0 - 2, x0 - 2, wave, lz, tz);
         StPool16::write(tile, v, ok, interior, wave, lz, tz);
       }
       write_w(wl, frags_in(FORM));
@@ -831,7 +831,7 @@ __global__ __launch_bounds__(256, 2) void psm_pair32_kernel(PsmPairArgs a) {
       asm volatile("" : "+v"(tz), "+v"(lz));
       if constexpr (KIND == 1)
         if (nxt.form == CK_UP32)                             // in flight during this chunk's MFMAs
-          StLow::issue(pf, pok, in0, a.c0, nxt.cb, a.H / 2, a.W / 2, (y0 - 2) / 2, (x0 - 2) / 2, wave, lz, tz);
+          StLow::issue(pf, pok, in0, a.c0, nxt.cb, a.H / 2, a.W / 2, a.P0, (y0 - 2) / 2, (x0 - 2) / 2, wave, lz, tz);
       if (nxt.form != CK_NONE) issue_w(a.wA + frag_of(nxt) * 64, frags_in(nxt.form)); else issue_w(a.wB, 18);
       if constexpr (FORM == CK_UP32) conv32_up<2, RA>(tile, rA, 16 * xh + px, kq, wget, acc);
       else if constexpr (FORM == CK_SAME32 || FORM == CK_POOL32) conv32<2, RA>(tile, rA, 16 * xh + px, kq, wget, acc);
