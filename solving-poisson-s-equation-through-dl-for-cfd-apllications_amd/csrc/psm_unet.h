@@ -68,6 +68,17 @@ hipError_t psm_launch_conv_stem(const PsmConvArgs& a, int n_cases, hipStream_t s
 #define PSM_PAIR_TX 30          // output tile of a workgroup (the mid tile is 32 x 16: two MFMA pixel tiles wide)
 #define PSM_PAIR_TY 14
 enum { PSM_PAIR_STEM = 0, PSM_PAIR_UPCAT = 1, PSM_PAIR_POOL = 2 };
+// One fused-pair tile, host-built (psm_unet_api.cpp, build_pair_tiles): the kernel reads it with ONE scalar load per tile instead of
+// two integer divisions and 64-bit address chains.  Offsets are BYTES from the tensors' (0, 0) pointers -- 32 bits: a case batch
+// of activations is < 4 GB (checked at plan time).
+struct PsmPairTile {
+  int off0;     // in0: first staged source pixel of the tile (UPCAT: low-resolution pixel ((y0 - 2) / 2, (x0 - 2) / 2); POOL: (2 y0 - 4, 2 x0 - 4))
+  int off1;     // in1: pixel (y0 - 2, x0 - 2)
+  int offo;     // out / mid_out: pixel (y0, x0)
+  int pix;      // dense pixel index cs * H * W + y0 * W + x0 (fused head's output, STEM's raw image)
+  int y0, x0, cs;
+  int flags;    // bit 0: every pixel the tile stages and computes lies inside the image
+};
 struct PsmPairArgs {
   const void* in0;             // STEM: float32 image [H][W][c0];  POOL: bf16 [2H][2W][c0];  UPCAT: bf16 [H/2][W/2][c0]
   const void* in1;             // UPCAT: bf16 skip [H][W][c1]
@@ -77,10 +88,11 @@ struct PsmPairArgs {
   unsigned short* out;         // bf16 [H][W][cm], or nullptr (head only)
   unsigned short* mid_out;     // introspection: conv A's activation, bf16 [H][W][cm], or nullptr
   const float* head_w; const float* head_b; float* head_out; int head_cout; int64_t head_case;   // fused linear 1x1 head (cm == 16)
-  int H, W, c0, c1;
+  int H, W, c0, c1, cm;        // cm: channels of the level (conv A's and conv B's output)
   int tiles_x, tiles_y, n_cases;
   int64_t in0_case, in1_case, out_case;   // per-case strides (elements)
   int P0, P1, PO;              // row pitches in pixels of in0 (at its own resolution), in1, out / mid_out (see PsmConvArgs)
+  const PsmPairTile* tiles;    // [n_cases * tiles_y * tiles_x], tile t = (cs * tiles_y + by) * tiles_x + bx
 };
 hipError_t psm_unet_pair_read_stamps(unsigned long long* out);   // [64]: 3 workgroups x 16 stamps; zeros unless built with -DPSM_STAMPS
 bool psm_pair_kernel_available(int kind, int cm, int c0, int c1, bool head);   // shared by the planner and the launcher

@@ -32,6 +32,7 @@ struct Conv {
   int pair = 0, pair_kind = 0;
   uint4* d_wpa = nullptr;       // pair leader: conv A's fragments
   uint4* d_wpb = nullptr;       // pair leader: conv B's fragments
+  PsmPairTile* d_tiles = nullptr;   // pair leader: one descriptor per tile of the planned case batch (build_pair_tiles)
   std::vector<float> W, b;     // host copies (HWIO), kept for re-packing at plan time
   bool set = false;
   float4* d_w = nullptr;
@@ -91,6 +92,35 @@ void act_layout(Conv& c, int H, int W, bool padded) {
 // pixel (0, 0) of case 0 of a convolution's output, as the kernels' float pointer (bf16 tensors are addressed in 2-byte elements)
 float* act_ptr(const Conv& c) {
   return c.padded ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(c.d_out) + c.origin) : c.d_out;
+}
+// bytes of a zero-haloed bf16 tensor for the whole case batch: the pair kernels address it with 32-bit offsets
+int64_t padded_bytes(int H, int W, int C, int cases) { return (int64_t)cases * (ACT_PADT + H + ACT_PADB) * (ACT_PADL + W + ACT_PADR) * C * 2; }
+
+// Per-tile descriptors of a fused pair (PsmPairTile, psm_unet.h) for the planned case batch: tile t = (cs * tiles_y + by) * tiles_x + bx.
+int build_pair_tiles(psm_unet* u, Conv& A, const Conv& B, const Conv* pv, const Conv* sk, int H, int W, int cases) {
+  const int tx = (W + PSM_PAIR_TX - 1) / PSM_PAIR_TX, ty = (H + PSM_PAIR_TY - 1) / PSM_PAIR_TY;
+  std::vector<PsmPairTile> t((size_t)cases * tx * ty);
+  for (int cs = 0; cs < cases; ++cs)
+    for (int by = 0; by < ty; ++by)
+      for (int bx = 0; bx < tx; ++bx) {
+        PsmPairTile& d = t[((size_t)cs * ty + by) * tx + bx];
+        const int y0 = by * PSM_PAIR_TY, x0 = bx * PSM_PAIR_TX;
+        d.y0 = y0; d.x0 = x0; d.cs = cs;
+        d.pix = (cs * H + y0) * W + x0;
+        d.flags = (x0 >= 2 && x0 + 33 <= W && y0 >= 2 && y0 + 16 <= H) ? 1 : 0;
+        d.offo = (int)(((int64_t)cs * B.case_elems + ((int64_t)y0 * B.P + x0) * B.cout) * 2);
+        d.off0 = d.off1 = 0;
+        if (A.pair_kind == PSM_PAIR_UPCAT) {
+          d.off0 = (int)(((int64_t)cs * pv->case_elems + ((int64_t)(y0 / 2 - 1) * pv->P + (x0 / 2 - 1)) * pv->cout) * 2);
+          d.off1 = (int)(((int64_t)cs * sk->case_elems + ((int64_t)(y0 - 2) * sk->P + (x0 - 2)) * sk->cout) * 2);
+        } else if (A.pair_kind == PSM_PAIR_POOL) {
+          d.off0 = (int)(((int64_t)cs * pv->case_elems + ((int64_t)(2 * y0 - 4) * pv->P + (2 * x0 - 4)) * pv->cout) * 2);
+        }
+      }
+  free_dev(A.d_tiles); A.d_tiles = nullptr;
+  UCHK(u, psm_dev_malloc((void**)&A.d_tiles, t.size() * sizeof(PsmPairTile)));
+  UCHK(u, psm_copy_h2d(A.d_tiles, t.data(), t.size() * sizeof(PsmPairTile)));
+  return PSM_OK;
 }
 
 // MFMA operand order: wpack[cog][chunk g][tap][ct][lane][j] = W[tap][16g + 4*(lane>>4) + j][16*(cog*nct + ct) + (lane&15)]
@@ -261,7 +291,7 @@ void choose_config(Conv& c, int H, int W, int n_cases, bool can_split, int chunk
 
 int upload_conv(psm_unet* u, Conv& c) {
   free_dev(c.d_w); c.d_w = nullptr; free_dev(c.d_b); c.d_b = nullptr; free_dev(c.d_w1); c.d_w1 = nullptr;
-  free_dev(c.d_wpa); c.d_wpa = nullptr; free_dev(c.d_wpb); c.d_wpb = nullptr;
+  free_dev(c.d_wpa); c.d_wpa = nullptr; free_dev(c.d_wpb); c.d_wpb = nullptr; free_dev(c.d_tiles); c.d_tiles = nullptr;
   std::vector<float> bias((size_t)((c.cout + 15) / 16 + 4) * 16, 0.f);
   std::memcpy(bias.data(), c.b.data(), c.cout * sizeof(float));
   UCHK(u, psm_dev_malloc((void**)&c.d_b, bias.size() * sizeof(float)));
@@ -315,6 +345,7 @@ int forward(psm_unet* u, const float* d_grid, int n, float* d_field, hipStream_t
       p.wA = c.d_wpa; p.wB = c.d_wpb; p.biasA = c.d_b; p.biasB = B.d_b;
       p.H = H; p.W = W; p.tiles_x = (W + PSM_PAIR_TX - 1) / PSM_PAIR_TX; p.tiles_y = (H + PSM_PAIR_TY - 1) / PSM_PAIR_TY; p.n_cases = n;
       p.out_case = B.case_elems; p.PO = B.P;                // conv A's kept activation (mid_out) has the same layout
+      p.tiles = c.d_tiles; p.cm = c.cout;
       p.out = (B.fuse_head && !u->keep_act) ? nullptr : reinterpret_cast<unsigned short*>(act_ptr(B));
       p.mid_out = u->keep_act ? reinterpret_cast<unsigned short*>(act_ptr(c)) : nullptr;
       if (c.pair_kind == PSM_PAIR_STEM) { p.in0 = d_grid; p.c0 = c.cin; p.in0_case = (int64_t)H * W * c.cin; p.P0 = W; }
@@ -413,7 +444,7 @@ void psm_unet_destroy(psm_unet* u) {
   if (!u) return;
   (void)hipSetDevice(u->device);
   if (u->stream) (void)hipStreamSynchronize(u->stream);
-  for (Conv& c : u->convs) { free_dev(c.d_w); free_dev(c.d_b); free_dev(c.d_w1); free_dev(c.d_out); free_dev(c.d_wpa); free_dev(c.d_wpb); }
+  for (Conv& c : u->convs) { free_dev(c.d_w); free_dev(c.d_b); free_dev(c.d_w1); free_dev(c.d_out); free_dev(c.d_wpa); free_dev(c.d_wpb); free_dev(c.d_tiles); }
   free_dev(u->d_in); free_dev(u->d_field);
   if (u->h_in) (void)hipHostFree(u->h_in);
   if (u->h_out) (void)hipHostFree(u->h_out);
@@ -520,10 +551,18 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
       else if (A.src == 2 && A.in_bf) kind = PSM_PAIR_POOL;
       else if (A.src == 3 && A.in_bf) { kind = PSM_PAIR_UPCAT; c0 = u->convs[i - 1].cout; c1 = u->convs[A.skip].cout; }
       if (kind < 0 || !psm_pair_kernel_available(kind, cm, c0, c1, B.fuse_head)) continue;
+      {   // the tile descriptors hold 32-bit byte offsets into the (zero-haloed) tensors of the whole case batch
+        int64_t big = padded_bytes(H, W, cm, max_cases);
+        if (kind == PSM_PAIR_POOL) big = std::max(big, padded_bytes(2 * H, 2 * W, c0, max_cases));
+        if (kind == PSM_PAIR_UPCAT) big = std::max(big, std::max(padded_bytes(H / 2, W / 2, c0, max_cases), padded_bytes(H, W, c1, max_cases)));
+        if (big >= ((int64_t)1 << 31)) continue;
+      }
       if (cm == 32 && getenv("PSM_UNET_PAIR32") && atoi(getenv("PSM_UNET_PAIR32")) == 0) continue;     // diagnostic: 16-channel pairs only
       A.pair = 1; A.pair_kind = kind; B.pair = 2;
     }
   }
+  // bf16 tensors (finished activations of bf16 mode; a fused pair always writes bf16) get the zero halo
+  if (pass == 1) for (Conv& c : u->convs) act_layout(c, ny >> c.level, nx >> c.level, u->bf16 && c.k == 3 && (c.out_bf || c.pair != 0));
   for (Conv& c : u->convs) {
     const int H = ny >> c.level, W = nx >> c.level;
     const size_t ci = &c - u->convs.data();
@@ -531,10 +570,10 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
     if (pass == 1) {
       int rc = upload_conv(u, c);
       if (rc) return rc;
+      if (c.pair == 1 && (rc = build_pair_tiles(u, c, u->convs[ci + 1], c.src != 0 ? &u->convs[ci - 1] : nullptr, c.src == 3 ? &u->convs[c.skip] : nullptr,
+                                                H, W, max_cases))) return rc;
       free_dev(c.d_out); c.d_out = nullptr;
       c.slab = (int64_t)max_cases * H * W * c.cout;
-      // bf16 tensors (finished activations of bf16 mode; a fused pair always writes bf16) get the zero halo
-      act_layout(c, H, W, u->bf16 && c.k == 3 && (c.out_bf || c.pair != 0));
       if (c.padded) {
         const size_t bytes = (size_t)max_cases * c.case_elems * sizeof(uint16_t) + 4096;      // + slack: a tile's last LDS-DMA piece may start past its last row
         UCHK(u, psm_dev_malloc((void**)&c.d_out, bytes));

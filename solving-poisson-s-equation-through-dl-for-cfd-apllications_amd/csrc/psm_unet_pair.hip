@@ -32,10 +32,14 @@ __device__ unsigned long long g_pair_stamps[64];
 #ifndef PSM_STAMP_WG
 #define PSM_STAMP_WG 0
 #endif
-#define PSTAMP(k) do { if (blockIdx.x == PSM_STAMP_WG && threadIdx.x == 0 && 9 * g_it + (k) < 64) g_pair_stamps[9 * g_it + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define PSTAMP(k) do { if (blockIdx.x == PSM_STAMP_WG && threadIdx.x == 0 && 9 * g_it + (k) < 63) g_pair_stamps[9 * g_it + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define PSTAMP_ENTRY() do { if (blockIdx.x == PSM_STAMP_WG && threadIdx.x == 0) g_pair_stamps[63] = __builtin_amdgcn_s_memrealtime(); } while (0)   // kernel entry
+#define PSTAMP_PRO(k) do { if (blockIdx.x == PSM_STAMP_WG && threadIdx.x == 0) g_pair_stamps[56 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)   // prologue, k < 7
 hipError_t psm_unet_pair_read_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pair_stamps), sizeof(g_pair_stamps)); }
 #else
 #define PSTAMP(k) do { } while (0)
+#define PSTAMP_ENTRY() do { } while (0)
+#define PSTAMP_PRO(k) do { } while (0)
 hipError_t psm_unet_pair_read_stamps(unsigned long long* out) { for (int i = 0; i < 64; ++i) out[i] = 0; return hipSuccess; }
 #endif
 
@@ -343,11 +347,35 @@ __device__ __forceinline__ int tile_of(int it, int total) {
   const int t = w + it * G;
   return t < total ? t : -1;
 }
-struct TilePos { int cs, y0, x0; };
-__device__ __forceinline__ TilePos tile_pos(const PsmPairArgs& a, int t) {
+// The same descriptor computed in the kernel (two integer divisions, ~100 scalar instructions): for a workgroup's FIRST tile, whose
+// table entry would be a cold fetch in front of everything else (measured: the 128^2 pairs, one tile per workgroup, 13 -> 15 us
+// and 19 -> 21 us with the table alone).  Later tiles come from the table, requested a whole tile ahead.
+template <int KIND>
+__device__ __forceinline__ PsmPairTile tile_calc(const PsmPairArgs& a, int t) {
   const int per_case = a.tiles_x * a.tiles_y;
-  const int cs = t / per_case, r = t - cs * per_case, by = r / a.tiles_x;
-  return {cs, by * TY, (r - by * a.tiles_x) * TX};
+  const int cs = t / per_case, r = t - cs * per_case, by = r / a.tiles_x, bx = r - by * a.tiles_x;
+  PsmPairTile d;
+  d.y0 = by * TY; d.x0 = bx * TX; d.cs = cs;
+  d.pix = (cs * a.H + d.y0) * a.W + d.x0;
+  d.flags = (d.x0 >= 2 && d.x0 + 33 <= a.W && d.y0 >= 2 && d.y0 + 16 <= a.H) ? 1 : 0;
+  d.offo = (int)((cs * a.out_case + ((int64_t)d.y0 * a.PO + d.x0) * a.cm) * 2);
+  d.off0 = d.off1 = 0;
+  if (KIND == PSM_PAIR_UPCAT) {
+    d.off0 = (int)((cs * a.in0_case + ((int64_t)(d.y0 / 2 - 1) * a.P0 + (d.x0 / 2 - 1)) * a.c0) * 2);
+    d.off1 = (int)((cs * a.in1_case + ((int64_t)(d.y0 - 2) * a.P1 + (d.x0 - 2)) * a.c1) * 2);
+  } else if (KIND == PSM_PAIR_POOL) {
+    d.off0 = (int)((cs * a.in0_case + ((int64_t)(2 * d.y0 - 4) * a.P0 + (2 * d.x0 - 4)) * a.c0) * 2);
+  }
+  return d;
+}
+// tile t's descriptor (host-built, psm_unet.h): a wave-uniform index -> scalar loads
+// (constant address space + a readfirstlane'd index: s_load_dwordx8; through the generic pointer the compiler issued eight
+// vector loads and a readfirstlane each, and their vmcnt waits landed in the MFMA stream)
+__device__ __forceinline__ PsmPairTile tile_desc(const PsmPairArgs& a, int t) {
+  typedef int i32x8 __attribute__((ext_vector_type(8)));
+  const auto* p = (const __attribute__((address_space(4))) i32x8*)a.tiles;
+  const i32x8 v = p[__builtin_amdgcn_readfirstlane(t)];
+  return PsmPairTile{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
 }
 
 // ---- epilogues ------------------------------------------------------------------------------------------------------
@@ -395,21 +423,21 @@ __device__ __forceinline__ void mid_epilogue(const PsmPairArgs& a, char* mid, in
 // 0-31 and row B's in lanes 32-63; v_permlane16_swap of two such registers + one add finishes four rows in one register
 // (16-lane group g holds row {0, 2, 1, 3}[g]) -- 6 instructions and ONE store for four rows.
 template <int NT, int R, bool STORE, bool HEAD>
-__device__ __forceinline__ void out_epilogue(const PsmPairArgs& a, int cs, int y0, int x0, int r0, int xh, int lane,
+__device__ __forceinline__ void out_epilogue(const PsmPairArgs& a, char* otile, float* htile, int y0, int x0, int r0, int xh, int lane,
                                              const float* headw, f32x4 (&acc)[R][NT]) {
+  // otile: pixel (y0, x0) of this case in a.out (bytes);  htile: the same pixel in a.head_out -- both wave-uniform; a lane adds 32-bit offsets
   static_assert(!HEAD || NT == 1, "the fused head reads one channel tile");
   const int px = lane & 15, kq = lane >> 4;
   const int col = 16 * xh + px, x = x0 + col;
   const bool xok = col < TX && x < a.W;
   if constexpr (STORE) {
-    const unsigned loff = (unsigned)((((y0 + r0) * a.PO + x) * (16 * NT) + 4 * kq) * 2);       // bytes within the case
-    char* obase = reinterpret_cast<char*>(a.out + (int64_t)cs * a.out_case);
+    const unsigned loff = (unsigned)(((r0 * a.PO + col) * (16 * NT) + 4 * kq) * 2);
 #pragma unroll
     for (int m = 0; m < R; ++m) {
       const bool ok = xok && y0 + r0 + m < a.H;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
-        if (ok) *reinterpret_cast<u32x2*>(obase + loff + (unsigned)(m * a.PO * (16 * NT) * 2) + nt * 32) = pack4_relu(acc[m][nt]);
+        if (ok) *reinterpret_cast<u32x2*>(otile + loff + (unsigned)(m * a.PO * (16 * NT) * 2) + nt * 32) = pack4_relu(acc[m][nt]);
     }
   }
   if constexpr (HEAD) {
@@ -440,11 +468,14 @@ __device__ __forceinline__ void out_epilogue(const PsmPairArgs& a, int cs, int y
 #if defined(PSM_PAIR_EXP) && (PSM_PAIR_EXP == 16)
         if (tot == 12345.678f)                     // diagnostic: the head's result computed, (almost) never stored
 #endif
-        if (xok && m < R && y < a.H) a.head_out[(int64_t)cs * a.head_case + ((int64_t)y * a.W + x) * a.head_cout + o] = tot;
+        if (xok && m < R && y < a.H) htile[(unsigned)(((r0 + m) * a.W + col) * a.head_cout + o)] = tot;
       }
     }
   }
 }
+// the two tile pointers from a descriptor (one 64-bit scalar add each)
+__device__ __forceinline__ char* out_tile(const PsmPairArgs& a, const PsmPairTile& d) { return reinterpret_cast<char*>(a.out) + d.offo; }
+__device__ __forceinline__ float* head_tile(const PsmPairArgs& a, const PsmPairTile& d) { return a.head_out + (int64_t)d.pix * a.head_cout; }
 __device__ __forceinline__ void load_head(const PsmPairArgs& a, float* headw, int tid) {
   if (a.head_w) {
     if (tid < 16 * a.head_cout) headw[tid] = a.head_w[tid];
@@ -464,11 +495,6 @@ __device__ __forceinline__ void zero_mid_pad32(char* mid, int tid) {          //
     *reinterpret_cast<f32x4*>(mid + (r * P32 + c) * 64 + (tid & 3) * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 }
-// every pixel the tile stages (x0 - 2 .. x0 + 32, y0 - 2 .. y0 + 15) and computes lies inside the image
-__device__ __forceinline__ bool tile_interior(const PsmPairArgs& a, const TilePos& t) {
-  return t.x0 >= 2 && t.x0 + 33 <= a.W && t.y0 >= 2 && t.y0 + 16 <= a.H;
-}
-
 // ====================================================================================================================
 // level 0, encoder: raw image (C0 = 3 or 4 float32 channels) -> 16 -> 16.  conv A flattens k = tap*C0 + channel and
 // pads it to KS steps of 32; its operand is gathered from the bf16 image tile with per-lane fixed offsets.
@@ -506,7 +532,7 @@ __global__ __launch_bounds__(256, 2) void psm_pair_stem16_kernel(PsmPairArgs a) 
   // image staging, row-wise: wave w takes rows w, w + 4, ...; a lane keeps KR value positions of the row
   float ev[RW][KR];
   unsigned evok = 0;
-  auto issue = [&](const TilePos& t) {
+  auto issue = [&](const PsmPairTile& t) {
     const float* in0 = reinterpret_cast<const float*>(a.in0) + (int64_t)t.cs * a.in0_case;
     int xo[KR];
     unsigned xok = 0;
@@ -531,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void psm_pair_stem16_kernel(PsmPairArgs a) 
   };
   int it = 0, tile = tile_of(0, total);
   if (tile < 0) return;
-  TilePos cur = tile_pos(a, tile);
+  PsmPairTile cur = tile_calc<PSM_PAIR_STEM>(a, tile);
   issue(cur);
 #ifdef PSM_STAMPS
   int g_it = 0;
@@ -547,9 +573,9 @@ __global__ __launch_bounds__(256, 2) void psm_pair_stem16_kernel(PsmPairArgs a) 
     PSTAMP(1);
     lds_barrier();
     PSTAMP(2);
-    const bool interior = tile_interior(a, cur);
+    const bool interior = (cur.flags & 1) != 0;
     const int next = tile_of(++it, total);
-    const TilePos nxt = tile_pos(a, next >= 0 ? next : tile);          // past the end: the same tile again (no branch around the loads)
+    const PsmPairTile nxt = tile_desc(a, next >= 0 ? next : tile);     // past the end: the same tile again (no branch around the loads)
     issue(nxt);
     PSTAMP(3);
     {
@@ -587,7 +613,7 @@ __global__ __launch_bounds__(256, 2) void psm_pair_stem16_kernel(PsmPairArgs a) 
       for (int m = 0; m < R; ++m) acc[m][0] = bB;
       conv16<1, R, false>(mid, r0, 16 * xh + px, kq, [&](int i) { return wbf[i * 64]; }, acc);
       PSTAMP(7);
-      out_epilogue<1, R, true, false>(a, cur.cs, cur.y0, cur.x0, r0, xh, lane, nullptr, acc);
+      out_epilogue<1, R, true, false>(a, out_tile(a, cur), nullptr, cur.y0, cur.x0, r0, xh, lane, nullptr, acc);
     }
     PSTAMP(8);
 #ifdef PSM_STAMPS
@@ -599,88 +625,134 @@ __global__ __launch_bounds__(256, 2) void psm_pair_stem16_kernel(PsmPairArgs a) 
 }
 
 // ====================================================================================================================
-// level 0, decoder: upsample(32 channels) ++ skip(16 channels) -> 16 -> 16 (+ head).  Weights in LDS.
+// LDS-DMA staging (global_load_lds_dwordx4): every lane names its own 16 source bytes, the destination is a wave-uniform LDS
+// address + 16 * lane.  The LDS image of a tile ([row][PITCH pixels][PXB bytes]; 64-byte pixels with swizzled slots, the swizzle
+// applied on the SOURCE side: a lane fetches the channel group that belongs in its slot) is cut into pieces of 1 KiB, piece i is
+// issued by wave i % 4.  A lane's source offset relative to the tile's first source pixel depends on (piece, lane) only, so it is
+// computed ONCE per kernel (one VGPR per piece) and a tile costs a wave PW instructions: no staging registers, no LDS stores, no
+// address arithmetic per tile.  The tensors are zero-haloed (psm_unet_api.cpp, act_layout), so there is nothing to clamp or to
+// zero: the 'same' padding and the overhang of the last tile are read from memory like any other pixel.
+//   PXB: bytes per LDS pixel;  PITCH x NROW: the LDS image;  NCOL: source columns that exist for the tile (columns beyond repeat
+//   the last one -- they are LDS padding no convolution reads)
+// ====================================================================================================================
+template <int PXB, int PITCH, int NROW, int NCOL>
+struct Dma {
+  static constexpr int G = PXB / 16, NI = (NROW * PITCH * G + 63) / 64, PW = (NI + 3) / 4, BYTES = NI * 1024;
+  // row_bytes: one source row;  px_bytes: one source pixel;  cb_bytes: first channel of the chunk within the pixel
+  static __device__ __forceinline__ void offsets(unsigned (&off)[PW], int wave, int lane, int row_bytes, int px_bytes, int cb_bytes) {
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      const int i = min(wave + 4 * j, NI - 1);                 // a wave without a piece of its own in the last round repeats the last piece
+      const int q = i * 64 + lane, P = q / G, sl = q % G;
+      const int r = min(P / PITCH, NROW - 1), cl = P % PITCH, c = min(cl, NCOL - 1);
+      const int g = PXB == 64 ? ((sl - ((cl >> 1) & 2)) & 3) : sl;      // slot64(): slot sl of column cl holds channel group g
+      off[j] = (unsigned)(r * row_bytes + c * px_bytes + cb_bytes + 16 * g);
+    }
+  }
+  static __device__ __forceinline__ void issue(char* tile, const char* src, const unsigned (&off)[PW], int wave) {
+#pragma unroll
+    for (int j = 0; j < PW; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off[j]),
+                                       (__attribute__((address_space(3))) void*)(tile + min(wave + 4 * j, NI - 1) * 1024), 16, 0, 0);
+  }
+};
+typedef Dma<64, PL, IH / 2, 17> DmaLow;                    // upsample source at its own resolution, 32 channels
+typedef Dma<32, P16, IH, P16> Dma16;                       // 16 channels, same resolution (35 columns: the paired tap of kx = 2 reads one further)
+static_assert(DmaLow::BYTES >= LOW_BYTES && Dma16::BYTES >= T16_BYTES, "whole pieces");
+
+// a lane-linear copy of n_pieces KiB (weight fragments as the host packed them) into LDS, piece i by wave i % 4
+__device__ __forceinline__ void dma_copy(char* dst, const void* src, int n_pieces, int wave, int lane) {
+  const char* s = reinterpret_cast<const char*>(src) + 16 * lane;
+  for (int i = wave; i < n_pieces; i += 4)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s + i * 1024),
+                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+}
+// the issuing wave's LDS-DMA pieces have landed (vmcnt counts them like loads); the barrier behind it publishes them to the others
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// ====================================================================================================================
+// level 0, decoder: upsample(32 channels) ++ skip(16 channels) -> 16 -> 16 (+ head).  Weights in LDS, input tiles by LDS-DMA.
+// Per tile: [wait for the tile's pieces] barrier | conv A (120 MFMAs) -> mid tile | barrier | request the NEXT tile's pieces
+// (every wave is done with the input tiles) | conv B (42 MFMAs) -> stores.  The requests are in flight during conv B, the
+// epilogue and the other workgroup of the CU.
 // ====================================================================================================================
 template <bool KEEP, bool HEAD>
 __global__ __launch_bounds__(256, 2) void psm_pair_up16_kernel(PsmPairArgs a) {
-  __shared__ __attribute__((aligned(16))) char tlow[LOW_BYTES];             // upsample source at its own resolution, 32 channels
-  __shared__ __attribute__((aligned(16))) char t16[T16_BYTES];              // skip input, 16 channels
-  __shared__ __attribute__((aligned(16))) char mid[M16_BYTES];
-  __shared__ __attribute__((aligned(16))) bf16x8 wl[21 * 64];               // conv A: 9 + 6 fragments, conv B: 6
-  __shared__ float headw[272];
+  // ONE __shared__ object: with several, hipcc's wait-count pass ties the LDS reads of conv B (mid tile, weights) to the LDS-DMA
+  // pieces just requested and drains vmcnt(0) in front of them -- the requests would never be in flight during anything
+  // (cdna_hip_programming.md, 'Projection GEMM at M = 256', item 4(a)).  With one object it inserts no such waits at all, so the
+  // ordering is this kernel's: dma_wait_all() + barrier before the first read of a DMA'd tile, a barrier after the last.
+  constexpr int O_LOW = 0, O_T16 = O_LOW + DmaLow::BYTES, O_MID = O_T16 + Dma16::BYTES, O_W = O_MID + M16_BYTES, O_HEAD = O_W + 21 * 1024;
+  __shared__ __attribute__((aligned(16))) char lds[O_HEAD + 272 * 4];
+  char* tlow = lds + O_LOW;                                                  // upsample source at its own resolution, 32 channels
+  char* t16 = lds + O_T16;                                                   // skip input, 16 channels
+  char* mid = lds + O_MID;
+  bf16x8* wl = reinterpret_cast<bf16x8*>(lds + O_W);                         // conv A: 9 + 6 fragments, conv B: 6
+  float* headw = reinterpret_cast<float*>(lds + O_HEAD);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int px = lane & 15, kq = lane >> 4, xh = wave & 1;
   const int total = a.tiles_x * a.tiles_y * a.n_cases;
-  for (int i = tid; i < 21 * 64; i += 256)
-    reinterpret_cast<uint4*>(wl)[i] = i < 15 * 64 ? a.wA[i] : a.wB[i - 15 * 64];
-  const f32x4 bA = *reinterpret_cast<const f32x4*>(a.biasA + 4 * kq), bB = *reinterpret_cast<const f32x4*>(a.biasB + 4 * kq);
-  load_head(a, headw, tid);
-  zero_mid_pad16(mid, tid);
-  const bf16x8* wf = wl + lane;
-  f32x4 vlo[StLow::NP][1], v16[St16::NP][1];
-  unsigned oklo, ok16;
-  auto issue = [&](const TilePos& t) {
-    StLow::issue(vlo, oklo, reinterpret_cast<const unsigned short*>(a.in0) + (int64_t)t.cs * a.in0_case, 32, 0, a.H / 2, a.W / 2, a.P0,
-                 (t.y0 - 2) / 2, (t.x0 - 2) / 2, wave, lane, tid);                     // tile origins are even: exact, also for -2
-    St16::issue(v16, ok16, reinterpret_cast<const unsigned short*>(a.in1) + (int64_t)t.cs * a.in1_case, 16, 0, a.H, a.W, a.P1,
-                t.y0 - 2, t.x0 - 2, wave, lane, tid);
-  };
+  PSTAMP_ENTRY();
   int it = 0, tile = tile_of(0, total);
   if (tile < 0) return;
-  TilePos cur = tile_pos(a, tile);
-  issue(cur);
+  PsmPairTile cur = tile_calc<PSM_PAIR_UPCAT>(a, tile);
+  PSTAMP_PRO(0);
+  // Everything the workgroup needs before its first MFMA is requested here in ONE go -- biases and head weights to registers, the
+  // weight fragments and the first tile by LDS-DMA -- and waited for once, at the top of the tile loop.  (Stamps of the previous
+  // form: weights through registers 2.8 us, then biases + head another 0.6 us -- three dependent round trips, 4.9 us from kernel
+  // entry to the first MFMA out of a 19 us launch.)
+  const f32x4 bA = *reinterpret_cast<const f32x4*>(a.biasA + 4 * kq), bB = *reinterpret_cast<const f32x4*>(a.biasB + 4 * kq);
+  float hw0 = 0.f, hw1 = 0.f;
+  if (a.head_w) { hw0 = a.head_w[min(tid, 16 * a.head_cout - 1)]; hw1 = a.head_b[min(tid, a.head_cout - 1)]; }
+  dma_copy(reinterpret_cast<char*>(wl), a.wA, 15, wave, lane);
+  dma_copy(reinterpret_cast<char*>(wl) + 15 * 1024, a.wB, 6, wave, lane);
+  unsigned olo[DmaLow::PW], o16[Dma16::PW];
+  DmaLow::offsets(olo, wave, lane, a.P0 * 64, 64, 0);
+  Dma16::offsets(o16, wave, lane, a.P1 * 32, 32, 0);
+  PSTAMP_PRO(1);
+  const char* in0 = reinterpret_cast<const char*>(a.in0);
+  const char* in1 = reinterpret_cast<const char*>(a.in1);
+  DmaLow::issue(tlow, in0 + cur.off0, olo, wave);
+  Dma16::issue(t16, in1 + cur.off1, o16, wave);
+  PSTAMP_PRO(2);
+  zero_mid_pad16(mid, tid);
+  if (a.head_w) {
+    if (tid < 16 * a.head_cout) headw[tid] = hw0;
+    if (tid < a.head_cout) headw[256 + tid] = hw1;
+  }
+  PSTAMP_PRO(3);
+  const bf16x8* wf = wl + lane;
 #ifdef PSM_STAMPS
   int g_it = 0;
 #endif
   while (true) {
-    const bool interior = tile_interior(a, cur);
     PSTAMP(0);
-    StLow::write(tlow, vlo, oklo, interior, wave, lane, tid);
-    St16::write(t16, v16, ok16, interior, wave, lane, tid);
+    dma_wait_all();
     PSTAMP(1);
     lds_barrier();
     PSTAMP(2);
     const int next = tile_of(++it, total);
-    const TilePos nxt = tile_pos(a, next >= 0 ? next : tile);          // past the end: the same tile again (no branch around the loads)
-#if PSM_PAIR_SPREAD
-    // the ten requests of the next tile, two per MFMA step of conv A (three steps on the upsample source, two on the skip input)
-    const unsigned short* nlo = reinterpret_cast<const unsigned short*>(a.in0) + (int64_t)nxt.cs * a.in0_case;
-    const unsigned short* n16 = reinterpret_cast<const unsigned short*>(a.in1) + (int64_t)nxt.cs * a.in1_case;
-    auto piece = [&](int p) {
-#define LO_PIECE(I) StLow::template issue_piece<I>(vlo, oklo, nlo, 32, 0, a.H / 2, a.W / 2, a.P0, (nxt.y0 - 2) / 2, (nxt.x0 - 2) / 2, wave, lane, tid)
-#define SK_PIECE(I) St16::template issue_piece<I>(v16, ok16, n16, 16, 0, a.H, a.W, a.P1, nxt.y0 - 2, nxt.x0 - 2, wave, lane, tid)
-      static_assert(StLow::NP == 4 && St16::NP == 6, "ten pieces over five steps");
-      if (p == 0) LO_PIECE(0); else if (p == 1) LO_PIECE(1); else if (p == 2) LO_PIECE(2); else if (p == 3) LO_PIECE(3);
-      else if (p == 4) SK_PIECE(0); else if (p == 5) SK_PIECE(1); else if (p == 6) SK_PIECE(2); else if (p == 7) SK_PIECE(3);
-      else if (p == 8) SK_PIECE(4); else if (p == 9) SK_PIECE(5);
-#undef LO_PIECE
-#undef SK_PIECE
-    };
-#else
-    issue(nxt);
-#endif
+    const PsmPairTile nxt = tile_desc(a, next >= 0 ? next : tile);
     {
       constexpr int R = MH / 2;
       const int r0 = R * (wave >> 1);
       f32x4 acc[R][1];
 #pragma unroll
       for (int m = 0; m < R; ++m) acc[m][0] = bA;
-#if PSM_PAIR_SPREAD
-      conv32_up<1, R>(tlow, r0, 16 * xh + px, kq, [&](int i) { return wf[i * 64]; }, acc, [&](int i) { piece(i); });
-      PSTAMP(3);
-      conv16<1, R>(t16, r0, 16 * xh + px, kq, [&](int i) { return wf[(9 + i) * 64]; }, acc, [&](int i) { piece(6 + i); });
-#else
       conv32_up<1, R>(tlow, r0, 16 * xh + px, kq, [&](int i) { return wf[i * 64]; }, acc);
       PSTAMP(3);
       conv16<1, R>(t16, r0, 16 * xh + px, kq, [&](int i) { return wf[(9 + i) * 64]; }, acc);
-#endif
       PSTAMP(4);
-      mid_epilogue<1, R, KEEP>(a, mid, cur.cs, cur.y0, cur.x0, r0, xh, lane, interior, acc);
+      mid_epilogue<1, R, KEEP>(a, mid, cur.cs, cur.y0, cur.x0, r0, xh, lane, (cur.flags & 1) != 0, acc);
     }
     PSTAMP(5);
     lds_barrier();
     PSTAMP(6);
+    if (next >= 0) {                                         // uniform; no register waits for these
+      DmaLow::issue(tlow, in0 + nxt.off0, olo, wave);
+      Dma16::issue(t16, in1 + nxt.off1, o16, wave);
+    }
     {
       constexpr int R = TY / 2;
       const int r0 = R * (wave >> 1);
@@ -689,7 +761,8 @@ __global__ __launch_bounds__(256, 2) void psm_pair_up16_kernel(PsmPairArgs a) {
       for (int m = 0; m < R; ++m) acc[m][0] = bB;
       conv16<1, R>(mid, r0, 16 * xh + px, kq, [&](int i) { return wf[(15 + i) * 64]; }, acc);
       PSTAMP(7);
-      out_epilogue<1, R, KEEP || !HEAD, HEAD>(a, cur.cs, cur.y0, cur.x0, r0, xh, lane, headw, acc);
+      out_epilogue<1, R, KEEP || !HEAD, HEAD>(a, (KEEP || !HEAD) ? out_tile(a, cur) : nullptr, HEAD ? head_tile(a, cur) : nullptr, cur.y0, cur.x0,
+                                              r0, xh, lane, headw, acc);
     }
     PSTAMP(8);
 #ifdef PSM_STAMPS
@@ -759,9 +832,9 @@ __global__ __launch_bounds__(256, 2) void psm_pair32_kernel(PsmPairArgs a) {
   for (int it = 0;; ++it) {
     const int tl = tile_of(it, total);
     if (tl < 0) break;
-    const TilePos t = tile_pos(a, tl);
+    const PsmPairTile t = tile_calc<KIND == 1 ? PSM_PAIR_UPCAT : PSM_PAIR_POOL>(a, tl);      // (one tile per workgroup where it is planned)
     const int y0 = t.y0, x0 = t.x0;
-    const bool interior = tile_interior(a, t);
+    const bool interior = (t.flags & 1) != 0;
     const unsigned short* in0 = reinterpret_cast<const unsigned short*>(a.in0) + (int64_t)t.cs * a.in0_case;
     const unsigned short* in1 = reinterpret_cast<const unsigned short*>(a.in1) + (int64_t)t.cs * a.in1_case;
     int tz = tid, lz = lane;                                  // opaque copies, refreshed where they are used: staging positions are
@@ -867,7 +940,7 @@ __global__ __launch_bounds__(256, 2) void psm_pair32_kernel(PsmPairArgs a) {
       const bf16x8* wbf = reinterpret_cast<const bf16x8*>(wbl) + lane;
       conv32<2, RB>(mid, rB, 16 * xh + px, kq, [&](int i) { return wbf[i * 64]; }, accb);
       PSTAMP32();
-      out_epilogue<2, RB, true, false>(a, t.cs, y0, x0, rB, xh, lane, nullptr, accb);
+      out_epilogue<2, RB, true, false>(a, out_tile(a, t), nullptr, y0, x0, rB, xh, lane, nullptr, accb);
       PSTAMP32();
     }
   }
