@@ -48,37 +48,26 @@ hipError_t psm_unet_read_stamps(unsigned long long* out) { for (int i = 0; i < 6
 
 namespace {
 
-// sum over the 16 lanes of a DPP row (lanes sharing l >> 4); the total lands in lane 15 of the row
-__device__ __forceinline__ float row16_sum(float v) {
-#define PSM_ROW_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, true))
-  PSM_ROW_ADD(0x111); PSM_ROW_ADD(0x112); PSM_ROW_ADD(0x114); PSM_ROW_ADD(0x118);
-#undef PSM_ROW_ADD
-  return v;
-}
-
-// fused linear 1x1 head on the finished 16-channel tiles of a wave: v[m][r] = activation of (row m, pixel 4*(lane>>4)+r,
-// channel lane & 15).  The head's weight is loaded ONCE per output channel and only after every activation store has
-// been issued: a load between the stores would make each of them a full round trip (stores count in vmcnt too).
+// fused linear 1x1 head on the finished 16-channel tiles of a wave: v[m][r] = activation of (row m, pixel lane & 15,
+// channel 4 * (lane >> 4) + r).  In-lane part of the 16-channel sum, then the four lanes l, l ^ 16, l ^ 32, l ^ 48 of a pixel.
+// The head's weight is loaded ONCE per output channel and only after every activation store has been issued: a load between
+// the stores would make each of them a full round trip (stores count in vmcnt too).
 template <int WM>
 __device__ __forceinline__ void head_epilogue(const PsmConvArgs& a, int cs, int y_first, int x0, int lane, const f32x4 (&v)[WM]) {
-  const int co = lane & 15, kq = lane >> 4;
+  const int px = lane & 15, kq = lane >> 4;
   for (int o = 0; o < a.head_cout; ++o) {
-    const float w = a.head_w[co * a.head_cout + o], hb = a.head_b[o];
+    f32x4 w;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w[r] = a.head_w[(4 * kq + r) * a.head_cout + o];
+    const float hb = a.head_b[o];
 #pragma unroll
     for (int m = 0; m < WM; ++m) {
       const int y = y_first + m;
-      f32x4 s;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s[r] = row16_sum(v[m][r] * w) + hb;      // lane 15 of each 16-lane row holds the sums
-      float* dst = a.head_out + (int64_t)cs * a.head_case + ((int64_t)y * a.W + x0 + 4 * kq) * a.head_cout + o;
-      if (co == 15 && y < a.H) {
-        if (a.head_cout == 1 && (a.W & 3) == 0 && x0 + 4 * kq + 3 < a.W) *reinterpret_cast<f32x4*>(dst) = s;     // 4 consecutive pixels
-        else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (x0 + 4 * kq + r < a.W) dst[(int64_t)r * a.head_cout] = s[r];
-        }
-      }
+      float s = v[m][0] * w[0] + v[m][1] * w[1] + v[m][2] * w[2] + v[m][3] * w[3];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (kq == 0 && y < a.H && x0 + px < a.W)
+        a.head_out[(int64_t)cs * a.head_case + ((int64_t)y * a.W + x0 + px) * a.head_cout + o] = s + hb;
     }
   }
 }
@@ -326,6 +315,12 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
   for (int m = 0; m < WM; ++m)
 #pragma unroll
     for (int n = 0; n < WN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // the epilogue's bias, requested HERE with the first chunk's operands: loaded in the epilogue it was an exposed round trip
+  // at the end of every workgroup (stamps: last barrier -> end 1.5 us of a 5 us workgroup on the 64^2 layers)
+  // (the bias array is zero-padded to whole channel tiles and four tiles beyond: upload_conv)
+  f32x4 bias_r[WN];
+#pragma unroll
+  for (int n = 0; n < WN; ++n) bias_r[n] = *reinterpret_cast<const f32x4*>(a.bias + (cog * NCT + ct_w + n) * 16 + 4 * kq);
   const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpack) + (int64_t)cog * a.n_chunks * WQ;
   const int cps = (a.n_chunks + a.ksplit - 1) / a.ksplit;          // chunks per split
   const int g_beg = split * cps, g_end = min(a.n_chunks, (split + 1) * cps);
@@ -511,7 +506,7 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
           for (int m = 0; m < WM; ++m)
 #pragma unroll
             for (int n = 0; n < WN; ++n)
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, avr[s2][m + ky]), __builtin_bit_cast(bf16x8, bvr[s2][ky][n]),
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bvr[s2][ky][n]), __builtin_bit_cast(bf16x8, avr[s2][m + ky]),
                                                                   acc[m][n], 0, 0, 0);
 #endif
           __builtin_amdgcn_sched_barrier(0);
@@ -556,14 +551,14 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
           for (int m = 0; m < WM; ++m)
 #pragma unroll
             for (int n = 0; n < WN; ++n)
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[s][m][PA[t6]]),
-                                                                  __builtin_bit_cast(bf16x8, bv[s][n][PB[t6]]), acc[m][n], 0, 0, 0);
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bv[s][n][PB[t6]]),
+                                                                  __builtin_bit_cast(bf16x8, av[s][m][PA[t6]]), acc[m][n], 0, 0, 0);
       } else if constexpr (BF) {
 #pragma unroll
         for (int m = 0; m < WM; ++m)
 #pragma unroll
           for (int n = 0; n < WN; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[s][m][0]), __builtin_bit_cast(bf16x8, bv[s][n][0]),
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bv[s][n][0]), __builtin_bit_cast(bf16x8, av[s][m][0]),
                                                                 acc[m][n], 0, 0, 0);
       } else {
         // consecutive MFMAs go to different accumulators (dependent-accumulator latency 40 > issue 32 cycles)
@@ -572,7 +567,7 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
 #pragma unroll
           for (int m = 0; m < WM; ++m)
 #pragma unroll
-            for (int n = 0; n < WN; ++n) acc[m][n] = MFMA16(av[s][m][0][j], bv[s][n][0][j], acc[m][n]);
+            for (int n = 0; n < WN; ++n) acc[m][n] = MFMA16(bv[s][n][0][j], av[s][m][0][j], acc[m][n]);
       }
 #endif
       // nothing may move across: above all not the combines / LDS stores below, which wait for the loads issued above
@@ -603,21 +598,48 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
   // ---- epilogue: bias + ReLU (split-K: the raw partial sum into this split's slab), NHWC store
   float* out = a.out_bf ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(a.out) + (int64_t)cs * a.out_case)
                         : a.out + (int64_t)cs * a.out_case + (int64_t)split * a.out_slab;
+  // The MFMAs take the WEIGHTS as their first operand: D[channel][pixel], i.e. lane l holds the four consecutive channels
+  // 4 * (l >> 4) .. + 3 of pixel l & 15 -- one 8-byte (bf16) or 16-byte (float32) store per (row, channel tile) and one address per
+  // lane.  (Round 4's layout, a lane = four pixels of ONE channel, needed 16 predicated 4-byte stores with a 64-bit address chain
+  // each: stamps showed 1.5 us between the last barrier and the end of a 5 us workgroup.)
   const bool fin = a.ksplit == 1;
+  const int x = x0 + px;
+  const bool xok = x < a.W;
+  const int64_t pix0 = ((int64_t)(y0 + row_w) * a.PO + x) * a.cout;
 #pragma unroll
   for (int n = 0; n < WN; ++n) {
-    const int co = (cog * NCT + ct_w + n) * 16 + (lane & 15);
-    const float b = (fin && co < a.cout) ? a.bias[co] : 0.f;
+    const int co4 = (cog * NCT + ct_w + n) * 16 + 4 * kq;
+    const f32x4 b = fin ? bias_r[n] : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < WM; ++m) {
-      const int y = y0 + row_w + m;
+      f32x4 v = acc[m][n] + b;
+      if (fin && a.relu) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int x = x0 + 4 * kq + r;
-        float v = acc[m][n][r] + b;
-        if (fin && a.relu) v = fmaxf(v, 0.f);
-        store_act(out, ((int64_t)y * a.PO + x) * a.cout + co, v, y < a.H && x < a.W && co < a.cout, a.out_bf != 0, co);
-        acc[m][n][r] = v;
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      acc[m][n] = v;
+      const bool ok = xok && y0 + row_w + m < a.H;
+      const int64_t e = pix0 + (int64_t)m * a.PO * a.cout + co4;
+      if ((a.cout & 3) == 0) {
+        if (ok && co4 < a.cout) {
+          if (a.out_bf) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+            u32x2 pk;
+            pk[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
+            pk[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
+            *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(out) + e) = pk;
+          } else *reinterpret_cast<f32x4*>(out + e) = v;
+        }
+      } else {                                              // channel counts that are not multiples of four: element-wise
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (ok && co4 + r < a.cout) {
+            if (a.out_bf) reinterpret_cast<unsigned short*>(out)[e + r] = __builtin_bit_cast(unsigned short, (__bf16)v[r]);
+            else out[e + r] = v[r];
+          }
       }
     }
   }

@@ -495,6 +495,16 @@ __device__ __forceinline__ void zero_mid_pad32(char* mid, int tid) {          //
     *reinterpret_cast<f32x4*>(mid + (r * P32 + c) * 64 + (tid & 3) * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 }
+// a lane-linear copy of n_pieces KiB (weight fragments as the host packed them) into LDS, piece i by wave i % 4
+__device__ __forceinline__ void dma_copy(char* dst, const void* src, int n_pieces, int wave, int lane) {
+  const char* s = reinterpret_cast<const char*>(src) + 16 * lane;
+  for (int i = wave; i < n_pieces; i += 4)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s + i * 1024),
+                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+}
+// the issuing wave's LDS-DMA pieces have landed (vmcnt counts them like loads); the barrier behind it publishes them to the others
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // ====================================================================================================================
 // level 0, encoder: raw image (C0 = 3 or 4 float32 channels) -> 16 -> 16.  conv A flattens k = tap*C0 + channel and
 // pads it to KS steps of 32; its operand is gathered from the bf16 image tile with per-lane fixed offsets.
@@ -512,13 +522,8 @@ __global__ __launch_bounds__(256, 2) void psm_pair_stem16_kernel(PsmPairArgs a) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int px = lane & 15, kq = lane >> 4, xh = wave & 1;
   const int total = a.tiles_x * a.tiles_y * a.n_cases;
-  bf16x8 wA[KS];
-  const bf16x8* wa = reinterpret_cast<const bf16x8*>(a.wA) + lane;
-#pragma unroll
-  for (int s = 0; s < KS; ++s) wA[s] = wa[s * 64];
-  for (int i = tid; i < 6 * 64; i += 256) reinterpret_cast<uint4*>(wbl)[i] = a.wB[i];
+  PSTAMP_ENTRY();
   const bf16x8* wbf = wbl + lane;
-  const f32x4 bA = *reinterpret_cast<const f32x4*>(a.biasA + 4 * kq), bB = *reinterpret_cast<const f32x4*>(a.biasB + 4 * kq);
   int off[KS][8];
 #pragma unroll
   for (int s = 0; s < KS; ++s)
@@ -558,7 +563,16 @@ __global__ __launch_bounds__(256, 2) void psm_pair_stem16_kernel(PsmPairArgs a) 
   int it = 0, tile = tile_of(0, total);
   if (tile < 0) return;
   PsmPairTile cur = tile_calc<PSM_PAIR_STEM>(a, tile);
+  // one-shot prologue (see psm_pair_up16_kernel): the first tile, conv A's fragments and the biases to registers, conv B's
+  // fragments by LDS-DMA -- all requested before anything waits
   issue(cur);
+  bf16x8 wA[KS];
+  const bf16x8* wa = reinterpret_cast<const bf16x8*>(a.wA) + lane;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) wA[s] = wa[s * 64];
+  const f32x4 bA = *reinterpret_cast<const f32x4*>(a.biasA + 4 * kq), bB = *reinterpret_cast<const f32x4*>(a.biasB + 4 * kq);
+  dma_copy(reinterpret_cast<char*>(wbl), a.wB, 6, wave, lane);
+  dma_wait_all();                                            // (the first use of `ev` below waits for everything anyway)
 #ifdef PSM_STAMPS
   int g_it = 0;
 #endif
@@ -659,16 +673,6 @@ struct Dma {
 typedef Dma<64, PL, IH / 2, 17> DmaLow;                    // upsample source at its own resolution, 32 channels
 typedef Dma<32, P16, IH, P16> Dma16;                       // 16 channels, same resolution (35 columns: the paired tap of kx = 2 reads one further)
 static_assert(DmaLow::BYTES >= LOW_BYTES && Dma16::BYTES >= T16_BYTES, "whole pieces");
-
-// a lane-linear copy of n_pieces KiB (weight fragments as the host packed them) into LDS, piece i by wave i % 4
-__device__ __forceinline__ void dma_copy(char* dst, const void* src, int n_pieces, int wave, int lane) {
-  const char* s = reinterpret_cast<const char*>(src) + 16 * lane;
-  for (int i = wave; i < n_pieces; i += 4)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s + i * 1024),
-                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
-}
-// the issuing wave's LDS-DMA pieces have landed (vmcnt counts them like loads); the barrier behind it publishes them to the others
-__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ====================================================================================================================
 // level 0, decoder: upsample(32 channels) ++ skip(16 channels) -> 16 -> 16 (+ head).  Weights in LDS, input tiles by LDS-DMA.
@@ -801,6 +805,7 @@ __global__ __launch_bounds__(256, 2) void psm_pair32_kernel(PsmPairArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int px = lane & 15, kq = lane >> 4, xh = wave & 1;
   const int total = a.tiles_x * a.tiles_y * a.n_cases;
+  PSTAMP_ENTRY();
   constexpr int RA = MH / 2, RB = TY / 2;
   const int rA = RA * (wave >> 1), rB = RB * (wave >> 1);
   if (tid < 64) bias_l[tid] = tid < 32 ? a.biasA[tid] : a.biasB[tid - 32];

@@ -16,7 +16,7 @@ with UNetSurrogate(W, 256, 256, max_cases=n, precision="bf16") as net:
             acc.append(st)
         st = np.median(np.array(acc), axis=0)
         if len(sys.argv) > 2 and idx in (2, 14):       # 32-channel pair: raw stamp list of the first tile
-            print(f"layer {idx}:", " ".join(f"{v:6.2f}" for v in st[:24] if v >= 0))
+            print(f"layer {idx}: kernel entry {st[63]:6.2f};", " ".join(f"{v:6.2f}" for v in st[:24] if v >= 0))
             continue
         print(f"layer {idx}: kernel entry {st[63]:6.2f} (us after the earliest stamp); prologue stamps " + " ".join(f"{v:5.2f}" for v in st[56:63] if v >= 0))
         for it in range(7):
