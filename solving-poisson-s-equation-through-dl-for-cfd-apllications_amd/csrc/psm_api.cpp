@@ -85,6 +85,7 @@ struct psm_handle {
   int64_t c1_stride = 0;                // floats per block row of the Conv1D activation buffers
   float *d_mean_in = nullptr, *d_mean_out = nullptr;
   float4 *d_bpack_in = nullptr, *d_bpack_out = nullptr;
+  uint4* d_bpack_x6 = nullptr;          // encode basis as three bf16 planes in MFMA fragment order (pack_comp_in_x6): the large-batch encode
   float *d_ia = nullptr, *d_ib = nullptr, *d_sa = nullptr, *d_sb = nullptr;
   // plan
   bool planned = false;
@@ -533,6 +534,36 @@ struct Timer {                      // optional event pair around one kernel gro
   }
 };
 
+// K groups of the large-batch encode (psm_encode_x6_mt_kernel) for Mpad block rows, 1 = the one-slab-per-slice forms.
+// From 432 block rows up (>= 48 cases of 9 blocks): about 512 workgroups = two per CU, i.e. 512 / row groups K groups (64 cases:
+// nine row groups of 64 -> 56 groups of 4-5 slices, 16.5 MB of slabs; the one-slab-per-slice form writes 75 MB).  PSM_ENCODE_KGROUPS=n forces the group count (1: the old form).
+int encode_groups(const psm_handle* h, int Mpad) {
+  // crossover measured on one box (us per step, whole solve): 40 cases 101.6 one-slab-per-slice / 106.2 M-tiled, 48 cases 113.8 / 110.6,
+  // 56 cases 124.7 / 104.8, 64 cases 141.5 / 123.5 -- from 432 block rows (48 cases of 9 blocks) up
+  static const int min_rows = getenv("PSM_ENCODE_MT_MIN_ROWS") ? atoi(getenv("PSM_ENCODE_MT_MIN_ROWS")) : 432;
+  if (h->cfg.precision == PSM_PRECISION_BF16 || h->NT > 4 || Mpad % 32 != 0 || Mpad < min_rows || ((PSM_PIX_PER_SLICE * h->cfg.c_in) % 32) != 0) return 1;
+  if (h->x6_mode >= 0 && !(h->x6_mode & 1)) return 1;
+  static const int kg_env = getenv("PSM_ENCODE_KGROUPS") ? atoi(getenv("PSM_ENCODE_KGROUPS")) : 0;
+  const int row_groups = (Mpad + PSM_ENC_MT_ROWS - 1) / PSM_ENC_MT_ROWS;
+  // measured at 64 cases (one box, us: encode + reduce): 512 workgroups 49.1 + 6.2, 768: 61.4 + 8.2, 1024: 56.6 + 10.1, 1536: 56.2 + 12.9
+  static const int wg_target = getenv("PSM_ENCODE_WGS") ? atoi(getenv("PSM_ENCODE_WGS")) : 512;
+  int groups = std::max((h->n_slices + 7) / 8, std::min(h->n_slices, wg_target / row_groups));
+  if (kg_env > 0) groups = kg_env;
+  return (groups > 1 && groups <= h->n_slices && (h->n_slices + groups - 1) / groups <= 8) ? groups : 1;
+}
+// What that encode needs beyond the plan, built on first use and OUTSIDE any stream capture (it allocates): the basis pre-split
+// into three bf16 planes (1.5 x the bytes of the float32 pack), made on the device from the float32 pack.
+int ensure_encode_aux(psm_handle* h, int n_cases) {
+  const int Mpad = round_up(n_cases * h->B, 32);
+  if (h->d_bpack_x6 || encode_groups(h, Mpad) <= 1) return PSM_OK;
+  const size_t n16 = (size_t)h->n_slices * h->NT * (PSM_PIX_PER_SLICE * h->cfg.c_in / 16) * 3 * 64;
+  int rc = dev_alloc(h, &h->d_bpack_x6, n16);
+  if (rc) return rc;
+  HIPCHK(h, psm_launch_split_basis(h->d_bpack_in, h->d_bpack_x6, h->n_slices, h->NT, PSM_PIX_PER_SLICE * h->cfg.c_in, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return PSM_OK;
+}
+
 int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, float* d_fields, const float* d_row_scale,
                hipStream_t st, hipEvent_t* prof) {
   const int M = n_cases * h->B, Mpad = round_up(M, 32);
@@ -555,6 +586,13 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
   // psm_encode_x6_kernel) from two row tiles up, where the matrix phase is the longest serial phase of the launch
   // (8 cases: 17.6 -> 15.5 us, 64 cases: 75 -> 60 us).  PSM_X6=0 / 1 forces float32 / x6 everywhere.
   ea.x6 = h->x6_mode < 0 ? (Mpad > 32 ? 1 : 0) : ((h->x6_mode & 1) ? 1 : 0);
+  // Large case batches (>= 32 cases of 9 blocks): the M-tiled, wave-specialised x6 form (encode_groups / ensure_encode_aux)
+  ea.kgroup = 1;
+  int n_slabs = h->n_slices;
+  {
+    const int groups = (ea.x6 && !bf16) ? encode_groups(h, Mpad) : 1;
+    if (groups > 1 && h->d_bpack_x6) { ea.kgroup = groups; n_slabs = groups; ea.bpack_x6 = h->d_bpack_x6; }
+  }
 
   if (h->timed_kernel == PSM_K_ENCODE && !prof) {
     // dominant kernel: dispatch-level begin / end stamps (no marker packets around the launch)
@@ -583,7 +621,7 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
   const bool use_cf = use_bound && h->bound_cf && w.d_dots2;
   const int CB = h->cfg.c_out * h->B;
   if (&w == &h->ws0) { h->last_row_scale = d_row_scale; h->last_used_cf = use_cf; }
-  PsmReduceArgs ra{w.d_part, w.d_xin, h->d_ia, h->d_ib, h->n_slices, Mpad, h->ld_in};
+  PsmReduceArgs ra{w.d_part, w.d_xin, h->d_ia, h->d_ib, n_slabs, Mpad, h->ld_in};
   const int nl = (int)h->dense.size();
   auto dense_args = [&](int l, const float* cur, int ld_cur) {
     const DenseLayer& d = h->dense[l];
@@ -801,7 +839,9 @@ int solve_device(psm_handle* h, const float* d_grid, int n_cases, const float* o
   HIPCHK(h, hipSetDevice(h->cfg.device));
   if (!st) st = h->stream;
   const float* d_scale = nullptr;
-  int rc = prepare_scale(h, h->ws0, out_scale, n_cases, st, &d_scale);
+  int rc = ensure_encode_aux(h, n_cases);
+  if (rc) return rc;
+  rc = prepare_scale(h, h->ws0, out_scale, n_cases, st, &d_scale);
   if (rc) return rc;
   h->last_cases = n_cases;
   const bool eager = prof || h->timed_kernel >= 0 || !h->use_graph;
@@ -963,7 +1003,7 @@ void psm_destroy(psm_handle* h) {
   free_plan(h);
   free_geometry(h);
   for (auto& d : h->dense) { dev_free(d.W); dev_free(d.b); if (d.Wp) { (void)psm_dev_free(d.Wp); d.Wp = nullptr; } }
-  dev_free(h->d_mean_in); dev_free(h->d_mean_out); dev_free(h->d_bpack_in); dev_free(h->d_bpack_out);
+  dev_free(h->d_mean_in); dev_free(h->d_mean_out); dev_free(h->d_bpack_in); dev_free(h->d_bpack_out); dev_free(h->d_bpack_x6);
   if (h->scr_dev) (void)psm_dev_free(h->scr_dev);
   if (h->scr_pin) (void)hipHostFree(h->scr_pin);
   dev_free(h->d_comp_nat); dev_free(h->d_g2); dev_free(h->d_c2); dev_free(h->d_cnt); dev_free(h->d_row_of); dev_free(h->d_ownbits);
@@ -1016,6 +1056,7 @@ int psm_set_pca(psm_handle* h, const double* comp_in, const double* mean_in, con
     }
   } else {
   if ((rc = dev_upload(h, &h->d_bpack_in, pack_comp_in(comp_in, h->cfg.p_in, h->K_in, h->cfg.c_in, h->S, h->NT)))) return rc;
+  dev_free(h->d_bpack_x6);                                  // the pre-split copy of the large-batch encode is rebuilt on first use
   if ((rc = dev_upload(h, &h->d_bpack_out, pack_comp_out(comp_out, h->cfg.p_out, h->K_out, h->Gd)))) return rc;
   {
     std::vector<float> nat((size_t)h->ld_out * h->K_out, 0.f);
@@ -1659,6 +1700,7 @@ static int ring_capture(psm_handle* h, psm_handle::Slot& s, int n_cases, bool sc
 // Enqueue one ticket.  src / dst: where the grid is read from / the field is written to (the slot's pinned buffers or
 // registered caller memory).
 static int ring_launch(psm_handle* h, psm_handle::Slot& s, int n_cases, const float* out_scale, const float* src, float* dst) {
+  { int rc0 = ensure_encode_aux(h, n_cases); if (rc0) return rc0; }
   const size_t npix = (size_t)h->Ny * h->Nx;
   const size_t gin = (size_t)n_cases * npix * h->cfg.c_in * sizeof(float), gout = (size_t)n_cases * npix * h->cfg.c_out * sizeof(float);
   const bool scale = out_scale != nullptr;

@@ -24,7 +24,12 @@ struct PsmEncodeArgs {
   int M, Mpad, NT, ldp, S, c_in, aligned;
   int whole;               // 33..128 rows: stage all rows at once (PSM_ENCODE_CHUNKED=1 keeps the double-buffered chunks)
   int x6;                  // float32 contraction as six bf16 MFMA terms of exactly split operands (psm_encode_x6_kernel)
+  const uint4* bpack_x6;   // the basis pre-split into three bf16 planes, MFMA fragment order (pack_comp_in_x6); psm_encode_x6_mt_kernel only
+  int kgroup;              // > 1: the M-tiled, wave-specialised form for large case batches (psm_encode_x6_mt_kernel) with `kgroup` K GROUPS: a
+                           // workgroup owns one group of consecutive K slices x 96 block rows and writes ONE slab -- part [kgroup][Mpad][ldp];
+                           // 0 / 1: one slab per slice (psm_encode_x6_kernel / psm_encode_kernel)
 };
+constexpr int PSM_ENC_MT_ROWS = 64;    // block rows of a workgroup of the M-tiled encode (two 32-row MFMA tiles)
 
 struct PsmReduceArgs {
   const float* part; float* xin;       // xin [Mpad][ldp]
@@ -212,6 +217,8 @@ hipError_t psm_launch_res_dots(const PsmDotsArgs& d, const float* res, int ld_re
 hipError_t psm_read_stamps(unsigned long long* out);   // [64]; zeros unless built with -DPSM_STAMPS
 // ev_start / ev_stop (optional): stamped with the dispatch's own begin / end (hipExtLaunchKernel)
 hipError_t psm_launch_encode(const PsmEncodeArgs& a, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// basis [slices][NT][KS/8][64] float4 (pack_comp_in) -> three bf16 planes in MFMA fragment order [slices][NT][KS/16][plane 3][64] uint4
+hipError_t psm_launch_split_basis(const float4* bpack, uint4* out, int n_slices, int NT, int KS, hipStream_t s);
 // bf16 operand path (psm_bf16.hip): bpack / weights point to bf16 data in the same tilings
 hipError_t psm_launch_encode_bf16(const PsmEncodeArgs& a, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 hipError_t psm_launch_decode_bf16(const PsmDecodeArgs& a, hipStream_t s);

@@ -16,6 +16,7 @@
 // The K order inside a group of 8 is permuted (step j of group g uses k = 8g + 4h + j for
 // lane half h) so that one 16-byte read per lane feeds four MFMAs; both operands use it.
 #include "psm_kernels.h"
+#include <type_traits>
 
 #include <algorithm>
 #include <cstdlib>
@@ -32,9 +33,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifdef PSM_STAMPS
 __device__ unsigned long long g_psm_stamps[64];
 #define PSM_STAMP(buf, k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_psm_stamps[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define PSM_STAMP_T(tid_, k) do { if (blockIdx.x == 0 && threadIdx.x == (tid_) && (k) < 64) g_psm_stamps[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 hipError_t psm_read_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_psm_stamps), sizeof(g_psm_stamps)); }
 #else
 #define PSM_STAMP(buf, k) do { } while (0)
+#define PSM_STAMP_T(tid_, k) do { } while (0)
 hipError_t psm_read_stamps(unsigned long long* out) { for (int i = 0; i < 64; ++i) out[i] = 0; return hipSuccess; }
 #endif
 
@@ -459,6 +462,184 @@ __global__ __launch_bounds__(256) void psm_encode_x6_kernel(PsmEncodeArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// encode, x6 arithmetic, M-TILED, for large case batches (>= 32 cases per step; BASELINE configs[3] on one card runs 64).
+// psm_encode_x6_kernel gives every K slice of 192 its own workgroup, whatever the row count: at 576 block rows that is 256 slabs
+// of 576 x 128 floats = 75 MB written by the launch and read again by the reduce.  Here a workgroup owns a GROUP of consecutive K
+// slices x 64 block rows (two MFMA row tiles) x all components and keeps its accumulators in registers across the group: one slab
+// per K group (56 groups at 64 cases: 16.5 MB), the activations are read exactly once, the basis once per row group -- from the
+// XCD's L2 for all but the first (XCD-aware workgroup mapping below).
+//   wave w = component tile w (32 components), as in psm_encode_x6_kernel.  Its basis comes PRE-SPLIT (three bf16 planes in MFMA
+//   fragment order, psm_split_basis_kernel, 1.5 x the bytes): half a slice (96 k) at a time in 72 registers, loads and MFMAs only --
+//   splitting the float32 pack in the kernel cost 344 vector instructions per half-slice and the registers for the raw copy.  The
+//   activation rows of a (half-slice, row tile) step go through LDS (three bf16 planes, 32 rows, one buffer per row tile: 38 KB,
+//   two workgroups per CU); the rows of the next step are requested before a step's MFMAs and split + written after them.
+// Measured at 64 cases (one box): 49 us + 6 us reduce against 60 + 12 us for the one-slab-per-slice form.  Built and measured on
+// the way, none faster (profiles/r05_case_batch.txt): three row tiles with the float32 basis split in the kernel (49-56 us), an
+// eight-wave form with four multiplying and four staging waves per workgroup (57-64 us: the staging wave of a SIMD runs its ~260
+// instructions per step at half speed beside the multiplying wave), three workgroups per CU at 168 registers (spills: 64-82 us).
+// Summation order: k ascending inside a K group (MFMA accumulators), then the groups in slab order (psm_reduce_kernel) --
+// deterministic, but not the order of the one-slab-per-slice form (float32 rounding differs in the last bits).
+// ---------------------------------------------------------------------------
+template <int C_IN, bool ALIGNED>
+__global__ __launch_bounds__(256, 2) void psm_encode_x6_mt_kernel(PsmEncodeArgs a) {
+  constexpr int KS = PSM_PIX_PER_SLICE * C_IN;  // K elements per slice
+  constexpr int KH = KS / 2;                    // ... per half-slice
+  constexpr int NSH = KH / 16;                  // MFMA steps per half-slice
+  constexpr int LDB = KH + 4;                   // plane row stride in bf16 (KH / 2 + 2 dwords: conflict-free ds_read_b64 of 32 rows)
+  constexpr int QH = KH / 4;                    // float4 per activation row and half-slice
+  constexpr int NX = (32 * QH + 255) / 256;     // float4 per thread and step
+  constexpr int MT = PSM_ENC_MT_ROWS / 32;
+  constexpr int PL = 32 * LDB;                  // plane stride (bf16)
+  constexpr int MAXG = 8;                       // slices per K group, at most
+  static_assert(KH % 16 == 0 && MT == 2, "whole MFMA steps per half-slice; two named row tiles");
+  __shared__ __attribute__((aligned(16))) __bf16 ldsx[2 * 3 * PL];
+  __shared__ __attribute__((aligned(16))) float mean_l[MAXG * KS];       // the workgroup's K range of the mean
+  __shared__ int hs_off[2 * MAXG];                                        // float offset of half-slice hs within a block row
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n_slices = a.S * a.S / PSM_PIX_PER_SLICE;
+  // Workgroup -> (K group g, row group): the row groups of ONE K group read the same basis slices, so they get consecutive slots of
+  // ONE XCD (workgroup i runs on XCD i % 8, tools/xcc_probe.hip): id = ((g / 8) * row_groups + rg) * 8 + g % 8 -- the basis then comes
+  // from memory once per K group and from that XCD's L2 for the other row groups.  Placement is a speed matter only.  Ids whose K
+  // group does not exist (the last, partial block of eight) leave at once.
+  const int n_groups = a.kgroup, row_groups = (a.Mpad + PSM_ENC_MT_ROWS - 1) / PSM_ENC_MT_ROWS;
+  const int slot = blockIdx.x >> 3, g_blk = slot / row_groups, rg = slot - g_blk * row_groups;
+  const int grp = g_blk * 8 + (blockIdx.x & 7);
+  if (grp >= n_groups) return;
+  const int s_first = (int)(((long long)grp * n_slices) / n_groups);
+  const int s_end = (int)(((long long)(grp + 1) * n_slices) / n_groups);
+  const int n_hs = 2 * (s_end - s_first);                    // half-slices of this workgroup (2 .. 2 MAXG)
+  const int m0 = rg * PSM_ENC_MT_ROWS;
+  const int runs = a.S / PSM_PIX_PER_SLICE;
+  for (int k = tid; k < (s_end - s_first) * KS; k += 256) mean_l[k] = a.mean[(int64_t)s_first * KS + k];
+  if (tid < n_hs) {
+    const int s = s_first + (tid >> 1), r = s / runs, c0 = (s - r * runs) * PSM_PIX_PER_SLICE;
+    hs_off[tid] = (int)((int64_t)r * a.row_stride + (int64_t)c0 * C_IN + (tid & 1) * KH);
+  }
+  const int NT = a.NT;
+  const int t = min(wave, NT - 1);
+  const int i = lane & 31, h = lane >> 5;
+  // staging: 256 threads move one step's 32 rows x KH floats, float4 idx = tid + 256 u -> (row, q), fixed over the steps.  Everything a
+  // request needs is ONE 32-bit float offset per (row tile, piece) -- row base (a case batch of grids is < 2^31 floats) + column --
+  // plus the half-slice's scalar offset from LDS; padding rows are one bit each
+  int ldst[NX], o0[NX], o1[NX], mq[NX];
+  unsigned keep_bits = 0, live = 0;
+#pragma unroll
+  for (int u = 0; u < NX; ++u) {
+    const int idx = min(tid + 256 * u, 32 * QH - 1);
+    const int xrow = idx / QH, xq = idx - xrow * QH;
+    const int m = m0 + xrow;
+    o0[u] = (int)a.row_base[min(m, a.M - 1)] + 4 * xq;
+    o1[u] = (int)a.row_base[min(m + 32, a.M - 1)] + 4 * xq;
+    ldst[u] = xrow * LDB + 4 * xq;                            // bf16 offset within a plane
+    mq[u] = 4 * xq;
+    live |= (tid + 256 * u < 32 * QH) ? (1u << u) : 0u;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) keep_bits |= (m + 32 * mt) < a.M ? (1u << (mt * NX + u)) : 0u;
+  }
+  float4 xr[NX];
+  auto load_x = [&](int hs, auto mt_tag) {
+    constexpr int MTI = decltype(mt_tag)::value;
+    const float* base = a.grid + hs_off[hs];
+#pragma unroll
+    for (int u = 0; u < NX; ++u) {
+      const float* src = base + (MTI == 0 ? o0[u] : o1[u]);
+      if (ALIGNED) xr[u] = *reinterpret_cast<const float4*>(src);
+      else xr[u] = make_float4(src[0], src[1], src[2], src[3]);
+    }
+  };
+  auto write_x = [&](int hs, auto mt_tag, int buf) {
+    constexpr int MTI = decltype(mt_tag)::value;
+#pragma unroll
+    for (int u = 0; u < NX; ++u) {
+      const float k = ((keep_bits >> (MTI * NX + u)) & 1u) ? 1.f : 0.f;
+      const float4 mu = *reinterpret_cast<const float4*>(&mean_l[hs * KH + mq[u]]);
+      const float4 x = xr[u];
+      const f32x4 v = {(x.x - mu.x) * k, (x.y - mu.y) * k, (x.z - mu.z) * k, (x.w - mu.w) * k};
+      x6_bf16x4 vh, vm, vl;
+      psm_split3(v, vh, vm, vl);
+      if ((live >> u) & 1u) {
+        __bf16* dst = &ldsx[buf * 3 * PL + ldst[u]];
+        *reinterpret_cast<x6_bf16x4*>(dst) = vh;
+        *reinterpret_cast<x6_bf16x4*>(dst + PL) = vm;
+        *reinterpret_cast<x6_bf16x4*>(dst + 2 * PL) = vl;
+      }
+    }
+  };
+  // basis planes of a half-slice: [step][plane h, m, l] fragments as they lie in a.bpack_x6 (psm_split_basis_kernel): loads and
+  // MFMAs only.  ONE register set (72): the next half-slice is requested when the current one's last MFMA is issued; the wait is
+  // covered by the CU's other workgroups (three per CU at <= 168 registers)
+  x6_bf16x8 P[NSH][3];
+  auto load_b = [&](int hs) {
+    const uint4* p = a.bpack_x6 + ((((int64_t)(s_first + (hs >> 1)) * NT + t) * (2 * NSH) + (hs & 1) * NSH) * 3) * 64 + lane;
+#pragma unroll
+    for (int st = 0; st < NSH; ++st)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) P[st][q] = __builtin_bit_cast(x6_bf16x8, p[(st * 3 + q) * 64]);
+  };
+  f32x16 acc0 = {0}, acc1 = {0};
+  auto mfma_tile = [&](f32x16& c, int buf) {
+    const __bf16* arow = &ldsx[buf * 3 * PL + i * LDB + 4 * h];
+    x6_bf16x8 A[2][3];
+    auto rd = [&](int st, int sl) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        A[sl][pl] = psm_cat4(*reinterpret_cast<const x6_bf16x4*>(arow + pl * PL + 16 * st), *reinterpret_cast<const x6_bf16x4*>(arow + pl * PL + 16 * st + 8));
+    };
+    rd(0, 0);
+#pragma unroll
+    for (int st = 0; st < NSH; ++st) {
+      const int sl = st & 1;
+      if (st + 1 < NSH) rd(st + 1, sl ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      c = MFMA_X6(A[sl][1], P[st][1], c);            // small terms first: mm, lh, hl, mh, hm, hh
+      c = MFMA_X6(A[sl][2], P[st][0], c);
+      c = MFMA_X6(A[sl][0], P[st][2], c);
+      c = MFMA_X6(A[sl][1], P[st][0], c);
+      c = MFMA_X6(A[sl][0], P[st][1], c);
+      c = MFMA_X6(A[sl][0], P[st][0], c);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  typedef std::integral_constant<int, 0> T0; typedef std::integral_constant<int, 1> T1;
+  __syncthreads();                                            // mean_l, hs_off
+  load_x(0, T0{});
+  load_b(0);
+  __builtin_amdgcn_sched_barrier(0);
+  write_x(0, T0{}, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  // steps (half-slice hs, row tile): buffer = tile (two steps per half-slice).  The rows of the next step are requested before a
+  // step's MFMAs and written after them.  (The last half-slice is a second compile-time copy: behind a run-time "is there a next
+  // one" the plane registers became a conditional assignment and spilled.)
+  auto run_hs = [&](int hs, auto more_tag) {
+    constexpr bool more = decltype(more_tag)::value;
+    load_x(hs, T1{});
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_tile(acc0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    write_x(hs, T1{}, 1);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (more) load_x(hs + 1, T0{});
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_tile(acc1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) { load_b(hs + 1); write_x(hs + 1, T0{}, 0); }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  for (int hs = 0; hs + 1 < n_hs; ++hs) run_hs(hs, std::true_type{});
+  run_hs(n_hs - 1, std::false_type{});
+  if (wave < NT) {
+    float* out = a.part + ((int64_t)grp * a.Mpad + m0) * a.ldp + t * 32 + i;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) out[(int64_t)acc_row(q, h) * a.ldp] = acc0[q];
+    if (m0 + 32 < a.Mpad) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) out[(int64_t)(32 + acc_row(q, h)) * a.ldp] = acc1[q];
+    }
+  }
+}
+
 // x6 covers <= 128 components (NT <= 4) and an LDS footprint of three bf16 planes
 static bool psm_encode_x6_fits(const PsmEncodeArgs& a, size_t* lds, int* row_wgs) {
   // Negative result, kept as a knob: two workgroups per slice (64 rows each, half the LDS, two per CU so that one's matrix
@@ -477,6 +658,23 @@ hipError_t psm_launch_encode(const PsmEncodeArgs& a, hipStream_t st, hipEvent_t 
   size_t lds = (size_t)rows * (PSM_PIX_PER_SLICE * a.c_in + 4) * sizeof(float);
   size_t lds_x6 = 0;
   int row_wgs = 1;
+  if (a.x6 && a.kgroup > 1) {
+    // kgroup = number of K GROUPS here (the slab count); a group holds n_slices / kgroup slices, rounded either way, at most 8
+    if (a.NT > 4 || a.Mpad % 32 != 0 || a.kgroup > n_slices || (n_slices + a.kgroup - 1) / a.kgroup > 8 || !a.bpack_x6) return hipErrorInvalidValue;
+    const int row_groups = (a.Mpad + PSM_ENC_MT_ROWS - 1) / PSM_ENC_MT_ROWS;
+    const dim3 grid((unsigned)(((a.kgroup + 7) / 8) * row_groups * 8));      // XCD-aware 1-D mapping, see the kernel
+#define ENCM2(C, AL)                                                                                          \
+  if (ev_start) hipExtLaunchKernelGGL((psm_encode_x6_mt_kernel<C, AL>), grid, dim3(256), 0, st, ev_start, ev_stop, 0, a); \
+  else PSM_LAUNCH((psm_encode_x6_mt_kernel<C, AL>), grid, dim3(256), 0, st, a)
+#define ENCM(C) case C: if (a.aligned) { ENCM2(C, true); } else { ENCM2(C, false); } break;
+    switch (a.c_in) {
+      ENCM(1) ENCM(2) ENCM(3) ENCM(4)
+      default: return hipErrorInvalidValue;
+    }
+#undef ENCM
+#undef ENCM2
+    return hipGetLastError();
+  }
   if (a.x6 && psm_encode_x6_fits(a, &lds_x6, &row_wgs)) {
     lds = lds_x6;
 #define ENCX2(C, AL)                                                                                          \
@@ -503,6 +701,31 @@ hipError_t psm_launch_encode(const PsmEncodeArgs& a, hipStream_t st, hipEvent_t 
   }
 #undef ENC
 #undef ENC2
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// basis of the large-batch encode: the float32 pack (pack_comp_in: [slice][ntile][KS/8 groups][64 lanes] float4) split exactly into
+// three bf16 planes in the fragment order of the MFMA's second operand: [slice][ntile][KS/16 steps][plane h, m, l][64 lanes] x 8 bf16
+// (step st = groups 2 st and 2 st + 1 of the same lane).  Once per handle (psm_api.cpp, ensure_encode_aux).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void psm_split_basis_kernel(const float4* bpack, uint4* out, long long n_frag, int NS) {
+  const long long f = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);       // fragment = (slice, ntile, step)
+  const int lane = threadIdx.x & 63;
+  if (f >= n_frag) return;
+  const long long tile = f / NS; const int st = (int)(f - tile * NS);
+  const float4 g0 = bpack[(tile * (2 * NS) + 2 * st) * 64 + lane], g1 = bpack[(tile * (2 * NS) + 2 * st + 1) * 64 + lane];
+  x6_bf16x4 h0, m0, l0, h1, m1, l1;
+  psm_split3((f32x4){g0.x, g0.y, g0.z, g0.w}, h0, m0, l0);
+  psm_split3((f32x4){g1.x, g1.y, g1.z, g1.w}, h1, m1, l1);
+  out[(f * 3 + 0) * 64 + lane] = __builtin_bit_cast(uint4, psm_cat4(h0, h1));
+  out[(f * 3 + 1) * 64 + lane] = __builtin_bit_cast(uint4, psm_cat4(m0, m1));
+  out[(f * 3 + 2) * 64 + lane] = __builtin_bit_cast(uint4, psm_cat4(l0, l1));
+}
+hipError_t psm_launch_split_basis(const float4* bpack, uint4* out, int n_slices, int NT, int KS, hipStream_t st) {
+  if (KS % 16 != 0) return hipErrorInvalidValue;
+  const long long n_frag = (long long)n_slices * NT * (KS / 16);
+  PSM_LAUNCH(psm_split_basis_kernel, dim3((unsigned)((n_frag + 3) / 4)), dim3(256), 0, st, bpack, out, n_frag, KS / 16);
   return hipGetLastError();
 }
 

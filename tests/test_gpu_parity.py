@@ -182,6 +182,32 @@ def test_config3_case_batch_equals_single_cases():
     np.testing.assert_allclose(batch, singles, rtol=0, atol=2e-6 * np.abs(singles).max())
 
 
+def test_config3_all_64_cases_on_one_card():
+    """BASELINE config 3 as this pool can run it: the whole batch of 64 random-obstacle cases in ONE call on one card (576 block
+    rows: the M-tiled encode, psm_encode_x6_mt_kernel, one slab per K group).  Four of the cases against the oracle at the usual
+    tolerance, every case against the same case solved alone (other encode form and dense-layer path: float32 summation order
+    only), general path and one bound geometry per case slot."""
+    model = synthetic.make_model("deltas")
+    n = 64
+    grids = synthetic.random_obstacle_cases(n, 256, 256, seed=3).astype(np.float32)
+    scales = np.linspace(0.5, 1.5, n).astype(np.float32)
+    with GridSurrogate(model, 256, 256, max_cases=n) as sur:
+        batch = sur.solve(grids, out_scale=scales)
+        om = oracle_model(model)
+        for c in (0, 21, 42, 63):
+            om.out_scale = float(scales[c])
+            sol = orc.solve_grid(grids[c].astype(np.float64), om)
+            assert np.abs(batch[c] - sol.fields).max() <= 1e-4 * np.abs(sol.fields).max(), c
+        singles = np.stack([sur.solve(grids[c], out_scale=[scales[c]])[0] for c in range(n)])
+        np.testing.assert_allclose(batch, singles, rtol=0, atol=3e-6 * np.abs(singles).max())
+        assert sur.bind_geometry(grids)
+        bound = sur.solve(grids, out_scale=scales)
+        np.testing.assert_allclose(bound, batch, rtol=0, atol=5e-5 * np.abs(batch).max())
+        # 32 cases through the same handle: 288 block rows, other K grouping
+        half = sur.solve(grids[:32], out_scale=scales[:32])
+        np.testing.assert_allclose(half, singles[:32], rtol=0, atol=3e-6 * np.abs(singles).max())
+
+
 def test_config0_chapter5_real_weights_via_solver_module():
     grid, model = cases.build("chapter5_128x128_real")
     gold = cases.load_golden("chapter5_128x128_real")
