@@ -414,6 +414,7 @@ def emit(obj):
         sys.stdout.flush()
 
 
+Q_CHUNK = 10                 # solves per sample of the quantile pass (value_p50 / p10 / p90)
 LINE_LIMIT = 4096            # the driver keeps about 8 KB of stdout: the line must stay well inside it (tests assert < 4096)
 DETAIL_FILE = "bench_detail.json"
 
@@ -471,9 +472,17 @@ def compact_line(d):
         cb = d["cpu_baseline"]
         out["cpu_baseline"] = {"value": _sig(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
                                "sample": _clip(cb.get("sample", ""), 120)}
-    for k in ("l2_vs_oracle", "gpu_over_cpu", "value_end_to_end"):
+    for k in ("l2_vs_oracle", "gpu_over_cpu", "value_end_to_end", "value_p50", "value_p10", "value_p90"):
         if k in d:
             out[k] = _sig(d[k])
+    if "frac_pass" in d:
+        out["frac_pass"] = _sig(d["frac_pass"], 4)          # whole solve against its (time-weighted) ceiling, as every leg reports it
+    if isinstance(d.get("shipped_case"), dict):             # the reference's deployment shape in ITS unit (DLPoissonFoam.C:111: ms per call)
+        sc = d["shipped_case"]
+        out["shipped_case"] = ({"error": _clip(sc["error"], 80)} if "error" in sc else
+                               {"ms_per_call": _sig(sc.get("ms_per_call"), 4), "p10": _sig(sc.get("ms_per_call_p10"), 4), "p90": _sig(sc.get("ms_per_call_p90"), 4),
+                                "cells": sc.get("cells"), "grid": sc.get("grid"), "blocks": sc.get("blocks"),
+                                "cpu_ms": _sig((sc.get("cpu_baseline") or {}).get("value"), 4)})
     if isinstance(d.get("l2_vs_reference_goldens"), dict):   # reference-run golden vectors (one per block layout)
         out["l2_vs_reference_goldens"] = {_clip(k, 24): (_sig(v, 3) if isinstance(v, float) else _clip(v, 60)) for k, v in list(d["l2_vs_reference_goldens"].items())[:4]}
     for k in ("world_size_reported", "dry_run"):
@@ -656,6 +665,62 @@ def solver_boundary_leg(synthetic, device, steps):
             "what": "psm_solve on registered buffers (psm_pin_buffers), synchronous, Python call overhead included"}
 
 
+def shipped_case_leg(synthetic, device, steps, with_cpu):
+    """The reference's one real deployment shape, in the unit its solver prints (DLPoissonFoam.C:106-111, "DL pressure prediction &
+    data transport: %.2f ms"): ONE synchronous psm_solve per PISO step on the shipped case's shape -- 400 x 3000 grid (15 x 2 m at
+    delta 0.005), Chapter-5 layout = 104 blocks, the shipped weights.h5 network (45 -> 512 x 3 -> 48; tests/golden/chapter5_weights.npz),
+    a channel mesh of ~31 k cells (the shipped meshes: 31 k - 207 k) -- cells[N,5] float64 in, p[N] float64 out, the solver's arrays
+    registered (psm_pin_buffers).  Beside it the C port of the grid solve on the same grid (no mesh interpolation on the CPU side)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cases
+    from psm_amd import SolverModule
+    W, maxs4, maxs_pca = cases.real_chapter5_weights()
+    model = synthetic.make_model("chapter5", p_in=45, p_out=48, weights=W)
+    model.in_a, model.out_a = float(maxs_pca[0]), float(maxs_pca[1])
+    array, top, obst = synthetic.channel_mesh(Lx=15.0, Ly=2.0, h=0.031, cx=3.0, R=0.25)
+    sm = SolverModule(model, tuple(float(v) for v in maxs4), device=device, geometry="native")
+    t0 = time.perf_counter()
+    sm.init_func(array, top, obst)
+    t_init = time.perf_counter() - t0
+    cells, p = np.ascontiguousarray(array, np.float64).copy(), np.empty(array.shape[0], np.float64)
+    sm.pin(cells, p)
+    for _ in range(20):
+        sm.py_func(cells, out=p)
+    per = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        sm.py_func(cells, out=p)
+        per.append(time.perf_counter() - t0)
+    per.sort()
+    sm.unpin()
+    leg = {"what": "one synchronous psm_solve per call on the reference's shipped case shape (DLPoissonFoam.C:106-111 prints this time in ms)",
+           "ms_per_call": per[len(per) // 2] * 1e3, "ms_per_call_p10": per[len(per) // 10] * 1e3, "ms_per_call_p90": per[(len(per) * 9) // 10] * 1e3,
+           "calls": steps, "cells": int(array.shape[0]), "grid": [int(sm._sur.ny), int(sm._sur.nx)], "blocks": int(sm._sur.B),
+           "components": [45, 48], "geometry_bound": bool(sm._sur.geometry_bound), "init_func_s": t_init,
+           "finite": bool(np.isfinite(p).all()), "unit": "ms per psm_solve call (registered buffers, Python call overhead included)"}
+    if with_cpu:
+        try:
+            from oracle import psm_cpu                       # checker / cpu_baseline leg only
+            from psm_amd import hostinfo
+            cores = hostinfo.available_cpus()
+            om = oracle_model(model)
+            g = synthetic.channel_grid(int(sm._sur.ny), int(sm._sur.nx), seed=1).astype(np.float64)
+            cm = psm_cpu.CpuModel(om)
+            psm_cpu.solve_grid(g, cm, threads=int(cores))
+            n, t0 = 0, time.perf_counter()
+            while n < 20 and (n == 0 or time.perf_counter() - t0 < 6.0):
+                psm_cpu.solve_grid(g, cm, threads=int(cores))
+                n += 1
+            dt = (time.perf_counter() - t0) / n
+            leg["cpu_baseline"] = {"value": dt * 1e3, "unit": "ms per grid solve", "cores": int(cores), "kind": "port",
+                                   "sample": f"{n} solves of the C / OpenMP port oracle/psm_cpu.c on the same {g.shape[0]}x{g.shape[1]} grid "
+                                             f"(grid in, field out: no mesh interpolation), {int(cores)} threads"}
+        except Exception as e:
+            leg["cpu_baseline"] = {"error": repr(e)[:200]}
+    return leg
+
+
 def host_rates(sur, grids, n_cases, steps, warmup, modes):
     """psm_bench_host (C++ loop through the public C-ABI): {mode name: (solves/s per rank, last field)}."""
     import ctypes as C
@@ -672,19 +737,21 @@ def host_rates(sur, grids, n_cases, steps, warmup, modes):
     return out
 
 
-def time_kernels(sur, d_grid, n_cases, d_fields, steps):
-    """psm_time_kernels -> [(name, avg_us, launches)] in launch order."""
+def time_kernels(sur, d_grid, n_cases, d_fields, steps, quantiles=False):
+    """psm_time_kernels_q -> [(name, MEDIAN us of the kernel's dispatches, launches)] in launch order; with ``quantiles`` a fourth
+    element (p10 us, p90 us).  Median, not mean: one slow dispatch among a few hundred must not pick the dominant kernel."""
     import ctypes as C
     cap = 32
     names = C.create_string_buffer(cap * 64)
-    ms = (C.c_double * cap)()
+    med, p10, p90 = (C.c_double * cap)(), (C.c_double * cap)(), (C.c_double * cap)()
     cnt = (C.c_int64 * cap)()
     nk = C.c_int32()
-    sur._chk(sur.lib.psm_time_kernels(sur.h, C.c_void_p(d_grid), n_cases, C.c_void_p(d_fields), steps, names, ms, cnt, cap, C.byref(nk)))
+    sur._chk(sur.lib.psm_time_kernels_q(sur.h, C.c_void_p(d_grid), n_cases, C.c_void_p(d_fields), steps, names, med, p10, p90, cnt, cap, C.byref(nk)))
     out = []
     for k in range(min(nk.value, cap)):
         nm = names.raw[k * 64:(k + 1) * 64].split(b"\0", 1)[0].decode()
-        out.append((nm, ms[k] / max(cnt[k], 1) * 1e3, int(cnt[k])))
+        rec = (nm, float(med[k]), int(cnt[k]))
+        out.append(rec + ((float(p10[k]), float(p90[k])),) if quantiles else rec)
     return out
 
 
@@ -723,7 +790,7 @@ def pca_roofline(sur, model, ny, nx, n_cases, precision, d_grid, d_fields, steps
         roof.update(achieved=tfl, peak=peak_f, unit="TFLOP/s", frac=f_mfma)
     roof.update(traffic=traffic, traffic_source=traffic_src, algorithmic_bytes=dom["algorithmic_bytes"], algorithmic_flops=dom["algorithmic_flops"],
                 avg_launch_us=dom["avg_us"], launches=int(dom["launches_per_solve"] * steps), frac_hbm=f_hbm, frac_mfma=f_mfma,
-                selection="largest measured time per solve among all launches of the instrumented pass (every Dense layer is its own "
+                selection="largest MEDIAN dispatch time per solve among all launches of the instrumented pass (every Dense layer is its own "
                           "entry: the two hidden layers run the same template instantiation, which rocprofv3 lists as one kernel "
                           "with two calls per solve); bound = the ceiling it sits closer to",
                 whole_solve={"algorithmic_bytes": tot_b, "algorithmic_flops": af["total"],
@@ -782,7 +849,7 @@ def unet_leg(name, args, torch, pdist, rank, world, local_rank, backend, steps, 
     else:
         roof.update(achieved=dom["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=f_hbm)
     roof.update(traffic=None, avg_launch_us=dom["avg_us"], algorithmic_flops=dom["flops"], algorithmic_bytes=dom["algorithmic_bytes"],
-                frac_mfma=f_mfma, frac_hbm=f_hbm, selection="the launch of the forward pass with the largest dispatch-stamped duration",
+                frac_mfma=f_mfma, frac_hbm=f_hbm, selection="the launch of the forward pass with the largest MEDIAN dispatch-stamped duration",
                 whole_pass={"algorithmic_flops": flops, "achieved_TFLOPs": achieved,
                             # every launch against the pipe it runs on: ceiling = sum(t_i * peak_i) / sum(t_i); a pass whose launches
                             # are each below their own peak cannot exceed 1
@@ -893,6 +960,7 @@ def main():
     ap.add_argument("--inputs", type=int, default=4, help="distinct input grids rotated through (all resident in HBM)")
     ap.add_argument("--no-bind", action="store_true", help="do not bind the geometry: general 8-launch path")
     ap.add_argument("--no-extras", action="store_true", help="skip the end-to-end, case-batch and other legs")
+    ap.add_argument("--no-shipped-case", action="store_true", help="skip the shipped_case leg (psm_solve on the reference's 400 x 3000 / 104-block shape)")
     ap.add_argument("--legs", default=",".join(DEFAULT_LEGS), help="comma-separated extra legs at N = 1 (BASELINE configs and conv path); 'none' skips them")
     ap.add_argument("--dry-run", action="store_true", help="launcher / process-group plumbing only (no GPU work)")
     ap.add_argument("--workload", default="config1", choices=sorted(WORKLOADS) + sorted(UNET_WORKLOADS),
@@ -989,10 +1057,31 @@ def main():
     value = pdist.aggregate_throughput(NC, args.steps, world, dt_max)
     roofline = pca_roofline(sur, model, NY, NX, NC, precision, d_in[0].data_ptr(), d_out[0].data_ptr(), args.steps, dt_max / args.steps,
                             args.workload, bound, kt=kt_head)
+    # BASELINE.md section 2's protocol beside the contract's K-step mean: >= 200 timed samples, median and 10th / 90th percentile.
+    # A sample = Q_CHUNK consecutive solves between two events on the stream (back to back, no host synchronisation), i.e. the
+    # per-solve time averaged over a chunk.  (An event after EVERY solve makes the pass host-bound -- 31 us of submission per
+    # solve -- and the idle gaps let the chip clock up: its median interval read 25 us against 34.5 us in steady state.)
+    n_q = 200
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_q + 1)]
+    for i in range(n_q):
+        evs[i].record()
+        for j in range(Q_CHUNK):
+            step(i * Q_CHUNK + j)
+    evs[n_q].record()
+    torch.cuda.synchronize()
+    per_ms = sorted(evs[i].elapsed_time(evs[i + 1]) / Q_CHUNK for i in range(n_q))
+    q_ms = {"p50": per_ms[n_q // 2], "p10": per_ms[n_q // 10], "p90": per_ms[(n_q * 9) // 10]}
 
     out = {
         "metric": "pressure-solves/sec (256x256 U->p inference)",
         "value": value, "value_device_resident": value,
+        # rates at the median / 10th / 90th percentile of the per-solve time of n_q event-separated solves on this rank (x world: case-
+        # sharded, no collective); p10 is the FAST end of the time distribution, i.e. the high rate
+        "value_p50": NC * world / (q_ms["p50"] * 1e-3), "value_p10": NC * world / (q_ms["p90"] * 1e-3), "value_p90": NC * world / (q_ms["p10"] * 1e-3),
+        "per_solve_quantiles": {"solves": n_q * Q_CHUNK, "samples": n_q, "solves_per_sample": Q_CHUNK, "ms_p50": q_ms["p50"], "ms_p10": q_ms["p10"], "ms_p90": q_ms["p90"],
+                                "what": "one event per chunk of consecutive solves, back to back on the stream; a sample = the chunk's time per solve; "
+                                        "value_p10 / value_p90 = rate at the slow / fast decile"},
+        "frac_pass": roofline["whole_solve"]["frac"],
         "unit": "solves/s", "n_gpus": world, "world_size_reported": world_reported, "devices": devices,
         "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -1041,6 +1130,13 @@ def main():
             out["end_to_end"]["psm_solve"] = solver_boundary_leg(synthetic, local_rank, max(200, min(args.steps, 2000)))
         except Exception as e:                                # reported, not fatal for the headline
             out["end_to_end"]["psm_solve"] = {"error": repr(e)[:200]}
+
+    # ---- the reference's deployment shape in its own unit (ms per call), N = 1 default run only
+    if not args.no_extras and world == 1 and args.workload == "config1" and not args.no_shipped_case:
+        try:
+            out["shipped_case"] = shipped_case_leg(synthetic, local_rank, 200, rank == 0 and not args.no_cpu_baseline)
+        except Exception as e:                                # reported, not fatal for the headline
+            out["shipped_case"] = {"error": repr(e)[:200]}
 
     # ---- parity against the reference-run golden vectors (non-degenerate grids), on the line beside l2_vs_oracle
     if not args.no_extras and rank == 0 and world == 1 and args.workload == "config1" and not args.no_cpu_baseline:

@@ -396,6 +396,10 @@ int psm_get_kernel_timing(psm_handle* h, int32_t kernel, double* total_ms, int64
  * *n_kernels the number of distinct kernels (may exceed cap). */
 int psm_time_kernels(psm_handle* h, const float* d_grid, int32_t n_cases, float* d_fields, int32_t steps, char* names,
                      double* total_ms, int64_t* launches, int32_t cap, int32_t* n_kernels);
+/* The same pass, reported per kernel as the MEDIAN and the 10th / 90th percentile of its dispatch durations in microseconds
+ * (p10_us / p90_us may be NULL): one slow dispatch moves a mean of a few hundred samples, not these.  bench.py's roofline uses it. */
+int psm_time_kernels_q(psm_handle* h, const float* d_grid, int32_t n_cases, float* d_fields, int32_t steps, char* names,
+                       double* median_us, double* p10_us, double* p90_us, int64_t* launches, int32_t cap, int32_t* n_kernels);
 /* Host-buffer throughput measured from a C++ loop on the calling thread (no per-call binding overhead), through the
  * public entries only: `steps` solves of the `n_inputs` host grids [n_inputs][n_cases, ny, nx, c_in] in rotation after
  * `warmup` untimed ones; *seconds = wall time of the timed solves (steady_clock, first submission to last result).

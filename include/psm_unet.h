@@ -94,6 +94,9 @@ int psm_unet_plan_info(const psm_unet* u, int32_t idx, int32_t* info);
  * per pass (0 or 1); names [num_convs][64] (may be NULL): the kernel instantiation that ran. */
 int psm_unet_time_kernels(psm_unet* u, const float* d_grid, int32_t n_cases, float* d_field, int32_t steps, double* us,
                           int32_t* launches, char* names);
+/* The same pass, per launch the MEDIAN and the 10th / 90th percentile (may be NULL) of its dispatch durations in microseconds. */
+int psm_unet_time_kernels_q(psm_unet* u, const float* d_grid, int32_t n_cases, float* d_field, int32_t steps, double* median_us,
+                            double* p10_us, double* p90_us, int32_t* launches, char* names);
 /* Diagnostic builds (-DPSM_STAMPS) only: runs the network up to and including convolution `idx` on the staged input of
  * the last psm_unet_forward and returns workgroup-0 time stamps of that last layer, stamps_us[64] in microseconds
  * after the first (-1: not reached; all -1 in the shipped library). */

@@ -104,6 +104,8 @@ SIGNATURES = {
     "psm_event_pair_overhead": (C.c_int, [_hp, C.c_int32, C.POINTER(C.c_double)]),
     "psm_time_kernels": (C.c_int, [_hp, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_char_p, C.POINTER(C.c_double),
                                    C.POINTER(C.c_int64), C.c_int32, _i32p]),
+    "psm_time_kernels_q": (C.c_int, [_hp, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                     C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32, _i32p]),
     "psm_bench_host": (C.c_int, [_hp, _f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                  C.POINTER(C.c_double), _f32p]),
     "psm_layout": (C.c_int, [C.c_int32] * 5 + [_i32p, C.c_int32, _i32p, _i32p]),
@@ -141,6 +143,8 @@ SIGNATURES_UNET = {
     "psm_unet_ksplit": (C.c_int, [_up, C.c_int32]),
     "psm_unet_plan_info": (C.c_int, [_up, C.c_int32, _i32ptr]),
     "psm_unet_time_kernels": (C.c_int, [_up, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_double), _i32ptr, C.c_char_p]),
+    "psm_unet_time_kernels_q": (C.c_int, [_up, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                          C.POINTER(C.c_double), _i32ptr, C.c_char_p]),
     "psm_unet_debug_run_layer": (C.c_int, [_up, C.c_int32, _f32p]),
     "psm_unet_flops": (C.c_int64, [_up]),
 }

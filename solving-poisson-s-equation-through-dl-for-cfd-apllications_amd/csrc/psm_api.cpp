@@ -2558,17 +2558,14 @@ int psm_get_kernel_timing(psm_handle* h, int32_t kernel, double* total_ms, int64
 
 // Dispatch-level time of EVERY kernel of the solve path: `steps` solves through the same launch sequence as
 // psm_solve_grid_device, each dispatch stamped by hipExtLaunchKernelGGL (its own begin / end, what rocprofv3 reads).
-int psm_time_kernels(psm_handle* h, const float* d_grid, int32_t n_cases, float* d_fields, int32_t steps, char* names,
-                     double* total_ms, int64_t* launches, int32_t cap, int32_t* n_kernels) {
-  if (!h || !names || !total_ms || !launches || !n_kernels || cap < 1 || steps < 1) return PSM_ERR_ARG;
+// every dispatch of `steps` solves with its own begin / end stamps: per kernel (launch order of first appearance) the samples in ms
+static int collect_kernel_samples(psm_handle* h, const float* d_grid, int32_t n_cases, float* d_fields, int32_t steps,
+                                  std::vector<std::string>& seen, std::vector<std::vector<float>>& samp) {
   if (!h->planned) return fail(h, PSM_ERR_STATE, "psm_plan_grid has not been called");
   if (h->timed_kernel >= 0) return fail(h, PSM_ERR_STATE, "psm_enable_kernel_timing is active");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   PsmLaunchProbe probe;
-  std::vector<std::string> seen;
-  std::vector<double> ms;
-  std::vector<int64_t> cnt;
   auto drain = [&]() -> int {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (auto& r : probe.recs) {
@@ -2585,8 +2582,8 @@ int psm_time_kernels(psm_handle* h, const float* d_grid, int32_t n_cases, float*
       if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) {
         size_t k = 0;
         while (k < seen.size() && seen[k] != nm) ++k;
-        if (k == seen.size()) { seen.push_back(nm); ms.push_back(0.0); cnt.push_back(0); }
-        ms[k] += t; cnt[k] += 1;
+        if (k == seen.size()) { seen.push_back(nm); samp.emplace_back(); }
+        samp[k].push_back(t);
       }
       probe.pool.push_back(r.e0); probe.pool.push_back(r.e1);
     }
@@ -2606,11 +2603,46 @@ int psm_time_kernels(psm_handle* h, const float* d_grid, int32_t n_cases, float*
   if (rc == PSM_OK) rc = drain(); else (void)hipStreamSynchronize(h->stream);
   for (auto& r : probe.recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto e : probe.pool) (void)hipEventDestroy(e);
+  return rc;
+}
+
+int psm_time_kernels(psm_handle* h, const float* d_grid, int32_t n_cases, float* d_fields, int32_t steps, char* names,
+                     double* total_ms, int64_t* launches, int32_t cap, int32_t* n_kernels) {
+  if (!h || !names || !total_ms || !launches || !n_kernels || cap < 1 || steps < 1) return PSM_ERR_ARG;
+  std::vector<std::string> seen;
+  std::vector<std::vector<float>> samp;
+  int rc = collect_kernel_samples(h, d_grid, n_cases, d_fields, steps, seen, samp);
   if (rc) return rc;
   *n_kernels = (int32_t)seen.size();
   for (int k = 0; k < (int)seen.size() && k < cap; ++k) {
     snprintf(names + (size_t)k * 64, 64, "%s", seen[k].c_str());
-    total_ms[k] = ms[k]; launches[k] = cnt[k];
+    double tot = 0.0;
+    for (float t : samp[k]) tot += t;
+    total_ms[k] = tot; launches[k] = (int64_t)samp[k].size();
+  }
+  return PSM_OK;
+}
+
+// the same pass, per kernel the MEDIAN and the 10th / 90th percentile of its dispatch durations (microseconds): one slow dispatch
+// (a clock dip, a page fault) moves a mean of 20-200 samples, not these
+int psm_time_kernels_q(psm_handle* h, const float* d_grid, int32_t n_cases, float* d_fields, int32_t steps, char* names,
+                       double* median_us, double* p10_us, double* p90_us, int64_t* launches, int32_t cap, int32_t* n_kernels) {
+  if (!h || !names || !median_us || !launches || !n_kernels || cap < 1 || steps < 1) return PSM_ERR_ARG;
+  std::vector<std::string> seen;
+  std::vector<std::vector<float>> samp;
+  int rc = collect_kernel_samples(h, d_grid, n_cases, d_fields, steps, seen, samp);
+  if (rc) return rc;
+  *n_kernels = (int32_t)seen.size();
+  for (int k = 0; k < (int)seen.size() && k < cap; ++k) {
+    snprintf(names + (size_t)k * 64, 64, "%s", seen[k].c_str());
+    std::vector<float>& v = samp[k];
+    std::sort(v.begin(), v.end());
+    const size_t n = v.size();
+    auto q = [&](double f) { return n ? (double)v[std::min(n - 1, (size_t)(f * (double)(n - 1) + 0.5))] * 1e3 : 0.0; };
+    median_us[k] = q(0.5);
+    if (p10_us) p10_us[k] = q(0.1);
+    if (p90_us) p90_us[k] = q(0.9);
+    launches[k] = (int64_t)n;
   }
   return PSM_OK;
 }

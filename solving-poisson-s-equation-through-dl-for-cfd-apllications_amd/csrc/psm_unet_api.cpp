@@ -724,16 +724,15 @@ int psm_unet_profile(psm_unet* u, const float* d_grid, int32_t n_cases, float* d
   return rc;
 }
 
-int psm_unet_time_kernels(psm_unet* u, const float* d_grid, int32_t n_cases, float* d_field, int32_t steps, double* us, int32_t* launches,
-                          char* names) {
-  if (!u || !us || steps < 1) return PSM_ERR_ARG;
+// every dispatch of `steps` forward passes with its own begin / end stamps: per convolution that owns a launch, the samples in ms
+static int unet_collect_samples(psm_unet* u, const float* d_grid, int32_t n_cases, float* d_field, int32_t steps,
+                                std::vector<std::vector<float>>& samp, char* names) {
   if (!u->planned) return fail(u, PSM_ERR_STATE, "psm_unet_plan has not been called");
   if (!d_grid || !d_field || n_cases < 1 || n_cases > u->max_cases) return fail(u, PSM_ERR_ARG, "bad arguments");
   UCHK(u, hipSetDevice(u->device));
   UCHK(u, hipStreamSynchronize(u->stream));
   const size_t nc = u->convs.size();
-  std::vector<double> tot(nc, 0.0);
-  std::vector<int64_t> cnt(nc, 0);
+  samp.assign(nc, {});
   if (names) std::memset(names, 0, nc * 64);
   PsmLaunchProbe probe;
   auto drain = [&]() -> int {
@@ -741,7 +740,7 @@ int psm_unet_time_kernels(psm_unet* u, const float* d_grid, int32_t n_cases, flo
     for (auto& r : probe.recs) {
       float t = 0.f;
       if (r.tag >= 0 && r.tag < (int)nc && hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) {
-        tot[r.tag] += t; cnt[r.tag] += 1;
+        samp[r.tag].push_back(t);
         if (names && !names[(size_t)r.tag * 64]) {
           std::string nm(r.name);
           while (!nm.empty() && (nm[0] == '(' || nm[0] == ' ')) nm.erase(0, 1);
@@ -764,10 +763,40 @@ int psm_unet_time_kernels(psm_unet* u, const float* d_grid, int32_t n_cases, flo
   if (rc == PSM_OK) rc = drain(); else (void)hipStreamSynchronize(u->stream);
   for (auto& r : probe.recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto e : probe.pool) (void)hipEventDestroy(e);
+  return rc;
+}
+
+int psm_unet_time_kernels(psm_unet* u, const float* d_grid, int32_t n_cases, float* d_field, int32_t steps, double* us, int32_t* launches,
+                          char* names) {
+  if (!u || !us || steps < 1) return PSM_ERR_ARG;
+  std::vector<std::vector<float>> samp;
+  int rc = unet_collect_samples(u, d_grid, n_cases, d_field, steps, samp, names);
   if (rc) return rc;
-  for (size_t i = 0; i < nc; ++i) {
-    us[i] = cnt[i] ? tot[i] / (double)cnt[i] * 1e3 : 0.0;
-    if (launches) launches[i] = (int32_t)(cnt[i] / steps);
+  for (size_t i = 0; i < samp.size(); ++i) {
+    double tot = 0.0;
+    for (float t : samp[i]) tot += t;
+    us[i] = samp[i].empty() ? 0.0 : tot / (double)samp[i].size() * 1e3;
+    if (launches) launches[i] = (int32_t)(samp[i].size() / (size_t)steps);
+  }
+  return PSM_OK;
+}
+
+// the same pass, per launch the MEDIAN and the 10th / 90th percentile of its dispatch durations (microseconds)
+int psm_unet_time_kernels_q(psm_unet* u, const float* d_grid, int32_t n_cases, float* d_field, int32_t steps, double* median_us,
+                            double* p10_us, double* p90_us, int32_t* launches, char* names) {
+  if (!u || !median_us || steps < 1) return PSM_ERR_ARG;
+  std::vector<std::vector<float>> samp;
+  int rc = unet_collect_samples(u, d_grid, n_cases, d_field, steps, samp, names);
+  if (rc) return rc;
+  for (size_t i = 0; i < samp.size(); ++i) {
+    std::vector<float>& v = samp[i];
+    std::sort(v.begin(), v.end());
+    const size_t n = v.size();
+    auto q = [&](double f) { return n ? (double)v[std::min(n - 1, (size_t)(f * (double)(n - 1) + 0.5))] * 1e3 : 0.0; };
+    median_us[i] = q(0.5);
+    if (p10_us) p10_us[i] = q(0.1);
+    if (p90_us) p90_us[i] = q(0.9);
+    if (launches) launches[i] = (int32_t)(n / (size_t)steps);
   }
   return PSM_OK;
 }

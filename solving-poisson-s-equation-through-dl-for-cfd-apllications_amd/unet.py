@@ -162,18 +162,21 @@ class UNetSurrogate:
         self._chk(self.lib.psm_unet_plan_info(self.h, idx, info))
         return [int(v) for v in info]
 
-    def time_kernels(self, d_grid: int, n_cases: int, d_field: int, steps: int = 20):
-        """Dispatch-level timing (psm_unet_time_kernels) -> [(first conv index, convs covered, kernel name, avg us)] per launch."""
+    def time_kernels(self, d_grid: int, n_cases: int, d_field: int, steps: int = 20, quantiles: bool = False):
+        """Dispatch-level timing -> per launch (first conv index, convs covered, kernel name, MEDIAN us) -- psm_unet_time_kernels_q;
+        with ``quantiles`` a fifth element (p10 us, p90 us).  (The mean of psm_unet_time_kernels let one slow dispatch pick the
+        "dominant" launch of a bench line.)"""
         n = len(self.shapes)
-        us = (C.c_double * n)()
+        us, p10, p90 = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
         cnt = (C.c_int32 * n)()
         names = C.create_string_buffer(n * 64)
-        self._chk(self.lib.psm_unet_time_kernels(self.h, d_grid, n_cases, d_field, steps, us, cnt, names))
+        self._chk(self.lib.psm_unet_time_kernels_q(self.h, d_grid, n_cases, d_field, steps, us, p10, p90, cnt, names))
         starts = [i for i in range(n) if cnt[i] > 0]
         out = []
         for j, i in enumerate(starts):
             end = starts[j + 1] if j + 1 < len(starts) else n
-            out.append((i, list(range(i, end)), names.raw[i * 64:(i + 1) * 64].split(b"\0", 1)[0].decode(), float(us[i])))
+            rec = (i, list(range(i, end)), names.raw[i * 64:(i + 1) * 64].split(b"\0", 1)[0].decode(), float(us[i]))
+            out.append(rec + ((float(p10[i]), float(p90[i])),) if quantiles else rec)
         return out
 
     def conv_flops(self, idx: int) -> int:

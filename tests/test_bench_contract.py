@@ -69,6 +69,28 @@ def test_line_built_from_a_recorded_run_fits_the_driver():
     assert len(line) < LINE_LIMIT and KEYS <= set(json.loads(line))
 
 
+def test_round5_keys_reach_the_line():
+    """Round-5 additions to the record -- the per-solve quantiles (BASELINE.md section 2's protocol: >= 200 solves, median and the
+    10th / 90th percentile), the headline's frac_pass and the shipped_case leg (the reference's deployment shape in ITS unit, ms per
+    psm_solve call, DLPoissonFoam.C:111) -- are carried by the compact line, rounded, and the line still fits the driver."""
+    b = _bench_module()
+    detail = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_detail_r03.json")))
+    detail.update(value_p50=29123.456789, value_p10=27001.2, value_p90=30555.9, frac_pass=0.161234567,
+                  per_solve_quantiles={"solves": 200, "ms_p50": 0.0343, "ms_p10": 0.0327, "ms_p90": 0.037},
+                  shipped_case={"what": "x" * 400, "ms_per_call": 0.2865123, "ms_per_call_p10": 0.27, "ms_per_call_p90": 0.31, "calls": 200, "cells": 31234,
+                                "grid": [400, 3000], "blocks": 104, "components": [45, 48], "geometry_bound": True, "init_func_s": 4.2, "finite": True,
+                                "cpu_baseline": {"value": 812.3456, "unit": "ms per grid solve", "cores": 8, "kind": "port", "sample": "y" * 300}})
+    line = b.compact_line(detail)
+    assert len(line) < LINE_LIMIT
+    d = json.loads(line)
+    assert d["value_p50"] == 29123.5 and d["value_p10"] == 27001.2 and d["value_p90"] == 30555.9 and d["frac_pass"] == 0.1612
+    assert d["shipped_case"] == {"ms_per_call": 0.2865, "p10": 0.27, "p90": 0.31, "cells": 31234, "grid": [400, 3000], "blocks": 104, "cpu_ms": 812.3}
+    assert d["value_p10"] <= d["value_p50"] <= d["value_p90"]
+    # a failed leg is reported, not fatal, and bounded
+    line = b.compact_line(dict(detail, shipped_case={"error": "z" * 1000}))
+    assert len(line) < LINE_LIMIT and len(json.loads(line)["shipped_case"]["error"]) <= 80
+
+
 def test_eight_ranks_dry_run(tmp_path):
     """First contact of the N = 8 launch, rehearsed on the CPU: `bench.py --gpus 8 --dry-run` starts eight gloo ranks itself,
     the process group reports 8, configs[3]'s 64 cases are sharded 8 per rank (rank 3 owns cases 24..31) and the N > 1 line
@@ -203,6 +225,13 @@ def test_default_bench_line():
     assert d["l2_vs_oracle"] < 1e-5 and d["value_end_to_end"] > 1000 and len(d["devices"]) == 1
     gp = d["l2_vs_reference_goldens"]                     # outputs of the reference's own statements, one golden per block layout
     assert set(gp) == {"gradp_272x288", "deltas_256x256", "chapter5_300x400"} and all(0 < v < 5e-5 for v in gp.values()), gp
+    # round 5: per-solve quantiles, the headline's whole-solve fraction, the reference's deployment shape in ms per call
+    assert d["value_p10"] <= d["value_p50"] <= d["value_p90"] and 0.5 * d["value"] < d["value_p50"] < 1.5 * d["value"]
+    assert 0 < d["frac_pass"] < 1 and abs(d["frac_pass"] - full["roofline"]["whole_solve"]["frac"]) < 1e-3
+    sc = d["shipped_case"]
+    assert sc["grid"][0] == 400 and 2990 <= sc["grid"][1] <= 3010 and sc["blocks"] == 104 and 20000 < sc["cells"] < 250000 and 0.02 < sc["ms_per_call"] < 5 and sc["p10"] <= sc["ms_per_call"] <= sc["p90"], sc
+    assert sc["cpu_ms"] > sc["ms_per_call"] and full["shipped_case"]["finite"] is True and full["shipped_case"]["components"] == [45, 48]
+    assert full["per_solve_quantiles"]["samples"] >= 200 and full["per_solve_quantiles"]["solves"] >= 2000
     cbat = d["case_batch"]
     assert cbat["cases_per_step_per_gpu"] == 8 and cbat["value"] > 1000 and cbat["total_cases"] == 8 and cbat["guard_trips"] == 0
     assert cbat["bound"] in ("mfma", "hbm") and 0 < cbat["frac"] < 1 and cbat["l2_vs_oracle"] < 1e-5

@@ -4,5 +4,5 @@ for wl in unet_bf16 unet8_bf16 unet512_bf16; do
   python bench.py --workload $wl --steps 300 --warmup 30 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
-print('$wl', round(d['ms_per_step']*1e3,1), 'us', [round(l['avg_us'],1) for l in d['roofline']['launches']])"
+det=json.load(open('bench_detail.json')); print('$wl', round(d['ms_per_step']*1e3,1), 'us', [round(l['avg_us'],1) for l in det['roofline']['launches']])"
 done
