@@ -231,7 +231,7 @@ def test_default_bench_line():
     sc = d["shipped_case"]
     assert sc["grid"][0] == 400 and 2990 <= sc["grid"][1] <= 3010 and sc["blocks"] == 104 and 20000 < sc["cells"] < 250000 and 0.02 < sc["ms_per_call"] < 5 and sc["p10"] <= sc["ms_per_call"] <= sc["p90"], sc
     assert sc["cpu_ms"] > sc["ms_per_call"] and full["shipped_case"]["finite"] is True and full["shipped_case"]["components"] == [45, 48]
-    assert full["per_solve_quantiles"]["samples"] >= 200 and full["per_solve_quantiles"]["solves"] >= 2000
+    assert full["per_solve_quantiles"]["samples"] >= 200 and full["per_solve_quantiles"]["solves"] >= 10000
     cbat = d["case_batch"]
     assert cbat["cases_per_step_per_gpu"] == 8 and cbat["value"] > 1000 and cbat["total_cases"] == 8 and cbat["guard_trips"] == 0
     assert cbat["bound"] in ("mfma", "hbm") and 0 < cbat["frac"] < 1 and cbat["l2_vs_oracle"] < 1e-5
