@@ -46,6 +46,10 @@ hipError_t psm_unet_read_stamps(unsigned long long* out) { return hipMemcpyFromS
 hipError_t psm_unet_read_stamps(unsigned long long* out) { for (int i = 0; i < 64; ++i) out[i] = 0; return hipSuccess; }
 #endif
 
+#ifndef PSM_WT_STORES
+#define PSM_WT_STORES 1
+#endif
+
 namespace {
 
 // fused linear 1x1 head on the finished 16-channel tiles of a wave: v[m][r] = activation of (row m, pixel lane & 15,
@@ -598,6 +602,8 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
   // ---- epilogue: bias + ReLU (split-K: the raw partial sum into this split's slab), NHWC store
   float* out = a.out_bf ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(a.out) + (int64_t)cs * a.out_case)
                         : a.out + (int64_t)cs * a.out_case + (int64_t)split * a.out_slab;
+  // Stores are write-through (sc1, PSM_WT_STORES): see store_act8 in psm_unet_pair.hip -- the dirty lines of an activation would be
+  // written back in one burst at the end of the kernel anyway (the consumers run on other XCDs).
   // The MFMAs take the WEIGHTS as their first operand: D[channel][pixel], i.e. lane l holds the four consecutive channels
   // 4 * (l >> 4) .. + 3 of pixel l & 15 -- one 8-byte (bf16) or 16-byte (float32) store per (row, channel tile) and one address per
   // lane.  (Round 4's layout, a lane = four pixels of ONE channel, needed 16 predicated 4-byte stores with a 64-bit address chain
@@ -630,8 +636,13 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
             u32x2 pk;
             pk[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
             pk[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
+#if PSM_WT_STORES
+            asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(reinterpret_cast<unsigned short*>(out) + e), "v"(pk) : "memory");
+          } else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(out + e), "v"(v) : "memory");
+#else
             *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(out) + e) = pk;
           } else *reinterpret_cast<f32x4*>(out + e) = v;
+#endif
         }
       } else {                                              // channel counts that are not multiples of four: element-wise
 #pragma unroll

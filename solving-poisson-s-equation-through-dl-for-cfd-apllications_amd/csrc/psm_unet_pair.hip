@@ -417,6 +417,22 @@ __device__ __forceinline__ void mid_epilogue(const PsmPairArgs& a, char* mid, in
     }
   }
 }
+// Activation stores are WRITE-THROUGH (sc1) where PSM_WT_STORES is on: the next launch runs on other XCDs, whose L2s are not
+// coherent with this one's, so every dirty line is written back at the end of the kernel anyway -- as one burst behind the last
+// workgroup (MI355X_MICROARCH.md, 'boundary': + B / 6 TB/s for B dirty bytes: 2.8 us behind the stem pair's 16.8 MB).  Written
+// through, the lines leave L2 while the kernel still computes.  (Inline asm: hipcc has no store builtin with cache bits for a flat
+// address; an 8-byte store needs no trailing wait state, the compiler does not count it in vmcnt -- its own counted waits then
+// over-wait, never under-wait.)
+#ifndef PSM_WT_STORES
+#define PSM_WT_STORES 1
+#endif
+__device__ __forceinline__ void store_act8(void* p, u32x2 v) {
+#if PSM_WT_STORES
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+#else
+  *reinterpret_cast<u32x2*>(p) = v;
+#endif
+}
 // conv B: ReLU, bf16 NHWC store (STORE), fused linear 1x1 head (HEAD; headw in LDS: [16][head_cout], biases at [256]).
 // The head needs the sum over a pixel's 16 channels = the four lanes l, l ^ 16, l ^ 32, l ^ 48 after the in-lane part.
 // Four rows at a time: v_permlane32_swap of two rows' partial sums + one add leaves row A's lane-pair sums in lanes
@@ -437,7 +453,7 @@ __device__ __forceinline__ void out_epilogue(const PsmPairArgs& a, char* otile, 
       const bool ok = xok && y0 + r0 + m < a.H;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
-        if (ok) *reinterpret_cast<u32x2*>(otile + loff + (unsigned)(m * a.PO * (16 * NT) * 2) + nt * 32) = pack4_relu(acc[m][nt]);
+        if (ok) store_act8(otile + loff + (unsigned)(m * a.PO * (16 * NT) * 2) + nt * 32, pack4_relu(acc[m][nt]));
     }
   }
   if constexpr (HEAD) {
