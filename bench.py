@@ -87,7 +87,7 @@ P = 128
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 matrix peak (256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz)
 MFMA_BF16_PEAK_TFLOPS = 2516.6   # dense bf16 matrix peak (16x the f32 rate)
-PMC_FILE = "profiles/r04_pmc.json"
+PMC_FILE = "profiles/r05_pmc.json"
 
 # BASELINE.json configs as (variant, Ny, Nx, cases per step per GPU, precision, description)
 WORKLOADS = {
@@ -1062,7 +1062,7 @@ def main():
     # synchronisation costs ~1 % of a chunk).  (torch.cuda.Event pairs around single solves were tried first: recording one per
     # solve makes the pass host-bound -- 31 us of submission per solve -- and the intervals between them, median 25 us, did not add
     # up to the wall time of the pass; not used.)
-    n_q = 200
+    n_q = 20 if args.no_extras else 200                      # (profiling passes run with --no-extras: keep their traces small)
     per_ms = []
     for i in range(n_q):
         torch.cuda.synchronize()

@@ -20,3 +20,7 @@ export PSM_BENCH_LOGDIR=$O/detail_unet; timeout -k 10 300 python bench.py --work
 export PSM_BENCH_LOGDIR=$O/detail_unet8; timeout -k 10 300 python bench.py --workload unet8 --no-cpu-baseline > $O/bench_unet8.log 2>&1; tail -1 $O/bench_unet8.log | cut -c1-160
 export PSM_BENCH_LOGDIR=$O/detail_unet8_bf16; timeout -k 10 300 python bench.py --workload unet8_bf16 --no-cpu-baseline > $O/bench_unet8_bf16.log 2>&1; tail -1 $O/bench_unet8_bf16.log | cut -c1-160
 python tools/pmc_summary.py $TAG
+# the box returns gpurun_out/ only (<= 64 MiB): the condensed files go there, the raw traces are dropped
+mkdir -p $R/gpurun_out/profiles_$TAG
+cp $R/profiles/${TAG}_* $R/profiles/pmc_encode.json $R/gpurun_out/profiles_$TAG/ 2>/dev/null
+rm -rf $O/stats $O/fetch $O/write $O/unet_stats
