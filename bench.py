@@ -1084,6 +1084,10 @@ def main():
                                 "what": "a sample = wall time of a chunk of solves issued back to back between two device synchronisations, per solve; "
                                         "value_p10 / value_p90 = rate at the slow / fast decile"},
         "frac_pass": roofline["whole_solve"]["frac"],
+        # a timed region starts on a drained stream (the contract's synchronise): its first solve waits for the host's first launches
+        # (~25 us of pipeline fill).  At K = 2000 that is 0.04 % of the region, at the driver's K = 20 it is 3-4 %: the round-4 driver line
+        # (27.8 k) against the builder's K = 2000 lines (29.2 k) on equal boxes; value_p50 (chunks of 50) sits between the two.
+        "pipeline_fill_note": f"K={args.steps}: one fill of ~25 us = {25.0 / (dt_max / args.steps * 1e6 * args.steps) * 100:.1f} % of the timed region",
         "unit": "solves/s", "n_gpus": world, "world_size_reported": world_reported, "devices": devices,
         "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",

@@ -208,6 +208,30 @@ def test_config3_all_64_cases_on_one_card():
         np.testing.assert_allclose(part, singles[:50], rtol=0, atol=3e-6 * np.abs(singles).max())
 
 
+@pytest.mark.parametrize("c_in,p_in,variant", [(4, 48, "deltas"), (3, 40, "chapter5"), (3, 100, "gradp")])
+def test_large_batch_encode_other_shapes(c_in, p_in, variant):
+    """The M-tiled encode (>= 432 block rows) on shapes the 64-case test does not reach: four input channels (K slices of 256), fewer
+    component tiles than waves (40 / 48 components: waves 2, 3 idle), a Chapter-5 layout (16 blocks per 256 x 256 case: 30 cases = 480 rows),
+    U_to_gradP's 30 blocks per case (16 cases = 480 rows).  Every case against the same case solved alone, three against the oracle."""
+    model = synthetic.make_model(variant, p_in=p_in, p_out=32, c_in=c_in, scaler_kind="min_max" if c_in == 4 else None)
+    if c_in == 4:
+        model.sdf_ch = 3
+    with GridSurrogate(model, 256, 256) as probe:
+        blocks = probe.B
+    n = -(-432 // blocks) + 1
+    g3 = synthetic.random_obstacle_cases(n, 256, 256, seed=21).astype(np.float32)
+    grids = np.concatenate([g3[..., :1] * g3[..., 1:2], g3], axis=-1).astype(np.float32) if c_in == 4 else g3
+    with GridSurrogate(model, 256, 256, max_cases=n) as sur:
+        assert n * sur.B >= 432
+        batch = sur.solve(grids)
+        singles = np.stack([sur.solve(grids[c])[0] for c in range(n)])
+        om = oracle_model(model)
+        for c in (0, n // 2, n - 1):
+            sol = orc.solve_grid(grids[c].astype(np.float64), om)
+            assert np.abs(batch[c] - sol.fields).max() <= 1e-4 * np.abs(sol.fields).max(), c
+    np.testing.assert_allclose(batch, singles, rtol=0, atol=3e-6 * np.abs(singles).max())
+
+
 def test_config0_chapter5_real_weights_via_solver_module():
     grid, model = cases.build("chapter5_128x128_real")
     gold = cases.load_golden("chapter5_128x128_real")
