@@ -4,24 +4,35 @@
 namespace psm_impl {
 
 
-// K groups of the large-batch encode (psm_encode_x6_mt_kernel) for Mpad block rows, 1 = the one-slab-per-slice forms.
-// From 432 block rows up (>= 48 cases of 9 blocks): about 512 workgroups = two per CU, i.e. 512 / row groups K groups (64 cases:
-// nine row groups of 64 -> 56 groups of 4-5 slices, 16.5 MB of slabs; the one-slab-per-slice form writes 75 MB).  PSM_ENCODE_KGROUPS=n forces the group count (1: the old form).
+// K groups of the M-tiled x6 encode (psm_encode_x6_mt_kernel) for Mpad block rows; 1 = the one-slab-per-slice form (psm_encode_x6_kernel).
+// A workgroup = one K group x 64 block rows, two workgroups per CU: the group count decides both the slab bytes and how the
+// workgroups fill 512 slots.  Measured on one box, whole step of the deltas case batch in us (g1 = one slab per slice):
+//   cases  rows(pad)  row groups   g1      256 groups  128     64      uneven 512 / row groups
+//     8      96         2          42.2    41.0
+//    12     128         2          47.9    44.6
+//    16     160         3          59.8    56.1        56.8    59.1
+//    20     192         3          64.6    60.0        59.7    61.5
+//    28     256         4          74.5    70.1        65.7    65.9
+//    32     288         5          88.9    84.1        85.4    86.3    92.1 (102 groups)
+//    40     384         6         102.0    95.7        91.4    92.0
+//    48     448         7         113.8   106.3       104.0    99.1   110.6 (73)
+//    56     512         8         124.7   116.9       110.6   106.5
+//    64     576         9         140.7   132.1       130.4   134.9   123.5 (56)
+// Even groups (a power of two) by row-group count from that table; from nine row groups up 512 / row groups (uneven by one slice).
+// Below 96 rows (4 cases: 37.6 against 38.0 us) the launch is bound by the basis stream and the one-slab-per-slice form stays.
+// PSM_ENCODE_KGROUPS=n forces the group count (1: the old form), PSM_ENCODE_MT_MIN_ROWS the first row count.
 int encode_groups(const psm_handle* h, int Mpad) {
-  // crossover measured on one box (us per step, whole solve): 40 cases 101.6 one-slab-per-slice / 106.2 M-tiled, 48 cases 113.8 / 110.6,
-  // 56 cases 124.7 / 104.8, 64 cases 141.5 / 123.5 -- from 432 block rows (48 cases of 9 blocks) up
-  static const int min_rows = getenv("PSM_ENCODE_MT_MIN_ROWS") ? atoi(getenv("PSM_ENCODE_MT_MIN_ROWS")) : 432;
+  static const int min_rows = getenv("PSM_ENCODE_MT_MIN_ROWS") ? atoi(getenv("PSM_ENCODE_MT_MIN_ROWS")) : 96;
   if (h->cfg.precision == PSM_PRECISION_BF16 || h->NT > 4 || Mpad % 32 != 0 || Mpad < min_rows || ((PSM_PIX_PER_SLICE * h->cfg.c_in) % 32) != 0) return 1;
   if (h->x6_mode >= 0 && !(h->x6_mode & 1)) return 1;
   static const int kg_env = getenv("PSM_ENCODE_KGROUPS") ? atoi(getenv("PSM_ENCODE_KGROUPS")) : 0;
   const int row_groups = (Mpad + PSM_ENC_MT_ROWS - 1) / PSM_ENC_MT_ROWS;
-  // measured at 64 cases (one box, us: encode + reduce): 512 workgroups 49.1 + 6.2, 768: 61.4 + 8.2, 1024: 56.6 + 10.1, 1536: 56.2 + 12.9
-  static const int wg_target = getenv("PSM_ENCODE_WGS") ? atoi(getenv("PSM_ENCODE_WGS")) : 512;
-  int groups = std::max((h->n_slices + 7) / 8, std::min(h->n_slices, wg_target / row_groups));
+  static const int by_rg[9] = {0, 256, 256, 256, 128, 256, 128, 64, 64};
+  int groups = row_groups <= 8 ? by_rg[row_groups] : std::max(1, 512 / row_groups);
+  groups = std::max((h->n_slices + 7) / 8, std::min(h->n_slices, groups));
   if (kg_env > 0) groups = kg_env;
   return (groups > 1 && groups <= h->n_slices && (h->n_slices + groups - 1) / groups <= 8) ? groups : 1;
 }
-
 // What that encode needs beyond the plan, built on first use and OUTSIDE any stream capture (it allocates): the basis pre-split
 // into three bf16 planes (1.5 x the bytes of the float32 pack), made on the device from the float32 pack.
 int ensure_encode_aux(psm_handle* h, int n_cases) {
