@@ -92,14 +92,16 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
   // bound-geometry contract: guard riders in the launch that computes the strip dots (not for psm_solve, whose grid is
   // built from the bound sdfunct itself)
   PsmGuardArgs ga{};
+  const int guard_wgs = (h->guard_waves + PSM_GUARD_WG_WAVES - 1) / PSM_GUARD_WG_WAVES;
   const bool guard = use_bound && h->guard_on && h->bound_scope == 2 && h->d_maskbits && w.d_gflags;
   if (guard) {
     ga.sdf = d_grid + h->cfg.sdf_channel; ga.bits = h->d_maskbits; ga.flags = w.d_gflags;
     ga.host_flag = h->m_guard ? h->m_guard + w.gidx : nullptr;
     ga.npix = (long long)n_cases * h->Ny * h->Nx; ga.c_in = h->cfg.c_in; ga.n_ballots = h->guard_ballots; ga.n_waves = h->guard_waves;
+    ga.wg_first = 0; ga.wg_count = guard_wgs;            // all of them behind the head layer, unless dealt out below
   }
   const float* gflags = guard ? w.d_gflags : h->d_gzero;
-  const int n_gwaves = guard ? h->guard_waves : 1;
+  const int n_gwaves = guard ? guard_wgs : 1;              // flags the decode launch sums: one per guard workgroup
   // case batches (and single cases of more than 64 blocks) on a bound geometry: closed form of the chain where it was built
   const bool use_cf = use_bound && h->bound_cf && w.d_dots2;
   const int CB = h->cfg.c_out * h->B;
@@ -157,6 +159,19 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
     // launches every normalisation on its own.
     const char* ln_env = getenv("PSM_LN_FUSE");            // read per solve (diagnostic; the tests switch it in-process)
     const bool ln_fuse = !(ln_env && atoi(ln_env) == 0);
+    // Large case batches: the guard workgroups (one per 4096 pixels: 1024 for 64 cases, 50 MB of grid to look at again) are dealt
+    // evenly over the hidden-layer launches and the head launch instead of all riding behind the head (64 cases: 14.9 us for a
+    // 4.3 us layer).  PSM_GUARD_SPREAD=0 keeps them behind the head.
+    static const bool spread_env = !(getenv("PSM_GUARD_SPREAD") && atoi(getenv("PSM_GUARD_SPREAD")) == 0);
+    const int carriers = nl - 1 - (fuse1 ? 1 : 0);       // hidden layers launched through psm_launch_dense
+    const bool spread = guard && spread_env && guard_wgs > 256 && carriers > 0;
+    const int share = spread ? guard_wgs / (carriers + 1) : 0;
+    int dealt = 0;
+    auto riders = [&]() -> const PsmGuardArgs* {         // the next hidden launch's share
+      if (!spread) return nullptr;
+      ga.wg_first = dealt; ga.wg_count = share; dealt += share;
+      return &ga;
+    };
     bool pending = false;                               // `cur` is a raw output whose LayerNormalization the next launch applies
     int pending_l = -1;
     auto after_dense = [&](int l, float* act, const float* layer_in, int ld_layer_in, bool residual_done) -> int {
@@ -186,12 +201,13 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
         residual_done = da.ln_residual != 0;
       }
       if (l < nl - 1) {
-        HIPCHK(h, psm_launch_dense(da, st));
+        HIPCHK(h, psm_launch_dense(da, st, riders()));
         int rcl = after_dense(l, da.out, cur, ld_cur, residual_done);
         if (rcl) return rcl;
         cur = da.out; ld_cur = h->dense[l].ldw;
         continue;
       }
+      ga.wg_first = dealt; ga.wg_count = guard ? guard_wgs - dealt : 0;    // the head launch (or the bf16 handles' dots launch) carries the rest
       if (use_bound && !bf16 && l == nl - 1) { // head layer + strip dots of the bound geometry in one launch
         PsmDotsArgs dd = use_cf ? PsmDotsArgs{h->d_g2p, h->d_c2p, h->d_cntp, h->d_row_of_p, d_row_scale, w.d_dots2, n_cases * CB, h->dense[nl - 1].Kpad, ga, h->B, CB}
                                 : PsmDotsArgs{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, d_row_scale, w.d_dots, h->bound_rows * n_cases, h->dense[nl - 1].Kpad, ga};

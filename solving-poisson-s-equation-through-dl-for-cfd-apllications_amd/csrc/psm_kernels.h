@@ -146,19 +146,24 @@ struct PsmBindArgs {                   // table build, once per geometry
 };
 // Guard of the bound-geometry contract (psm.h: "the SDF channel of every solved grid must have the bound flow-cell
 // pattern"): extra waves of the launch that computes the strip dots re-derive the pattern of the grid BEING SOLVED --
-// one ballot per 64 consecutive pixels, 8 ballots per wave -- and compare it with the bound one.  A wave writes
-// flags[wave] = 0 (match) or NaN (mismatch) on every solve (no reset needed); the launch that writes the field adds the
+// one ballot per 64 consecutive pixels, 8 ballots per wave, 8 waves per guard workgroup -- and compare it with the bound one.
+// A guard workgroup writes flags[workgroup] = 0 (match) or NaN (mismatch) on every solve (no reset needed; one flag per 4096
+// pixels, so that the consumers sum 1024 flags for 64 cases, not 8192); the launch that writes the field adds the
 // sum of the flags to the global shift, so a solve on another geometry returns NaN everywhere instead of a plausible
 // wrong field, and *host_flag (mapped pinned memory) is raised for the host-side entries, which then fall back to the
-// general path.  The riders run on CUs the head layer leaves idle: no launch, nothing on the critical path.
+// general path.  The riders run on CUs the head layer leaves idle: no launch, nothing on the critical path.  A large case
+// batch re-reads 0.8 MB per case this way (64 cases: 1024 guard workgroups behind a 4 us layer cost it 6 us), so its guard
+// workgroups are dealt over ALL Dense launches between the encode and the decode: [wg_first, wg_first + wg_count) per launch.
 struct PsmGuardArgs {
   const float* sdf;                    // grid + sdf_channel (pixel stride c_in floats); null: no guard waves
   const unsigned long long* bits;      // [n_ballots] bound pattern, bit l of word g = pixel min(64 g + l, npix - 1) is a flow cell
-  float* flags;                        // [n_waves]
+  float* flags;                        // [ceil(n_waves / 8)]: one per guard workgroup
   int* host_flag;                      // device-side address of the workspace's word in mapped pinned memory (may be null)
   long long npix;                      // cases * Ny * Nx
   int c_in, n_ballots, n_waves;
+  int wg_first, wg_count;              // the guard workgroups THIS launch carries
 };
+constexpr int PSM_GUARD_WG_WAVES = 8;  // guard waves per flag
 constexpr int PSM_GUARD_BALLOTS = 8;   // per guard wave: 512 pixels
 struct PsmDotsArgs {                   // rows: [c_out][nst] strip means, then [c_out][B] shift partial sums
   const float* g2; const float* c2; const float* cnt; const int32_t* row_of; const float* row_scale;
@@ -225,7 +230,7 @@ hipError_t psm_launch_decode_bf16(const PsmDecodeArgs& a, hipStream_t s);
 hipError_t psm_launch_reduce(const PsmReduceArgs& a, hipStream_t s);
 // slab reduce + first dense layer in one launch (ldp <= 512, layer width <= 1024)
 hipError_t psm_launch_reduce_dense1(const PsmReduceArgs& r, const PsmDenseArgs& d, hipStream_t s);
-hipError_t psm_launch_dense(const PsmDenseArgs& a, hipStream_t s);
+hipError_t psm_launch_dense(const PsmDenseArgs& a, hipStream_t s, const PsmGuardArgs* riders = nullptr);   // riders: guard workgroups behind the layer's own
 hipError_t psm_launch_decode(const PsmDecodeArgs& a, hipStream_t s);
 hipError_t psm_launch_strips(const PsmStripArgs& a, int n_cases, hipStream_t s);
 hipError_t psm_launch_chain(const PsmChainArgs& a, int n_cases, hipStream_t s);

@@ -968,9 +968,19 @@ hipError_t psm_launch_conv1d(const PsmConv1dArgs& a, hipStream_t st) {
 // ROWS = 16 (few block rows: twice the workgroups, each pulling 2/3 of the bytes -- the layer
 // is bound by what ONE CU can pull per round trip) or 32 (weights read once per 32 rows).
 __device__ __forceinline__ float wave_sum(float v);
+// A loaded value whose FIRST use would sit inside run-time predicated store blocks is consumed once before them, through an opaque
+// move.  The wait-count pass cannot count the stores in flight behind run-time predicates, so with a load still pending at their
+// first use it emits s_waitcnt vmcnt(0) in front of EVERY store: sixteen store round trips in series per epilogue (the decode
+// kernels' `mean` value; tools/isa_store_waits.py finds the pattern in a listing).
+__device__ __forceinline__ float psm_settled(float v) {
+  float r;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+constexpr int PSM_DOTS_WG_ROWS = 256;   // closed-form dots: up to this many rows one workgroup per row, beyond it two rows per workgroup
 
 // One guard wave (PsmGuardArgs): 8 ballots of 64 consecutive pixels each against the bound pattern.
-__device__ __forceinline__ void psm_guard_wave(const PsmGuardArgs& g, int gw, int lane) {
+__device__ __forceinline__ bool psm_guard_wave(const PsmGuardArgs& g, int gw, int lane) {
   constexpr int NB = PSM_GUARD_BALLOTS;
   float v[NB];
   unsigned long long want[NB];
@@ -986,9 +996,29 @@ __device__ __forceinline__ void psm_guard_wave(const PsmGuardArgs& g, int gw, in
     const unsigned long long got = __ballot(v[u] != 0.f);           // NaN != 0 is true, like NumPy's `!= 0`
     bad |= (gw * NB + u < g.n_ballots) && got != want[u];
   }
-  if (lane == 0) {
-    g.flags[gw] = bad ? __int_as_float(0x7fc00000) : 0.f;
-    if (bad && g.host_flag) __hip_atomic_store(g.host_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return bad;                                          // wave-uniform
+}
+// One guard workgroup (index gwg of this launch's range, uniform): PSM_GUARD_WG_WAVES guard waves' worth of pixels by the WAVES
+// waves of the calling workgroup, one flag.  Every thread of the workgroup must call it (barriers).
+template <int WAVES>
+__device__ __forceinline__ void psm_guard_wg(const PsmGuardArgs& g, int gwg, int wave, int lane) {
+  __shared__ int guard_bad[WAVES];
+  if (gwg >= g.wg_count) return;                       // uniform
+  const int wg = g.wg_first + gwg;
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < PSM_GUARD_WG_WAVES / WAVES; ++k) {
+    const int gw = wg * PSM_GUARD_WG_WAVES + wave * (PSM_GUARD_WG_WAVES / WAVES) + k;
+    if (gw < g.n_waves) bad |= psm_guard_wave(g, gw, lane);
+  }
+  if (lane == 0) guard_bad[wave] = bad ? 1 : 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int any = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) any |= guard_bad[w];
+    g.flags[wg] = any ? __int_as_float(0x7fc00000) : 0.f;
+    if (any && g.host_flag) __hip_atomic_store(g.host_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 // sum of the guard flags of a solve (0, or NaN after a mismatch): one wave, every lane gets the total
@@ -1016,17 +1046,67 @@ __device__ __forceinline__ float psm_guard_sum(const float* flags, int n, int la
 // the workgroup's own rows in a prologue, operands normalised on their way into the MFMAs, optional residual in the epilogue.
 template <int NGC, bool BF16, int ROWS, bool DOTS, bool LNIN = false>   // NGC: groups of 16 k per wave per pass
 __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a, PsmDotsArgs d) {
+  constexpr int NCT = 1;   // column tiles of 16 per workgroup.  (Two, for 576 block rows x 512 columns = 576 workgroups on 512 slots, measured no
+                           // gain: 7.7 / 8.7 us either way -- the layer is 4.3 us of latency + 147 456 float32 MFMAs of 32 cycles on 1024 SIMDs.)
+  if (!DOTS && blockIdx.z > 0) {                       // guard riders behind a hidden layer (large case batches)
+    const int wg = ((int)(blockIdx.z - 1) * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
+    psm_guard_wg<8>(d.guard, wg, threadIdx.x >> 6, threadIdx.x & 63);
+    return;
+  }
   if (DOTS && blockIdx.z > 0) {
     constexpr int RPW = 2, NQ = 4;                     // rows per wave; float4 per lane and row (Kh <= 1024)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wg = ((int)(blockIdx.z - 1) * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
-    const int n_dot_wgs = d.n_src > 1 ? d.n_rows : (d.n_rows + 8 * RPW - 1) / (8 * RPW);
+    const bool wave_rows = d.n_src > 1 && d.n_rows > PSM_DOTS_WG_ROWS;      // closed form, many rows: two rows per workgroup
+    const int n_dot_wgs = d.n_src > 1 ? (wave_rows ? (d.n_rows + 1) / 2 : d.n_rows) : (d.n_rows + 8 * RPW - 1) / (8 * RPW);
     if (wg >= n_dot_wgs) {                               // guard riders behind the dots workgroups (uniform per workgroup)
-      const int gw = (wg - n_dot_wgs) * 8 + wave;
-      if (gw < d.guard.n_waves) psm_guard_wave(d.guard, gw, lane);
+      psm_guard_wg<8>(d.guard, wg - n_dot_wgs, wave, lane);
       return;
     }
     const int nq = d.Kh / 4;
+    if (wave_rows) {
+      // closed form, case batches of more than PSM_DOTS_WG_ROWS rows: TWO rows per workgroup -- four waves per row, wave q of a
+      // row takes the source blocks q, q + 4, ... (four per batch, all loads of a batch up front; up to 16 blocks are one round
+      // trip), the partial sums meet in LDS.  64 cases x 9 rows: 288 workgroups instead of 576 behind the head's 144.
+      __shared__ float lsum2[8];
+      const int rsel = wave >> 2, q4 = wave & 3;
+      const int row = wg * 2 + rsel, rc = min(row, d.n_rows - 1);
+      const int cs = rc / d.rows_per_case;
+      const f32x4* gp = reinterpret_cast<const f32x4*>(d.g2) + (int64_t)rc * d.n_src * nq;
+      const float* ap = a.in + (int64_t)cs * d.n_src * a.ld_in;
+      const float rsv = d.row_scale[cs * d.n_src];
+      float acc = 0.f;
+      for (int b0 = q4; b0 < d.n_src; b0 += 16) {
+        f32x4 gg[4][NQ], xx[4][NQ];
+        float cc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int blk = min(b0 + 4 * t, d.n_src - 1);
+          cc[t] = d.c2[(int64_t)rc * d.n_src + blk];
+#pragma unroll
+          for (int u = 0; u < NQ; ++u) {
+            const int q = min(lane + 64 * u, nq - 1);
+            gg[t][u] = gp[(int64_t)blk * nq + q];
+            xx[t][u] = reinterpret_cast<const f32x4*>(ap + (int64_t)blk * a.ld_in)[q];
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const bool on = b0 + 4 * t < d.n_src;
+#pragma unroll
+          for (int u = 0; u < NQ; ++u) {
+            const float s4 = (gg[t][u].x * xx[t][u].x + gg[t][u].y * xx[t][u].y) + (gg[t][u].z * xx[t][u].z + gg[t][u].w * xx[t][u].w);
+            acc += (on && lane + 64 * u < nq) ? s4 : 0.f;
+          }
+          acc += (on && lane == 0) ? cc[t] : 0.f;
+        }
+      }
+      const float tot = wave_sum(acc);
+      if (lane == 0) lsum2[wave] = tot;
+      __syncthreads();
+      if (lane == 0 && q4 == 0 && row < d.n_rows) d.out[row] = rsv * ((lsum2[4 * rsel] + lsum2[4 * rsel + 1]) + (lsum2[4 * rsel + 2] + lsum2[4 * rsel + 3]));
+      return;
+    }
     if (d.n_src > 1) {
       // closed form: one WORKGROUP per row -- wave w takes the source blocks w, w + 8, ... (four per batch, all loads of a
       // batch up front), the eight partial sums meet in LDS
@@ -1102,19 +1182,25 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a, PsmDotsA
     }
     return;
   }
-  __shared__ float red[8][2][16 * 17];
+  __shared__ float red[8][2 * NCT][16 * 17];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nt = blockIdx.x, mt = blockIdx.y;
+  const int nt = blockIdx.x * NCT, mt = blockIdx.y;
   const int i = lane & 15, kq = lane >> 4;
   const int groups = a.Kp / 16;                      // all waves
   const int ng = groups / 8;                         // per wave: a multiple of NGC
   PSM_STAMP(0, 44 + 4 * (a.layer & 3));
   // epilogue operands of this thread's output column: in flight from the start
   const int n_out = nt * 16 + (tid & 15);
-  const float bias_v = a.bias[n_out];
-  const float sa_v = a.head ? a.sa[n_out] : 1.f, sb_v = a.head ? a.sb[n_out] : 0.f;
-  f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+  float bias_v[NCT], sa_v[NCT], sb_v[NCT];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c) {
+    bias_v[c] = a.bias[n_out + 16 * c];
+    sa_v[c] = a.head ? a.sa[n_out + 16 * c] : 1.f; sb_v[c] = a.head ? a.sb[n_out + 16 * c] : 0.f;
+  }
+  f32x4 acc0[NCT], acc1[NCT];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c) { acc0[c] = (f32x4){0, 0, 0, 0}; acc1[c] = (f32x4){0, 0, 0, 0}; }
   const float* arow0 = a.in + (int64_t)(mt * ROWS + i) * a.ld_in;
   const float* arow1 = arow0 + (int64_t)16 * a.ld_in;
   const int g_first = wave * ng;
@@ -1137,10 +1223,10 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a, PsmDotsA
       bt[g] = *reinterpret_cast<const f32x4*>(a.ln_beta + kcol);
     }
   };
-  auto load_w = [&](int g0, f32x4 (&w)[NGC]) {
+  auto load_w = [&](int g0, f32x4 (&w)[NGC], int c = 0) {
 #pragma unroll
     for (int g = 0; g < NGC; ++g) {
-      const int64_t widx = ((int64_t)nt * groups + g_first + g0 + g) * 64 + lane;
+      const int64_t widx = ((int64_t)(nt + c) * groups + g_first + g0 + g) * 64 + lane;
       if (BF16) {
         const uint2 u = reinterpret_cast<const uint2*>(a.Wp)[widx];
         w[g] = (f32x4){__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
@@ -1150,13 +1236,13 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a, PsmDotsA
       }
     }
   };
-  auto mma = [&](const f32x4 (&a0)[NGC], const f32x4 (&a1)[NGC], const f32x4 (&w)[NGC]) {
+  auto mma = [&](const f32x4 (&a0)[NGC], const f32x4 (&a1)[NGC], const f32x4 (&w)[NGC], int c = 0) {
 #pragma unroll
     for (int g = 0; g < NGC; ++g) {
-      acc0 = MFMA16(rnd(a0[g].x), w[g].x, acc0); if (ROWS == 32) acc1 = MFMA16(rnd(a1[g].x), w[g].x, acc1);
-      acc0 = MFMA16(rnd(a0[g].y), w[g].y, acc0); if (ROWS == 32) acc1 = MFMA16(rnd(a1[g].y), w[g].y, acc1);
-      acc0 = MFMA16(rnd(a0[g].z), w[g].z, acc0); if (ROWS == 32) acc1 = MFMA16(rnd(a1[g].z), w[g].z, acc1);
-      acc0 = MFMA16(rnd(a0[g].w), w[g].w, acc0); if (ROWS == 32) acc1 = MFMA16(rnd(a1[g].w), w[g].w, acc1);
+      acc0[c] = MFMA16(rnd(a0[g].x), w[g].x, acc0[c]); if (ROWS == 32) acc1[c] = MFMA16(rnd(a1[g].x), w[g].x, acc1[c]);
+      acc0[c] = MFMA16(rnd(a0[g].y), w[g].y, acc0[c]); if (ROWS == 32) acc1[c] = MFMA16(rnd(a1[g].y), w[g].y, acc1[c]);
+      acc0[c] = MFMA16(rnd(a0[g].z), w[g].z, acc0[c]); if (ROWS == 32) acc1[c] = MFMA16(rnd(a1[g].z), w[g].z, acc1[c]);
+      acc0[c] = MFMA16(rnd(a0[g].w), w[g].w, acc0[c]); if (ROWS == 32) acc1[c] = MFMA16(rnd(a1[g].w), w[g].w, acc1[c]);
     }
   };
   // ---- pending LayerNormalization of the input: moments of rows i (and i + 16) over the first ln_n columns, two passes like
@@ -1254,41 +1340,50 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a, PsmDotsA
   }
   PSM_STAMP(0, 45 + 4 * (a.layer & 3));
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    red[wave][0][(4 * kq + r) * 17 + i] = acc0[r];
-    if (ROWS == 32) red[wave][1][(4 * kq + r) * 17 + i] = acc1[r];
-  }
+  for (int c = 0; c < NCT; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      red[wave][2 * c][(4 * kq + r) * 17 + i] = acc0[c][r];
+      if (ROWS == 32) red[wave][2 * c + 1][(4 * kq + r) * 17 + i] = acc1[c][r];
+    }
   __syncthreads();
   if (tid < ROWS * 16) {
     const int row = tid >> 4, col = tid & 15;          // ROWS rows x 16 cols
     const int half = row >> 4, r16 = row & 15;
-    float v = 0.f;
 #pragma unroll
-    for (int w8 = 0; w8 < 8; ++w8) v += red[w8][half][r16 * 17 + col];
-    v += bias_v;
-    if (a.relu) v = fmaxf(v, 0.f);
-    if constexpr (LNIN) {
-      if (a.ln_residual) v += (res_raw - ln_stat[0][row]) * ln_stat[1][row] * res_g + res_b;     // x + LN(input) (NNs.py:64)
+    for (int c = 0; c < NCT; ++c) {
+      float v = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) v += red[w8][2 * c + half][r16 * 17 + col];
+      v += bias_v[c];
+      if (a.relu) v = fmaxf(v, 0.f);
+      if constexpr (LNIN) {
+        if (a.ln_residual) v += (res_raw - ln_stat[0][row]) * ln_stat[1][row] * res_g + res_b;     // x + LN(input) (NNs.py:64)
+      }
+      if (a.head) v = v * sa_v[c] + sb_v[c];
+      a.out[(int64_t)(mt * ROWS + row) * a.ld_out + n_out + 16 * c] = v;
     }
-    if (a.head) v = v * sa_v + sb_v;
-    a.out[(int64_t)(mt * ROWS + row) * a.ld_out + n_out] = v;
   }
   PSM_STAMP(0, 46 + 4 * (a.layer & 3));
 }
 
-hipError_t psm_launch_dense(const PsmDenseArgs& a, hipStream_t st) {
+hipError_t psm_launch_dense(const PsmDenseArgs& a, hipStream_t st, const PsmGuardArgs* riders) {
   const int ng = a.Kp / 128;                       // groups of 16 k per wave
   if (!a.Wp || a.Kp % 128 != 0 || (ng > 2 && ng % 4 != 0) || a.ld_in < 4) return hipErrorInvalidValue;
   const bool r16 = a.Mpad <= 128;     // up to 128 block rows: 16-row tiles keep >= 64 workgroups pulling <= 64 KB each
-  const dim3 grid(a.ld_w / 16, a.Mpad / (r16 ? 16 : 32)), blk(512);
+  const int gx = a.ld_w / 16, gy = a.Mpad / (r16 ? 16 : 32);
+  PsmDotsArgs rd{};
+  int gz = 1;
+  if (riders && riders->sdf && riders->wg_count > 0) { rd.guard = *riders; gz = 1 + (riders->wg_count + gx * gy - 1) / (gx * gy); }
+  const dim3 grid(gx, gy, gz), blk(512);
 #define DENSE2(N, L)                                                                        \
   do {                                                                                      \
     if (r16) {                                                                              \
-      if (a.bf16) PSM_LAUNCH((psm_dense_kernel<N, true, 16, false, L>), grid, blk, 0, st, a, PsmDotsArgs{}); \
-      else PSM_LAUNCH((psm_dense_kernel<N, false, 16, false, L>), grid, blk, 0, st, a, PsmDotsArgs{});       \
+      if (a.bf16) PSM_LAUNCH((psm_dense_kernel<N, true, 16, false, L>), grid, blk, 0, st, a, rd); \
+      else PSM_LAUNCH((psm_dense_kernel<N, false, 16, false, L>), grid, blk, 0, st, a, rd);       \
     } else {                                                                                \
-      if (a.bf16) PSM_LAUNCH((psm_dense_kernel<N, true, 32, false, L>), grid, blk, 0, st, a, PsmDotsArgs{}); \
-      else PSM_LAUNCH((psm_dense_kernel<N, false, 32, false, L>), grid, blk, 0, st, a, PsmDotsArgs{});       \
+      if (a.bf16) PSM_LAUNCH((psm_dense_kernel<N, true, 32, false, L>), grid, blk, 0, st, a, rd); \
+      else PSM_LAUNCH((psm_dense_kernel<N, false, 32, false, L>), grid, blk, 0, st, a, rd);       \
     }                                                                                       \
   } while (0)
 #define DENSE(N) do { if (a.ln_gamma) DENSE2(N, true); else DENSE2(N, false); } while (0)
@@ -1308,7 +1403,7 @@ hipError_t psm_launch_dense_dots(const PsmDenseArgs& a, const PsmDotsArgs& d, hi
   const bool r16 = a.Mpad <= 128;                   // same tile choice as psm_launch_dense
   const int gx = a.ld_w / 16, gy = a.Mpad / (r16 ? 16 : 32);
   // z planes > 0: ceil(n_rows / 16) dots workgroups (8 waves x 2 rows), then ceil(guard waves / 8) guard workgroups
-  const int extra = (d.n_src > 1 ? d.n_rows : (d.n_rows + 15) / 16) + (d.guard.sdf ? (d.guard.n_waves + 7) / 8 : 0);
+  const int extra = (d.n_src > 1 ? (d.n_rows > PSM_DOTS_WG_ROWS ? (d.n_rows + 1) / 2 : d.n_rows) : (d.n_rows + 15) / 16) + (d.guard.sdf ? d.guard.wg_count : 0);
   const dim3 grid(gx, gy, 1 + (extra + gx * gy - 1) / (gx * gy)), blk(512);
 #define DD(N)                                                                                          \
   do {                                                                                                 \
@@ -1413,8 +1508,9 @@ __global__ __launch_bounds__(256) void psm_decode128_kernel(PsmDecodeArgs a, int
 #pragma unroll
   for (int g = 0; g < GD; ++g) b[g] = stream_load(bp + g * 64);
   const int col = ct * 32 + i;
-  const float mu = a.mean[col];
+  const float mu_raw = a.mean[col];
   __builtin_amdgcn_sched_barrier(0);
+  const float mu = psm_settled(mu_raw);
   float* lrs = lds + MTC * 32 * LDA;             // [MTC*32] out_scale per block row
   const int m_step = MTC * 32 * (int)gridDim.y;    // row chunks are dealt round-robin to the gridDim.y row groups
   for (int m_base = m_first; m_base < m_end; m_base += m_step) {
@@ -1506,12 +1602,18 @@ __global__ __launch_bounds__(256) void psm_decode_kernel(PsmDecodeArgs a, int m_
     }
   }
   if (!live) return;
+  const float mu_r = psm_settled(mu);
 #pragma unroll
   for (int mt = 0; mt < MTC; ++mt) {
+    float rsv[16];                                   // the tile's row scales first, straight-line (see psm_settled)
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) rsv[rg] = a.row_scale[min(m_base + mt * 32 + acc_row(rg, h), a.M - 1)];
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) rsv[rg] = psm_settled(rsv[rg]);
 #pragma unroll
     for (int rg = 0; rg < 16; ++rg) {
       const int m = m_base + mt * 32 + acc_row(rg, h);
-      if (m < a.M) a.pred[(int64_t)m * a.K_out + col] = (acc[mt][rg] + mu) * a.row_scale[m];
+      if (m < a.M) a.pred[(int64_t)m * a.K_out + col] = (acc[mt][rg] + mu_r) * rsv[rg];
     }
   }
 }
@@ -2412,6 +2514,7 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
     if (tid < C) p.shift[tid] = wred[tid];
   }
   if (!live) return;
+  const float mu_r = psm_settled(mu);
   const int px = col / C, f = col - px * C;
   const int pxl = px - (int)blockIdx.x * (128 / C);
   const int r = px / S, c = px - r * S;
@@ -2436,7 +2539,7 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
       const bool mine = m < B && ((word >> (pxl & 31)) & 1u);
       if (mine) {
         const int y = __float_as_int(ra[rg][0]) + r, xx = __float_as_int(ra[rg][1]) + c;
-        p.fields[((int64_t)y * p.Nx + xx) * C + f] = (acc[mt][rg] + mu) * ra[rg][2] - of[rg] - sh;
+        p.fields[((int64_t)y * p.Nx + xx) * C + f] = (acc[mt][rg] + mu_r) * ra[rg][2] - of[rg] - sh;
       }
     }
   }
@@ -2528,11 +2631,11 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int B = p.B, S = p.cp.S, wps = S * S / 32;
-  float* lrs = lds + R * LDA;                          // [R] out_scale per block row
-  float* lsub = lrs + R;                               // [R][C] offset + shift of the row's block
-  uint32_t* lown = reinterpret_cast<uint32_t*>(lsub + R * C);   // [R][WPB]
-  int* lcb = reinterpret_cast<int*>(lown + R * WPB);   // [R][2] case, block
-  int* yx = lcb + 2 * R;                               // [B][2]
+  // per-row operands of the epilogue, ONE 16-byte LDS read per output value: {out_scale, offset + shift of field 0, of field 1,
+  // element offset of the block's first cell in `fields` (bits)}; ownership words beside them (rows >= M own nothing)
+  float4* lrow = reinterpret_cast<float4*>(lds + R * LDA);          // [R]
+  uint32_t* lown = reinterpret_cast<uint32_t*>(lrow + R);           // [R][WPB]
+  float* lg = reinterpret_cast<float*>(lown + R * WPB);             // [4] guard partial per wave
   const int ct = min((int)blockIdx.x * 4 + wave, a.n_coltiles - 1);
   const bool live = ((int)blockIdx.x * 4 + wave) < a.n_coltiles;
   const int m_first = (int)blockIdx.y * R, m_step = R * (int)gridDim.y;
@@ -2544,11 +2647,13 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
     }
   };
   // per-row operands of the epilogue (thread = row of the chunk): scale, offset + shift, ownership words
-  struct RowOps { float rs, sub[C]; uint32_t own[WPB]; int cs, b; };
+  struct RowOps { float rs, sa[C], sb[C]; uint32_t own[WPB]; int cs, b, y0, x0; bool in; };    // offset + shift = sa + sb, added when the row is written (the prefetch must not wait)
   auto load_rows = [&](RowOps& o, int m_base) {
-    const int m = min(m_base + min(tid, R - 1), a.M - 1);
+    const int mr = m_base + min(tid, R - 1), m = min(mr, a.M - 1);
+    o.in = mr < a.M;
     o.cs = m / B; o.b = m - o.cs * B;
     o.rs = a.row_scale[m];
+    o.y0 = p.blk_y0x0[2 * o.b]; o.x0 = p.blk_y0x0[2 * o.b + 1];
 #pragma unroll
     for (int w = 0; w < WPB; ++w) o.own[w] = p.ownbits[((int64_t)o.cs * B + o.b) * wps + (int)blockIdx.x * WPB + w];
   };
@@ -2558,9 +2663,9 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
 #pragma unroll
     for (int f = 0; f < C; ++f) {
       if (p.cf) {                                      // closed form: a0 + the B pair dots of this (case, field, block)
-        o.sub[f] = p.cf_a0[((int64_t)o.cs * C + f) * B + o.b] + p.cf_dots[((int64_t)o.cs * C + f) * B + o.b];
+        o.sa[f] = p.cf_a0[((int64_t)o.cs * C + f) * B + o.b]; o.sb[f] = p.cf_dots[((int64_t)o.cs * C + f) * B + o.b];
       } else {
-        o.sub[f] = p.offs[((int64_t)o.cs * C + f) * B + o.b] + p.shift[o.cs * C + f];
+        o.sa[f] = p.offs[((int64_t)o.cs * C + f) * B + o.b]; o.sb[f] = p.shift[o.cs * C + f];
       }
     }
   };
@@ -2589,8 +2694,6 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
       for (int u = 0; u < 4; ++u) gpart += (k0 + 256 * u < p.n_gwaves) ? gv[u] : 0.f;
     }
   }
-  for (int t = tid; t < 2 * B; t += 256) yx[t] = p.blk_y0x0[t];      // B may exceed 128 here (single cases with many blocks)
-  float* lg = reinterpret_cast<float*>(yx + 2 * B);                  // [4] guard partial per wave
   {
     const float gw = wave_sum(gpart);
     if (lane == 0) lg[wave] = gw;
@@ -2609,13 +2712,14 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
   const int px = col / C, f = col - px * C;
   const int pxl = px - (int)blockIdx.x * (128 / C);
   const int r = px / S, c = px - r * S;
+  const uint32_t pix_off = (uint32_t)((r * p.Nx + c) * C + f);       // this lane's cell within a block's window, in elements
+  const int own_w = pxl >> 5;
+  const uint32_t own_bit = 1u << (pxl & 31);
+  const float mu_r = psm_settled(mu);                  // (64 cases: 4.6 us per chunk for 0.6 us of MFMAs before this)
+  // Row chunks.  The NEXT chunk's activation tile and row operands are requested as soon as the current tile sits in LDS and
+  // land during its MFMAs and stores (they were a full exposed round trip per chunk: 64 cases are 4-5 chunks per workgroup).
   for (int m_base = m_first; m_base < m_end; m_base += m_step) {
-    if (m_base != m_first) {
-      __syncthreads();                                 // every wave is done with the previous chunk
-      load_tile(x, m_base);
-      load_rows(ro, m_base);
-      load_sub(ro);
-    }
+    if (m_base != m_first) __syncthreads();            // every wave is done with the previous chunk's tile and row operands
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
       const int idx = tid + 256 * u, row = idx / Q, q = idx - row * Q;
@@ -2635,14 +2739,18 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
       }
     }
     if (tid < R) {
-      lrs[tid] = ro.rs;
+      const uint32_t off = (uint32_t)(((int64_t)ro.cs * p.npix + (int64_t)ro.y0 * p.Nx + ro.x0) * C);
+      lrow[tid] = make_float4(ro.rs, ro.sa[0] + ro.sb[0], ro.sa[C - 1] + ro.sb[C - 1], __uint_as_float(off));
 #pragma unroll
-      for (int ff = 0; ff < C; ++ff) lsub[tid * C + ff] = ro.sub[ff];
-#pragma unroll
-      for (int w = 0; w < WPB; ++w) lown[tid * WPB + w] = ro.own[w];
-      lcb[2 * tid] = ro.cs; lcb[2 * tid + 1] = ro.b;
+      for (int w = 0; w < WPB; ++w) lown[tid * WPB + w] = ro.in ? ro.own[w] : 0u;
     }
     __syncthreads();
+    if (m_base + m_step < m_end) {                     // uniform
+      load_tile(x, m_base + m_step);
+      load_rows(ro, m_base + m_step);
+      load_sub(ro);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     f32x16 acc[MTC];
 #pragma unroll
     for (int mt = 0; mt < MTC; ++mt) {
@@ -2689,12 +2797,9 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
 #pragma unroll
         for (int rg = 0; rg < 16; ++rg) {
           const int rr = mt * 32 + acc_row(rg, h);
-          const bool mine = (m_base + rr) < a.M && ((lown[rr * WPB + (pxl >> 5)] >> (pxl & 31)) & 1u);
-          if (mine) {
-            const int cs = lcb[2 * rr], bb = lcb[2 * rr + 1];
-            const int y = yx[2 * bb] + r, xx = yx[2 * bb + 1] + c;
-            p.fields[((int64_t)cs * p.npix + (int64_t)y * p.Nx + xx) * C + f] = (acc[mt][rg] + mu) * lrs[rr] - lsub[rr * C + f] - gsum;
-          }
+          const float4 ro4 = lrow[rr];
+          if (lown[rr * WPB + own_w] & own_bit)
+            p.fields[(size_t)(__float_as_uint(ro4.w) + pix_off)] = (acc[mt][rg] + mu_r) * ro4.x - (C == 2 && f ? ro4.z : ro4.y) - gsum;
         }
       }
     }
@@ -2722,7 +2827,8 @@ hipError_t psm_launch_decode_paste_batch(const PsmDecodeArgs& a, const PsmBoundB
   const int R = mtc * 32;
   const bool x6 = a.x6 && !bf16;
   const size_t tile_floats = x6 ? (size_t)R * (a.ld_res + 4) * 3 / 2 : (size_t)R * (a.ld_res + 4);
-  const size_t lds = (tile_floats + R + (size_t)R * c_out + (size_t)R * wpb + 2 * (size_t)R + 2 * (size_t)p.B + 4) * sizeof(float);
+  const size_t lds = (tile_floats + 4 * (size_t)R + (size_t)R * wpb + 4) * sizeof(float);
+  if ((int64_t)p.n_cases * p.npix * c_out >= (int64_t)1 << 32) return hipErrorInvalidValue;   // cell offsets are 32-bit element counts
   const dim3 grid(nwg, groups);
 #define DP(M_, C_, L_)                                                                                                          \
   do {                                                                                                                          \
@@ -2791,8 +2897,7 @@ __global__ __launch_bounds__(256) void psm_res_dots_kernel(PsmDotsArgs d, const 
   const int lane = threadIdx.x & 63, row = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int n_dot_wgs = d.n_src > 1 ? d.n_rows : (d.n_rows + 3) / 4;
   if ((int)blockIdx.x >= n_dot_wgs) {                    // guard riders (PsmGuardArgs)
-    const int gw = ((int)blockIdx.x - n_dot_wgs) * 4 + (int)(threadIdx.x >> 6);
-    if (gw < d.guard.n_waves) psm_guard_wave(d.guard, gw, lane);
+    psm_guard_wg<4>(d.guard, (int)blockIdx.x - n_dot_wgs, (int)(threadIdx.x >> 6), lane);
     return;
   }
   const int rc = min(row, d.n_rows - 1);
@@ -2844,7 +2949,7 @@ __global__ __launch_bounds__(256) void psm_res_dots_kernel(PsmDotsArgs d, const 
 
 hipError_t psm_launch_res_dots(const PsmDotsArgs& d, const float* res, int ld_res, hipStream_t st) {
   if (ld_res > 128 || ld_res < 1 || d.n_rows < 1) return hipErrorInvalidValue;
-  const int nwg = (d.n_src > 1 ? d.n_rows : (d.n_rows + 3) / 4) + (d.guard.sdf ? (d.guard.n_waves + 3) / 4 : 0);
+  const int nwg = (d.n_src > 1 ? d.n_rows : (d.n_rows + 3) / 4) + (d.guard.sdf ? d.guard.wg_count : 0);
   PSM_LAUNCH(psm_res_dots_kernel, dim3(nwg), dim3(256), 0, st, d, res, ld_res);
   return hipGetLastError();
 }
