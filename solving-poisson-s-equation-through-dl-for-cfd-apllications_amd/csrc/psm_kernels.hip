@@ -43,6 +43,21 @@ hipError_t psm_read_stamps(unsigned long long* out) { for (int i = 0; i < 64; ++
 
 __device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
+// One scalar load from every 64-byte line of the kernel-argument segment, all requested together at the top of a kernel.  hipcc
+// fetches arguments lazily, in the basic block that first needs them: a kernel with 250-300 bytes of arguments (two argument
+// structs) took three or four scalar-cache MISSES one after the other on its way to its first vector load (decode + paste: 1.9 us
+// from entry to "all requests issued").  With the lines warmed by one batch the later loads hit.
+template <int BYTES>
+__device__ __forceinline__ void psm_warm_kernargs() {
+  typedef const __attribute__((address_space(4))) int* kptr;
+  kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+  int v[(BYTES + 63) / 64];
+#pragma unroll
+  for (int o = 0; o < (BYTES + 63) / 64; ++o) v[o] = ka[16 * o];
+#pragma unroll
+  for (int o = 0; o < (BYTES + 63) / 64; ++o) asm volatile("" ::"s"(v[o]));
+}
+
 // streamed-once operands (PCA bases): -DPSM_NT_STREAM selects non-temporal loads (so that the 42 MB of basis data per
 // solve do not displace the small tables and dense weights from the L2s).  Measured on MI355X: SLOWER, 44.1 vs
 // 41.9 us per solve -- back-to-back solves re-read the bases from L2 / Infinity Cache, which nt gives up.  Off.
@@ -61,6 +76,7 @@ __device__ __forceinline__ float4 stream_load(const float4* p) { return *p; }
 // ---------------------------------------------------------------------------
 template <int C_IN, bool ALIGNED>
 __global__ __launch_bounds__(256) void psm_encode_kernel(PsmEncodeArgs a) {
+  psm_warm_kernargs<sizeof(PsmEncodeArgs)>();
   constexpr int KS = PSM_PIX_PER_SLICE * C_IN;  // K elements per workgroup
   constexpr int G = KS / 8;                     // groups of 8 k
   constexpr int LDA = KS + 4;                   // LDS row stride (floats): 16-B slots rotate by one per row
@@ -309,6 +325,7 @@ __device__ __forceinline__ x6_bf16x8 psm_cat4(x6_bf16x4 a, x6_bf16x4 b) { return
 
 template <int C_IN, bool ALIGNED>
 __global__ __launch_bounds__(256) void psm_encode_x6_kernel(PsmEncodeArgs a) {
+  psm_warm_kernargs<sizeof(PsmEncodeArgs)>();
   constexpr int KS = PSM_PIX_PER_SLICE * C_IN;  // K elements per workgroup
   constexpr int G = KS / 8;                     // float4 groups of the packed basis per lane
   constexpr int NS = KS / 16;                   // MFMA steps
@@ -483,6 +500,7 @@ __global__ __launch_bounds__(256) void psm_encode_x6_kernel(PsmEncodeArgs a) {
 // ---------------------------------------------------------------------------
 template <int C_IN, bool ALIGNED>
 __global__ __launch_bounds__(256, 2) void psm_encode_x6_mt_kernel(PsmEncodeArgs a) {
+  psm_warm_kernargs<sizeof(PsmEncodeArgs)>();
   constexpr int KS = PSM_PIX_PER_SLICE * C_IN;  // K elements per slice
   constexpr int KH = KS / 2;                    // ... per half-slice
   constexpr int NSH = KH / 16;                  // MFMA steps per half-slice
@@ -1046,6 +1064,7 @@ __device__ __forceinline__ float psm_guard_sum(const float* flags, int n, int la
 // the workgroup's own rows in a prologue, operands normalised on their way into the MFMAs, optional residual in the epilogue.
 template <int NGC, bool BF16, int ROWS, bool DOTS, bool LNIN = false>   // NGC: groups of 16 k per wave per pass
 __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a, PsmDotsArgs d) {
+  psm_warm_kernargs<sizeof(PsmDenseArgs) + sizeof(PsmDotsArgs)>();
   constexpr int NCT = 1;   // column tiles of 16 per workgroup.  (Two, for 576 block rows x 512 columns = 576 workgroups on 512 slots, measured no
                            // gain: 7.7 / 8.7 us either way -- the layer is 4.3 us of latency + 147 456 float32 MFMAs of 32 cycles on 1024 SIMDs.)
   if (!DOTS && blockIdx.z > 0) {                       // guard riders behind a hidden layer (large case batches)
@@ -1335,6 +1354,7 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a, PsmDotsA
       } else {
         load_w(g0, w);
       }
+      __builtin_amdgcn_sched_barrier(0);               // every request of the pass before its first MFMA (the scheduler had sunk half of them behind it: two round trips)
       mma(a0, a1, w);
     }
   }
@@ -2357,10 +2377,11 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
   constexpr int NST = 8;                               // staging rounds of 384 floats (C*nst + nst <= 3072)
   constexpr int R = MTC * 32;
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  psm_warm_kernargs<sizeof(PsmDecodeArgs) + sizeof(PsmBoundArgs)>();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int B = p.B, nst = p.n_strips, S = p.cp.S;
-  // per block row, one 32-byte record for the epilogue: {y0, x0, out_scale, -, ownership words (WPB <= 4)}
+  // per block row, one 32-byte record for the epilogue: {element offset of the block's first cell (bits), -, out_scale, -, ownership words (WPB <= 4)}
   float* rec = lds + R * LDA;                          // [R][8]
   float* smean = rec + R * 8;                          // [C][nst]
   float* scnt = smean + C * nst;                       // [nst]
@@ -2374,15 +2395,23 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
   // ---- every load of the prologue, clamped and unconditional
   const int n_stage = p.cf ? 1 : C * nst + nst;
   float sv[NST];
+  if (!p.cf) {                                         // (closed form: nothing to stage -- eight clamped loads and their address chains less)
 #pragma unroll
-  for (int u = 0; u < NST; ++u) {
-    const int idx = min(tid + 384 * u, n_stage - 1);
-    const float* src = p.cf ? p.cf_dots : (idx < C * nst ? p.dots + idx : p.scnt + (idx - C * nst));
-    sv[u] = *src;
+    for (int u = 0; u < NST; ++u) {
+      const int idx = min(tid + 384 * u, n_stage - 1);
+      const float* src = idx < C * nst ? p.dots + idx : p.scnt + (idx - C * nst);
+      sv[u] = *src;
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < NST; ++u) sv[u] = 0.f;
   }
   // closed form of the chain: offset + shift of block b = a0 + the long dot the head launch left (one thread per value)
   const int cfi = min(tid, C * B - 1);
-  const float cfv = p.cf ? p.cf_a0[cfi] + p.cf_dots[cfi] : 0.f;
+  // (the two terms are added where they are written to LDS: added here, the sum waited vmcnt(0) for both -- a full round trip to
+  // what the head launch has just written -- BEFORE the basis stream below was requested)
+  float cfa = 0.f, cfb = 0.f;
+  if (p.cf) { cfa = p.cf_a0[cfi]; cfb = p.cf_dots[cfi]; }
   const int rb = min(tid, B - 1);                      // threads < B: the record of block row tid
   uint32_t ow[WPB];
 #pragma unroll
@@ -2407,14 +2436,15 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
   const int col = ct * 32 + i;
   const float mu = a.mean[col];
   __builtin_amdgcn_sched_barrier(0);
+  PSM_STAMP(0, 24);
   // ---- LDS staging; the barrier drains LDS traffic only, so the basis loads above stay in flight behind it
 #pragma unroll
   for (int u = 0; u < NST; ++u)
     if (!p.cf && tid + 384 * u < n_stage) smean[tid + 384 * u] = sv[u];       // smean and scnt are contiguous
-  if (p.cf && tid < C * B) offs[tid] = cfv;
+  if (p.cf && tid < C * B) offs[tid] = cfa + cfb;
   if (tid < B) {
     float* rr = rec + tid * 8;
-    rr[0] = __int_as_float(y0v); rr[1] = __int_as_float(x0v); rr[2] = rs; rr[3] = 0.f;
+    rr[0] = __uint_as_float((uint32_t)((y0v * p.Nx + x0v) * C)); rr[1] = 0.f; rr[2] = rs; rr[3] = 0.f;   // element offset of the block's first cell (one case: < 2^31)
 #pragma unroll
     for (int w = 0; w < WPB; ++w) rr[4 + w] = __uint_as_float(ow[w]);
   }
@@ -2438,6 +2468,7 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
       }
     }
   }
+  PSM_STAMP(0, 25);
   PSM_LDS_BARRIER();
   PSM_STAMP(0, 21);
   f32x16 acc[MTC];
@@ -2519,6 +2550,7 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
   const int pxl = px - (int)blockIdx.x * (128 / C);
   const int r = px / S, c = px - r * S;
   const float sh = wred[f];
+  const uint32_t pix_off = (uint32_t)((r * p.Nx + c) * C + f);       // this lane's cell within a block's window, in elements
   // epilogue in two passes so that the LDS reads of all 16 rows are in flight together: records and offsets first
   // (straight-line), then the owned values are stored
 #pragma unroll
@@ -2537,10 +2569,7 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
       const int m = mt * 32 + acc_row(rg, h);
       const uint32_t word = __float_as_uint(rb4[rg][pxl >> 5]);
       const bool mine = m < B && ((word >> (pxl & 31)) & 1u);
-      if (mine) {
-        const int y = __float_as_int(ra[rg][0]) + r, xx = __float_as_int(ra[rg][1]) + c;
-        p.fields[((int64_t)y * p.Nx + xx) * C + f] = (acc[mt][rg] + mu_r) * ra[rg][2] - of[rg] - sh;
-      }
+      if (mine) p.fields[(size_t)(__float_as_uint(ra[rg][0]) + pix_off)] = (acc[mt][rg] + mu_r) * ra[rg][2] - of[rg] - sh;
     }
   }
   PSM_STAMP(0, 23);
@@ -2622,6 +2651,7 @@ hipError_t psm_launch_chain_dots(const PsmBoundBatchArgs& p, int c_out, hipStrea
 
 template <int MTC, int C, int LDR, int MODE>           // MODE 0: exact-f32 MFMA, 1: bf16 handle (operands rounded), 2: x6 (float32 accuracy on the bf16 pipe)
 __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeArgs a, PsmBoundBatchArgs p, int m_end) {
+  psm_warm_kernargs<sizeof(PsmDecodeArgs) + sizeof(PsmBoundBatchArgs)>();
   constexpr bool BF = MODE == 1, X6 = MODE == 2;
   constexpr int LDX = LDR + 4;                         // x6: plane row stride in bf16 (LDR / 2 + 2 dwords = 2 * odd: ds_read_b64 conflict-free)
   constexpr int LDA = X6 ? 3 * LDX / 2 : (BF ? (LDR + 8) / 2 : LDR + 4);    // tile floats per row (bf16: LDR + 8 halves; x6: three planes)

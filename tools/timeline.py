@@ -8,7 +8,7 @@ import psm_amd
 from psm_amd import synthetic
 from hipmem import DeviceArray
 NAMES = {0: "encode start", 1: "encode staged", 2: "encode end", 3: "encode tile 0 done", 4: "encode other tiles staged", 8: "rd1 start", 9: "rd1 slabs summed", 10: "rd1 L1 partials", 11: "rd1 end",
-         16: "reduce start", 17: "reduce summed", 20: "decode start", 21: "decode staged", 22: "decode mfma done", 23: "decode end",
+         16: "reduce start", 17: "reduce summed", 20: "decode start", 24: "decode requests issued", 25: "decode own rows staged (thread 0)", 21: "decode staged", 22: "decode mfma done", 23: "decode end",
          28: "strips start", 29: "strips loads landed", 30: "strips end", 36: "assemble start", 37: "assemble phase1", 38: "assemble pre",
          39: "assemble chain", 40: "assemble post", 41: "assemble end"}
 for l in range(4):
