@@ -1,0 +1,21 @@
+// Device-side helpers shared by the .hip files.
+#pragma once
+
+// One scalar load from every 64-byte line of the kernel-argument segment, all requested together at the top of a kernel.  hipcc
+// fetches arguments lazily, in the basic block that first needs them: a kernel with 250-300 bytes of arguments (two argument
+// structs) took three or four scalar-cache MISSES one after the other on its way to its first vector load (decode + paste: 1.9 us
+// from entry to "all requests issued", 1.6 us with the lines warmed by one batch -- the later loads hit).
+// (-DPSM_NO_WARM_KERNARGS: diagnostic build without it, for A/B runs on one box.)
+template <int BYTES>
+__device__ __forceinline__ void psm_warm_kernargs() {
+#ifdef PSM_NO_WARM_KERNARGS
+  return;
+#endif
+  typedef const __attribute__((address_space(4))) int* kptr;
+  kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+  int v[(BYTES + 63) / 64];
+#pragma unroll
+  for (int o = 0; o < (BYTES + 63) / 64; ++o) v[o] = ka[16 * o];
+#pragma unroll
+  for (int o = 0; o < (BYTES + 63) / 64; ++o) asm volatile("" ::"s"(v[o]));
+}

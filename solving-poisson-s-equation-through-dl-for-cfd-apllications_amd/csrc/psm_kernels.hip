@@ -16,6 +16,7 @@
 // The K order inside a group of 8 is permuted (step j of group g uses k = 8g + 4h + j for
 // lane half h) so that one 16-byte read per lane feeds four MFMAs; both operands use it.
 #include "psm_kernels.h"
+#include "psm_devutil.h"
 #include <type_traits>
 
 #include <algorithm>
@@ -42,21 +43,6 @@ hipError_t psm_read_stamps(unsigned long long* out) { for (int i = 0; i < 64; ++
 #endif
 
 __device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
-
-// One scalar load from every 64-byte line of the kernel-argument segment, all requested together at the top of a kernel.  hipcc
-// fetches arguments lazily, in the basic block that first needs them: a kernel with 250-300 bytes of arguments (two argument
-// structs) took three or four scalar-cache MISSES one after the other on its way to its first vector load (decode + paste: 1.9 us
-// from entry to "all requests issued").  With the lines warmed by one batch the later loads hit.
-template <int BYTES>
-__device__ __forceinline__ void psm_warm_kernargs() {
-  typedef const __attribute__((address_space(4))) int* kptr;
-  kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
-  int v[(BYTES + 63) / 64];
-#pragma unroll
-  for (int o = 0; o < (BYTES + 63) / 64; ++o) v[o] = ka[16 * o];
-#pragma unroll
-  for (int o = 0; o < (BYTES + 63) / 64; ++o) asm volatile("" ::"s"(v[o]));
-}
 
 // streamed-once operands (PCA bases): -DPSM_NT_STREAM selects non-temporal loads (so that the 42 MB of basis data per
 // solve do not displace the small tables and dense weights from the L2s).  Measured on MI355X: SLOWER, 44.1 vs
@@ -2703,6 +2689,12 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
   RowOps ro;
   load_tile(x, m_first);
   load_rows(ro, m_first);
+  // guard flags of this solve (0, or NaN after a geometry mismatch): with the closed form there is no chain launch to fold
+  // them into the shift, so every workgroup sums them itself.  The first 1024 (64 cases) are requested HERE, in front of the
+  // basis stream: as a loop behind it they were a round trip of their own after everything else had landed.
+  float gv0[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) gv0[u] = p.gflags[min(tid + 256 * u, p.n_gwaves - 1)];     // (unconditional: never null, >= 1 entry)
   __builtin_amdgcn_sched_barrier(0);
   float4 b[GD];
   const float4* bp = a.bpack + ((int64_t)ct * GD) * 64 + lane;
@@ -2712,11 +2704,11 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
   const float mu = a.mean[col];
   __builtin_amdgcn_sched_barrier(0);
   load_sub(ro);
-  // guard flags of this solve (0, or NaN after a geometry mismatch): with the closed form there is no chain launch to fold
-  // them into the shift, so every workgroup sums them itself (a few loads per thread, in flight with everything else)
   float gpart = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) gpart += (p.cf && tid + 256 * u < p.n_gwaves) ? gv0[u] : 0.f;
   if (p.cf) {
-    for (int k0 = tid; k0 < p.n_gwaves; k0 += 256 * 4) {
+    for (int k0 = tid + 1024; k0 < p.n_gwaves; k0 += 256 * 4) {      // more than 64 cases' worth of flags
       float gv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) gv[u] = p.gflags[min(k0 + 256 * u, p.n_gwaves - 1)];
