@@ -4,7 +4,8 @@
 // One scalar load from every 64-byte line of the kernel-argument segment, all requested together at the top of a kernel.  hipcc
 // fetches arguments lazily, in the basic block that first needs them: a kernel with 250-300 bytes of arguments (two argument
 // structs) took three or four scalar-cache MISSES one after the other on its way to its first vector load (decode + paste: 1.9 us
-// from entry to "all requests issued", 1.6 us with the lines warmed by one batch -- the later loads hit).
+// from entry to "all requests issued", 1.6 us with the lines warmed by one batch -- the later loads hit).  The convolution kernels
+// (one argument struct, A/B on one box: 145.0 / 144.1 against 144.7 / 146.1 us per pass) do not use it.
 // (-DPSM_NO_WARM_KERNARGS: diagnostic build without it, for A/B runs on one box.)
 template <int BYTES>
 __device__ __forceinline__ void psm_warm_kernargs() {

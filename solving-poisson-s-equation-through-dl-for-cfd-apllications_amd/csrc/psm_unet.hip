@@ -15,7 +15,6 @@
 //   D: lane l, register r holds pixel 4*(l >> 4) + r, output channel (l & 15)
 // Epilogue: bias, ReLU, NHWC store (16 consecutive channels = 64 B per pixel).
 #include "psm_unet.h"
-#include "psm_devutil.h"
 
 #include <type_traits>
 
@@ -283,7 +282,6 @@ __device__ __forceinline__ void store_act(float* out, int64_t elem, float v, boo
 //     of 32 channels, three LDS planes per operand; the weights (27 KiB x NCT per chunk) are single-buffered.
 template <int TH, int WM, int NCT, int WN, int SRC, int KSM, bool BF, int NB, bool ABF = false, bool X6 = false>     // SRC: PSM_SRC_*, -1 = unaligned stem, 3 = upsample + skip with the seam inside a chunk
 __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_groups) {
-  psm_warm_kernargs<sizeof(PsmConvArgs) + 8>();
   static_assert(!ABF || (BF && KSM == 1 && SRC >= 0 && SRC != 3), "bf16 activations: finished same / upsample / max-pool sources only");
   static_assert(!X6 || (BF && !ABF && NB == 2 && SRC >= 0), "x6: float32 inputs, bf16 MFMA, double-buffered input planes");
   constexpr int PL = X6 ? 3 : 1;                                    // operand planes

@@ -21,7 +21,6 @@
 //   16-channel chunks: 32-byte LDS pixel, unswizzled; lane groups 2,3 read the NEXT pixel, so one MFMA does the taps
 //     kx and kx + 1 (weights of the pair stacked along k; the partner of kx = 2 has zero weights): 6 MFMAs per row.
 #include "psm_unet.h"
-#include "psm_devutil.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -528,7 +527,6 @@ __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0
 // ====================================================================================================================
 template <int C0, bool KEEP>
 __global__ __launch_bounds__(256, 2) void psm_pair_stem16_kernel(PsmPairArgs a) {
-  psm_warm_kernargs<sizeof(PsmPairArgs)>();
   constexpr int K = 9 * C0, KS = (K + 31) / 32;
   constexpr int PI = 34;                                  // pitch of the image tile (pixels)
   constexpr int RW = (IH + 3) / 4;                        // image rows per wave
@@ -700,7 +698,6 @@ static_assert(DmaLow::BYTES >= LOW_BYTES && Dma16::BYTES >= T16_BYTES, "whole pi
 // ====================================================================================================================
 template <bool KEEP, bool HEAD>
 __global__ __launch_bounds__(256, 2) void psm_pair_up16_kernel(PsmPairArgs a) {
-  psm_warm_kernargs<sizeof(PsmPairArgs)>();
   // ONE __shared__ object: with several, hipcc's wait-count pass ties the LDS reads of conv B (mid tile, weights) to the LDS-DMA
   // pieces just requested and drains vmcnt(0) in front of them -- the requests would never be in flight during anything
   // (cdna_hip_programming.md, 'Projection GEMM at M = 256', item 4(a)).  With one object it inserts no such waits at all, so the
@@ -814,7 +811,6 @@ struct Chunk { int form, cb; };                          // form, first channel 
 
 template <int KIND, bool KEEP>
 __global__ __launch_bounds__(256, 2) void psm_pair32_kernel(PsmPairArgs a) {
-  psm_warm_kernargs<sizeof(PsmPairArgs)>();
   __shared__ __attribute__((aligned(16))) char lds[PAIR32_LDS];
   __shared__ __attribute__((aligned(16))) float bias_l[64];       // conv A's, then conv B's
   char* tile = lds;
