@@ -132,3 +132,34 @@ def test_case_batch_guard():
         got = sur.solve(swapped)
         assert sur.guard_trips == 1 and not sur.geometry_bound
         np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("odd_case", [0, 17, 39])
+def test_large_batch_guard_riders_are_dealt_over_the_dense_launches(odd_case):
+    """From 256 guard workgroups up (more than 16 cases of 256 x 256) the riders are dealt over ALL Dense launches of the step
+    (psm_api_solve.cpp, PSM_GUARD_SPREAD), one flag per guard workgroup: a single foreign case anywhere in the batch -- in the
+    share of the first hidden layer, of a middle one, of the head launch -- must still trip the guard."""
+    n = 40
+    model = synthetic.make_model("deltas", p_in=32, p_out=32)
+    grids = synthetic.random_obstacle_cases(n, 256, 256, seed=3).astype(np.float32)
+    other = synthetic.random_obstacle_cases(n, 256, 256, seed=11).astype(np.float32)
+    foreign = grids.copy()
+    foreign[odd_case] = other[odd_case]
+    assert not np.array_equal(foreign[odd_case, ..., 2] != 0, grids[odd_case, ..., 2] != 0)
+    with GridSurrogate(model, 256, 256, max_cases=n) as sur:
+        want = sur.solve(foreign)                      # general path
+        assert sur.bind_geometry(grids)
+        got = sur.solve(grids)
+        assert np.isfinite(got).all() and sur.guard_trips == 0 and sur.geometry_bound
+        got = sur.solve(foreign)
+        assert sur.guard_trips == 1 and not sur.geometry_bound
+        np.testing.assert_array_equal(got, want)
+        # the device-pointer entry: the whole field of the step is NaN (never a plausible field of the wrong geometry)
+        assert sur.bind_geometry(grids)
+        d_in, d_out = DeviceArray(foreign), DeviceArray(shape=(n, 256, 256, 1))
+        sur.solve_device(d_in.ptr, n, d_out.ptr, 0)
+        with pytest.raises(_lib.PsmError) as e:
+            sur.synchronize()
+        assert e.value.code == -7                          # PSM_ERR_GEOMETRY
+        assert np.isnan(d_out.numpy()).all()
+        d_in.free(); d_out.free()
