@@ -76,6 +76,9 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
     const int groups = (ea.x6 && !bf16) ? encode_groups(h, Mpad) : 1;
     if (groups > 1 && h->d_bpack_x6) { ea.kgroup = groups; n_slabs = groups; ea.bpack_x6 = h->d_bpack_x6; }
   }
+  // a single case of four component tiles: two K slices per workgroup, half the slabs (psm_encode_pair_kernel)
+  ea.pairs_ok = bf16 ? 0 : 1;
+  if (psm_encode_pairs(ea)) n_slabs = h->n_slices / 2;
 
   if (h->timed_kernel == PSM_K_ENCODE && !prof) {
     // dominant kernel: dispatch-level begin / end stamps (no marker packets around the launch)

@@ -286,6 +286,92 @@ __global__ __launch_bounds__(256) void psm_encode_kernel(PsmEncodeArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// encode of ONE row tile (a single case, <= 32 block rows) with four component tiles: a workgroup owns TWO consecutive K
+// slices and one HALF of the components -- waves (slice 0 | 1) x (component tile 2 half + (0 | 1)) -- and adds the two
+// slices' partial sums through LDS before it stores: n_slices / 2 slabs instead of n_slices.  Same basis bytes, same
+// MFMAs per wave (one slice x one component tile, the whole basis slice in registers, counted waits) as the one-slice
+// form above; what halves is the slab traffic (4.2 -> 2.1 MB written) and, above all, what the ONE workgroup per block row
+// of psm_reduce_dense1_kernel has to pull in front of the first Dense layer (128 -> 64 KB: that launch's longest phase).
+// ---------------------------------------------------------------------------
+template <int C_IN, bool ALIGNED>
+__global__ __launch_bounds__(256) void psm_encode_pair_kernel(PsmEncodeArgs a) {
+  psm_warm_kernargs<sizeof(PsmEncodeArgs)>();
+  constexpr int KS = PSM_PIX_PER_SLICE * C_IN;  // K elements per slice
+  constexpr int G = KS / 8;                     // groups of 8 k
+  constexpr int LDA = KS + 4;                   // LDS row stride (floats): 16-B slots rotate by one per row
+  constexpr int Q = KS / 4;                     // 16-byte pieces per activation row (<= 64)
+  extern __shared__ __attribute__((aligned(16))) float lds[];                  // [2 slices][32 rows][LDA], then [2 tiles][64 lanes][16]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int sl = wave >> 1, j = wave & 1;       // this wave's slice of the pair; its row parity in the staging and its component tile of the half
+  const int pair = (int)blockIdx.x >> 1, half = (int)blockIdx.x & 1;
+  const int s = 2 * pair + sl, t = 2 * half + j;
+  const int runs = a.S / PSM_PIX_PER_SLICE;
+  const int r = s / runs, c0 = (s - r * runs) * PSM_PIX_PER_SLICE;
+  const int64_t src_off = (int64_t)r * a.row_stride + (int64_t)c0 * C_IN;
+  const int NT = a.NT;
+  const int i = lane & 31, h = lane >> 5;
+  const int ql = lane < Q ? lane : Q - 1;       // lanes >= Q idle in the staging (C_IN < 4)
+  const float4 mu = *reinterpret_cast<const float4*>(a.mean + (int64_t)s * KS + 4 * ql);
+  // staging: the two waves of a slice take its even / odd rows (16 each); every request before any use
+  float4 x[16];
+  {
+    int64_t rb[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) rb[u] = a.row_base[min(j + 2 * u, a.M - 1)];                       // wave-uniform
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const float* src = a.grid + rb[u] + src_off + 4 * ql;
+      if (ALIGNED) x[u] = *reinterpret_cast<const float4*>(src);
+      else x[u] = make_float4(src[0], src[1], src[2], src[3]);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  float4 b[G];
+  {
+    const float4* p = a.bpack + (((int64_t)s * NT + t) * G) * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < G; ++g) b[g] = stream_load(p + g * 64);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  float* tile = lds + sl * 32 * LDA;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {                // waits for the activation rows only (counted vmcnt)
+    const int row = j + 2 * u;
+    const float keep = row < a.M ? 1.f : 0.f;   // padding rows -> 0 (no branch)
+    const float4 v = make_float4((x[u].x - mu.x) * keep, (x[u].y - mu.y) * keep, (x[u].z - mu.z) * keep, (x[u].w - mu.w) * keep);
+    if (lane < Q) *reinterpret_cast<float4*>(&tile[row * LDA + 4 * lane]) = v;
+  }
+  __syncthreads();
+  f32x16 acc = {0};
+  {
+    const float* arow = &tile[i * LDA + 4 * h];
+    float4 av = *reinterpret_cast<const float4*>(arow);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float4 an = *reinterpret_cast<const float4*>(arow + 8 * (g + 1 < G ? g + 1 : g));   // next group in flight
+      acc = MFMA32(av.x, b[g].x, acc);
+      acc = MFMA32(av.y, b[g].y, acc);
+      acc = MFMA32(av.z, b[g].z, acc);
+      acc = MFMA32(av.w, b[g].w, acc);
+      av = an;
+    }
+  }
+  // slice 1's partial sums meet slice 0's through LDS ([tile j][register][lane]: conflict-free both ways); fixed order s0 + s1
+  float* red = lds + 2 * 32 * LDA + j * 16 * 64;
+  if (sl == 1) {
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) red[rg * 64 + lane] = acc[rg];
+  }
+  __syncthreads();
+  if (sl == 0) {
+    float* out = a.part + ((int64_t)pair * a.Mpad) * a.ldp + t * 32 + i;
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) out[(int64_t)acc_row(rg, h) * a.ldp] = acc[rg] + red[rg * 64 + lane];
+  }
+}
+
+// ---------------------------------------------------------------------------
 // encode, "x6" arithmetic: the same contraction on the bf16 matrix pipe at float32 accuracy.
 // Every float32 operand is split EXACTLY into three bf16 terms, x = hi + mid + lo (8 + 8 + 8 significant bits: the two
 // remainders x - hi and (x - hi) - mid are exact in float32), and a product a * w is taken as the six terms whose
@@ -656,6 +742,13 @@ static bool psm_encode_x6_fits(const PsmEncodeArgs& a, size_t* lds, int* row_wgs
   return a.NT <= 4 && *lds <= 156 * 1024 && a.Mpad % 32 == 0;
 }
 
+// the two-slices-per-workgroup form (psm_encode_pair_kernel): one row tile, exactly four component tiles, float32 MFMA, an even
+// number of slices.  PSM_ENCODE_PAIRS=0 keeps one slab per slice.  The slab count the reduce launches must use: psm_encode_slabs.
+bool psm_encode_pairs(const PsmEncodeArgs& a) {
+  static const bool on = !(getenv("PSM_ENCODE_PAIRS") && atoi(getenv("PSM_ENCODE_PAIRS")) == 0);
+  const int n_slices = a.S * a.S / PSM_PIX_PER_SLICE;
+  return on && a.pairs_ok && !a.x6 && a.kgroup <= 1 && a.Mpad == 32 && a.NT == 4 && n_slices % 2 == 0;
+}
 hipError_t psm_launch_encode(const PsmEncodeArgs& a, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
   const int n_slices = a.S * a.S / PSM_PIX_PER_SLICE;
   const int rows = a.Mpad <= 32 ? 32 : 32 * PSM_MT_CHUNK;        // one tile, or 2 x 64-row buffers / a 128-row chunk
@@ -691,6 +784,20 @@ hipError_t psm_launch_encode(const PsmEncodeArgs& a, hipStream_t st, hipEvent_t 
     }
 #undef ENCX
 #undef ENCX2
+    return hipGetLastError();
+  }
+  if (psm_encode_pairs(a)) {                       // one row tile, four component tiles: two slices per workgroup, n_slices / 2 slabs
+    const size_t lds_p = ((size_t)2 * 32 * (PSM_PIX_PER_SLICE * a.c_in + 4) + 2 * 16 * 64) * sizeof(float);
+#define ENCP2(C, AL)                                                                                          \
+  if (ev_start) hipExtLaunchKernelGGL((psm_encode_pair_kernel<C, AL>), dim3(n_slices), dim3(256), (std::uint32_t)lds_p, st, ev_start, ev_stop, 0, a); \
+  else PSM_LAUNCH((psm_encode_pair_kernel<C, AL>), dim3(n_slices), dim3(256), lds_p, st, a)
+#define ENCP(C) case C: if (a.aligned) { ENCP2(C, true); } else { ENCP2(C, false); } break;
+    switch (a.c_in) {
+      ENCP(1) ENCP(2) ENCP(3) ENCP(4)
+      default: return hipErrorInvalidValue;
+    }
+#undef ENCP
+#undef ENCP2
     return hipGetLastError();
   }
   // With events: hipExtLaunchKernelGGL stamps them with the dispatch's own begin / end times
@@ -753,6 +860,13 @@ __global__ __launch_bounds__(1024) void psm_reduce_kernel(PsmReduceArgs a) {
     for (int u = 0; u < 16; ++u) v[u] = p[(int64_t)(s + u) * total];
 #pragma unroll
     for (int u = 0; u < 16; ++u) acc += v[u];       // fixed order: deterministic
+  }
+  for (; s + 4 <= s1; s += 4) {                     // fewer than 16 slabs per wave (K groups, slice pairs): still every load of a batch in flight together
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = p[(int64_t)(s + u) * total];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc += v[u];
   }
   for (; s < s1; ++s) acc += p[(int64_t)s * total];
   red[wave][lane] = acc;
@@ -831,6 +945,19 @@ __global__ __launch_bounds__(1024) void psm_reduce_dense1_kernel(PsmReduceArgs r
 #pragma unroll
       for (int u = 0; u < 16; ++u) acc1 += v1[u];
     }
+    for (; s + 8 <= s1; s += 8) {                  // 128 slabs (slice pairs): 8 per wave, all 16 loads in flight together
+      float v0[8], v1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float* slab = r.part + (int64_t)(s + u) * total;                     // uniform
+        v0[u] = slab[o0];
+        v1[u] = slab[o1];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc0 += v0[u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc1 += v1[u];
+    }
     for (; s < s1; ++s) { const float* slab = r.part + (int64_t)s * total; acc0 += slab[o0]; acc1 += slab[o1]; }
     if (pc0 < r.ldp) red[wave][pc0] = acc0;
     if (pc1 < r.ldp) red[wave][pc1] = acc1;
@@ -900,7 +1027,7 @@ __global__ __launch_bounds__(1024) void psm_reduce_dense1_kernel(PsmReduceArgs r
 
 hipError_t psm_launch_reduce_dense1(const PsmReduceArgs& r, const PsmDenseArgs& d, hipStream_t st) {
   if (r.ldp > 512 || d.ld_w > 1024 || (d.ld_w / 2) % 1 != 0) return hipErrorInvalidValue;
-  const dim3 grid(r.Mpad, 2);
+  const dim3 grid(r.Mpad, 2);                        // (4 or 8 column workgroups per row: 4.64-4.76 us against 4.72 -- no difference)
   if (d.bf16) PSM_LAUNCH((psm_reduce_dense1_kernel<true>), grid, dim3(1024), 0, st, r, d);
   else PSM_LAUNCH((psm_reduce_dense1_kernel<false>), grid, dim3(1024), 0, st, r, d);
   return hipGetLastError();
