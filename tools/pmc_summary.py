@@ -40,7 +40,7 @@ def _short(k):
 json.dump({"workload": "config1", "kernel_source_hash": _bench.kernel_source_hash(), "profile_tag": tag,
            "unit": "HBM-side bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024; separate --pmc passes with --kernel-trace only",
            "kernels": {_short(r[0]): r[3] for r in rows}}, open(_bench.PMC_FILE, "w"), indent=1)
-enc = [r for r in rows if "psm_encode_kernel" in r[0]][0]
+enc = [r for r in rows if "psm_encode" in r[0]][0]          # psm_encode_kernel / psm_encode_pair_kernel: the single-case encode of this run
 json.dump({"kernel": enc[0], "FETCH_SIZE_KB": enc[1], "WRITE_SIZE_KB": enc[2],
            "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B for 16-B/lane coalesced streams -> doubled (MI355X_MICROARCH.md HBM section); WRITE_SIZE exact",
            "hbm_bytes_per_launch": enc[3],
