@@ -259,6 +259,31 @@ def test_unaligned_grid_and_four_channels():
     assert np.abs(f - sol.fields).max() <= 1e-4 * np.abs(sol.fields).max()
 
 
+@pytest.mark.parametrize("c_in,ny,nx", [(3, 256, 256), (3, 200, 259), (4, 256, 320)])
+def test_single_case_encode_with_two_slices_per_workgroup(c_in, ny, nx):
+    """One case, four component tiles (97 ... 128 input components): psm_encode_pair_kernel -- a workgroup takes two K slices and
+    half of the components and adds the slices through LDS (128 slabs) -- in its aligned, unaligned (odd Nx) and four-channel
+    instances; every stage against the oracle, and more than 32 block rows of the same model through the one-slice-per-slab
+    kernels on the same handle."""
+    model = synthetic.make_model("deltas", p_in=120, p_out=128, c_in=c_in, scaler_kind="std")
+    if c_in == 4:
+        model.sdf_ch = 3
+    g3 = synthetic.channel_grid(ny, nx, seed=8)
+    grid = (g3 if c_in == 3 else np.concatenate([g3[..., :1] * g3[..., 1:2], g3], axis=-1)).astype(np.float32)
+    with GridSurrogate(model, ny, nx, max_cases=5) as sur:
+        assert sur.B <= 32
+        f = sur.solve(grid)[0]
+        sol = orc.solve_grid(grid.astype(np.float64), oracle_model(model))
+        check_against_oracle(sur, grid, model, sol)
+        assert np.abs(f - sol.fields).max() <= 1e-4 * np.abs(sol.fields).max()
+        five = np.stack([grid * np.float32(1.0 + 0.1 * k) for k in range(5)])
+        five[..., model.sdf_ch] = grid[..., model.sdf_ch]
+        got = sur.solve(five)
+        assert np.abs(got[0] - sol.fields).max() <= 1e-4 * np.abs(sol.fields).max()
+        again = sur.solve(grid)[0]
+        np.testing.assert_array_equal(again, f)
+
+
 def test_big_architecture_and_many_components():
     """MLP_small_unet (9 layers, widths 512..32..512) with 200 input / 136 output PCs (more than 4 N-tiles)."""
     model = synthetic.make_model("deltas", p_in=200, p_out=136, arch="MLP_small_unet", scaler_kind="std")
