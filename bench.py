@@ -678,7 +678,7 @@ def shipped_case_leg(synthetic, device, steps, with_cpu):
     W, maxs4, maxs_pca = cases.real_chapter5_weights()
     model = synthetic.make_model("chapter5", p_in=45, p_out=48, weights=W)
     model.in_a, model.out_a = float(maxs_pca[0]), float(maxs_pca[1])
-    array, top, obst = synthetic.channel_mesh(Lx=15.0, Ly=2.0, h=0.031, cx=3.0, R=0.25)
+    array, top, obst = synthetic.shipped_case_mesh()
     sm = SolverModule(model, tuple(float(v) for v in maxs4), device=device, geometry="native")
     t0 = time.perf_counter()
     sm.init_func(array, top, obst)

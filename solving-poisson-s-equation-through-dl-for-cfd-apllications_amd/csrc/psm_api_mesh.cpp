@@ -257,6 +257,7 @@ int psm_solve_begin(psm_handle* h, const double* cells, int64_t n, int32_t rank,
   if (n != h->n_cells) return fail(h, PSM_ERR_ARG, "cell count differs from the geometry");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   hipStream_t st = h->stream;
+  { int rc0 = ensure_encode_aux(h, 1); if (rc0) return rc0; }   // many-block cases (the shipped 104-block shape): the M-tiled encode's split basis, once, outside any capture
   // Both arrays registered (psm_pin_buffers) and mapped: the whole call is ONE hipGraph replay -- psm_stage_cells_kernel reads
   // the cells over PCIe and takes the partial maxima of U_max on the way (no DMA-engine copy, no host pass, U_max never leaves
   // the device: to_grid reduces the partials and hands the scalar to to_mesh through d_umax), to_grid, the kernels of the

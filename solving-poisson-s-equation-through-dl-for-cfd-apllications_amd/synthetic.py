@@ -292,6 +292,22 @@ def channel_mesh(Lx: float = 1.5, Ly: float = 0.7, h: float = 0.008, seed: int =
     return array, top, obst
 
 
+def shipped_case_mesh(delta: float = 0.005, ny: int = 400, nx: int = 3000, h: float = 0.031):
+    """A channel mesh whose cell-centre extents are exactly ny * delta by nx * delta, so that init_func's grid is the reference's shipped
+    case shape (400 x 3000 at delta 0.005: 104 blocks of the Chapter-5 layout; python_module.py:190-217): channel_mesh stretched by a
+    fraction of a percent in x and y (its jitter leaves the extents a few cells short: 400 x 2998, an unaligned row pitch)."""
+    array, top, obst = channel_mesh(Lx=nx * delta, Ly=ny * delta, h=h, cx=3.0, R=0.25)
+    x0, x1, y0, y1 = array[:, 2].min(), array[:, 2].max(), array[:, 3].min(), array[:, 3].max()
+    sx, sy = nx * delta / (x1 - x0), ny * delta / (y1 - y0)
+    ym = 0.5 * (y0 + y1)
+    def tf(pts, cx, cy):
+        pts = pts.copy()
+        pts[:, cx] = (pts[:, cx] - x0) * sx + x0
+        pts[:, cy] = (pts[:, cy] - ym) * sy + ym
+        return pts
+    return tf(array, 2, 3), tf(top, 0, 1), tf(obst, 0, 1)
+
+
 # --------------------------------------------------------------------------
 # convolutional path: layer shapes and seeded weights of the build-defined UNet-S (include/psm_unet.h)
 # --------------------------------------------------------------------------

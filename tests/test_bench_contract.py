@@ -229,7 +229,7 @@ def test_default_bench_line():
     assert d["value_p10"] <= d["value_p50"] <= d["value_p90"] and 0.5 * d["value"] < d["value_p50"] < 1.5 * d["value"]
     assert 0 < d["frac_pass"] < 1 and abs(d["frac_pass"] - full["roofline"]["whole_solve"]["frac"]) < 1e-3
     sc = d["shipped_case"]
-    assert sc["grid"][0] == 400 and 2990 <= sc["grid"][1] <= 3010 and sc["blocks"] == 104 and 20000 < sc["cells"] < 250000 and 0.02 < sc["ms_per_call"] < 5 and sc["p10"] <= sc["ms_per_call"] <= sc["p90"], sc
+    assert sc["grid"] == [400, 3000] and sc["blocks"] == 104 and 20000 < sc["cells"] < 250000 and 0.02 < sc["ms_per_call"] < 5 and sc["p10"] <= sc["ms_per_call"] <= sc["p90"], sc
     assert sc["cpu_ms"] > sc["ms_per_call"] and full["shipped_case"]["finite"] is True and full["shipped_case"]["components"] == [45, 48]
     assert full["per_solve_quantiles"]["samples"] >= 200 and full["per_solve_quantiles"]["solves"] >= 10000
     cbat = d["case_batch"]
