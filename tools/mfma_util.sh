@@ -9,3 +9,8 @@ timeout -k 10 300 rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d
 timeout -k 10 300 rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $O/pca -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --legs none > $O/pca.log 2>&1; echo "pca rc=$?"
 timeout -k 10 300 rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $O/pca64 -- python3 $R/tools/configs_one.py 64 > $O/pca64.log 2>&1; echo "pca64 rc=$?"
 cd $R
+# the box returns gpurun_out/ only (<= 64 MiB): summarise there, keep the condensed file, drop the raw counter traces
+python tools/mfma_summary.py $TAG
+mkdir -p $R/gpurun_out/profiles_$TAG
+cp $R/profiles/${TAG}_mfma_util.csv $R/gpurun_out/profiles_$TAG/
+rm -rf $O/unet8 $O/unet8b $O/pca $O/pca64
