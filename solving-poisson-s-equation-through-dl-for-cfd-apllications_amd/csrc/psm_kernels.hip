@@ -1178,8 +1178,8 @@ __device__ __forceinline__ float psm_guard_sum(const float* flags, int n, int la
 template <int NGC, bool BF16, int ROWS, bool DOTS, bool LNIN = false>   // NGC: groups of 16 k per wave per pass
 __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a, PsmDotsArgs d) {
   psm_warm_kernargs<sizeof(PsmDenseArgs) + sizeof(PsmDotsArgs)>();
-  constexpr int NCT = 1;   // column tiles of 16 per workgroup.  (Two, for 576 block rows x 512 columns = 576 workgroups on 512 slots, measured no
-                           // gain: 7.7 / 8.7 us either way -- the layer is 4.3 us of latency + 147 456 float32 MFMAs of 32 cycles on 1024 SIMDs.)
+  // (One column tile of 16 per workgroup.  Two, for 576 block rows x 512 columns = 576 workgroups on 512 slots, measured no gain: 7.7 / 8.7 us
+  // either way -- the layer is 4.3 us of latency + 147 456 float32 MFMAs of 32 cycles on 1024 SIMDs; profiles/r05_case_batch.txt (6a).)
   if (!DOTS && blockIdx.z > 0) {                       // guard riders behind a hidden layer (large case batches)
     const int wg = ((int)(blockIdx.z - 1) * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
     psm_guard_wg<8>(d.guard, wg, threadIdx.x >> 6, threadIdx.x & 63);
@@ -1314,25 +1314,19 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a, PsmDotsA
     }
     return;
   }
-  __shared__ float red[8][2 * NCT][16 * 17];
+  __shared__ float red[8][2][16 * 17];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nt = blockIdx.x * NCT, mt = blockIdx.y;
+  const int nt = blockIdx.x, mt = blockIdx.y;
   const int i = lane & 15, kq = lane >> 4;
   const int groups = a.Kp / 16;                      // all waves
   const int ng = groups / 8;                         // per wave: a multiple of NGC
   PSM_STAMP(0, 44 + 4 * (a.layer & 3));
   // epilogue operands of this thread's output column: in flight from the start
   const int n_out = nt * 16 + (tid & 15);
-  float bias_v[NCT], sa_v[NCT], sb_v[NCT];
-#pragma unroll
-  for (int c = 0; c < NCT; ++c) {
-    bias_v[c] = a.bias[n_out + 16 * c];
-    sa_v[c] = a.head ? a.sa[n_out + 16 * c] : 1.f; sb_v[c] = a.head ? a.sb[n_out + 16 * c] : 0.f;
-  }
-  f32x4 acc0[NCT], acc1[NCT];
-#pragma unroll
-  for (int c = 0; c < NCT; ++c) { acc0[c] = (f32x4){0, 0, 0, 0}; acc1[c] = (f32x4){0, 0, 0, 0}; }
+  const float bias_v = a.bias[n_out];
+  const float sa_v = a.head ? a.sa[n_out] : 1.f, sb_v = a.head ? a.sb[n_out] : 0.f;
+  f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
   const float* arow0 = a.in + (int64_t)(mt * ROWS + i) * a.ld_in;
   const float* arow1 = arow0 + (int64_t)16 * a.ld_in;
   const int g_first = wave * ng;
@@ -1355,10 +1349,10 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a, PsmDotsA
       bt[g] = *reinterpret_cast<const f32x4*>(a.ln_beta + kcol);
     }
   };
-  auto load_w = [&](int g0, f32x4 (&w)[NGC], int c = 0) {
+  auto load_w = [&](int g0, f32x4 (&w)[NGC]) {
 #pragma unroll
     for (int g = 0; g < NGC; ++g) {
-      const int64_t widx = ((int64_t)(nt + c) * groups + g_first + g0 + g) * 64 + lane;
+      const int64_t widx = ((int64_t)nt * groups + g_first + g0 + g) * 64 + lane;
       if (BF16) {
         const uint2 u = reinterpret_cast<const uint2*>(a.Wp)[widx];
         w[g] = (f32x4){__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
@@ -1368,13 +1362,13 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a, PsmDotsA
       }
     }
   };
-  auto mma = [&](const f32x4 (&a0)[NGC], const f32x4 (&a1)[NGC], const f32x4 (&w)[NGC], int c = 0) {
+  auto mma = [&](const f32x4 (&a0)[NGC], const f32x4 (&a1)[NGC], const f32x4 (&w)[NGC]) {
 #pragma unroll
     for (int g = 0; g < NGC; ++g) {
-      acc0[c] = MFMA16(rnd(a0[g].x), w[g].x, acc0[c]); if (ROWS == 32) acc1[c] = MFMA16(rnd(a1[g].x), w[g].x, acc1[c]);
-      acc0[c] = MFMA16(rnd(a0[g].y), w[g].y, acc0[c]); if (ROWS == 32) acc1[c] = MFMA16(rnd(a1[g].y), w[g].y, acc1[c]);
-      acc0[c] = MFMA16(rnd(a0[g].z), w[g].z, acc0[c]); if (ROWS == 32) acc1[c] = MFMA16(rnd(a1[g].z), w[g].z, acc1[c]);
-      acc0[c] = MFMA16(rnd(a0[g].w), w[g].w, acc0[c]); if (ROWS == 32) acc1[c] = MFMA16(rnd(a1[g].w), w[g].w, acc1[c]);
+      acc0 = MFMA16(rnd(a0[g].x), w[g].x, acc0); if (ROWS == 32) acc1 = MFMA16(rnd(a1[g].x), w[g].x, acc1);
+      acc0 = MFMA16(rnd(a0[g].y), w[g].y, acc0); if (ROWS == 32) acc1 = MFMA16(rnd(a1[g].y), w[g].y, acc1);
+      acc0 = MFMA16(rnd(a0[g].z), w[g].z, acc0); if (ROWS == 32) acc1 = MFMA16(rnd(a1[g].z), w[g].z, acc1);
+      acc0 = MFMA16(rnd(a0[g].w), w[g].w, acc0); if (ROWS == 32) acc1 = MFMA16(rnd(a1[g].w), w[g].w, acc1);
     }
   };
   // ---- pending LayerNormalization of the input: moments of rows i (and i + 16) over the first ln_n columns, two passes like
@@ -1473,29 +1467,24 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a, PsmDotsA
   }
   PSM_STAMP(0, 45 + 4 * (a.layer & 3));
 #pragma unroll
-  for (int c = 0; c < NCT; ++c)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      red[wave][2 * c][(4 * kq + r) * 17 + i] = acc0[c][r];
-      if (ROWS == 32) red[wave][2 * c + 1][(4 * kq + r) * 17 + i] = acc1[c][r];
-    }
+  for (int r = 0; r < 4; ++r) {
+    red[wave][0][(4 * kq + r) * 17 + i] = acc0[r];
+    if (ROWS == 32) red[wave][1][(4 * kq + r) * 17 + i] = acc1[r];
+  }
   __syncthreads();
   if (tid < ROWS * 16) {
     const int row = tid >> 4, col = tid & 15;          // ROWS rows x 16 cols
     const int half = row >> 4, r16 = row & 15;
+    float v = 0.f;
 #pragma unroll
-    for (int c = 0; c < NCT; ++c) {
-      float v = 0.f;
-#pragma unroll
-      for (int w8 = 0; w8 < 8; ++w8) v += red[w8][2 * c + half][r16 * 17 + col];
-      v += bias_v[c];
-      if (a.relu) v = fmaxf(v, 0.f);
-      if constexpr (LNIN) {
-        if (a.ln_residual) v += (res_raw - ln_stat[0][row]) * ln_stat[1][row] * res_g + res_b;     // x + LN(input) (NNs.py:64)
-      }
-      if (a.head) v = v * sa_v[c] + sb_v[c];
-      a.out[(int64_t)(mt * ROWS + row) * a.ld_out + n_out + 16 * c] = v;
+    for (int w8 = 0; w8 < 8; ++w8) v += red[w8][half][r16 * 17 + col];
+    v += bias_v;
+    if (a.relu) v = fmaxf(v, 0.f);
+    if constexpr (LNIN) {
+      if (a.ln_residual) v += (res_raw - ln_stat[0][row]) * ln_stat[1][row] * res_g + res_b;     // x + LN(input) (NNs.py:64)
     }
+    if (a.head) v = v * sa_v + sb_v;
+    a.out[(int64_t)(mt * ROWS + row) * a.ld_out + n_out] = v;
   }
   PSM_STAMP(0, 46 + 4 * (a.layer & 3));
 }
