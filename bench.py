@@ -1058,19 +1058,27 @@ def main():
     roofline = pca_roofline(sur, model, NY, NX, NC, precision, d_in[0].data_ptr(), d_out[0].data_ptr(), args.steps, dt_max / args.steps,
                             args.workload, bound, kt=kt_head)
     # BASELINE.md section 2's protocol beside the contract's K-step mean: >= 200 timed samples, median and 10th / 90th percentile.
-    # A sample = the wall time of Q_CHUNK solves issued back to back between two device synchronisations, per solve (the
-    # synchronisation costs ~1 % of a chunk).  (torch.cuda.Event pairs around single solves were tried first: recording one per
-    # solve makes the pass host-bound -- 31 us of submission per solve -- and the intervals between them, median 25 us, did not add
-    # up to the wall time of the pass; not used.)
+    # A sample = the DEVICE time between two events recorded Q_CHUNK solves apart on the solve stream, per solve; the stream is
+    # never drained between samples, so the samples are the steady state `value` averages over.  (Two other forms were tried and
+    # dropped: an event pair around every single solve makes the pass host-bound -- 31 us of submission per solve; wall-clocked
+    # chunks between device synchronisations restart from an idle GPU every 1.6 ms and read 5-20 % slow depending on how fast the
+    # box drops its clocks: 32.4-39.8 us per solve between boxes for the same build.)
     n_q = 20 if args.no_extras else 200                      # (profiling passes run with --no-extras: keep their traces small)
-    per_ms = []
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_q + 1)]
+    q_stream = torch.cuda.Stream()                           # (stream 0 of `step` means "the handle's own stream", which torch cannot record on)
+    def step_q(i):
+        k = i % len(d_in)
+        sur.solve_device(d_in[k].data_ptr(), NC, d_out[k].data_ptr(), q_stream.cuda_stream)
+    torch.cuda.synchronize()
+    for j in range(Q_CHUNK):                                 # a filled pipeline in front of the first event
+        step_q(j)
+    evs[0].record(q_stream)
     for i in range(n_q):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
         for j in range(Q_CHUNK):
-            step(i * Q_CHUNK + j)
-        torch.cuda.synchronize()
-        per_ms.append((time.perf_counter() - t0) * 1e3 / Q_CHUNK)
+            step_q(i * Q_CHUNK + j)
+        evs[i + 1].record(q_stream)
+    torch.cuda.synchronize()
+    per_ms = [evs[i].elapsed_time(evs[i + 1]) / Q_CHUNK for i in range(n_q)]
     per_ms.sort()
     q_ms = {"p50": per_ms[n_q // 2], "p10": per_ms[n_q // 10], "p90": per_ms[(n_q * 9) // 10]}
 
