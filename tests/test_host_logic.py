@@ -30,6 +30,22 @@ def test_block_counts_of_the_baseline_configs():
     assert len(surrogate.layout("gradp", 256, 256)[0]) == 30
 
 
+def test_shipped_case_mesh_gives_the_reference_grid():
+    """bench.py's shipped_case leg: the synthetic channel mesh is stretched so that init_func's uniform grid (python_module.py:190-217:
+    num = int(round(extent / delta)) from the cell-centre extents) is the reference's 400 x 3000 at delta 0.005 -- through the
+    library's host-only shape entry (no GPU)."""
+    import ctypes as C
+    from psm_amd import _lib, synthetic
+    array, top, obst = synthetic.shipped_case_mesh()
+    a = np.ascontiguousarray(array, np.float64)
+    ny, nx, bd = C.c_int32(), C.c_int32(), np.zeros(4)
+    f64 = C.POINTER(C.c_double)
+    assert _lib.load().psm_geometry_shape(a.ctypes.data_as(f64), a.shape[0], 0.005, C.byref(ny), C.byref(nx), bd.ctypes.data_as(f64)) == 0
+    assert (ny.value, nx.value) == (400, 3000) and 20000 < a.shape[0] < 250000
+    assert len(surrogate.layout("chapter5", ny.value, nx.value)[0]) == 104
+    assert top[:, 0].min() >= array[:, 2].min() - 0.05 and obst.shape[1] == 2
+
+
 def test_layout_errors():
     with pytest.raises(_lib.PsmError):
         surrogate.layout("deltas", 100, 300)            # smaller than a block
