@@ -824,7 +824,10 @@ __global__ __launch_bounds__(256, 2) void psm_pair32_kernel(PsmPairArgs a) {
   PSTAMP_ENTRY();
   constexpr int RA = MH / 2, RB = TY / 2;
   const int rA = RA * (wave >> 1), rB = RB * (wave >> 1);
-  if (tid < 64) bias_l[tid] = tid < 32 ? a.biasA[tid] : a.biasB[tid - 32];
+  // conv B's bias: requested here, written to LDS in front of conv B's barrier.  (Written here it was a load -> wait -> ds_write chain at
+  // the very top of wave 0, a full round trip before that wave requested anything else: 0.8-1.2 us from entry to the first staging
+  // request in the stamps of the one-tile-per-workgroup 128^2 pairs.)
+  const float bias_v = (tid < 32 ? a.biasA : a.biasB - 32)[min(tid, 63)];
   const bf16x8* wfrag = reinterpret_cast<const bf16x8*>(wl) + lane;
   auto wget = [&](int i) { return wfrag[i * 64]; };
   // Chunk order: the skip input first (its staging is not prefetched -- at the start of a tile there is nothing to hide it
@@ -948,6 +951,7 @@ __global__ __launch_bounds__(256, 2) void psm_pair32_kernel(PsmPairArgs a) {
     mid_epilogue<2, RA, KEEP>(a, mid, t.cs, y0, x0, rA, xh, lane, interior, acc);
     zero_mid_pad32(mid, tid);
     write_w(wbl, 18);
+    if (tid < 64) bias_l[tid] = bias_v;
     PSTAMP32();
     lds_barrier();
     PSTAMP32();
