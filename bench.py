@@ -1180,14 +1180,14 @@ def main():
         def step3(i):
             k = i % len(g3)
             sur3.solve_device(g3[k].data_ptr(), count, o3[k].data_ptr(), stream)
-        k3 = max(100, args.steps // 4)
+        k3 = max(300, args.steps // 4)                     # (legs are not under the K contract: long enough that one pipeline fill is < 1 % of the region)
         dt3 = pdist.timed_region(step3, k3, max(10, args.warmup // 4), torch.cuda.synchronize, red_dev)
         torch.cuda.synchronize()
         trips3 = guard_trips_after(sur3, "config3")
         whole = pdist.gather_cases(o3[0] if red_dev == "cuda" else torch.from_numpy(to_host(torch, o3[0])), total_cases)     # one all-gather, untimed
         out["case_batch"] = {"workload": desc3, "value": total_cases * k3 / dt3, "unit": "solves/s", "steps": k3,
                              "ms_per_step": dt3 / k3 * 1e3, "dtype": prec3, "cases_per_step_per_gpu": count, "total_cases": total_cases,
-                             "geometry": "one bound geometry per case slot (7 launches per step)" if b3 else "general path (9 launches per step)",
+                             "geometry": "one bound geometry per case slot (6 launches per step up to 128 block rows, 7 beyond)" if b3 else "general path (8-9 launches per step)",
                              "guard_trips": trips3, "gathered_shape": list(whole.shape),
                              "roofline": pca_roofline(sur3, m3, ny3, nx3, count, prec3, g3[0].data_ptr(), o3[0].data_ptr(), k3, dt3 / k3, "config3", bool(b3))}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -1207,7 +1207,7 @@ def main():
                 g64 = to_device(torch, all64)
                 o64 = torch.empty((n64, ny3, nx3, m3.c_out), dtype=torch.float32, device="cuda")
                 b64 = sur64.bind_geometry(g64.data_ptr(), on_device=True, n_cases=n64)
-                k64 = max(50, min(200, args.steps // 10))
+                k64 = max(150, min(200, args.steps // 10))
                 dt64 = pdist.timed_region(lambda i: sur64.solve_device(g64.data_ptr(), n64, o64.data_ptr(), stream), k64, 10,
                                           torch.cuda.synchronize, red_dev)
                 torch.cuda.synchronize()
@@ -1225,7 +1225,7 @@ def main():
     legs = [] if (args.no_extras or world > 1 or args.workload != "config1" or args.legs in ("", "none")) else [l for l in args.legs.split(",") if l]
     if legs:
         out["legs"] = {}
-        k_leg, w_leg = max(100, args.steps // 4), max(10, args.warmup // 4)
+        k_leg, w_leg = max(300, args.steps // 4), max(20, args.warmup // 4)
         with_oracle = rank == 0 and not args.no_cpu_baseline
         for name in legs:
             t0 = time.perf_counter()
@@ -1235,7 +1235,7 @@ def main():
                 mdl = m3 if WORKLOADS[name][0] == "deltas" else model
                 leg = pca_leg(name, mdl, args, torch, pdist, psm_amd, synthetic, rank, world, local_rank, red_dev, k_leg, w_leg, with_oracle)
             elif name in UNET_WORKLOADS:
-                ku = max(20, min(k_leg, 200 if UNET_WORKLOADS[name][0] <= 256 else 100))
+                ku = max(100, min(k_leg, 200 if UNET_WORKLOADS[name][0] <= 256 else 100))
                 leg = unet_leg(name, args, torch, pdist, rank, world, local_rank, backend, ku, max(5, w_leg // 2), with_oracle)
             else:
                 raise SystemExit(f"unknown leg {name!r}")
