@@ -13,13 +13,36 @@
 
 #include <algorithm>
 
+// U_max = max sqrt(Ux^2 + Uy^2) as NumPy takes it (PM:270), bit for bit, and bit for bit what the host pass of psm_solve takes
+// (psm_api_mesh.cpp: max of the squares, one sqrt).  Found by tests/test_embed_host.py (round 6): the device reduction and the host
+// pass gave U_max one ulp apart on 2 of 7 velocity scales -- and with it every pressure of those steps -- because hipcc contracts
+// ux * ux + uy * uy into an fma in device code.  The squares and their sum are computed under `fp contract(off)`; the kernels
+// reduce the SQUARED speed like the host does and take one square root at the end (sqrt_rn: the device's sqrt with a
+// round-to-nearest correction from the exact residual -- a guard, no last-bit difference of sqrt itself was observed).
+__device__ __forceinline__ double speed2_np(double ux, double uy) {
+#pragma clang fp contract(off)               // (__dmul_rn / __dadd_rn are plain operators in this toolchain's headers and get contracted too)
+  const double xx = ux * ux, yy = uy * uy;
+  return xx + yy;
+}
+__device__ __forceinline__ double sqrt_rn(double x) {
+  double r = sqrt(x);
+  const unsigned long long eb = __double_as_longlong(r) & 0x7ff0000000000000ull;
+  if (eb > (53ull << 52) && eb < 0x7ff0000000000000ull) {                       // normal, finite, not NaN
+    const double u = __longlong_as_double(eb - (52ull << 52));                  // ulp(r)
+    const double e = fma(-r, r, x);                                             // x - r^2, exact
+    const double lim = r * u;                                                   // |sqrt(x) - r| <= u / 2  <=>  |e| <= r u (to 2nd order)
+    if (e > lim) r += u; else if (e < -lim) r -= u;
+  }
+  return r;
+}
+
 __global__ __launch_bounds__(1024) void psm_umax_kernel(const double* cells, int64_t n, double* umax) {
   __shared__ double red[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double m = 0.0;
   for (int64_t i = tid; i < n; i += 1024) {
     const double ux = cells[i * 5], uy = cells[i * 5 + 1];
-    const double v = sqrt(ux * ux + uy * uy);
+    const double v = speed2_np(ux, uy);
     m = (v > m || v != v) ? v : m;          // np.max propagates NaN
   }
   for (int o = 32; o > 0; o >>= 1) {
@@ -31,7 +54,7 @@ __global__ __launch_bounds__(1024) void psm_umax_kernel(const double* cells, int
   if (tid == 0) {
     double r = red[0];
     for (int w = 1; w < 16; ++w) r = (red[w] > r || red[w] != red[w]) ? red[w] : r;
-    *umax = r;
+    *umax = sqrt_rn(r);
   }
 }
 
@@ -44,7 +67,7 @@ __global__ __launch_bounds__(1024) void psm_umax_partial_kernel(const double* ce
   double m = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 1024 + tid; i < n; i += (int64_t)gridDim.x * 1024) {
     const double ux = cells[i * 5], uy = cells[i * 5 + 1];
-    m = nanmax2(m, sqrt(ux * ux + uy * uy));
+    m = nanmax2(m, speed2_np(ux, uy));
   }
   for (int o = 32; o > 0; o >>= 1) m = nanmax2(m, __shfl_down(m, o, 64));
   if (lane == 0) red[wave] = m;
@@ -111,7 +134,7 @@ __global__ __launch_bounds__(256) void psm_stage_cells_kernel(const double* host
       const int r = k * 256 + tid;
       if (chunk * ROWS + r < n) {
         const double ux = row[r * 5], uy = row[r * 5 + 1];
-        m = nanmax2(m, sqrt(ux * ux + uy * uy));
+        m = nanmax2(m, speed2_np(ux, uy));
       }
     }
     __syncthreads();                                         // the rows are consumed: the next round may overwrite them
@@ -140,7 +163,7 @@ __global__ __launch_bounds__(256) void psm_to_grid_kernel(PsmToGridArgs a) {
     for (int o = 32; o > 0; o >>= 1) m = nanmax2(m, __shfl_down(m, o, 64));
     if ((threadIdx.x & 63) == 0) um_s[threadIdx.x >> 6] = m;
     __syncthreads();
-    umax_v = nanmax2(nanmax2(um_s[0], um_s[1]), nanmax2(um_s[2], um_s[3]));
+    umax_v = sqrt_rn(nanmax2(nanmax2(um_s[0], um_s[1]), nanmax2(um_s[2], um_s[3])));      // the partials are maxima of the SQUARED speed
     if (blockIdx.x == 0 && threadIdx.x == 0) *a.umax_out = umax_v;
   }
   const int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x;

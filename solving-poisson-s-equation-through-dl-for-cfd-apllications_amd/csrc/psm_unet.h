@@ -56,8 +56,13 @@ struct PsmHeadArgs {           // 1x1 convolution on a thin activation (c_in <= 
 // in two 14.3 us and its consumer +2.2 us; profiles/r04_conv_experiments.txt; not kept)
 // (4 x 16 and 8 x 16 pixel tiles with 4 channel tiles per wave were measured too: within 1 us per layer at batch 1,
 // slower at 8 cases per step -- the staged bytes per MFMA are not what limits these layers; not kept)
-inline int psm_conv_tile_rows(int arrangement) { return arrangement == 0 ? 8 : arrangement == 1 ? 2 : 0; }
-inline int psm_conv_tile_nct(int arrangement, int nct) { return arrangement == 0 ? (nct == 2 ? 2 : 1) : 4; }
+// Round 6, bf16 activations only (finished bf16 inputs, no split-K slabs on the input side): larger per-wave register blocks, i.e. fewer
+// LDS operand reads (ds_read_b128) per MFMA than the 1 : 1 of arrangement 0 / nct 2 --
+//   2 = 16 rows x 4 channel tiles, each wave 4 rows x 4 channel tiles (64 px x 64 channels: 8 reads per 16 MFMAs)
+//   3 = 16 rows x 2 channel tiles, each wave 4 rows x 2 channel tiles (6 reads per 8 MFMAs)
+//   4 =  8 rows x 4 channel tiles, each wave 2 rows x 4 channel tiles (6 reads per 8 MFMAs; the input tile staged once for 64 channels)
+inline int psm_conv_tile_rows(int arrangement) { return arrangement == 0 ? 8 : arrangement == 1 ? 2 : arrangement == 2 ? 16 : arrangement == 3 ? 16 : arrangement == 4 ? 8 : 0; }
+inline int psm_conv_tile_nct(int arrangement, int nct) { return arrangement == 0 ? (nct == 2 ? 2 : 1) : arrangement == 3 ? 2 : 4; }
 hipError_t psm_launch_conv3x3(const PsmConvArgs& a, int arrangement, int nct, int n_cases, hipStream_t st);
 hipError_t psm_launch_head1x1(const PsmHeadArgs& a, hipStream_t st);
 hipError_t psm_unet_read_stamps(unsigned long long* out);   // [64]; zeros unless built with -DPSM_STAMPS

@@ -797,6 +797,25 @@ static void launch_variant(const PsmConvArgs& a, dim3 grid, int groups, hipStrea
 #undef GO
 }
 
+// arrangements 2-4 (round 6): finished bf16 inputs only
+template <int TH, int WM, int NCT, int WN>
+static hipError_t launch_variant_abf(const PsmConvArgs& a, dim3 grid, int groups, hipStream_t st) {
+  const bool stem = (a.c0 % 4 != 0) || (a.c1 % 4 != 0);
+  const bool seam_inside = a.mode0 == PSM_SRC_UPSAMPLE && a.c1 > 0 && (a.c0 % 32) != 0;
+  if (stem || !a.bf16 || !a.in_bf || a.ks0 > 1 || a.ks1 > 1 || a.x6 || seam_inside) return hipErrorInvalidValue;
+  const bool one = (a.n_chunks + a.ksplit - 1) / a.ksplit <= 1;
+#define GOA(S)                                                                                                         \
+  do {                                                                                                                 \
+    if (one) PSM_LAUNCH((psm_conv3x3_kernel<TH, WM, NCT, WN, S, 1, true, 1, true>), grid, dim3(256), 0, st, a, groups);  \
+    else PSM_LAUNCH((psm_conv3x3_kernel<TH, WM, NCT, WN, S, 1, true, 2, true>), grid, dim3(256), 0, st, a, groups);      \
+  } while (0)
+  if (a.mode0 == PSM_SRC_SAME) GOA(PSM_SRC_SAME);
+  else if (a.mode0 == PSM_SRC_UPSAMPLE) GOA(PSM_SRC_UPSAMPLE);
+  else GOA(PSM_SRC_MAXPOOL);
+#undef GOA
+  return hipSuccess;
+}
+
 hipError_t psm_launch_conv3x3(const PsmConvArgs& a, int arrangement, int nct, int n_cases, hipStream_t st) {
   const int cout_tiles = (a.cout + 15) / 16;
   const bool stem = (a.c0 % 4 != 0) || (a.c1 % 4 != 0);
@@ -812,6 +831,9 @@ hipError_t psm_launch_conv3x3(const PsmConvArgs& a, int arrangement, int nct, in
       if (nct == 1) launch_variant<8, 2, 1, 1>(a, grid, groups, st); else launch_variant<8, 2, 2, 2>(a, grid, groups, st);
       break;
     case 1: launch_variant<2, 2, 4, 1>(a, grid, groups, st); break;    // channel-major: 2 rows x 16 columns, 4 waves = 4 channel tiles
+    case 2: { const hipError_t e = launch_variant_abf<16, 4, 4, 4>(a, grid, groups, st); if (e != hipSuccess) return e; break; }
+    case 3: { const hipError_t e = launch_variant_abf<16, 4, 2, 2>(a, grid, groups, st); if (e != hipSuccess) return e; break; }
+    case 4: { const hipError_t e = launch_variant_abf<8, 2, 4, 4>(a, grid, groups, st); if (e != hipSuccess) return e; break; }
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
