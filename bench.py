@@ -87,7 +87,8 @@ P = 128
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 matrix peak (256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz)
 MFMA_BF16_PEAK_TFLOPS = 2516.6   # dense bf16 matrix peak (16x the f32 rate)
-PMC_FILE = "profiles/r05_pmc.json"
+PMC_FILE = "profiles/r06_pmc.json"
+UNET_PMC_FILE = "profiles/r06_unet_pmc.json"
 
 # BASELINE.json configs as (variant, Ny, Nx, cases per step per GPU, precision, description)
 WORKLOADS = {
@@ -108,8 +109,12 @@ UNET_WORKLOADS = {           # the convolutional path (SURVEY.md section 8 row a
     "unet8_bf16": (256, 256, 8, "UNet-S, 256x256x3 -> 256x256x1, 8 cases per step per GPU, bf16 operands / f32 accumulate"),
     "unet512_bf16": (512, 512, 1, "UNet-S, 512x512x3 -> 512x512x1 (BASELINE configs[4] as worded: bf16 MFMA conv path), batch 1, "
                      "bf16 operands / f32 accumulate"),
+    # configs[3]'s 64 cases on the conv path: 8x the work per launch of unet8_bf16 -- separates what the kernels sustain from what
+    # the chain of 14 dependent launches costs (round-5 verdict, item 1a)
+    "unet64_bf16": (256, 256, 64, "UNet-S, 256x256x3 -> 256x256x1, 64 cases per step on one GPU (BASELINE configs[3]'s batch on the conv path), "
+                    "bf16 operands / f32 accumulate"),
 }
-DEFAULT_LEGS = ("config2", "config4", "unet", "unet8", "unet8_bf16", "unet512_bf16")
+DEFAULT_LEGS = ("config2", "config4", "unet", "unet8", "unet8_bf16", "unet512_bf16", "unet64_bf16")
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -315,6 +320,41 @@ def committed_traffic(kernel, workload):
     return (v, PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2*FETCH + WRITE KiB, gfx950 correction)") if v else (None, None)
 
 
+def unet_source_hash():
+    h = hashlib.sha256()
+    for f in ("psm_unet.hip", "psm_unet_pair.hip", "psm_unet.h", "psm_unet_api.cpp"):
+        p = os.path.join(ROOT, "solving-poisson-s-equation-through-dl-for-cfd-apllications_amd", "csrc", f)
+        if os.path.exists(p):
+            h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def unet_launch_key(net, first, kname, wgs):
+    """What identifies a launch of the conv path in a rocprofv3 trace (tools/unet_hbm_summary.py writes the same keys): the generic
+    kernel by tile rows, channel tiles, source transform and grid size; a fused pair by its template instantiation."""
+    base = kname.strip("() ").split("(")[0]
+    if not base.startswith("psm_conv3x3_kernel"):
+        return "pair|" + base.replace(" ", "")
+    th, nct = net.plan_info(first)[:2]
+    n = len(net.shapes)
+    L = (n + 1) // 4
+    src = 2 if (0 < first < 2 * L and first % 2 == 0) else (1 if (2 * L <= first < n - 1 and (first - 2 * L) % 2 == 0) else 0)
+    return f"conv3x3|{th}|{nct}|{src}|{int(wgs[first]) * 256}"
+
+
+def committed_unet_traffic(workload, key):
+    """HBM-side bytes per launch of a conv-path launch from the committed counter passes (tools/unet_hbm.sh), while the conv
+    sources are the ones that were profiled."""
+    try:
+        d = json.load(open(os.path.join(ROOT, UNET_PMC_FILE)))
+    except Exception:
+        return None, None
+    if d.get("unet_source_hash") != unet_source_hash():
+        return None, UNET_PMC_FILE + ": other conv sources, not used"
+    v = (d.get("workloads", {}).get(workload) or {}).get(key)
+    return (v, UNET_PMC_FILE + " (rocprofv3 --pmc, 2*FETCH+WRITE KiB)") if v else (None, None)
+
+
 def oracle_model(model):
     from oracle import psm_oracle as orc
     sc = orc.Scaler(model.scaler_kind, model.in_a, model.in_b, model.out_a, model.out_b)
@@ -437,6 +477,8 @@ def _compact_roofline(r):
     keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "avg_launch_us")
     out = {k: _sig(r.get(k)) for k in keep}
     out["kernel"] = _clip(out["kernel"], 100)
+    if r.get("traffic_source"):
+        out["traffic_source"] = _clip(r["traffic_source"], 64)
     return out
 
 
@@ -774,7 +816,11 @@ def pca_roofline(sur, model, ny, nx, n_cases, precision, d_grid, d_fields, steps
                         "peak_TFLOPs": kernel_peak_tflops(nm, precision),      # the pipe THIS launch runs on (x6: bf16 peak / 6)
                         "achieved_GBs": (b / (us * 1e-6) / 1e9) if b else None,
                         "achieved_TFLOPs": (f / (us * 1e-6) / 1e12) if f else None})
-    dom = max(kernels, key=lambda k: k["avg_us"] * k["launches_per_solve"])
+    # the dominant launch = the longest among those that carry a non-trivial share (>= 5 %) of the solve's algorithmic bytes or flops:
+    # a launch-bound 0.26 MB layer that happens to be the longest says nothing about a ceiling (configs[4]'s PCA-bf16 leg, rounds 4-5)
+    tot_b, tot_f = ab_batch["total"], af["total"]
+    heavy = [k for k in kernels if (k["algorithmic_bytes"] or 0) >= 0.05 * tot_b or (k["algorithmic_flops"] or 0) >= 0.05 * tot_f]
+    dom = max(heavy or kernels, key=lambda k: k["avg_us"] * k["launches_per_solve"])
     peak_f = dom["peak_TFLOPs"]
     gbs, tfl = dom["achieved_GBs"] or 0.0, dom["achieved_TFLOPs"] or 0.0
     f_hbm, f_mfma = gbs / HBM_PEAK_GBS, tfl / peak_f
@@ -782,7 +828,6 @@ def pca_roofline(sur, model, ny, nx, n_cases, precision, d_grid, d_fields, steps
     t_sum = sum(k["avg_us"] * k["launches_per_solve"] for k in kernels)
     ceil_f = sum(k["avg_us"] * k["launches_per_solve"] * k["peak_TFLOPs"] for k in kernels) / max(t_sum, 1e-12)
     traffic, traffic_src = committed_traffic(dom["name"], workload) if bound_path else (None, None)
-    tot_b = ab_batch["total"]
     roof = {"kernel": dom["name"], "bound": "mfma" if f_mfma > f_hbm else "hbm"}
     if roof["bound"] == "hbm":
         roof.update(achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=f_hbm)
@@ -790,7 +835,8 @@ def pca_roofline(sur, model, ny, nx, n_cases, precision, d_grid, d_fields, steps
         roof.update(achieved=tfl, peak=peak_f, unit="TFLOP/s", frac=f_mfma)
     roof.update(traffic=traffic, traffic_source=traffic_src, algorithmic_bytes=dom["algorithmic_bytes"], algorithmic_flops=dom["algorithmic_flops"],
                 avg_launch_us=dom["avg_us"], launches=int(dom["launches_per_solve"] * steps), frac_hbm=f_hbm, frac_mfma=f_mfma,
-                selection="largest MEDIAN dispatch time per solve among all launches of the instrumented pass (every Dense layer is its own "
+                selection="largest MEDIAN dispatch time per solve among the launches of the instrumented pass that carry >= 5 % of the solve's "
+                          "algorithmic bytes or flops (every Dense layer is its own "
                           "entry: the two hidden layers run the same template instantiation, which rocprofv3 lists as one kernel "
                           "with two calls per solve); bound = the ceiling it sits closer to",
                 whole_solve={"algorithmic_bytes": tot_b, "algorithmic_flops": af["total"],
@@ -811,7 +857,7 @@ def unet_leg(name, args, torch, pdist, rank, world, local_rank, backend, steps, 
     prec = "bf16" if name.endswith("bf16") else "f32"
     peak = MFMA_BF16_PEAK_TFLOPS if prec == "bf16" else MFMA_F32_PEAK_TFLOPS
     net = UNetSurrogate(W, NY, NX, max_cases=NC, device=local_rank, precision=prec, autotune=True)   # plan-time, outside the timed region
-    n_in = min(args.inputs, 2 if NY > 256 else args.inputs)
+    n_in = min(args.inputs, 2 if (NY > 256 or NC > 8) else args.inputs)
     grids = [np.stack([synthetic.channel_grid(NY, NX, seed=1 + 1000 * rank + 10 * i + k, noise=0.05 if NY > 256 else 0.02).astype(np.float32)
                        for k in range(NC)]) for i in range(n_in)]
     d_in = [to_device(torch, g) for g in grids]
@@ -829,6 +875,7 @@ def unet_leg(name, args, torch, pdist, rank, world, local_rank, backend, steps, 
     # every launch of the forward pass with its own dispatch stamps: flops and activation / weight bytes of the convolutions it covers
     ab, wbts = (2, 2) if prec == "bf16" else (4, 4)
     launches = []
+    wgs_all = net.profile(d_in[0].data_ptr(), NC, d_out[0].data_ptr())[1]
     for first, convs, kname, us in net.time_kernels(d_in[0].data_ptr(), NC, d_out[0].data_ptr(), steps=max(5, min(20, steps))):
         fl = sum(net.conv_flops(c) for c in convs) * NC
         # a fused launch (level pair, fused 1x1 head) reads the first convolution's input and writes the last one's output
@@ -837,7 +884,7 @@ def unet_leg(name, args, torch, pdist, rank, world, local_rank, backend, steps, 
         # the bf16 matrix peak / 6 (419 TFLOP/s of float32-accurate products), not the f32 MFMA peak
         x6 = prec == "f32" and bool(net.plan_info(first)[3] & 4)
         pk = MFMA_BF16_PEAK_TFLOPS / 6.0 if x6 else peak
-        launches.append({"convs": convs, "kernel": kname, "avg_us": us, "flops": fl, "algorithmic_bytes": by,
+        launches.append({"convs": convs, "kernel": kname, "key": unet_launch_key(net, first, kname, wgs_all), "avg_us": us, "flops": fl, "algorithmic_bytes": by,
                          "arithmetic": "x6 (3 bf16 planes per operand, 6 MFMA terms)" if x6 else ("bf16 MFMA" if prec == "bf16" else "f32 MFMA"),
                          "peak_TFLOPs": pk, "achieved_TFLOPs": fl / (us * 1e-6) / 1e12, "achieved_GBs": by / (us * 1e-6) / 1e9})
     dom = max(launches, key=lambda l: l["avg_us"])
@@ -848,7 +895,10 @@ def unet_leg(name, args, torch, pdist, rank, world, local_rank, backend, steps, 
         roof.update(achieved=dom["achieved_TFLOPs"], peak=dom["peak_TFLOPs"], unit="TFLOP/s", frac=f_mfma, arithmetic=dom["arithmetic"])
     else:
         roof.update(achieved=dom["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=f_hbm)
-    roof.update(traffic=None, avg_launch_us=dom["avg_us"], algorithmic_flops=dom["flops"], algorithmic_bytes=dom["algorithmic_bytes"],
+    traffic, traffic_src = committed_unet_traffic(name, dom["key"])
+    for l in launches:
+        l["traffic"] = committed_unet_traffic(name, l["key"])[0]
+    roof.update(traffic=traffic, traffic_source=traffic_src, avg_launch_us=dom["avg_us"], algorithmic_flops=dom["flops"], algorithmic_bytes=dom["algorithmic_bytes"],
                 frac_mfma=f_mfma, frac_hbm=f_hbm, selection="the launch of the forward pass with the largest MEDIAN dispatch-stamped duration",
                 whole_pass={"algorithmic_flops": flops, "achieved_TFLOPs": achieved,
                             # every launch against the pipe it runs on: ceiling = sum(t_i * peak_i) / sum(t_i); a pass whose launches
@@ -962,6 +1012,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the end-to-end, case-batch and other legs")
     ap.add_argument("--no-shipped-case", action="store_true", help="skip the shipped_case leg (psm_solve on the reference's 400 x 3000 / 104-block shape)")
     ap.add_argument("--legs", default=",".join(DEFAULT_LEGS), help="comma-separated extra legs at N = 1 (BASELINE configs and conv path); 'none' skips them")
+    ap.add_argument("--leg-budget-s", type=float, default=240.0, help="wall-clock budget of the optional legs: legs that would start after it are skipped and say so")
     ap.add_argument("--dry-run", action="store_true", help="launcher / process-group plumbing only (no GPU work)")
     ap.add_argument("--workload", default="config1", choices=sorted(WORKLOADS) + sorted(UNET_WORKLOADS),
                     help="BASELINE.json config to run as the headline (default: configs[1], the one the metric is quoted on)")
@@ -1085,12 +1136,12 @@ def main():
     out = {
         "metric": "pressure-solves/sec (256x256 U->p inference)",
         "value": value, "value_device_resident": value,
-        # rates at the median / 10th / 90th percentile of the per-solve time of n_q event-separated solves on this rank (x world: case-
-        # sharded, no collective); p10 is the FAST end of the time distribution, i.e. the high rate
+        # rates at the median / 90th / 10th percentile of the per-solve time of n_q event-separated samples on this rank (x world: case-
+        # sharded, no collective): value_p10 is computed from ms_p90, the SLOW decile of the times (the low rate), value_p90 from ms_p10
         "value_p50": NC * world / (q_ms["p50"] * 1e-3), "value_p10": NC * world / (q_ms["p90"] * 1e-3), "value_p90": NC * world / (q_ms["p10"] * 1e-3),
         "per_solve_quantiles": {"solves": n_q * Q_CHUNK, "samples": n_q, "solves_per_sample": Q_CHUNK, "ms_p50": q_ms["p50"], "ms_p10": q_ms["p10"], "ms_p90": q_ms["p90"],
-                                "what": "a sample = wall time of a chunk of solves issued back to back between two device synchronisations, per solve; "
-                                        "value_p10 / value_p90 = rate at the slow / fast decile"},
+                                "what": "a sample = device time between two events recorded solves_per_sample solves apart on a stream that is never "
+                                        "drained, per solve; value_p10 / value_p90 = rate at the slow / fast decile of the times"},
         "frac_pass": roofline["whole_solve"]["frac"],
         # a timed region starts on a drained stream (the contract's synchronise): its first solve waits for the host's first launches
         # (~25 us of pipeline fill).  At K = 2000 that is 0.04 % of the region, at the driver's K = 20 it is 3-4 %: the round-4 driver line
@@ -1227,8 +1278,12 @@ def main():
         out["legs"] = {}
         k_leg, w_leg = max(300, args.steps // 4), max(20, args.warmup // 4)
         with_oracle = rank == 0 and not args.no_cpu_baseline
+        t_legs = time.perf_counter()
         for name in legs:
             t0 = time.perf_counter()
+            if t0 - t_legs > args.leg_budget_s:                      # a slow box must not cost the driver its line: the rest is skipped, loudly
+                out["legs"][name] = {"skipped": f"leg budget of {args.leg_budget_s:.0f} s spent"}
+                continue
             if name in WORKLOADS:
                 if m3 is None:
                     m3 = synthetic.make_model("deltas", p_in=P, p_out=P)
@@ -1236,7 +1291,9 @@ def main():
                 leg = pca_leg(name, mdl, args, torch, pdist, psm_amd, synthetic, rank, world, local_rank, red_dev, k_leg, w_leg, with_oracle)
             elif name in UNET_WORKLOADS:
                 ku = max(100, min(k_leg, 200 if UNET_WORKLOADS[name][0] <= 256 else 100))
-                leg = unet_leg(name, args, torch, pdist, rank, world, local_rank, backend, ku, max(5, w_leg // 2), with_oracle)
+                big = UNET_WORKLOADS[name][2] > 8                    # 64 cases: 0.8 ms per step; the CPU oracle is timed by the other legs
+                leg = unet_leg(name, args, torch, pdist, rank, world, local_rank, backend, 60 if big else ku, max(5, w_leg // 2), with_oracle,
+                               cpu_budget_s=0.0 if big else 4.0)
             else:
                 raise SystemExit(f"unknown leg {name!r}")
             leg["leg_wall_s"] = time.perf_counter() - t0

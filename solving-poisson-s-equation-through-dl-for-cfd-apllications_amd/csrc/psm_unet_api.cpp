@@ -247,15 +247,22 @@ std::vector<uint16_t> pack_pair(const Conv& c, bool flat, int c0, int c1) {
 // workgroup count first (fill 256 CUs), then the most reuse per workgroup
 // forced: index into the candidate list (psm_unet_autotune's measured tile choice), -1 = by rule; the split rule below then
 // runs for the tile that was chosen, not for the rule's.
-void choose_config(Conv& c, int H, int W, int n_cases, bool can_split, int chunk_ch, int ks_cap = 8, bool x6_ok = false, int forced = -1) {
+// big_ok (round 6): the layer may take arrangement 2 (16 rows x 64 channels per workgroup, a 64 px x 64 channel register block per
+// wave: half the LDS operand reads per MFMA and half the staged bytes per flop) -- bf16 mode, not the stem; whether its inputs
+// really are finished bf16 activations is only known after every layer's split is (psm_unet_plan falls back to the 8-row tile
+// otherwise).  Rule from profiles/r06_conv_experiments.txt (2): only where such tiles still fill the chip AND the layer walks six or
+// more channel chunks (64 cases of 256 x 256: dec3a 72.4 -> 65.4 us, enc4b 27.6 -> 24.4, dec2a 82.3 -> 78.5; shorter layers and
+// every layer at 8 cases per step are slower with it).
+void choose_config(Conv& c, int H, int W, int n_cases, bool can_split, int chunk_ch, int ks_cap = 8, bool x6_ok = false, int forced = -1,
+                   bool big_ok = false) {
   const int ctiles = (c.cout + 15) / 16;
   struct Cand { int arr, nct, th; };
-  const Cand cands[3] = {{0, 2, 8}, {0, 1, 8}, {1, 4, 2}};
+  const Cand cands[4] = {{0, 2, 8}, {0, 1, 8}, {1, 4, 2}, {2, 4, 16}};
   // diagnostic knobs (tools/unet_bench.py sweeps): workgroups wanted before reuse counts, deepest split
   const long fill = getenv("PSM_UNET_FILL") ? atol(getenv("PSM_UNET_FILL")) : 256;
   const int ks_max = getenv("PSM_UNET_KSPLIT_MAX") ? atoi(getenv("PSM_UNET_KSPLIT_MAX")) : 8;
   long best_score = -1;
-  const bool use_forced = forced >= 0 && forced < 3 && cands[forced].nct <= ctiles;
+  const bool use_forced = forced >= 0 && forced < (big_ok ? 4 : 3) && cands[forced].nct <= ctiles;
   if (use_forced) {
     const Cand& k = cands[forced];
     c.arrangement = k.arr; c.nct = k.nct; c.groups = (ctiles + k.nct - 1) / k.nct;
@@ -268,6 +275,10 @@ void choose_config(Conv& c, int H, int W, int n_cases, bool can_split, int chunk
     const long reuse = (long)k.nct * k.th;
     const long score = wgs >= fill ? 1000000 + reuse * 1000 + (k.arr ? 1 : 0) : wgs * 10 + (k.arr ? 1 : 0);
     if (score > best_score) { best_score = score; c.arrangement = k.arr; c.nct = k.nct; c.groups = groups; }
+  }
+  if (!use_forced && big_ok && ctiles >= 4 && ctiles % 4 == 0 && (c.cin + chunk_ch - 1) / chunk_ch >= 6 && getenv("PSM_UNET_NO_BIG_TILES") == nullptr) {
+    const long wgs16 = (long)((W + 15) / 16) * ((H + 15) / 16) * (ctiles / 4) * n_cases;
+    if (wgs16 >= fill) { c.arrangement = 2; c.nct = 4; c.groups = ctiles / 4; }
   }
   c.x6 = x6_ok && c.arrangement == 0;                 // the x6 form exists for the 8-row tiles (psm_unet.hip)
   if (c.x6) chunk_ch = 32;
@@ -532,6 +543,9 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
       }
     }
     for (size_t i = 0; i < n; ++i) u->convs[i].out_bf = obf[i] != 0;
+    // arrangements 2-4 exist for finished bf16 inputs only (psm_unet.hip, launch_variant_abf): back to the 8-row tile otherwise
+    for (Conv& c : u->convs)
+      if (c.k == 3 && c.arrangement >= 2 && !c.in_bf) { c.arrangement = 0; c.nct = 2; c.groups = ((c.cout + 15) / 16 + 1) / 2; }
     // fused level pairs (psm_unet_pair.hip): both 3x3 convolutions of a level in one launch, where the level is wide
     // enough to fill the chip with 30 x 14 tiles and the shapes are ones the pair kernels are written for
     for (size_t i = 0; i + 1 < n; ++i) { u->convs[i].pair = 0; u->convs[i + 1].pair = 0; }
@@ -590,7 +604,8 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
     const bool x6_ok = !u->bf16 && u->x6 && c.k == 3 && !stem_layer && c.src != 0 && (x6c == 1 || (x6c < 0 && c.cin >= 64));
     if (c.k == 3) choose_config(c, H, W, max_cases, feeds_conv3 && getenv("PSM_UNET_NO_SPLIT") == nullptr, u->bf16 ? 32 : 16,
                                 ci < u->ksplit_cap.size() ? u->ksplit_cap[ci] : 8, x6_ok,
-                                ci < u->tile_choice.size() ? u->tile_choice[ci] : -1);     // measured choice of psm_unet_autotune
+                                ci < u->tile_choice.size() ? u->tile_choice[ci] : -1,      // measured choice of psm_unet_autotune
+                                u->bf16 && !stem_layer && c.src != 0);
     // diagnostic override: PSM_UNET_FORCE="layer:arrangement:nct:ksplit,..." (tools/unet_bench.py experiments)
     if (const char* f = getenv("PSM_UNET_FORCE")) {
       for (const char* q = f; q && *q; q = std::strchr(q, ',') ? std::strchr(q, ',') + 1 : nullptr) {
@@ -863,7 +878,7 @@ int psm_unet_autotune(psm_unet* u, int32_t n_cases, int32_t iters, float* us_bef
   for (size_t i = 0; i < nc; ++i) {
     const Conv& c = u->convs[i];
     if (c.k != 3 || c.stem || c.pair != 0 || c.fuse_head) continue;
-    const int cur = c.arrangement == 1 ? 2 : (c.nct == 2 ? 0 : 1);
+    const int cur = c.arrangement == 2 ? 3 : c.arrangement == 1 ? 2 : (c.nct == 2 ? 0 : 1);
     for (int cand = 0; cand < 3; ++cand) {
       static const int NCT[3] = {2, 1, 4};
       if (cand == cur || NCT[cand] > (c.cout + 15) / 16) continue;

@@ -48,6 +48,11 @@ json.dump({"kernel": enc[0], "FETCH_SIZE_KB": enc[1], "WRITE_SIZE_KB": enc[2],
            "profile_tag": tag, "all_kernels": allk}, open("profiles/pmc_encode.json", "w"), indent=1)
 st = sorted(glob.glob(f"{O}/stats/*/*kernel_stats.csv"))[-1]
 shutil.copy(st, f"profiles/{tag}_kernel_stats.csv")
+# per-kernel median / p10 / p90 from the same trace (bench.py's roofline uses medians; --stats reports means)
+import subprocess
+subprocess.run([sys.executable, "tools/trace_quantiles.py", f"{O}/stats", f"profiles/{tag}_kernel_quantiles.csv"], check=False, stdout=subprocess.DEVNULL)
+if glob.glob(f"{O}/unet_stats/*/*kernel_trace.csv"):
+    subprocess.run([sys.executable, "tools/trace_quantiles.py", f"{O}/unet_stats", f"profiles/{tag}_unet8_bf16_kernel_quantiles.csv"], check=False, stdout=subprocess.DEVNULL)
 open(f"profiles/{tag}_bench.json.log", "w").write([l for l in open(f"{O}/bench.log").read().strip().splitlines() if l.startswith("{")][-1] + "\n")
 if os.path.exists(f"{O}/detail_bench/bench_detail.json"):
     shutil.copy(f"{O}/detail_bench/bench_detail.json", f"profiles/{tag}_bench_detail.json")

@@ -28,3 +28,31 @@ with open(f"profiles/{tag}_{wl}_hbm.csv", "w") as f:
         gbs = hb / (us * 1e-6) / 1e9
         f.write('"%s",%s,%d,%.2f,%.1f,%.1f,%.0f,%.0f,%.3f\n' % (k[0][:96], k[1], dur[k][1], us, fetch[k], write.get(k, 0.0), hb, gbs, gbs / 8000))
         print(f"{k[0][40:92]:52s} grid={k[1]:>9s} {us:7.1f} us  fetch {fetch[k]/1024:7.1f} MB(x2) write {write.get(k,0)/1024:7.1f} MB  -> {gbs:6.0f} GB/s")
+
+# the form bench.py reads for the conv legs' roofline.traffic (committed_unet_traffic): launches keyed like bench.unet_launch_key,
+# guarded by a hash of the conv sources that were profiled; one file for all workloads
+import json, re
+sys.path.insert(0, ".")
+import bench as _bench
+def _key(name, grid):
+    m = re.search(r"psm_conv3x3_kernel<(\d+), (\d+), (\d+), (\d+), (-?\d+), ", name)
+    if m:
+        return f"conv3x3|{m.group(1)}|{m.group(3)}|{m.group(5)}|{grid}"
+    m = re.search(r"(psm_pair\w*<[^(]*>)\(", name)
+    return "pair|" + m.group(1).replace(" ", "") if m else None
+pj = os.path.join(".", _bench.UNET_PMC_FILE)
+try:
+    d = json.load(open(pj))
+except Exception:
+    d = {}
+if d.get("unet_source_hash") != _bench.unet_source_hash():
+    d = {"unet_source_hash": _bench.unet_source_hash(), "profile_tag": tag,
+         "unit": "HBM-side bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024; separate --pmc passes with --kernel-trace only", "workloads": {}}
+w = {}
+for k in fetch:
+    kk = _key(k[0], k[1])
+    if kk and k in dur:
+        w[kk] = (2 * fetch[k] + write.get(k, 0.0)) * 1024.0
+d["workloads"][wl] = w
+json.dump(d, open(pj, "w"), indent=1)
+print("wrote", pj, len(w), "launch keys for", wl)
