@@ -81,7 +81,7 @@ int psm_read_stage(psm_handle* h, int32_t stage, float* dst, size_t dst_floats) 
         // the last solve took the closed form: run the chain itself once, from the strip means of the same activations
         const int nl = (int)h->dense.size();
         const bool bf = h->cfg.precision == PSM_PRECISION_BF16;
-        const float* act = bf ? h->ws0.d_res : h->ws0.d_act[(nl - 2) & 1];
+        const float* act = bf ? h->ws0.d_res : (h->last_act_packed ? h->ws0.d_act_rows : h->ws0.d_act[(nl - 2) & 1]);
         const int ld_act = bf ? h->ld_out : h->dense[nl - 2].ldw;
         PsmDotsArgs dd{h->d_g2, h->d_c2, h->d_cnt, h->d_row_of, h->last_row_scale ? h->last_row_scale : h->d_ones, h->ws0.d_dots,
                        h->bound_rows * h->last_cases, bf ? h->ld_out : h->dense[nl - 1].Kpad, PsmGuardArgs{}};

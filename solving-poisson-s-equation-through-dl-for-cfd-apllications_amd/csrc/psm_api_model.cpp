@@ -74,7 +74,7 @@ void destroy_graphs(psm_handle* h) {
 
 
 void ws_free(Workspace& w) {
-  dev_free(w.d_part); dev_free(w.d_xin); dev_free(w.d_act[0]); dev_free(w.d_act[1]); dev_free(w.d_res); dev_free(w.d_pred);
+  dev_free(w.d_part); dev_free(w.d_xin); dev_free(w.d_act[0]); dev_free(w.d_act[1]); dev_free(w.d_act_rows); w.d_act_rows = nullptr; dev_free(w.d_res); dev_free(w.d_pred);
   dev_free(w.d_row_scale); dev_free(w.d_spart); dev_free(w.d_colpart); dev_free(w.d_offs); dev_free(w.d_shift); dev_free(w.d_dots);
   dev_free(w.d_gflags); dev_free(w.d_c1[0]); dev_free(w.d_c1[1]); dev_free(w.d_dots2);
 }

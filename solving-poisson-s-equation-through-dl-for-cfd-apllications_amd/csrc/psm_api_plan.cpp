@@ -20,6 +20,7 @@ int ws_alloc(psm_handle* h, Workspace& w) {
   if ((rc = dev_alloc(h, &w.d_xin, (size_t)h->Mpad_cap * h->ld_in))) return rc;
   if ((rc = dev_alloc(h, &w.d_act[0], (size_t)h->Mpad_cap * h->max_width))) return rc;
   if ((rc = dev_alloc(h, &w.d_act[1], (size_t)h->Mpad_cap * h->max_width))) return rc;
+  if (h->Mpad_cap > 128 && (rc = dev_alloc(h, &w.d_act_rows, (size_t)h->Mpad_cap * h->max_width))) return rc;   // only batches beyond 128 block rows pack
   if ((rc = dev_alloc(h, &w.d_res, (size_t)h->Mpad_cap * h->ld_out))) return rc;
   if ((rc = dev_alloc(h, &w.d_pred, (size_t)h->Mcap * h->K_out))) return rc;
   if ((rc = dev_alloc(h, &w.d_row_scale, (size_t)h->Mpad_cap))) return rc;
@@ -32,6 +33,7 @@ int ws_alloc(psm_handle* h, Workspace& w) {
   HIPCHK(h, hipMemset(w.d_part, 0, (size_t)h->n_slices * h->Mpad_cap * h->ld_in * sizeof(float)));
   HIPCHK(h, hipMemset(w.d_act[0], 0, (size_t)h->Mpad_cap * h->max_width * sizeof(float)));
   HIPCHK(h, hipMemset(w.d_act[1], 0, (size_t)h->Mpad_cap * h->max_width * sizeof(float)));
+  if (w.d_act_rows) HIPCHK(h, hipMemset(w.d_act_rows, 0, (size_t)h->Mpad_cap * h->max_width * sizeof(float)));
   if (h->bound && h->bound_dots) { if ((rc = dev_alloc(h, &w.d_dots, h->bound_dots))) return rc; }
   if (h->bound && (rc = ws_alloc_guard(h, w))) return rc;
   if (h->bound && h->bound_cf) { if ((rc = dev_alloc(h, &w.d_dots2, h->cf_rows_all))) return rc; }

@@ -111,6 +111,18 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
   if (&w == &h->ws0) { h->last_row_scale = d_row_scale; h->last_used_cf = use_cf; }
   PsmReduceArgs ra{w.d_part, w.d_xin, h->d_ia, h->d_ib, n_slabs, Mpad, h->ld_in};
   const int nl = (int)h->dense.size();
+  // Large case batches (more than 128 block rows): the activation between two plain float32 Dense launches in MFMA operand order
+  // (PsmDenseArgs::in_packed / out_packed): the consumer's row loads are then contiguous KiBs -- 64 cases: 10.0 -> 8.4 us per hidden
+  // layer, 32 cases: 6.7 -> 5.2 (profiles/r06_case_batch.txt).  Not with a LayerNormalization behind the producer (its kernel and the
+  // fused form read rows), not for bf16 handles, not in front of the Conv1D head.  PSM_DENSE_PACKED=0 keeps rows everywhere.
+  static const bool packed_env = !(getenv("PSM_DENSE_PACKED") && atoi(getenv("PSM_DENSE_PACKED")) == 0);
+  auto packable = [&](int l) {          // output of layer l
+    if (!packed_env || l < 0 || l >= nl - 1 || Mpad <= 128 || bf16) return false;
+    for (const DenseLayer& q : h->dense) if (q.ln) return false;       // densePCA_attention: its normalisations (and their residuals) read rows
+    const DenseLayer& d = h->dense[l];
+    return d.ldw % 16 == 0 && h->dense[l + 1].Kp <= d.ldw;
+  };
+  if (&w == &h->ws0) h->last_act_packed = packable(nl - 2);           // psm_read_stage then takes the row-major copy (d_act_rows)
   auto dense_args = [&](int l, const float* cur, int ld_cur) {
     const DenseLayer& d = h->dense[l];
     const bool head = (l == nl - 1);
@@ -121,6 +133,11 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
     da.Kpad = d.Kpad; da.Mpad = Mpad; da.relu = (head || d.linear) ? 0 : 1; da.head = head ? 1 : 0;
     da.bf16 = (h->cfg.precision == PSM_PRECISION_BF16) ? 1 : 0;
     da.layer = l;
+    da.out_packed = packable(l) ? 1 : 0;                 // hidden activation of a large batch: written in MFMA operand order ...
+    da.in_packed = (l > 0 && packable(l - 1)) ? 1 : 0;   // ... and read as such by the next Dense launch
+    // the head's strip-dot riders (and psm_read_stage) read whole rows: the last hidden layer also leaves a row-major copy
+    if (da.out_packed && l == nl - 2) da.out_rows = w.d_act_rows;
+    if (da.in_packed && head) da.in_rows = w.d_act_rows;
     return da;
   };
   // few block rows: slab reduce + first dense layer in one launch (one workgroup per row)

@@ -68,6 +68,7 @@ struct GraphKey {
 // ring slot, so that the solves of neighbouring tickets run on their own streams without sharing scratch.
 struct Workspace {
   float *d_part = nullptr, *d_xin = nullptr, *d_act[2] = {nullptr, nullptr}, *d_res = nullptr, *d_pred = nullptr;
+  float* d_act_rows = nullptr;          // row-major copy of the last hidden activation when the chain between the Dense launches is packed (large batches)
   float *d_row_scale = nullptr;
   float4* d_spart = nullptr;
   float2* d_colpart = nullptr;
@@ -193,6 +194,7 @@ struct psm_handle {
   int32_t* d_row_of_p = nullptr;
   std::vector<float> h_shiftW;          // host copy of d_shiftW [c_out][B]
   const float* last_row_scale = nullptr;   // row scale of the last solve on ws0 (introspection)
+  bool last_act_packed = false;         // the last solve on ws0 left its last hidden activation in MFMA operand order (PsmDenseArgs::out_packed)
   bool last_used_cf = false;            // the last solve on ws0 took the closed form: offsets / shift are computed on demand
   // guard of the bound-geometry contract (psm_kernels.h PsmGuardArgs)
   unsigned long long* d_maskbits = nullptr;   // bound flow-cell pattern, one 64-pixel ballot per word

@@ -55,7 +55,19 @@ struct PsmDenseArgs {
   // (v - mean) * rsqrt(var + ln_eps) * ln_gamma + ln_beta.  ln_gamma / ln_beta: [>= ld_in], zero beyond ln_n; nullptr = plain input.
   // ln_residual: the epilogue adds the NORMALISED input at the output column (NNs.py:64 `x + attn_output`; square layer).
   const float* ln_gamma; const float* ln_beta; float ln_eps; int ln_n, ln_residual;
+  // Large case batches (round 6): hidden activations in MFMA operand order instead of rows -- [row tile of 16][k group of 16][lane][4]
+  // floats, lane = 16 * ((k % 16) / 4) + row % 16 -- so that the consumer's 16-byte-per-lane row loads are one contiguous KiB per wave
+  // (a row-major [Mpad][512] activation gives sixteen 64-byte pieces of sixteen rows per load).  in_packed: `in` is such a tensor of
+  // ld_in / 16 groups; out_packed: `out` is written as one of ld_out / 16 groups.  Plain float32 layers of 32-row tiles only.
+  int in_packed, out_packed;
+  // the strip-dot riders of the head launch read whole rows: the last hidden layer of a packed chain writes a second, row-major copy
+  // (out_rows, [Mpad][ld_out]) beside the packed one, and the head launch hands it to its riders as in_rows ([Mpad][ld_in]); else nullptr
+  float* out_rows; const float* in_rows;
 };
+// float offset of element (row, k) of a packed activation with `groups` k groups per row tile
+static inline __host__ __device__ long long psm_packed_offset(int row, int k, int groups) {
+  return ((((long long)(row >> 4) * groups + (k >> 4)) * 64) + ((k & 15) >> 2) * 16 + (row & 15)) * 4 + (k & 3);
+}
 
 // LayerNormalization of the reference's densePCA_attention (NNs.py:56, 64; Keras defaults: last axis, epsilon 1e-3, centre and
 // scale), in place on a finished activation, with the optional residual of NNs.py:64 (`x + attn_output`, where attn_output
@@ -209,7 +221,7 @@ struct PsmPairFoldArgs {               // bind time: pair rows as linear combina
 };
 hipError_t psm_launch_pair_fold(const PsmPairFoldArgs& a, hipStream_t s);
 // strip dots from an arbitrary activation (introspection under the closed form; the bf16 handles' own dots launch)
-hipError_t psm_launch_act_dots(const PsmDotsArgs& d, const float* act, int ld_act, int round_bf16, hipStream_t s);
+hipError_t psm_launch_act_dots(const PsmDotsArgs& d, const float* act, int ld_act, int round_bf16, hipStream_t s, int packed = 0);
 hipError_t psm_launch_bind(const PsmBindArgs& a, hipStream_t s);
 hipError_t psm_launch_chain_dots(const PsmBoundBatchArgs& p, int c_out, hipStream_t s);
 hipError_t psm_launch_decode_paste_batch(const PsmDecodeArgs& a, const PsmBoundBatchArgs& p, int c_out, hipStream_t s, int bf16 = 0);

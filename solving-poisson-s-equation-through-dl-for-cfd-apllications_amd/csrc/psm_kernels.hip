@@ -1175,6 +1175,13 @@ __device__ __forceinline__ float psm_guard_sum(const float* flags, int n, int la
 // empty strip, like np.mean([])).
 // LNIN (hidden layers of densePCA_attention): the input carries a pending LayerNormalization (PsmDenseArgs::ln_*) -- moments of
 // the workgroup's own rows in a prologue, operands normalised on their way into the MFMAs, optional residual in the epilogue.
+// float4 number q (columns 4 q .. 4 q + 3) of row `row` of a Dense input: rows of ld_in floats, or the packed form of PsmDenseArgs
+__device__ __forceinline__ f32x4 psm_act_q(const PsmDenseArgs& a, int row, int q) {
+  if (a.in_rows) return reinterpret_cast<const f32x4*>(a.in_rows + (int64_t)row * a.ld_in)[q];
+  if (a.in_packed) return reinterpret_cast<const f32x4*>(a.in)[((int64_t)(row >> 4) * (a.ld_in >> 4) + (q >> 2)) * 64 + (q & 3) * 16 + (row & 15)];
+  return reinterpret_cast<const f32x4*>(a.in + (int64_t)row * a.ld_in)[q];
+}
+
 template <int NGC, bool BF16, int ROWS, bool DOTS, bool LNIN = false>   // NGC: groups of 16 k per wave per pass
 __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a, PsmDotsArgs d) {
   psm_warm_kernargs<sizeof(PsmDenseArgs) + sizeof(PsmDotsArgs)>();
@@ -1205,7 +1212,7 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a, PsmDotsA
       const int row = wg * 2 + rsel, rc = min(row, d.n_rows - 1);
       const int cs = rc / d.rows_per_case;
       const f32x4* gp = reinterpret_cast<const f32x4*>(d.g2) + (int64_t)rc * d.n_src * nq;
-      const float* ap = a.in + (int64_t)cs * d.n_src * a.ld_in;
+      const int arow_base = cs * d.n_src;
       const float rsv = d.row_scale[cs * d.n_src];
       float acc = 0.f;
       for (int b0 = q4; b0 < d.n_src; b0 += 16) {
@@ -1219,7 +1226,7 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a, PsmDotsA
           for (int u = 0; u < NQ; ++u) {
             const int q = min(lane + 64 * u, nq - 1);
             gg[t][u] = gp[(int64_t)blk * nq + q];
-            xx[t][u] = reinterpret_cast<const f32x4*>(ap + (int64_t)blk * a.ld_in)[q];
+            xx[t][u] = psm_act_q(a, arow_base + blk, q);
           }
         }
 #pragma unroll
@@ -1246,7 +1253,7 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a, PsmDotsA
       const int row = wg, rc = min(row, d.n_rows - 1);
       const int cs = rc / d.rows_per_case;
       const f32x4* gp = reinterpret_cast<const f32x4*>(d.g2) + (int64_t)rc * d.n_src * nq;
-      const float* ap = a.in + (int64_t)cs * d.n_src * a.ld_in;
+      const int arow_base = cs * d.n_src;
       const float rsv = d.row_scale[cs * d.n_src];
       float acc = 0.f;
       for (int b0 = wave; b0 < d.n_src; b0 += 32) {
@@ -1260,7 +1267,7 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a, PsmDotsA
           for (int u = 0; u < NQ; ++u) {
             const int q = min(lane + 64 * u, nq - 1);
             gg[t][u] = gp[(int64_t)blk * nq + q];
-            xx[t][u] = reinterpret_cast<const f32x4*>(ap + (int64_t)blk * a.ld_in)[q];
+            xx[t][u] = psm_act_q(a, arow_base + blk, q);
           }
         }
 #pragma unroll
@@ -1298,7 +1305,7 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a, PsmDotsA
       for (int u = 0; u < NQ; ++u) {
         const int q = min(lane + 64 * u, nq - 1);
         g[t][u] = reinterpret_cast<const f32x4*>(d.g2)[(int64_t)rc * nq + q];
-        x[t][u] = reinterpret_cast<const f32x4*>(a.in + (int64_t)blk * a.ld_in)[q];
+        x[t][u] = psm_act_q(a, blk, q);
       }
     }
 #pragma unroll
@@ -1360,6 +1367,30 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a, PsmDotsA
       } else {
         w[g] = reinterpret_cast<const f32x4*>(a.Wp)[widx];
       }
+    }
+  };
+  auto load_aw = [&](int g0, f32x4 (&a0)[NGC], f32x4 (&a1)[NGC], f32x4 (&w)[NGC]) {
+#pragma unroll
+    for (int g = 0; g < NGC; ++g) {
+      const int kcol = min(16 * (g_first + g0 + g) + 4 * kq, kmax);
+      if (!LNIN && !BF16 && ROWS == 32 && a.in_packed) {                 // uniform: one contiguous KiB per wave and row tile
+        const int gin = a.ld_in >> 4;
+        const f32x4* pk = reinterpret_cast<const f32x4*>(a.in) + ((int64_t)(2 * mt) * gin + min(g_first + g0 + g, gin - 1)) * 64 + lane;
+        a0[g] = pk[0];
+        a1[g] = pk[(int64_t)gin * 64];
+      } else {
+        a0[g] = *reinterpret_cast<const f32x4*>(arow0 + kcol);
+        if (ROWS == 32) a1[g] = *reinterpret_cast<const f32x4*>(arow1 + kcol);
+      }
+      const int64_t widx = ((int64_t)nt * groups + g_first + g0 + g) * 64 + lane;
+      if (BF16) {
+        const uint2 u = reinterpret_cast<const uint2*>(a.Wp)[widx];
+        w[g] = (f32x4){__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                       __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+      } else {
+        w[g] = reinterpret_cast<const f32x4*>(a.Wp)[widx];
+      }
+      __builtin_amdgcn_sched_barrier(0);               // keeps the groups' requests in this order (the scheduler clusters the row loads otherwise)
     }
   };
   auto mma = [&](const f32x4 (&a0)[NGC], const f32x4 (&a1)[NGC], const f32x4 (&w)[NGC]) {
@@ -1452,14 +1483,17 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a, PsmDotsA
   } else {
     for (int g0 = 0; g0 < ng; g0 += NGC) {
       f32x4 a0[NGC], a1[NGC], w[NGC];
-      load_a(g0, a0, a1);
       if constexpr (LNIN) {
         f32x4 gm[NGC], bt[NGC];
+        load_a(g0, a0, a1);
         load_gb(g0, gm, bt);
         load_w(g0, w);
         normalise(a0, a1, gm, bt);
       } else {
-        load_w(g0, w);
+        // requests in the order the MFMAs consume them -- (rows, weights) of k group 0, then of group 1, ...: loads return in issue
+        // order, so the first group's MFMAs need vmcnt(3 (NGC - 1)) instead of everything but the last weight groups, and the
+        // matrix steps of group g run while groups g + 1 ... are still arriving (round 6; was: all rows, then all weights)
+        load_aw(g0, a0, a1, w);
       }
       __builtin_amdgcn_sched_barrier(0);               // every request of the pass before its first MFMA (the scheduler had sunk half of them behind it: two round trips)
       mma(a0, a1, w);
@@ -1484,7 +1518,10 @@ __global__ __launch_bounds__(512) void psm_dense_kernel(PsmDenseArgs a, PsmDotsA
       if (a.ln_residual) v += (res_raw - ln_stat[0][row]) * ln_stat[1][row] * res_g + res_b;     // x + LN(input) (NNs.py:64)
     }
     if (a.head) v = v * sa_v + sb_v;
-    a.out[(int64_t)(mt * ROWS + row) * a.ld_out + n_out] = v;
+    if (!LNIN && !BF16 && ROWS == 32 && a.out_packed) {
+      a.out[psm_packed_offset(mt * ROWS + row, n_out, a.ld_out >> 4)] = v;
+      if (a.out_rows) a.out_rows[(int64_t)(mt * ROWS + row) * a.ld_out + n_out] = v;
+    } else a.out[(int64_t)(mt * ROWS + row) * a.ld_out + n_out] = v;
   }
   PSM_STAMP(0, 46 + 4 * (a.layer & 3));
 }
@@ -1493,6 +1530,8 @@ hipError_t psm_launch_dense(const PsmDenseArgs& a, hipStream_t st, const PsmGuar
   const int ng = a.Kp / 128;                       // groups of 16 k per wave
   if (!a.Wp || a.Kp % 128 != 0 || (ng > 2 && ng % 4 != 0) || a.ld_in < 4) return hipErrorInvalidValue;
   const bool r16 = a.Mpad <= 128;     // up to 128 block rows: 16-row tiles keep >= 64 workgroups pulling <= 64 KB each
+  if ((a.in_packed || a.out_packed) && (r16 || a.bf16 || a.ln_gamma || (a.in_packed && (a.ld_in % 16 != 0 || a.Kp > a.ld_in)) || (a.out_packed && a.ld_out % 16 != 0)))
+    return hipErrorInvalidValue;       // packed activations: float32 layers on 32-row tiles, no pending LayerNormalization
   const int gx = a.ld_w / 16, gy = a.Mpad / (r16 ? 16 : 32);
   PsmDotsArgs rd{};
   int gz = 1;
@@ -1523,6 +1562,7 @@ hipError_t psm_launch_dense_dots(const PsmDenseArgs& a, const PsmDotsArgs& d, hi
   if (!a.Wp || a.Kp % 128 != 0 || (ng > 2 && ng % 4 != 0) || a.ld_in < 4 || a.bf16) return hipErrorInvalidValue;
   if (d.Kh < 4 || d.Kh % 4 != 0 || d.Kh > 1024 || d.Kh > a.ld_in || d.n_rows < 1) return hipErrorInvalidValue;
   const bool r16 = a.Mpad <= 128;                   // same tile choice as psm_launch_dense
+  if (a.out_packed || (a.in_packed && (r16 || a.ld_in % 16 != 0 || a.Kp > a.ld_in))) return hipErrorInvalidValue;
   const int gx = a.ld_w / 16, gy = a.Mpad / (r16 ? 16 : 32);
   // z planes > 0: ceil(n_rows / 16) dots workgroups (8 waves x 2 rows), then ceil(guard waves / 8) guard workgroups
   const int extra = (d.n_src > 1 ? (d.n_rows > PSM_DOTS_WG_ROWS ? (d.n_rows + 1) / 2 : d.n_rows) : (d.n_rows + 15) / 16) + (d.guard.sdf ? d.guard.wg_count : 0);
@@ -3012,22 +3052,22 @@ hipError_t psm_launch_pair_fold(const PsmPairFoldArgs& a, hipStream_t st) {
 
 // table dots from any activation [rows][ld_act] (one wave per table row; d.Kh <= ld_act): introspection under the closed
 // form (the strip means the chain would have consumed)
-__global__ __launch_bounds__(256) void psm_act_dots_kernel(PsmDotsArgs d, const float* act, int ld_act, int round_bf16) {
+__global__ __launch_bounds__(256) void psm_act_dots_kernel(PsmDotsArgs d, const float* act, int ld_act, int round_bf16, int packed) {
   const int lane = threadIdx.x & 63, row = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int rc = min(row, d.n_rows - 1);
   const int blk = d.row_of[rc];
   float acc = 0.f;
   for (int k = lane; k < d.Kh; k += 64) {
-    float x = act[(int64_t)blk * ld_act + k];
+    float x = packed ? act[psm_packed_offset(blk, k, ld_act >> 4)] : act[(int64_t)blk * ld_act + k];
     if (round_bf16) x = (float)(__bf16)x;
     acc += x * d.g2[(int64_t)rc * d.Kh + k];
   }
   const float tot = wave_sum(acc);
   if (lane == 0 && row < d.n_rows) d.out[row] = d.row_scale[blk] * (tot + d.c2[rc]) / d.cnt[rc];
 }
-hipError_t psm_launch_act_dots(const PsmDotsArgs& d, const float* act, int ld_act, int round_bf16, hipStream_t st) {
-  if (d.n_rows < 1 || d.Kh < 1 || d.Kh > ld_act) return hipErrorInvalidValue;
-  PSM_LAUNCH(psm_act_dots_kernel, dim3((d.n_rows + 3) / 4), dim3(256), 0, st, d, act, ld_act, round_bf16);
+hipError_t psm_launch_act_dots(const PsmDotsArgs& d, const float* act, int ld_act, int round_bf16, hipStream_t st, int packed) {
+  if (d.n_rows < 1 || d.Kh < 1 || d.Kh > ld_act || (packed && ld_act % 16 != 0)) return hipErrorInvalidValue;
+  PSM_LAUNCH(psm_act_dots_kernel, dim3((d.n_rows + 3) / 4), dim3(256), 0, st, d, act, ld_act, round_bf16, packed);
   return hipGetLastError();
 }
 
