@@ -26,9 +26,9 @@ struct PsmEncodeArgs {
   int x6;                  // float32 contraction as six bf16 MFMA terms of exactly split operands (psm_encode_x6_kernel)
   const uint4* bpack_x6;   // the basis pre-split into three bf16 planes, MFMA fragment order (pack_comp_in_x6); psm_encode_x6_mt_kernel only
   int kgroup;              // > 1: the M-tiled, wave-specialised form for large case batches (psm_encode_x6_mt_kernel) with `kgroup` K GROUPS: a
-                           // workgroup owns one group of consecutive K slices x 96 block rows and writes ONE slab -- part [kgroup][Mpad][ldp];
+                           // workgroup owns one group of consecutive K slices x PSM_ENC_MT_ROWS (64) block rows and writes ONE slab -- part [kgroup][Mpad][ldp];
                            // 0 / 1: one slab per slice (psm_encode_x6_kernel / psm_encode_kernel)
-  int pairs_ok;            // the caller reduces psm_encode_slabs() slabs: the two-slices-per-workgroup form may run (psm_encode_pair_kernel)
+  int pairs_ok;            // the two-slices-per-workgroup form may run (psm_encode_pair_kernel): when psm_encode_pairs(args) is true the launch writes n_slices / 2 slabs and the caller's reduce must sum that many (launch_all, psm_api_solve.cpp)
 };
 bool psm_encode_pairs(const PsmEncodeArgs& a);   // true: this launch writes n_slices / 2 slabs
 constexpr int PSM_ENC_MT_ROWS = 64;    // block rows of a workgroup of the M-tiled encode (two 32-row MFMA tiles)

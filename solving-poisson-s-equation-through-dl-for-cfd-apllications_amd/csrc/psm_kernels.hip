@@ -743,7 +743,7 @@ static bool psm_encode_x6_fits(const PsmEncodeArgs& a, size_t* lds, int* row_wgs
 }
 
 // the two-slices-per-workgroup form (psm_encode_pair_kernel): one row tile, exactly four component tiles, float32 MFMA, an even
-// number of slices.  PSM_ENCODE_PAIRS=0 keeps one slab per slice.  The slab count the reduce launches must use: psm_encode_slabs.
+// number of slices.  PSM_ENCODE_PAIRS=0 keeps one slab per slice.  The slab count the reduce launches must use: n_slices / 2 when psm_encode_pairs(args) (launch_all, psm_api_solve.cpp).
 bool psm_encode_pairs(const PsmEncodeArgs& a) {
   static const bool on = !(getenv("PSM_ENCODE_PAIRS") && atoi(getenv("PSM_ENCODE_PAIRS")) == 0);
   const int n_slices = a.S * a.S / PSM_PIX_PER_SLICE;
@@ -818,7 +818,7 @@ hipError_t psm_launch_encode(const PsmEncodeArgs& a, hipStream_t st, hipEvent_t 
 // ---------------------------------------------------------------------------
 // basis of the large-batch encode: the float32 pack (pack_comp_in: [slice][ntile][KS/8 groups][64 lanes] float4) split exactly into
 // three bf16 planes in the fragment order of the MFMA's second operand: [slice][ntile][KS/16 steps][plane h, m, l][64 lanes] x 8 bf16
-// (step st = groups 2 st and 2 st + 1 of the same lane).  Once per handle (psm_api.cpp, ensure_encode_aux).
+// (step st = groups 2 st and 2 st + 1 of the same lane).  Once per handle (psm_api_solve.cpp, ensure_encode_aux).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void psm_split_basis_kernel(const float4* bpack, uint4* out, long long n_frag, int NS) {
   const long long f = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);       // fragment = (slice, ntile, step)
@@ -1091,7 +1091,7 @@ hipError_t psm_launch_conv1d(const PsmConv1dArgs& a, hipStream_t st) {
 // and the f32 MFMA accumulates them exactly like v_mfma_*_bf16 would (this layer is latency
 // bound, the bf16 storage only halves its weight bytes).
 //
-// Weights come MFMA-packed (psm_api.cpp pack_dense): the four k of a lane's group are one
+// Weights come MFMA-packed (psm_api_model.cpp, pack_dense): the four k of a lane's group are one
 // 16-byte (bf16: 8-byte) piece and a wave's group is 1 KiB contiguous, so the whole operand set
 // of a wave (NGC groups: 2*NGC + NGC loads per lane) is requested up front, unconditionally, and
 // the MFMAs wait on it with counted vmcnt -- one memory round trip per pass.  Columns of the

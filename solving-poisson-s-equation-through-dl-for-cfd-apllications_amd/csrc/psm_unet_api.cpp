@@ -659,7 +659,7 @@ int psm_unet_forward(psm_unet* u, const float* grid, int32_t n_cases, float* fie
   int rc = forward(u, u->d_in, n_cases, u->d_field, u->stream);
   if (rc) return rc;
   UCHK(u, hipMemcpyAsync(u->h_out, u->d_field, npix * u->c_out * sizeof(float), hipMemcpyDeviceToHost, u->stream));
-  {   // synchronous call of a few hundred us: poll instead of sleeping (see psm_api.cpp wait_stream); PSM_SYNC_BLOCK=1 blocks
+  {   // synchronous call of a few hundred us: poll instead of sleeping (see psm_api_solve.cpp, wait_stream); PSM_SYNC_BLOCK=1 blocks
     static const bool block = getenv("PSM_SYNC_BLOCK") != nullptr;
     hipError_t e = hipSuccess;
     if (block) e = hipStreamSynchronize(u->stream);
