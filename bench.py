@@ -37,7 +37,7 @@ Objects of the full record (the line carries their summary):
   roofline     the kernel with the largest measured time in this run: every dispatch of K instrumented solves carries
                its own begin / end stamps (hipExtLaunchKernelGGL events, psm_time_kernels); achieved = that kernel's
                algorithmic bytes per launch / its average duration.  "traffic" = HBM-side bytes per launch from the
-               committed PMC run of the same kernel (profiles/r04_pmc.json; null when the kernel source has changed
+               committed PMC run of the same kernel (profiles/archive/r04_pmc.json; null when the kernel source has changed
                since that run).
   cpu_baseline the C / OpenMP port of the reference's algorithm (float64 PCA + float32 MLP like the reference) timed on
                the host cores, rank 0, N=1; the NumPy oracle beside it.

@@ -357,7 +357,7 @@ struct Timer {                      // optional event pair around one kernel gro
 
 // cells up to which psm_solve reads registered input with the stage kernel; above, the DMA engine's higher large-copy rate (49 against
 // 40 GB/s over this PCIe link) wins: measured crossover between 44 k (stage 107 / DMA 110 us) and 69 k cells (147 / 142 us),
-// profiles/r04_psm_solve.txt
+// profiles/archive/r04_psm_solve.txt
 #define PSM_MESH_STAGE_MAX_DEFAULT 50000
 
 #endif

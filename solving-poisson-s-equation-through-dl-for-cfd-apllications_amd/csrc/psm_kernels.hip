@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256, 2) void psm_encode_x6_mt_kernel(PsmEncodeArgs 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n_slices = a.S * a.S / PSM_PIX_PER_SLICE;
   // Workgroup -> (K group g, row group): the row groups of ONE K group read the same basis slices, so they get consecutive slots of
-  // ONE XCD (workgroup i runs on XCD i % 8, tools/xcc_probe.hip): id = ((g / 8) * row_groups + rg) * 8 + g % 8 -- the basis then comes
+  // ONE XCD (workgroup i runs on XCD i % 8, tools/attic/xcc_probe.hip): id = ((g / 8) * row_groups + rg) * 8 + g % 8 -- the basis then comes
   // from memory once per K group and from that XCD's L2 for the other row groups.  Placement is a speed matter only.  Ids whose K
   // group does not exist (the last, partial block of eight) leave at once.
   const int n_groups = a.kgroup, row_groups = (a.Mpad + PSM_ENC_MT_ROWS - 1) / PSM_ENC_MT_ROWS;
@@ -1102,7 +1102,7 @@ __device__ __forceinline__ float wave_sum(float v);
 // A loaded value whose FIRST use would sit inside run-time predicated store blocks is consumed once before them, through an opaque
 // move.  The wait-count pass cannot count the stores in flight behind run-time predicates, so with a load still pending at their
 // first use it emits s_waitcnt vmcnt(0) in front of EVERY store: sixteen store round trips in series per epilogue (the decode
-// kernels' `mean` value; tools/isa_store_waits.py finds the pattern in a listing).
+// kernels' `mean` value; tools/attic/isa_store_waits.py finds the pattern in a listing).
 __device__ __forceinline__ float psm_settled(float v) {
   float r;
   asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(v));
@@ -2997,7 +2997,7 @@ hipError_t psm_launch_decode_paste_batch(const PsmDecodeArgs& a, const PsmBoundB
   // One 32-row tile per chunk, the row tiles spread over up to `target / nwg` row groups (grid.y): measured against two and
   // three tiles per chunk (fewer passes over the basis slice, but 2-3x the LDS and registers per workgroup) at 8 ... 64
   // cases and both field counts -- 16 cases: 12.5 against 20.0 us, 64 cases: 30.2 against 48.8 us, U_to_gradP 8 cases: 24.1
-  // against 36.8 us, 8 deltas cases: equal (tools/decode_mtc_sweep.py).  PSM_DECODE_MTC / PSM_DECODE_WGS: diagnostic.
+  // against 36.8 us, 8 deltas cases: equal (tools/attic/decode_mtc_sweep.py).  PSM_DECODE_MTC / PSM_DECODE_WGS: diagnostic.
   static const int mtc_force = getenv("PSM_DECODE_MTC") ? atoi(getenv("PSM_DECODE_MTC")) : 0;
   static const int wg_target = getenv("PSM_DECODE_WGS") ? atoi(getenv("PSM_DECODE_WGS")) : 512;
   const int mtc = mtc_force ? std::min(std::max(mtc_force, 1), 3) : 1;

@@ -53,7 +53,7 @@ struct PsmHeadArgs {           // 1x1 convolution on a thin activation (c_in <= 
 //   1 = 2 rows x 4 channel tiles, each wave both rows x one channel tile
 // (round 4: 8 rows x 4 channel tiles with one channel tile per wave and the activation rows kept across ky -- 13 LDS operand
 // reads per 24 MFMAs -- measured at 8 cases per step, bf16: slower on every deep layer, dec3a 21.7 against 15.3 us, with a split
-// in two 14.3 us and its consumer +2.2 us; profiles/r04_conv_experiments.txt; not kept)
+// in two 14.3 us and its consumer +2.2 us; profiles/archive/r04_conv_experiments.txt; not kept)
 // (4 x 16 and 8 x 16 pixel tiles with 4 channel tiles per wave were measured too: within 1 us per layer at batch 1,
 // slower at 8 cases per step -- the staged bytes per MFMA are not what limits these layers; not kept)
 // Round 6, bf16 activations only (finished bf16 inputs, no split-K slabs on the input side): larger per-wave register blocks, i.e. fewer

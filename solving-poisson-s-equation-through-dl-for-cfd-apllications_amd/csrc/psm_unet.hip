@@ -23,7 +23,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define PSM_CONV_PD 1
 #endif
 // bf16 form: activation rows kept across ky (round 4 experiment).  Measured A/B on one box, 8 cases per step: 157.3 / 157.2 us
-// with it, 154.4 / 155.1 us without (profiles/r04_conv_experiments.txt) -- a third of the LDS operand reads gone and the pass
+// with it, 154.4 / 155.1 us without (profiles/archive/r04_conv_experiments.txt) -- a third of the LDS operand reads gone and the pass
 // 1.5 % SLOWER: the matrix phase is not what these layers wait for.  Off; -DPSM_CONV_KYREUSE=1 builds it.
 #ifndef PSM_CONV_KYREUSE
 #define PSM_CONV_KYREUSE 0

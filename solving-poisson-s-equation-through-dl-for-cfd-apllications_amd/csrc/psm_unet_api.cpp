@@ -258,7 +258,7 @@ void choose_config(Conv& c, int H, int W, int n_cases, bool can_split, int chunk
   const int ctiles = (c.cout + 15) / 16;
   struct Cand { int arr, nct, th; };
   const Cand cands[4] = {{0, 2, 8}, {0, 1, 8}, {1, 4, 2}, {2, 4, 16}};
-  // diagnostic knobs (tools/unet_bench.py sweeps): workgroups wanted before reuse counts, deepest split
+  // diagnostic knobs (tools/attic/unet_bench.py sweeps): workgroups wanted before reuse counts, deepest split
   const long fill = getenv("PSM_UNET_FILL") ? atol(getenv("PSM_UNET_FILL")) : 256;
   const int ks_max = getenv("PSM_UNET_KSPLIT_MAX") ? atoi(getenv("PSM_UNET_KSPLIT_MAX")) : 8;
   long best_score = -1;
@@ -606,7 +606,7 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
                                 ci < u->ksplit_cap.size() ? u->ksplit_cap[ci] : 8, x6_ok,
                                 ci < u->tile_choice.size() ? u->tile_choice[ci] : -1,      // measured choice of psm_unet_autotune
                                 u->bf16 && !stem_layer && c.src != 0);
-    // diagnostic override: PSM_UNET_FORCE="layer:arrangement:nct:ksplit,..." (tools/unet_bench.py experiments)
+    // diagnostic override: PSM_UNET_FORCE="layer:arrangement:nct:ksplit,..." (tools/attic/unet_bench.py experiments)
     if (const char* f = getenv("PSM_UNET_FORCE")) {
       for (const char* q = f; q && *q; q = std::strchr(q, ',') ? std::strchr(q, ',') + 1 : nullptr) {
         int li, arr, nct, ks;

@@ -71,7 +71,7 @@ constexpr int M16_BYTES = P16 * MH * 32;                 // 17920
 #define MFMA_BF(w, x, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((w), (x), (c), 0, 0, 0)
 #endif
 // level-0 decoder pair: the next tile's ten requests spread over conv A's MFMA steps, two per step (1), or issued in one go
-// before them (0).  Measured A/B on one box (round 4, profiles/r04_conv_experiments.txt (5g)): 20.50 / 19.80 us spread against
+// before them (0).  Measured A/B on one box (round 4, profiles/archive/r04_conv_experiments.txt (5g)): 20.50 / 19.80 us spread against
 // 20.06 / 20.00 us in one go at 8 cases, 13.30 / 13.16 against 13.46 / 13.42 us at 512 x 512 x 1 -- the address path is not what
 // the tile waits for either.  Off; -DPSM_PAIR_SPREAD=1 builds it (parity tests green in both forms).
 #ifndef PSM_PAIR_SPREAD

@@ -1,5 +1,5 @@
 """densePCA_attention ('MLP_attention', 3 x 512 + attention block) on the 256 x 256 deltas shape: launches and time per solve, bound path.
-    python tools/attention_bench.py            (PSM_LN_FUSE=0: every LayerNormalization as its own launch)"""
+    python tools/attic/attention_bench.py            (PSM_LN_FUSE=0: every LayerNormalization as its own launch)"""
 import sys, time
 import numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')

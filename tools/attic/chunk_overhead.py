@@ -1,6 +1,6 @@
 """Wall time of a chunk of n back-to-back bound solves between two device synchronisations, for several n: per solve and the fixed part
 (fill + drain + synchronise) from a straight-line fit -- what the driver's K = 20 run sees against K = 2000.
-    python tools/chunk_overhead.py [workload=config1]"""
+    python tools/attic/chunk_overhead.py [workload=config1]"""
 import sys, time
 import numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')

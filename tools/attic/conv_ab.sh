@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/conv_ab.sh ENVVAR -- every conv workload of bench.py with and without ENVVAR=1 (planner experiments)
+# usage: tools/attic/conv_ab.sh ENVVAR -- every conv workload of bench.py with and without ENVVAR=1 (planner experiments)
 for wl in unet unet_bf16 unet8 unet8_bf16 unet512_bf16; do
   for on in 0 1; do
     if [ $on = 1 ]; then export $1=1; else unset $1; fi

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/conv_all.sh -- every conv workload of bench.py (autotuned plan), one line each
+# usage: tools/attic/conv_all.sh -- every conv workload of bench.py (autotuned plan), one line each
 for wl in unet unet_bf16 unet8 unet8_bf16 unet512_bf16; do
   python bench.py --workload $wl --steps 300 --warmup 30 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys

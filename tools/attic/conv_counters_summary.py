@@ -1,4 +1,4 @@
-"""Condense tools/conv_counters.sh TAG: per kernel, the SQ counters summed over the chip and averaged over launches."""
+"""Condense tools/attic/conv_counters.sh TAG: per kernel, the SQ counters summed over the chip and averaged over launches."""
 import csv, glob, os, sys
 tag = sys.argv[1]
 rows = {}

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/conv_f32.sh -- the float32 conv workloads of bench.py (autotuned plan), one line each
+# usage: tools/attic/conv_f32.sh -- the float32 conv workloads of bench.py (autotuned plan), one line each
 for wl in unet unet8; do
   python bench.py --workload $wl --steps 300 --warmup 30 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys

@@ -3,7 +3,7 @@
 // memory), then reads the 4 KB a workgroup of ANOTHER XCD wrote in that phase and checks it.  Compared with N dependent
 // launches of the same body.  Every spin is bounded (a workgroup that never sees the counter sets an error flag and goes
 // on), so the grid always drains.
-//   hipcc -O3 --offload-arch=gfx950 tools/grid_barrier_probe.hip -o gpurun_out/grid_barrier_probe
+//   hipcc -O3 --offload-arch=gfx950 tools/attic/grid_barrier_probe.hip -o gpurun_out/grid_barrier_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,7 +1,7 @@
 """Finds the pattern that cost the case-batch decode 16 store round trips per chunk: an `s_waitcnt vmcnt(0)` INSIDE a predicated store block
 (between s_cbranch_execz and the global_store of that block) -- the wait-count pass cannot count stores issued under run-time predicates, so the
 first use of any register with a load still pending waits for every store in flight.
-    hipcc -O3 -std=c++17 --offload-arch=gfx950 -x hip --cuda-device-only -S FILE.hip -o FILE.s;  python tools/isa_store_waits.py FILE.s"""
+    hipcc -O3 -std=c++17 --offload-arch=gfx950 -x hip --cuda-device-only -S FILE.hip -o FILE.s;  python tools/attic/isa_store_waits.py FILE.s"""
 import re
 import sys
 

@@ -1,8 +1,8 @@
 // What does a dependent launch cost with the kernel's arguments preloaded into SGPRs by the command processor (gfx950:
 // -mllvm -amdgpu-kernarg-preload-count=N, flat arguments only) against the ordinary s_load of the kernarg segment?
 // A chain of small dependent kernels (each reads 64 KB the previous one wrote and writes 64 KB), plain launches on one stream.
-//   hipcc -O3 --offload-arch=gfx950 tools/kernarg_preload_probe.hip -o tools/_bin/kp_plain
-//   hipcc -O3 --offload-arch=gfx950 -mllvm -amdgpu-kernarg-preload-count=16 tools/kernarg_preload_probe.hip -o tools/_bin/kp_preload
+//   hipcc -O3 --offload-arch=gfx950 tools/attic/kernarg_preload_probe.hip -o tools/_bin/kp_plain
+//   hipcc -O3 --offload-arch=gfx950 -mllvm -amdgpu-kernarg-preload-count=16 tools/attic/kernarg_preload_probe.hip -o tools/_bin/kp_preload
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>

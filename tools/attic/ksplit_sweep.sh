@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/ksplit_sweep.sh -- conv path, deepest split-K allowed by the planner (PSM_UNET_KSPLIT_MAX) per workload
+# usage: tools/attic/ksplit_sweep.sh -- conv path, deepest split-K allowed by the planner (PSM_UNET_KSPLIT_MAX) per workload
 for wl in unet512_bf16 unet_bf16 unet; do
   for ks in 8 4 2 1; do
     PSM_UNET_KSPLIT_MAX=$ks python bench.py --workload $wl --steps 300 --warmup 30 --no-cpu-baseline 2>/dev/null | python -c "

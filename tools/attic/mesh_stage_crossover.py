@@ -1,5 +1,5 @@
 """psm_solve on registered buffers for meshes of growing size: the PCIe-reading stage kernel against the DMA copy (PSM_MESH_STAGE_MAX=0).
-    python tools/mesh_stage_crossover.py"""
+    python tools/attic/mesh_stage_crossover.py"""
 import os, subprocess, sys, time
 if len(sys.argv) > 1:
     import numpy as np

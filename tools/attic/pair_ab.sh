@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/pair_ab.sh [SIZE CASES] -- the fused pairs of this build against a reference build (tools/_bin/libpsm_base.so, e.g. the previous
+# usage: tools/attic/pair_ab.sh [SIZE CASES] -- the fused pairs of this build against a reference build (tools/_bin/libpsm_base.so, e.g. the previous
 # round's library built from its commit) on ONE box, alternating runs: per-launch dispatch times of tools/unet_layers.py
 SIZE=${1:-256}; CASES=${2:-8}
 for rep in 1 2; do

@@ -1,5 +1,5 @@
 """Host-buffer entries of BASELINE config 1 through psm_bench_host (C++ loop inside the library):
-    python tools/ring_probe.py [mode depth steps] ...   (triples; default: every mode)
+    python tools/attic/ring_probe.py [mode depth steps] ...   (triples; default: every mode)
 mode 0 sync pageable, 1 ring pageable, 2 ring registered, 3 ring zero-copy (include/psm.h: psm_bench_host)."""
 import ctypes as C, sys, time
 import numpy as np

@@ -1,5 +1,5 @@
 """psm_solve on the reference's shipped case shape (bench.py's shipped_case leg), 300 calls -- for
-    rocprofv3 --kernel-trace --stats -- python3 tools/shipped_trace.py"""
+    rocprofv3 --kernel-trace --stats -- python3 tools/attic/shipped_trace.py"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

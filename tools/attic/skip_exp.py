@@ -5,7 +5,7 @@ def run(keep, extra=None):
     for k, n in enumerate(names):
         if n not in keep: mask |= 1 << k
     env = dict(os.environ, PSM_DEBUG_SKIP=str(mask)); env.update(extra or {})
-    out = subprocess.run([sys.executable, "tools/hostbound.py"], env=env, capture_output=True, text=True).stdout.strip().splitlines()[-1]
+    out = subprocess.run([sys.executable, "tools/attic/hostbound.py"], env=env, capture_output=True, text=True).stdout.strip().splitlines()[-1]
     return float(out.split("total")[1].split()[0])
 seq = ["encode","mlp","decode","strips","paste"]
 prev = 0.0

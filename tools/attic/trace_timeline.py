@@ -1,5 +1,5 @@
 """Timeline of a rocprofv3 --kernel-trace (+ --memory-copy-trace) run from its results .db:
-    python tools/trace_timeline.py <results.db> [window_us=300] [offset_from_end_us=3000]
+    python tools/attic/trace_timeline.py <results.db> [window_us=300] [offset_from_end_us=3000]
 prints start (us), duration (us), stream and name of every dispatch / copy inside the window, then the per-stream busy
 fraction and the fraction of the window in which >= 2 dispatches overlap."""
 import sqlite3, sys

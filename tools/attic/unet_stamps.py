@@ -6,7 +6,7 @@ sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from psm_amd import UNetSurrogate, synthetic
 W = synthetic.unet_he_weights(seed=7)
 import os
-n = int(os.environ.get("N_CASES", "1")); prec = os.environ.get("PRECISION", "f32")        # N_CASES=8 PRECISION=bf16 python tools/unet_stamps.py 7
+n = int(os.environ.get("N_CASES", "1")); prec = os.environ.get("PRECISION", "f32")        # N_CASES=8 PRECISION=bf16 python tools/attic/unet_stamps.py 7
 g = np.stack([synthetic.channel_grid(256, 256, seed=1 + k).astype(np.float32) for k in range(n)])
 names = ['enc0a','enc0b','enc1a','enc1b','enc2a','enc2b','enc3a','enc3b','enc4a','enc4b','dec3a','dec3b','dec2a','dec2b','dec1a','dec1b','dec0a','dec0b','head']
 with UNetSurrogate(W, 256, 256, max_cases=n, precision=prec) as net:

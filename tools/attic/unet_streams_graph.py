@@ -1,6 +1,6 @@
 """Conv path: n cases as S independent chains of n/S cases on S streams, captured as ONE hipGraph with S parallel
 branches (fork / join through events) and replayed once per step -- against one handle x n cases launched plainly.
-The plain-launch form of the same split (tools/unet_streams.py) is bound by the host's launch rate; a graph replay is not.
+The plain-launch form of the same split (tools/attic/unet_streams.py) is bound by the host's launch rate; a graph replay is not.
 usage: unet_streams_graph.py [n_cases] [precision] [size]"""
 import sys, time
 import numpy as np

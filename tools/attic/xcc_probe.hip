@@ -1,4 +1,4 @@
-// Which XCD does workgroup i of a launch run on?  (HW_REG_XCC_ID, gfx950.)  hipcc --offload-arch=gfx950 tools/xcc_probe.hip -o xcc_probe
+// Which XCD does workgroup i of a launch run on?  (HW_REG_XCC_ID, gfx950.)  hipcc --offload-arch=gfx950 tools/attic/xcc_probe.hip -o xcc_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

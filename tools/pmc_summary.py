@@ -1,5 +1,5 @@
 """Condense the rocprofv3 outputs of tools/prof_full.sh TAG into the files kept under profiles/:
-profiles/<TAG>_kernel_stats.csv, <TAG>_bench.json.log, <TAG>_pmc_summary.csv, pmc_encode.json.
+profiles/<TAG>_kernel_stats.csv, <TAG>_kernel_quantiles.csv, <TAG>_bench.json.log, <TAG>_pmc_summary.csv, <TAG>_pmc.json (what bench.py reads for roofline.traffic).
 HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (KB counters; FETCH doubled per the gfx950 note in
 MI355X_MICROARCH.md's HBM section for 16-B/lane coalesced streams)."""
 import csv, glob, json, os, shutil, sys
@@ -40,12 +40,6 @@ def _short(k):
 json.dump({"workload": "config1", "kernel_source_hash": _bench.kernel_source_hash(), "profile_tag": tag,
            "unit": "HBM-side bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024; separate --pmc passes with --kernel-trace only",
            "kernels": {_short(r[0]): r[3] for r in rows}}, open(_bench.PMC_FILE, "w"), indent=1)
-enc = [r for r in rows if "psm_encode" in r[0]][0]          # psm_encode_kernel / psm_encode_pair_kernel: the single-case encode of this run
-json.dump({"kernel": enc[0], "FETCH_SIZE_KB": enc[1], "WRITE_SIZE_KB": enc[2],
-           "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B for 16-B/lane coalesced streams -> doubled (MI355X_MICROARCH.md HBM section); WRITE_SIZE exact",
-           "hbm_bytes_per_launch": enc[3],
-           "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline (second pass with --pmc WRITE_SIZE)",
-           "profile_tag": tag, "all_kernels": allk}, open("profiles/pmc_encode.json", "w"), indent=1)
 st = sorted(glob.glob(f"{O}/stats/*/*kernel_stats.csv"))[-1]
 shutil.copy(st, f"profiles/{tag}_kernel_stats.csv")
 # per-kernel median / p10 / p90 from the same trace (bench.py's roofline uses medians; --stats reports means)

@@ -22,5 +22,5 @@ export PSM_BENCH_LOGDIR=$O/detail_unet8_bf16; timeout -k 10 300 python bench.py 
 python tools/pmc_summary.py $TAG
 # the box returns gpurun_out/ only (<= 64 MiB): the condensed files go there, the raw traces are dropped
 mkdir -p $R/gpurun_out/profiles_$TAG
-cp $R/profiles/${TAG}_* $R/profiles/pmc_encode.json $R/gpurun_out/profiles_$TAG/ 2>/dev/null
+cp $R/profiles/${TAG}_* $R/gpurun_out/profiles_$TAG/ 2>/dev/null
 rm -rf $O/stats $O/fetch $O/write $O/unet_stats
