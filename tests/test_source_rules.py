@@ -45,7 +45,8 @@ def test_product_and_bench_timed_region_do_not_import_the_oracle():
         if f.endswith(".py"):
             text = open(os.path.join(PKG, f)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
-    for f in sorted(os.listdir(os.path.join(ROOT, "tools"))):
-        if f.endswith((".py", ".sh")):
-            text = open(os.path.join(ROOT, "tools", f)).read()
-            assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f"tools/{f}: oracle users live under tests/measure"
+    for sub in ("tools", os.path.join("tools", "attic")):
+        for f in sorted(os.listdir(os.path.join(ROOT, sub))):
+            if f.endswith((".py", ".sh")):
+                text = open(os.path.join(ROOT, sub, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f"{sub}/{f}: oracle users live under tests/measure"
