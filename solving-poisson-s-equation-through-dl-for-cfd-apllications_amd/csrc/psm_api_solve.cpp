@@ -254,6 +254,11 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
     ba.blk_y0x0 = h->d_blk; ba.shiftW = h->d_shiftW;
     for (int f = 0; f < 2; ++f) ba.shiftL[f] = (int)h->plan.shiftA[f].size();
     ba.fields = d_fields; ba.offs = w.d_offs; ba.shift = w.d_shift; ba.Nx = h->Nx; ba.n_strips = h->n_strips; ba.B = h->B;
+    {
+      static const bool bufst = !(getenv("PSM_PASTE_BUFFER_STORES") && atoi(getenv("PSM_PASTE_BUFFER_STORES")) == 0);
+      const int64_t fb = (int64_t)n_cases * h->Ny * h->Nx * h->cfg.c_out * (int64_t)sizeof(float);
+      ba.field_bytes = (bufst && fb < ((int64_t)1 << 32)) ? (uint32_t)fb : 0u;
+    }
     ba.gflags = gflags; ba.n_gwaves = n_gwaves;
     ba.cf = use_cf ? 1 : 0; ba.cf_dots = w.d_dots2; ba.cf_a0 = h->d_cfa0;
     if (h->bound_zero_fill)                    // cells no block covers stay 0 like the reference's np.zeros field
@@ -278,6 +283,7 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
     bb.blk_y0x0 = h->d_blk; bb.shiftW = h->d_shiftW;
     for (int f = 0; f < 2; ++f) bb.shiftL[f] = (int)h->plan.shiftA[f].size();
     bb.fields = d_fields; bb.offs = w.d_offs; bb.shift = w.d_shift; bb.Nx = h->Nx; bb.npix = h->Ny * h->Nx;
+    bb.field_bytes = ba.field_bytes;
     bb.n_strips = h->n_strips; bb.B = h->B; bb.rows_pc = h->bound_rows; bb.n_cases = n_cases;
     bb.gflags = gflags; bb.n_gwaves = n_gwaves;
     bb.cf = use_cf ? 1 : 0; bb.cf_dots = w.d_dots2; bb.cf_a0 = h->d_cfa0;

@@ -195,6 +195,8 @@ struct PsmBoundArgs {
   int Nx, n_strips, B;
   const float* gflags; int n_gwaves;   // guard flags of this solve (0 / NaN), summed into the shift; never null (>= 1 entry)
   const float* cf_dots; const float* cf_a0; int cf;   // closed form of the chain (see PsmBoundBatchArgs): [C][B] each
+  uint32_t field_bytes;                // size of `fields` in bytes when it is below 4 GiB (else 0): the paste then stores through a buffer
+                                       // descriptor and switches a lane off by an out-of-range offset instead of a branch per value
 };
 struct PsmBoundBatchArgs {             // case batches: chain in its own small launch, then decode + paste
   PsmChainParams cp; const PsmBlock* blocks;
@@ -212,6 +214,7 @@ struct PsmBoundBatchArgs {             // case batches: chain in its own small l
   // long dot per (field, block): cf_dots [cases][C][B].  The value subtracted from block b is cf_a0[case][f][b] + cf_dots
   // -- no chain launch between the head and this one, no chain waves in the single-case kernel.
   const float* cf_dots; const float* cf_a0; int cf;
+  uint32_t field_bytes;                          // as in PsmBoundArgs
 };
 struct PsmPairFoldArgs {               // bind time: pair rows as linear combinations of the strip / shift rows
   const int32_t* ptr; const int32_t* src; const float* coef;    // CSR over the pair rows

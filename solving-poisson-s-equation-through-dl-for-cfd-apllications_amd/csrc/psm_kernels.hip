@@ -44,6 +44,16 @@ hipError_t psm_read_stamps(unsigned long long* out) { for (int i = 0; i < 64; ++
 
 __device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
+// Predicated 4-byte store without a branch: through a raw buffer descriptor over the whole destination, a lane that must not write
+// gets the offset 0xffffffff, which the hardware's range check drops (round 6: the paste epilogues were sixteen s_and_saveexec /
+// branch / 64-bit address / store sequences per row chunk -- half the instructions of a chunk of the batch decode).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t psm_store_rsrc(float* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void psm_store_if(__amdgpu_buffer_rsrc_t r, uint32_t elem, bool on, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, on ? elem * 4u : 0xffffffffu, 0, 0);
+}
+
 // streamed-once operands (PCA bases): -DPSM_NT_STREAM selects non-temporal loads (so that the 42 MB of basis data per
 // solve do not displace the small tables and dense weights from the L2s).  Measured on MI355X: SLOWER, 44.1 vs
 // 41.9 us per solve -- back-to-back solves re-read the bases from L2 / Infinity Cache, which nt gives up.  Off.
@@ -2706,13 +2716,19 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
       rb4[rg] = *reinterpret_cast<const v4f*>(rec + mc * 8 + 4);
       of[rg] = offs[f * B + mc];
     }
+    auto paste = [&](auto buffered) {
+      const __amdgpu_buffer_rsrc_t frs = psm_store_rsrc(p.fields, p.field_bytes);
 #pragma unroll
-    for (int rg = 0; rg < 16; ++rg) {
-      const int m = mt * 32 + acc_row(rg, h);
-      const uint32_t word = __float_as_uint(rb4[rg][pxl >> 5]);
-      const bool mine = m < B && ((word >> (pxl & 31)) & 1u);
-      if (mine) p.fields[(size_t)(__float_as_uint(ra[rg][0]) + pix_off)] = (acc[mt][rg] + mu_r) * ra[rg][2] - of[rg] - sh;
-    }
+      for (int rg = 0; rg < 16; ++rg) {
+        const int m = mt * 32 + acc_row(rg, h);
+        const uint32_t word = __float_as_uint(rb4[rg][pxl >> 5]);
+        const bool mine = m < B && ((word >> (pxl & 31)) & 1u);
+        const float val = (acc[mt][rg] + mu_r) * ra[rg][2] - of[rg] - sh;
+        if constexpr (decltype(buffered)::value) psm_store_if(frs, __float_as_uint(ra[rg][0]) + pix_off, mine, val);
+        else if (mine) p.fields[(size_t)(__float_as_uint(ra[rg][0]) + pix_off)] = val;
+      }
+    };
+    if (p.field_bytes) paste(std::true_type{}); else paste(std::false_type{});        // uniform
   }
   PSM_STAMP(0, 23);
 }
@@ -2969,17 +2985,23 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
       }
     }
     if (live) {
+      const __amdgpu_buffer_rsrc_t frs = psm_store_rsrc(p.fields, p.field_bytes);
       const float gsum = (lg[0] + lg[1]) + (lg[2] + lg[3]);            // written before the barrier above
+      auto paste = [&](auto buffered) {
 #pragma unroll
-      for (int mt = 0; mt < MTC; ++mt) {
+        for (int mt = 0; mt < MTC; ++mt) {
 #pragma unroll
-        for (int rg = 0; rg < 16; ++rg) {
-          const int rr = mt * 32 + acc_row(rg, h);
-          const float4 ro4 = lrow[rr];
-          if (lown[rr * WPB + own_w] & own_bit)
-            p.fields[(size_t)(__float_as_uint(ro4.w) + pix_off)] = (acc[mt][rg] + mu_r) * ro4.x - (C == 2 && f ? ro4.z : ro4.y) - gsum;
+          for (int rg = 0; rg < 16; ++rg) {
+            const int rr = mt * 32 + acc_row(rg, h);
+            const float4 ro4 = lrow[rr];
+            const bool mine = (lown[rr * WPB + own_w] & own_bit) != 0u;
+            const float val = (acc[mt][rg] + mu_r) * ro4.x - (C == 2 && f ? ro4.z : ro4.y) - gsum;
+            if constexpr (decltype(buffered)::value) psm_store_if(frs, __float_as_uint(ro4.w) + pix_off, mine, val);
+            else if (mine) p.fields[(size_t)(__float_as_uint(ro4.w) + pix_off)] = val;
+          }
         }
-      }
+      };
+      if (p.field_bytes) paste(std::true_type{}); else paste(std::false_type{});      // uniform
     }
   }
 }
