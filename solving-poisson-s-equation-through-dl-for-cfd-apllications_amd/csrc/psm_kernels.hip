@@ -2810,6 +2810,12 @@ hipError_t psm_launch_chain_dots(const PsmBoundBatchArgs& p, int c_out, hipStrea
 template <int MTC, int C, int LDR, int MODE>           // MODE 0: exact-f32 MFMA, 1: bf16 handle (operands rounded), 2: x6 (float32 accuracy on the bf16 pipe)
 __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeArgs a, PsmBoundBatchArgs p, int m_end) {
   psm_warm_kernargs<sizeof(PsmDecodeArgs) + sizeof(PsmBoundBatchArgs)>();
+#ifdef PSM_STAMPS
+#define DSTAMP(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && (k) < 40) g_psm_stamps[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define DSTAMP(k) do { } while (0)
+#endif
+  DSTAMP(0);
   constexpr bool BF = MODE == 1, X6 = MODE == 2;
   constexpr int LDX = LDR + 4;                         // x6: plane row stride in bf16 (LDR / 2 + 2 dwords = 2 * odd: ds_read_b64 conflict-free)
   constexpr int LDA = X6 ? 3 * LDX / 2 : (BF ? (LDR + 8) / 2 : LDR + 4);    // tile floats per row (bf16: LDR + 8 halves; x6: three planes)
@@ -2912,8 +2918,11 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
   const float mu_r = psm_settled(mu);                  // (64 cases: 4.6 us per chunk for 0.6 us of MFMAs before this)
   // Row chunks.  The NEXT chunk's activation tile and row operands are requested as soon as the current tile sits in LDS and
   // land during its MFMAs and stores (they were a full exposed round trip per chunk: 64 cases are 4-5 chunks per workgroup).
-  for (int m_base = m_first; m_base < m_end; m_base += m_step) {
+  DSTAMP(1);
+  int dchunk = 0;
+  for (int m_base = m_first; m_base < m_end; m_base += m_step, ++dchunk) {
     if (m_base != m_first) __syncthreads();            // every wave is done with the previous chunk's tile and row operands
+    DSTAMP(2 + 5 * dchunk);
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
       const int idx = tid + 256 * u, row = idx / Q, q = idx - row * Q;
@@ -2939,12 +2948,14 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
       for (int w = 0; w < WPB; ++w) lown[tid * WPB + w] = ro.in ? ro.own[w] : 0u;
     }
     __syncthreads();
+    DSTAMP(3 + 5 * dchunk);
     if (m_base + m_step < m_end) {                     // uniform
       load_tile(x, m_base + m_step);
       load_rows(ro, m_base + m_step);
       load_sub(ro);
     }
     __builtin_amdgcn_sched_barrier(0);
+    DSTAMP(4 + 5 * dchunk);
     f32x16 acc[MTC];
 #pragma unroll
     for (int mt = 0; mt < MTC; ++mt) {
@@ -2984,6 +2995,7 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
         }
       }
     }
+    DSTAMP(5 + 5 * dchunk);
     if (live) {
       const __amdgpu_buffer_rsrc_t frs = psm_store_rsrc(p.fields, p.field_bytes);
       const float gsum = (lg[0] + lg[1]) + (lg[2] + lg[3]);            // written before the barrier above
@@ -3003,6 +3015,7 @@ __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeAr
       };
       if (p.field_bytes) paste(std::true_type{}); else paste(std::false_type{});      // uniform
     }
+    DSTAMP(6 + 5 * dchunk);
   }
 }
 
