@@ -3,7 +3,7 @@
 import os, subprocess, sys, time
 if len(sys.argv) > 1:
     import numpy as np
-    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     sys.path.insert(0, ROOT)
     from psm_amd import SolverModule, synthetic
     Lx, Ly = float(sys.argv[1]), float(sys.argv[2])

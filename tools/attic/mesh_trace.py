@@ -1,7 +1,7 @@
 """psm_solve with registered buffers, 300 calls (for rocprofv3 --kernel-trace --memory-copy-trace)."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import cases
 from psm_amd import SolverModule

@@ -2,7 +2,7 @@
     rocprofv3 --kernel-trace --stats -- python3 tools/attic/shipped_trace.py"""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import cases
 from psm_amd import SolverModule, synthetic
