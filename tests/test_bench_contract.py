@@ -236,7 +236,8 @@ def test_default_bench_line():
     cbat = d["case_batch"]
     assert cbat["cases_per_step_per_gpu"] == 8 and cbat["value"] > 1000 and cbat["total_cases"] == 8 and cbat["guard_trips"] == 0
     assert cbat["bound"] in ("mfma", "hbm") and 0 < cbat["frac"] < 1 and cbat["l2_vs_oracle"] < 1e-5
-    assert set(d["legs"]) == {"config2", "config4", "unet", "unet8", "unet8_bf16", "unet512_bf16"}
+    assert set(d["legs"]) == {"config2", "config4", "unet", "unet8", "unet8_bf16", "unet512_bf16", "unet64_bf16"}
+    assert full["legs"]["unet64_bf16"]["cases_per_step_per_gpu"] == 64 and full["legs"]["config4"]["roofline"]["frac"] > 0.05   # (config4: a byte-carrying launch, not a 0.26 MB layer)
     for name, leg in d["legs"].items():
         assert leg["ms_per_step"] > 0 and leg["value"] > 100 and leg["l2_vs_oracle"] < (2e-2 if leg["dtype"] == "bf16" else 1e-5), name
         assert leg["bound"] in ("mfma", "hbm") and 0 < leg["frac"] < 1 and 0 < leg["frac_pass"] < 1, name
