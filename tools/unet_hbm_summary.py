@@ -48,11 +48,14 @@ except Exception:
 if d.get("unet_source_hash") != _bench.unet_source_hash():
     d = {"unet_source_hash": _bench.unet_source_hash(), "profile_tag": tag,
          "unit": "HBM-side bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024; separate --pmc passes with --kernel-trace only", "workloads": {}}
-w = {}
+w, wn = {}, {}
 for k in fetch:
     kk = _key(k[0], k[1])
-    if kk and k in dur:
+    # several instantiations can share a key (the plan-time autotuner tries other splits / buffer counts on the same grid): the one
+    # with the most launches is the planned layer
+    if kk and k in dur and dur[k][1] > wn.get(kk, 0):
         w[kk] = (2 * fetch[k] + write.get(k, 0.0)) * 1024.0
+        wn[kk] = dur[k][1]
 d["workloads"][wl] = w
 json.dump(d, open(pj, "w"), indent=1)
 print("wrote", pj, len(w), "launch keys for", wl)
