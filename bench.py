@@ -314,7 +314,9 @@ def committed_traffic(kernel, workload):
         d = json.load(open(f))
     except Exception:
         return None, None
-    if d.get("workload") != workload or d.get("kernel_source_hash") != kernel_source_hash():
+    if d.get("workload") != workload:
+        return None, None                                   # the committed counter passes are of the headline workload only
+    if d.get("kernel_source_hash") != kernel_source_hash():
         return None, PMC_FILE + " is from other kernel sources: not used"
     v = d.get("kernels", {}).get(kernel.split("#layer")[0])          # rocprofv3 names the symbol, not the layer
     return (v, PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2*FETCH + WRITE KiB, gfx950 correction)") if v else (None, None)
@@ -478,7 +480,7 @@ def _compact_roofline(r):
     out = {k: _sig(r.get(k)) for k in keep}
     out["kernel"] = _clip(out["kernel"], 100)
     if r.get("traffic_source"):
-        out["traffic_source"] = _clip(r["traffic_source"], 64)
+        out["traffic_source"] = _clip(r["traffic_source"], 48)
     return out
 
 

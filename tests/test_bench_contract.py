@@ -58,7 +58,7 @@ def test_line_built_from_a_recorded_run_fits_the_driver():
     assert "configs[1]" in d["config"]["workload"] and d["dtype"] == "f32" and d["detail"] == "bench_detail.json"
     assert all(len(v) <= 160 for v in d["config"].values() if isinstance(v, str)) and len(d["cpu_baseline"]["sample"]) <= 120
     assert set(d["roofline"]) - {"traffic_source"} == {"kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "avg_launch_us"}
-    assert len(d["roofline"].get("traffic_source", "")) <= 64           # round 6: where `traffic` comes from stays on the line, shortened
+    assert len(d["roofline"].get("traffic_source", "")) <= 48           # round 6: where `traffic` comes from stays on the line, shortened
     assert set(d["legs"]) == set(detail["legs"])
     for leg in list(d["legs"].values()) + [d["case_batch"]]:
         assert {"value", "ms_per_step", "dtype", "l2_vs_oracle", "bound", "frac", "cpu"} <= set(leg)
