@@ -9,6 +9,7 @@
 // MFMA operand maps (wave64, 32x32x16): lane l (r = l&31, h = l>>5) holds A[r][8h+j] and
 // B[8h+j][r], j = 0..7 (one 16-byte register group each); D as for the f32 32x32 form.
 #include "psm_kernels.h"
+#include "psm_devutil.h"
 
 #include <hip/hip_ext.h>
 
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void psm_encode_bf16_kernel(PsmEncodeArgs a) {
   auto load_rows = [&](v4f (&x)[8], int m0, int row0) {
     int64_t rb[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) rb[u] = a.row_base[min(m0 + row0 + wave + 4 * u, a.M - 1)];
+    for (int u = 0; u < 8; ++u) rb[u] = psm_row_base(a.row_base, min(m0 + row0 + wave + 4 * u, a.M - 1));
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const float* src = a.grid + rb[u] + src_off + 4 * ql;

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void psm_encode_kernel(PsmEncodeArgs a) {
   auto load_rows = [&](float4 (&x)[8], int m0, int row0) {    // rows row0 + wave + 4u (u < 8) of chunk m0
     int64_t rb[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) rb[u] = a.row_base[min(m0 + row0 + wave + 4 * u, a.M - 1)];   // wave-uniform: scalar loads
+    for (int u = 0; u < 8; ++u) rb[u] = psm_row_base(a.row_base, min(m0 + row0 + wave + 4 * u, a.M - 1));   // wave-uniform: scalar loads
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const float* src = a.grid + rb[u] + src_off + 4 * ql;
@@ -323,26 +323,33 @@ __global__ __launch_bounds__(256) void psm_encode_pair_kernel(PsmEncodeArgs a) {
   const int i = lane & 31, h = lane >> 5;
   const int ql = lane < Q ? lane : Q - 1;       // lanes >= Q idle in the staging (C_IN < 4)
   const float4 mu = *reinterpret_cast<const float4*>(a.mean + (int64_t)s * KS + 4 * ql);
+  // Request order (round 6): the block-row offsets are a dependent table lookup in front of the activation rows.  They are
+  // wave-uniform, so they come through the scalar cache (address space 4: s_load_dwordx2, its own counter) instead of sixteen
+  // wave-wide vector loads, and the FIRST HALF of the basis stream is requested before anything waits for them: the lookup's round
+  // trip hides behind it.  Then the rows, then the second half of the stream; the staging below waits for the rows (and, the counter
+  // being in order, the first half of the stream, which was requested earlier anyway), the MFMAs of k group g for groups <= g.
+  float4 b[G];
+  const float4* bp = a.bpack + (((int64_t)s * NT + t) * G) * 64 + lane;
+  int64_t rb[16];
+  {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) rb[u] = psm_row_base(a.row_base, min(j + 2 * u, a.M - 1));              // wave-uniform
+  }
+  __builtin_amdgcn_sched_barrier(0);             // (the scheduler sinks the scalar loads behind the stream's first half otherwise)
+#pragma unroll
+  for (int g = 0; g < G / 2; ++g) b[g] = stream_load(bp + g * 64);
+  __builtin_amdgcn_sched_barrier(0);
   // staging: the two waves of a slice take its even / odd rows (16 each); every request before any use
   float4 x[16];
-  {
-    int64_t rb[16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) rb[u] = a.row_base[min(j + 2 * u, a.M - 1)];                       // wave-uniform
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const float* src = a.grid + rb[u] + src_off + 4 * ql;
-      if (ALIGNED) x[u] = *reinterpret_cast<const float4*>(src);
-      else x[u] = make_float4(src[0], src[1], src[2], src[3]);
-    }
+  for (int u = 0; u < 16; ++u) {
+    const float* src = a.grid + rb[u] + src_off + 4 * ql;
+    if (ALIGNED) x[u] = *reinterpret_cast<const float4*>(src);
+    else x[u] = make_float4(src[0], src[1], src[2], src[3]);
   }
   __builtin_amdgcn_sched_barrier(0);
-  float4 b[G];
-  {
-    const float4* p = a.bpack + (((int64_t)s * NT + t) * G) * 64 + lane;
 #pragma unroll
-    for (int g = 0; g < G; ++g) b[g] = stream_load(p + g * 64);
-  }
+  for (int g = G / 2; g < G; ++g) b[g] = stream_load(bp + g * 64);
   __builtin_amdgcn_sched_barrier(0);
   float* tile = lds + sl * 32 * LDA;
 #pragma unroll
@@ -433,7 +440,7 @@ __global__ __launch_bounds__(256) void psm_encode_x6_kernel(PsmEncodeArgs a) {
   auto load_rows = [&](float4 (&x)[8], int m0, int row0) {
     int64_t rb[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) rb[u] = a.row_base[min(m0 + row0 + wave + 4 * u, a.M - 1)];
+    for (int u = 0; u < 8; ++u) rb[u] = psm_row_base(a.row_base, min(m0 + row0 + wave + 4 * u, a.M - 1));
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const float* src = a.grid + rb[u] + src_off + 4 * ql;
