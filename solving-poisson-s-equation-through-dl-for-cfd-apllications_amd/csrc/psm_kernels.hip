@@ -2551,6 +2551,14 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
   const int ct = min((int)blockIdx.x * 4 + min(wave, 3), a.n_coltiles - 1);
   const bool live = dec && ((int)blockIdx.x * 4 + wave) < a.n_coltiles;
   PSM_STAMP(0, 20);
+  // The FIRST HALF of the basis stream is requested before anything else (round 6): its addresses need nothing but the column tile,
+  // while the small operands below cost ~250 instructions of address arithmetic and branches before the stream could start.  They
+  // return behind that half (the counter is in order), which is still well before the second half has landed.
+  float4 b[GD];                                        // bf16: 8 halves per 16-byte piece
+  const float4* bp = a.bpack + ((int64_t)ct * GD) * 64 + lane;
+#pragma unroll
+  for (int g = 0; g < GD / 2; ++g) b[g] = stream_load(bp + g * 64);
+  __builtin_amdgcn_sched_barrier(0);
   // ---- every load of the prologue, clamped and unconditional
   const int n_stage = p.cf ? 1 : C * nst + nst;
   float sv[NST];
@@ -2588,10 +2596,8 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
     x[u] = *reinterpret_cast<const v4f*>(a.res + (int64_t)min(row, a.Mpad - 1) * LDR + 4 * q);
   }
   __builtin_amdgcn_sched_barrier(0);
-  float4 b[GD];                                        // bf16: 8 halves per 16-byte piece
-  const float4* bp = a.bpack + ((int64_t)ct * GD) * 64 + lane;
 #pragma unroll
-  for (int g = 0; g < GD; ++g) b[g] = stream_load(bp + g * 64);
+  for (int g = GD / 2; g < GD; ++g) b[g] = stream_load(bp + g * 64);
   const int col = ct * 32 + i;
   const float mu = a.mean[col];
   __builtin_amdgcn_sched_barrier(0);
