@@ -809,12 +809,15 @@ def pca_roofline(sur, model, ny, nx, n_cases, precision, d_grid, d_fields, steps
                     decode=ab["decode"] + (n_cases - 1) * 4 * ny * nx * model.c_out)       # bases read once, fields per case
     af = algorithmic_flops(model, n_cases * sur.B)
     if kt is None:
-        kt = time_kernels(sur, d_grid, n_cases, d_fields, steps)
-    per_solve = {nm: n / steps for nm, _, n in kt}
+        kt = time_kernels(sur, d_grid, n_cases, d_fields, steps, quantiles=True)
+    per_solve = {rec[0]: rec[2] / steps for rec in kt}
     kernels = []
-    for nm, us, n in kt:
+    for rec in kt:
+        nm, us, n = rec[:3]
+        q10, q90 = rec[3] if len(rec) > 3 else (None, None)
         b, f = kernel_algorithmic(nm, ab_batch, per_solve[nm]), kernel_algorithmic(nm, af, per_solve[nm])
-        kernels.append({"name": nm, "avg_us": us, "launches_per_solve": per_solve[nm], "algorithmic_bytes": b, "algorithmic_flops": f,
+        kernels.append({"name": nm, "avg_us": us, "p10_us": q10, "p90_us": q90,      # avg_us = MEDIAN of this run's dispatch stamps (name kept from round 3)
+                        "launches_per_solve": per_solve[nm], "algorithmic_bytes": b, "algorithmic_flops": f,
                         "peak_TFLOPs": kernel_peak_tflops(nm, precision),      # the pipe THIS launch runs on (x6: bf16 peak / 6)
                         "achieved_GBs": (b / (us * 1e-6) / 1e9) if b else None,
                         "achieved_TFLOPs": (f / (us * 1e-6) / 1e12) if f else None})
@@ -1099,8 +1102,8 @@ def main():
     # steps and K timed steps: it is not part of either, and it leaves clocks, caches and the runtime's kernel objects warm, so
     # that a short driver run (K = 20) measures the same steady state as the default K = 2000.
     kt_steps = max(args.steps, 200)
-    kt_head = time_kernels(sur, d_in[0].data_ptr(), NC, d_out[0].data_ptr(), kt_steps)
-    kt_head = [(nm, us, n * args.steps // kt_steps) for nm, us, n in kt_head]      # launches per `steps` solves, as pca_roofline counts them
+    kt_head = time_kernels(sur, d_in[0].data_ptr(), NC, d_out[0].data_ptr(), kt_steps, quantiles=True)
+    kt_head = [(nm, us, n * args.steps // kt_steps, q) for nm, us, n, q in kt_head]    # launches per `steps` solves, as pca_roofline counts them
     torch.cuda.synchronize()
 
     dt_max = pdist.timed_region(step, args.steps, args.warmup, torch.cuda.synchronize, red_dev)
