@@ -17,7 +17,8 @@
 // (test_case/log.DL:34-42: SIGSEGV inside PyObject_GetAttrString); the reference counts the shim's persistent arrays are
 // printed so the test can see that nothing accumulates.
 //
-// usage: embed_host serial|parallel STEPS cells.f64 top.f64 obst.f64 out.f64      (run from the case directory)
+// usage: embed_host serial|parallel STEPS cells.f64 top.f64 obst.f64 out.f64 [RANK]      (run from the case directory; RANK = what
+//        Pstream::myProcNo() would return in this solver process, default 0)
 #define NPY_NO_DEPRECATED_API NPY_1_7_API_VERSION
 #include <Python.h>
 #include <numpy/arrayobject.h>
@@ -78,7 +79,7 @@ static int run(int argc, char** argv) {
   Py_DECREF(pModule);                                              // :21
   if (!py_func || !init_func) { PyErr_Print(); std::fprintf(stderr, "embed_host: python_module lacks py_func / init_func\n"); return 3; }
 
-  PyObject* rank_val = PyLong_FromLong(0);                         // :28 (Pstream::myProcNo() of the only rank)
+  PyObject* rank_val = PyLong_FromLong(argc > 7 ? std::atol(argv[7]) : 0);   // :28 (Pstream::myProcNo())
 
   long n_cells = 0, n_top = 0, n_obst = 0;
   std::vector<double> cells0 = read_f64(argv[3], 5, &n_cells), top0 = read_f64(argv[4], 2, &n_top), obst0 = read_f64(argv[5], 2, &n_obst);

@@ -52,11 +52,18 @@ def _write_mesh(d, array, top, obst):
         np.ascontiguousarray(a, "<f8").tofile(os.path.join(d, name))
 
 
-def _run(host, d, mode, steps=STEPS, env=None):
+def _cmd(host, mode, steps, tag="", rank=None):
+    return [host, mode, str(steps), f"cells{tag}.f64", f"top{tag}.f64", f"obst{tag}.f64", f"out{tag}.f64"] + ([str(rank)] if rank is not None else [])
+
+
+def _env(env=None):
     e = dict(os.environ, **(env or {}))
     e.pop("PYTHONPATH", None)                  # the solver's environment: only "." is appended (PythonComm_init.H:5)
-    r = subprocess.run([host, mode, str(steps), "cells.f64", "top.f64", "obst.f64", "out.f64"], cwd=d, env=e, capture_output=True, text=True, timeout=600)
-    return r
+    return e
+
+
+def _run(host, d, mode, steps=STEPS, env=None):
+    return subprocess.run(_cmd(host, mode, steps), cwd=d, env=_env(env), capture_output=True, text=True, timeout=600)
 
 
 def _refcounts(stdout):
@@ -169,3 +176,92 @@ def test_embedded_solver_sequence_equals_solver_module(host, case_dir, mode, pin
     else:
         assert a["pin_array"] == b["pin_array"] == -1 and a["pin_out"] == b["pin_out"] == -1
     assert a["cat_buf"] == b["cat_buf"] == -1                       # the gather buffer exists only with more than one rank
+
+
+# A process-level stand-in for mpi4py (not installable here): object-mode gather / scatter of COMM_WORLD over a Unix socket, rank and
+# size from the environment -- what `mpirun -np N DLPoissonFoam -parallel` gives every solver process.  Written into the case
+# directory, where the solver's sys.path.append(".") finds it.
+FAKE_MPI_INIT = "import types\nrc = types.SimpleNamespace(initialize=True, finalize=True)\n"
+FAKE_MPI = '''
+import os, time
+from multiprocessing.connection import Listener, Client
+_rank, _size, _addr = int(os.environ["FAKE_MPI_RANK"]), int(os.environ["FAKE_MPI_SIZE"]), os.environ["FAKE_MPI_ADDR"]
+def Is_initialized():
+    return True
+class _Comm:
+    def __init__(self):
+        if _rank == 0:
+            self.listener = Listener(_addr, family="AF_UNIX")
+            self.conns = {}
+            for _ in range(_size - 1):
+                c = self.listener.accept()
+                self.conns[c.recv()] = c
+        else:
+            for _ in range(1200):
+                try:
+                    self.c = Client(_addr, family="AF_UNIX")
+                    break
+                except (FileNotFoundError, ConnectionRefusedError):
+                    time.sleep(0.1)
+            self.c.send(_rank)
+    def Get_rank(self):
+        return _rank
+    def Get_size(self):
+        return _size
+    def gather(self, obj, root=0):
+        if _rank == 0:
+            return [obj] + [self.conns[r].recv() for r in range(1, _size)]
+        self.c.send(obj)
+        return None
+    def scatter(self, objs, root=0):
+        if _rank == 0:
+            for r in range(1, _size):
+                self.conns[r].send(objs[r])
+            return objs[0]
+        return self.c.recv()
+COMM_WORLD = _Comm()
+'''
+
+
+@needs_embed
+@pytest.mark.gpu
+def test_three_embedded_solver_processes_funnel_to_rank_0(host, case_dir):  # noqa: F811
+    """The parallel solver as it is deployed: N solver processes, each with its own embedded interpreter, python_module's gather to
+    rank 0 / solve / scatter (python_module.py:179-191, 258-264, 501-511).  Three embed_host processes own an uneven split of the
+    cells (rank 2 has no boundary faces), only rank 0 touches the GPU; every rank's pressures over 20 steps must be its slice of the
+    one-process result, bit for bit."""
+    from psm_amd import SolverModule
+    array, top, obst, model, maxs = case_dir
+    d = os.getcwd()
+    shutil.copy(SHIM, os.path.join(d, "python_module.py"))
+    os.makedirs(os.path.join(d, "mpi4py"))
+    open(os.path.join(d, "mpi4py", "__init__.py"), "w").write(FAKE_MPI_INIT)
+    open(os.path.join(d, "mpi4py", "MPI.py"), "w").write(FAKE_MPI)
+    n = array.shape[0]
+    cuts = [0, n // 2 + 17, n - n // 5, n]                               # uneven three-way decomposition
+    tcut = [0, top.shape[0] // 3, top.shape[0], top.shape[0]]            # rank 2: no top faces ...
+    ocut = [0, obst.shape[0], obst.shape[0], obst.shape[0]]              # ... ranks 1, 2: no obstacle faces
+    for r in range(3):
+        for name, a, c in (("cells", array, cuts), ("top", top, tcut), ("obst", obst, ocut)):
+            np.ascontiguousarray(a[c[r]:c[r + 1]], "<f8").tofile(os.path.join(d, f"{name}_r{r}.f64"))
+    steps = 20
+    sock = os.path.join(d, "fake_mpi.sock")
+    procs = []
+    for r in range(3):
+        env = _env({"PSM_AMD_HOME": ROOT, "FAKE_MPI_RANK": str(r), "FAKE_MPI_SIZE": "3", "FAKE_MPI_ADDR": sock})
+        procs.append(subprocess.Popen(_cmd(host, "parallel", steps, tag=f"_r{r}", rank=r), cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    try:
+        for pr in procs:
+            outs.append(pr.communicate(timeout=600))
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    for r, (pr, (so, se)) in enumerate(zip(procs, outs)):
+        assert pr.returncode == 0 and "Traceback" not in se, (r, so[-800:], se[-3000:])
+    got = np.concatenate([np.fromfile(os.path.join(d, f"out_r{r}.f64"), "<f8").reshape(steps, -1) for r in range(3)], axis=1)
+    ref_mod = SolverModule(model, maxs)
+    ref_mod.init_func(array, top, obst)
+    ref = _replay(ref_mod.py_func, array, steps)
+    np.testing.assert_array_equal(got, ref)
