@@ -236,6 +236,8 @@ def test_default_bench_line():
     cbat = d["case_batch"]
     assert cbat["cases_per_step_per_gpu"] == 8 and cbat["value"] > 1000 and cbat["total_cases"] == 8 and cbat["guard_trips"] == 0
     assert cbat["bound"] in ("mfma", "hbm") and 0 < cbat["frac"] < 1 and cbat["l2_vs_oracle"] < 1e-5
+    cs = full["case_streams"]                                 # four independent batch-1 streams on the card (never the headline)
+    assert cs["streams"] == 4 and cs["finite"] is True and cs["guard_trips"] == 0 and d["case_streams4"] > 0.8 * d["value"], cs
     assert set(d["legs"]) == {"config2", "config4", "unet", "unet8", "unet8_bf16", "unet512_bf16", "unet64_bf16"}
     assert full["legs"]["unet64_bf16"]["cases_per_step_per_gpu"] == 64 and full["legs"]["config4"]["roofline"]["frac"] > 0.05   # (config4: a byte-carrying launch, not a 0.26 MB layer)
     for name, leg in d["legs"].items():
