@@ -330,7 +330,11 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
   const int g_beg = split * cps, g_end = min(a.n_chunks, (split + 1) * cps);
 
   f32x4 xr[NF][NRAW], xb[NF], wr[NWF];
-  auto load_w_one = [&](int g, int u) { wr[u] = wsrc[(int64_t)g * WQ + min(tid + 256 * u, WQ - 1)]; };
+  // (uniform chunk base + this thread's piece, which is the same for every chunk: a scalar add and no vector address arithmetic per request)
+  unsigned wpiece[NWF];
+#pragma unroll
+  for (int u = 0; u < NWF; ++u) { wpiece[u] = (unsigned)min(tid + 256 * u, WQ - 1); asm volatile("" : "+v"(wpiece[u])); }
+  auto load_w_one = [&](int g, int u) { wr[u] = (wsrc + (int64_t)g * WQ)[wpiece[u]]; };
   auto store_w = [&](int buf) {
 #pragma unroll
     for (int u = 0; u < NWF; ++u) w_tile[buf * WQP + tid + 256 * u] = wr[u];
@@ -358,17 +362,20 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
       if constexpr (ABF) {                  // 8 bf16 channels per 16-byte load, element offsets in halves
         const unsigned short* h0 = reinterpret_cast<const unsigned short*>(a.in0) + (int64_t)cs * a.in0_case;
         const unsigned short* h1 = reinterpret_cast<const unsigned short*>(a.in1) + (int64_t)cs * a.in1_case;
+        // a wave-uniform base pointer + an unsigned 32-bit element offset per lane (offsets into a case's tensor are non-negative and
+        // below 2^31: act_layout): the scalar-base form of global_load, one or two vector instructions per request instead of a 64-bit chain
         if constexpr (SRCP == PSM_SRC_MAXPOOL) {
-          const unsigned short* p = h0 + fp[u].off0 + chc;
-          xr[u][0] = *reinterpret_cast<const f32x4*>(p);
-          xr[u][1] = *reinterpret_cast<const f32x4*>(p + a.c0);
-          xr[u][2] = *reinterpret_cast<const f32x4*>(p + a.P0 * a.c0);
-          xr[u][3] = *reinterpret_cast<const f32x4*>(p + a.P0 * a.c0 + a.c0);
+          const unsigned e = (unsigned)(fp[u].off0 + chc);
+          xr[u][0] = *reinterpret_cast<const f32x4*>(h0 + e);
+          xr[u][1] = *reinterpret_cast<const f32x4*>(h0 + (e + (unsigned)a.c0));
+          xr[u][2] = *reinterpret_cast<const f32x4*>(h0 + (e + (unsigned)(a.P0 * a.c0)));
+          xr[u][3] = *reinterpret_cast<const f32x4*>(h0 + (e + (unsigned)(a.P0 * a.c0 + a.c0)));
         } else if constexpr (SRCP == PSM_SRC_UPSAMPLE) {
-          const unsigned short* p = from0 ? h0 + fp[u].off0 + chc : h1 + fp[u].off1 + (chc - a.c0);
-          xr[u][0] = *reinterpret_cast<const f32x4*>(p);
+          const unsigned short* base = from0 ? h0 : h1;                                   // uniform
+          const unsigned e = (unsigned)(from0 ? fp[u].off0 + chc : fp[u].off1 + (chc - a.c0));
+          xr[u][0] = *reinterpret_cast<const f32x4*>(base + e);
         } else {
-          xr[u][0] = *reinterpret_cast<const f32x4*>(h0 + fp[u].off0 + chc);
+          xr[u][0] = *reinterpret_cast<const f32x4*>(h0 + (unsigned)(fp[u].off0 + chc));
         }
       }
       else if constexpr (SRC < 0) xr[u][0] = fetch4_stem(a, in0, y0 - 1 + rr, x0 - 1 + c, ch);
@@ -452,6 +459,18 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
     }
   };
 
+  // LDS slots of the activation operand reads: (WM + 2) tile rows x 3 tap columns, the same for every chunk and buffer (round 6).  hipcc
+  // recomputed the swizzled slot -- five vector instructions -- in front of each of a chunk's 9 WM reads, inside a matrix phase whose 36
+  // MFMAs the wave's own instruction stream, not the matrix pipe, paces (stamps: 0.60 us per chunk for 0.27 us of MFMA issue); the
+  // empty asm keeps the values in registers instead of rematerialising them.
+  int a_slot[WM + 2][3];
+#pragma unroll
+  for (int r = 0; r < WM + 2; ++r)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      a_slot[r][kx] = lds_slot((row_w + r) * (TW + 2) + px + kx, kq);
+      asm volatile("" : "+v"(a_slot[r][kx]));
+    }
   USTAMP(0);
   if (g_beg < g_end) {
 #pragma unroll
@@ -525,7 +544,7 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
       for (int m = 0; m < WM; ++m)
 #pragma unroll
         for (int p = 0; p < PL; ++p)
-          av[s][m][p] = *reinterpret_cast<const f32x4*>(&tile[p * TILE + lds_slot((row_w + m + ky) * (TW + 2) + px + kx, kq)]);
+          av[s][m][p] = *reinterpret_cast<const f32x4*>(&tile[p * TILE + a_slot[m + ky][kx]]);
 #pragma unroll
       for (int n = 0; n < WN; ++n)
 #pragma unroll
