@@ -480,12 +480,14 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   USTAMP(1);
-  int buf = 0;
+  // (the LDS buffer of a chunk is a COMPILE-TIME constant of its code copy -- the chunk loop is unrolled by two -- so that every LDS read and
+  // write of the matrix phase is a register slot + an immediate offset: with a run-time buffer index each read cost a vector add; round 6)
   // one chunk; MORE (compile time): the next chunk's requests are issued among the taps and stored after them.  The
   // last chunk is a second copy of the body rather than a run-time `more` flag: requests behind a condition the
   // compiler cannot correlate from tap to tap get a full vmcnt(0) drain in front of each of them
-  auto run_chunk = [&](int g, auto more_tag) {
+  auto run_chunk = [&](int g, auto more_tag, auto buf_tag) {
     constexpr bool more = decltype(more_tag)::value;
+    constexpr int buf = decltype(buf_tag)::value;
     USTAMP(2 + 4 * (g - g_beg));
     const float* tile = &in_tile[buf * PL * TILE];
     const f32x4* wt = &w_tile[(NBW == 2 ? buf : 0) * WQP + ct_w * 64 + lane];
@@ -613,11 +615,17 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
     USTAMP(5 + 4 * (g - g_beg));
-    buf ^= 1;
   };
-  if constexpr (NB == 2)
-    for (int g = g_beg; g + 1 < g_end; ++g) run_chunk(g, std::true_type{});
-  if (g_beg < g_end) run_chunk(g_end - 1, std::false_type{});
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  if constexpr (NB == 2) {
+    int g = g_beg;
+    for (; g + 2 < g_end; g += 2) { run_chunk(g, std::true_type{}, B0{}); run_chunk(g + 1, std::true_type{}, B1{}); }
+    if (g + 1 < g_end) { run_chunk(g, std::true_type{}, B0{}); run_chunk(g + 1, std::false_type{}, B1{}); }
+    else if (g < g_end) run_chunk(g, std::false_type{}, B0{});
+  } else {
+    if (g_beg < g_end) run_chunk(g_end - 1, std::false_type{}, B0{});
+  }
   // ---- epilogue: bias + ReLU (split-K: the raw partial sum into this split's slab), NHWC store
   float* out = a.out_bf ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(a.out) + (int64_t)cs * a.out_case)
                         : a.out + (int64_t)cs * a.out_case + (int64_t)split * a.out_slab;
