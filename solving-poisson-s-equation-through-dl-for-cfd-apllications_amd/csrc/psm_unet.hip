@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
       auto lds_read_kx = [&](int kx, int s2) {
 #pragma unroll
         for (int r = 0; r < WM + 2; ++r)
-          avr[s2][r] = *reinterpret_cast<const f32x4*>(&tile[lds_slot((row_w + r) * (TW + 2) + px + kx, kq)]);
+          avr[s2][r] = *reinterpret_cast<const f32x4*>(&tile[a_slot[r][kx]]);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
