@@ -459,6 +459,12 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
     }
   };
 
+  USTAMP(0);
+  if (g_beg < g_end) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) issue_item(g_beg, i);
+  }
+  __builtin_amdgcn_sched_barrier(0);             // the first chunk's requests are in flight: the slot arithmetic below runs under their latency
   // LDS slots of the activation operand reads: (WM + 2) tile rows x 3 tap columns, the same for every chunk and buffer (round 6).  hipcc
   // recomputed the swizzled slot -- five vector instructions -- in front of each of a chunk's 9 WM reads, inside a matrix phase whose 36
   // MFMAs the wave's own instruction stream, not the matrix pipe, paces (stamps: 0.60 us per chunk for 0.27 us of MFMA issue); the
@@ -471,10 +477,7 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
       a_slot[r][kx] = lds_slot((row_w + r) * (TW + 2) + px + kx, kq);
       asm volatile("" : "+v"(a_slot[r][kx]));
     }
-  USTAMP(0);
   if (g_beg < g_end) {
-#pragma unroll
-    for (int i = 0; i < NI; ++i) issue_item(g_beg, i);
     finish_x(g_beg, 0);
     store_w(0);
   }
