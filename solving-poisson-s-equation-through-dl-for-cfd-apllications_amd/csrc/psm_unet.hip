@@ -234,18 +234,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// element-wise maximum of two groups of 8 packed bf16 (16 bytes each): every half is widened (a shift), compared as
-// float32 and truncated back -- exact, the values are bf16 already
+// element-wise maximum of two groups of 8 packed bf16 (16 bytes each).  The 2 x 2 max-pool only ever reads outputs of ReLU'd convolutions
+// (every 3x3 layer has one; the linear head feeds no pool): NON-NEGATIVE values, whose bf16 bit patterns order like signed 16-bit integers
+// (-0 below +0, a positive NaN above everything, so it propagates like np.maximum) -- four v_pk_max_i16 instead of the 36 shift / mask /
+// float-max / pack instructions of the float form, three times per staged piece (round 6: the pool staging of the encoder launches is
+// vector-instruction bound).
 __device__ __forceinline__ f32x4 bf16x8_max(f32x4 a, f32x4 b) {
-  const u32x4 ua = __builtin_bit_cast(u32x4, a), ub = __builtin_bit_cast(u32x4, b);
-  u32x4 r;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float lo = fmaxf(__uint_as_float(ua[j] << 16), __uint_as_float(ub[j] << 16));
-    const float hi = fmaxf(__uint_as_float(ua[j] & 0xffff0000u), __uint_as_float(ub[j] & 0xffff0000u));
-    r[j] = (__float_as_uint(hi) & 0xffff0000u) | (__float_as_uint(lo) >> 16);
-  }
-  return __builtin_bit_cast(f32x4, r);
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  return __builtin_bit_cast(f32x4, __builtin_elementwise_max(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b)));
 }
 // activation store of one value per lane (lane & 15 = channel): float32, or bf16 with the channel pair (c, c+1) packed
 // into one 4-byte store by the even lane (the odd neighbour's value arrives through a DPP quad permute)
