@@ -147,19 +147,21 @@ struct Stage {
 #endif
     const int M = NQ == 4 ? 2 : 1;                           // source pixels per tile pixel and direction
     const int64_t row_bytes = (int64_t)Ps * cpx * 2;         // one source row (Ps: the source tensor's pitch in ITS pixels)
-    unsigned xoff[KM];
-    unsigned xok = 0;
+    // (round 6) the sources of the 32-channel pairs are ZERO-HALOED bf16 tensors (psm_unet_api.cpp, act_layout: 4 pixels left / top, 64 / 32
+    // right / bottom): the 'same' padding, the last tile's overhang and a max-pool's doubled extent are read from memory like any other
+    // pixel -- no clamps, no predicates, and write() below needs no selects (Hs, Ws stay in the signature for the callers)
+    (void)Hs; (void)Ws;
+    int xoff[KM];
 #pragma unroll
     for (int k = 0; k < KM; ++k) {
       const int c = PPI * k + lane / G, g = lane % G, x = xs0 + c;
-      xok |= (x >= 0 && x < Ws) ? (1u << k) : 0u;
-      xoff[k] = (unsigned)((M * min(max(x, 0), Ws - 1) * cpx + cb + 8 * g) * 2);
+      xoff[k] = (M * x * cpx + cb + 8 * g) * 2;
     }
+    ok = ~0u;
 #pragma unroll
     for (int jj = 0; jj < JN; ++jj) {
       const int j = jj, r = min(wave + 4 * (J0 + jj), NROW - 1), y = ys0 + r;          // uniform
-      const bool yok = y >= 0 && y < Hs;
-      const char* rowp = reinterpret_cast<const char*>(src) + (int64_t)(M * min(max(y, 0), Hs - 1)) * row_bytes;
+      const char* rowp = reinterpret_cast<const char*>(src) + (int64_t)(M * y) * row_bytes;
 #pragma unroll
       for (int k = 0; k < KM; ++k) {
         const char* q = rowp + xoff[k];
@@ -169,15 +171,12 @@ struct Stage {
           v[j * KM + k][NQ == 4 ? 2 : 0] = *reinterpret_cast<const f32x4*>(q + row_bytes);
           v[j * KM + k][NQ == 4 ? 3 : 0] = *reinterpret_cast<const f32x4*>(q + row_bytes + cpx * 2);
         }
-        ok |= (yok && ((xok >> k) & 1u)) ? (1u << (j * KM + k)) : 0u;
       }
     }
     if (SIDE) {
       const int q = min(tid, NSIDE - 1), r = q / (SIDEW * G), rem = q - r * (SIDEW * G), c = MAINPX + rem / G, g = rem % G;
       const int y = ys0 + r, x = xs0 + c;
-      ok |= (y >= 0 && y < Hs && x >= 0 && x < Ws) ? (1u << (NV - 1)) : 0u;
-      const char* qp = reinterpret_cast<const char*>(src) + (int64_t)(M * min(max(y, 0), Hs - 1)) * row_bytes +
-                       (M * min(max(x, 0), Ws - 1) * cpx + cb + 8 * g) * 2;
+      const char* qp = reinterpret_cast<const char*>(src) + (int64_t)(M * y) * row_bytes + (M * x * cpx + cb + 8 * g) * 2;
       v[NV - 1][0] = *reinterpret_cast<const f32x4*>(qp);
       if (NQ == 4) {
         v[NV - 1][NQ == 4 ? 1 : 0] = *reinterpret_cast<const f32x4*>(qp + cpx * 2);
@@ -195,27 +194,23 @@ struct Stage {
   static __device__ __forceinline__ void issue_piece(f32x4 (&v)[NP][NQ], unsigned& ok, const unsigned short* src, int cpx, int cb,
                                                      int Hs, int Ws, int Ps, int ys0, int xs0, int wave, int lane, int tid) {
     static_assert(NQ == 1 && I >= 0 && I < NP, "same-resolution pieces of a whole tile");
-    if (I == 0) ok = 0;
+    if (I == 0) ok = ~0u;                                  // zero-haloed sources: nothing to clamp, nothing to zero (see issue())
 #if defined(PSM_PAIR_EXP) && (PSM_PAIR_EXP & 2)
     return;
 #endif
+    (void)Hs; (void)Ws;
     const int64_t row_bytes = (int64_t)Ps * cpx * 2;
     if constexpr (I < RW * KM) {
       constexpr int jj = I / KM, k = I % KM;
       const int c = PPI * k + lane / G, g = lane % G, x = xs0 + c;
-      const bool xin = x >= 0 && x < Ws;
-      const unsigned xoff = (unsigned)((min(max(x, 0), Ws - 1) * cpx + cb + 8 * g) * 2);
+      const int xoff = (x * cpx + cb + 8 * g) * 2;
       const int r = min(wave + 4 * jj, NROW - 1), y = ys0 + r;          // uniform
-      const bool yok = y >= 0 && y < Hs;
-      const char* rowp = reinterpret_cast<const char*>(src) + (int64_t)min(max(y, 0), Hs - 1) * row_bytes;
+      const char* rowp = reinterpret_cast<const char*>(src) + (int64_t)y * row_bytes;
       v[I][0] = *reinterpret_cast<const f32x4*>(rowp + xoff);
-      ok |= (yok && xin) ? (1u << I) : 0u;
     } else {
       const int q = min(tid, NSIDE - 1), r = q / (SIDEW * G), rem = q - r * (SIDEW * G), c = MAINPX + rem / G, g = rem % G;
       const int y = ys0 + r, x = xs0 + c;
-      ok |= (y >= 0 && y < Hs && x >= 0 && x < Ws) ? (1u << I) : 0u;
-      const char* qp = reinterpret_cast<const char*>(src) + (int64_t)min(max(y, 0), Hs - 1) * row_bytes +
-                       (min(max(x, 0), Ws - 1) * cpx + cb + 8 * g) * 2;
+      const char* qp = reinterpret_cast<const char*>(src) + (int64_t)y * row_bytes + (x * cpx + cb + 8 * g) * 2;
       v[I][0] = *reinterpret_cast<const f32x4*>(qp);
     }
   }
@@ -240,11 +235,7 @@ struct Stage {
     auto piece = [&](int i) {
       f32x4 t = v[i][0];
       if (NQ == 4) t = bf16x8_max(bf16x8_max(v[i][0], v[i][NQ == 4 ? 1 : 0]), bf16x8_max(v[i][NQ == 4 ? 2 : 0], v[i][NQ == 4 ? 3 : 0]));
-      if (!interior) {
-        const bool in = (ok >> i) & 1u;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = in ? t[e] : 0.f;
-      }
+      (void)ok; (void)interior;                            // zero-haloed sources: out-of-image pixels arrive as zeros
       return t;
     };
 #pragma unroll
