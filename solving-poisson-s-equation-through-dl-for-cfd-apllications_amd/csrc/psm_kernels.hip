@@ -33,13 +33,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // Diagnostic stamps (100 MHz wall clock) -- compiled only with -DPSM_STAMPS, never in the shipped library.
 #ifdef PSM_STAMPS
 __device__ unsigned long long g_psm_stamps[64];
+hipError_t psm_read_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_psm_stamps), sizeof(g_psm_stamps)); }
+#else
+hipError_t psm_read_stamps(unsigned long long* out) { for (int i = 0; i < 64; ++i) out[i] = 0; return hipSuccess; }
+#endif
+#if defined(PSM_STAMPS) && !defined(PSM_STAMPS_ENC)      // -DPSM_STAMPS_ENC: all 64 slots belong to psm_encode_x6_mt_kernel (ESTAMP below)
 #define PSM_STAMP(buf, k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_psm_stamps[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define PSM_STAMP_T(tid_, k) do { if (blockIdx.x == 0 && threadIdx.x == (tid_) && (k) < 64) g_psm_stamps[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
-hipError_t psm_read_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_psm_stamps), sizeof(g_psm_stamps)); }
 #else
 #define PSM_STAMP(buf, k) do { } while (0)
 #define PSM_STAMP_T(tid_, k) do { } while (0)
-hipError_t psm_read_stamps(unsigned long long* out) { for (int i = 0; i < 64; ++i) out[i] = 0; return hipSuccess; }
 #endif
 
 __device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
@@ -587,9 +590,15 @@ __global__ __launch_bounds__(256) void psm_encode_x6_kernel(PsmEncodeArgs a) {
 // Summation order: k ascending inside a K group (MFMA accumulators), then the groups in slab order (psm_reduce_kernel) --
 // deterministic, but not the order of the one-slab-per-slice form (float32 rounding differs in the last bits).
 // ---------------------------------------------------------------------------
+#if defined(PSM_STAMPS) && defined(PSM_STAMPS_ENC)      // make stamps EXTRA=-DPSM_STAMPS_ENC: this kernel's stamps instead of the decode's (tools/encode_stamps.py)
+#define ESTAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == (PSM_STAMPS_ENC) && (k) < 64) g_psm_stamps[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ESTAMP(k) do { } while (0)
+#endif
 template <int C_IN, bool ALIGNED>
 __global__ __launch_bounds__(256, 2) void psm_encode_x6_mt_kernel(PsmEncodeArgs a) {
   psm_warm_kernargs<sizeof(PsmEncodeArgs)>();
+  ESTAMP(0);
   constexpr int KS = PSM_PIX_PER_SLICE * C_IN;  // K elements per slice
   constexpr int KH = KS / 2;                    // ... per half-slice
   constexpr int NSH = KH / 16;                  // MFMA steps per half-slice
@@ -630,63 +639,72 @@ __global__ __launch_bounds__(256, 2) void psm_encode_x6_mt_kernel(PsmEncodeArgs 
   // staging: 256 threads move one step's 32 rows x KH floats, float4 idx = tid + 256 u -> (row, q), fixed over the steps.  Everything a
   // request needs is ONE 32-bit float offset per (row tile, piece) -- row base (a case batch of grids is < 2^31 floats) + column --
   // plus the half-slice's scalar offset from LDS; padding rows are one bit each
+  static_assert(32 * QH == 256 * NX, "every thread moves exactly NX pieces of a step");
   int ldst[NX], o0[NX], o1[NX], mq[NX];
-  unsigned keep_bits = 0, live = 0;
+  unsigned keep_bits = 0;
 #pragma unroll
   for (int u = 0; u < NX; ++u) {
-    const int idx = min(tid + 256 * u, 32 * QH - 1);
+    const int idx = tid + 256 * u;
     const int xrow = idx / QH, xq = idx - xrow * QH;
     const int m = m0 + xrow;
     o0[u] = (int)a.row_base[min(m, a.M - 1)] + 4 * xq;
     o1[u] = (int)a.row_base[min(m + 32, a.M - 1)] + 4 * xq;
     ldst[u] = xrow * LDB + 4 * xq;                            // bf16 offset within a plane
     mq[u] = 4 * xq;
-    live |= (tid + 256 * u < 32 * QH) ? (1u << u) : 0u;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) keep_bits |= (m + 32 * mt) < a.M ? (1u << (mt * NX + u)) : 0u;
   }
-  float4 xr[NX];
+  // one register set per row tile: a tile's rows are requested TWO steps ahead of their split (stamps, tools/encode_stamps.py: with one
+  // step of lead the staging phase waited ~0.6 us per step for rows that come from HBM / MALL exactly once)
+  float4 xr0[NX], xr1[NX];
   auto load_x = [&](int hs, auto mt_tag) {
     constexpr int MTI = decltype(mt_tag)::value;
     const float* base = a.grid + hs_off[hs];
 #pragma unroll
     for (int u = 0; u < NX; ++u) {
       const float* src = base + (MTI == 0 ? o0[u] : o1[u]);
-      if (ALIGNED) xr[u] = *reinterpret_cast<const float4*>(src);
-      else xr[u] = make_float4(src[0], src[1], src[2], src[3]);
+      float4& dst = MTI == 0 ? xr0[u] : xr1[u];
+      if (ALIGNED) dst = *reinterpret_cast<const float4*>(src);
+      else dst = make_float4(src[0], src[1], src[2], src[3]);
     }
   };
-  auto write_x = [&](int hs, auto mt_tag, int buf) {
+  auto write_piece = [&](int hs, auto mt_tag, int buf, int u) {
     constexpr int MTI = decltype(mt_tag)::value;
+    const float k = ((keep_bits >> (MTI * NX + u)) & 1u) ? 1.f : 0.f;
+    const float4 mu = *reinterpret_cast<const float4*>(&mean_l[hs * KH + mq[u]]);
+    const float4 x = MTI == 0 ? xr0[u] : xr1[u];
+    const f32x4 v = {(x.x - mu.x) * k, (x.y - mu.y) * k, (x.z - mu.z) * k, (x.w - mu.w) * k};
+    x6_bf16x4 vh, vm, vl;
+    psm_split3(v, vh, vm, vl);
+    __bf16* dst = &ldsx[buf * 3 * PL + ldst[u]];
+    *reinterpret_cast<x6_bf16x4*>(dst) = vh;
+    *reinterpret_cast<x6_bf16x4*>(dst + PL) = vm;
+    *reinterpret_cast<x6_bf16x4*>(dst + 2 * PL) = vl;
+  };
+  auto write_x = [&](int hs, auto mt_tag, int buf) {
 #pragma unroll
-    for (int u = 0; u < NX; ++u) {
-      const float k = ((keep_bits >> (MTI * NX + u)) & 1u) ? 1.f : 0.f;
-      const float4 mu = *reinterpret_cast<const float4*>(&mean_l[hs * KH + mq[u]]);
-      const float4 x = xr[u];
-      const f32x4 v = {(x.x - mu.x) * k, (x.y - mu.y) * k, (x.z - mu.z) * k, (x.w - mu.w) * k};
-      x6_bf16x4 vh, vm, vl;
-      psm_split3(v, vh, vm, vl);
-      if ((live >> u) & 1u) {
-        __bf16* dst = &ldsx[buf * 3 * PL + ldst[u]];
-        *reinterpret_cast<x6_bf16x4*>(dst) = vh;
-        *reinterpret_cast<x6_bf16x4*>(dst + PL) = vm;
-        *reinterpret_cast<x6_bf16x4*>(dst + 2 * PL) = vl;
-      }
-    }
+    for (int u = 0; u < NX; ++u) write_piece(hs, mt_tag, buf, u);
   };
   // basis planes of a half-slice: [step][plane h, m, l] fragments as they lie in a.bpack_x6 (psm_split_basis_kernel): loads and
   // MFMAs only.  ONE register set (72): the next half-slice is requested when the current one's last MFMA is issued; the wait is
   // covered by the CU's other workgroups (three per CU at <= 168 registers)
   x6_bf16x8 P[NSH][3];
+  auto b_ptr = [&](int hs) { return a.bpack_x6 + ((((int64_t)(s_first + (hs >> 1)) * NT + t) * (2 * NSH) + (hs & 1) * NSH) * 3) * 64 + lane; };
   auto load_b = [&](int hs) {
-    const uint4* p = a.bpack_x6 + ((((int64_t)(s_first + (hs >> 1)) * NT + t) * (2 * NSH) + (hs & 1) * NSH) * 3) * 64 + lane;
+    const uint4* p = b_ptr(hs);
 #pragma unroll
     for (int st = 0; st < NSH; ++st)
 #pragma unroll
       for (int q = 0; q < 3; ++q) P[st][q] = __builtin_bit_cast(x6_bf16x8, p[(st * 3 + q) * 64]);
   };
   f32x16 acc0 = {0}, acc1 = {0};
-  auto mfma_tile = [&](f32x16& c, int buf) {
+  // `next` != nullptr: the planes of step st are dead after its six MFMAs in a half-slice's SECOND row tile -- the next half-slice's
+  // planes of that step are requested right there (a whole matrix phase + staging ahead of their first use instead of behind the
+  // last MFMA of the phase)
+  // `stage(u)`: piece u of the NEXT step's rows (split + LDS writes into the other tile's buffer, which nobody reads during this step) rides
+  // in the shadow of MFMA groups 2u, 2u + 1: one MFMA, then a few of its vector instructions, in turn (the MFMAs are one dependent chain of
+  // 32 cycles each; behind the phase the same instructions cost ~1 us per step, tools/encode_stamps.py)
+  auto mfma_tile = [&](f32x16& c, int buf, const uint4* next, int stamp, auto&& stage) {
     const __bf16* arow = &ldsx[buf * 3 * PL + i * LDB + 4 * h];
     x6_bf16x8 A[2][3];
     auto rd = [&](int st, int sl) {
@@ -700,12 +718,24 @@ __global__ __launch_bounds__(256, 2) void psm_encode_x6_mt_kernel(PsmEncodeArgs 
       const int sl = st & 1;
       if (st + 1 < NSH) rd(st + 1, sl ^ 1);
       __builtin_amdgcn_sched_barrier(0);
+      if ((st & 1) == 0) stage(st >> 1);
       c = MFMA_X6(A[sl][1], P[st][1], c);            // small terms first: mm, lh, hl, mh, hm, hh
       c = MFMA_X6(A[sl][2], P[st][0], c);
       c = MFMA_X6(A[sl][0], P[st][2], c);
       c = MFMA_X6(A[sl][1], P[st][0], c);
       c = MFMA_X6(A[sl][0], P[st][1], c);
       c = MFMA_X6(A[sl][0], P[st][0], c);
+#pragma unroll
+      for (int k6 = 0; k6 < 6; ++k6) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+      }
+      if (st == 0) ESTAMP(stamp);
+      if (next) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) P[st][q] = __builtin_bit_cast(x6_bf16x8, next[(st * 3 + q) * 64]);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -713,26 +743,29 @@ __global__ __launch_bounds__(256, 2) void psm_encode_x6_mt_kernel(PsmEncodeArgs 
   __syncthreads();                                            // mean_l, hs_off
   load_x(0, T0{});
   load_b(0);
+  load_x(0, T1{});
   __builtin_amdgcn_sched_barrier(0);
   write_x(0, T0{}, 0);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  // steps (half-slice hs, row tile): buffer = tile (two steps per half-slice).  The rows of the next step are requested before a
-  // step's MFMAs and written after them.  (The last half-slice is a second compile-time copy: behind a run-time "is there a next
+  ESTAMP(1);
+  // steps (half-slice hs, row tile): buffer = tile (two steps per half-slice).  The rows a step splits and writes after its MFMAs (those
+  // of the NEXT step) were requested before the PREVIOUS step's MFMAs; what it requests itself is for the step after next.  (The last half-slice is a second compile-time copy: behind a run-time "is there a next
   // one" the plane registers became a conditional assignment and spilled.)
   auto run_hs = [&](int hs, auto more_tag) {
     constexpr bool more = decltype(more_tag)::value;
-    load_x(hs, T1{});
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_tile(acc0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    write_x(hs, T1{}, 1);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (more) load_x(hs + 1, T0{});
     __builtin_amdgcn_sched_barrier(0);
-    mfma_tile(acc1, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) { load_b(hs + 1); write_x(hs + 1, T0{}, 0); }
+    mfma_tile(acc0, 0, nullptr, 2 + 6 * hs, [&](int u) { write_piece(hs, T1{}, 1, u); });
+    ESTAMP(3 + 6 * hs);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    ESTAMP(4 + 6 * hs);
+    if (more) load_x(hs + 1, T1{});
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) mfma_tile(acc1, 1, b_ptr(hs + 1), 5 + 6 * hs, [&](int u) { write_piece(hs + 1, T0{}, 0, u); });
+    else mfma_tile(acc1, 1, nullptr, 5 + 6 * hs, [](int) {});
+    ESTAMP(6 + 6 * hs);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    ESTAMP(7 + 6 * hs);
   };
   for (int hs = 0; hs + 1 < n_hs; ++hs) run_hs(hs, std::true_type{});
   run_hs(n_hs - 1, std::false_type{});
@@ -745,6 +778,7 @@ __global__ __launch_bounds__(256, 2) void psm_encode_x6_mt_kernel(PsmEncodeArgs 
       for (int q = 0; q < 16; ++q) out[(int64_t)(32 + acc_row(q, h)) * a.ldp] = acc1[q];
     }
   }
+  ESTAMP(63);
 }
 
 // x6 covers <= 128 components (NT <= 4) and an LDS footprint of three bf16 planes
@@ -2698,7 +2732,7 @@ __global__ __launch_bounds__(384) void psm_decode_paste_kernel(PsmDecodeArgs a, 
       if (lane == 0) wred[f] = raw / (float)p.shiftL[f] / 3.f - t_shift + guard;
     }
     if (blockIdx.x == 0 && f == 0 && lane == 0) {
-#ifdef PSM_STAMPS
+#if defined(PSM_STAMPS) && !defined(PSM_STAMPS_ENC)
       g_psm_stamps[39] = __builtin_amdgcn_s_memrealtime();
 #endif
     }
@@ -2823,7 +2857,7 @@ hipError_t psm_launch_chain_dots(const PsmBoundBatchArgs& p, int c_out, hipStrea
 template <int MTC, int C, int LDR, int MODE>           // MODE 0: exact-f32 MFMA, 1: bf16 handle (operands rounded), 2: x6 (float32 accuracy on the bf16 pipe)
 __global__ __launch_bounds__(256) void psm_decode_paste_batch_kernel(PsmDecodeArgs a, PsmBoundBatchArgs p, int m_end) {
   psm_warm_kernargs<sizeof(PsmDecodeArgs) + sizeof(PsmBoundBatchArgs)>();
-#ifdef PSM_STAMPS
+#if defined(PSM_STAMPS) && !defined(PSM_STAMPS_ENC)
 #define DSTAMP(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && (k) < 40) g_psm_stamps[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define DSTAMP(k) do { } while (0)
