@@ -25,8 +25,8 @@ int encode_groups(const psm_handle* h, int Mpad) {
   static const int min_rows = getenv("PSM_ENCODE_MT_MIN_ROWS") ? atoi(getenv("PSM_ENCODE_MT_MIN_ROWS")) : 96;
   if (h->cfg.precision == PSM_PRECISION_BF16 || h->NT > 4 || Mpad % 32 != 0 || Mpad < min_rows || ((PSM_PIX_PER_SLICE * h->cfg.c_in) % 32) != 0) return 1;
   if (h->x6_mode >= 0 && !(h->x6_mode & 1)) return 1;
-  // psm_encode_x6_mt_kernel addresses the grids of the whole case batch with 32-bit element offsets (row_base narrowed to int)
-  if ((int64_t)h->cfg.max_cases * h->Ny * h->Nx * h->cfg.c_in >= ((int64_t)1 << 31)) return 1;
+  // psm_encode_x6_mt_kernel addresses the grids of the whole case batch with unsigned 32-bit BYTE offsets from a scalar base
+  if ((int64_t)h->cfg.max_cases * h->Ny * h->Nx * h->cfg.c_in >= ((int64_t)1 << 30)) return 1;
   static const int kg_env = getenv("PSM_ENCODE_KGROUPS") ? atoi(getenv("PSM_ENCODE_KGROUPS")) : 0;
   const int row_groups = (Mpad + PSM_ENC_MT_ROWS - 1) / PSM_ENC_MT_ROWS;
   static const int by_rg[9] = {0, 256, 256, 256, 128, 256, 128, 64, 64};

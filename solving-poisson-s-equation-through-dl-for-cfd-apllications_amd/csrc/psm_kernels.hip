@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256, 2) void psm_encode_x6_mt_kernel(PsmEncodeArgs 
   static_assert(KH % 16 == 0 && MT == 2, "whole MFMA steps per half-slice; two named row tiles");
   __shared__ __attribute__((aligned(16))) __bf16 ldsx[2 * 3 * PL];
   __shared__ __attribute__((aligned(16))) float mean_l[MAXG * KS];       // the workgroup's K range of the mean
-  __shared__ int hs_off[2 * MAXG];                                        // float offset of half-slice hs within a block row
+  __shared__ int hs_off[2 * MAXG + 2];                                    // float offset of half-slice hs within a block row (read two ahead)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n_slices = a.S * a.S / PSM_PIX_PER_SLICE;
@@ -640,15 +640,16 @@ __global__ __launch_bounds__(256, 2) void psm_encode_x6_mt_kernel(PsmEncodeArgs 
   // request needs is ONE 32-bit float offset per (row tile, piece) -- row base (a case batch of grids is < 2^31 floats) + column --
   // plus the half-slice's scalar offset from LDS; padding rows are one bit each
   static_assert(32 * QH == 256 * NX, "every thread moves exactly NX pieces of a step");
-  int ldst[NX], o0[NX], o1[NX], mq[NX];
+  int ldst[NX], mq[NX];
+  unsigned o0[NX], o1[NX];                                                 // BYTE offsets (the launcher keeps a case batch of grids under 4 GiB)
   unsigned keep_bits = 0;
 #pragma unroll
   for (int u = 0; u < NX; ++u) {
     const int idx = tid + 256 * u;
     const int xrow = idx / QH, xq = idx - xrow * QH;
     const int m = m0 + xrow;
-    o0[u] = (int)a.row_base[min(m, a.M - 1)] + 4 * xq;
-    o1[u] = (int)a.row_base[min(m + 32, a.M - 1)] + 4 * xq;
+    o0[u] = 4u * (unsigned)((int)a.row_base[min(m, a.M - 1)] + 4 * xq);
+    o1[u] = 4u * (unsigned)((int)a.row_base[min(m + 32, a.M - 1)] + 4 * xq);
     ldst[u] = xrow * LDB + 4 * xq;                            // bf16 offset within a plane
     mq[u] = 4 * xq;
 #pragma unroll
@@ -657,21 +658,26 @@ __global__ __launch_bounds__(256, 2) void psm_encode_x6_mt_kernel(PsmEncodeArgs 
   // one register set per row tile: a tile's rows are requested TWO steps ahead of their split (stamps, tools/encode_stamps.py: with one
   // step of lead the staging phase waited ~0.6 us per step for rows that come from HBM / MALL exactly once)
   float4 xr0[NX], xr1[NX];
-  auto load_x = [&](int hs, auto mt_tag) {
+  auto load_x = [&](int off, auto mt_tag) {                               // off = hs_off[hs] as a wave-uniform value: scalar base + 32-bit lane offset
     constexpr int MTI = decltype(mt_tag)::value;
-    const float* base = a.grid + hs_off[hs];
+    const char* base = reinterpret_cast<const char*>(a.grid + off);
 #pragma unroll
     for (int u = 0; u < NX; ++u) {
-      const float* src = base + (MTI == 0 ? o0[u] : o1[u]);
+      const float* src = reinterpret_cast<const float*>(base + (MTI == 0 ? o0[u] : o1[u]));
       float4& dst = MTI == 0 ? xr0[u] : xr1[u];
       if (ALIGNED) dst = *reinterpret_cast<const float4*>(src);
       else dst = make_float4(src[0], src[1], src[2], src[3]);
     }
   };
-  auto write_piece = [&](int hs, auto mt_tag, int buf, int u) {
+  float4 mu_r[NX];                                                         // the step's mean pieces, read at the top of its matrix phase
+  auto read_mean = [&](int hs) {
+#pragma unroll
+    for (int u = 0; u < NX; ++u) mu_r[u] = *reinterpret_cast<const float4*>(&mean_l[hs * KH + mq[u]]);
+  };
+  auto write_piece = [&](auto mt_tag, int buf, int u) {
     constexpr int MTI = decltype(mt_tag)::value;
     const float k = ((keep_bits >> (MTI * NX + u)) & 1u) ? 1.f : 0.f;
-    const float4 mu = *reinterpret_cast<const float4*>(&mean_l[hs * KH + mq[u]]);
+    const float4 mu = mu_r[u];
     const float4 x = MTI == 0 ? xr0[u] : xr1[u];
     const f32x4 v = {(x.x - mu.x) * k, (x.y - mu.y) * k, (x.z - mu.z) * k, (x.w - mu.w) * k};
     x6_bf16x4 vh, vm, vl;
@@ -682,8 +688,9 @@ __global__ __launch_bounds__(256, 2) void psm_encode_x6_mt_kernel(PsmEncodeArgs 
     *reinterpret_cast<x6_bf16x4*>(dst + 2 * PL) = vl;
   };
   auto write_x = [&](int hs, auto mt_tag, int buf) {
+    read_mean(hs);
 #pragma unroll
-    for (int u = 0; u < NX; ++u) write_piece(hs, mt_tag, buf, u);
+    for (int u = 0; u < NX; ++u) write_piece(mt_tag, buf, u);
   };
   // basis planes of a half-slice: [step][plane h, m, l] fragments as they lie in a.bpack_x6 (psm_split_basis_kernel): loads and
   // MFMAs only.  ONE register set (72): the next half-slice is requested when the current one's last MFMA is issued; the wait is
@@ -704,8 +711,9 @@ __global__ __launch_bounds__(256, 2) void psm_encode_x6_mt_kernel(PsmEncodeArgs 
   // `stage(u)`: piece u of the NEXT step's rows (split + LDS writes into the other tile's buffer, which nobody reads during this step) rides
   // in the shadow of MFMA groups 2u, 2u + 1: one MFMA, then a few of its vector instructions, in turn (the MFMAs are one dependent chain of
   // 32 cycles each; behind the phase the same instructions cost ~1 us per step, tools/encode_stamps.py)
-  auto mfma_tile = [&](f32x16& c, int buf, const uint4* next, int stamp, auto&& stage) {
+  auto mfma_tile = [&](f32x16& c, int buf, const uint4* next, int stamp, int hs_stage, auto&& stage) {
     const __bf16* arow = &ldsx[buf * 3 * PL + i * LDB + 4 * h];
+    if (hs_stage >= 0) read_mean(hs_stage);
     x6_bf16x8 A[2][3];
     auto rd = [&](int st, int sl) {
 #pragma unroll
@@ -741,9 +749,10 @@ __global__ __launch_bounds__(256, 2) void psm_encode_x6_mt_kernel(PsmEncodeArgs 
   };
   typedef std::integral_constant<int, 0> T0; typedef std::integral_constant<int, 1> T1;
   __syncthreads();                                            // mean_l, hs_off
-  load_x(0, T0{});
+  load_x(__builtin_amdgcn_readfirstlane(hs_off[0]), T0{});
   load_b(0);
-  load_x(0, T1{});
+  load_x(__builtin_amdgcn_readfirstlane(hs_off[0]), T1{});
+  int off_next = __builtin_amdgcn_readfirstlane(hs_off[1]);    // hs_off[hs + 1] at the top of run_hs(hs); the one after is read a half-slice ahead
   __builtin_amdgcn_sched_barrier(0);
   write_x(0, T0{}, 0);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -753,16 +762,18 @@ __global__ __launch_bounds__(256, 2) void psm_encode_x6_mt_kernel(PsmEncodeArgs 
   // one" the plane registers became a conditional assignment and spilled.)
   auto run_hs = [&](int hs, auto more_tag) {
     constexpr bool more = decltype(more_tag)::value;
-    if (more) load_x(hs + 1, T0{});
+    if (more) load_x(off_next, T0{});
+    const int off_raw = hs_off[hs + 2];
     __builtin_amdgcn_sched_barrier(0);
-    mfma_tile(acc0, 0, nullptr, 2 + 6 * hs, [&](int u) { write_piece(hs, T1{}, 1, u); });
+    mfma_tile(acc0, 0, nullptr, 2 + 6 * hs, hs, [&](int u) { write_piece(T1{}, 1, u); });
     ESTAMP(3 + 6 * hs);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     ESTAMP(4 + 6 * hs);
-    if (more) load_x(hs + 1, T1{});
+    if (more) load_x(off_next, T1{});
     __builtin_amdgcn_sched_barrier(0);
-    if (more) mfma_tile(acc1, 1, b_ptr(hs + 1), 5 + 6 * hs, [&](int u) { write_piece(hs + 1, T0{}, 0, u); });
-    else mfma_tile(acc1, 1, nullptr, 5 + 6 * hs, [](int) {});
+    if (more) mfma_tile(acc1, 1, b_ptr(hs + 1), 5 + 6 * hs, hs + 1, [&](int u) { write_piece(T0{}, 0, u); });
+    else mfma_tile(acc1, 1, nullptr, 5 + 6 * hs, -1, [](int) {});
+    off_next = __builtin_amdgcn_readfirstlane(off_raw);
     ESTAMP(6 + 6 * hs);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     ESTAMP(7 + 6 * hs);
