@@ -582,7 +582,10 @@ __global__ __launch_bounds__(256) void psm_encode_x6_kernel(PsmEncodeArgs a) {
 //   fragment order, psm_split_basis_kernel, 1.5 x the bytes): half a slice (96 k) at a time in 72 registers, loads and MFMAs only --
 //   splitting the float32 pack in the kernel cost 344 vector instructions per half-slice and the registers for the raw copy.  The
 //   activation rows of a (half-slice, row tile) step go through LDS (three bf16 planes, 32 rows, one buffer per row tile: 38 KB,
-//   two workgroups per CU); the rows of the next step are requested before a step's MFMAs and split + written after them.
+//   two workgroups per CU).  Round 6 (stamps: tools/encode_stamps.py; record: profiles/r06_case_batch.txt (6)): the next step's rows are
+//   split and written to the OTHER tile's buffer in the shadow of the step's MFMA chain (sched_group_barrier: one MFMA, six vector
+//   instructions, in turn) -- behind the chain the same instructions cost ~1 us of every 2.1 us step; rows are requested two steps
+//   ahead, a half-slice's basis planes as the previous half-slice's second tile releases them, step by step.
 // Measured at 64 cases (one box): 49 us + 6 us reduce against 60 + 12 us for the one-slab-per-slice form.  Built and measured on
 // the way, none faster (profiles/r05_case_batch.txt): three row tiles with the float32 basis split in the kernel (49-56 us), an
 // eight-wave form with four multiplying and four staging waves per workgroup (57-64 us: the staging wave of a SIMD runs its ~260
@@ -693,8 +696,7 @@ __global__ __launch_bounds__(256, 2) void psm_encode_x6_mt_kernel(PsmEncodeArgs 
     for (int u = 0; u < NX; ++u) write_piece(mt_tag, buf, u);
   };
   // basis planes of a half-slice: [step][plane h, m, l] fragments as they lie in a.bpack_x6 (psm_split_basis_kernel): loads and
-  // MFMAs only.  ONE register set (72): the next half-slice is requested when the current one's last MFMA is issued; the wait is
-  // covered by the CU's other workgroups (three per CU at <= 168 registers)
+  // MFMAs only.  ONE register set (72), refilled step by step (mfma_tile's `next`)
   x6_bf16x8 P[NSH][3];
   auto b_ptr = [&](int hs) { return a.bpack_x6 + ((((int64_t)(s_first + (hs >> 1)) * NT + t) * (2 * NSH) + (hs & 1) * NSH) * 3) * 64 + lane; };
   auto load_b = [&](int hs) {
@@ -757,9 +759,10 @@ __global__ __launch_bounds__(256, 2) void psm_encode_x6_mt_kernel(PsmEncodeArgs 
   write_x(0, T0{}, 0);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   ESTAMP(1);
-  // steps (half-slice hs, row tile): buffer = tile (two steps per half-slice).  The rows a step splits and writes after its MFMAs (those
-  // of the NEXT step) were requested before the PREVIOUS step's MFMAs; what it requests itself is for the step after next.  (The last half-slice is a second compile-time copy: behind a run-time "is there a next
-  // one" the plane registers became a conditional assignment and spilled.)
+  // steps (half-slice hs, row tile): buffer = tile (two steps per half-slice).  The rows a step splits and writes beside its MFMAs (those
+  // of the NEXT step) were requested before the PREVIOUS step's MFMAs; what it requests itself is for the step after next.  (The last
+  // half-slice is a second compile-time copy: behind a run-time "is there a next one" the plane registers became a conditional
+  // assignment and spilled.)
   auto run_hs = [&](int hs, auto more_tag) {
     constexpr bool more = decltype(more_tag)::value;
     if (more) load_x(off_next, T0{});
