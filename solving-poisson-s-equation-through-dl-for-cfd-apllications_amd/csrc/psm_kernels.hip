@@ -679,10 +679,11 @@ __global__ __launch_bounds__(256, 2) void psm_encode_x6_mt_kernel(PsmEncodeArgs 
   };
   auto write_piece = [&](auto mt_tag, int buf, int u) {
     constexpr int MTI = decltype(mt_tag)::value;
-    const float k = ((keep_bits >> (MTI * NX + u)) & 1u) ? 1.f : 0.f;
-    const float4 mu = mu_r[u];
+    const uint32_t k = ((keep_bits >> (MTI * NX + u)) & 1u) ? 0xffffffffu : 0u;   // padding rows: zeros (a bit mask: as a float factor the
+    const float4 mu = mu_r[u];                                                     // compiler packed the multiplies -- v_pk_mul_f32 is slow beside MFMAs)
     const float4 x = MTI == 0 ? xr0[u] : xr1[u];
-    const f32x4 v = {(x.x - mu.x) * k, (x.y - mu.y) * k, (x.z - mu.z) * k, (x.w - mu.w) * k};
+    const f32x4 v = {__uint_as_float(__float_as_uint(x.x - mu.x) & k), __uint_as_float(__float_as_uint(x.y - mu.y) & k),
+                     __uint_as_float(__float_as_uint(x.z - mu.z) & k), __uint_as_float(__float_as_uint(x.w - mu.w) & k)};
     x6_bf16x4 vh, vm, vl;
     psm_split3(v, vh, vm, vl);
     __bf16* dst = &ldsx[buf * 3 * PL + ldst[u]];
