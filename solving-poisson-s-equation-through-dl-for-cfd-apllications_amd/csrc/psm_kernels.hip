@@ -605,7 +605,11 @@ __global__ __launch_bounds__(256, 2) void psm_encode_x6_mt_kernel(PsmEncodeArgs 
   constexpr int KS = PSM_PIX_PER_SLICE * C_IN;  // K elements per slice
   constexpr int KH = KS / 2;                    // ... per half-slice
   constexpr int NSH = KH / 16;                  // MFMA steps per half-slice
-  constexpr int LDB = KH + 4;                   // plane row stride in bf16 (KH / 2 + 2 dwords: conflict-free ds_read_b64 of 32 rows)
+  constexpr int LDB = KH + 8;                   // plane row stride in bf16: a multiple of 16 bytes, an odd number of 16-byte slots (13 at C_in = 3)
+                                                // -- the 16 lanes of a ds_read_b128 group fall on 16 different slots.  Inside every 16 k the four
+                                                // 4-element groups are stored 0, 2, 1, 3: lane half h's MFMA operand (k 4h.. and 8 + 4h.., the order
+                                                // of the basis pack) is ONE 16-byte read (as two 8-byte reads the compiler emitted ds_read2_b64:
+                                                // 16 LDS cycles for what ds_read_b128 moves in 4, MI355X_MICROARCH.md LDS table)
   constexpr int QH = KH / 4;                    // float4 per activation row and half-slice
   constexpr int NX = (32 * QH + 255) / 256;     // float4 per thread and step
   constexpr int MT = PSM_ENC_MT_ROWS / 32;
@@ -653,7 +657,7 @@ __global__ __launch_bounds__(256, 2) void psm_encode_x6_mt_kernel(PsmEncodeArgs 
     const int m = m0 + xrow;
     o0[u] = 4u * (unsigned)((int)a.row_base[min(m, a.M - 1)] + 4 * xq);
     o1[u] = 4u * (unsigned)((int)a.row_base[min(m + 32, a.M - 1)] + 4 * xq);
-    ldst[u] = xrow * LDB + 4 * xq;                            // bf16 offset within a plane
+    ldst[u] = xrow * LDB + 16 * (xq >> 2) + 4 * ((xq & 3) == 1 ? 2 : ((xq & 3) == 2 ? 1 : (xq & 3)));   // bf16 offset within a plane
     mq[u] = 4 * xq;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) keep_bits |= (m + 32 * mt) < a.M ? (1u << (mt * NX + u)) : 0u;
@@ -715,13 +719,13 @@ __global__ __launch_bounds__(256, 2) void psm_encode_x6_mt_kernel(PsmEncodeArgs 
   // in the shadow of MFMA groups 2u, 2u + 1: one MFMA, then a few of its vector instructions, in turn (the MFMAs are one dependent chain of
   // 32 cycles each; behind the phase the same instructions cost ~1 us per step, tools/encode_stamps.py)
   auto mfma_tile = [&](f32x16& c, int buf, const uint4* next, int stamp, int hs_stage, auto&& stage) {
-    const __bf16* arow = &ldsx[buf * 3 * PL + i * LDB + 4 * h];
+    const __bf16* arow = &ldsx[buf * 3 * PL + i * LDB + 8 * h];
     if (hs_stage >= 0) read_mean(hs_stage);
     x6_bf16x8 A[2][3];
     auto rd = [&](int st, int sl) {
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
-        A[sl][pl] = psm_cat4(*reinterpret_cast<const x6_bf16x4*>(arow + pl * PL + 16 * st), *reinterpret_cast<const x6_bf16x4*>(arow + pl * PL + 16 * st + 8));
+        A[sl][pl] = *reinterpret_cast<const x6_bf16x8*>(arow + pl * PL + 16 * st);
     };
     rd(0, 0);
 #pragma unroll
