@@ -413,6 +413,9 @@ __device__ __forceinline__ void psm_split3(f32x4 x, x6_bf16x4& h, x6_bf16x4& m, 
   l = __builtin_convertvector(r2, x6_bf16x4);
 }
 __device__ __forceinline__ x6_bf16x8 psm_cat4(x6_bf16x4 a, x6_bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+// LDS image of x6 activation planes read as ONE ds_read_b128 per MFMA operand: rows a multiple of 16 bytes (an odd number of 16-byte slots),
+// the four 4-element groups of every 16 k stored 0, 2, 1, 3 (lane half h holds k 4h.. and 8 + 4h..).  Position (bf16) of 4-element group q:
+__device__ __forceinline__ int psm_x6_group_pos(int q) { const int g = q & 3; return 16 * (q >> 2) + 4 * (g == 1 ? 2 : (g == 2 ? 1 : g)); }
 #define MFMA_X6(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
 template <int C_IN, bool ALIGNED>
@@ -657,7 +660,7 @@ __global__ __launch_bounds__(256, 2) void psm_encode_x6_mt_kernel(PsmEncodeArgs 
     const int m = m0 + xrow;
     o0[u] = 4u * (unsigned)((int)a.row_base[min(m, a.M - 1)] + 4 * xq);
     o1[u] = 4u * (unsigned)((int)a.row_base[min(m + 32, a.M - 1)] + 4 * xq);
-    ldst[u] = xrow * LDB + 16 * (xq >> 2) + 4 * ((xq & 3) == 1 ? 2 : ((xq & 3) == 2 ? 1 : (xq & 3)));   // bf16 offset within a plane
+    ldst[u] = xrow * LDB + psm_x6_group_pos(xq);             // bf16 offset within a plane
     mq[u] = 4 * xq;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) keep_bits |= (m + 32 * mt) < a.M ? (1u << (mt * NX + u)) : 0u;
