@@ -1306,8 +1306,8 @@ def main():
                 g64 = to_device(torch, all64)
                 o64 = torch.empty((n64, ny3, nx3, m3.c_out), dtype=torch.float32, device="cuda")
                 b64 = sur64.bind_geometry(g64.data_ptr(), on_device=True, n_cases=n64)
-                k64 = max(150, min(200, args.steps // 10))
-                dt64 = pdist.timed_region(lambda i: sur64.solve_device(g64.data_ptr(), n64, o64.data_ptr(), stream), k64, 10,
+                k64 = max(300, min(400, args.steps // 10))       # (40 untimed steps first: with 10 the leg read 7-8 % under the back-to-back rate of tools/kernel_times.py -- clocks and caches still settling)
+                dt64 = pdist.timed_region(lambda i: sur64.solve_device(g64.data_ptr(), n64, o64.data_ptr(), stream), k64, 40,
                                           torch.cuda.synchronize, red_dev)
                 torch.cuda.synchronize()
                 trips64 = guard_trips_after(sur64, "config3 x64")
