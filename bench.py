@@ -337,11 +337,11 @@ def unet_launch_key(net, first, kname, wgs):
     base = kname.strip("() ").split("(")[0]
     if not base.startswith("psm_conv3x3_kernel"):
         return "pair|" + base.replace(" ", "")
-    th, nct = net.plan_info(first)[:2]
+    th, nct, _, role = net.plan_info(first)[:4]
     n = len(net.shapes)
     L = (n + 1) // 4
     src = 2 if (0 < first < 2 * L and first % 2 == 0) else (1 if (2 * L <= first < n - 1 and (first - 2 * L) % 2 == 0) else 0)
-    return f"conv3x3|{th}|{nct}|{src}|{int(wgs[first]) * 256}"
+    return f"conv3x3|{th}|{nct}|{src}|{int(wgs[first]) * (512 if role & 8 else 256)}"                # (eight-wave workgroups with the in-workgroup K split)
 
 
 def committed_unet_traffic(workload, key):

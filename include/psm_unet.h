@@ -68,7 +68,9 @@ int psm_unet_profile(psm_unet* u, const float* d_grid, int32_t n_cases, float* d
  * up to float32 summation order (bf16: rounding flips).
  * psm_unet_ksplit: the split of convolution idx in the current plan; psm_unet_plan_info: info[4] = {tile rows, channel tiles
  * per workgroup, split, role}: role & 3 = pair role (0 none, 1 leader, 2 computed by the leader's launch), role & 4 = the layer
- * runs the x6 form.
+ * runs the x6 form, role & 8 = in-workgroup K split (bf16 mode: eight-wave workgroups, the two halves of a workgroup's channel
+ * chunks on waves 0-3 / 4-7, summed through LDS -- chosen by rule for layers of four or more chunks whose launch has at most
+ * one workgroup per CU; PSM_UNET_KW=0 switches it off).
  * x6 (float32 mode, default on; PSM_UNET_X6=0 switches it off): layers with at least 64 input channels and an 8-row tile run
  * their float32 contractions on the bf16 matrix pipe -- activations and weights split EXACTLY into three bf16 planes
  * (x = hi + mid + lo), six MFMA terms per product (hh, hm, mh, hl, lh, mm; the dropped terms are below 2^-24 of the

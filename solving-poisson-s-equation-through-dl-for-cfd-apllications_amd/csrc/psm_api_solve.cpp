@@ -35,6 +35,13 @@ int encode_groups(const psm_handle* h, int Mpad) {
   if (kg_env > 0) groups = kg_env;
   return (groups > 1 && groups <= h->n_slices && (h->n_slices + groups - 1) / groups <= 8) ? groups : 1;
 }
+// Slabs the float32 / x6 encode launch (psm_launch_encode, psm_kernels.hip) writes for these arguments = what the reduce behind it must sum.
+// ONE place mirrors the launcher's three branches (the count used to be rebuilt step by step inside launch_all).
+static int encode_slabs(const PsmEncodeArgs& a) {
+  const int n_slices = a.S * a.S / PSM_PIX_PER_SLICE;
+  if (a.x6 && a.kgroup > 1) return a.kgroup;              // M-tiled x6 form: one slab per K group
+  return psm_encode_pairs(a) ? n_slices / 2 : n_slices;   // two slices per workgroup, or one slab per slice
+}
 // What that encode needs beyond the plan, built on first use and OUTSIDE any stream capture (it allocates): the basis pre-split
 // into three bf16 planes (1.5 x the bytes of the float32 pack), made on the device from the float32 pack.
 int ensure_encode_aux(psm_handle* h, int n_cases) {
@@ -73,14 +80,13 @@ int launch_all(psm_handle* h, Workspace& w, const float* d_grid, int n_cases, fl
   ea.x6 = h->x6_mode < 0 ? (Mpad > 32 ? 1 : 0) : ((h->x6_mode & 1) ? 1 : 0);
   // Large case batches (>= 32 cases of 9 blocks): the M-tiled, wave-specialised x6 form (encode_groups / ensure_encode_aux)
   ea.kgroup = 1;
-  int n_slabs = h->n_slices;
   {
     const int groups = (ea.x6 && !bf16) ? encode_groups(h, Mpad) : 1;
-    if (groups > 1 && h->d_bpack_x6) { ea.kgroup = groups; n_slabs = groups; ea.bpack_x6 = h->d_bpack_x6; }
+    if (groups > 1 && h->d_bpack_x6) { ea.kgroup = groups; ea.bpack_x6 = h->d_bpack_x6; }
   }
   // a single case of four component tiles: two K slices per workgroup, half the slabs (psm_encode_pair_kernel)
   ea.pairs_ok = bf16 ? 0 : 1;
-  if (psm_encode_pairs(ea)) n_slabs = h->n_slices / 2;
+  const int n_slabs = bf16 ? h->n_slices : encode_slabs(ea);          // bf16 handles (psm_launch_encode_bf16): one slab per slice
 
   if (h->timed_kernel == PSM_K_ENCODE && !prof) {
     // dominant kernel: dispatch-level begin / end stamps (no marker packets around the launch)

@@ -31,6 +31,7 @@ struct PsmConvArgs {
   // in_bf: in0 and in1 are bf16 [..][c] (only with ks0 == ks1 == 1); out_bf: this layer stores bf16 (only with ksplit == 1)
   int in_bf, out_bf;
   int ksplit;                  // this layer's own split: workgroup z handles chunks [z*cps, (z+1)*cps) and writes slab z
+  int kw;                      // 2: in-workgroup K split (eight waves, two halves of the workgroup's chunks, sums through LDS) -- bf16 activations, 8-row tiles, >= 2 chunks; else 1
   int64_t out_slab;
   int mode0;
   int H, W;                    // resolution of the convolution (its output)

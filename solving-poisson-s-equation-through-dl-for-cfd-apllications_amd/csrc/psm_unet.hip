@@ -276,8 +276,15 @@ __device__ __forceinline__ void store_act(float* out, int64_t elem, float v, boo
 //     product runs as the six MFMA terms hh, hm, mh, hl, lh, mm (what is dropped is below 2^-24 of the product), small
 //     terms first, float32 accumulation: 6 x 16 cycles per 32 channels against 8 x 32 for v_mfma_f32_16x16x4_f32.  Chunks
 //     of 32 channels, three LDS planes per operand; the weights (27 KiB x NCT per chunk) are single-buffered.
-template <int TH, int WM, int NCT, int WN, int SRC, int KSM, bool BF, int NB, bool ABF = false, bool X6 = false>     // SRC: PSM_SRC_*, -1 = unaligned stem, 3 = upsample + skip with the seam inside a chunk
-__global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_groups) {
+//   KW = 2 (bf16 activations, two or more chunks; PsmConvArgs::kw): IN-WORKGROUP K SPLIT.  A workgroup of eight waves; waves 0-3 walk the first half of
+//     the workgroup's channel chunks, waves 4-7 the second half, each half with its own pair of LDS buffers per operand (the halves share
+//     the chunk barriers: same chunk count, a make-up barrier where it differs by one); the accumulators of the second half meet the
+//     first half's through LDS behind the last chunk, waves 0-3 run the epilogue.  Half as long a chain of dependent chunks per wave and
+//     two waves per SIMD on a chip the launch cannot fill with workgroups -- what a split over workgroups (ksplit) buys, without
+//     float32 partial-sum slabs for the consumer to add up.
+template <int TH, int WM, int NCT, int WN, int SRC, int KSM, bool BF, int NB, bool ABF = false, bool X6 = false, int KW = 1>     // SRC: PSM_SRC_*, -1 = unaligned stem, 3 = upsample + skip with the seam inside a chunk
+__global__ __launch_bounds__(256 * KW) void psm_conv3x3_kernel(PsmConvArgs a, int co_groups) {
+  static_assert(KW == 1 || (KW == 2 && ABF && NB == 2 && !X6), "in-workgroup K split: bf16 activations, double-buffered chunks");
   static_assert(!ABF || (BF && KSM == 1 && SRC >= 0 && SRC != 3), "bf16 activations: finished same / upsample / max-pool sources only");
   static_assert(!X6 || (BF && !ABF && NB == 2 && SRC >= 0), "x6: float32 inputs, bf16 MFMA, double-buffered input planes");
   constexpr int PL = X6 ? 3 : 1;                                    // operand planes
@@ -298,10 +305,13 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
   constexpr int NQ = SRCP == PSM_SRC_MAXPOOL ? 4 : 1;               // source pixels per fetch
   constexpr bool DEFER = ABF || (SRC >= 0 && SRC != 3 && NF * NQ * KSM <= 24);   // raw loads held across the MFMAs (<= 96 VGPRs)
   constexpr int NRAW = DEFER ? NQ * KSM : 1;
-  __shared__ __attribute__((aligned(16))) float in_tile[NB * PL * TILE];
-  __shared__ __attribute__((aligned(16))) f32x4 w_tile[NBW * WQP];
-  const int tid = threadIdx.x, lane = tid & 63;
+  __shared__ __attribute__((aligned(16))) float in_tile[KW * NB * PL * TILE];
+  __shared__ __attribute__((aligned(16))) f32x4 w_tile[KW * NBW * WQP];
+  static_assert(KW == 1 || (size_t)WM * WN * 256 <= (size_t)KW * NBW * WQP, "the second half's accumulators fit the weight buffers");
+  const int tid = KW == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 255), lane = tid & 63;     // position within the half
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = KW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+  const int hin = half * (NB * PL * TILE), hw = half * (NBW * WQP);                             // the half's LDS areas (floats / 16-byte pieces)
   const int zz = blockIdx.z / a.ksplit, split = blockIdx.z - zz * a.ksplit;
   const int cs = zz / co_groups, cog = zz - cs * co_groups;
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
@@ -323,7 +333,9 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
   for (int n = 0; n < WN; ++n) bias_r[n] = *reinterpret_cast<const f32x4*>(a.bias + (cog * NCT + ct_w + n) * 16 + 4 * kq);
   const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpack) + (int64_t)cog * a.n_chunks * WQ;
   const int cps = (a.n_chunks + a.ksplit - 1) / a.ksplit;          // chunks per split
-  const int g_beg = split * cps, g_end = min(a.n_chunks, (split + 1) * cps);
+  const int g_beg0 = split * cps, g_end0 = min(a.n_chunks, (split + 1) * cps);
+  const int hc = KW == 1 ? g_end0 - g_beg0 : (g_end0 - g_beg0 + 1) / 2;           // chunks of a half (the first half's count)
+  const int g_beg = g_beg0 + half * hc, g_end = min(g_end0, g_beg + hc);
 
   f32x4 xr[NF][NRAW], xb[NF], wr[NWF];
   // (uniform chunk base + this thread's piece, which is the same for every chunk: a scalar add and no vector address arithmetic per request)
@@ -333,7 +345,7 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
   auto load_w_one = [&](int g, int u) { wr[u] = (wsrc + (int64_t)g * WQ)[wpiece[u]]; };
   auto store_w = [&](int buf) {
 #pragma unroll
-    for (int u = 0; u < NWF; ++u) w_tile[buf * WQP + tid + 256 * u] = wr[u];
+    for (int u = 0; u < NWF; ++u) w_tile[hw + buf * WQP + tid + 256 * u] = wr[u];
   };
   // loop-invariant fetch positions; chunks normally lie on one side of the concatenation seam (channel counts
   // are multiples of the chunk), else the general per-lane path is taken
@@ -419,7 +431,7 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
         const bool ok = fp[u].ok && (g * CB + FG * c4 < lim);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0.f;
-        *reinterpret_cast<f32x4*>(&in_tile[buf * TILE + lds_slot(pos, c4)]) = v;      // 8 bf16 = one 16-byte slot of the pixel
+        *reinterpret_cast<f32x4*>(&in_tile[hin + buf * TILE + lds_slot(pos, c4)]) = v;      // 8 bf16 = one 16-byte slot of the pixel
         continue;
       }
       if constexpr (DEFER) {
@@ -470,7 +482,7 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
   for (int r = 0; r < WM + 2; ++r)
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
-      a_slot[r][kx] = lds_slot((row_w + r) * (TW + 2) + px + kx, kq);
+      a_slot[r][kx] = hin + lds_slot((row_w + r) * (TW + 2) + px + kx, kq);
       asm volatile("" : "+v"(a_slot[r][kx]));
     }
   if (g_beg < g_end) {
@@ -489,7 +501,7 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
     constexpr int buf = decltype(buf_tag)::value;
     USTAMP(2 + 4 * (g - g_beg));
     const float* tile = &in_tile[buf * PL * TILE];
-    const f32x4* wt = &w_tile[(NBW == 2 ? buf : 0) * WQP + ct_w * 64 + lane];
+    const f32x4* wt = &w_tile[hw + (NBW == 2 ? buf : 0) * WQP + ct_w * 64 + lane];
     // operand prefetch depth in taps (-DPSM_CONV_PD=n, bf16 form).  Measured with 3 instead of 1: nothing (8 cases bf16 158.4 vs
     // 157.5 us, dec3a 14.6 vs 14.5): a bf16 chunk's matrix phase (0.57 us for 36 MFMAs = 0.24 us of issue) is bound by the
     // THROUGHPUT of its 36 ds_read_b128 per wave (four waves: 0.48 us), not by their latency
@@ -624,6 +636,24 @@ __global__ __launch_bounds__(256) void psm_conv3x3_kernel(PsmConvArgs a, int co_
     else if (g < g_end) run_chunk(g, std::false_type{}, B0{});
   } else {
     if (g_beg < g_end) run_chunk(g_end - 1, std::false_type{}, B0{});
+  }
+  if constexpr (KW == 2) {
+    // the halves share the workgroup barrier: the second half makes up for a chunk it does not have (odd chunk counts)
+    for (int i = g_end - g_beg; i < hc; ++i) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // K halves meet: behind the last chunk's barrier nobody reads the weight buffers any more
+    f32x4* red = w_tile;
+    if (half == 1) {
+#pragma unroll
+      for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n) red[(m * WN + n) * 256 + tid] = acc[m][n];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (half == 1) return;
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+      for (int n = 0; n < WN; ++n) acc[m][n] += red[(m * WN + n) * 256 + tid];
   }
   // ---- epilogue: bias + ReLU (split-K: the raw partial sum into this split's slab), NHWC store
   float* out = a.out_bf ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(a.out) + (int64_t)cs * a.out_case)
@@ -794,6 +824,9 @@ static void launch_variant(const PsmConvArgs& a, dim3 grid, int groups, hipStrea
   do {                                                                                                                   \
     if constexpr (K == 1 && S >= 0 && S != 3) {                                                                          \
       if (a.bf16 && a.in_bf) {                                                                                           \
+        if constexpr (TH == 8 && NCT <= 2) {       /* in-workgroup K split (PsmConvArgs::kw): eight waves, the 8-row tiles only (LDS) */ \
+          if (a.kw == 2 && !one) { PSM_LAUNCH((psm_conv3x3_kernel<TH, WM, NCT, WN, S, 1, true, 2, true, false, 2>), grid, dim3(512), 0, st, a, groups); break; } \
+        }                                                                                                                \
         if (one) PSM_LAUNCH((psm_conv3x3_kernel<TH, WM, NCT, WN, S, 1, true, 1, true>), grid, dim3(256), 0, st, a, groups);     \
         else PSM_LAUNCH((psm_conv3x3_kernel<TH, WM, NCT, WN, S, 1, true, 2, true>), grid, dim3(256), 0, st, a, groups);         \
         break;                                                                                                           \

@@ -24,6 +24,7 @@ struct Conv {
   int relu = 1;
   // launch configuration and packed operands
   int arrangement = 0, nct = 1, n_chunks = 0, groups = 1, ksplit = 1;
+  int kw = 1;                  // 2: in-workgroup K split (PsmConvArgs::kw)
   bool stem = false;            // K = 9*c_in flattened (first layer on the raw image)
   bool fuse_head = false;       // this layer's epilogue also computes the 1x1 head
   bool in_bf = false, out_bf = false;   // bf16 mode: inputs read / output stored as bf16 (finished activations only)
@@ -254,7 +255,7 @@ std::vector<uint16_t> pack_pair(const Conv& c, bool flat, int c0, int c1) {
 // more channel chunks (64 cases of 256 x 256: dec3a 72.4 -> 65.4 us, enc4b 27.6 -> 24.4, dec2a 82.3 -> 78.5; shorter layers and
 // every layer at 8 cases per step are slower with it).
 void choose_config(Conv& c, int H, int W, int n_cases, bool can_split, int chunk_ch, int ks_cap = 8, bool x6_ok = false, int forced = -1,
-                   bool big_ok = false) {
+                   bool big_ok = false, bool in_split = false) {
   const int ctiles = (c.cout + 15) / 16;
   struct Cand { int arr, nct, th; };
   const Cand cands[4] = {{0, 2, 8}, {0, 1, 8}, {1, 4, 2}, {2, 4, 16}};
@@ -273,7 +274,14 @@ void choose_config(Conv& c, int H, int W, int n_cases, bool can_split, int chunk
     const int groups = (ctiles + k.nct - 1) / k.nct;
     const long wgs = (long)((W + 15) / 16) * ((H + k.th - 1) / k.th) * groups * n_cases;
     const long reuse = (long)k.nct * k.th;
-    const long score = wgs >= fill ? 1000000 + reuse * 1000 + (k.arr ? 1 : 0) : wgs * 10 + (k.arr ? 1 : 0);
+    // equal workgroup count / reuse: the 2-row x 64-channel tile (arrangement 1), except for long bf16 layers (eight or more 32-channel chunks), where the
+    // 8-row x 16-channel tile stages half the bytes per chunk for the same MFMAs and can take the in-workgroup K split (psm_unet_plan): enc4b at 8 cases
+    // 8.9 us as 2 x 64, 7.7 us as 8 x 16, 6.8 us with the split on top (profiles/r06_conv_experiments.txt (8))
+    const bool kw_off = getenv("PSM_UNET_KW") && atoi(getenv("PSM_UNET_KW")) == 0;              // PSM_UNET_KW=0: the planner without either change
+    // (in_split: an input arrives as float32 partial-sum slabs -- the summing loader, no in-workgroup split: 512 x 512 x 1, enc4b behind a split enc4a, 10.1 us as 2 x 64, 11.2 us as 8 x 16)
+    const bool long_bf16 = chunk_ch == 32 && !x6_ok && !kw_off && !in_split && (c.cin + chunk_ch - 1) / chunk_ch >= 8;
+    const long tie = long_bf16 ? (k.arr == 0 && k.nct == 1 ? 1 : 0) : (k.arr ? 1 : 0);
+    const long score = wgs >= fill ? 1000000 + reuse * 1000 + tie : wgs * 10 + tie;
     if (score > best_score) { best_score = score; c.arrangement = k.arr; c.nct = k.nct; c.groups = groups; }
   }
   if (!use_forced && big_ok && ctiles >= 4 && ctiles % 4 == 0 && (c.cin + chunk_ch - 1) / chunk_ch >= 6 && getenv("PSM_UNET_NO_BIG_TILES") == nullptr) {
@@ -382,7 +390,7 @@ int forward(psm_unet* u, const float* d_grid, int n, float* d_field, hipStream_t
     a.wpack = c.d_w; a.bias = c.d_b; a.out = out; a.n_chunks = c.n_chunks; a.H = H; a.W = W; a.cout = c.cout; a.relu = c.relu;
     a.out_case = (i + 1 == u->convs.size()) ? (int64_t)H * W * c.cout : c.case_elems;
     a.PO = (i + 1 == u->convs.size()) ? W : c.P;
-    a.ksplit = c.ksplit; a.out_slab = c.slab; a.ks0 = 1; a.ks1 = 1; a.bf16 = u->bf16;
+    a.kw = c.kw; a.ksplit = c.ksplit; a.out_slab = c.slab; a.ks0 = 1; a.ks1 = 1; a.bf16 = u->bf16;
     a.in_bf = c.in_bf ? 1 : 0; a.out_bf = c.out_bf ? 1 : 0; a.x6 = c.x6 ? 1 : 0;
     if (c.src == 0) { a.in0 = d_grid; a.c0 = c.cin; a.mode0 = PSM_SRC_SAME; a.H0 = H; a.W0 = W; a.P0 = W; a.in0_case = (int64_t)H * W * c.cin; }
     else {
@@ -574,6 +582,19 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
       if (cm == 32 && getenv("PSM_UNET_PAIR32") && atoi(getenv("PSM_UNET_PAIR32")) == 0) continue;     // diagnostic: 16-channel pairs only
       A.pair = 1; A.pair_kind = kind; B.pair = 2;
     }
+    // in-workgroup K split (psm_conv3x3_kernel<..., KW = 2>): generic launches on finished bf16 inputs, 8-row tiles, two or more chunks, no split over workgroups
+    {
+      // Rule (profiles/r06_conv_experiments.txt (8)): four or more chunks AND at most one workgroup per CU -- an eight-wave workgroup holds 128 KB of LDS, so a
+      // launch of more than 256 of them runs in two rounds (dec2a at 8 cases, 512 workgroups: 11.6 -> 14.3 us), and a two-chunk layer has nothing to pipeline
+      // in a half (enc2b 6.0 -> 9.2 us).  PSM_UNET_KW=0 switches it off, PSM_UNET_KW=-n forces it for every eligible layer of n or more chunks (diagnostic).
+      const int kw_env = getenv("PSM_UNET_KW") ? atoi(getenv("PSM_UNET_KW")) : 1;
+      for (Conv& c : u->convs) {
+        const bool can = u->bf16 && c.k == 3 && !c.stem && c.pair == 0 && !c.fuse_head && c.arrangement == 0 && c.in_bf && c.ksplit == 1 && c.n_chunks >= 2 && !c.x6;
+        const int H = ny >> c.level, W = nx >> c.level;
+        const long wgs = (long)((W + 15) / 16) * ((H + 7) / 8) * c.groups * max_cases;
+        c.kw = !can || kw_env == 0 ? 1 : kw_env < 0 ? (c.n_chunks >= -kw_env ? 2 : 1) : (c.n_chunks >= 4 && wgs <= 256 ? 2 : 1);
+      }
+    }
   }
   // bf16 tensors (finished activations of bf16 mode; a fused pair always writes bf16) get the zero halo
   if (pass == 1) for (Conv& c : u->convs) act_layout(c, ny >> c.level, nx >> c.level, u->bf16 && c.k == 3 && (c.out_bf || c.pair != 0));
@@ -605,7 +626,8 @@ int psm_unet_plan(psm_unet* u, int32_t ny, int32_t nx, int32_t max_cases) {
     if (c.k == 3) choose_config(c, H, W, max_cases, feeds_conv3 && getenv("PSM_UNET_NO_SPLIT") == nullptr, u->bf16 ? 32 : 16,
                                 ci < u->ksplit_cap.size() ? u->ksplit_cap[ci] : 8, x6_ok,
                                 ci < u->tile_choice.size() ? u->tile_choice[ci] : -1,      // measured choice of psm_unet_autotune
-                                u->bf16 && !stem_layer && c.src != 0);
+                                u->bf16 && !stem_layer && c.src != 0,
+                                (c.src != 0 && ci > 0 && u->convs[ci - 1].ksplit > 1) || (c.src == 3 && u->convs[c.skip].ksplit > 1));   // producers are planned before their consumers
     // diagnostic override: PSM_UNET_FORCE="layer:arrangement:nct:ksplit,..." (tools/attic/unet_bench.py experiments)
     if (const char* f = getenv("PSM_UNET_FORCE")) {
       for (const char* q = f; q && *q; q = std::strchr(q, ',') ? std::strchr(q, ',') + 1 : nullptr) {
@@ -874,6 +896,10 @@ int psm_unet_autotune(psm_unet* u, int32_t n_cases, int32_t iters, float* us_bef
     if (A.k != 3 || B.k != 3 || B.src != 1 || A.level != B.level || B.cout != A.cout || (A.cout != 16 && A.cout != 32)) continue;
     if ((rc = try_set(u->pair_choice, i, A.pair == 1 ? 0 : 1))) return rc;
   }
+  // Steps 2 and 3 run twice: a shallower split of a producer changes what its consumer can run (finished bf16 inputs: the
+  // in-workgroup K split, the 8-row x 16-channel tile of the long layers), which only a second look at the tiles can pick up.
+  for (int sweep = 0; sweep < 2; ++sweep) {
+  const double best_at_sweep = best;
   // 2. tile shape of the unfused 3x3 layers: the two candidates the planner did not pick
   for (size_t i = 0; i < nc; ++i) {
     const Conv& c = u->convs[i];
@@ -909,6 +935,8 @@ int psm_unet_autotune(psm_unet* u, int32_t n_cases, int32_t iters, float* us_bef
       if ((rc = psm_unet_plan(u, ny, nx, mc))) return rc;
       break;
     }
+  }
+  if (best >= best_at_sweep) break;                                // nothing moved: a second sweep would only chase timing noise
   }
   if (us_after) *us_after = (float)best;
   return PSM_OK;
@@ -955,7 +983,7 @@ int psm_unet_ksplit(const psm_unet* u, int32_t idx) {
 int psm_unet_plan_info(const psm_unet* u, int32_t idx, int32_t* info) {
   if (!u || !info || !u->planned || idx < 0 || idx >= (int)u->convs.size()) return PSM_ERR_ARG;
   const Conv& c = u->convs[idx];
-  info[0] = psm_conv_tile_rows(c.arrangement); info[1] = c.nct; info[2] = c.ksplit; info[3] = c.pair | (c.x6 ? 4 : 0);
+  info[0] = psm_conv_tile_rows(c.arrangement); info[1] = c.nct; info[2] = c.ksplit; info[3] = c.pair | (c.x6 ? 4 : 0) | (c.kw == 2 ? 8 : 0);
   return PSM_OK;
 }
 

@@ -157,7 +157,8 @@ class UNetSurrogate:
 
     def plan_info(self, idx: int):
         """(tile rows, channel tiles per workgroup, split-K, role) of convolution idx in the current plan; role & 3 = pair role
-        (0 none, 1 leader, 2 computed by the leader's launch), role & 4 = x6 arithmetic (float32 mode)."""
+        (0 none, 1 leader, 2 computed by the leader's launch), role & 4 = x6 arithmetic (float32 mode), role & 8 = in-workgroup K split
+        (eight-wave workgroups, bf16 mode)."""
         info = (C.c_int32 * 4)()
         self._chk(self.lib.psm_unet_plan_info(self.h, idx, info))
         return [int(v) for v in info]

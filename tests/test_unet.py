@@ -257,6 +257,63 @@ def test_gpu_unet_bf16_pairs_other_shapes(c_in, widths, c_out, monkeypatch):
             assert np.linalg.norm(out[k] - ref) / np.linalg.norm(ref) <= 1e-2
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("c_in,widths,ny,nx,n", [(3, (16, 32, 64, 128, 256), 64, 96, 2), (3, (16, 32, 96, 160), 40, 72, 3), (4, (16, 32, 64, 96), 48, 80, 1)])
+def test_gpu_unet_bf16_in_workgroup_k_split(c_in, widths, ny, nx, n, monkeypatch):
+    """The in-workgroup K split of the generic conv kernel (psm_conv3x3_kernel<..., KW = 2>: eight waves, the two halves of a workgroup's
+    channel chunks on waves 0-3 / 4-7, accumulators summed through LDS), FORCED on every eligible layer of two or more chunks
+    (PSM_UNET_KW=-2; the rule takes four or more chunks and launches of at most one workgroup per CU): even chunk counts, odd ones
+    (96- and 160-channel levels: 3 and 5 chunks, upsample ++ skip sources of 7 / 8 chunks -- the second half then makes up a barrier),
+    max-pool / same / upsample sources, tiles that straddle the image edge; layer by layer against the bf16 oracle, and the same
+    field as the unsplit kernels up to bf16 rounding flips."""
+    from psm_amd import UNetSurrogate
+    specs = uo.unet_specs(c_in, widths, 1)
+    W = uo.he_weights(specs, seed=70 + len(widths))
+    g = np.random.default_rng(5).standard_normal((n, ny, nx, c_in)).astype(np.float32)
+    monkeypatch.setenv("PSM_UNET_KW", "-2")
+    monkeypatch.setenv("PSM_UNET_FILL", "1")          # small grids: keep the 8-row tiles and no split over workgroups (the planner would spread these layers thin)
+    with UNetSurrogate(W, ny, nx, c_in=c_in, c_out=1, widths=widths, max_cases=n, precision="bf16", keep_activations=True) as net:
+        roles = [net.plan_info(i)[3] for i in range(len(specs))]
+        assert sum(1 for r in roles if r & 8) >= 4, roles                      # the split really ran on several layers
+        out = net.forward(g)
+        for k in range(n):
+            ref, acts = uo.unet_forward(g[k], W, widths, return_all=True, precision="bf16")
+            for i in range(len(specs) - 1):
+                a = net.activation(i, n)[k]
+                err = np.linalg.norm(a - acts[i]) / max(np.linalg.norm(acts[i]), 1e-12)
+                assert err <= 1e-2, (specs[i].name, roles[i], err)
+            # (white-noise images: more activations sit near a bf16 rounding boundary than on the smooth channel grids -- the unsplit
+            # kernels are 1.0-1.1e-2 from the oracle on the 96 / 160-channel network too; tests/measure/soak_unet.py uses the same 2e-2)
+            assert np.linalg.norm(out[k] - ref) / np.linalg.norm(ref) <= 2e-2
+    monkeypatch.setenv("PSM_UNET_KW", "0")
+    with UNetSurrogate(W, ny, nx, c_in=c_in, c_out=1, widths=widths, max_cases=n, precision="bf16") as net:
+        assert not any(net.plan_info(i)[3] & 8 for i in range(len(specs)))
+        off = net.forward(g)
+    assert np.linalg.norm(out - off) / np.linalg.norm(off) <= 1e-2           # measured: 1e-9 ... 6e-3 (float32 summation order -> bf16 rounding flips)
+
+
+@pytest.mark.gpu
+def test_gpu_unet_bf16_k_split_rule_at_eight_cases():
+    """The planner's rule on the bench shape (8 cases of 256 x 256, bf16): the long layers whose launch has at most one workgroup per
+    CU take the in-workgroup split -- enc4b (eight chunks, as 8-row x 16-channel tiles) and dec3a (twelve chunks) among them --,
+    the 64 x 64 level (512 workgroups of four waves already) and the fused pairs do not; result against the bf16 oracle."""
+    from psm_amd import UNetSurrogate
+    specs = uo.unet_specs()
+    W = uo.he_weights(specs, seed=13)
+    g = np.stack([synthetic.channel_grid(256, 256, seed=30 + k).astype(np.float32) for k in range(8)])
+    with UNetSurrogate(W, 256, 256, max_cases=8, precision="bf16") as net:
+        info = [net.plan_info(i) for i in range(len(specs))]
+        names = [s_.name for s_ in specs]
+        split = {names[i] for i in range(len(specs)) if info[i][3] & 8}
+        assert {"enc4b", "dec3a"} <= split, (split, info)
+        assert not ({"enc2b", "dec2a", "dec2b", "enc0a", "enc0b", "dec0a", "dec0b"} & split), split
+        assert info[names.index("enc4b")][:2] == [8, 1], info[names.index("enc4b")]
+        out = net.forward(g)
+    for k in (0, 7):
+        ref = uo.unet_forward(g[k], W, precision="bf16")
+        assert np.linalg.norm(out[k] - ref) / np.linalg.norm(ref) <= 1e-2
+
+
 def test_bf16_rounding_helper():
     x = np.array([1.0, 1.00390625, 1.0078125, -3.1415927, 0.0], np.float32)       # 1 + 2^-8 ties to even -> 1.0
     np.testing.assert_array_equal(uo.bf16_round(x), np.array([1.0, 1.0, 1.0078125, -3.140625, 0.0], np.float32))
