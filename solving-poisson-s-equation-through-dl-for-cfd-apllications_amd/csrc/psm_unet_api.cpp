@@ -274,12 +274,12 @@ void choose_config(Conv& c, int H, int W, int n_cases, bool can_split, int chunk
     const int groups = (ctiles + k.nct - 1) / k.nct;
     const long wgs = (long)((W + 15) / 16) * ((H + k.th - 1) / k.th) * groups * n_cases;
     const long reuse = (long)k.nct * k.th;
-    // equal workgroup count / reuse: the 2-row x 64-channel tile (arrangement 1), except for long bf16 layers (eight or more 32-channel chunks), where the
+    // equal workgroup count / reuse: the 2-row x 64-channel tile (arrangement 1), except for bf16 layers of four or more 32-channel chunks, where the
     // 8-row x 16-channel tile stages half the bytes per chunk for the same MFMAs and can take the in-workgroup K split (psm_unet_plan): enc4b at 8 cases
-    // 8.9 us as 2 x 64, 7.7 us as 8 x 16, 6.8 us with the split on top (profiles/r06_conv_experiments.txt (8))
+    // 8.9 us as 2 x 64, 7.7 us as 8 x 16, 6.8 us with the split on top; 512 x 512 x 1: enc3b 5.6 -> 5.0, dec3b 5.4 -> 4.6 us (profiles/r06_conv_experiments.txt (8))
     const bool kw_off = getenv("PSM_UNET_KW") && atoi(getenv("PSM_UNET_KW")) == 0;              // PSM_UNET_KW=0: the planner without either change
     // (in_split: an input arrives as float32 partial-sum slabs -- the summing loader, no in-workgroup split: 512 x 512 x 1, enc4b behind a split enc4a, 10.1 us as 2 x 64, 11.2 us as 8 x 16)
-    const bool long_bf16 = chunk_ch == 32 && !x6_ok && !kw_off && !in_split && (c.cin + chunk_ch - 1) / chunk_ch >= 8;
+    const bool long_bf16 = chunk_ch == 32 && !x6_ok && !kw_off && !in_split && (c.cin + chunk_ch - 1) / chunk_ch >= 4;
     const long tie = long_bf16 ? (k.arr == 0 && k.nct == 1 ? 1 : 0) : (k.arr ? 1 : 0);
     const long score = wgs >= fill ? 1000000 + reuse * 1000 + tie : wgs * 10 + tie;
     if (score > best_score) { best_score = score; c.arrangement = k.arr; c.nct = k.nct; c.groups = groups; }
@@ -305,7 +305,12 @@ void choose_config(Conv& c, int H, int W, int n_cases, bool can_split, int chunk
   // 9.4 us against 9.2 us whole while its consumer dec3a then reads float32 partial-sum slabs through the summing loader
   // instead of finished bf16 activations (25.6 against 13.4 us); 256 x 256 batch 1, dec2a split in two: 9.0 against 14.3 us.
   // psm_unet_autotune measures it per layer (ksplit_cap); this is the starting point.
-  while (can_split && wgs * c.ksplit < fill && c.ksplit < std::min(ks_max, ks_cap) && c.n_chunks / (c.ksplit * 2) >= min_chunks) c.ksplit *= 2;
+  // (A bf16 layer that can take the IN-WORKGROUP split -- 8-row tile, four or more chunks, at most one workgroup per CU, inputs that are not slabs themselves -- is
+  // not split over workgroups: its consumer keeps reading finished bf16 activations.  512 x 512 x 1: enc4a / enc4b / dec3a / dec3b 5.2 + 7.0 + 16.9 + 5.3 us with the
+  // splits over workgroups the rule below starts from (the autotuner got them to 4.3 + 10.1 + 8.5 + 6.5), 6.3 + 6.4 + 8.5 + 5.3 us this way.)
+  const bool kw_off = getenv("PSM_UNET_KW") && atoi(getenv("PSM_UNET_KW")) == 0;
+  const bool kw_ok = chunk_ch == 32 && !c.x6 && !kw_off && !in_split && c.arrangement == 0 && c.n_chunks >= 4 && wgs <= 256;
+  while (can_split && !kw_ok && wgs * c.ksplit < fill && c.ksplit < std::min(ks_max, ks_cap) && c.n_chunks / (c.ksplit * 2) >= min_chunks) c.ksplit *= 2;
 }
 
 int upload_conv(psm_unet* u, Conv& c) {
