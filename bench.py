@@ -1338,9 +1338,11 @@ def main():
                 mdl = m3 if WORKLOADS[name][0] == "deltas" else model
                 leg = pca_leg(name, mdl, args, torch, pdist, psm_amd, synthetic, rank, world, local_rank, red_dev, k_leg, w_leg, with_oracle)
             elif name in UNET_WORKLOADS:
-                ku = max(100, min(k_leg, 200 if UNET_WORKLOADS[name][0] <= 256 else 100))
                 big = UNET_WORKLOADS[name][2] > 8                    # 64 cases: 0.8 ms per step; the CPU oracle is timed by the other legs
-                leg = unet_leg(name, args, torch, pdist, rank, world, local_rank, backend, 60 if big else ku, max(5, w_leg // 2), with_oracle,
+                # 400 timed steps behind 100 untimed ones (64 cases: 100 behind 30): with 100-200 behind 25 the bf16 legs read 2 % above the same workload run on its
+                # own (K = 2000) on the same box -- clocks still settling behind the plan-time autotune, as for the 64-case PCA leg above
+                ku, wu = (100, 30) if big else (max(100, min(k_leg, 400)), max(100, w_leg // 2))
+                leg = unet_leg(name, args, torch, pdist, rank, world, local_rank, backend, ku, wu, with_oracle,
                                cpu_budget_s=0.0 if big else 4.0)
             else:
                 raise SystemExit(f"unknown leg {name!r}")
